@@ -1,0 +1,281 @@
+"""oracle/tracker_np.py -- TEST INFRASTRUCTURE ONLY.
+
+Compact numpy restatement of the reference's SORT and ByteTrack association state
+machines, for use where /root/reference is absent (the GPU box) and as the "port"
+CPU baseline in bench.py:
+
+  * BaseTracker.update          /root/reference/tracker/basetrack.py:368-487   (kind='sort')
+  * ByteTrack.update            /root/reference/tracker/bytetrack.py:41-204    (kind='bytetrack')
+  * update_without_detection    /root/reference/tracker/basetrack.py:489-537
+  * STrack activate/update/re_activate/tlwh/tlbr, multi_predict  basetrack.py:74-339
+  * joint/sub/remove_duplicate_stracks                            basetrack.py:540-576
+  * iou_distance / linear_assignment                              matching.py:30-82
+
+It is pinned against the reference's own modules (imported through
+oracle/ref_harness.py) in tests/test_oracle_pinned.py and through tests/golden/.
+The float32/float64 dtype flow of the reference (float32 `_tlwh`, float32 mean right
+after `initiate`, float64 afterwards) is kept by using the same numpy dtypes.
+"""
+import numpy as np
+
+from . import cnative
+from .kalman_np import KalmanNP
+
+NEW, TRACKED, LOST, REMOVED = 0, 1, 2, 3
+
+
+class IdCounter:
+    """Mirror of the process-global BaseTrack._count (basetrack.py:22,43-46)."""
+
+    def __init__(self):
+        self.count = 0
+
+    def next(self):
+        self.count += 1
+        return self.count
+
+
+GLOBAL_IDS = IdCounter()
+
+
+class T:
+    __slots__ = ("cls", "box", "score", "activated", "tid", "start", "frame", "tsu", "state", "mean", "cov", "fmt",
+                 "len")
+
+    def __init__(self, cls, tlwh, score, fmt):
+        self.cls, self.score, self.fmt = cls, score, fmt
+        self.box = np.asarray(tlwh, dtype=np.float32)
+        self.activated, self.tid, self.start, self.frame, self.tsu = False, None, None, None, None
+        self.state, self.mean, self.cov, self.len = NEW, None, None, 0
+
+    @property
+    def tlwh(self):
+        if self.mean is None:
+            return self.box.copy()
+        r = self.mean[:4].copy()
+        if self.fmt in ("default", "strongsort"):
+            r[2] *= r[3]
+            r[:2] -= r[2:] / 2
+        elif self.fmt == "botsort":
+            r[:2] -= r[2:] / 2
+        else:
+            raise NotImplementedError(self.fmt)
+        return r
+
+    @property
+    def tlbr(self):
+        r = self.tlwh.copy()
+        r[2:] += r[:2]
+        return r
+
+    def meas(self, tlwh):
+        r = np.asarray(tlwh).copy()
+        if self.fmt in ("default", "strongsort"):
+            r[:2] += r[2:] / 2
+            r[2] /= r[-1]
+        elif self.fmt == "botsort":
+            r[:2] += r[2:] // 2
+        else:
+            raise NotImplementedError(self.fmt)
+        return r
+
+
+def _iou_dist(a, b):
+    at = [t.tlbr for t in a]
+    bt = [t.tlbr for t in b]
+    if len(at) == 0 or len(bt) == 0:
+        return np.zeros((len(at), len(bt)), dtype=np.float64)
+    return 1 - cnative.bbox_overlaps(np.ascontiguousarray(at, dtype=np.float64),
+                                     np.ascontiguousarray(bt, dtype=np.float64))
+
+
+def _assign(cost, thresh):
+    if cost.size == 0:
+        return [], list(range(cost.shape[0])), list(range(cost.shape[1]))
+    _, x, y = cnative.lapjv(cost, extend_cost=True, cost_limit=thresh)
+    m = [(i, int(j)) for i, j in enumerate(x) if j >= 0]
+    return m, [int(i) for i in np.where(x < 0)[0]], [int(j) for j in np.where(y < 0)[0]]
+
+
+def _joint(a, b):
+    seen, out = set(), []
+    for t in a:
+        seen.add(t.tid)
+        out.append(t)
+    for t in b:
+        if t.tid not in seen:
+            seen.add(t.tid)
+            out.append(t)
+    return out
+
+
+def _sub(a, b):
+    d = {}
+    for t in a:
+        d[t.tid] = t
+    for t in b:
+        if d.get(t.tid, 0):
+            del d[t.tid]
+    return list(d.values())
+
+
+def _dedup(a, b):
+    pd = _iou_dist(a, b)
+    da, db = set(), set()
+    for p, q in zip(*np.where(pd < 0.15)):
+        if a[p].frame - a[p].start > b[q].frame - b[q].start:
+            db.add(q)
+        else:
+            da.add(p)
+    return [t for i, t in enumerate(a) if i not in da], [t for i, t in enumerate(b) if i not in db]
+
+
+class TrackerNP:
+    def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
+                 frame_rate=30, ids=None):
+        assert kind in ("sort", "bytetrack")
+        self.kind, self.fmt = kind, kalman_format
+        self.det_thresh = conf_thresh
+        self.iou_thresh = iou_thresh
+        self.max_time_lost = int(frame_rate / 30.0 * track_buffer)
+        self.low_thresh = max(0.15, conf_thresh - 0.3)
+        self.kf = KalmanNP(kalman_format)
+        self.tracked, self.lost, self.removed = [], [], []
+        self.frame_id = 0
+        self.ids = ids if ids is not None else GLOBAL_IDS
+
+    # --- per-track operations ------------------------------------------------
+    def _activate(self, t):
+        t.tid = self.ids.next()
+        t.mean, t.cov = self.kf.initiate(t.meas(t.box), f32_std=True)
+        t.state = TRACKED
+        if self.frame_id == 1:
+            t.activated = True
+        t.frame = t.start = self.frame_id
+        t.tsu = 0
+
+    def _kf_update(self, t, det):
+        z = t.meas(det.tlwh)
+        if self.fmt == "strongsort":
+            return self.kf.update(t.mean, t.cov, z, det.score)
+        return self.kf.update(t.mean, t.cov, z)
+
+    def _update(self, t, det):
+        t.frame = self.frame_id
+        t.len += 1
+        t.score = det.score
+        t.mean, t.cov = self._kf_update(t, det)
+        t.state, t.activated, t.tsu = TRACKED, True, 0
+
+    def _reactivate(self, t, det):
+        z = t.meas(det.tlwh)
+        t.mean, t.cov = self.kf.update(t.mean, t.cov, z)  # no confidence: basetrack.py:283-285
+        t.len = 0
+        t.state, t.activated, t.frame, t.score, t.tsu = TRACKED, True, self.frame_id, det.score, 0
+
+    def _multi_predict(self, pool):
+        if pool:
+            mm = np.asarray([t.mean.copy() for t in pool])
+            cc = np.asarray([t.cov for t in pool])
+            for i, t in enumerate(pool):
+                if t.state != TRACKED:
+                    mm[i][-1] = 0
+            mm, cc = self.kf.multi_predict(mm, cc)
+            for t, m, c in zip(pool, mm, cc):
+                t.mean, t.cov = m, c
+        for t in pool:
+            t.tsu += 1
+
+    def _mk(self, rows):
+        return [T(r[5], np.array([r[0], r[1], r[2] - r[0], r[3] - r[1]], dtype=rows.dtype), r[4], self.fmt)
+                for r in rows]
+
+    def _finish(self, act, refind, lost, removed):
+        self.tracked = [t for t in self.tracked if t.state == TRACKED]
+        self.tracked = _joint(self.tracked, act)
+        self.tracked = _joint(self.tracked, refind)
+        self.lost = _sub(self.lost, self.tracked)
+        self.lost.extend(lost)
+        self.lost = _sub(self.lost, self.removed)
+        self.removed.extend(removed)
+        self.tracked, self.lost = _dedup(self.tracked, self.lost)
+        return [t for t in self.tracked if t.activated]
+
+    def _match_apply(self, tracks, dets, matches, act, refind, only_update=False):
+        for it, idt in matches:
+            t, d = tracks[it], dets[idt]
+            if only_update or t.state == TRACKED:
+                self._update(t, d)
+                act.append(t)
+            elif self.kind == "sort" or t.state == LOST:
+                self._reactivate(t, d)
+                refind.append(t)
+
+    # --- frame step -----------------------------------------------------------
+    def update(self, det):
+        det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
+        self.frame_id += 1
+        act, refind, lost, removed = [], [], [], []
+        unconf = [t for t in self.tracked if not t.activated]
+        conf = [t for t in self.tracked if t.activated]
+        if self.kind == "sort":
+            dets = self._mk(det[det[:, 4] > self.det_thresh])
+            pool = _joint(conf, self.lost)
+            self._multi_predict(pool)
+            m, ut, ud = _assign(_iou_dist(pool, dets), self.iou_thresh)
+            self._match_apply(pool, dets, m, act, refind)
+            for i in ut:
+                if pool[i].state == TRACKED:
+                    pool[i].state = LOST
+                    lost.append(pool[i])
+            left = [dets[i] for i in ud]
+            m, ut, ud = _assign(_iou_dist(unconf, left), self.iou_thresh + 0.1)
+            self._match_apply(unconf, left, m, act, refind)
+            gate = self.det_thresh + 0.1
+        else:
+            hi = det[:, 4] >= self.det_thresh
+            lo = np.logical_and(np.logical_not(hi), det[:, 4] > self.low_thresh)
+            d_hi, d_lo = self._mk(det[hi]), self._mk(det[lo])
+            pool = _joint(conf, self.lost)
+            self._multi_predict(pool)
+            m, ut, ud = _assign(_iou_dist(pool, d_hi), 0.9)
+            self._match_apply(pool, d_hi, m, act, refind)
+            rem = [pool[i] for i in ut if pool[i].state == TRACKED]
+            left = [d_hi[i] for i in ud]
+            m, ut2, _ = _assign(_iou_dist(rem, d_lo), 0.5)
+            self._match_apply(rem, d_lo, m, act, refind)
+            for i in ut2:
+                rem[i].state = LOST
+                lost.append(rem[i])
+            m, ut, ud = _assign(_iou_dist(unconf, left), 0.7)
+            self._match_apply(unconf, left, m, act, refind, only_update=True)
+            gate = self.det_thresh + 0.1
+        for i in ut:
+            unconf[i].state = REMOVED
+            removed.append(unconf[i])
+        for i in ud:
+            if left[i].score > gate:
+                self._activate(left[i])
+                act.append(left[i])
+        for t in self.lost:
+            if self.frame_id - t.frame > self.max_time_lost:
+                t.state = REMOVED
+                removed.append(t)
+        return self._finish(act, refind, lost, removed)
+
+    def update_without_detection(self):
+        self.frame_id += 1
+        conf = [t for t in self.tracked if t.activated]
+        self._multi_predict(_joint(conf, self.lost))
+        return self._finish([], [], [], [])
+
+
+def run(kind, dets_per_frame, ids=None, **kw):
+    """-> per-frame list of (track_id, tlwh float64[4], cls, score), like ref_harness.run_reference_tracker."""
+    trk = TrackerNP(kind, ids=ids if ids is not None else IdCounter(), **kw)
+    out = []
+    for det in dets_per_frame:
+        cur = trk.update_without_detection() if det is None else trk.update(det)
+        out.append([(int(t.tid), np.asarray(t.tlwh, dtype=np.float64).copy(), float(t.cls), float(t.score))
+                    for t in cur])
+    return out

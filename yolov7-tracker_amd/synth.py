@@ -1,0 +1,90 @@
+"""Deterministic synthetic workloads for the tracking hot path.
+
+No dataset or trained checkpoint ships with the reference, so every parity test and
+benchmark in this repo runs on seeded synthetic sequences:
+
+* `make_detections` -- ground-truth rectangles moving with constant velocity + jitter,
+  emitted at the tracker's `(N, 6)` seam `[x1, y1, x2, y2, conf, cls]` exactly as
+  `post_process_v7` hands them over (integer-rounded corners, float32;
+  /root/reference/tracker/track.py:234-244).
+* `make_frames` -- uint8 BGR frames of VisDrone-like shape for the detector.
+"""
+import numpy as np
+
+BASE_SEED = 20260924
+
+
+def _tracks(rng, n_obj, size):
+    w = np.clip(rng.lognormal(np.log(30.0), 0.5, n_obj), 8, 300)
+    h = np.clip(rng.lognormal(np.log(30.0), 0.5, n_obj) * 1.6, 8, 300)
+    cx = rng.uniform(0.05 * size, 0.95 * size, n_obj)
+    cy = rng.uniform(0.05 * size, 0.95 * size, n_obj)
+    vx = rng.normal(0, 2.0, n_obj)
+    vy = rng.normal(0, 2.0, n_obj)
+    cls = rng.integers(0, 10, n_obj)
+    conf0 = rng.uniform(0.1, 0.95, n_obj)
+    return cx, cy, w, h, vx, vy, cls, conf0
+
+
+def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=0.05, conf_jitter=0.05):
+    """-> list of float32 (N_t, 6) arrays, one per frame."""
+    rng = np.random.default_rng(BASE_SEED + seq_idx)
+    cx, cy, w, h, vx, vy, cls, conf0 = _tracks(rng, n_obj, size)
+    out = []
+    for _ in range(n_frames):
+        cx = cx + vx
+        cy = cy + vy
+        jx = rng.normal(0, 0.5, n_obj)
+        jy = rng.normal(0, 0.5, n_obj)
+        keep = rng.random(n_obj) >= miss
+        x1 = cx + jx - w / 2
+        y1 = cy + jy - h / 2
+        x2 = x1 + w
+        y2 = y1 + h
+        conf = np.clip(conf0 + rng.normal(0, conf_jitter, n_obj), 0.02, 0.99)
+        rows = np.stack([x1, y1, x2, y2, conf, cls.astype(np.float64)], 1)[keep]
+        n_fp = rng.binomial(n_obj, fp)
+        if n_fp:
+            fw = np.clip(rng.lognormal(np.log(30.0), 0.5, n_fp), 8, 300)
+            fh = np.clip(rng.lognormal(np.log(30.0), 0.5, n_fp) * 1.6, 8, 300)
+            fx = rng.uniform(0, size - 8, n_fp)
+            fy = rng.uniform(0, size - 8, n_fp)
+            fr = np.stack([fx, fy, fx + fw, fy + fh, rng.uniform(0.1, 0.95, n_fp),
+                           rng.integers(0, 10, n_fp).astype(np.float64)], 1)
+            rows = np.concatenate([rows, fr], 0)
+        rows[:, :4] = np.clip(np.round(rows[:, :4]), 0, size)
+        ok = (rows[:, 2] - rows[:, 0] >= 2) & (rows[:, 3] - rows[:, 1] >= 2)
+        rows = rows[ok]
+        # reject exact duplicate boxes so assignment optima stay unique
+        _, first = np.unique(rows[:, :4], axis=0, return_index=True)
+        rows = rows[np.sort(first)]
+        # the detector hands rows over sorted by confidence (NMS output order)
+        rows = rows[np.argsort(-rows[:, 4], kind="stable")]
+        out.append(rows.astype(np.float32))
+    return out
+
+
+def make_frames(n_frames=4, n_obj=80, size=1280, seq_idx=0):
+    """-> uint8 (n_frames, size, size, 3) BGR frames: smooth background + moving filled rectangles."""
+    rng = np.random.default_rng(BASE_SEED + 1000 + seq_idx)
+    cx, cy, w, h, vx, vy, cls, _ = _tracks(rng, n_obj, size)
+    colors = rng.integers(0, 256, (n_obj, 3))
+    coarse = rng.integers(60, 200, (40, 40, 3)).astype(np.float32)
+    rep = size // 40 + 1
+    bg = np.kron(coarse, np.ones((rep, rep, 1), np.float32))[:size, :size]
+    # cheap separable box blur to make it low-frequency
+    k = max(rep // 2, 1)
+    bg = (bg + np.roll(bg, k, 0) + np.roll(bg, -k, 0) + np.roll(bg, k, 1) + np.roll(bg, -k, 1)) / 5.0
+    frames = np.empty((n_frames, size, size, 3), np.uint8)
+    for t in range(n_frames):
+        cx = cx + vx
+        cy = cy + vy
+        img = bg.copy()
+        for i in range(n_obj):
+            x1 = int(np.clip(cx[i] - w[i] / 2, 0, size - 1))
+            y1 = int(np.clip(cy[i] - h[i] / 2, 0, size - 1))
+            x2 = int(np.clip(cx[i] + w[i] / 2, x1 + 1, size))
+            y2 = int(np.clip(cy[i] + h[i] / 2, y1 + 1, size))
+            img[y1:y2, x1:x2] = colors[i]
+        frames[t] = img.astype(np.uint8)
+    return frames
