@@ -1,0 +1,117 @@
+/*
+ * y7t.h -- C ABI of liby7t.so, the MI355X (gfx950) implementation of the Yolov7-tracker hot path.
+ *
+ * The reference (JackWoo0831/Yolov7-tracker) is pure Python and has no FFI of its own; its
+ * "operator API" for this path is the set of Python call sites cited on each function below
+ * (paths relative to the reference repo).  This header is what a binding for those call sites
+ * binds; INTEGRATION.md shows the ctypes stubs a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is caller-owned; pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
+ *     with respect to the host unless stated otherwise;
+ *   - return value: 0 = OK, < 0 = error (message via y7t_last_error(), thread-local);
+ *   - no torch types, no exceptions across the boundary, no hidden global state except the
+ *     explicit id counter object that mirrors BaseTrack._count.
+ */
+#ifndef Y7T_H
+#define Y7T_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* y7t_stream;
+
+enum { Y7T_OK = 0, Y7T_E_ARG = -1, Y7T_E_HIP = -2, Y7T_E_CAPACITY = -3, Y7T_E_STATE = -4 };
+
+/* Kalman filter kinds == KALMAN_DICT keys, tracker/basetrack.py:64-69 */
+enum { Y7T_KALMAN_DEFAULT = 0, Y7T_KALMAN_NAIVE = 1, Y7T_KALMAN_BOTSORT = 2, Y7T_KALMAN_STRONGSORT = 3 };
+/* tracker kinds == TRACKER_DICT keys implemented on the device, tracker/track.py:56-65 */
+enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1 };
+
+const char* y7t_last_error(void);
+int y7t_version(void);
+/* number of HIP devices visible (0 when there is none); host-synchronous */
+int y7t_device_count(void);
+
+/* ---------------------------------------------------------------- tracker math (float64) ---- */
+
+/* matching.iou_distance -> ious -> cython_bbox.bbox_overlaps, tracker/matching.py:44-82.
+ * cost[i*m + j] = 1 - IoU(a_i, b_j) with the "+1 pixel" convention. a: n x 4 tlbr, b: m x 4. */
+int y7t_iou_cost_f64(const double* a_tlbr, int n, const double* b_tlbr, int m, double* cost, y7t_stream stream);
+
+/* KalmanFilter.initiate, tracker/kalman_filter.py:190-221 (xyah), :436-467 (xywh).
+ * z: K x 4 measurements; mean: K x 8; cov: K x 64.  flags bit0: keep the std products in
+ * float32 (what the reference does under numpy >= 2 when handed a float32 measurement). */
+int y7t_kf_initiate_f64(int kind, const double* z, double* mean, double* cov, int K, int flags, y7t_stream stream);
+
+/* KalmanFilter.multi_predict, tracker/kalman_filter.py:289-329, fused with the "zero the last
+ * state component of non-Tracked tracks" step of STrack.multi_predict, tracker/basetrack.py:253-271.
+ * In place on mean (N x 8) / cov (N x 64); zero_last_mask: N bytes or NULL. */
+int y7t_kf_multi_predict_f64(int kind, double* mean, double* cov, const uint8_t* zero_last_mask, int N,
+                             y7t_stream stream);
+
+/* KalmanFilter.project, tracker/kalman_filter.py:260-287 (conf: N confidences for the NSA filter or NULL).
+ * pmean: N x 4, pcov: N x 16. */
+int y7t_kf_project_f64(int kind, const double* mean, const double* cov, const double* conf, double* pmean,
+                       double* pcov, int N, y7t_stream stream);
+
+/* KalmanFilter.update, tracker/kalman_filter.py:331-363, batched over K (track, measurement) pairs:
+ * pair k updates track track_idx[k] (or track k when track_idx is NULL) with z[k] (K x 4). In place. */
+int y7t_kf_update_batch_f64(int kind, double* mean, double* cov, const double* z, const int* track_idx,
+                            const double* conf, int K, y7t_stream stream);
+
+/* KalmanFilter.gating_distance(metric='maha'), tracker/kalman_filter.py:365-411:
+ * out[i*M + j] = squared Mahalanobis distance of measurement j to track i. */
+int y7t_kf_gating_f64(int kind, const double* mean, const double* cov, const double* z, int N, int M,
+                      int only_position, double* out, y7t_stream stream);
+
+/* matching.linear_assignment -> lap.lapjv(cost, extend_cost=True, cost_limit=limit),
+ * tracker/matching.py:30-41.  cost: n x m row-major.  x[n]: column of row i or -1; y[m]: row of
+ * column j or -1; opt (may be NULL): sum of the kept costs.  One workgroup on the device;
+ * workspace: y7t_lapjv_workspace_bytes(n, m) bytes of device memory. */
+size_t y7t_lapjv_workspace_bytes(int n, int m);
+int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit, int* x, int* y, double* opt, void* workspace,
+                  y7t_stream stream);
+
+/* ---------------------------------------------------------------- device-resident tracker ---- */
+/* BaseTrack._count (tracker/basetrack.py:22,43-46): one int in device memory, shared by every
+ * tracker object of the process.  The caller allocates 4 bytes and zeroes them. */
+
+/* size in bytes of the state blob of one tracker (tracked_stracks + lost_stracks pool etc.) */
+size_t y7t_tracker_state_bytes(int cap_tracks, int cap_dets);
+
+/* BaseTracker.__init__ / ByteTrack.__init__, tracker/basetrack.py:346-367, tracker/bytetrack.py:9-17.
+ * conf_thresh = opts.conf_thresh, iou_thresh = opts.iou_thresh, max_time_lost = int(frame_rate/30*track_buffer).
+ * flags bit0: numpy>=2 float32 flow of freshly initiated tracks (see y7t_kf_initiate_f64). */
+int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kind, int kalman_kind, int cap_tracks, int cap_dets,
+                     double conf_thresh, double iou_thresh, int max_time_lost, int flags, int* id_counter,
+                     y7t_stream stream);
+
+/* ByteTrack.update / BaseTracker.update (tracker/bytetrack.py:41-204, tracker/basetrack.py:368-487) as ONE
+ * kernel launch, one workgroup per tracker.  `batch` trackers step together (independent sequences):
+ *   states[b]   state blob of tracker b
+ *   dets[b]     n x 6 float32 rows [x1,y1,x2,y2,conf,cls] (what post_process_v7 hands over, track.py:234-244)
+ *   n_dets[b]   row count, read ON THE DEVICE (so it can come straight from NMS); < 0 = update_without_detection
+ *   out_rows[b] out_cap x 8 float64 rows (track_id, x, y, w, h, cls, score, slot) of the returned tracks
+ *   out_count[b] number of returned tracks
+ * states/dets/n_dets/out_rows/out_count are DEVICE arrays of `batch` entries. threads: 0 = default. */
+int y7t_tracker_step_batch(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
+                           int* out_count, int out_cap, int batch, int threads, y7t_stream stream);
+
+/* convenience for batch == 1 with host-known n (n < 0: update_without_detection, basetrack.py:489-537) */
+int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count, int threads,
+                     y7t_stream stream);
+
+/* byte offsets of the arrays inside a state blob, for host-side views (tracked_stracks, lost_stracks, ...).
+ * names/offsets: see y7t_tracker_field_name(i); returns the number of fields. */
+int y7t_tracker_layout(int cap_tracks, int cap_dets, int64_t* offsets, int max_fields);
+const char* y7t_tracker_field_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Y7T_H */

@@ -1,0 +1,90 @@
+"""tests/_hostsim -- TEST INFRASTRUCTURE ONLY: CPU build (nt = 1) of the portable tracker
+workgroup programs, so their control flow can be tested without a GPU.  Never imported by the
+product package."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liby7t_hostsim.so")
+_SRC = os.path.join(_HERE, "y7t_hostsim.cpp")
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "yolov7-tracker_amd", "csrc")
+
+
+def build(force=False):
+    deps = [_SRC, os.path.join(_CSRC, "y7t_track_core.h"), os.path.join(_CSRC, "y7t_track_step.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO, _SRC])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.hs_tracker_bytes.restype = ctypes.c_size_t
+        L.hs_tracker_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.hs_tracker_init.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_double] * 3 + [ctypes.c_void_p]
+        L.hs_tracker_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.hs_tracker_status.argtypes = [ctypes.c_void_p]
+        L.hs_lapjv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_iou_cost.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.hs_kf_initiate.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_kf_predict.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_kf_update.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+        L.hs_kf_project.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_kf_gating.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.hs_kf_gating.restype = ctypes.c_double
+        _lib = L
+    return _lib
+
+
+def lapjv(cost, limit):
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    x = np.empty(max(nr, 1), np.int32)
+    y = np.empty(max(nc, 1), np.int32)
+    if nr and nc:
+        lib().hs_lapjv(cost.ctypes.data, nr, nc, float(limit), x.ctypes.data, y.ctypes.data)
+    else:
+        x[:] = -1
+        y[:] = -1
+    return x[:nr].copy(), y[:nc].copy()
+
+
+class HostSimTracker:
+    TRACKERS = {"sort": 0, "bytetrack": 1}
+    KINDS = {"default": 0, "naive": 1, "botsort": 2, "strongsort": 3}
+
+    def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
+                 frame_rate=30, cap_t=1024, cap_d=1024, ids=None, f32_quirk=1):
+        self.ids = ids if ids is not None else np.zeros(1, np.int32)
+        n = lib().hs_tracker_bytes(cap_t, cap_d)
+        self.blob = np.zeros(n, np.uint8)
+        self.cap_t = cap_t
+        lib().hs_tracker_init(self.blob.ctypes.data, self.TRACKERS[kind], self.KINDS[kalman_format], cap_t, cap_d,
+                              int(frame_rate / 30.0 * track_buffer), f32_quirk, conf_thresh, max(0.15, conf_thresh - 0.3),
+                              iou_thresh, self.ids.ctypes.data)
+        self.out = np.zeros((cap_t, 8), np.float64)
+
+    def update(self, det):
+        if det is None:
+            n, ptr = -1, None
+        else:
+            det = np.ascontiguousarray(det, dtype=np.float32).reshape(-1, 6)
+            n, ptr = det.shape[0], det.ctypes.data
+        cnt = lib().hs_tracker_step(self.blob.ctypes.data, ptr, n, self.out.ctypes.data, self.cap_t)
+        st = lib().hs_tracker_status(self.blob.ctypes.data)
+        if st:
+            raise RuntimeError("tracker capacity exceeded (status %d)" % st)
+        return [(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in self.out[:cnt]]
+
+
+def run(kind, dets_per_frame, **kw):
+    trk = HostSimTracker(kind, **kw)
+    return [trk.update(d) for d in dets_per_frame]

@@ -1,0 +1,50 @@
+// tests/_hostsim/y7t_hostsim.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the portable workgroup programs of yolov7-tracker_amd/csrc/y7t_track_*.h for the
+// CPU (one "thread", nt = 1) so the control flow of the device tracker can be exercised by the
+// `-m "not gpu"` suite where no GPU exists.  The product package never loads this library.
+#define Y7T_HOSTSIM 1
+#include "../../yolov7-tracker_amd/csrc/y7t_track_step.h"
+#include <stdlib.h>
+#include <string.h>
+
+static Y7TExec hs_ex() { Y7TExec e; e.tid = 0; e.nt = 1; e.rv = 0; e.ri = 0; e.fast = 0; e.fast_bytes = 0; return e; }
+
+extern "C" {
+size_t hs_tracker_bytes(int cap_t, int cap_d) { return y7t_trk_layout(cap_t, cap_d).total; }
+
+void hs_tracker_init(void* blob, int tracker, int kf, int cap_t, int cap_d, int max_time_lost, int f32_quirk,
+                     double det_thresh, double low_thresh, double iou_thresh, int* id_counter) {
+    Y7TTrkCfg c;
+    c.tracker = tracker; c.kf = kf; c.cap_t = cap_t; c.cap_d = cap_d; c.max_time_lost = max_time_lost;
+    c.f32_quirk = f32_quirk; c.det_thresh = det_thresh; c.low_thresh = low_thresh; c.iou_thresh = iou_thresh;
+    y7t_tracker_init(hs_ex(), blob, c, (unsigned long long)(uintptr_t)id_counter);
+}
+
+int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int out_cap) {
+    int cnt = 0;
+    y7t_tracker_step(hs_ex(), blob, dets, n, out_rows, out_cap, &cnt);
+    return cnt;
+}
+
+int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
+
+void hs_lapjv(const double* cost, int nr, int nc, double limit, int* x, int* y) {
+    Y7TLap L;
+    L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0;
+    void* ws = malloc(y7t_lap_ws_bytes(L.n) + 64);
+    y7t_lap_bind(L, ws, L.n);
+    y7t_lap_solve(hs_ex(), L);
+    for (int i = 0; i < nr; ++i) x[i] = L.x[i] >= nc ? -1 : L.x[i];
+    for (int j = 0; j < nc; ++j) y[j] = L.y[j] >= nr ? -1 : L.y[j];
+    free(ws);
+}
+
+void hs_iou_cost(const double* a, int n, const double* b, int m, double* cost) {
+    for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) cost[(size_t)i * m + j] = y7t_iou_dist(a + 4 * i, b + 4 * j);
+}
+void hs_kf_initiate(int kind, const double* z, int f32_std, double* mean, double* cov) { y7t_kf_initiate(kind, z, f32_std, mean, cov); }
+void hs_kf_predict(int kind, double* mean, double* cov) { y7t_kf_predict(kind, mean, cov); }
+void hs_kf_update(int kind, double* mean, double* cov, const double* z, double conf) { y7t_kf_update(kind, mean, cov, z, conf); }
+void hs_kf_project(int kind, const double* mean, const double* cov, double conf, double* pm, double* S) { y7t_kf_project(kind, mean, cov, conf, pm, S); }
+double hs_kf_gating(int kind, const double* mean, const double* cov, const double* z, int only_pos) { return y7t_kf_gating(kind, mean, cov, z, only_pos); }
+}

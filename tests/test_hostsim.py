@@ -1,0 +1,79 @@
+"""CPU: the portable workgroup programs of the device tracker (csrc/y7t_track_core.h, y7t_track_step.h) compiled
+for the host with one thread (tests/_hostsim), against the reference's golden vectors and the oracle.  This checks
+the control flow / arithmetic of the text that hipcc compiles for gfx950; the `-m gpu` tests check the real thing."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cnative
+from tests import _hostsim as hs
+from tests import util
+
+
+@pytest.mark.parametrize("name", util.TRACKER_CASES)
+def test_hostsim_tracker_matches_reference_golden(name):
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    got = hs.run(trk, dets, kalman_format=fmt)
+    util.assert_same_tracks(got, want, name)
+
+
+def test_hostsim_lapjv_equals_oracle():
+    rng = np.random.default_rng(0)
+    for t in range(200):
+        nr, nc = rng.integers(1, 45, 2)
+        c = rng.random((nr, nc))
+        if t % 3 == 0:
+            c = np.where(rng.random((nr, nc)) < 0.7, 1.0, c)  # mostly "no overlap", like real IoU costs
+        lim = [0.9, 0.5, 0.7][t % 3]
+        _, x0, y0 = cnative.lapjv(c, extend_cost=True, cost_limit=lim)
+        x1, y1 = hs.lapjv(c, lim)
+        np.testing.assert_array_equal(x0, x1)
+        np.testing.assert_array_equal(y0, y1)
+
+
+def test_hostsim_kalman_matches_reference_golden():
+    kal = np.load(util.GOLDEN + "/kalman.npz")
+    L = hs.lib()
+    for kind, kid in (("default", 0), ("botsort", 2), ("strongsort", 3)):
+        mean, cov, z, conf = (kal[kind + "_" + k] for k in ("mean", "cov", "z", "conf"))
+        for i in range(len(mean)):
+            m, P = mean[i].copy(), cov[i].copy()
+            L.hs_kf_predict(kid, m.ctypes.data, P.ctypes.data)
+            np.testing.assert_allclose(m, kal[kind + "_pred_mean"][i], rtol=1e-13)
+            np.testing.assert_allclose(P, kal[kind + "_pred_cov"][i], rtol=1e-12, atol=1e-12)
+            m, P = mean[i].copy(), cov[i].copy()
+            L.hs_kf_update(kid, m.ctypes.data, P.ctypes.data, z[i].ctypes.data, ctypes.c_double(conf[i] if kind == "strongsort" else 0.0))
+            np.testing.assert_allclose(m, kal[kind + "_upd_mean"][i], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(P, kal[kind + "_upd_cov"][i], rtol=1e-8, atol=1e-9)
+            z32 = z[i].astype(np.float32).astype(np.float64)
+            m, P = np.zeros(8), np.zeros((8, 8))
+            L.hs_kf_initiate(kid, z32.ctypes.data, 1, m.ctypes.data, P.ctypes.data)
+            np.testing.assert_array_equal(m, kal[kind + "_init32_mean"][i])
+            np.testing.assert_allclose(P, kal[kind + "_init32_cov"][i], rtol=1e-7)
+            if kind != "botsort":
+                for j in range(len(z)):
+                    g = L.hs_kf_gating(kid, mean[i].ctypes.data, cov[i].ctypes.data, z[j].ctypes.data, 0)
+                    np.testing.assert_allclose(g, kal[kind + "_gate4"][i][j], rtol=1e-9)
+
+
+def test_hostsim_capacity_error_is_loud():
+    from yolov7_tracker_amd import synth
+    dets = synth.make_detections(3, 80, seq_idx=0)
+    trk = hs.HostSimTracker("bytetrack", cap_t=16, cap_d=128)
+    with pytest.raises(RuntimeError):
+        for d in dets:
+            trk.update(d)
+
+
+def test_hostsim_empty_and_ragged_frames():
+    trk = hs.HostSimTracker("bytetrack")
+    assert trk.update(np.zeros((0, 6), np.float32)) == []
+    assert trk.update(None) == []
+    one = np.array([[10, 10, 50, 90, 0.9, 3]], np.float32)
+    out = trk.update(one)           # frame 3: new track is born unconfirmed (only frame-1 births are active)
+    assert out == []
+    out = trk.update(one)
+    assert [r[0] for r in out] == [1]
+    out = trk.update(np.zeros((0, 6), np.float32))
+    assert out == []

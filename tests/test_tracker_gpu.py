@@ -1,0 +1,205 @@
+"""GPU parity tests of the tracker half of the hot path, through the C ABI of liby7t.so.
+Oracle: the golden vectors recorded from the reference's own sources (tests/golden) and the CPU restatements in
+oracle/.  Bars: integer outputs (assignments, track ids) bit-exact; IoU cost bit-exact (same IEEE operations);
+Kalman within the stated float64 tolerances."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from yolov7_tracker_amd import _lib
+    _lib.require_gpu()
+    return _lib.load()
+
+
+def make_opts(**kw):
+    o = types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5,
+                              reid_model_path="", gamma=0.1, min_area=150)
+    o.__dict__.update(kw)
+    return o
+
+
+def run_device_tracker(trk, fmt, dets, **kw):
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack, BaseTracker
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    cls = {"sort": BaseTracker, "bytetrack": ByteTrack}[trk]
+    t = cls(make_opts(kalman_format=fmt, **kw), frame_rate=30)
+    out = []
+    for d in dets:
+        cur = t.update_without_detection(None, None) if d is None else t.update(d, None)
+        out.append([(tr.track_id, tr.tlwh, float(tr.cls), float(tr.score)) for tr in cur])
+    return out, t
+
+
+@pytest.mark.parametrize("name", util.TRACKER_CASES)
+def test_fused_tracker_matches_reference_golden(name):
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    got, _ = run_device_tracker(trk, fmt, dets)
+    util.assert_same_tracks(got, want, name)
+
+
+@pytest.mark.parametrize("threads", [64, 256, 1024])
+def test_fused_tracker_thread_counts_agree(threads):
+    trk, fmt, dets, want = util.load_tracker_case("bytetrack_default")
+    got, _ = run_device_tracker(trk, fmt, dets[:40], tracker_threads=threads)
+    util.assert_same_tracks(got, want[:40], "threads=%d" % threads)
+
+
+def test_fused_tracker_accepts_device_tensor_and_views():
+    trk, fmt, dets, want = util.load_tracker_case("bytetrack_default")
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack, TrackState
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    t = ByteTrack(make_opts(), frame_rate=30)
+    for f in range(12):
+        cur = t.update(torch.from_numpy(dets[f]).cuda(), None)
+        assert [c.track_id for c in cur] == [r[0] for r in want[f]]
+    tracked, lost = t.tracked_stracks, t.lost_stracks
+    assert all(s.state == TrackState.Tracked for s in tracked)
+    assert all(s.state in (TrackState.Lost, TrackState.Removed) for s in lost)
+    s = tracked[0]
+    assert s.mean.shape == (8,) and s.cov.shape == (8, 8) and s.frame_id == 12
+    np.testing.assert_allclose(s.tlbr[2:] - s.tlbr[:2], s.tlwh[2:])
+    assert BaseTrack._count == max(r[0] for fr in want[:12] for r in fr) or BaseTrack._count >= len(tracked)
+    assert t.frame_id == 12
+
+
+def test_empty_and_ragged_frames():
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    t = ByteTrack(make_opts(), frame_rate=30)
+    assert t.update(np.zeros((0, 6), np.float32), None) == []
+    assert t.update_without_detection(None, None) == []
+    one = np.array([[10, 10, 50, 90, 0.9, 3]], np.float32)
+    assert t.update(one, None) == []
+    cur = t.update(one, None)
+    assert [c.track_id for c in cur] == [1] and cur[0].cls == 3
+    assert t.update(np.zeros((0, 6), np.float32), None) == []
+
+
+def test_capacity_overflow_is_loud():
+    from yolov7_tracker_amd import _lib, synth
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    t = ByteTrack(make_opts(max_tracks=16, max_dets=128), frame_rate=30)
+    with pytest.raises(_lib.Y7TError):
+        for d in synth.make_detections(3, 80, seq_idx=0):
+            t.update(d, None)
+
+
+# ---------------------------------------------------------------- per-op kernels through the C ABI
+def test_iou_cost_bit_exact_vs_oracle():
+    from oracle import cnative
+    from yolov7_tracker_amd.tracker import matching
+    g = np.load(util.GOLDEN + "/lap_iou.npz")
+    for k in range(int(g["n_cases"])):
+        a, b = g["a%d" % k], g["b%d" % k]
+        np.testing.assert_array_equal(matching.iou_distance(list(a), list(b)), 1 - g["iou%d" % k])
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 1280, (500, 4)); a[:, 2:] = a[:, :2] + rng.uniform(5, 200, (500, 2))
+    b = np.round(a[rng.integers(0, 500, 500)] + rng.normal(0, 8, (500, 4)))
+    np.testing.assert_array_equal(matching.iou_distance(list(a), list(b)), 1 - cnative.bbox_overlaps(a, b))
+    assert matching.iou_distance([], list(b)).shape == (0, 500)
+
+
+def test_lapjv_device_bit_exact_vs_oracle_and_golden():
+    from oracle import cnative
+    from yolov7_tracker_amd.tracker import matching
+    g = np.load(util.GOLDEN + "/lap_iou.npz")
+    for k in range(int(g["n_cases"])):
+        cost = 1 - g["iou%d" % k]
+        m, ua, ub = matching.linear_assignment(cost, float(g["lim%d" % k]))
+        x = g["x%d" % k]
+        want = np.asarray([[i, j] for i, j in enumerate(x) if j >= 0]).reshape(-1, 2)
+        np.testing.assert_array_equal(np.asarray(m).reshape(-1, 2), want)
+        np.testing.assert_array_equal(ua, np.where(x < 0)[0])
+        np.testing.assert_array_equal(ub, np.where(g["y%d" % k] < 0)[0])
+    rng = np.random.default_rng(2)
+    for t in range(40):
+        nr, nc = rng.integers(1, 70, 2)
+        c = rng.random((nr, nc))
+        if t % 2:
+            c = np.where(rng.random((nr, nc)) < 0.8, 1.0, c)
+        lim = [0.9, 0.5, 0.7][t % 3]
+        opt0, x0, y0 = cnative.lapjv(c, extend_cost=True, cost_limit=lim)
+        opt1, x1, y1 = matching.lapjv_device(c, lim)
+        np.testing.assert_array_equal(x0, x1)
+        np.testing.assert_array_equal(y0, y1)
+        assert abs(opt0 - opt1) < 1e-12
+    m, ua, ub = matching.linear_assignment(np.zeros((0, 5)), 0.9)
+    assert m.shape == (0, 2) and ua == () and ub == (0, 1, 2, 3, 4)
+
+
+def test_lapjv_device_500x500_optimal():
+    """BASELINE config 3 size: properties instead of the O(n^3) oracle -- valid partial matching, every kept cost
+    below the limit, total cost equal to scipy's optimum of the explicit extended problem."""
+    from scipy.optimize import linear_sum_assignment
+    from yolov7_tracker_amd.tracker import matching
+    rng = np.random.default_rng(4)
+    n = 500
+    a = rng.uniform(0, 1280, (n, 4)); a[:, 2:] = a[:, :2] + rng.uniform(8, 120, (n, 2))
+    b = np.round(a[rng.permutation(n)] + rng.normal(0, 5, (n, 4)))
+    cost = matching.iou_distance(list(a), list(b))
+    opt, x, y = matching.lapjv_device(cost, 0.9)
+    sel = x >= 0
+    assert len(set(x[sel])) == sel.sum()
+    assert np.all(y[x[sel]] == np.where(sel)[0])
+    assert np.all(cost[np.where(sel)[0], x[sel]] < 0.9)
+    ext = np.full((2 * n, 2 * n), 0.45); ext[n:, n:] = 0; ext[:n, :n] = cost
+    r, c = linear_sum_assignment(ext)
+    tot = cost[np.where(sel)[0], x[sel]].sum() + 0.45 * ((x < 0).sum() + (y < 0).sum())
+    assert abs(tot - ext[r, c].sum()) < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["default", "botsort", "strongsort"])
+def test_kalman_kernels_match_reference_golden(kind):
+    from yolov7_tracker_amd.tracker.basetrack import KALMAN_DICT
+    kal = np.load(util.GOLDEN + "/kalman.npz")
+    f = KALMAN_DICT[kind]()
+    mean, cov, z, conf = (kal[kind + "_" + k] for k in ("mean", "cov", "z", "conf"))
+    mp, cp = f.multi_predict(mean, cov)
+    np.testing.assert_allclose(mp, kal[kind + "_pred_mean"], rtol=1e-13)
+    np.testing.assert_allclose(cp, kal[kind + "_pred_cov"], rtol=1e-12, atol=1e-12)
+    for i in range(len(mean)):
+        c = conf[i] if kind == "strongsort" else 0.0
+        pm, pc = f.project(mean[i], cov[i], c)
+        np.testing.assert_allclose(pm, kal[kind + "_proj_mean"][i], rtol=1e-13)
+        np.testing.assert_allclose(pc, kal[kind + "_proj_cov"][i], rtol=1e-12)
+        um, uc = f.update(mean[i], cov[i], z[i], c)
+        np.testing.assert_allclose(um, kal[kind + "_upd_mean"][i], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(uc, kal[kind + "_upd_cov"][i], rtol=1e-8, atol=1e-9)
+        a, b = f.initiate(z[i].astype(np.float32))
+        assert a.dtype == np.float32
+        np.testing.assert_array_equal(a.astype(np.float64), kal[kind + "_init32_mean"][i])
+        np.testing.assert_allclose(b, kal[kind + "_init32_cov"][i], rtol=1e-7)
+        a, b = f.initiate(z[i])
+        np.testing.assert_array_equal(a, kal[kind + "_init64_mean"][i])
+        np.testing.assert_allclose(b, kal[kind + "_init64_cov"][i], rtol=1e-14)
+        if kind != "botsort":
+            np.testing.assert_allclose(f.gating_distance(mean[i], cov[i], z), kal[kind + "_gate4"][i], rtol=1e-9)
+            np.testing.assert_allclose(f.gating_distance(mean[i], cov[i], z, True), kal[kind + "_gate2"][i], rtol=1e-9)
+
+
+def test_kalman_batch_500_tracks_roundtrip_properties(L):
+    """config-3 size: predict is linear in P (F P F^T + Q), update keeps P symmetric PSD and shrinks its trace."""
+    from oracle.kalman_np import KalmanNP
+    from yolov7_tracker_amd.tracker.basetrack import KALMAN_DICT
+    rng = np.random.default_rng(8)
+    n = 500
+    f, o = KALMAN_DICT["default"](), KalmanNP("default")
+    mean = np.zeros((n, 8)); mean[:, :2] = rng.uniform(0, 1280, (n, 2)); mean[:, 2] = rng.uniform(0.3, 2, n); mean[:, 3] = rng.uniform(10, 300, n)
+    A = rng.normal(0, 1, (n, 8, 8)); cov = np.einsum("nij,nkj->nik", A, A) + np.eye(8)
+    mp, cp = f.multi_predict(mean, cov)
+    m0, c0 = o.multi_predict(mean, cov)
+    np.testing.assert_allclose(mp, m0, rtol=1e-13)
+    np.testing.assert_allclose(cp, c0, rtol=1e-12, atol=1e-12)
+    assert np.abs(cp - cp.transpose(0, 2, 1)).max() < 1e-9

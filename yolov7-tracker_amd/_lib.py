@@ -1,0 +1,85 @@
+"""ctypes binding of liby7t.so (the C ABI declared in include/y7t.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no CPU fallback anywhere in the package (the CPU oracle lives in /oracle and is test-only).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liby7t.so")
+
+c_void_p, c_int, c_double, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); kept in sync with include/y7t.h (tests/test_abi.py checks the header)
+SIGNATURES = {
+    "y7t_last_error": (ctypes.c_char_p, []),
+    "y7t_version": (c_int, []),
+    "y7t_device_count": (c_int, []),
+    "y7t_iou_cost_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "y7t_kf_initiate_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "y7t_kf_multi_predict_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "y7t_kf_project_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "y7t_kf_update_batch_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "y7t_kf_gating_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "y7t_lapjv_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "y7t_lapjv_f64": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y7t_tracker_state_bytes": (c_size_t, [c_int, c_int]),
+    "y7t_tracker_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p,
+                                 c_void_p]),
+    "y7t_tracker_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "y7t_tracker_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "y7t_tracker_layout": (c_int, [c_int, c_int, c_void_p, c_int]),
+    "y7t_tracker_field_name": (ctypes.c_char_p, [c_int]),
+}
+
+_lib = None
+
+
+class Y7TError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liby7t.so; raises Y7TError when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Y7TError("liby7t.so is missing (%s): build it with `python -m yolov7_tracker_amd.build` -- "
+                       "this package has no CPU fallback" % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise Y7TError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise Y7TError("liby7t.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise Y7TError("liby7t call failed (%d): %s" % (rc, load().y7t_last_error().decode()))
+
+
+def require_gpu():
+    """The hot path runs on the device only."""
+    import torch
+    if not torch.cuda.is_available() or load().y7t_device_count() < 1:
+        raise Y7TError("no MI355X / HIP device visible: the yolov7_tracker_amd hot path has no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

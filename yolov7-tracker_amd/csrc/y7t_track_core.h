@@ -1,0 +1,548 @@
+// y7t_track_core.h -- tracker arithmetic for the MI355X tracking hot path.
+//
+// One source, two compilations:
+//   * hipcc --offload-arch=gfx950 : every function is a __device__ function executed by ONE
+//     workgroup (nt = 64..1024 threads).  This is the product.
+//   * g++ -DY7T_HOSTSIM           : the same text with nt = 1, used ONLY by the CPU test-suite
+//     (tests/_hostsim) to exercise the control flow where no GPU exists.  It is never loaded by
+//     the product package.
+//
+// What it restates (reference file:line, /root/reference/...):
+//   * Kalman filters  tracker/kalman_filter.py:158-411 (xyah), :414-605 (xywh), :607-646 (NSA)
+//   * IoU distance    tracker/matching.py:44-82  (-> cython_bbox.bbox_overlaps, "+1" convention)
+//   * linear_assignment tracker/matching.py:30-41 (-> lap.lapjv(extend_cost=True, cost_limit=t))
+//   * ByteTrack / SORT frame step  tracker/bytetrack.py:41-204, tracker/basetrack.py:368-537
+//   * STrack glue     tracker/basetrack.py:74-339, list helpers :540-576
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define Y7T_FN __device__ __forceinline__
+#define Y7T_HD __host__ __device__ __forceinline__
+#define Y7T_NOINL __device__ __noinline__
+#define Y7T_DEVICE 1
+#else
+#define Y7T_FN static inline
+#define Y7T_HD static inline
+#define Y7T_NOINL static
+#define Y7T_DEVICE 0
+#endif
+
+#define Y7T_LARGE 1000000.0
+#define Y7T_SP (1.0 / 20)
+#define Y7T_SV (1.0 / 160)
+
+enum { Y7T_KF_XYAH = 0, Y7T_KF_NAIVE = 1, Y7T_KF_XYWH = 2, Y7T_KF_NSA = 3 };
+enum { Y7T_NEW = 0, Y7T_TRACKED = 1, Y7T_LOST = 2, Y7T_REMOVED = 3 };
+enum { Y7T_SORT = 0, Y7T_BYTETRACK = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// execution context: one workgroup; rv/ri are >=32-entry cross-wave scratch arrays (LDS on device)
+// ---------------------------------------------------------------------------------------------
+struct Y7TExec {
+    int tid, nt;
+    double* rv;
+    int* ri;
+    char* fast;         // workgroup-private fast scratch (LDS) or null
+    size_t fast_bytes;
+};
+
+Y7T_FN void y7t_sync(const Y7TExec&) {
+#if Y7T_DEVICE
+    __syncthreads();
+#endif
+}
+
+#if Y7T_DEVICE
+#define Y7T_ATOMIC_MAX(p, v) atomicMax((p), (v))
+#define Y7T_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#else
+#define Y7T_ATOMIC_MAX(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
+#define Y7T_ATOMIC_ADD(p, v) (*(p) += (v))
+#endif
+
+Y7T_FN bool y7t_lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }
+
+// all-reduce: lexicographic minimum of (v, i) over the workgroup; every thread gets the result
+Y7T_FN void y7t_argmin(const Y7TExec& ex, double& v, int& i) {
+#if Y7T_DEVICE
+    for (int off = 32; off; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (y7t_lex_less(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+    if (ex.nt > 64) {
+        const int w = ex.tid >> 6, nw = ex.nt >> 6;
+        __syncthreads();
+        if ((ex.tid & 63) == 0) { ex.rv[w] = v; ex.ri[w] = i; }
+        __syncthreads();
+        v = ex.rv[0]; i = ex.ri[0];
+        for (int k = 1; k < nw; ++k) {
+            const double ov = ex.rv[k];
+            const int oi = ex.ri[k];
+            if (y7t_lex_less(ov, oi, v, i)) { v = ov; i = oi; }
+        }
+    }
+#else
+    (void)ex; (void)v; (void)i;
+#endif
+}
+
+// all-reduce: the two lexicographically smallest (v, i) pairs
+struct Y7TMin2 { double v1, v2; int i1, i2; };
+Y7T_FN void y7t_min2_push(Y7TMin2& m, double v, int i) {
+    if (y7t_lex_less(v, i, m.v1, m.i1)) { m.v2 = m.v1; m.i2 = m.i1; m.v1 = v; m.i1 = i; }
+    else if (y7t_lex_less(v, i, m.v2, m.i2)) { m.v2 = v; m.i2 = i; }
+}
+Y7T_FN void y7t_min2(const Y7TExec& ex, Y7TMin2& m) {
+#if Y7T_DEVICE
+    for (int off = 32; off; off >>= 1) {
+        const double a1 = __shfl_xor(m.v1, off), a2 = __shfl_xor(m.v2, off);
+        const int b1 = __shfl_xor(m.i1, off), b2 = __shfl_xor(m.i2, off);
+        y7t_min2_push(m, a1, b1);
+        y7t_min2_push(m, a2, b2);
+    }
+    if (ex.nt > 64) {
+        const int w = ex.tid >> 6, nw = ex.nt >> 6;
+        __syncthreads();
+        if ((ex.tid & 63) == 0) { ex.rv[2 * w] = m.v1; ex.rv[2 * w + 1] = m.v2; ex.ri[2 * w] = m.i1; ex.ri[2 * w + 1] = m.i2; }
+        __syncthreads();
+        Y7TMin2 r = {HUGE_VAL, HUGE_VAL, 0x7fffffff, 0x7fffffff};
+        for (int k = 0; k < 2 * nw; ++k) y7t_min2_push(r, ex.rv[k], ex.ri[k]);
+        m = r;
+    }
+#else
+    (void)ex; (void)m;
+#endif
+}
+
+// all-reduce of two independent integer minima
+Y7T_FN void y7t_imin2(const Y7TExec& ex, int& a, int& b) {
+#if Y7T_DEVICE
+    for (int off = 32; off; off >>= 1) {
+        const int oa = __shfl_xor(a, off), ob = __shfl_xor(b, off);
+        a = oa < a ? oa : a;
+        b = ob < b ? ob : b;
+    }
+    if (ex.nt > 64) {
+        const int w = ex.tid >> 6, nw = ex.nt >> 6;
+        __syncthreads();
+        if ((ex.tid & 63) == 0) { ex.ri[2 * w] = a; ex.ri[2 * w + 1] = b; }
+        __syncthreads();
+        a = ex.ri[0]; b = ex.ri[1];
+        for (int k = 1; k < nw; ++k) {
+            a = ex.ri[2 * k] < a ? ex.ri[2 * k] : a;
+            b = ex.ri[2 * k + 1] < b ? ex.ri[2 * k + 1] : b;
+        }
+    }
+#else
+    (void)ex; (void)a; (void)b;
+#endif
+}
+
+// ordered stream compaction: out[cnt++] = i for every i in [0,n) with flag(i), ascending i.
+// Returns the new count (uniform).  `out` may be appended to (cnt0).
+template <class F>
+Y7T_FN int y7t_compact(const Y7TExec& ex, int n, F flag, int* out, int cnt0) {
+#if Y7T_DEVICE
+    int cnt = cnt0;
+    const int lane = ex.tid & 63, w = ex.tid >> 6, nw = (ex.nt + 63) >> 6;
+    for (int base = 0; base < n; base += ex.nt) {
+        const int i = base + ex.tid;
+        const bool f = (i < n) && flag(i);
+        const unsigned long long b = __ballot(f);
+        const int rank = __popcll(b & ((1ull << lane) - 1ull));
+        const int tot = __popcll(b);
+        int off = 0, all = tot;
+        if (nw > 1) {
+            __syncthreads();
+            if (lane == 0) ex.ri[w] = tot;
+            __syncthreads();
+            all = 0;
+            for (int k = 0; k < nw; ++k) { if (k == w) off = all; all += ex.ri[k]; }
+        }
+        if (f) out[cnt + off + rank] = i;
+        cnt += all;
+    }
+    __syncthreads();
+    return cnt;
+#else
+    (void)ex;
+    int cnt = cnt0;
+    for (int i = 0; i < n; ++i) if (flag(i)) out[cnt++] = i;
+    return cnt;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kalman filters (8-d state; float64).  kind: 0 xyah ('default'), 2 xywh ('botsort'), 3 NSA
+// ('strongsort').  The 7-d 'naive' filter is not part of the ByteTrack/SORT hot path.
+// ---------------------------------------------------------------------------------------------
+Y7T_FN double y7t_sq(double a) { return a * a; }
+
+// kalman_filter.py:190-221 / :436-467.  z = measurement (xyah or xywh).  f32_std reproduces the
+// reference under numpy>=2: a float32 measurement keeps the std products in float32 (NEP 50).
+Y7T_FN void y7t_kf_initiate(int kind, const double* z, int f32_std, double* mean, double* cov) {
+    for (int i = 0; i < 4; ++i) { mean[i] = z[i]; mean[4 + i] = 0.0; }
+    for (int i = 0; i < 64; ++i) cov[i] = 0.0;
+    double std_[8];
+    if (f32_std) {
+        const float p2 = (float)(2 * Y7T_SP), v10 = (float)(10 * Y7T_SV);
+        if (kind == Y7T_KF_XYWH) {
+            const float w = (float)z[2], h = (float)z[3];
+            const float s[8] = {p2 * w, p2 * h, p2 * w, p2 * h, v10 * w, v10 * h, v10 * w, v10 * h};
+            // every entry is float32 there, so np.square runs in float32 too
+            for (int i = 0; i < 8; ++i) { const float q = s[i] * s[i]; cov[i * 9] = (double)q; }
+            return;
+        }
+        const float h = (float)z[3];
+        const float a = p2 * h, b = v10 * h;
+        std_[0] = a; std_[1] = a; std_[2] = 1e-2; std_[3] = a;
+        std_[4] = b; std_[5] = b; std_[6] = 1e-5; std_[7] = b;
+    } else if (kind == Y7T_KF_XYWH) {
+        const double w = z[2], h = z[3];
+        std_[0] = 2 * Y7T_SP * w; std_[1] = 2 * Y7T_SP * h; std_[2] = 2 * Y7T_SP * w; std_[3] = 2 * Y7T_SP * h;
+        std_[4] = 10 * Y7T_SV * w; std_[5] = 10 * Y7T_SV * h; std_[6] = 10 * Y7T_SV * w; std_[7] = 10 * Y7T_SV * h;
+    } else {
+        const double h = z[3];
+        std_[0] = 2 * Y7T_SP * h; std_[1] = 2 * Y7T_SP * h; std_[2] = 1e-2; std_[3] = 2 * Y7T_SP * h;
+        std_[4] = 10 * Y7T_SV * h; std_[5] = 10 * Y7T_SV * h; std_[6] = 1e-5; std_[7] = 10 * Y7T_SV * h;
+    }
+    for (int i = 0; i < 8; ++i) cov[i * 9] = y7t_sq(std_[i]);
+}
+
+// kalman_filter.py:289-329 (multi_predict) / :534-571.  In place on one track.
+// F = [[I4, I4], [0, I4]]:  x <- F x ;  P <- F P F^T + diag(q)
+Y7T_FN void y7t_kf_predict(int kind, double* mean, double* cov) {
+    double q[8];
+    if (kind == Y7T_KF_XYWH) {
+        const double w = mean[2], h = mean[3];
+        q[0] = Y7T_SP * w; q[1] = Y7T_SP * h; q[2] = Y7T_SP * w; q[3] = Y7T_SP * h;
+        q[4] = Y7T_SV * w; q[5] = Y7T_SV * h; q[6] = Y7T_SV * w; q[7] = Y7T_SV * h;
+    } else {
+        const double h = mean[3];
+        q[0] = Y7T_SP * h; q[1] = Y7T_SP * h; q[2] = 1e-2; q[3] = Y7T_SP * h;
+        q[4] = Y7T_SV * h; q[5] = Y7T_SV * h; q[6] = 1e-5; q[7] = Y7T_SV * h;
+    }
+    for (int i = 0; i < 4; ++i) mean[i] = mean[i] + mean[4 + i];
+    // left = F P : rows 0..3 += rows 4..7
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 8; ++c) cov[r * 8 + c] = cov[r * 8 + c] + cov[(r + 4) * 8 + c];
+    // (F P) F^T : cols 0..3 += cols 4..7 ; + Q
+    for (int r = 0; r < 8; ++r) {
+        for (int c = 0; c < 4; ++c) cov[r * 8 + c] = cov[r * 8 + c] + cov[r * 8 + c + 4];
+        cov[r * 9] = cov[r * 9] + y7t_sq(q[r]);
+    }
+}
+
+// measurement-noise std, kalman_filter.py:277-282 / :522-527 / :618-626
+Y7T_FN void y7t_kf_rstd(int kind, const double* mean, double conf, double* r) {
+    if (kind == Y7T_KF_XYWH) {
+        const double w = mean[2], h = mean[3];
+        r[0] = Y7T_SP * w; r[1] = Y7T_SP * h; r[2] = Y7T_SP * w; r[3] = Y7T_SP * h;
+    } else {
+        const double h = mean[3];
+        r[0] = Y7T_SP * h; r[1] = Y7T_SP * h; r[2] = 1e-1; r[3] = Y7T_SP * h;
+        if (kind == Y7T_KF_NSA) for (int i = 0; i < 4; ++i) r[i] = (1 - conf) * r[i];
+    }
+}
+
+// kalman_filter.py:260-287: projected mean (4) and S = H P H^T + R (4x4)
+Y7T_FN void y7t_kf_project(int kind, const double* mean, const double* cov, double conf, double* pm, double* S) {
+    double r[4];
+    y7t_kf_rstd(kind, mean, conf, r);
+    for (int a = 0; a < 4; ++a) {
+        pm[a] = mean[a];
+        for (int b = 0; b < 4; ++b) S[a * 4 + b] = cov[a * 8 + b];
+        S[a * 5] = S[a * 5] + y7t_sq(r[a]);
+    }
+}
+
+// lower Cholesky of a 4x4 SPD matrix (LAPACK dpotrf 'L' order of operations)
+Y7T_FN void y7t_chol4(const double* S, double* L) {
+    for (int j = 0; j < 4; ++j) {
+        double s = S[j * 4 + j];
+        for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
+        const double d = sqrt(s);
+        L[j * 4 + j] = d;
+        for (int i = j + 1; i < 4; ++i) {
+            double t = S[i * 4 + j];
+            for (int k = 0; k < j; ++k) t -= L[i * 4 + k] * L[j * 4 + k];
+            L[i * 4 + j] = t / d;
+        }
+    }
+}
+
+// solve (L L^T) x = b in place
+Y7T_FN void y7t_chol4_solve(const double* L, double* b) {
+    for (int i = 0; i < 4; ++i) {
+        double t = b[i];
+        for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * b[k];
+        b[i] = t / L[i * 4 + i];
+    }
+    for (int i = 3; i >= 0; --i) {
+        double t = b[i];
+        for (int k = i + 1; k < 4; ++k) t -= L[k * 4 + i] * b[k];
+        b[i] = t / L[i * 4 + i];
+    }
+}
+
+// kalman_filter.py:331-363.  K = P H^T S^-1 (Cholesky), x += K (z - Hx), P -= K (S K^T).  In place.
+Y7T_FN void y7t_kf_update(int kind, double* mean, double* cov, const double* z, double conf) {
+    double pm[4], S[16], L[16], K[32], W[32];
+    y7t_kf_project(kind, mean, cov, conf, pm, S);
+    y7t_chol4(S, L);
+    for (int r = 0; r < 8; ++r) {
+        double b[4] = {cov[r * 8 + 0], cov[r * 8 + 1], cov[r * 8 + 2], cov[r * 8 + 3]};
+        y7t_chol4_solve(L, b);
+        for (int a = 0; a < 4; ++a) K[r * 4 + a] = b[a];
+    }
+    double innov[4];
+    for (int a = 0; a < 4; ++a) innov[a] = z[a] - pm[a];
+    for (int r = 0; r < 8; ++r) {
+        double s = 0.0;
+        for (int a = 0; a < 4; ++a) s += innov[a] * K[r * 4 + a];
+        mean[r] = mean[r] + s;
+    }
+    // numpy multi_dot((K, S, K^T)) with equal costs evaluates K (S K^T)
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 8; ++c) {
+            double s = 0.0;
+            for (int b = 0; b < 4; ++b) s += S[a * 4 + b] * K[c * 4 + b];
+            W[a * 8 + c] = s;
+        }
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+            double s = 0.0;
+            for (int a = 0; a < 4; ++a) s += K[r * 4 + a] * W[a * 8 + c];
+            cov[r * 8 + c] = cov[r * 8 + c] - s;
+        }
+}
+
+// kalman_filter.py:365-411: squared Mahalanobis distance of one measurement (metric='maha')
+Y7T_FN double y7t_kf_gating(int kind, const double* mean, const double* cov, const double* z, int only_position) {
+    double pm[4], S[16], L[16] = {0};
+    y7t_kf_project(kind, mean, cov, 0.0, pm, S);
+    const int n = only_position ? 2 : 4;
+    // Cholesky of the leading n x n block, forward substitution
+    double acc = 0.0, yv[4];
+    for (int j = 0; j < n; ++j) {
+        double s = S[j * 4 + j];
+        for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
+        const double d = sqrt(s);
+        L[j * 4 + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double t = S[i * 4 + j];
+            for (int k = 0; k < j; ++k) t -= L[i * 4 + k] * L[j * 4 + k];
+            L[i * 4 + j] = t / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        double t = z[i] - pm[i];
+        for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * yv[k];
+        yv[i] = t / L[i * 4 + i];
+        acc += yv[i] * yv[i];
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IoU distance with the "+1 pixel" convention (cython_bbox.bbox_overlaps; matching.py:56-82)
+// ---------------------------------------------------------------------------------------------
+Y7T_FN double y7t_iou_dist(const double* b, const double* q) {
+    const double box_area = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+    double ov = 0.0;
+    const double iw = fmin(b[2], q[2]) - fmax(b[0], q[0]) + 1;
+    if (iw > 0) {
+        const double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]) + 1;
+        if (ih > 0) {
+            const double ua = (b[2] - b[0] + 1) * (b[3] - b[1] + 1) + box_area - iw * ih;
+            ov = iw * ih / ua;
+        }
+    }
+    return 1 - ov;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lap.lapjv(cost, extend_cost=True, cost_limit=limit): Jonker-Volgenant on the IMPLICIT
+// (nr+nc)^2 extended matrix [[cost, limit/2], [limit/2, 0]] -- never materialised.
+// Work arrays (length n = nr + nc) live in LDS on the device.
+// Column reduction, reduction transfer and augmenting row reduction reproduce lap's sequential
+// scans exactly (parallel reductions break ties towards the lowest index, which is what the
+// sequential strict-< scans do).  The augmentation phase explores tied columns in ascending
+// column order instead of lap's internal permutation order; both are optimal, and they return
+// the same assignment whenever the optimal partial matching is unique.
+// ---------------------------------------------------------------------------------------------
+struct Y7TLap {
+    const double* c;  // nr x nc, row stride ld
+    int nr, nc, ld, n;
+    double half;
+    int *x, *y, *fr, *pred, *st, *cnt;  // n each
+    double *v, *d;                      // n each
+};
+
+Y7T_FN double y7t_lap_cost(const Y7TLap& L, int i, int j) {
+    if (i < L.nr) return j < L.nc ? L.c[(size_t)i * L.ld + j] : L.half;
+    return j < L.nc ? L.half : 0.0;
+}
+
+Y7T_HD size_t y7t_lap_ws_bytes(int n) { return (size_t)n * (6 * sizeof(int) + 2 * sizeof(double)); }
+
+Y7T_FN void y7t_lap_bind(Y7TLap& L, void* ws, int n) {
+    double* dp = (double*)ws;
+    L.v = dp; L.d = dp + n;
+    int* ip = (int*)(dp + 2 * (size_t)n);
+    L.x = ip; L.y = ip + n; L.fr = ip + 2 * (size_t)n; L.pred = ip + 3 * (size_t)n; L.st = ip + 4 * (size_t)n;
+    L.cnt = ip + 5 * (size_t)n;
+}
+
+// returns nothing; fills L.x[0..n), L.y[0..n) with the square solution of the extended problem
+Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
+    const int n = L.n, tid = ex.tid, nt = ex.nt;
+    if (n <= 0) return;
+    // ---- column reduction (lap: _ccrrt_dense) ----
+    for (int j = tid; j < n; j += nt) {
+        double best = Y7T_LARGE;
+        int bi = 0;
+        for (int i = 0; i < n; ++i) {
+            const double c = y7t_lap_cost(L, i, j);
+            if (c < best) { best = c; bi = i; }
+        }
+        L.v[j] = best; L.y[j] = bi;
+        L.x[j] = -1; L.cnt[j] = 0;
+    }
+    y7t_sync(ex);
+    for (int j = tid; j < n; j += nt) { Y7T_ATOMIC_MAX(&L.x[L.y[j]], j); Y7T_ATOMIC_ADD(&L.cnt[L.y[j]], 1); }
+    y7t_sync(ex);
+    for (int j = tid; j < n; j += nt) if (L.x[L.y[j]] != j) L.y[j] = -1;
+    y7t_sync(ex);
+    // free rows, ascending
+    int n_free = y7t_compact(ex, n, [&](int i) { return L.x[i] < 0; }, L.fr, 0);
+    // reduction transfer: rows assigned to a column that only they claimed
+    for (int i = 0; i < n; ++i) {
+        const int j = L.x[i];
+        if (j < 0 || L.cnt[i] != 1) continue;  // uniform
+        double m = Y7T_LARGE;
+        int mi = 0;
+        for (int j2 = tid; j2 < n; j2 += nt) {
+            if (j2 == j) continue;
+            const double c = y7t_lap_cost(L, i, j2) - L.v[j2];
+            if (c < m) m = c;
+        }
+        y7t_argmin(ex, m, mi);
+        y7t_sync(ex);
+        if (tid == 0) L.v[j] -= m;
+        y7t_sync(ex);
+    }
+    // ---- augmenting row reduction, two passes (lap: _carr_dense) ----
+    for (int pass = 0; pass < 2 && n_free > 0; ++pass) {
+        unsigned current = 0, rr_cnt = 0;
+        int new_free = 0;
+        while (current < (unsigned)n_free) {
+            rr_cnt++;
+            const int free_i = L.fr[current++];
+            Y7TMin2 m = {HUGE_VAL, HUGE_VAL, 0x7fffffff, 0x7fffffff};
+            for (int j = tid; j < n; j += nt) y7t_min2_push(m, y7t_lap_cost(L, free_i, j) - L.v[j], j);
+            y7t_min2(ex, m);
+            int j1 = m.i1, j2 = m.i2;
+            double v1 = m.v1, v2 = m.v2;
+            if (n < 2 || !(v2 < Y7T_LARGE)) { v2 = Y7T_LARGE; j2 = -1; }
+            int i0 = L.y[j1];
+            const double vj1 = L.v[j1];
+            const double v1_new = vj1 - (v2 - v1);
+            const bool lowers = v1_new < vj1;
+            const bool budget = rr_cnt < current * (unsigned)n;
+            if (budget && !lowers && i0 >= 0 && j2 >= 0) { j1 = j2; i0 = L.y[j2]; }
+            y7t_sync(ex);
+            if (budget) {
+                if (i0 >= 0) {
+                    if (lowers) { --current; if (tid == 0) L.fr[current] = i0; }
+                    else { if (tid == 0) L.fr[new_free] = i0; ++new_free; }
+                }
+                if (lowers && tid == 0) L.v[j1] = v1_new;
+            } else if (i0 >= 0) {
+                if (tid == 0) L.fr[new_free] = i0;
+                ++new_free;
+            }
+            if (tid == 0) { L.x[free_i] = j1; L.y[j1] = free_i; }
+            y7t_sync(ex);
+        }
+        n_free = new_free;
+    }
+    // ---- augmentation: shortest augmenting paths (lap: _ca_dense / _find_path_dense) ----
+    for (int f = 0; f < n_free; ++f) {
+        const int start = L.fr[f];
+        for (int j = tid; j < n; j += nt) {
+            L.st[j] = 0;
+            L.pred[j] = start;
+            L.d[j] = y7t_lap_cost(L, start, j) - L.v[j];
+        }
+        y7t_sync(ex);
+        int final_j = -1;
+        double mind = 0.0;
+        while (final_j < 0) {
+            // new frontier: all TODO columns at the minimum distance
+            double mv = HUGE_VAL;
+            int mj = 0x7fffffff;
+            for (int j = tid; j < n; j += nt) {
+                if (L.st[j] == 3) L.st[j] = 2;
+                if (L.st[j] == 0 && y7t_lex_less(L.d[j], j, mv, mj)) { mv = L.d[j]; mj = j; }
+            }
+            y7t_argmin(ex, mv, mj);
+            mind = mv;
+            int fin = 0x7fffffff, nxt = 0x7fffffff;
+            for (int j = tid; j < n; j += nt) {
+                if (L.st[j] == 0 && L.d[j] == mind) {
+                    L.st[j] = 1;
+                    if (L.y[j] < 0) { if (j < fin) fin = j; }
+                    else if (j < nxt) nxt = j;
+                }
+            }
+            y7t_imin2(ex, fin, nxt);
+            y7t_sync(ex);
+            if (fin != 0x7fffffff) { final_j = fin; break; }
+            // scan the frontier (it may grow while scanning)
+            while (nxt != 0x7fffffff) {
+                const int jc = nxt, i = L.y[jc];
+                const double h = y7t_lap_cost(L, i, jc) - L.v[jc] - mind;
+                fin = 0x7fffffff; nxt = 0x7fffffff;
+                for (int j = tid; j < n; j += nt) {
+                    int s = L.st[j];
+                    if (j == jc) { L.st[j] = 3; continue; }
+                    if (s == 0) {
+                        const double cred = y7t_lap_cost(L, i, j) - L.v[j] - h;
+                        if (cred < L.d[j]) {
+                            L.d[j] = cred;
+                            L.pred[j] = i;
+                            if (cred == mind) {
+                                if (L.y[j] < 0) { if (j < fin) fin = j; }
+                                else { L.st[j] = 1; s = 1; }
+                            }
+                        }
+                    }
+                    if (s == 1 && j < nxt) nxt = j;
+                }
+                y7t_imin2(ex, fin, nxt);
+                y7t_sync(ex);
+                if (fin != 0x7fffffff) { final_j = fin; break; }
+            }
+        }
+        // dual update of the columns that were READY before the last frontier
+        for (int j = tid; j < n; j += nt) if (L.st[j] == 2) L.v[j] += L.d[j] - mind;
+        y7t_sync(ex);
+        if (tid == 0) {
+            int i = -1, j = final_j;
+            while (i != start) {
+                i = L.pred[j];
+                L.y[j] = i;
+                const int t = j;
+                j = L.x[i];
+                L.x[i] = t;
+            }
+        }
+        y7t_sync(ex);
+    }
+}

@@ -1,0 +1,537 @@
+// y7t_track_step.h -- the ByteTrack / SORT per-frame association state machine as ONE workgroup
+// program over a device-resident struct-of-arrays track pool.  Portable text (see
+// y7t_track_core.h for the two ways it is compiled).
+//
+// Restates /root/reference/tracker/bytetrack.py:41-204 (ByteTrack.update),
+// tracker/basetrack.py:368-487 (BaseTracker.update == SORT), :489-537
+// (update_without_detection), :222-339 (STrack.activate/re_activate/update/multi_predict),
+// :183-219 (tlwh/tlbr), :540-576 (joint/sub/remove_duplicate_stracks).
+//
+// Lists (tracked / lost) are ordered arrays of pool slots and keep the reference's list order,
+// because list position is what the assignment indices refer to and what the returned track
+// order is.  The reference's ever-growing `removed_stracks` list is represented by the per-slot
+// flag `inrem` (the list itself is only ever used for id-membership tests); a slot is recycled
+// once it is in neither list.
+#pragma once
+#include "y7t_track_core.h"
+
+struct Y7TTrkCfg {
+    int tracker;        // Y7T_SORT / Y7T_BYTETRACK
+    int kf;             // Kalman kind
+    int cap_t, cap_d;   // capacities: live tracks (tracked+lost), detections per frame
+    int max_time_lost;  // int(frame_rate / 30 * track_buffer)
+    int f32_quirk;      // 1: reproduce numpy>=2 float32 flow of freshly initiated tracks
+    double det_thresh;  // opts.conf_thresh
+    double low_thresh;  // max(0.15, conf_thresh - 0.3)
+    double iou_thresh;  // opts.iou_thresh (SORT)
+};
+
+struct Y7TTrkHdr {
+    int magic, frame_id, n_tracked, n_lost, n_free, status, n_out, n_removed_total;
+    int n_act_last, n_refind_last, n_lostn_last, n_removed_last;
+    int pad0, pad1;
+    unsigned long long id_counter_ptr;  // device int* shared by every tracker of the process
+    Y7TTrkCfg cfg;
+};
+
+// byte offsets of every array inside the state blob
+struct Y7TTrkLayout {
+    size_t mean, cov, box, score, cls, tid, start, frame, tsu, state, act, len, inrem, f32m;
+    size_t tracked, lost, freel, mark;
+    size_t pool, unconf, rem, actl, refind, lostn, removedl, tmpa, tmpb;
+    size_t dhi, dlo, left, dbox, dtlbr, ttlbr, cost, lapws, xrow, ycol;
+    size_t total;
+};
+
+Y7T_HD size_t y7t_al(size_t x) { return (x + 63) & ~(size_t)63; }
+
+Y7T_HD Y7TTrkLayout y7t_trk_layout(int cap_t, int cap_d) {
+    Y7TTrkLayout L;
+    size_t o = y7t_al(sizeof(Y7TTrkHdr));
+    const size_t T = (size_t)cap_t, D = (size_t)cap_d;
+#define Y7T_TAKE(f, bytes) L.f = o; o = y7t_al(o + (bytes));
+    Y7T_TAKE(mean, T * 8 * 8) Y7T_TAKE(cov, T * 64 * 8)
+    Y7T_TAKE(box, T * 4 * 4) Y7T_TAKE(score, T * 4) Y7T_TAKE(cls, T * 4)
+    Y7T_TAKE(tid, T * 4) Y7T_TAKE(start, T * 4) Y7T_TAKE(frame, T * 4) Y7T_TAKE(tsu, T * 4)
+    Y7T_TAKE(state, T * 4) Y7T_TAKE(act, T * 4) Y7T_TAKE(len, T * 4) Y7T_TAKE(inrem, T * 4) Y7T_TAKE(f32m, T * 4)
+    Y7T_TAKE(tracked, T * 4) Y7T_TAKE(lost, T * 4) Y7T_TAKE(freel, T * 4) Y7T_TAKE(mark, T * 4)
+    Y7T_TAKE(pool, T * 4) Y7T_TAKE(unconf, T * 4) Y7T_TAKE(rem, T * 4) Y7T_TAKE(actl, T * 4)
+    Y7T_TAKE(refind, T * 4) Y7T_TAKE(lostn, T * 4) Y7T_TAKE(removedl, T * 4) Y7T_TAKE(tmpa, T * 4) Y7T_TAKE(tmpb, T * 4)
+    Y7T_TAKE(dhi, D * 4) Y7T_TAKE(dlo, D * 4) Y7T_TAKE(left, D * 4)
+    Y7T_TAKE(dbox, D * 4 * 4) Y7T_TAKE(dtlbr, D * 4 * 8) Y7T_TAKE(ttlbr, T * 4 * 8)
+    Y7T_TAKE(cost, T * (T > D ? T : D) * 8)
+    Y7T_TAKE(lapws, y7t_lap_ws_bytes(cap_t + (cap_t > cap_d ? cap_t : cap_d)))
+    Y7T_TAKE(xrow, T * 4) Y7T_TAKE(ycol, (T > D ? T : D) * 4)
+#undef Y7T_TAKE
+    L.total = o;
+    return L;
+}
+
+struct Y7TTrk {
+    Y7TTrkHdr* h;
+    double *mean, *cov;
+    float *box, *score, *cls;
+    int *tid, *start, *frame, *tsu, *state, *act, *len, *inrem, *f32m;
+    int *tracked, *lost, *freel, *mark;
+    int *pool, *unconf, *rem, *actl, *refind, *lostn, *removedl, *tmpa, *tmpb;
+    int *dhi, *dlo, *left;
+    float* dbox;
+    double *dtlbr, *ttlbr, *cost;
+    void* lapws;
+    int *xrow, *ycol;
+};
+
+Y7T_FN Y7TTrk y7t_trk_bind(void* blob, int cap_t, int cap_d) {
+    const Y7TTrkLayout L = y7t_trk_layout(cap_t, cap_d);
+    char* b = (char*)blob;
+    Y7TTrk s;
+    s.h = (Y7TTrkHdr*)b;
+    s.mean = (double*)(b + L.mean); s.cov = (double*)(b + L.cov);
+    s.box = (float*)(b + L.box); s.score = (float*)(b + L.score); s.cls = (float*)(b + L.cls);
+    s.tid = (int*)(b + L.tid); s.start = (int*)(b + L.start); s.frame = (int*)(b + L.frame); s.tsu = (int*)(b + L.tsu);
+    s.state = (int*)(b + L.state); s.act = (int*)(b + L.act); s.len = (int*)(b + L.len); s.inrem = (int*)(b + L.inrem);
+    s.f32m = (int*)(b + L.f32m);
+    s.tracked = (int*)(b + L.tracked); s.lost = (int*)(b + L.lost); s.freel = (int*)(b + L.freel); s.mark = (int*)(b + L.mark);
+    s.pool = (int*)(b + L.pool); s.unconf = (int*)(b + L.unconf); s.rem = (int*)(b + L.rem); s.actl = (int*)(b + L.actl);
+    s.refind = (int*)(b + L.refind); s.lostn = (int*)(b + L.lostn); s.removedl = (int*)(b + L.removedl);
+    s.tmpa = (int*)(b + L.tmpa); s.tmpb = (int*)(b + L.tmpb);
+    s.dhi = (int*)(b + L.dhi); s.dlo = (int*)(b + L.dlo); s.left = (int*)(b + L.left);
+    s.dbox = (float*)(b + L.dbox); s.dtlbr = (double*)(b + L.dtlbr); s.ttlbr = (double*)(b + L.ttlbr);
+    s.cost = (double*)(b + L.cost); s.lapws = (void*)(b + L.lapws);
+    s.xrow = (int*)(b + L.xrow); s.ycol = (int*)(b + L.ycol);
+    return s;
+}
+
+enum { Y7T_ERR_CAP_T = 1, Y7T_ERR_CAP_D = 2, Y7T_ERR_OUT = 4 };
+
+// ---- STrack geometry -----------------------------------------------------------------------
+// tlwh of a pool track from its Kalman mean, basetrack.py:183-211 (xyah: w = a*h; tl = c - wh/2).
+// f32m: the mean still has the float32 dtype it gets from initiate under numpy>=2, so the
+// reference evaluates this property in float32.
+Y7T_FN void y7t_track_tlwh(int kf, const double* m, int f32m, double* o) {
+    if (f32m) {
+        float x = (float)m[0], y = (float)m[1], w = (float)m[2], h = (float)m[3];
+        if (kf != Y7T_KF_XYWH) w = w * h;
+        x = x - w / 2; y = y - h / 2;
+        o[0] = x; o[1] = y; o[2] = w; o[3] = h;
+    } else {
+        double x = m[0], y = m[1], w = m[2], h = m[3];
+        if (kf != Y7T_KF_XYWH) w = w * h;
+        x = x - w / 2; y = y - h / 2;
+        o[0] = x; o[1] = y; o[2] = w; o[3] = h;
+    }
+}
+
+Y7T_FN void y7t_track_tlbr(int kf, const double* m, int f32m, double* o) {
+    y7t_track_tlwh(kf, m, f32m, o);
+    if (f32m) { o[2] = (float)o[2] + (float)o[0]; o[3] = (float)o[3] + (float)o[1]; }
+    else { o[2] = o[2] + o[0]; o[3] = o[3] + o[1]; }
+}
+
+// measurement from a detection's float32 tlwh: tlwh2xyah (basetrack.py:122-129) or tlwh2xywh
+// with its floor division (basetrack.py:144-150); float32 arithmetic like numpy on a float32 array
+Y7T_FN void y7t_meas(int kf, const float* tlwh, double* z) {
+    float x = tlwh[0], y = tlwh[1], w = tlwh[2], h = tlwh[3];
+    if (kf == Y7T_KF_XYWH) { x = x + floorf(w / 2); y = y + floorf(h / 2); }
+    else { x = x + w / 2; y = y + h / 2; w = w / h; }
+    z[0] = x; z[1] = y; z[2] = w; z[3] = h;
+}
+
+// ---- building blocks -----------------------------------------------------------------------
+// cost[i*ld + j] = 1 - IoU+1(track tlbr i, det tlbr j)
+Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const double* b, int nb, double* cost, int ld) {
+    const int tot = na * nb;
+    for (int k = ex.tid; k < tot; k += ex.nt) {
+        const int i = k / nb, j = k - i * nb;
+        cost[(size_t)i * ld + j] = y7t_iou_dist(a + 4 * i, b + 4 * j);
+    }
+    y7t_sync(ex);
+}
+
+// iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
+// dtlbr[0..nb)  ->  xrow[na] (det index or -1), ycol[nb] (track index or -1).
+// The LAP work arrays and, when it fits, the cost matrix are placed in the workgroup's fast
+// scratch (LDS on the device); otherwise they stay in the state blob (HBM/L2).
+Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+    if (na == 0 || nb == 0) {  // empty cost matrix: everything unmatched (matching.py:31-32)
+        for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = -1;
+        for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = -1;
+        y7t_sync(ex);
+        return;
+    }
+    Y7TLap L;
+    L.nr = na; L.nc = nb; L.ld = nb; L.n = na + nb; L.half = thresh / 2.0;
+    const size_t ws = y7t_al(y7t_lap_ws_bytes(L.n)), cb = (size_t)na * nb * sizeof(double);
+    void* lapws = s.lapws;
+    double* cost = s.cost;
+    size_t off = 0;
+    if (ex.fast && ws <= ex.fast_bytes) { lapws = ex.fast; off = ws; }
+    if (ex.fast && off + cb <= ex.fast_bytes) cost = (double*)(ex.fast + off);
+    y7t_cost_matrix(ex, s.ttlbr, na, s.dtlbr, nb, cost, nb);
+    L.c = cost;
+    y7t_lap_bind(L, lapws, L.n);
+    y7t_lap_solve(ex, L);
+    for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
+    for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];
+    y7t_sync(ex);
+}
+
+// gather tlbr of listed pool tracks
+Y7T_FN void y7t_gather_track_tlbr(const Y7TExec& ex, const Y7TTrk& s, const int* list, int n) {
+    const int kf = s.h->cfg.kf;
+    for (int i = ex.tid; i < n; i += ex.nt) {
+        const int sl = list[i];
+        y7t_track_tlbr(kf, s.mean + 8 * (size_t)sl, s.f32m[sl], s.ttlbr + 4 * (size_t)i);
+    }
+}
+
+// gather tlbr of listed detections
+Y7T_FN void y7t_gather_det_tlbr(const Y7TExec& ex, const Y7TTrk& s, const int* list, int n) {
+    for (int i = ex.tid; i < n; i += ex.nt) {
+        const float* b = s.dbox + 4 * (size_t)list[i];
+        // STrack.tlbr of a detection: float32 tlwh, then ret[2:] += ret[:2] in float32
+        s.dtlbr[4 * (size_t)i + 0] = b[0];
+        s.dtlbr[4 * (size_t)i + 1] = b[1];
+        s.dtlbr[4 * (size_t)i + 2] = b[2] + b[0];
+        s.dtlbr[4 * (size_t)i + 3] = b[3] + b[1];
+    }
+}
+
+// apply matches of one association (parallel over pairs: distinct tracks), then append to the
+// act / refind lists in row order.  mode 0: ByteTrack pool semantics (Tracked->update,
+// Lost->re_activate, anything else untouched); 1: SORT (Tracked->update, else re_activate);
+// 2: update only.
+Y7T_FN void y7t_apply_matches(const Y7TExec& ex, const Y7TTrk& s, const int* tracks, int na, const int* dets,
+                              const float* det_rows, int mode, int& n_act, int& n_refind) {
+    const int kf = s.h->cfg.kf, frame_id = s.h->frame_id;
+    for (int i = ex.tid; i < na; i += ex.nt) {
+        const int jd = s.xrow[i];
+        if (jd < 0) continue;
+        const int sl = tracks[i], dj = dets[jd];
+        const int st = s.state[sl];
+        int what = 0;  // 1 update, 2 re_activate
+        if (mode == 2 || st == Y7T_TRACKED) what = 1;
+        else if (mode == 1 || st == Y7T_LOST) what = 2;
+        s.tmpa[i] = what;
+        if (!what) continue;
+        double z[4];
+        y7t_meas(kf, s.dbox + 4 * (size_t)dj, z);
+        const float sc = det_rows[6 * (size_t)dj + 4];
+        // basetrack.py:317-321: only `update` hands the confidence to the NSA filter
+        const double conf = (kf == Y7T_KF_NSA && what == 1) ? (double)sc : 0.0;
+        y7t_kf_update(kf, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl, z, conf);
+        s.f32m[sl] = 0;
+        s.frame[sl] = frame_id;
+        s.score[sl] = sc;
+        s.state[sl] = Y7T_TRACKED;
+        s.act[sl] = 1;
+        s.tsu[sl] = 0;
+        s.len[sl] = (what == 1) ? s.len[sl] + 1 : 0;
+    }
+    y7t_sync(ex);
+    n_act = y7t_compact(ex, na, [&](int i) { return s.xrow[i] >= 0 && s.tmpa[i] == 1; }, s.tmpb, 0);
+    // tmpb holds row indices; translate into slots appended to actl
+    {
+        const int base = s.h->n_act_last;
+        for (int k = ex.tid; k < n_act; k += ex.nt) s.actl[base + k] = tracks[s.tmpb[k]];
+        y7t_sync(ex);
+        if (ex.tid == 0) s.h->n_act_last = base + n_act;
+        y7t_sync(ex);
+    }
+    n_refind = y7t_compact(ex, na, [&](int i) { return s.xrow[i] >= 0 && s.tmpa[i] == 2; }, s.tmpb, 0);
+    {
+        const int base = s.h->n_refind_last;
+        for (int k = ex.tid; k < n_refind; k += ex.nt) s.refind[base + k] = tracks[s.tmpb[k]];
+        y7t_sync(ex);
+        if (ex.tid == 0) s.h->n_refind_last = base + n_refind;
+        y7t_sync(ex);
+    }
+}
+
+// STrack.multi_predict over a slot list (basetrack.py:253-271)
+Y7T_FN void y7t_multi_predict(const Y7TExec& ex, const Y7TTrk& s, const int* list, int n) {
+    const int kf = s.h->cfg.kf;
+    for (int i = ex.tid; i < n; i += ex.nt) {
+        const int sl = list[i];
+        double* m = s.mean + 8 * (size_t)sl;
+        if (s.state[sl] != Y7T_TRACKED) m[7] = 0.0;
+        y7t_kf_predict(kf, m, s.cov + 64 * (size_t)sl);
+        s.f32m[sl] = 0;
+        s.tsu[sl] += 1;
+    }
+    y7t_sync(ex);
+}
+
+// the end-of-frame list bookkeeping shared by update / update_without_detection
+// (bytetrack.py:185-194).  act/refind/lostn/removedl hold this frame's lists.
+Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int out_cap, int* out_count) {
+    Y7TTrkHdr* h = s.h;
+    const int kf = h->cfg.kf;
+    int nt_ = h->n_tracked, nl = h->n_lost;
+    const int n_act = h->n_act_last, n_ref = h->n_refind_last, n_lostn = h->n_lostn_last, n_rem = h->n_removed_last;
+    // tracked = [t for t in tracked if t.state == Tracked]
+    int n1 = y7t_compact(ex, nt_, [&](int i) { return s.state[s.tracked[i]] == Y7T_TRACKED; }, s.tmpa, 0);
+    for (int k = ex.tid; k < n1; k += ex.nt) s.tmpb[k] = s.tracked[s.tmpa[k]];
+    y7t_sync(ex);
+    for (int k = ex.tid; k < h->cfg.cap_t; k += ex.nt) s.mark[k] = 0;
+    y7t_sync(ex);
+    for (int k = ex.tid; k < n1; k += ex.nt) { s.tracked[k] = s.tmpb[k]; s.mark[s.tmpb[k]] = 1; }
+    y7t_sync(ex);
+    // joint_stracks(tracked, activated) then (.., refind): append slots not yet present, in order.
+    // Every slot occurs at most once in act / refind (a track is matched at most once per frame).
+    {
+        const int a = y7t_compact(ex, n_act, [&](int k) { return !s.mark[s.actl[k]]; }, s.tmpa, 0);
+        for (int k = ex.tid; k < a; k += ex.nt) s.tracked[n1 + k] = s.actl[s.tmpa[k]];
+        n1 += a;
+        const int r = y7t_compact(ex, n_ref, [&](int k) { return !s.mark[s.refind[k]]; }, s.tmpa, 0);
+        for (int k = ex.tid; k < r; k += ex.nt) s.tracked[n1 + k] = s.refind[s.tmpa[k]];
+        n1 += r;
+        y7t_sync(ex);
+        for (int k = ex.tid; k < n1; k += ex.nt) s.mark[s.tracked[k]] = 1;
+        if (ex.tid == 0) h->n_tracked = n1;
+        y7t_sync(ex);
+    }
+    // lost = sub_stracks(lost, tracked); lost.extend(lost_new); lost = sub_stracks(lost, self.removed_stracks)
+    // (membership in removed_stracks as of BEFORE this frame's removals are appended == inrem flag;
+    //  lost_new holds tracks that were Tracked, so it is disjoint from the old lost list)
+    int n2 = y7t_compact(ex, nl, [&](int i) { return !s.mark[s.lost[i]] && !s.inrem[s.lost[i]]; }, s.tmpa, 0);
+    for (int k = ex.tid; k < n2; k += ex.nt) s.tmpb[k] = s.lost[s.tmpa[k]];
+    y7t_sync(ex);
+    for (int k = ex.tid; k < n2; k += ex.nt) s.lost[k] = s.tmpb[k];
+    {
+        const int a = y7t_compact(ex, n_lostn, [&](int k) { return !s.inrem[s.lostn[k]]; }, s.tmpa, 0);
+        for (int k = ex.tid; k < a; k += ex.nt) s.lost[n2 + k] = s.lostn[s.tmpa[k]];
+        n2 += a;
+        y7t_sync(ex);
+    }
+    // self.removed_stracks.extend(removed)
+    for (int k = ex.tid; k < n_rem; k += ex.nt) s.inrem[s.removedl[k]] = 1;
+    if (ex.tid == 0) { h->n_removed_total += n_rem; h->n_lost = n2; }
+    y7t_sync(ex);
+    // remove_duplicate_stracks(tracked, lost): pairs with IoU distance < 0.15 (basetrack.py:563-576)
+    if (n1 > 0 && n2 > 0) {
+        y7t_gather_track_tlbr(ex, s, s.tracked, n1);
+        y7t_sync(ex);
+        // lost boxes go through dtlbr-sized scratch? use cost tail: keep a second tlbr array in `cost`
+        double* lb = s.cost;  // n2*4 doubles, consumed before cost is needed again
+        for (int i = ex.tid; i < n2; i += ex.nt) {
+            const int sl = s.lost[i];
+            y7t_track_tlbr(kf, s.mean + 8 * (size_t)sl, s.f32m[sl], lb + 4 * (size_t)i);
+        }
+        for (int i = ex.tid; i < n1; i += ex.nt) s.tmpa[i] = 0;
+        for (int i = ex.tid; i < n2; i += ex.nt) s.tmpb[i] = 0;
+        y7t_sync(ex);
+        const int tot = n1 * n2;
+        for (int k = ex.tid; k < tot; k += ex.nt) {
+            const int p = k / n2, q = k - p * n2;
+            const double dist = y7t_iou_dist(s.ttlbr + 4 * (size_t)p, lb + 4 * (size_t)q);
+            if (dist < 0.15) {
+                const int a = s.tracked[p], b = s.lost[q];
+                const int timep = s.frame[a] - s.start[a], timeq = s.frame[b] - s.start[b];
+                if (timep > timeq) s.tmpb[q] = 1; else s.tmpa[p] = 1;  // benign same-value races
+            }
+        }
+        y7t_sync(ex);
+        const int m1 = y7t_compact(ex, n1, [&](int i) { return !s.tmpa[i]; }, s.pool, 0);
+        const int m2 = y7t_compact(ex, n2, [&](int i) { return !s.tmpb[i]; }, s.unconf, 0);
+        for (int k = ex.tid; k < m1; k += ex.nt) s.rem[k] = s.tracked[s.pool[k]];
+        for (int k = ex.tid; k < m2; k += ex.nt) s.actl[k] = s.lost[s.unconf[k]];
+        y7t_sync(ex);
+        for (int k = ex.tid; k < m1; k += ex.nt) s.tracked[k] = s.rem[k];
+        for (int k = ex.tid; k < m2; k += ex.nt) s.lost[k] = s.actl[k];
+        y7t_sync(ex);
+        if (ex.tid == 0) { h->n_tracked = m1; h->n_lost = m2; }
+        y7t_sync(ex);
+        n1 = m1; n2 = m2;
+    }
+    // recycle slots that are in neither list
+    for (int k = ex.tid; k < h->cfg.cap_t; k += ex.nt) s.mark[k] = 0;
+    y7t_sync(ex);
+    for (int k = ex.tid; k < n1; k += ex.nt) s.mark[s.tracked[k]] = 1;
+    for (int k = ex.tid; k < n2; k += ex.nt) s.mark[s.lost[k]] = 1;
+    y7t_sync(ex);
+    {
+        const int nf = y7t_compact(ex, h->cfg.cap_t, [&](int i) { return !s.mark[i]; }, s.freel, 0);
+        if (ex.tid == 0) h->n_free = nf;
+        for (int k = ex.tid; k < h->cfg.cap_t; k += ex.nt) if (!s.mark[k]) { s.state[k] = Y7T_NEW; s.inrem[k] = 0; s.tid[k] = 0; }
+    }
+    // return [t for t in tracked if t.is_activated]: rows (id, x, y, w, h, cls, score, slot)
+    const int n_out = y7t_compact(ex, n1, [&](int i) { return s.act[s.tracked[i]] != 0; }, s.tmpa, 0);
+    if (ex.tid == 0) {
+        h->n_out = n_out;
+        if (out_count) *out_count = n_out;
+        if (n_out > out_cap) h->status |= Y7T_ERR_OUT;
+    }
+    if (out_rows) {
+        for (int k = ex.tid; k < n_out && k < out_cap; k += ex.nt) {
+            const int sl = s.tracked[s.tmpa[k]];
+            double* o = out_rows + 8 * (size_t)k;
+            o[0] = s.tid[sl];
+            y7t_track_tlwh(kf, s.mean + 8 * (size_t)sl, s.f32m[sl], o + 1);
+            o[5] = s.cls[sl]; o[6] = s.score[sl]; o[7] = sl;
+        }
+    }
+    y7t_sync(ex);
+}
+
+// One frame.  dets: n x 6 float32 rows [x1, y1, x2, y2, conf, cls] (n < 0: update_without_detection)
+Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets, int n, double* out_rows, int out_cap,
+                                int* out_count) {
+    Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
+    const Y7TTrkCfg cfg = h->cfg;
+    const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
+    const int kf = cfg.kf;
+    y7t_sync(ex);
+    if (ex.tid == 0) {
+        h->frame_id += 1;
+        h->n_act_last = h->n_refind_last = h->n_lostn_last = h->n_removed_last = 0;
+        if (n > cfg.cap_d) h->status |= Y7T_ERR_CAP_D;
+    }
+    y7t_sync(ex);
+    if (n > cfg.cap_d) n = cfg.cap_d;
+    const int frame_id = h->frame_id;
+    const int nt0 = h->n_tracked, nl0 = h->n_lost;
+    // unconfirmed / confirmed split of tracked (bytetrack.py:95-100)
+    const int n_unc = y7t_compact(ex, nt0, [&](int i) { return !s.act[s.tracked[i]]; }, s.tmpa, 0);
+    for (int k = ex.tid; k < n_unc; k += ex.nt) s.unconf[k] = s.tracked[s.tmpa[k]];
+    const int n_conf = y7t_compact(ex, nt0, [&](int i) { return s.act[s.tracked[i]] != 0; }, s.tmpb, 0);
+    // strack_pool = joint_stracks(confirmed, lost): the two lists are disjoint by construction
+    for (int k = ex.tid; k < n_conf; k += ex.nt) s.pool[k] = s.tracked[s.tmpb[k]];
+    for (int k = ex.tid; k < nl0; k += ex.nt) s.pool[n_conf + k] = s.lost[k];
+    y7t_sync(ex);
+    const int n_pool = n_conf + nl0;
+    y7t_multi_predict(ex, s, s.pool, n_pool);
+    if (n < 0) {  // update_without_detection (basetrack.py:489-537)
+        y7t_finish(ex, s, out_rows, out_cap, out_count);
+        return;
+    }
+    // detections -> STrack(cls, tlbr2tlwh(tlbr), score): float32 tlwh
+    for (int j = ex.tid; j < n; j += ex.nt) {
+        const float* r = dets + 6 * (size_t)j;
+        s.dbox[4 * (size_t)j + 0] = r[0];
+        s.dbox[4 * (size_t)j + 1] = r[1];
+        s.dbox[4 * (size_t)j + 2] = r[2] - r[0];
+        s.dbox[4 * (size_t)j + 3] = r[3] - r[1];
+    }
+    y7t_sync(ex);
+    const float det_t = (float)cfg.det_thresh, low_t = (float)cfg.low_thresh;
+    const float new_gate = (float)(cfg.det_thresh + 0.1);
+    int n_hi, n_lo = 0;
+    if (cfg.tracker == Y7T_SORT)
+        n_hi = y7t_compact(ex, n, [&](int j) { return dets[6 * (size_t)j + 4] > det_t; }, s.dhi, 0);
+    else {
+        n_hi = y7t_compact(ex, n, [&](int j) { return dets[6 * (size_t)j + 4] >= det_t; }, s.dhi, 0);
+        n_lo = y7t_compact(ex, n, [&](int j) { const float c = dets[6 * (size_t)j + 4]; return !(c >= det_t) && c > low_t; }, s.dlo, 0);
+    }
+    int na, nr;
+    // ---- first association: pool vs high-score detections ----
+    y7t_gather_track_tlbr(ex, s, s.pool, n_pool);
+    y7t_gather_det_tlbr(ex, s, s.dhi, n_hi);
+    y7t_sync(ex);
+    y7t_assoc(ex, s, n_pool, n_hi, cfg.tracker == Y7T_SORT ? cfg.iou_thresh : 0.9);
+    y7t_apply_matches(ex, s, s.pool, n_pool, s.dhi, dets, cfg.tracker == Y7T_SORT ? 1 : 0, na, nr);
+    // unmatched detections, in detection order: left = [D_high[i] for i in u_dets]
+    int n_left = y7t_compact(ex, n_hi, [&](int j) { return s.ycol[j] < 0; }, s.tmpa, 0);
+    for (int k = ex.tid; k < n_left; k += ex.nt) s.left[k] = s.dhi[s.tmpa[k]];
+    y7t_sync(ex);
+    if (cfg.tracker == Y7T_SORT) {
+        // unmatched Tracked pool tracks -> Lost
+        const int nl_new = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && s.state[s.pool[i]] == Y7T_TRACKED; }, s.tmpa, 0);
+        for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.pool[s.tmpa[k]]; s.lostn[k] = sl; }
+        y7t_sync(ex);
+        for (int k = ex.tid; k < nl_new; k += ex.nt) s.state[s.lostn[k]] = Y7T_LOST;
+        if (ex.tid == 0) h->n_lostn_last = nl_new;
+        y7t_sync(ex);
+    } else {
+        // ---- second association: remaining Tracked pool tracks vs low-score detections ----
+        const int n_rem = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && s.state[s.pool[i]] == Y7T_TRACKED; }, s.tmpa, 0);
+        for (int k = ex.tid; k < n_rem; k += ex.nt) s.rem[k] = s.pool[s.tmpa[k]];
+        y7t_sync(ex);
+        y7t_gather_track_tlbr(ex, s, s.rem, n_rem);
+        y7t_gather_det_tlbr(ex, s, s.dlo, n_lo);
+        y7t_sync(ex);
+        y7t_assoc(ex, s, n_rem, n_lo, 0.5);
+        y7t_apply_matches(ex, s, s.rem, n_rem, s.dlo, dets, 0, na, nr);
+        const int nl_new = y7t_compact(ex, n_rem, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
+        for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.rem[s.tmpa[k]]; s.lostn[k] = sl; s.state[sl] = Y7T_LOST; }
+        if (ex.tid == 0) h->n_lostn_last = nl_new;
+        y7t_sync(ex);
+    }
+    // ---- unconfirmed tracks vs leftover high detections ----
+    y7t_gather_track_tlbr(ex, s, s.unconf, n_unc);
+    y7t_gather_det_tlbr(ex, s, s.left, n_left);
+    y7t_sync(ex);
+    y7t_assoc(ex, s, n_unc, n_left, cfg.tracker == Y7T_SORT ? cfg.iou_thresh + 0.1 : 0.7);
+    y7t_apply_matches(ex, s, s.unconf, n_unc, s.left, dets, cfg.tracker == Y7T_SORT ? 1 : 2, na, nr);
+    {
+        const int n_rm = y7t_compact(ex, n_unc, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
+        for (int k = ex.tid; k < n_rm; k += ex.nt) { const int sl = s.unconf[s.tmpa[k]]; s.removedl[k] = sl; s.state[sl] = Y7T_REMOVED; }
+        if (ex.tid == 0) h->n_removed_last = n_rm;
+        y7t_sync(ex);
+    }
+    // ---- new tracks from still-unmatched detections above the gate (activate; ids in order) ----
+    {
+        const int n_new = y7t_compact(ex, n_left, [&](int j) { return s.ycol[j] < 0 && dets[6 * (size_t)s.left[j] + 4] > new_gate; }, s.tmpa, 0);
+        int* idc = (int*)(uintptr_t)h->id_counter_ptr;
+        if (ex.tid == 0) {
+            int nf = h->n_free, base = h->n_act_last, made = 0;
+            for (int k = 0; k < n_new; ++k) {
+                if (nf <= 0) { h->status |= Y7T_ERR_CAP_T; break; }
+                const int sl = s.freel[--nf];
+                s.tmpb[k] = sl;
+                s.tid[sl] = ++(*idc);
+                s.actl[base + k] = sl;
+                ++made;
+            }
+            h->n_free = nf;
+            h->n_act_last = base + made;
+            s.xrow[0] = made;
+        }
+        y7t_sync(ex);
+        const int made = s.xrow[0];
+        for (int k = ex.tid; k < made; k += ex.nt) {
+            const int sl = s.tmpb[k], dj = s.left[s.tmpa[k]];
+            double z[4];
+            for (int c = 0; c < 4; ++c) s.box[4 * (size_t)sl + c] = s.dbox[4 * (size_t)dj + c];
+            y7t_meas(kf, s.dbox + 4 * (size_t)dj, z);
+            y7t_kf_initiate(kf, z, cfg.f32_quirk, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl);
+            s.f32m[sl] = cfg.f32_quirk;
+            s.score[sl] = dets[6 * (size_t)dj + 4];
+            s.cls[sl] = dets[6 * (size_t)dj + 5];
+            s.state[sl] = Y7T_TRACKED;
+            s.act[sl] = (frame_id == 1) ? 1 : 0;
+            s.frame[sl] = frame_id; s.start[sl] = frame_id;
+            s.tsu[sl] = 0; s.len[sl] = 0; s.inrem[sl] = 0;
+        }
+        y7t_sync(ex);
+    }
+    // ---- age out long-lost tracks (bytetrack.py:180-183) ----
+    {
+        const int n_old = y7t_compact(ex, nl0, [&](int i) { return frame_id - s.frame[s.lost[i]] > cfg.max_time_lost; }, s.tmpa, 0);
+        const int base = h->n_removed_last;
+        for (int k = ex.tid; k < n_old; k += ex.nt) { const int sl = s.lost[s.tmpa[k]]; s.removedl[base + k] = sl; s.state[sl] = Y7T_REMOVED; }
+        y7t_sync(ex);
+        if (ex.tid == 0) h->n_removed_last = base + n_old;
+        y7t_sync(ex);
+    }
+    y7t_finish(ex, s, out_rows, out_cap, out_count);
+}
+
+// initialise a state blob (single thread is enough; called once)
+Y7T_FN void y7t_tracker_init(const Y7TExec& ex, void* blob, const Y7TTrkCfg& cfg, unsigned long long idc) {
+    Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
+    const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
+    if (ex.tid == 0) {
+        h->magic = 0x59375431;
+        h->frame_id = 0; h->n_tracked = 0; h->n_lost = 0; h->n_free = cfg.cap_t; h->status = 0; h->n_out = 0;
+        h->n_removed_total = 0;
+        h->n_act_last = h->n_refind_last = h->n_lostn_last = h->n_removed_last = 0;
+        h->id_counter_ptr = idc;
+        h->cfg = cfg;
+    }
+    for (int k = ex.tid; k < cfg.cap_t; k += ex.nt) {
+        s.freel[k] = cfg.cap_t - 1 - k;  // pop order 0,1,2,...
+        s.state[k] = Y7T_NEW; s.act[k] = 0; s.inrem[k] = 0; s.tid[k] = 0; s.f32m[k] = 0; s.mark[k] = 0;
+    }
+    y7t_sync(ex);
+}

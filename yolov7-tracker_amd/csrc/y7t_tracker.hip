@@ -1,0 +1,350 @@
+// y7t_tracker.hip -- gfx950 kernels + C ABI for the tracker half of the hot path
+// (Kalman predict/update, IoU cost, linear assignment, fused ByteTrack/SORT frame step).
+// The arithmetic lives in y7t_track_core.h / y7t_track_step.h (reference citations there).
+//
+// Roofline notes: all of these are HBM/latency bound, none is a
+// contraction -> no MFMA.  Kalman predict moves 1152 B/track, IoU 32(N+M) B in + 8NM B out,
+// the fused step keeps the LAP work arrays and (when it fits) the cost matrix in LDS.
+#include "y7t_common.h"
+#include "y7t_track_step.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void y7t_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* y7t_last_error(void) { return g_err; }
+extern "C" int y7t_version(void) { return 100; }
+extern "C" int y7t_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-op kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_iou_cost(const double* __restrict__ a, int n, const double* __restrict__ b, int m,
+                                                  double* __restrict__ cost) {
+    // one thread per (i, j); j fastest -> coalesced 8-byte stores, box rows broadcast through L1
+    const long long tot = (long long)n * m;
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < tot; k += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(k / m), j = (int)(k - (long long)i * m);
+        double bi[4], bj[4];
+        for (int c = 0; c < 4; ++c) { bi[c] = a[4 * (size_t)i + c]; bj[c] = b[4 * (size_t)j + c]; }
+        cost[k] = y7t_iou_dist(bi, bj);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_kf_initiate(int kind, const double* __restrict__ z, double* mean, double* cov, int K,
+                                                    int flags) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double zz[4], m[8], P[64];
+    for (int c = 0; c < 4; ++c) zz[c] = z[4 * (size_t)k + c];
+    y7t_kf_initiate(kind, zz, flags & 1, m, P);
+    for (int c = 0; c < 8; ++c) mean[8 * (size_t)k + c] = m[c];
+    for (int c = 0; c < 64; ++c) cov[64 * (size_t)k + c] = P[c];
+}
+
+__global__ void __launch_bounds__(64) k_kf_predict(int kind, double* mean, double* cov, const uint8_t* __restrict__ mask, int N) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    double m[8], P[64];
+    for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)k + c];
+    for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)k + c];
+    if (mask && mask[k]) m[7] = 0.0;
+    y7t_kf_predict(kind, m, P);
+    for (int c = 0; c < 8; ++c) mean[8 * (size_t)k + c] = m[c];
+    for (int c = 0; c < 64; ++c) cov[64 * (size_t)k + c] = P[c];
+}
+
+__global__ void __launch_bounds__(64) k_kf_project(int kind, const double* __restrict__ mean, const double* __restrict__ cov,
+                                                   const double* __restrict__ conf, double* pm, double* pc, int N) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    double m[8], P[64], a[4], S[16];
+    for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)k + c];
+    for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)k + c];
+    y7t_kf_project(kind, m, P, conf ? conf[k] : 0.0, a, S);
+    for (int c = 0; c < 4; ++c) pm[4 * (size_t)k + c] = a[c];
+    for (int c = 0; c < 16; ++c) pc[16 * (size_t)k + c] = S[c];
+}
+
+__global__ void __launch_bounds__(64) k_kf_update(int kind, double* mean, double* cov, const double* __restrict__ z,
+                                                  const int* __restrict__ idx, const double* __restrict__ conf, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int t = idx ? idx[k] : k;
+    double m[8], P[64], zz[4];
+    for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)t + c];
+    for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)t + c];
+    for (int c = 0; c < 4; ++c) zz[c] = z[4 * (size_t)k + c];
+    y7t_kf_update(kind, m, P, zz, conf ? conf[k] : 0.0);
+    for (int c = 0; c < 8; ++c) mean[8 * (size_t)t + c] = m[c];
+    for (int c = 0; c < 64; ++c) cov[64 * (size_t)t + c] = P[c];
+}
+
+__global__ void __launch_bounds__(64) k_kf_gating(int kind, const double* __restrict__ mean, const double* __restrict__ cov,
+                                                  const double* __restrict__ z, int N, int M, int only_pos, double* out) {
+    const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (k >= (long long)N * M) return;
+    const int i = (int)(k / M), j = (int)(k - (long long)i * M);
+    double m[8], P[64], zz[4];
+    for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)i + c];
+    for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)i + c];
+    for (int c = 0; c < 4; ++c) zz[c] = z[4 * (size_t)j + c];
+    out[k] = y7t_kf_gating(kind, m, P, zz, only_pos);
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-workgroup programs: LAPJV and the fused tracker step.  Dynamic LDS layout:
+//   [0, 512)  rv  (64 doubles)   [512, 768) ri (64 ints)   [1024, ...) fast scratch
+// ---------------------------------------------------------------------------------------------
+#define Y7T_LDS_HDR 1024
+extern __shared__ __attribute__((aligned(16))) char y7t_smem[];
+
+__device__ __forceinline__ Y7TExec make_exec(unsigned fast_bytes) {
+    Y7TExec ex;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x;
+    ex.rv = (double*)y7t_smem; ex.ri = (int*)(y7t_smem + 512);
+    ex.fast = fast_bytes ? y7t_smem + Y7T_LDS_HDR : nullptr;
+    ex.fast_bytes = fast_bytes;
+    return ex;
+}
+
+__global__ void k_lapjv(const double* __restrict__ cost, int nr, int nc, double limit, int* x, int* y, double* opt, void* ws_g,
+                        unsigned fast_bytes) {
+    const Y7TExec ex = make_exec(fast_bytes);
+    Y7TLap L;
+    L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0;
+    const size_t ws = y7t_al(y7t_lap_ws_bytes(L.n)), cb = (size_t)nr * nc * sizeof(double);
+    void* lapws = ws_g;
+    size_t off = 0;
+    if (ws <= fast_bytes) { lapws = ex.fast; off = ws; }
+    const double* c = cost;
+    if (ex.fast && off + cb <= fast_bytes) {  // stage the cost matrix in LDS
+        double* cl = (double*)(ex.fast + off);
+        for (int k = ex.tid; k < nr * nc; k += ex.nt) cl[k] = cost[k];
+        c = cl;
+    }
+    __syncthreads();
+    L.c = c;
+    y7t_lap_bind(L, lapws, L.n);
+    y7t_lap_solve(ex, L);
+    for (int i = ex.tid; i < nr; i += ex.nt) x[i] = (L.x[i] >= nc) ? -1 : L.x[i];
+    for (int j = ex.tid; j < nc; j += ex.nt) y[j] = (L.y[j] >= nr) ? -1 : L.y[j];
+    if (opt && ex.tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nr; ++i) if (L.x[i] < nc) s += cost[(size_t)i * nc + L.x[i]];
+        *opt = s;
+    }
+}
+
+__global__ void k_tracker_init(void* blob, Y7TTrkCfg cfg, unsigned long long idc) {
+    Y7TExec ex;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    y7t_tracker_init(ex, blob, cfg, idc);
+}
+
+__global__ void k_tracker_step(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
+                               int* out_count, int out_cap, unsigned fast_bytes) {
+    const int b = blockIdx.x;
+    const Y7TExec ex = make_exec(fast_bytes);
+    y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b);
+}
+
+__global__ void k_tracker_step1(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count,
+                                unsigned fast_bytes) {
+    const Y7TExec ex = make_exec(fast_bytes);
+    y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static inline hipStream_t S(y7t_stream s) { return (hipStream_t)s; }
+static const unsigned kFastBytes = 128 * 1024;  // fast scratch per workgroup (of the CU's 160 KiB LDS)
+
+template <class K>
+static int ensure_lds(K kernel, unsigned bytes) {
+    Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+extern "C" int y7t_iou_cost_f64(const double* a, int n, const double* b, int m, double* cost, y7t_stream stream) {
+    Y7T_ARG_CHECK(n >= 0 && m >= 0);
+    if (n == 0 || m == 0) return 0;
+    Y7T_ARG_CHECK(a && b && cost);
+    const long long tot = (long long)n * m;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_iou_cost, dim3(blocks), dim3(256), 0, S(stream), a, n, b, m, cost);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+static int kind_ok(int kind) { return kind == Y7T_KF_XYAH || kind == Y7T_KF_XYWH || kind == Y7T_KF_NSA; }
+
+extern "C" int y7t_kf_initiate_f64(int kind, const double* z, double* mean, double* cov, int K, int flags, y7t_stream stream) {
+    Y7T_ARG_CHECK(K >= 0);
+    if (!kind_ok(kind)) { y7t_set_error("kalman kind %d is not implemented on the device (default/botsort/strongsort are)", kind); return Y7T_E_ARG; }
+    if (K == 0) return 0;
+    Y7T_ARG_CHECK(z && mean && cov);
+    hipLaunchKernelGGL(k_kf_initiate, dim3((K + 63) / 64), dim3(64), 0, S(stream), kind, z, mean, cov, K, flags);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_kf_multi_predict_f64(int kind, double* mean, double* cov, const uint8_t* mask, int N, y7t_stream stream) {
+    Y7T_ARG_CHECK(N >= 0);
+    if (!kind_ok(kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kind); return Y7T_E_ARG; }
+    if (N == 0) return 0;
+    Y7T_ARG_CHECK(mean && cov);
+    hipLaunchKernelGGL(k_kf_predict, dim3((N + 63) / 64), dim3(64), 0, S(stream), kind, mean, cov, mask, N);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_kf_project_f64(int kind, const double* mean, const double* cov, const double* conf, double* pmean,
+                                  double* pcov, int N, y7t_stream stream) {
+    Y7T_ARG_CHECK(N >= 0);
+    if (!kind_ok(kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kind); return Y7T_E_ARG; }
+    if (N == 0) return 0;
+    Y7T_ARG_CHECK(mean && cov && pmean && pcov);
+    hipLaunchKernelGGL(k_kf_project, dim3((N + 63) / 64), dim3(64), 0, S(stream), kind, mean, cov, conf, pmean, pcov, N);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_kf_update_batch_f64(int kind, double* mean, double* cov, const double* z, const int* track_idx,
+                                       const double* conf, int K, y7t_stream stream) {
+    Y7T_ARG_CHECK(K >= 0);
+    if (!kind_ok(kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kind); return Y7T_E_ARG; }
+    if (K == 0) return 0;
+    Y7T_ARG_CHECK(mean && cov && z);
+    hipLaunchKernelGGL(k_kf_update, dim3((K + 63) / 64), dim3(64), 0, S(stream), kind, mean, cov, z, track_idx, conf, K);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_kf_gating_f64(int kind, const double* mean, const double* cov, const double* z, int N, int M,
+                                 int only_position, double* out, y7t_stream stream) {
+    Y7T_ARG_CHECK(N >= 0 && M >= 0);
+    if (!kind_ok(kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kind); return Y7T_E_ARG; }
+    if (N == 0 || M == 0) return 0;
+    Y7T_ARG_CHECK(mean && cov && z && out);
+    const long long tot = (long long)N * M;
+    hipLaunchKernelGGL(k_kf_gating, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, S(stream), kind, mean, cov, z, N, M,
+                       only_position, out);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t y7t_lapjv_workspace_bytes(int n, int m) {
+    if (n < 0 || m < 0) return 0;
+    return y7t_al(y7t_lap_ws_bytes(n + m)) + 64;
+}
+
+extern "C" int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit, int* x, int* y, double* opt, void* workspace,
+                             y7t_stream stream) {
+    Y7T_ARG_CHECK(n >= 0 && m >= 0);
+    if (n == 0 || m == 0) {
+        // matching.py:31-32: an empty cost matrix leaves everything unmatched
+        if (n) Y7T_HIP_CHECK(hipMemsetAsync(x, 0xff, sizeof(int) * (size_t)n, S(stream)));
+        if (m) Y7T_HIP_CHECK(hipMemsetAsync(y, 0xff, sizeof(int) * (size_t)m, S(stream)));
+        if (opt) Y7T_HIP_CHECK(hipMemsetAsync(opt, 0, sizeof(double), S(stream)));
+        return 0;
+    }
+    Y7T_ARG_CHECK(cost && x && y && workspace);
+    static bool attr_done = false;
+    if (!attr_done) { if (int e = ensure_lds(k_lapjv, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    const int nn = n + m;
+    const int threads = nn <= 128 ? 64 : (nn <= 512 ? 256 : 1024);
+    hipLaunchKernelGGL(k_lapjv, dim3(1), dim3(threads), kFastBytes + Y7T_LDS_HDR, S(stream), cost, n, m, cost_limit, x, y, opt,
+                       workspace, kFastBytes);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t y7t_tracker_state_bytes(int cap_t, int cap_d) {
+    if (cap_t <= 0 || cap_d <= 0) return 0;
+    return y7t_trk_layout(cap_t, cap_d).total;
+}
+
+extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kind, int kalman_kind, int cap_t, int cap_d,
+                                double conf_thresh, double iou_thresh, int max_time_lost, int flags, int* id_counter,
+                                y7t_stream stream) {
+    Y7T_ARG_CHECK(state && id_counter && cap_t > 0 && cap_d > 0);
+    Y7T_ARG_CHECK(tracker_kind == Y7T_SORT || tracker_kind == Y7T_BYTETRACK);
+    if (!kind_ok(kalman_kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kalman_kind); return Y7T_E_ARG; }
+    Y7T_ARG_CHECK(state_bytes >= y7t_trk_layout(cap_t, cap_d).total);
+    Y7TTrkCfg c;
+    memset(&c, 0, sizeof(c));
+    c.tracker = tracker_kind; c.kf = kalman_kind; c.cap_t = cap_t; c.cap_d = cap_d; c.max_time_lost = max_time_lost;
+    c.f32_quirk = flags & 1;
+    c.det_thresh = conf_thresh;
+    c.low_thresh = (conf_thresh - 0.3 > 0.15) ? conf_thresh - 0.3 : 0.15;  // bytetrack.py:15
+    c.iou_thresh = iou_thresh;
+    hipLaunchKernelGGL(k_tracker_init, dim3(1), dim3(256), 0, S(stream), state, c, (unsigned long long)(uintptr_t)id_counter);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+static int step_threads(int threads) {
+    if (threads == 0) return 256;
+    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) return -1;
+    return threads;
+}
+
+extern "C" int y7t_tracker_step_batch(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
+                                      int* out_count, int out_cap, int batch, int threads, y7t_stream stream) {
+    Y7T_ARG_CHECK(batch >= 0 && out_cap >= 0);
+    if (batch == 0) return 0;
+    Y7T_ARG_CHECK(states && dets && n_dets && out_rows && out_count);
+    const int nt = step_threads(threads);
+    Y7T_ARG_CHECK(nt > 0);
+    static bool attr_done = false;
+    if (!attr_done) { if (int e = ensure_lds(k_tracker_step, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    hipLaunchKernelGGL(k_tracker_step, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows,
+                       out_count, out_cap, kFastBytes);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count, int threads,
+                                y7t_stream stream) {
+    Y7T_ARG_CHECK(state && out_rows && out_count && out_cap >= 0);
+    Y7T_ARG_CHECK(n <= 0 || dets);
+    const int nt = step_threads(threads);
+    Y7T_ARG_CHECK(nt > 0);
+    static bool attr_done = false;
+    if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
+                       out_count, kFastBytes);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+static const char* kFieldNames[] = {"mean", "cov", "box", "score", "cls", "tid", "start", "frame", "tsu", "state", "act", "len",
+                                    "inrem", "f32m", "tracked", "lost", "hdr_frame_id", "hdr_n_tracked", "hdr_n_lost",
+                                    "hdr_status", "hdr_n_out", "hdr_n_removed_total", "total"};
+
+extern "C" const char* y7t_tracker_field_name(int i) {
+    const int n = (int)(sizeof(kFieldNames) / sizeof(kFieldNames[0]));
+    return (i >= 0 && i < n) ? kFieldNames[i] : nullptr;
+}
+
+extern "C" int y7t_tracker_layout(int cap_t, int cap_d, int64_t* offsets, int max_fields) {
+    const int n = (int)(sizeof(kFieldNames) / sizeof(kFieldNames[0]));
+    if (!offsets || max_fields < n || cap_t <= 0 || cap_d <= 0) return n;
+    const Y7TTrkLayout L = y7t_trk_layout(cap_t, cap_d);
+    const size_t v[] = {L.mean, L.cov, L.box, L.score, L.cls, L.tid, L.start, L.frame, L.tsu, L.state, L.act, L.len, L.inrem, L.f32m,
+                        L.tracked, L.lost, offsetof(Y7TTrkHdr, frame_id), offsetof(Y7TTrkHdr, n_tracked), offsetof(Y7TTrkHdr, n_lost),
+                        offsetof(Y7TTrkHdr, status), offsetof(Y7TTrkHdr, n_out), offsetof(Y7TTrkHdr, n_removed_total), L.total};
+    for (int i = 0; i < n; ++i) offsets[i] = (int64_t)v[i];
+    return n;
+}

@@ -1,0 +1,358 @@
+"""Tracker plugin surface of the reference (/root/reference/tracker/basetrack.py): TrackState,
+BaseTrack (process-global id counter :21-61), STrack (:74-339) and BaseTracker == SORT (:346-537),
+re-designed for the MI355X: the track pool (Kalman means/covariances, states, the
+tracked/lost lists) lives in ONE device-resident struct-of-arrays blob and a whole
+`update()` -- multi_predict, the IoU cost matrices, the linear assignments, the Kalman updates
+and the list bookkeeping -- is one kernel launch of liby7t.so (y7t_tracker_step).  The Python
+objects here are views: `update()` returns STrack views built from the rows the kernel wrote;
+everything else (`mean`, `cov`, `state`, `tracked_stracks`, ...) is read back lazily.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import matching  # noqa: F401  (re-exported like the reference module does)
+from .kalman_filter import KalmanFilter, NaiveKalmanFilter, BoTSORTKalmanFilter, NSAKalmanFilter
+
+
+class TrackState(object):
+    New = 0
+    Tracked = 1
+    Lost = 2
+    Removed = 3
+
+
+class _IdCounter:
+    """BaseTrack._count on the device: one int32 shared by every tracker of the process."""
+    _tensor = None
+
+    @classmethod
+    def tensor(cls):
+        if cls._tensor is None:
+            _lib.require_gpu()
+            cls._tensor = torch.zeros(1, dtype=torch.int32, device="cuda")
+        return cls._tensor
+
+    @classmethod
+    def get(cls):
+        return int(cls.tensor().item()) if cls._tensor is not None or torch.cuda.is_available() else 0
+
+    @classmethod
+    def set(cls, v):
+        cls.tensor().fill_(int(v))
+
+
+class _BaseTrackMeta(type):
+    @property
+    def _count(cls):
+        return _IdCounter.get()
+
+    @_count.setter
+    def _count(cls, v):
+        _IdCounter.set(v)
+
+
+class BaseTrack(object, metaclass=_BaseTrackMeta):
+    track_id = 0
+    is_activated = False
+    state = TrackState.New
+    score = 0
+    start_frame = 0
+    frame_id = 0
+    time_since_update = 0
+    location = (np.inf, np.inf)
+
+    @property
+    def end_frame(self):
+        return self.frame_id
+
+    @staticmethod
+    def next_id():
+        BaseTrack._count = BaseTrack._count + 1
+        return BaseTrack._count
+
+    def activate(self, *args):
+        raise NotImplementedError
+
+    def predict(self):
+        raise NotImplementedError
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def mark_lost(self):
+        self.state = TrackState.Lost
+
+    def mark_removed(self):
+        self.state = TrackState.Removed
+
+
+KALMAN_DICT = {
+    'default': KalmanFilter,
+    'naive': NaiveKalmanFilter,
+    'botsort': BoTSORTKalmanFilter,
+    'strongsort': NSAKalmanFilter,
+}
+_KIND = {'default': 0, 'naive': 1, 'botsort': 2, 'strongsort': 3}
+
+
+class STrack(BaseTrack):
+    """Either a detection (constructed like the reference: STrack(cls, tlwh, score, kalman_format))
+    or a view of one slot of a device track pool (built by the tracker)."""
+
+    def __init__(self, cls, tlwh, score, kalman_format='default', feature=None, use_avg_of_feature=True,
+                 store_features_budget=100):
+        self.cls = cls
+        self._tlwh = np.asarray(tlwh, dtype=np.float32)
+        self.score = score
+        self.is_activated = False
+        self.tracklet_len = 0
+        self.track_id = None
+        self.start_frame = None
+        self.frame_id = None
+        self.time_since_update = None
+        self.features = [] if feature is None else [feature]
+        self.has_feature = feature is not None
+        self.kalman_format = kalman_format
+        self.mean, self.cov = None, None
+        self._pool = None
+
+    # -- converters (basetrack.py:110-181) -----------------------------------------------------
+    @staticmethod
+    def tlbr2tlwh(tlbr):
+        r = np.asarray(tlbr).copy()
+        r[2] -= r[0]
+        r[3] -= r[1]
+        return r
+
+    @staticmethod
+    def tlwh2xyah(tlwh):
+        r = np.asarray(tlwh).copy()
+        r[:2] += r[2:] / 2
+        r[2] /= r[-1]
+        return r
+
+    @staticmethod
+    def tlwh2xyar(tlwh):
+        r = np.asarray(tlwh).copy()
+        r[:2] += r[2:] / 2
+        r[2] *= r[3]
+        r[3] = tlwh[-1] / tlwh[-2]
+        return r
+
+    @staticmethod
+    def tlwh2xywh(tlwh):
+        r = np.asarray(tlwh).copy()
+        r[:2] += r[2:] // 2
+        return r
+
+    @property
+    def tlwh(self):
+        if self.mean is None:
+            return self._tlwh.copy()
+        r = np.asarray(self.mean[:4]).copy()
+        if self.kalman_format in ('default', 'strongsort'):
+            r[2] *= r[3]
+        r[:2] -= r[2:] / 2
+        return r
+
+    @property
+    def tlbr(self):
+        r = self.tlwh.copy()
+        r[2:] += r[:2]
+        return r
+
+    def __repr__(self):
+        return 'OT_{}_({}-{})'.format(self.track_id, self.start_frame, self.end_frame)
+
+
+class _PoolTrack(STrack):
+    """View of one slot of a tracker's device pool.  `track_id`, `tlwh`, `cls`, `score` come from the rows
+    the step kernel returned; every other attribute is read back lazily from a snapshot of the pool."""
+
+    def __init__(self, tracker, slot, track_id, tlwh, kcls, score):  # noqa: super().__init__ deliberately not called
+        self._pool, self._slot, self._epoch = tracker, int(slot), tracker.frame_id
+        self.track_id, self._tlwh_now, self.cls, self.score = int(track_id), np.asarray(tlwh, dtype=np.float64), kcls, score
+        self.kalman_format = tracker.opts.kalman_format
+        self.features, self.has_feature = [], False
+
+    def _snap(self, name):
+        if self._pool._snapshot()["tid"][self._slot] != self.track_id:
+            raise _lib.Y7TError("track %d is no longer in the device pool" % self.track_id)
+        return self._pool._snapshot()[name][self._slot]
+
+    mean = property(lambda self: self._snap("mean").copy())
+    cov = property(lambda self: self._snap("cov").reshape(8, 8).copy())
+    state = property(lambda self: int(self._snap("state")))
+    is_activated = property(lambda self: bool(self._snap("act")))
+    frame_id = property(lambda self: int(self._snap("frame")))
+    start_frame = property(lambda self: int(self._snap("start")))
+    time_since_update = property(lambda self: int(self._snap("tsu")))
+    tracklet_len = property(lambda self: int(self._snap("len")))
+    _tlwh = property(lambda self: self._snap("box").copy())
+
+    @property
+    def tlwh(self):
+        if self._epoch == self._pool.frame_id:
+            return self._tlwh_now.copy()
+        return STrack.tlwh.fget(self)
+
+
+class BaseTracker(object):
+    """SORT (basetrack.py:346-537).  opts: conf_thresh, track_buffer, kalman_format, img_size, iou_thresh
+    (+ optional max_tracks / max_dets capacities of the device pool)."""
+    _KIND = 0  # Y7T_TRACKER_SORT
+
+    def __init__(self, opts, frame_rate=30, *args, **kwargs):
+        _lib.require_gpu()
+        self._L = _lib.load()
+        self.opts = opts
+        self.frame_id = 0
+        self.det_thresh = opts.conf_thresh
+        self.buffer_size = int(frame_rate / 30.0 * opts.track_buffer)
+        self.max_time_lost = self.buffer_size
+        self.NMS = True
+        if opts.kalman_format not in KALMAN_DICT or opts.kalman_format == 'naive':
+            raise NotImplementedError("kalman_format %r is not implemented on the device" % (opts.kalman_format,))
+        self.kalman = KALMAN_DICT[opts.kalman_format]()
+        if isinstance(opts.img_size, int):
+            self.model_img_size = [opts.img_size, opts.img_size]
+        elif isinstance(opts.img_size, (list, tuple)):
+            self.model_img_size = opts.img_size
+        self.debug_mode = False
+        self.cap_t = int(getattr(opts, "max_tracks", 1024))
+        self.cap_d = int(getattr(opts, "max_dets", 1024))
+        self.threads = int(getattr(opts, "tracker_threads", 0))
+        nbytes = int(self._L.y7t_tracker_state_bytes(self.cap_t, self.cap_d))
+        self._state = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        # numpy >= 2 keeps the float32 dtype of a freshly initiated mean; follow the
+        # reference as it runs in this environment
+        self._flags = 1 if int(np.__version__.split(".")[0]) >= 2 else 0
+        _lib.check(self._L.y7t_tracker_init(_lib.ptr(self._state), nbytes, self._KIND, _KIND[opts.kalman_format], self.cap_t,
+                                            self.cap_d, float(opts.conf_thresh), float(getattr(opts, "iou_thresh", 0.5)),
+                                            self.max_time_lost, self._flags, _lib.ptr(_IdCounter.tensor()),
+                                            _lib.stream_ptr()))
+        # rows 0..cap_t-1: returned tracks; the int at the start of row cap_t: their count
+        self._out = torch.zeros((self.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+        self._out_host = torch.zeros((self.cap_t + 1, 8), dtype=torch.float64).pin_memory()
+        self._count_ptr = ctypes.c_void_p(self._out.data_ptr() + self.cap_t * 8 * 8)
+        n = self._L.y7t_tracker_layout(self.cap_t, self.cap_d, None, 0)
+        offs = (ctypes.c_int64 * n)()
+        self._L.y7t_tracker_layout(self.cap_t, self.cap_d, offs, n)
+        self._layout = {self._L.y7t_tracker_field_name(i).decode(): int(offs[i]) for i in range(n)}
+        self._snap_cache = None
+        self._det_keep = None
+
+    # ------------------------------------------------------------------------------------------
+    def _launch(self, det_results):
+        if det_results is None:
+            n, dptr = -1, None
+        else:
+            if isinstance(det_results, torch.Tensor):
+                d = det_results.detach()
+                if d.device.type != "cuda" or d.dtype != torch.float32 or not d.is_contiguous():
+                    d = d.to(device="cuda", dtype=torch.float32).contiguous()
+            else:
+                d = torch.as_tensor(np.ascontiguousarray(det_results, dtype=np.float32)).cuda()
+            d = d.reshape(-1, 6)
+            self._det_keep = d  # keep the buffer alive until the kernel has consumed it
+            n, dptr = d.shape[0], _lib.ptr(d)
+            if n > self.cap_d:
+                raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (n, self.cap_d))
+        _lib.check(self._L.y7t_tracker_step(_lib.ptr(self._state), dptr, n, _lib.ptr(self._out), self.cap_t, self._count_ptr,
+                                            self.threads, _lib.stream_ptr()))
+        self.frame_id += 1
+        self._snap_cache = None
+
+    def _collect(self):
+        self._out_host.copy_(self._out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = self._out_host.numpy()
+        cnt = int(host[self.cap_t].view(np.int32)[0])
+        st = self._status()
+        if st:
+            raise _lib.Y7TError("device track pool overflow (status %d): raise opts.max_tracks / opts.max_dets" % st)
+        rows = host[:cnt]
+        return [_PoolTrack(self, r[7], r[0], r[1:5], np.float32(r[5]), np.float32(r[6])) for r in rows]
+
+    def _status(self):
+        off = self._layout["hdr_status"]
+        return int(self._state[off:off + 4].view(torch.int32).item())
+
+    def update(self, det_results, ori_img=None):
+        """(N,6) [x1,y1,x2,y2,conf,cls] tensor/ndarray -> list of tracks (basetrack.py:368-487)."""
+        self._launch(det_results)
+        return self._collect()
+
+    def update_without_detection(self, det_results=None, ori_img=None):
+        """basetrack.py:489-537: predict only."""
+        self._launch(None)
+        return self._collect()
+
+    # -- lazy host views -----------------------------------------------------------------------
+    def _snapshot(self):
+        if self._snap_cache is None:
+            Lo = self._layout
+            end = Lo["lost"] + 4 * self.cap_t
+            raw = self._state[:end].cpu().numpy()
+            T = self.cap_t
+
+            def arr(name, dtype, width):
+                return raw[Lo[name]:Lo[name] + T * width * np.dtype(dtype).itemsize].view(dtype).reshape(T, width) if width > 1 \
+                    else raw[Lo[name]:Lo[name] + T * np.dtype(dtype).itemsize].view(dtype)
+            s = {"mean": arr("mean", np.float64, 8), "cov": arr("cov", np.float64, 64), "box": arr("box", np.float32, 4),
+                 "score": arr("score", np.float32, 1), "cls": arr("cls", np.float32, 1)}
+            for k in ("tid", "start", "frame", "tsu", "state", "act", "len", "inrem", "tracked", "lost"):
+                s[k] = arr(k, np.int32, 1)
+            for k in ("hdr_frame_id", "hdr_n_tracked", "hdr_n_lost", "hdr_n_removed_total"):
+                s[k] = int(raw[Lo[k]:Lo[k] + 4].view(np.int32)[0])
+            self._snap_cache = s
+        return self._snap_cache
+
+    def _views(self, list_name, n_name):
+        s = self._snapshot()
+        out = []
+        for slot in s[list_name][:s[n_name]]:
+            m = s["mean"][slot]
+            r = m[:4].copy()
+            if self.opts.kalman_format in ('default', 'strongsort'):
+                r[2] *= r[3]
+            r[:2] -= r[2:] / 2
+            out.append(_PoolTrack(self, slot, s["tid"][slot], r, s["cls"][slot], s["score"][slot]))
+        return out
+
+    @property
+    def tracked_stracks(self):
+        return self._views("tracked", "hdr_n_tracked")
+
+    @property
+    def lost_stracks(self):
+        return self._views("lost", "hdr_n_lost")
+
+    @property
+    def removed_stracks(self):
+        """The reference keeps every removed track forever; the device pool recycles them and only
+        keeps the count."""
+        return [None] * self._snapshot()["hdr_n_removed_total"]
+
+
+def joint_stracks(tlista, tlistb):
+    exists, res = {}, []
+    for t in tlista:
+        exists[t.track_id] = 1
+        res.append(t)
+    for t in tlistb:
+        if not exists.get(t.track_id, 0):
+            exists[t.track_id] = 1
+            res.append(t)
+    return res
+
+
+def sub_stracks(tlista, tlistb):
+    stracks = {t.track_id: t for t in tlista}
+    for t in tlistb:
+        if stracks.get(t.track_id, 0):
+            del stracks[t.track_id]
+    return list(stracks.values())

@@ -1,0 +1,88 @@
+"""Kalman filters with the reference's interface (/root/reference/tracker/kalman_filter.py):
+KalmanFilter :158-411 ('default', xyah), BoTSORTKalmanFilter :414-605 ('botsort', xywh),
+NSAKalmanFilter :607-646 ('strongsort').  numpy in / numpy out like the reference; the float64
+arithmetic runs in liby7t.so's batched kernels on the device.  The 7-d NaiveKalmanFilter
+(:23-155) is off the ByteTrack/SORT hot path and is not implemented (constructing it raises)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+chi2inv95 = {1: 3.8415, 2: 5.9915, 3: 7.8147, 4: 9.4877, 5: 11.070, 6: 12.592, 7: 14.067, 8: 15.507, 9: 16.919}
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+class KalmanFilter(object):
+    KIND = 0
+
+    def __init__(self):
+        _lib.require_gpu()
+        self._L = _lib.load()
+        self._std_weight_position = 1. / 20
+        self._std_weight_velocity = 1. / 160
+
+    def initiate(self, measurement):
+        m = np.asarray(measurement)
+        flags = 1 if m.dtype == np.float32 else 0
+        z = _dev(m.reshape(1, 4))
+        mean = torch.empty((1, 8), dtype=torch.float64, device="cuda")
+        cov = torch.empty((1, 64), dtype=torch.float64, device="cuda")
+        _lib.check(self._L.y7t_kf_initiate_f64(self.KIND, _lib.ptr(z), _lib.ptr(mean), _lib.ptr(cov), 1, flags, _lib.stream_ptr()))
+        mean = mean.cpu().numpy()[0]
+        if flags:  # the reference returns a float32 mean for a float32 measurement (numpy >= 2)
+            mean = mean.astype(np.float32)
+        return mean, cov.cpu().numpy().reshape(8, 8)
+
+    def multi_predict(self, mean, covariance):
+        mean = np.asarray(mean, dtype=np.float64).reshape(-1, 8)
+        n = mean.shape[0]
+        m, c = _dev(mean), _dev(np.asarray(covariance, dtype=np.float64).reshape(n, 64))
+        _lib.check(self._L.y7t_kf_multi_predict_f64(self.KIND, _lib.ptr(m), _lib.ptr(c), None, n, _lib.stream_ptr()))
+        return m.cpu().numpy(), c.cpu().numpy().reshape(n, 8, 8)
+
+    def predict(self, mean, covariance):
+        m, c = self.multi_predict(np.asarray(mean)[None], np.asarray(covariance)[None])
+        return m[0], c[0]
+
+    def project(self, mean, covariance, confidence=.0):
+        m, c = _dev(np.asarray(mean).reshape(1, 8)), _dev(np.asarray(covariance).reshape(1, 64))
+        conf = _dev(np.asarray([confidence]))
+        pm = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+        pc = torch.empty((1, 16), dtype=torch.float64, device="cuda")
+        _lib.check(self._L.y7t_kf_project_f64(self.KIND, _lib.ptr(m), _lib.ptr(c), _lib.ptr(conf), _lib.ptr(pm), _lib.ptr(pc), 1,
+                                              _lib.stream_ptr()))
+        return pm.cpu().numpy()[0], pc.cpu().numpy().reshape(4, 4)
+
+    def update(self, mean, covariance, measurement, confidence=.0):
+        m, c = _dev(np.asarray(mean).reshape(1, 8)), _dev(np.asarray(covariance).reshape(1, 64))
+        z, conf = _dev(np.asarray(measurement).reshape(1, 4)), _dev(np.asarray([confidence]))
+        _lib.check(self._L.y7t_kf_update_batch_f64(self.KIND, _lib.ptr(m), _lib.ptr(c), _lib.ptr(z), None, _lib.ptr(conf), 1,
+                                                   _lib.stream_ptr()))
+        return m.cpu().numpy()[0], c.cpu().numpy().reshape(8, 8)
+
+    def gating_distance(self, mean, covariance, measurements, only_position=False, metric='maha'):
+        if metric != 'maha':
+            raise ValueError("only metric='maha' is implemented on the device")
+        zs = np.asarray(measurements, dtype=np.float64).reshape(-1, 4)
+        m, c, z = _dev(np.asarray(mean).reshape(1, 8)), _dev(np.asarray(covariance).reshape(1, 64)), _dev(zs)
+        out = torch.empty(zs.shape[0], dtype=torch.float64, device="cuda")
+        _lib.check(self._L.y7t_kf_gating_f64(self.KIND, _lib.ptr(m), _lib.ptr(c), _lib.ptr(z), 1, zs.shape[0],
+                                             int(bool(only_position)), _lib.ptr(out), _lib.stream_ptr()))
+        return out.cpu().numpy()
+
+
+class BoTSORTKalmanFilter(KalmanFilter):
+    KIND = 2
+
+
+class NSAKalmanFilter(KalmanFilter):
+    KIND = 3
+
+
+class NaiveKalmanFilter(object):
+    def __init__(self):
+        raise NotImplementedError("kalman_format 'naive' (7-d filter, kalman_filter.py:23-155) is outside the "
+                                  "ByteTrack/SORT hot path this package implements")
