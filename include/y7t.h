@@ -111,6 +111,62 @@ int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, in
 int y7t_tracker_layout(int cap_tracks, int cap_dets, int64_t* offsets, int max_fields);
 const char* y7t_tracker_field_name(int i);
 
+
+/* ---------------------------------------------------------------- detector (YOLOv7 forward) ---- */
+/* One op of a lowered detector graph.  The host (Python) lowers the reference's model graph
+ * (models/yolo.py:321-351 forward_once over the yaml layer list, models/yolo.py:443-520 parse_model) into a
+ * static launch list over a pre-planned NHWC fp16 activation arena: concat is eliminated (producers write
+ * channel slices), BN is folded (utils/torch_utils.py:181-201), weights are packed [Cout_pad][K_pad] fp16. */
+enum { Y7T_OP_CONV = 0, Y7T_OP_UPSAMPLE2X = 1, Y7T_OP_MAXPOOL = 2 };
+typedef struct y7t_op {
+    int32_t type;
+    int32_t in_buf, in_ld, in_coff;     /* arena buffer id, channels of that buffer, first channel of the slice */
+    int32_t H, W, Cin;                  /* input spatial size and slice channels */
+    int32_t out_buf, out_ld, out_coff, out_f32;
+    int32_t Ho, Wo, Cout, Cout_pad;
+    int32_t KH, KW, stride, pad;        /* conv / pool window */
+    int32_t K, K_pad;
+    int32_t act;                        /* 0 none, 1 SiLU, 2 LeakyReLU(0.1) */
+    int32_t reserved0, reserved1;       /* keeps the int64 fields 8-byte aligned: sizeof(y7t_op) == 112 */
+    int64_t w_off;                      /* element offset into the fp16 weight blob */
+    int64_t bias_off;                   /* element offset into the fp32 bias blob */
+} y7t_op;
+
+typedef struct y7t_det y7t_det;
+
+/* Build an executable plan.  ops/buf_offsets are HOST arrays (copied); arena/weights/bias are DEVICE memory owned by
+ * the caller.  buf_offsets[i]: byte offset of arena buffer i, laid out for max_batch images. */
+int y7t_det_create(const y7t_op* ops_host, int n_ops, const int64_t* buf_offsets_host, int n_bufs, void* arena, size_t arena_bytes,
+                   const void* weights_f16, const void* bias_f32, int max_batch, y7t_det** out);
+int y7t_det_destroy(y7t_det* det);
+
+/* models/yolo.py:345 `x = m(x)` for every layer: runs the whole launch list for B images whose input layout
+ * (y7t_input_layout) is already in arena buffer 0.  Asynchronous on `stream`. */
+int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
+
+/* TrackerLoader.__getitem__ tail (tracker/tracker_dataloader.py:83-88) + ReOrg (models/common.py:48-53):
+ * img: (B,3,H,W) float32 RGB in [0,1] (is_u8 = 0) or (B,H,W,3) uint8 BGR (is_u8 = 1: BGR->RGB and /255 fused);
+ * out: NHWC fp16 with ldout channels (16 with reorg: 12 + 4 zero; 8 without: 3 + 5 zero). */
+int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg, void* out_f16, int ldout, y7t_stream stream);
+
+/* Detect.forward decode (models/yolo.py:39-57) + non_max_suppression (utils/general.py:607-695, multi_label=False,
+ * agnostic=False) + scale_coords/clip/round (general.py:319-340, tracker/track.py:234-244), all on the device.
+ * head[l]: NHWC fp32 output of the l-th Detect 1x1 conv, [B][ny][nx][na*no].  anchors: [nl][na][2] pixels (host).
+ * letterbox: DEVICE [B][5] = gain, pad_w, pad_h, H0, W0.  dets: [B][max_det][6]; ndets: [B];
+ * cand_count (may be NULL): [B] candidates above conf_thres (> cap == overflow, caller must check).
+ * workspace: y7t_det_postprocess_workspace_bytes(B, cap). */
+size_t y7t_det_postprocess_workspace_bytes(int B, int cap);
+int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const int* ny, const int* nx, const float* strides,
+                        const float* anchors, int nl, int na, int no, int B, float conf_thres, float iou_thres, int max_det,
+                        int max_nms, int cap, const float* letterbox, float* dets, int* ndets, int* keep_idx, int* cand_count,
+                        void* workspace, size_t workspace_bytes, y7t_stream stream);
+
+/* single fused Conv+bias+act launch (layer-level parity tests, rocprof attribution); same fields as y7t_op but
+ * with raw device pointers. */
+int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B, int H, int W, int Cin, const void* w_packed, const float* bias,
+                        void* out, int out_ld, int out_coff, int out_f32, int Cout, int Cout_pad, int KH, int KW, int stride, int pad,
+                        int act, const void* zeros16, y7t_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

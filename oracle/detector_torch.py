@@ -1,0 +1,153 @@
+"""oracle/detector_torch.py -- TEST INFRASTRUCTURE ONLY.
+
+Plain-PyTorch fp32 CPU restatement of the reference's detector path, used as the floating-point oracle of the HIP
+convolution / decode / NMS kernels on machines where /root/reference does not exist:
+
+  * forward walk      /root/reference/models/yolo.py:321-351 (forward_once), layer semantics models/common.py:23-111
+                      (autopad, MP, SP, ReOrg, Concat, Conv = act(bn(conv(x)))), :262-280 (SPPCSPC), yolo.py:39-57 (Detect)
+  * NMS               utils/general.py:607-695 with torchvision.ops.nms restated by oracle/y7t_oracle.c (greedy, strict >)
+  * scale_coords      utils/general.py:319-340 and the .round() of tracker/track.py:240
+
+It consumes the same graph description (yolov7_tracker_amd.detector.graph.parse -- host logic that carries no
+arithmetic) and the same reference-style state dict as the product.  Pinned against the reference's own
+models.yolo.Model / utils.general.non_max_suppression in tests/test_detector_oracle.py (build container only).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import cnative
+
+BN_EPS = 1e-3
+
+
+def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False):
+    if fp16:
+        # storage-precision emulation of the HIP path: BN folded into the weights (utils/torch_utils.py:181-201), folded
+        # weights rounded to fp16, fp32 accumulate + fp32 bias + activation, result rounded to fp16
+        w = sd[key + ".conv.weight"].double()
+        b = sd[key + ".conv.bias"].double() if key + ".conv.bias" in sd else torch.zeros(w.shape[0], dtype=torch.float64)
+        if key + ".bn.weight" in sd:
+            scale = sd[key + ".bn.weight"].double() / torch.sqrt(sd[key + ".bn.running_var"].double() + BN_EPS)
+            w = w * scale[:, None, None, None]
+            b = (b - sd[key + ".bn.running_mean"].double()) * scale + sd[key + ".bn.bias"].double()
+        y = F.conv2d(x, w.half().float(), b.float(), stride=s, padding=p)
+        y = F.silu(y) if act == 1 else (F.leaky_relu(y, 0.1) if act == 2 else y)
+        return y.half().float()
+    w = sd[key + ".conv.weight"].float()
+    b = sd.get(key + ".conv.bias")
+    y = F.conv2d(x, w, None if b is None else b.float(), stride=s, padding=p)
+    if key + ".bn.weight" in sd:
+        y = F.batch_norm(y, sd[key + ".bn.running_mean"].float(), sd[key + ".bn.running_var"].float(), sd[key + ".bn.weight"].float(),
+                         sd[key + ".bn.bias"].float(), False, 0.0, BN_EPS)
+    if act == 1:
+        y = F.silu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.1)
+    return y
+
+
+@torch.no_grad()
+def forward(nodes, sd, img, anchors, keep=False, fp16=False):
+    """img (B,3,H,W) float32 -> (decoded (B,A,no), raw list of (B,na,ny,nx,no), {node idx: tensor} if keep).
+    fp16=True emulates the storage precision of the HIP path (fp16 weights/activations, fp32 accumulate)."""
+    vals = {0: img.float().half().float() if fp16 else img.float()}
+    raw, z = [], []
+    H = img.shape[2]
+    for n in nodes[1:]:
+        src = [vals[j] for j in n.src] if n.kind != "detect" else None
+        if n.kind == "reorg":
+            x = src[0]
+            y = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+        elif n.kind == "conv":
+            if any(j not in vals for j in n.src):
+                continue
+            y = _conv_bn_act(src[0], sd, n.wkey, n.k, n.s, n.p, n.act, fp16)
+        elif n.kind == "concat":
+            y = torch.cat(src, 1)
+        elif n.kind == "up":
+            y = F.interpolate(src[0], scale_factor=2, mode="nearest")
+        elif n.kind == "pool":
+            y = F.max_pool2d(src[0], n.k, n.s, n.p)
+        elif n.kind == "detect":
+            ex = n.extra
+            a = torch.tensor(anchors, dtype=torch.float32).view(ex["nl"], -1, 2)
+            for l, j in enumerate(n.src):
+                x = vals[j]
+                base = "model.%d" % n.layer
+                if ex["kind"] in ("IDetect", "IAuxDetect") and "%s.ia.%d.implicit" % (base, l) in sd:
+                    x = x + sd["%s.ia.%d.implicit" % (base, l)].float()
+                wd = sd["%s.m.%d.weight" % (base, l)].float()
+                x = F.conv2d(x, wd.half().float() if fp16 else wd, sd["%s.m.%d.bias" % (base, l)].float())
+                if ex["kind"] in ("IDetect", "IAuxDetect") and "%s.im.%d.implicit" % (base, l) in sd:
+                    x = x * sd["%s.im.%d.implicit" % (base, l)].float()
+                bs, _, ny, nx = x.shape
+                x = x.view(bs, ex["na"], ex["no"], ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+                raw.append(x)
+                yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
+                grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
+                y = x.sigmoid()
+                stride = H / ny
+                y[..., 0:2] = (y[..., 0:2] * 2. - 0.5 + grid) * stride
+                y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * a[l].view(1, ex["na"], 1, 1, 2)
+                z.append(y.view(bs, -1, ex["no"]))
+            continue
+        else:
+            raise NotImplementedError(n.kind)
+        vals[n.idx] = y
+    out = (torch.cat(z, 1), raw)
+    return out + (vals,) if keep else out
+
+
+def xywh2xyxy(x):
+    y = x.clone()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+@torch.no_grad()
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, nms_fn=None):
+    """utils/general.py:607-695 with classes=None, agnostic=False, multi_label=False, labels=()."""
+    nms_fn = nms_fn or (lambda b, s, t: torch.from_numpy(cnative.nms(b.numpy(), s.numpy(), t)))
+    xc = prediction[..., 4] > conf_thres
+    max_wh, max_det, max_nms = 4096, 300, 30000
+    output = [torch.zeros((0, 6))] * prediction.shape[0]
+    for xi, x in enumerate(prediction):
+        x = x[xc[xi]]
+        if not x.shape[0]:
+            continue
+        x = x.clone()
+        x[:, 5:] *= x[:, 4:5]
+        box = xywh2xyxy(x[:, :4])
+        conf, j = x[:, 5:].max(1, keepdim=True)
+        x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]
+        n = x.shape[0]
+        if not n:
+            continue
+        elif n > max_nms:
+            x = x[x[:, 4].argsort(descending=True)[:max_nms]]
+        c = x[:, 5:6] * max_wh
+        boxes, scores = x[:, :4] + c, x[:, 4]
+        i = nms_fn(boxes, scores, iou_thres)
+        if i.shape[0] > max_det:
+            i = i[:max_det]
+        output[xi] = x[i]
+    return output
+
+
+def scale_coords_round(img1_shape, coords, img0_shape):
+    """scale_coords (general.py:319-340) followed by .round() (tracker/track.py:240); coords (n,4) float32 tensor"""
+    coords = coords.clone()
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    coords[:, 0].clamp_(0, img0_shape[1])
+    coords[:, 1].clamp_(0, img0_shape[0])
+    coords[:, 2].clamp_(0, img0_shape[1])
+    coords[:, 3].clamp_(0, img0_shape[0])
+    return coords.round()

@@ -1,0 +1,167 @@
+"""GPU parity tests of the detector half of the hot path (through the C ABI): MFMA implicit-GEMM conv per layer, the
+whole yolov7-tiny / yolov7-w6 forward, decode + NMS.  Oracle: oracle/detector_torch.py (plain torch fp32 on the CPU,
+pinned against the reference's models.yolo.Model in tests/test_detector_oracle.py).
+Stated tolerances (fp16 activations / fp32 accumulate vs the fp32 oracle): see each test."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from yolov7_tracker_amd import _lib
+    _lib.require_gpu()
+    return _lib.load()
+
+
+def pack_w(W, cin_pad, cout_pad):
+    cout, cin, k, _ = W.shape
+    K = k * k * cin_pad
+    K_pad = (K + 63) // 64 * 64
+    Wt = np.zeros((cout, k, k, cin_pad), np.float32)
+    Wt[..., :cin] = W.transpose(0, 2, 3, 1)
+    blk = np.zeros((cout_pad, K_pad), np.float16)
+    blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
+    return blk
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, act, in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 20, 20, 64, 64, 1, 1, 1, 64, 0, 64, 0, 0),
+    (2, 17, 23, 64, 128, 3, 1, 1, 64, 0, 128, 0, 0),
+    (1, 40, 40, 128, 256, 3, 2, 1, 128, 0, 256, 0, 0),
+    (2, 32, 32, 16, 64, 3, 1, 1, 16, 0, 64, 0, 0),          # stem-like (K = 144)
+    (1, 24, 24, 96, 192, 1, 1, 2, 256, 64, 384, 192, 0),    # slices of wider buffers, LeakyReLU
+    (1, 16, 16, 256, 45, 1, 1, 0, 256, 0, 45, 0, 1),        # Detect head: fp32 out, Cout not a multiple of 4
+    (3, 9, 9, 512, 512, 3, 1, 1, 512, 0, 512, 0, 0),        # small map, deep K
+    (1, 130, 130, 32, 64, 3, 2, 1, 32, 0, 64, 0, 0),        # M not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_layer_matches_torch_fp32(L, case):
+    from yolov7_tracker_amd import _lib
+    B, H, W, Cin, Cout, k, s, act, in_ld, in_coff, out_ld, out_coff, out_f32 = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
+    Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = rng.normal(0, 0.5, Cout).astype(np.float32)
+    cout_pad = (Cout + 63) // 64 * 64
+    wp = pack_w(Wt, Cin, cout_pad)
+    bp = np.zeros(cout_pad, np.float32); bp[:Cout] = bias
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    xd, wd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(wp).cuda(), torch.from_numpy(bp).cuda()
+    out = torch.full((B, Ho, Wo, out_ld), 7.0, dtype=torch.float32 if out_f32 else torch.float16, device="cuda")
+    zeros = torch.zeros(128, dtype=torch.float16, device="cuda")
+    _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(xd), in_ld, in_coff, B, H, W, Cin, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), out_ld, out_coff,
+                                     out_f32, Cout, cout_pad, k, k, s, pad, act, _lib.ptr(zeros), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    xs = torch.from_numpy(x[..., in_coff:in_coff + Cin].astype(np.float32)).permute(0, 3, 1, 2)
+    ref = F.conv2d(xs, torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias), stride=s, padding=pad)
+    ref = F.silu(ref) if act == 1 else (F.leaky_relu(ref, 0.1) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    g = got[..., out_coff:out_coff + Cout]
+    # fp16 inputs are exact in both; fp32 accumulate; the only error is the final fp16 store (rel 2^-11) + sum order
+    np.testing.assert_allclose(g, ref, rtol=6e-4, atol=3e-4)
+    # nothing outside the output slice may be touched
+    mask = np.ones(out_ld, bool); mask[out_coff:out_coff + Cout] = False
+    assert np.all(got[..., mask] == 7.0)
+
+
+def build(name, nc, hw, B, seed=0):
+    from yolov7_tracker_amd.detector import arch, model
+    return model.Detector(arch.ARCHS[name](nc), None, img_size=hw, max_batch=B, seed=seed)
+
+
+@pytest.mark.parametrize("name,nc,hw,B", [("yolov7-tiny", 80, (128, 192), 2), ("yolov7-w6", 10, (256, 320), 2)])
+def test_whole_network_heads_match_oracle(name, nc, hw, B):
+    from oracle import detector_torch as dt
+    det = build(name, nc, hw, B)
+    img = torch.rand((B, 3) + hw, generator=torch.Generator().manual_seed(1))
+    out = det(img)[0]
+    raw = [r.cpu() for r in out.raw()]
+    dec, raw_ref = dt.forward(det.nodes, det._sd, img, det.spec["anchors"])
+    _, raw_q = dt.forward(det.nodes, det._sd, img, det.spec["anchors"], fp16=True)
+    for l, (a, b, q) in enumerate(zip(raw, raw_ref, raw_q)):
+        assert a.shape == b.shape
+        scale = b.std().item()
+        # (1) against the oracle run at the SAME storage precision (fp16 weights/activations, fp32 accumulate): only the
+        #     summation order differs, i.e. rare one-ulp fp16 flips -- which a randomly initialised (chaotic) network
+        #     amplifies ~1.1-1.3x per layer (scripts/debug_layers.py prints the per-layer growth from 1e-7 at layer 0)
+        eq = (a - q).abs()
+        assert eq.mean().item() < 3e-2 * scale, (l, eq.mean().item(), scale)
+        assert eq.max().item() < 0.5 * scale, (l, eq.max().item(), scale)
+        # (2) against the fp32 oracle: the stated fp16-vs-fp32 tolerance on RAW LOGITS of a random-weight net -- mean below 8 % of
+        #     the logit spread (measured: 0.5 % tiny, 1.5-4 % w6); the layer-level test above is the tight one (6e-4)
+        err = (a - b).abs()
+        assert err.mean().item() < 0.08 * scale, (l, err.mean().item(), scale)
+        assert err.max().item() < 1.2 * scale, (l, err.max().item(), scale)
+        print("level", l, "vs fp16-oracle mean/max %.2e %.2e   vs fp32-oracle mean/max %.2e %.2e   (std %.2f)" % (
+            eq.mean().item(), eq.max().item(), err.mean().item(), err.max().item(), scale))
+
+
+def test_u8_bgr_input_equals_float_input():
+    det = build("yolov7-tiny", 80, (128, 128), 1)
+    frame = torch.randint(0, 256, (1, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    a = [r.clone() for r in det(frame.cuda())[0].raw()]
+    f = (frame[..., [2, 1, 0]].permute(0, 3, 1, 2).float() / 255.0).contiguous()   # tracker_dataloader.py:83-88
+    b = det(f)[0].raw()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_decode_nms_matches_oracle():
+    """plant head logits, run the device decode+NMS chain, compare with the oracle's non_max_suppression +
+    scale_coords + round on the decoded tensor of the SAME logits."""
+    from oracle import cnative, detector_torch as dt
+    det = build("yolov7-w6", 10, (256, 320), 2)
+    g = torch.Generator().manual_seed(3)
+    out = det(torch.rand((2, 3, 256, 320), generator=g))[0]
+    p = det.plan
+    for l in range(len(p.heads)):
+        t = det.head_tensor(l, 2)
+        v = torch.randn(t.shape, generator=g) * 1.5
+        v.view(2, t.shape[1], t.shape[2], 3, 15)[..., 4] -= 3.0     # few objectness hits
+        t.copy_(v.cuda())
+    dets, nd = det.postprocess(out, 0.01, 0.45, ori_shapes=[(200, 300), (256, 320)])
+    torch.cuda.synchronize()
+    det.check_overflow()
+    dec = out.decoded().cpu()
+    ref = dt.non_max_suppression(dec, 0.01, 0.45)
+    nd = nd.cpu().numpy()
+    for b, shp in enumerate([(200, 300), (256, 320)]):
+        r = ref[b]
+        assert nd[b] == len(r) and len(r) > 20
+        d = dets[b, :nd[b]].cpu()
+        rr = r.clone()
+        rr[:, :4] = dt.scale_coords_round((256, 320), r[:, :4], shp)
+        assert torch.equal(d[:, 5], rr[:, 5])
+        np.testing.assert_allclose(d[:, 4].numpy(), rr[:, 4].numpy(), rtol=1e-5, atol=1e-6)
+        assert (d[:, :4] - rr[:, :4]).abs().max().item() <= 1.0          # |dcoord| <= 1 px after round
+        assert ((d[:, :4] - rr[:, :4]).abs() > 0).float().mean().item() < 0.02
+    # exact greedy semantics on identical inputs: oracle NMS over the device's own candidates keeps the same set
+    cap = det.max_cand
+    ws = p.ws
+    B = det.max_batch
+    cbox = ws[:B * cap * 16].view(torch.float32).view(B, cap, 4).cpu().numpy()
+    off = (B * cap * 16 + 255) // 256 * 256
+    cscore = ws[off:off + B * cap * 4].view(torch.float32).view(B, cap).cpu().numpy()
+    off2 = off + (B * cap * 4 + 255) // 256 * 256
+    ccls = ws[off2:off2 + B * cap * 4].view(torch.float32).view(B, cap).cpu().numpy()
+    off3 = off2 + (B * cap * 4 + 255) // 256 * 256
+    cidx = ws[off3:off3 + B * cap * 4].view(torch.int32).view(B, cap).cpu().numpy()
+    cnt = p.cand.cpu().numpy()
+    keep = p.keep.cpu().numpy()
+    for b in range(2):
+        n = cnt[b]
+        order = np.lexsort((cidx[b, :n], -cscore[b, :n].astype(np.float64)))
+        boxes = (cbox[b, :n] + ccls[b, :n, None] * np.float32(4096)).astype(np.float32)[order]
+        k = cnative.nms(boxes, cscore[b, :n][order], 0.45)[:300]
+        np.testing.assert_array_equal(order[k], keep[b, :nd[b]])

@@ -1,0 +1,47 @@
+// y7t_det.h -- internal types shared by the detector translation units (conv, pooling, post-process, plan executor)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { Y7T_ACT_NONE = 0, Y7T_ACT_SILU = 1, Y7T_ACT_LEAKY = 2 };
+
+struct Y7TConvArgs {
+    const _Float16* in;  // NHWC fp16 buffer holding the input slice
+    int ldin, cin_off;   // channels of that buffer, first channel of the slice
+    int B, H, W, Cin;    // input batch / spatial size / channels of the slice (multiple of 8)
+    const _Float16* w;   // packed weights [Cout_pad][K_pad], k = (kh*KW + kw)*Cin + ci
+    const float* bias;   // [Cout_pad]
+    void* out;           // NHWC buffer (fp16, or fp32 when out_f32)
+    int ldout, cout_off, out_f32;
+    int Ho, Wo, Cout, Cout_pad;
+    int KH, KW, stride, pad;
+    int K, K_pad;        // K = KH*KW*Cin, K_pad = round_up(K, 64)
+    int M;               // B*Ho*Wo
+    int act;
+    const _Float16* zeros;  // >= 16 bytes of zeros (padding taps read from here)
+};
+
+int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);
+
+int y7t_upsample_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, _Float16* out, int ldout, int cout_off, hipStream_t s);
+int y7t_maxpool_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, int k, int st, int pd, _Float16* out, int ldout,
+                       int cout_off, hipStream_t s);
+
+// decode + NMS chain (y7t_post.hip)
+struct Y7TPostArgs {
+    const float* head[4];   // per level NHWC fp32 [B][ny][nx][na*no]
+    int ny[4], nx[4];
+    float stride[4];
+    float anchors[24];      // [nl][na][2] in pixels
+    int nl, na, no, B;
+    float conf_thres, iou_thres;
+    int max_det, max_nms, cap;
+    const float* letterbox_dev;  // [B][5] gain, padw, padh, H0, W0 (device)
+    float* dets;            // [B][max_det][6]
+    int* ndets;             // [B]
+    int* keep_idx;          // [B][max_det] candidate slot of each kept detection
+    int* count_out;         // [B] number of candidates found (> cap means overflow) or null
+    void* ws; size_t ws_bytes;
+};
+size_t y7t_post_ws_bytes(int B, int cap);
+int y7t_post_run(const Y7TPostArgs& a, hipStream_t s);

@@ -1,0 +1,108 @@
+// y7t_detector.hip -- plan executor + C ABI of the detector half of the hot path.
+// The launch list replaces the Python module walk of /root/reference/models/yolo.py:321-351 (forward_once): the graph
+// is lowered once on the host, then every frame batch is 110-odd back-to-back kernel launches with no host logic,
+// no allocation and no synchronisation in between (capturable in a hipGraph).
+#include "y7t_common.h"
+#include "y7t_det.h"
+#include <string.h>
+#include <vector>
+
+static_assert(sizeof(y7t_op) == 112, "y7t_op layout must match detector/graph.py OP_DTYPE");
+
+struct y7t_det {
+    std::vector<y7t_op> ops;
+    std::vector<int64_t> bufs;
+    char* arena; size_t arena_bytes;
+    const _Float16* w; const float* bias;
+    _Float16* zeros;
+    int max_batch;
+};
+
+extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs, int n_bufs, void* arena, size_t arena_bytes,
+                              const void* w, const void* bias, int max_batch, y7t_det** out) {
+    Y7T_ARG_CHECK(ops && n_ops > 0 && bufs && n_bufs > 0 && arena && w && bias && out && max_batch > 0);
+    for (int i = 0; i < n_ops; ++i) {
+        Y7T_ARG_CHECK(ops[i].in_buf >= 0 && ops[i].in_buf < n_bufs && ops[i].out_buf >= 0 && ops[i].out_buf < n_bufs);
+        Y7T_ARG_CHECK(ops[i].type >= Y7T_OP_CONV && ops[i].type <= Y7T_OP_MAXPOOL);
+    }
+    for (int i = 0; i < n_bufs; ++i) Y7T_ARG_CHECK(bufs[i] >= 0 && (size_t)bufs[i] < arena_bytes && bufs[i] % 256 == 0);
+    y7t_det* d = new y7t_det();
+    d->ops.assign(ops, ops + n_ops);
+    d->bufs.assign(bufs, bufs + n_bufs);
+    d->arena = (char*)arena; d->arena_bytes = arena_bytes;
+    d->w = (const _Float16*)w; d->bias = (const float*)bias; d->max_batch = max_batch;
+    d->zeros = nullptr;
+    if (hipMalloc((void**)&d->zeros, 256) != hipSuccess || hipMemset(d->zeros, 0, 256) != hipSuccess) {
+        delete d;
+        y7t_set_error("y7t_det_create: cannot allocate the zero page");
+        return Y7T_E_HIP;
+    }
+    *out = d;
+    return 0;
+}
+
+extern "C" int y7t_det_destroy(y7t_det* d) {
+    if (!d) return 0;
+    if (d->zeros) (void)hipFree(d->zeros);
+    delete d;
+    return 0;
+}
+
+extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) {
+    Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    for (const y7t_op& op : d->ops) {
+        const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);
+        void* outp = d->arena + d->bufs[op.out_buf];
+        int rc = 0;
+        if (op.type == Y7T_OP_CONV) {
+            Y7TConvArgs a;
+            a.in = in; a.ldin = op.in_ld; a.cin_off = op.in_coff; a.B = B; a.H = op.H; a.W = op.W; a.Cin = op.Cin;
+            a.w = d->w + op.w_off; a.bias = d->bias + op.bias_off;
+            a.out = outp; a.ldout = op.out_ld; a.cout_off = op.out_coff; a.out_f32 = op.out_f32;
+            a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.Cout_pad = op.Cout_pad;
+            a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
+            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros;
+            rc = y7t_conv_launch(a, s);
+        } else if (op.type == Y7T_OP_UPSAMPLE2X) {
+            rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
+        } else {
+            rc = y7t_maxpool_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, op.KH, op.stride, op.pad, (_Float16*)outp, op.out_ld,
+                                    op.out_coff, s);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" size_t y7t_det_postprocess_workspace_bytes(int B, int cap) { return (B > 0 && cap > 0) ? y7t_post_ws_bytes(B, cap) : 0; }
+
+extern "C" int y7t_det_postprocess(const float* const* head, const int* ny, const int* nx, const float* strides, const float* anchors, int nl,
+                                   int na, int no, int B, float conf_thres, float iou_thres, int max_det, int max_nms, int cap,
+                                   const float* letterbox, float* dets, int* ndets, int* keep_idx, int* cand_count, void* ws, size_t ws_bytes,
+                                   y7t_stream stream) {
+    Y7T_ARG_CHECK(head && ny && nx && strides && anchors && letterbox && dets && ndets && keep_idx && ws);
+    Y7T_ARG_CHECK(nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && B >= 1 && cap >= 64 && max_det >= 1 && max_nms >= 1);
+    Y7TPostArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < nl; ++l) { a.head[l] = head[l]; a.ny[l] = ny[l]; a.nx[l] = nx[l]; a.stride[l] = strides[l]; }
+    for (int i = 0; i < nl * na * 2; ++i) a.anchors[i] = anchors[i];
+    a.nl = nl; a.na = na; a.no = no; a.B = B; a.conf_thres = conf_thres; a.iou_thres = iou_thres;
+    a.max_det = max_det; a.max_nms = max_nms < cap ? max_nms : cap; a.cap = cap;
+    a.letterbox_dev = letterbox; a.dets = dets; a.ndets = ndets; a.keep_idx = keep_idx; a.count_out = cand_count;
+    a.ws = ws; a.ws_bytes = ws_bytes;
+    return y7t_post_run(a, (hipStream_t)stream);
+}
+
+extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B, int H, int W, int Cin, const void* w, const float* bias, void* out,
+                                   int out_ld, int out_coff, int out_f32, int Cout, int Cout_pad, int KH, int KW, int stride, int pad, int act,
+                                   const void* zeros16, y7t_stream stream) {
+    Y7T_ARG_CHECK(in && w && bias && out && zeros16 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && stride > 0);
+    Y7TConvArgs a;
+    a.in = (const _Float16*)in; a.ldin = in_ld; a.cin_off = in_coff; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
+    a.w = (const _Float16*)w; a.bias = bias; a.out = out; a.ldout = out_ld; a.cout_off = out_coff; a.out_f32 = out_f32;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
+    a.Cout = Cout; a.Cout_pad = Cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act; a.zeros = (const _Float16*)zeros16;
+    return y7t_conv_launch(a, (hipStream_t)stream);
+}

@@ -1,0 +1,369 @@
+// y7t_post.hip -- the HBM-bound kernels around the convolutions:
+//   * input layout kernels: (B,3,H,W) fp32 RGB in [0,1]  or  (B,H,W,3) uint8 BGR  ->  NHWC fp16, optionally fused with
+//     ReOrg (space-to-depth; /root/reference/models/common.py:48-53) -- tracker_dataloader.py:83-88 semantics (/255, BGR->RGB)
+//   * nearest x2 upsample (nn.Upsample(None, 2, 'nearest'), cfg/deploy/yolov7-w6.yaml:75,89,103) into a concat slice
+//   * max-pool k x k (SPPCSPC's 5/9/13 as a 5-cascade, models/common.py:271-278; MP 2x2/s2, SP, common.py:30-45)
+//   * Detect decode (models/yolo.py:39-57) fused with the candidate filter of non_max_suppression
+//     (utils/general.py:607-665), rank sort by confidence, class-offset bitmask NMS with torchvision's greedy
+//     semantics (general.py:676-682), top-300, scale_coords + clip + round (general.py:319-340, tracker/track.py:234-244)
+#include "y7t_common.h"
+#include "y7t_det.h"
+#include <string.h>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+
+// ------------------------------------------------------------------------------------------------ input layout
+// out[b][y][x][c]: reorg: c = g*3 + ch, g = (row parity) + 2*(col parity)  (cat order of ReOrg.forward), padded to ldout
+template <bool U8>
+__global__ void __launch_bounds__(256) k_input_layout(const void* __restrict__ img, int B, int H, int W, int reorg, half_t* __restrict__ out,
+                                                      int ldout) {
+    const int Ho = reorg ? H / 2 : H, Wo = reorg ? W / 2 : W;
+    const long long tot = (long long)B * Ho * Wo;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < tot; p += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(p / ((long long)Ho * Wo));
+        const int rem = (int)(p - (long long)b * Ho * Wo);
+        const int yo = rem / Wo, xo = rem - yo * Wo;
+        half_t v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = (half_t)0.f;
+        const int ng = reorg ? 4 : 1;
+        for (int g = 0; g < ng; ++g) {
+            const int y = reorg ? 2 * yo + (g & 1) : yo, x = reorg ? 2 * xo + (g >> 1) : xo;
+            for (int ch = 0; ch < 3; ++ch) {
+                float f;
+                if (U8) f = (float)((const uint8_t*)img)[(((size_t)b * H + y) * W + x) * 3 + (2 - ch)] / 255.0f;  // BGR -> RGB, /255
+                else f = ((const float*)img)[(((size_t)b * 3 + ch) * H + y) * W + x];
+                v[g * 3 + ch] = (half_t)f;
+            }
+        }
+        half_t* o = out + (size_t)p * ldout;
+        for (int c = 0; c < ldout; c += 8) *(half8*)(o + c) = *(half8*)(v + c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ upsample / pool
+// out[b][y][x][coff + c] = in[b][y/2][x/2][cin_off + c]; 8 channels (16 B) per thread
+__global__ void __launch_bounds__(256) k_upsample2x(const half_t* __restrict__ in, int ldin, int cin_off, int B, int H, int W, int C,
+                                                    half_t* __restrict__ out, int ldout, int cout_off) {
+    const int C8 = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const long long tot = (long long)B * Ho * Wo * C8;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        const long long p = t / C8;
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
+        const half8 v = *(const half8*)(in + (((size_t)b * H + (yo >> 1)) * W + (xo >> 1)) * ldin + cin_off + c8 * 8);
+        *(half8*)(out + (size_t)p * ldout + cout_off + c8 * 8) = v;
+    }
+}
+
+// max-pool k x k, stride s, padding pd (-inf padding like nn.MaxPool2d)
+__global__ void __launch_bounds__(256) k_maxpool(const half_t* __restrict__ in, int ldin, int cin_off, int B, int H, int W, int C, int k, int s,
+                                                 int pd, half_t* __restrict__ out, int ldout, int cout_off, int Ho, int Wo) {
+    const int C8 = C / 8;
+    const long long tot = (long long)B * Ho * Wo * C8;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        const long long p = t / C8;
+        const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)(-65504.f);
+        bool any = false;
+        for (int dy = 0; dy < k; ++dy) {
+            const int y = yo * s - pd + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int x = xo * s - pd + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const half8 v = *(const half8*)(in + (((size_t)b * H + y) * W + x) * ldin + cin_off + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = (any && m[e] > v[e]) ? m[e] : v[e];
+                any = true;
+            }
+        }
+        *(half8*)(out + (size_t)p * ldout + cout_off + c8 * 8) = m;
+    }
+}
+
+int y7t_upsample_launch(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, half_t* out, int ldout, int cout_off, hipStream_t s) {
+    if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("upsample: channel alignment"); return Y7T_E_ARG; }
+    const long long tot = (long long)B * 4 * H * W * (C / 8);
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_upsample2x, dim3(blocks), dim3(256), 0, s, in, ldin, cin_off, B, H, W, C, out, ldout, cout_off);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+int y7t_maxpool_launch(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, int k, int st, int pd, half_t* out, int ldout,
+                       int cout_off, hipStream_t s) {
+    if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("maxpool: channel alignment"); return Y7T_E_ARG; }
+    const int Ho = (H + 2 * pd - k) / st + 1, Wo = (W + 2 * pd - k) / st + 1;
+    const long long tot = (long long)B * Ho * Wo * (C / 8);
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_maxpool, dim3(blocks), dim3(256), 0, s, in, ldin, cin_off, B, H, W, C, k, st, pd, out, ldout, cout_off, Ho, Wo);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg, void* out_f16, int ldout, y7t_stream stream) {
+    Y7T_ARG_CHECK(img && out_f16 && B > 0 && H > 0 && W > 0);
+    Y7T_ARG_CHECK(ldout == 8 || ldout == 16);
+    Y7T_ARG_CHECK(reorg ? (ldout == 16 && H % 2 == 0 && W % 2 == 0) : 1);
+    const long long tot = (long long)B * (reorg ? H / 2 : H) * (reorg ? W / 2 : W);
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (is_u8) hipLaunchKernelGGL(k_input_layout<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, B, H, W, reorg, (half_t*)out_f16, ldout);
+    else hipLaunchKernelGGL(k_input_layout<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, B, H, W, reorg, (half_t*)out_f16, ldout);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ decode + filter
+struct DecodeLevel {
+    const float* p;   // head conv output, NHWC fp32: [B][ny][nx][na*no]
+    int ny, nx, row0; // row0: index of this level's first row in the reference's (B, A, no) ordering
+    float stride;
+    float aw[3], ah[3];
+};
+struct DecodeArgs {
+    DecodeLevel lv[4];
+    int nl, na, no, B;
+    float conf_thres;
+    int cap;              // candidate capacity per image
+    float* cbox;          // [B][cap][4] xyxy
+    float* cscore;        // [B][cap]
+    float* ccls;          // [B][cap]
+    int* cidx;            // [B][cap] row index (tie-break / parity checks)
+    int* count;           // [B] candidates found (may exceed cap -> overflow)
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_decode_filter(const DecodeArgs a, int level) {
+    const DecodeLevel L = a.lv[level];
+    const int per_img = a.na * L.ny * L.nx;
+    const long long tot = (long long)a.B * per_img;
+    const int nc = a.no - 5;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / per_img), r = (int)(t - (long long)b * per_img);
+        // thread order: x fastest, then anchor, then y -> neighbouring threads read neighbouring NHWC rows
+        const int x = r % L.nx, an = (r / L.nx) % a.na, y = r / (L.nx * a.na);
+        const float* p = L.p + ((((size_t)b * L.ny + y) * L.nx + x) * a.na + an) * a.no;
+        const float obj = sigmoidf_(p[4]);
+        if (!(obj > a.conf_thres)) continue;                  // xc = prediction[..., 4] > conf_thres
+        float best = -1.f; int bj = 0;
+        for (int c = 0; c < nc; ++c) {                        // x[:, 5:] *= x[:, 4:5]; conf, j = x[:, 5:].max(1)
+            const float s = sigmoidf_(p[5 + c]) * obj;
+            if (s > best) { best = s; bj = c; }
+        }
+        if (!(best > a.conf_thres)) continue;
+        const float sx = sigmoidf_(p[0]), sy = sigmoidf_(p[1]), sw = sigmoidf_(p[2]), sh = sigmoidf_(p[3]);
+        const float cx = (sx * 2.f - 0.5f + (float)x) * L.stride, cy = (sy * 2.f - 0.5f + (float)y) * L.stride;
+        const float w = (sw * 2.f) * (sw * 2.f) * L.aw[an], h = (sh * 2.f) * (sh * 2.f) * L.ah[an];
+        const int slot = atomicAdd(a.count + b, 1);
+        if (slot >= a.cap) continue;
+        float* bo = a.cbox + ((size_t)b * a.cap + slot) * 4;
+        bo[0] = cx - w / 2; bo[1] = cy - h / 2; bo[2] = cx + w / 2; bo[3] = cy + h / 2;   // xywh2xyxy
+        a.cscore[(size_t)b * a.cap + slot] = best;
+        a.ccls[(size_t)b * a.cap + slot] = (float)bj;
+        a.cidx[(size_t)b * a.cap + slot] = L.row0 + (an * L.ny + y) * L.nx + x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rank sort
+// rank by (score desc, row index asc); scatter class-offset boxes (x[:, :4] + cls*4096) into sorted order
+__global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbox, const float* __restrict__ cscore, const float* __restrict__ ccls,
+                                                   const int* __restrict__ cidx, const int* __restrict__ count, int cap, int max_nms,
+                                                   float* __restrict__ sbox, int* __restrict__ sorder, int* __restrict__ nsorted) {
+    __shared__ float ss[256];
+    __shared__ int si[256];
+    const int b = blockIdx.y;
+    int n = count[b]; if (n > cap) n = cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= n) return;
+    const float* sc = cscore + (size_t)b * cap;
+    const int* ix = cidx + (size_t)b * cap;
+    const float my_s = i < n ? sc[i] : 0.f;
+    const int my_i = i < n ? ix[i] : 0;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        ss[threadIdx.x] = j < n ? sc[j] : -1.f;
+        si[threadIdx.x] = j < n ? ix[j] : 0x7fffffff;
+        __syncthreads();
+        const int lim = (n - base) < 256 ? (n - base) : 256;
+        for (int t = 0; t < lim; ++t) rank += (ss[t] > my_s) || (ss[t] == my_s && si[t] < my_i);
+    }
+    if (i < n && rank < max_nms) {
+        const float off = ccls[(size_t)b * cap + i] * 4096.f;
+        const float* bo = cbox + ((size_t)b * cap + i) * 4;
+        float* so = sbox + ((size_t)b * cap + rank) * 4;
+        so[0] = bo[0] + off; so[1] = bo[1] + off; so[2] = bo[2] + off; so[3] = bo[3] + off;
+        sorder[(size_t)b * cap + rank] = i;
+    }
+    if (i == 0) nsorted[b] = n < max_nms ? n : max_nms;
+}
+
+// ------------------------------------------------------------------------------------------------ NMS mask
+// mask[b][i][tj] bit jj: sorted box (tj*64+jj) has IoU > thr with sorted box i (only j > i matter)
+__global__ void __launch_bounds__(64) k_nms_mask(const float* __restrict__ sbox, const int* __restrict__ nsorted, int cap, float thr,
+                                                 unsigned long long* __restrict__ mask, int words) {
+    __shared__ float bx[64][4];
+    const int b = blockIdx.y;
+    const int n = nsorted[b];
+    const int nt = (n + 63) / 64;
+    const long long pairs = (long long)nt * (nt + 1) / 2;
+    const float* sb = sbox + (size_t)b * cap * 4;
+    for (long long pr = blockIdx.x; pr < pairs; pr += gridDim.x) {
+        // unrank (ti <= tj) from the linear pair index, row-major over the upper triangle
+        int ti = (int)((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)pr)) * 0.5);
+        while ((long long)ti * nt - (long long)ti * (ti - 1) / 2 > pr) --ti;
+        while ((long long)(ti + 1) * nt - (long long)(ti + 1) * ti / 2 <= pr) ++ti;
+        const int tj = ti + (int)(pr - ((long long)ti * nt - (long long)ti * (ti - 1) / 2));
+        __syncthreads();
+        const int j = tj * 64 + threadIdx.x;
+        if (j < n) { bx[threadIdx.x][0] = sb[4 * (size_t)j]; bx[threadIdx.x][1] = sb[4 * (size_t)j + 1]; bx[threadIdx.x][2] = sb[4 * (size_t)j + 2]; bx[threadIdx.x][3] = sb[4 * (size_t)j + 3]; }
+        __syncthreads();
+        const int i = ti * 64 + threadIdx.x;
+        if (i >= n) continue;
+        const float x1 = sb[4 * (size_t)i], y1 = sb[4 * (size_t)i + 1], x2 = sb[4 * (size_t)i + 2], y2 = sb[4 * (size_t)i + 3];
+        const float ai = (x2 - x1) * (y2 - y1);
+        unsigned long long bits = 0;
+        const int lim = (n - tj * 64) < 64 ? (n - tj * 64) : 64;
+        for (int t = 0; t < lim; ++t) {
+            if (tj * 64 + t <= i) continue;
+            const float xx1 = fmaxf(x1, bx[t][0]), yy1 = fmaxf(y1, bx[t][1]), xx2 = fminf(x2, bx[t][2]), yy2 = fminf(y2, bx[t][3]);
+            const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+            const float inter = w * h;
+            const float aj = (bx[t][2] - bx[t][0]) * (bx[t][3] - bx[t][1]);
+            const float ovr = inter / (ai + aj - inter);
+            if (ovr > thr) bits |= 1ull << t;
+        }
+        mask[((size_t)b * cap + i) * words + tj] = bits;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NMS scan + finalize
+// one wave per image: greedy scan in score order, stops after max_det keeps; then writes the (n,6) rows
+// [x1,y1,x2,y2 (scale_coords, clip, round), conf, cls] in score order (== x[i] of the reference).
+__global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* __restrict__ mask, int words, const int* __restrict__ nsorted,
+                                                 const int* __restrict__ sorder, const float* __restrict__ cbox, const float* __restrict__ cscore,
+                                                 const float* __restrict__ ccls, int cap, int max_det, const float* __restrict__ lb /*[B][5] gain,padw,padh,H0,W0*/,
+                                                 float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/) {
+    extern __shared__ unsigned long long removed[];   // words
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = nsorted[b];
+    const int nw = (n + 63) / 64;
+    for (int w = lane; w < nw; w += 64) removed[w] = 0ull;
+    __syncthreads();
+    const unsigned long long* mk = mask + (size_t)b * cap * words;
+    const int* so = sorder + (size_t)b * cap;
+    int nkeep = 0;
+    for (int c = 0; c < nw && nkeep < max_det; ++c) {
+        const int i = c * 64 + lane;
+        const unsigned long long diag = (i < n) ? mk[(size_t)i * words + c] : 0ull;
+        unsigned long long rem = removed[c];
+        unsigned long long kept = 0ull;
+        const int lim = (n - c * 64) < 64 ? (n - c * 64) : 64;
+        for (int t = 0; t < lim; ++t) {           // uniform across the wave
+            if (!((rem >> t) & 1ull)) {
+                if (nkeep < max_det) {
+                    kept |= 1ull << t;
+                    ++nkeep;
+                    rem |= __shfl(diag, t);
+                } else break;
+            }
+        }
+        // record kept candidates of this chunk (lane t writes its own)
+        if ((kept >> lane) & 1ull) {
+            const int pos = (nkeep - __popcll(kept)) + __popcll(kept & ((1ull << lane) - 1ull));
+            keep_idx[(size_t)b * max_det + pos] = i;
+        }
+        // OR the kept rows into the removed words of later chunks
+        for (int w = c + 1 + lane; w < nw; w += 64) {
+            unsigned long long acc = removed[w];
+            unsigned long long kk = kept;
+            while (kk) {
+                const int t = __ffsll((long long)kk) - 1;
+                kk &= kk - 1;
+                acc |= mk[(size_t)(c * 64 + t) * words + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane == 0) ndets[b] = nkeep;
+    const float gain = lb[b * 5 + 0], padw = lb[b * 5 + 1], padh = lb[b * 5 + 2], H0 = lb[b * 5 + 3], W0 = lb[b * 5 + 4];
+    for (int k = lane; k < nkeep; k += 64) {
+        const int i = so[keep_idx[(size_t)b * max_det + k]];
+        const float* bo = cbox + ((size_t)b * cap + i) * 4;
+        float x1 = (bo[0] - padw) / gain, y1 = (bo[1] - padh) / gain, x2 = (bo[2] - padw) / gain, y2 = (bo[3] - padh) / gain;
+        x1 = fminf(fmaxf(x1, 0.f), W0); x2 = fminf(fmaxf(x2, 0.f), W0);
+        y1 = fminf(fmaxf(y1, 0.f), H0); y2 = fminf(fmaxf(y2, 0.f), H0);
+        float* o = dets + ((size_t)b * max_det + k) * 6;
+        o[0] = rintf(x1); o[1] = rintf(y1); o[2] = rintf(x2); o[3] = rintf(y2);
+        o[4] = cscore[(size_t)b * cap + i]; o[5] = ccls[(size_t)b * cap + i];
+        keep_idx[(size_t)b * max_det + k] = i;   // leave the candidate index for callers that want raw boxes
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+size_t y7t_post_ws_bytes(int B, int cap) {
+    const size_t words = (size_t)(cap + 63) / 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { o = (o + bytes + 255) & ~(size_t)255; };
+    take((size_t)B * cap * 16); take((size_t)B * cap * 4); take((size_t)B * cap * 4); take((size_t)B * cap * 4);  // cbox cscore ccls cidx
+    take((size_t)B * 4); take((size_t)B * 4);                                                                    // count nsorted
+    take((size_t)B * cap * 16); take((size_t)B * cap * 4);                                                       // sbox sorder
+    take((size_t)B * cap * words * 8);                                                                           // mask
+    take((size_t)B * 5 * 4);                                                                                     // letterbox params
+    return o + 256;
+}
+
+int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
+    const int B = a.B, cap = a.cap;
+    const size_t words = (size_t)(cap + 63) / 64;
+    char* base = (char*)a.ws;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base + o; o = (o + bytes + 255) & ~(size_t)255; return p; };
+    float* cbox = (float*)take((size_t)B * cap * 16);
+    float* cscore = (float*)take((size_t)B * cap * 4);
+    float* ccls = (float*)take((size_t)B * cap * 4);
+    int* cidx = (int*)take((size_t)B * cap * 4);
+    int* count = (int*)take((size_t)B * 4);
+    int* nsorted = (int*)take((size_t)B * 4);
+    float* sbox = (float*)take((size_t)B * cap * 16);
+    int* sorder = (int*)take((size_t)B * cap * 4);
+    unsigned long long* mask = (unsigned long long*)take((size_t)B * cap * words * 8);
+    float* lb = (float*)take((size_t)B * 5 * 4);
+    if (o + 256 > a.ws_bytes) { y7t_set_error("postprocess workspace too small (%zu < %zu)", a.ws_bytes, o + 256); return Y7T_E_ARG; }
+    Y7T_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int) * B, s));
+    Y7T_HIP_CHECK(hipMemcpyAsync(lb, a.letterbox_dev, sizeof(float) * 5 * B, hipMemcpyDeviceToDevice, s));
+    DecodeArgs d;
+    memset(&d, 0, sizeof(d));
+    d.nl = a.nl; d.na = a.na; d.no = a.no; d.B = B; d.conf_thres = a.conf_thres; d.cap = cap;
+    d.cbox = cbox; d.cscore = cscore; d.ccls = ccls; d.cidx = cidx; d.count = count;
+    int row0 = 0;
+    for (int l = 0; l < a.nl; ++l) {
+        d.lv[l].p = a.head[l]; d.lv[l].ny = a.ny[l]; d.lv[l].nx = a.nx[l]; d.lv[l].stride = a.stride[l]; d.lv[l].row0 = row0;
+        for (int k = 0; k < a.na; ++k) { d.lv[l].aw[k] = a.anchors[(l * a.na + k) * 2]; d.lv[l].ah[k] = a.anchors[(l * a.na + k) * 2 + 1]; }
+        row0 += a.na * a.ny[l] * a.nx[l];
+    }
+    for (int l = 0; l < a.nl; ++l) {
+        const long long tot = (long long)B * a.na * a.ny[l] * a.nx[l];
+        int blocks = (int)((tot + 255) / 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_decode_filter, dim3(blocks), dim3(256), 0, s, d, l);
+        Y7T_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rank_sort, dim3((cap + 255) / 256, B), dim3(256), 0, s, cbox, cscore, ccls, cidx, count, cap, a.max_nms, sbox, sorder, nsorted);
+    Y7T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nms_mask, dim3(1024, B), dim3(64), 0, s, sbox, nsorted, cap, a.iou_thres, mask, (int)words);
+    Y7T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(64), words * 8, s, mask, (int)words, nsorted, sorder, cbox, cscore, ccls, cap, a.max_det, lb, a.dets,
+                       a.ndets, a.keep_idx);
+    Y7T_LAUNCH_CHECK();
+    if (a.count_out) Y7T_HIP_CHECK(hipMemcpyAsync(a.count_out, count, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
+    return 0;
+}

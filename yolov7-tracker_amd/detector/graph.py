@@ -1,0 +1,284 @@
+"""Graph parse + lowering.
+
+`parse(spec)` restates the subset of /root/reference/models/yolo.py:443-520 (parse_model) that the yolov7-w6 /
+yolov7-tiny graphs use -- Conv, ReOrg, Concat, MP, SP, SPPCSPC, nn.Upsample, Detect / IDetect / IAuxDetect -- and
+expands SPPCSPC (models/common.py:262-280) into its 7 convs + 3 pools.  `lower(nodes, H, W)` turns the node list into
+the static launch list of include/y7t.h (`y7t_op`) over an NHWC fp16 arena:
+  * every tensor lives in exactly one buffer; a tensor consumed by a Concat lives INSIDE the concat's buffer at its
+    channel offset, so Concat (models/common.py:56-62) costs nothing (17 concats in w6);
+  * ReOrg is fused into the input layout kernel; branches that do not reach the Detect head (the aux head of
+    training checkpoints, models/yolo.py:141-153) are dropped.
+"""
+import math
+
+import numpy as np
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+class Node:
+    """one tensor-producing op after expansion. kind: input|reorg|conv|concat|up|pool|detect"""
+    __slots__ = ("idx", "kind", "src", "c", "k", "s", "p", "act", "wkey", "layer", "extra", "h", "w", "home", "coff", "ld")
+
+    def __init__(self, kind, src, c, k=1, s=1, p=0, act=0, wkey=None, layer=-1, extra=None):
+        self.kind, self.src, self.c, self.k, self.s, self.p, self.act, self.wkey, self.layer, self.extra = kind, list(src), c, k, s, p, act, wkey, layer, extra
+        self.idx = -1
+        self.h = self.w = 0
+        self.home, self.coff, self.ld = None, 0, 0
+
+
+def _act_code(a):
+    if a is None or a is True:
+        return 1  # SiLU (Conv default act=True)
+    s = str(a)
+    if "LeakyReLU" in s:
+        return 2
+    if s in ("False", "nn.Identity()", "Identity()"):
+        return 0
+    if "SiLU" in s:
+        return 1
+    raise NotImplementedError("activation %r" % (a,))
+
+
+def parse(spec, ch=3):
+    """-> (nodes, layer_out) : expanded node list and, per reference layer index, the node that is its output"""
+    nc, anchors, gw = spec["nc"], spec["anchors"], spec.get("width_multiple", 1.0)
+    na = len(anchors[0]) // 2
+    no = na * (nc + 5)
+    nodes = [Node("input", [], ch)]
+    layer_out, chs = [], []
+
+    def add(n):
+        n.idx = len(nodes)
+        nodes.append(n)
+        return n.idx
+
+    for i, (f, n, m, args) in enumerate(spec["layers"]):
+        if n != 1:
+            raise NotImplementedError("layer %d: number=%d" % (i, n))
+        fl = [f] if isinstance(f, int) else list(f)
+        src = [(0 if i == 0 else layer_out[i - 1]) if x == -1 else layer_out[x if x >= 0 else i + x] for x in fl]
+        cin = [(ch if i == 0 else chs[i - 1]) if x == -1 else chs[x if x >= 0 else i + x] for x in fl]
+        m = str(m)
+        if m == "Conv":
+            c2 = args[0]
+            if c2 != no:
+                c2 = make_divisible(c2 * gw, 8)
+            k = args[1] if len(args) > 1 else 1
+            s = args[2] if len(args) > 2 else 1
+            p = args[3] if len(args) > 3 and args[3] not in (None, "None") else k // 2   # yaml spells it 'None'
+            if len(args) > 4 and args[4] not in (1, None):
+                raise NotImplementedError("grouped conv")
+            act = _act_code(args[5] if len(args) > 5 else True)
+            out = add(Node("conv", src, c2, k, s, p, act, "model.%d" % i, i))
+        elif m == "ReOrg":
+            out, c2 = add(Node("reorg", src, cin[0] * 4, layer=i)), cin[0] * 4
+        elif m == "Concat":
+            out, c2 = add(Node("concat", src, sum(cin), layer=i)), sum(cin)
+        elif m == "MP":
+            k = args[0] if args else 2
+            out, c2 = add(Node("pool", src, cin[0], k, k, 0, layer=i)), cin[0]
+        elif m == "SP":
+            k = args[0] if args else 3
+            s = args[1] if len(args) > 1 else 1
+            out, c2 = add(Node("pool", src, cin[0], k, s, k // 2, layer=i)), cin[0]
+        elif m in ("nn.Upsample", "Upsample"):
+            if args[0] not in (None, "None") or args[1] != 2 or args[2] != "nearest":
+                raise NotImplementedError("Upsample%r" % (args,))
+            out, c2 = add(Node("up", src, cin[0], layer=i)), cin[0]
+        elif m == "SPPCSPC":
+            c2 = make_divisible(args[0] * gw, 8)
+            c_ = int(2 * c2 * 0.5)
+            key = "model.%d." % i
+            cv1 = add(Node("conv", src, c_, 1, 1, 0, 1, key + "cv1", i))
+            cv3 = add(Node("conv", [cv1], c_, 3, 1, 1, 1, key + "cv3", i))
+            cv4 = add(Node("conv", [cv3], c_, 1, 1, 0, 1, key + "cv4", i))
+            # max-pool 5/9/13 (stride 1, -inf padding) == 5, 5o5, 5o5o5
+            p5 = add(Node("pool", [cv4], c_, 5, 1, 2, layer=i))
+            p9 = add(Node("pool", [p5], c_, 5, 1, 2, layer=i))
+            p13 = add(Node("pool", [p9], c_, 5, 1, 2, layer=i))
+            cat1 = add(Node("concat", [cv4, p5, p9, p13], 4 * c_, layer=i))
+            cv5 = add(Node("conv", [cat1], c_, 1, 1, 0, 1, key + "cv5", i))
+            cv6 = add(Node("conv", [cv5], c_, 3, 1, 1, 1, key + "cv6", i))
+            cv2 = add(Node("conv", src, c_, 1, 1, 0, 1, key + "cv2", i))
+            cat2 = add(Node("concat", [cv6, cv2], 2 * c_, layer=i))
+            out = add(Node("conv", [cat2], c2, 1, 1, 0, 1, key + "cv7", i))
+        elif m in ("Detect", "IDetect", "IAuxDetect"):
+            nl = len(anchors)
+            out = add(Node("detect", src[:nl], no, layer=i, extra={"kind": m, "nl": nl, "na": na, "no": nc + 5, "cin": cin[:nl]}))
+            c2 = no
+        else:
+            raise NotImplementedError("module %s (layer %d) is outside the yolov7-w6 / yolov7-tiny hot path" % (m, i))
+        layer_out.append(out)
+        chs.append(c2)
+    return nodes, layer_out
+
+
+OP_DTYPE = np.dtype([("type", "<i4"), ("in_buf", "<i4"), ("in_ld", "<i4"), ("in_coff", "<i4"), ("H", "<i4"), ("W", "<i4"), ("Cin", "<i4"),
+                     ("out_buf", "<i4"), ("out_ld", "<i4"), ("out_coff", "<i4"), ("out_f32", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"),
+                     ("Cout", "<i4"), ("Cout_pad", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("K", "<i4"),
+                     ("K_pad", "<i4"), ("act", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4"), ("w_off", "<i8"), ("bias_off", "<i8")], align=False)
+assert OP_DTYPE.itemsize == 112   # == sizeof(y7t_op) in include/y7t.h
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Plan:
+    """result of `lower`: ops (structured array), buffer table, weight layout, head description"""
+
+
+def lower(nodes, H, W, max_batch=1):
+    det = next(n for n in nodes if n.kind == "detect")
+    # ---- liveness: only what reaches the (main) Detect inputs ----
+    live = set()
+    stack = list(det.src)
+    while stack:
+        i = stack.pop()
+        if i in live:
+            continue
+        live.add(i)
+        stack.extend(nodes[i].src)
+    # ---- shapes ----
+    for n in nodes:
+        if n.kind == "input":
+            n.h, n.w = H, W
+            continue
+        if n.kind == "detect":
+            continue
+        s0 = nodes[n.src[0]]
+        if n.kind == "reorg":
+            n.h, n.w = s0.h // 2, s0.w // 2
+        elif n.kind in ("conv", "pool"):
+            n.h, n.w = (s0.h + 2 * n.p - n.k) // n.s + 1, (s0.w + 2 * n.p - n.k) // n.s + 1
+        elif n.kind == "up":
+            n.h, n.w = s0.h * 2, s0.w * 2
+        elif n.kind == "concat":
+            n.h, n.w = s0.h, s0.w
+            for j in n.src:
+                assert (nodes[j].h, nodes[j].w) == (n.h, n.w), "concat of mismatched maps"
+    # ---- homes: a tensor consumed by a concat lives inside that concat's buffer ----
+    bufs = []  # (elems_per_image, itemsize)
+
+    def new_buf(n, ld, itemsize=2):
+        bufs.append((n.h * n.w * ld, itemsize))
+        return len(bufs) - 1
+    extra_copies = []  # (src_node, concat_node, coff) for tensors that sit in more than one concat
+    for n in nodes:
+        if n.idx in live and n.kind == "concat":
+            if any(n.idx in nodes[j].src for j in live if nodes[j].kind == "concat"):
+                raise NotImplementedError("nested Concat")
+            n.home, n.coff, n.ld = new_buf(n, n.c), 0, n.c
+            off = 0
+            for j in n.src:
+                t = nodes[j]
+                if t.home is None and t.kind not in ("input", "reorg", "concat"):
+                    t.home, t.coff, t.ld = n.home, off, n.c
+                else:
+                    extra_copies.append((j, n.idx, off))
+                off += t.c
+    first = nodes[1] if len(nodes) > 1 and nodes[1].kind == "reorg" else None
+    in_ld = 16 if first is not None else 8
+    nodes[0].home, nodes[0].coff, nodes[0].ld = None, 0, 0
+    bufs_input = None
+    for n in nodes:
+        if n.idx not in live and n.kind != "input":
+            continue
+        if n.kind in ("input", "reorg"):
+            continue
+        if n.home is None and n.kind != "detect":
+            n.home, n.coff, n.ld = new_buf(n, n.c), 0, n.c
+    # buffer 0 must be the input layout buffer: build the final table with it first
+    img_node = first if first is not None else nodes[0]
+    img_h, img_w = (H // 2, W // 2) if first is not None else (H, W)
+    table = [(img_h * img_w * in_ld, 2)] + bufs
+    shift = 1
+    for n in nodes:
+        if n.home is not None:
+            n.home += shift
+    img_node.home, img_node.coff, img_node.ld = 0, 0, in_ld
+    if first is not None:
+        nodes[0].home = None
+    # ---- ops ----
+    ops, wlayout = [], []   # wlayout: (wkey, cin_real, cin_pad, cout, cout_pad, k, K, K_pad, w_off, b_off, kind)
+    w_off = b_off = 0
+    heads = []
+
+    def emit_conv(n, src, out_buf, out_ld, out_coff, out_f32, cout, act, wkey, kind="conv"):
+        nonlocal w_off, b_off
+        cin_real = src.c
+        cin = _rup(cin_real, 8) if src.kind not in ("input", "reorg") else in_ld
+        if src.kind not in ("input", "reorg") and cin != cin_real:
+            raise NotImplementedError("conv input channels %d not a multiple of 8" % cin_real)
+        K = n.k * n.k * cin
+        K_pad = _rup(K, 64)
+        cout_pad = _rup(cout, 64)
+        op = np.zeros((), OP_DTYPE)
+        op["type"], op["in_buf"], op["in_ld"], op["in_coff"] = 0, src.home, src.ld, src.coff
+        op["H"], op["W"], op["Cin"] = src.h, src.w, cin
+        op["out_buf"], op["out_ld"], op["out_coff"], op["out_f32"] = out_buf, out_ld, out_coff, out_f32
+        op["Ho"], op["Wo"], op["Cout"], op["Cout_pad"] = n.h, n.w, cout, cout_pad
+        op["KH"], op["KW"], op["stride"], op["pad"], op["K"], op["K_pad"], op["act"] = n.k, n.k, n.s, n.p, K, K_pad, act
+        op["w_off"], op["bias_off"] = w_off, b_off
+        ops.append(op)
+        wlayout.append(dict(wkey=wkey, cin=cin_real, cin_pad=cin, cout=cout, cout_pad=cout_pad, k=n.k, K=K, K_pad=K_pad, w_off=w_off,
+                            b_off=b_off, kind=kind, act=act, macs=n.h * n.w * cout * n.k * n.k * cin_real))
+        w_off += cout_pad * K_pad
+        b_off += cout_pad
+
+    def emit_simple(typ, n, src, k=0, s=1, p=0, out=None):
+        out_home, out_ld, out_coff = out if out is not None else (n.home, n.ld, n.coff)
+        op = np.zeros((), OP_DTYPE)
+        op["type"], op["in_buf"], op["in_ld"], op["in_coff"] = typ, src.home, src.ld, src.coff
+        op["H"], op["W"], op["Cin"] = src.h, src.w, src.c
+        op["out_buf"], op["out_ld"], op["out_coff"] = out_home, out_ld, out_coff
+        op["Ho"], op["Wo"], op["Cout"] = (src.h + 2 * p - k) // s + 1 if typ == 2 else n.h, (src.w + 2 * p - k) // s + 1 if typ == 2 else n.w, src.c
+        op["KH"], op["KW"], op["stride"], op["pad"] = k, k, s, p
+        ops.append(op)
+
+    pending_copies = {}
+    for j, cidx, off in extra_copies:
+        pending_copies.setdefault(j, []).append((cidx, off))
+    for n in nodes:
+        if n.idx not in live and n.kind != "detect":
+            continue
+        if n.kind in ("input", "reorg", "concat"):
+            pass
+        elif n.kind == "conv":
+            emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
+        elif n.kind == "up":
+            emit_simple(1, n, nodes[n.src[0]])
+        elif n.kind == "pool":
+            emit_simple(2, n, nodes[n.src[0]], n.k, n.s, n.p)
+        elif n.kind == "detect":
+            ex = n.extra
+            for l, j in enumerate(n.src):
+                src = nodes[j]
+                hn = Node("conv", [j], ex["na"] * ex["no"], 1, 1, 0, 0)
+                hn.h, hn.w = src.h, src.w
+                hb = len(table)
+                table.append((src.h * src.w * ex["na"] * ex["no"], 4))
+                emit_conv(hn, src, hb, ex["na"] * ex["no"], 0, 1, ex["na"] * ex["no"], 0, "model.%d.m.%d" % (n.layer, l), kind=ex["kind"])
+                wlayout[-1]["level"] = l
+                heads.append(dict(buf=hb, ny=src.h, nx=src.w, stride=H // src.h))
+        for cidx, off in pending_copies.get(n.idx, []):   # tensor that sits in a second concat: copy (1x1 max-pool)
+            c = nodes[cidx]
+            emit_simple(2, n, n, 1, 1, 0, out=(c.home, c.ld, off))
+    plan = Plan()
+    plan.ops = np.array(ops, dtype=OP_DTYPE)
+    plan.buf_elems = table
+    offs, o = [], 0
+    for elems, isz in table:
+        offs.append(o)
+        o = _rup(o + elems * isz * max_batch, 256)
+    plan.buf_offsets = np.array(offs, dtype=np.int64)
+    plan.arena_bytes = o + 256
+    plan.wlayout, plan.w_elems, plan.b_elems = wlayout, w_off, b_off
+    plan.heads, plan.det = heads, det.extra
+    plan.in_ld, plan.reorg, plan.H, plan.W, plan.max_batch = in_ld, first is not None, H, W, max_batch
+    plan.macs = sum(w["macs"] for w in wlayout)
+    plan.nodes = nodes
+    return plan

@@ -1,0 +1,293 @@
+"""Detector seam of the reference: `attempt_load(weights)` -> callable whose output feeds
+`non_max_suppression`, `scale_coords`, `check_img_size` -- /root/reference/models/experimental.py:83-106,
+models/yolo.py:319-351, utils/general.py:123-128,319-340,607-695 -- running on the MI355X through liby7t.so.
+
+The forward pass is a static launch list over an NHWC fp16 arena (detector/graph.py); the Detect decode is fused with
+the candidate filter of NMS, so the reference's (B, 102000, 5+nc) tensor is never materialised: `model(img)` returns a
+`HeadOutput` handle that `non_max_suppression` consumes on the device."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import arch, graph, weights
+
+MAX_DET, MAX_NMS = 300, 30000   # utils/general.py:619-620
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def check_img_size(img_size, s=32):
+    """utils/general.py:123-128"""
+    new_size = make_divisible(img_size, int(s))
+    if new_size != img_size:
+        print('WARNING: --img-size %g must be multiple of max stride %g, updating to %g' % (img_size, s, new_size))
+    return new_size
+
+
+class HeadOutput:
+    """what `model(img)[0]` stands for: the raw Detect conv outputs of one forward, still on the device"""
+
+    def __init__(self, det, B, img_shape):
+        self.det, self.B, self.img_shape = det, B, img_shape
+
+    @property
+    def shape(self):
+        p = self.det.plan
+        return (self.B, sum(p.det["na"] * h["ny"] * h["nx"] for h in p.heads), p.det["no"])
+
+    def raw(self):
+        """list of (B, na, ny, nx, no) float32 tensors == the second element the reference's Detect returns"""
+        p, out = self.det.plan, []
+        for l, h in enumerate(p.heads):
+            t = self.det.head_tensor(l, self.B).reshape(self.B, h["ny"], h["nx"], p.det["na"], p.det["no"])
+            out.append(t.permute(0, 3, 1, 2, 4).contiguous())
+        return out
+
+    def decoded(self):
+        """(B, A, no) float32 == the reference's `model(img)[0]` (models/yolo.py:39-57); convenience, not on the hot path"""
+        p, z = self.det.plan, []
+        anchors = torch.tensor(self.det.spec["anchors"], dtype=torch.float32, device="cuda").view(len(p.heads), -1, 2)
+        for l, (h, x) in enumerate(zip(p.heads, self.raw())):
+            ny, nx = h["ny"], h["nx"]
+            yv, xv = torch.meshgrid(torch.arange(ny, device="cuda"), torch.arange(nx, device="cuda"), indexing="ij")
+            grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
+            y = x.sigmoid()
+            y[..., 0:2] = (y[..., 0:2] * 2. - 0.5 + grid) * h["stride"]
+            y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * anchors[l].view(1, -1, 1, 1, 2)
+            z.append(y.view(self.B, -1, p.det["no"]))
+        return torch.cat(z, 1)
+
+    def __getitem__(self, i):   # `out = model(img); out = out[0]`
+        if i == 0:
+            return self
+        raise IndexError(i)
+
+
+class Detector:
+    """spec: arch dict; state_dict: reference-style names (see detector/weights.py)."""
+
+    def __init__(self, spec, state_dict=None, img_size=(1280, 1280), max_batch=1, max_cand=16384, seed=0):
+        _lib.require_gpu()
+        self._L = _lib.load()
+        self.spec = spec
+        self.nodes, self.layer_out = graph.parse(spec)
+        self.max_batch, self.max_cand = int(max_batch), int(max_cand)
+        self.names = [str(i) for i in range(spec["nc"])]
+        self._sd, self._seed = state_dict, seed
+        self._plans = {}
+        self.plan = None
+        self._handle = None
+        strides = None
+        self.stride = None
+        self._select(tuple(img_size))
+        self.stride = torch.tensor([float(h["stride"]) for h in self.plan.heads])
+
+    # -- plan / arena per input size ---------------------------------------------------------------
+    def _select(self, hw):
+        if self.plan is not None and (self.plan.H, self.plan.W) == hw:
+            return
+        if hw not in self._plans:
+            s = int(max(8 * 2 ** (len(self.spec["anchors"]) - 1), 32))
+            if hw[0] % s or hw[1] % s:
+                raise ValueError("input %dx%d is not a multiple of the max stride %d" % (hw[0], hw[1], s))
+            nodes, _ = graph.parse(self.spec)
+            plan = graph.lower(nodes, hw[0], hw[1], self.max_batch)
+            if self._sd is None:
+                self._sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, self._seed), seed=self._seed)
+            wb, bb = weights.pack(plan.wlayout, self._sd, plan.w_elems, plan.b_elems)
+            plan.w_dev = torch.from_numpy(wb.view(np.int16)).cuda()
+            plan.b_dev = torch.from_numpy(bb).cuda()
+            plan.arena = torch.zeros(plan.arena_bytes, dtype=torch.uint8, device="cuda")
+            h = ctypes.c_void_p()
+            _lib.check(self._L.y7t_det_create(plan.ops.ctypes.data_as(ctypes.c_void_p), len(plan.ops),
+                                              plan.buf_offsets.ctypes.data_as(ctypes.c_void_p), len(plan.buf_offsets),
+                                              _lib.ptr(plan.arena), plan.arena_bytes, _lib.ptr(plan.w_dev), _lib.ptr(plan.b_dev),
+                                              self.max_batch, ctypes.byref(h)))
+            plan.handle = h
+            B, cap = self.max_batch, self.max_cand
+            plan.ws = torch.zeros(int(self._L.y7t_det_postprocess_workspace_bytes(B, cap)), dtype=torch.uint8, device="cuda")
+            plan.dets = torch.zeros((B, MAX_DET, 6), dtype=torch.float32, device="cuda")
+            plan.ndets = torch.zeros(B, dtype=torch.int32, device="cuda")
+            plan.keep = torch.zeros((B, MAX_DET), dtype=torch.int32, device="cuda")
+            plan.cand = torch.zeros(B, dtype=torch.int32, device="cuda")
+            plan.lb = torch.zeros((B, 5), dtype=torch.float32, device="cuda")
+            plan.head_ptrs = (ctypes.c_void_p * 4)(*[plan.arena.data_ptr() + int(plan.buf_offsets[hd["buf"]]) for hd in plan.heads] +
+                                                   [None] * (4 - len(plan.heads)))
+            plan.ny = (ctypes.c_int * 4)(*[hd["ny"] for hd in plan.heads] + [0] * (4 - len(plan.heads)))
+            plan.nx = (ctypes.c_int * 4)(*[hd["nx"] for hd in plan.heads] + [0] * (4 - len(plan.heads)))
+            plan.strides = (ctypes.c_float * 4)(*[float(hd["stride"]) for hd in plan.heads] + [0.0] * (4 - len(plan.heads)))
+            flat = [float(v) for lvl in self.spec["anchors"] for v in lvl]
+            plan.anchors = (ctypes.c_float * 24)(*(flat + [0.0] * (24 - len(flat))))
+            self._plans[hw] = plan
+        self.plan = self._plans[hw]
+
+    def head_tensor(self, level, B):
+        p = self.plan
+        h = p.heads[level]
+        n = h["ny"] * h["nx"] * p.det["na"] * p.det["no"]
+        off = int(p.buf_offsets[h["buf"]])
+        return p.arena[off:off + 4 * n * B].view(torch.float32).view(B, h["ny"], h["nx"], p.det["na"] * p.det["no"])
+
+    def buffer_view(self, buf, B, C):
+        """NHWC fp16 view of an arena buffer (tests)"""
+        p = self.plan
+        elems = p.buf_elems[buf][0]
+        off = int(p.buf_offsets[buf])
+        return p.arena[off:off + 2 * elems * B].view(torch.float16).view(B, -1, C)
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def forward(self, img):
+        """img: (B,3,H,W) float32 RGB in [0,1] (the reference's input) or (B,H,W,3) uint8 BGR frames (fused
+        BGR->RGB, /255).  -> HeadOutput."""
+        if img.dim() == 3:
+            img = img[None]
+        if img.device.type != "cuda":
+            img = img.cuda(non_blocking=True)
+        is_u8 = img.dtype == torch.uint8
+        if is_u8:
+            B, H, W = img.shape[0], img.shape[1], img.shape[2]
+        else:
+            img = img.float()
+            B, H, W = img.shape[0], img.shape[2], img.shape[3]
+        img = img.contiguous()
+        if B > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
+        self._select((H, W))
+        p = self.plan
+        s = _lib.stream_ptr()
+        _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
+        _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+        self._img_keep = img
+        return HeadOutput(self, B, (H, W))
+
+    def __call__(self, img, augment=False):
+        return (self.forward(img),)
+
+    def postprocess(self, out, conf_thres=0.01, iou_thres=0.45, ori_shapes=None):
+        """decode + NMS + scale_coords + round on the device.  ori_shapes: list of (H0, W0) per image (None: no rescale).
+        -> (dets (B, 300, 6) float32 device tensor, ndets (B,) int32 device tensor); asynchronous."""
+        p, B = self.plan, out.B
+        H, W = out.img_shape
+        lb = np.zeros((B, 5), np.float32)
+        for b in range(B):
+            h0, w0 = (H, W) if ori_shapes is None else ori_shapes[b][:2]
+            gain = min(H / h0, W / w0)
+            lb[b] = (gain, (W - w0 * gain) / 2, (H - h0 * gain) / 2, h0, w0)
+        key = lb.tobytes()
+        if getattr(p, "_lb_key", None) != key:
+            p.lb[:B].copy_(torch.from_numpy(lb))
+            p._lb_key = key
+        _lib.check(self._L.y7t_det_postprocess(p.head_ptrs, p.ny, p.nx, p.strides, p.anchors, len(p.heads), p.det["na"], p.det["no"], B,
+                                               float(conf_thres), float(iou_thres), MAX_DET, MAX_NMS, self.max_cand, _lib.ptr(p.lb),
+                                               _lib.ptr(p.dets), _lib.ptr(p.ndets), _lib.ptr(p.keep), _lib.ptr(p.cand), _lib.ptr(p.ws),
+                                               p.ws.numel(), _lib.stream_ptr()))
+        return p.dets, p.ndets
+
+    def check_overflow(self):
+        c = int(self.plan.cand.max().item())
+        if c > self.max_cand:
+            raise _lib.Y7TError("%d NMS candidates exceed max_cand=%d" % (c, self.max_cand))
+
+    def eval(self):
+        return self
+
+    def float(self):
+        return self
+
+    def fuse(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def gflop_per_frame(self):
+        return 2 * self.plan.macs / 1e9
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=()):
+    """utils/general.py:607-695 for the arguments the tracking path uses (classes=None, agnostic=False, multi_label=False).
+    prediction: the HeadOutput returned by Detector.  -> list of (n, 6) tensors [xyxy, conf, cls], score-descending."""
+    if not isinstance(prediction, HeadOutput):
+        raise TypeError("non_max_suppression expects the detector's HeadOutput (the decoded tensor is never materialised)")
+    if classes is not None or agnostic or multi_label or labels:
+        raise NotImplementedError("only the tracking path's NMS arguments are implemented")
+    det = prediction.det
+    dets, nd = det.postprocess(prediction, conf_thres, iou_thres, None)
+    nd = nd.cpu().numpy()
+    det.check_overflow()
+    out = []
+    for b in range(prediction.B):
+        d = dets[b, :nd[b]].clone()
+        d[:, :4] = det.plan_raw_boxes(b, int(nd[b]))   # un-rounded boxes: rounding is the caller's (track.py:240)
+        out.append(d)
+    return out
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """utils/general.py:319-340 (in place, torch)"""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    coords[:, 0].clamp_(0, img0_shape[1])
+    coords[:, 1].clamp_(0, img0_shape[0])
+    coords[:, 2].clamp_(0, img0_shape[1])
+    coords[:, 3].clamp_(0, img0_shape[0])
+    return coords
+
+
+def _plan_raw_boxes(self, b, n):
+    """xyxy of the kept detections before scale_coords/round (candidate boxes gathered by the kept slots)"""
+    p = self.plan
+    cap = self.max_cand
+    cbox = p.ws[:self.max_batch * cap * 16].view(torch.float32).view(self.max_batch, cap, 4)
+    idx = p.keep[b, :n].long()
+    return cbox[b, idx]
+
+
+Detector.plan_raw_boxes = _plan_raw_boxes
+
+
+def attempt_load(weights_path, map_location=None, cfg=None, nc=None, img_size=1280, max_batch=1):
+    """models/experimental.py:83-106 seam.  `weights_path`: a .pt holding a state dict / {'model': state_dict} /
+    (when the reference's classes are importable) a pickled reference Model; or 'random:<arch>[:seed]' for seeded
+    random weights of a named architecture (no trained checkpoint ships with the reference).  Never touches the
+    network (the reference's attempt_download would)."""
+    if isinstance(weights_path, (list, tuple)):
+        weights_path = weights_path[0]
+    sd, seed = None, 0
+    if str(weights_path).startswith("random:"):
+        parts = str(weights_path).split(":")
+        name = parts[1]
+        seed = int(parts[2]) if len(parts) > 2 else 0
+        spec = arch.ARCHS[name](nc if nc is not None else 80)
+    else:
+        if not os.path.isfile(weights_path):
+            raise FileNotFoundError(weights_path)
+        ck = torch.load(weights_path, map_location="cpu", weights_only=False)
+        m = ck.get("ema") or ck.get("model") if isinstance(ck, dict) and ("model" in ck or "ema" in ck) else ck
+        if hasattr(m, "state_dict"):
+            sd = {k: v.float() for k, v in m.float().state_dict().items()}
+            spec_yaml = getattr(m, "yaml", None)
+        else:
+            sd, spec_yaml = {k: v.float() for k, v in m.items()}, None
+        if cfg is not None:
+            spec = arch.load_yaml(cfg, nc) if os.path.isfile(str(cfg)) else arch.ARCHS[cfg](nc if nc is not None else 80)
+        elif spec_yaml is not None:
+            spec = {"nc": spec_yaml["nc"], "depth_multiple": spec_yaml.get("depth_multiple", 1.0), "width_multiple": spec_yaml.get("width_multiple", 1.0),
+                    "anchors": spec_yaml["anchors"], "layers": list(spec_yaml["backbone"]) + list(spec_yaml["head"])}
+        else:
+            raise ValueError("a state-dict checkpoint needs cfg=<yaml path or arch name>")
+    size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+    return Detector(spec, sd, img_size=size, max_batch=max_batch, seed=seed)

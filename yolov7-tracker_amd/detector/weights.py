@@ -1,0 +1,116 @@
+"""Weights: deterministic random initialisation (no trained checkpoint ships with the reference), BatchNorm folding
+(restating /root/reference/utils/torch_utils.py:181-201 fuse_conv_and_bn; BN eps = 1e-3 as set by
+utils/torch_utils.py initialize_weights), IDetect implicit-layer folding (what tools/reparameterization.ipynb does:
+m(x + ia) * im), and packing into the [Cout_pad][K_pad] fp16 layout of the implicit-GEMM kernel."""
+import numpy as np
+import torch
+
+BN_EPS = 1e-3
+GAIN_SILU, GAIN_LEAKY = 1.75, 1.40   # keep activation std ~O(1) through the depth of w6 / tiny
+
+
+def random_state_dict(wlayout, seed=0, fused=False):
+    """Reference-style state dict ({wkey}.conv.weight / {wkey}.bn.* / model.N.m.L.{weight,bias}) with seeded values that
+    keep activations O(1) through ~100 layers (so that fp16 storage is meaningful)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for w in wlayout:
+        cout, cin, k = w["cout"], w["cin"], w["k"]
+        fan_in = cin * k * k
+        if w["kind"] != "conv":   # Detect 1x1 conv: plain conv with bias
+            sd[w["wkey"] + ".weight"] = torch.from_numpy(rng.normal(0, 1.0 / np.sqrt(fan_in), (cout, cin, 1, 1)).astype(np.float32))
+            sd[w["wkey"] + ".bias"] = torch.from_numpy(rng.normal(0, 0.5, cout).astype(np.float32))
+            continue
+        gain = {0: 1.0, 1: GAIN_SILU, 2: GAIN_LEAKY}[w.get('act', 1)]
+        W = rng.normal(0, gain / np.sqrt(fan_in), (cout, cin, k, k)).astype(np.float32)
+        g = rng.uniform(0.7, 1.3, cout).astype(np.float32)
+        b = rng.normal(0, 0.1, cout).astype(np.float32)
+        mu = rng.normal(0, 0.1, cout).astype(np.float32)
+        var = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+        if fused:
+            scale = g / np.sqrt(var + BN_EPS)
+            sd[w["wkey"] + ".conv.weight"] = torch.from_numpy(W * scale[:, None, None, None])
+            sd[w["wkey"] + ".conv.bias"] = torch.from_numpy(b - mu * scale)
+        else:
+            sd[w["wkey"] + ".conv.weight"] = torch.from_numpy(W)
+            sd[w["wkey"] + ".bn.weight"], sd[w["wkey"] + ".bn.bias"] = torch.from_numpy(g), torch.from_numpy(b)
+            sd[w["wkey"] + ".bn.running_mean"], sd[w["wkey"] + ".bn.running_var"] = torch.from_numpy(mu), torch.from_numpy(var)
+    return sd
+
+
+@torch.no_grad()
+def calibrate_bn(nodes, sd, hw=(640, 640), seed=0):
+    """Data-dependent initialisation (host, once): set every BatchNorm's running statistics to the batch statistics its
+    conv produces on a random low-resolution image, layer by layer -- what a BN layer converges to in training -- so the
+    randomly initialised network keeps O(1) activations at any depth.  Weight INITIALISATION only; the hot path never
+    runs through torch."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    vals = {0: torch.rand((1, 3) + tuple(hw), generator=g)}
+    for n in nodes[1:]:
+        if n.kind == "detect" or any(j not in vals for j in n.src):
+            continue
+        x = vals[n.src[0]]
+        if n.kind == "reorg":
+            y = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+        elif n.kind == "conv":
+            y = F.conv2d(x, sd[n.wkey + ".conv.weight"], None, stride=n.s, padding=n.p)
+            mu, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+            sd[n.wkey + ".bn.running_mean"], sd[n.wkey + ".bn.running_var"] = mu.clone(), var.clone()
+            y = (y - mu[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS) * sd[n.wkey + ".bn.weight"][None, :, None, None] \
+                + sd[n.wkey + ".bn.bias"][None, :, None, None]
+            y = F.silu(y) if n.act == 1 else (F.leaky_relu(y, 0.1) if n.act == 2 else y)
+        elif n.kind == "concat":
+            y = torch.cat([vals[j] for j in n.src], 1)
+        elif n.kind == "up":
+            y = F.interpolate(x, scale_factor=2, mode="nearest")
+        elif n.kind == "pool":
+            y = F.max_pool2d(x, n.k, n.s, n.p)
+        else:
+            raise NotImplementedError(n.kind)
+        vals[n.idx] = y
+    return sd
+
+
+def folded(w, sd):
+    """-> (W' float64 (cout, cin, k, k), b' float64 (cout,)) of one conv of the plan"""
+    key = w["wkey"]
+    if w["kind"] == "conv":
+        W = sd[key + ".conv.weight"].detach().double().cpu().numpy()
+        if key + ".bn.weight" in sd:
+            g, b = sd[key + ".bn.weight"].double().cpu().numpy(), sd[key + ".bn.bias"].double().cpu().numpy()
+            mu, var = sd[key + ".bn.running_mean"].double().cpu().numpy(), sd[key + ".bn.running_var"].double().cpu().numpy()
+            scale = g / np.sqrt(var + BN_EPS)
+            b0 = sd[key + ".conv.bias"].double().cpu().numpy() if key + ".conv.bias" in sd else 0.0
+            return W * scale[:, None, None, None], (b0 - mu) * scale + b
+        b0 = sd[key + ".conv.bias"].double().cpu().numpy() if key + ".conv.bias" in sd else np.zeros(W.shape[0])
+        return W, b0
+    W = sd[key + ".weight"].detach().double().cpu().numpy()
+    b = sd[key + ".bias"].detach().double().cpu().numpy()
+    if w["kind"] in ("IDetect", "IAuxDetect"):   # models/yolo.py:93-94 / :136-137: m(ia(x)) then im(.)
+        base, lvl = key.rsplit(".m.", 1)
+        ia, im = sd.get("%s.ia.%s.implicit" % (base, lvl)), sd.get("%s.im.%s.implicit" % (base, lvl))
+        if ia is not None:
+            b = b + W.reshape(W.shape[0], -1) @ ia.double().cpu().numpy().reshape(-1)
+        if im is not None:
+            s = im.double().cpu().numpy().reshape(-1)
+            W, b = W * s[:, None, None, None], b * s
+    return W, b
+
+
+def pack(wlayout, sd, w_elems, b_elems):
+    """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
+    k = (kh*KW + kw)*Cin_pad + ci"""
+    wb = np.zeros(w_elems, np.float16)
+    bb = np.zeros(b_elems, np.float32)
+    for w in wlayout:
+        W, b = folded(w, sd)
+        cout, cin, k = w["cout"], w["cin"], w["k"]
+        assert W.shape == (cout, cin, k, k), (w["wkey"], W.shape, (cout, cin, k, k))
+        Wt = np.zeros((cout, k, k, w["cin_pad"]), np.float64)
+        Wt[..., :cin] = W.transpose(0, 2, 3, 1)
+        blk = np.zeros((w["cout_pad"], w["K_pad"]), np.float16)
+        blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
+        wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
+        bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
+    return wb, bb
