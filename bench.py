@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end fps (detect + track) of the hot path on N MI355X GPUs of one node.
+
+Workload (BASELINE.json configs[1]): YOLOv7-w6 @ 1280x1280 (nc=10, VisDrone) + ByteTrack, one synthetic
+VisDrone-shape sequence per GPU, ~80 objects per frame.  A "step" is one pass of the hot path over one batch of
+`--batch` consecutive frames of the sequence, frames already resident in HBM as uint8 BGR:
+
+    input layout (BGR->RGB, /255, ReOrg, fp16 NHWC)  ->  107 MFMA implicit-GEMM convs (+ SPPCSPC pools, upsamples)
+    ->  Detect decode + candidate filter + rank sort + bitmask NMS + scale_coords/round      [stream A]
+    ->  ByteTrack frame step (multi_predict, 3 x IoU cost + LAPJV, Kalman updates, list bookkeeping), one fused
+        kernel per frame, strictly in frame order                                              [stream B, waits on A]
+
+No trained checkpoint ships with the reference, so weights are seeded random (BN statistics calibrated at init) and
+-- exactly as SURVEY.md section 8d prescribes -- the tracker is fed the synthetic ground-truth detections of the same
+scene while decode+NMS run on the detector's real output (the Detect objectness bias is planted so that ~2000 anchors
+per frame pass conf_thres = 0.01, a typical VisDrone candidate load).
+
+One process per GPU (`torch.distributed.run`), sequences are independent -> weak scaling, no data-path collective;
+RCCL is used once, for the result gather (+ id re-basing so ids equal the reference's single-process global counter).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16 = 2.5e15      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_FRAME_W6 = 354.9   # 177.45 GMAC x 2, yolov7-w6 deploy graph, nc=10, 1280x1280
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (consecutive frames of the sequence)")
+    ap.add_argument("--n_obj", type=int, default=80)
+    ap.add_argument("--img", type=int, default=1280)
+    ap.add_argument("--arch", default="yolov7-w6")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def make_opts():
+    return types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5,
+                                 max_tracks=512, max_dets=512)
+
+
+def plant_objectness_bias(det, frames, target=2000):
+    """shift the Detect objectness biases so that ~`target` anchors per frame exceed conf_thres=0.01"""
+    out = det(frames[:1])[0]
+    torch.cuda.synchronize()
+    p = det.plan
+    no, na = p.det["no"], p.det["na"]
+    logits = torch.cat([det.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) for l in range(len(p.heads))])
+    q = torch.quantile(logits.float().cpu(), 1.0 - target / logits.numel()).item()
+    shift = float(np.log(0.01 / 0.99)) - q
+    for w in p.wlayout:
+        if w["kind"] != "conv":
+            for a in range(na):
+                p.b_dev[w["b_off"] + a * no + 4] += shift
+            # class logits: make the best class pass too (conf = obj * cls must exceed 0.01)
+            for a in range(na):
+                p.b_dev[w["b_off"] + a * no + 5: w["b_off"] + (a + 1) * no] += 4.0
+    return shift
+
+
+def cpu_baseline(args, det, frames_host, dets_seq):
+    """the oracle (CPU restatement of the reference path, kind='port') timed on this host's cores on a bounded sample:
+    `cpu_frames` frames through the torch-fp32 detector + NMS oracle, 100 frames through the numpy ByteTrack oracle."""
+    from oracle import detector_torch as dt, tracker_np
+    ncores = min(os.cpu_count(), 32)      # torch's CPU conv stops scaling (and thrashes) beyond a few dozen threads
+    torch.set_num_threads(ncores)
+    f = frames_host[:1]
+    img = (torch.from_numpy(f[..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    sd = {k: v for k, v in det._sd.items()}
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_frames):
+        dec, _ = dt.forward(det.nodes, sd, img, det.spec["anchors"])
+    t_det = (time.perf_counter() - t0) / args.cpu_frames
+    # NMS load comparable to the GPU run: plant ~2000 candidates
+    dec = dec.clone()
+    dec[..., 4] = 0.0
+    idx = torch.randperm(dec.shape[1], generator=torch.Generator().manual_seed(0))[:2000]
+    dec[0, idx, 4] = torch.rand(2000) * 0.9 + 0.05
+    dec[..., 5:] = torch.rand_like(dec[..., 5:])
+    t0 = time.perf_counter()
+    dt.non_max_suppression(dec, 0.01, 0.45)
+    t_nms = time.perf_counter() - t0
+    n = min(100, len(dets_seq))
+    t0 = time.perf_counter()
+    tracker_np.run("bytetrack", dets_seq[:n])
+    t_trk = (time.perf_counter() - t0) / n
+    fps = 1.0 / (t_det + t_nms + t_trk)
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d frames 1280x1280 through the torch-fp32 detector oracle (%.2f s/frame, %d threads) + 1 NMS call on 2000 "
+                      "candidates (%.1f ms) + %d frames through the numpy ByteTrack oracle (%.2f ms/frame, 1 thread)"
+                      % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.detector import arch, model
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+
+    B, K, Wm = args.batch, args.steps, args.warmup
+    H = W = args.img
+    nc = 10
+    det = model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=B, seed=0)
+    n_frames = (K + Wm) * B
+    frames_host = synth.make_frames(B, args.n_obj, H, seq_idx=rank)          # B distinct frames, reused every step
+    frames = torch.from_numpy(frames_host).cuda()
+    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=rank)  # the scene's detections, frame by frame
+    dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
+    plant_objectness_bias(det, frames)
+
+    BaseTrack._count = 0
+    trk = ByteTrack(make_opts(), frame_rate=30)
+    results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
+    ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
+    ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
+
+    def step(s):
+        with torch.cuda.stream(sA):
+            ev_fwd0[s].record(sA)
+            out = det(frames)[0]
+            ev_fwd1[s].record(sA)
+            det.postprocess(out, 0.01, 0.45, None)
+            ev_nms[s].record(sA)
+        with torch.cuda.stream(sB):
+            sB.wait_event(ev_nms[s])       # a frame's detections exist before its tracker step runs
+            for i in range(B):
+                t = s * B + i
+                trk._launch(dets_dev[t], out=results[t])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(Wm):
+        step(s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(Wm, Wm + K):
+        step(s)
+    barrier()
+    dt_s = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_s = float(tmax.item())
+        # result gather (the only collective): per-rank id counts -> exclusive prefix (id re-basing), rows to rank 0
+        cnt = torch.tensor([BaseTrack._count], dtype=torch.int64, device="cuda")
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        base = int(sum(int(c.item()) for c in allc[:rank]))
+        results[..., 0] += base * (results[..., 0] > 0)
+        gathered = [torch.empty_like(results) for _ in range(world)] if rank == 0 else None
+        dist.gather(results, gathered, dst=0)
+    torch.cuda.synchronize()
+    det.check_overflow()
+
+    fwd_ms = [ev_fwd0[s].elapsed_time(ev_fwd1[s]) for s in range(Wm, Wm + K)]
+    nms_ms = [ev_fwd1[s].elapsed_time(ev_nms[s]) for s in range(Wm, Wm + K)]
+    gflop_frame = det.gflop_per_frame
+    conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
+    if rank == 0:
+        # sanity: the tracker produced tracks
+        last = results[(Wm + K) * B - 1].cpu().numpy()
+        n_tracks_last = int(last[trk.cap_t].view(np.int32)[0])
+        fps = world * K * B / dt_s
+        line = {
+            "metric": "end-to-end fps (detect+track) YOLOv7-w6@1280 ByteTrack", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack, 1 synthetic VisDrone-shape sequence per GPU, ~%d dets/frame"
+                                   % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
+                       "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
+                       "parallelism": "sequence-sharded x%d" % world},
+            "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+                         "kernel": "k_conv_igemm<BM,BN> (all 107 conv launches of one forward)",
+                         "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
+                         "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
+            "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, det, frames_host, dets_seq)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

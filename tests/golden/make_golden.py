@@ -147,9 +147,39 @@ def golden_lap_iou():
     np.savez_compressed(os.path.join(HERE, "lap_iou.npz"), **out)
 
 
+def golden_detector():
+    """reference models.yolo.Model (built from ITS yaml) loaded with this repo's seeded random state dict, run on a
+    seeded input: decoded head + NMS output.  Pins oracle/detector_torch.py where /root/reference is absent."""
+    import torch
+    from oracle import detector_torch as dt
+    from yolov7_tracker_amd.detector import arch, graph, weights
+    out = {}
+    for name, cfg, nc, hw in (("tiny", "cfg/deploy/yolov7-tiny.yaml", 80, (64, 96)), ("w6", "cfg/deploy/yolov7-w6.yaml", 10, (128, 128))):
+        spec = arch.ARCHS["yolov7-" + name](nc)
+        nodes, _ = graph.parse(spec)
+        plan = graph.lower(graph.parse(spec)[0], hw[0], hw[1], 1)
+        sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0), hw=(128, 128), seed=0)
+        m = ref_harness.build_reference_model(cfg, nc)
+        missing = m.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.unexpected_keys], missing.unexpected_keys
+        assert all(("anchor" in k or "num_batches_tracked" in k) for k in missing.missing_keys), missing.missing_keys
+        img = torch.rand((1, 3) + hw, generator=torch.Generator().manual_seed(5))
+        with torch.no_grad():
+            dec = m(img)[0]
+        det = ref_harness.load_detector()
+        det.general.torchvision.ops.nms = lambda b, s, t: torch.from_numpy(cnative.nms(b.numpy(), s.numpy(), t))
+        pred = dec.clone()
+        pred[..., 4] = torch.rand(pred.shape[:2], generator=torch.Generator().manual_seed(6)) * 0.3
+        nms = det.general.non_max_suppression(pred.clone(), conf_thres=0.01)[0]
+        out[name + "_img"], out[name + "_decoded"], out[name + "_pred"], out[name + "_nms"] = img.numpy(), dec.numpy(), pred.numpy(), nms.numpy()
+        out[name + "_sd_checksum"] = np.array(sum(float(v.double().sum()) for v in sd.values()))
+    np.savez_compressed(os.path.join(HERE, "detector.npz"), **out)
+
+
 if __name__ == "__main__":
     assert ref_harness.available(), "needs /root/reference"
     golden_kalman()
     golden_tracker()
     golden_lap_iou()
+    golden_detector()
     print("golden vectors written to", HERE)

@@ -1,0 +1,90 @@
+"""CPU: the torch-fp32 detector oracle (oracle/detector_torch.py) and the graph host logic, pinned against the
+reference: (a) golden vectors recorded from the reference's models.yolo.Model / utils.general.non_max_suppression
+(tests/golden/detector.npz), (b) the live reference where /root/reference exists."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detector_torch as dt
+from tests import util
+from yolov7_tracker_amd.detector import arch, graph, weights
+
+CASES = [("tiny", "yolov7-tiny", 80, (64, 96)), ("w6", "yolov7-w6", 10, (128, 128))]
+
+
+def seeded_sd(name, nc, hw):
+    spec = arch.ARCHS[name](nc)
+    nodes, _ = graph.parse(spec)
+    plan = graph.lower(graph.parse(spec)[0], hw[0], hw[1], 1)
+    sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0), hw=(128, 128), seed=0)
+    return spec, nodes, plan, sd
+
+
+@pytest.mark.parametrize("key,name,nc,hw", CASES)
+def test_oracle_forward_and_nms_match_reference_golden(key, name, nc, hw):
+    g = np.load(util.GOLDEN + "/detector.npz")
+    spec, nodes, plan, sd = seeded_sd(name, nc, hw)
+    chk = sum(float(v.double().sum()) for v in sd.values())
+    if abs(chk - float(g[key + "_sd_checksum"])) > 1e-6 * abs(chk):
+        pytest.skip("seeded weights differ on this host (different BLAS summation in the BN calibration)")
+    dec, _ = dt.forward(nodes, sd, torch.from_numpy(g[key + "_img"]), spec["anchors"])
+    np.testing.assert_allclose(dec.numpy(), g[key + "_decoded"], rtol=1e-4, atol=1e-4)
+    nms = dt.non_max_suppression(torch.from_numpy(g[key + "_pred"]), 0.01, 0.45)[0]
+    np.testing.assert_array_equal(nms.numpy(), g[key + "_nms"])
+
+
+def test_graph_census_matches_survey():
+    """w6 @ 1280, nc=10 -> 107 convs, 177.45 GMAC; tiny @ 640 nc=80 -> 58 convs, 6.85 GMAC"""
+    p = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, 1)
+    assert (p.ops["type"] == 0).sum() == 107 and abs(p.macs / 1e9 - 177.45) < 0.01
+    assert [h["stride"] for h in p.heads] == [8, 16, 32, 64] and sum(3 * h["ny"] * h["nx"] for h in p.heads) == 102000
+    p = graph.lower(graph.parse(arch.yolov7_tiny(80))[0], 640, 640, 1)
+    assert (p.ops["type"] == 0).sum() == 58 and abs(p.macs / 1e9 - 6.85) < 0.01
+    assert sum(3 * h["ny"] * h["nx"] for h in p.heads) == 25200
+
+
+def test_concat_elimination_writes_disjoint_slices():
+    p = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 256, 256, 1)
+    seen = {}
+    for op in p.ops:
+        key = int(op["out_buf"])
+        rng = (int(op["out_coff"]), int(op["out_coff"]) + int(op["Cout"]))
+        for a, b in seen.get(key, []):
+            assert rng[1] <= a or rng[0] >= b, "overlapping writers in buffer %d" % key
+        seen.setdefault(key, []).append(rng)
+        assert rng[1] <= int(op["out_ld"])
+
+
+def test_specs_equal_reference_yaml(have_reference):
+    if not have_reference:
+        pytest.skip("/root/reference not present")
+    import yaml
+    for fn, cfg in ((arch.yolov7_w6, "cfg/deploy/yolov7-w6.yaml"), (arch.yolov7_tiny, "cfg/deploy/yolov7-tiny.yaml")):
+        y = yaml.safe_load(open("/root/reference/" + cfg))
+        ref = y["backbone"] + y["head"]
+        mine = fn(y["nc"])["layers"]
+        norm = lambda L: [str(x).replace("'None'", "None") for x in L]
+        assert norm(ref) == norm(mine) and y["anchors"] == fn(y["nc"])["anchors"]
+        loaded = arch.load_yaml("/root/reference/" + cfg)
+        assert norm(loaded["layers"]) == norm(ref)
+
+
+def test_oracle_equals_live_reference_model(have_reference):
+    if not have_reference:
+        pytest.skip("/root/reference not present (golden vectors cover this)")
+    from oracle import ref_harness
+    spec, nodes, plan, sd = seeded_sd("yolov7-tiny", 80, (64, 96))
+    m = ref_harness.build_reference_model("cfg/deploy/yolov7-tiny.yaml", 80)
+    m.load_state_dict(sd, strict=False)
+    img = torch.rand((2, 3, 64, 96), generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = m(img)
+    dec, raw = dt.forward(nodes, sd, img, spec["anchors"])
+    assert torch.equal(dec, ref[0])
+    # BN folding of the product's packer == the reference's fuse()
+    m.fuse()
+    for w in plan.wlayout[:6]:
+        W, b = weights.folded(w, sd)
+        conv = dict(m.named_modules())[w["wkey"]].conv
+        np.testing.assert_allclose(W, conv.weight.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(b, conv.bias.detach().numpy(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: sequence-sharded tracking + id re-basing + result gather reproduce the single-process
+run with the reference's global id counter.  (The per-rank tracker here is the CPU host-sim of the device programs --
+test infrastructure; on the GPU box the same sharding code runs over RCCL with the device tracker, see bench.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+N_SEQ, N_FRAMES, N_OBJ = 5, 25, 30
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _track(seq_idx, ids):
+    from tests import _hostsim as hs
+    from yolov7_tracker_amd import synth
+    dets = synth.make_detections(N_FRAMES, N_OBJ, seq_idx=seq_idx)
+    trk = hs.HostSimTracker("bytetrack", ids=ids, cap_t=256, cap_d=256)
+    rows = []
+    for f, d in enumerate(dets):
+        for (tid, tlwh, cls, score) in trk.update(d):
+            rows.append([f + 1, tid, tlwh[0], tlwh[1], tlwh[2], tlwh[3], cls, score])
+    return torch.tensor(rows, dtype=torch.float64).reshape(-1, 8)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolov7_tracker_amd import sharding
+    rows, nids = {}, {}
+    for s in sharding.owned_sequences(N_SEQ, rank, world):
+        ids = np.zeros(1, np.int32)          # local counter per sequence
+        rows[s] = _track(s, ids)
+        nids[s] = int(ids[0])
+    res = sharding.rebase_and_gather(rows, nids, N_SEQ)
+    if rank == 0:
+        q.put([r.numpy() for r in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_with_global_ids():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, one GLOBAL counter across sequences in sorted order (reference semantics)
+    ids = np.zeros(1, np.int32)
+    for s in range(N_SEQ):
+        want = _track(s, ids).numpy()
+        assert got[s].shape == want.shape
+        np.testing.assert_array_equal(got[s][:, :2], want[:, :2])       # frame, id: bit-exact
+        np.testing.assert_allclose(got[s][:, 2:], want[:, 2:], rtol=0, atol=0)
+
+
+def test_single_rank_path():
+    from yolov7_tracker_amd import sharding
+    rows = {0: torch.tensor([[1, 1, 0, 0, 1, 1, 0, .5]], dtype=torch.float64), 1: torch.tensor([[1, 1, 0, 0, 1, 1, 0, .5], [1, 2, 0, 0, 1, 1, 0, .5]], dtype=torch.float64)}
+    res = sharding.rebase_and_gather(rows, {0: 3, 1: 2}, 2)
+    assert res[0][0, 1] == 1 and res[1][0, 1] == 4 and res[1][1, 1] == 5

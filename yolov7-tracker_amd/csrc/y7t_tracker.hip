@@ -294,8 +294,10 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
     return 0;
 }
 
-static int step_threads(int threads) {
-    if (threads == 0) return 256;
+static int step_threads(int threads, int n_hint = -1) {
+    // measured on MI355X (scripts/time_tracker.py): one wave wins for ~100-object scenes (no cross-wave barriers in the
+    // LAP reductions), four waves for crowded ones
+    if (threads == 0) return (n_hint >= 0 && n_hint <= 192) ? 64 : 256;
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) return -1;
     return threads;
 }
@@ -319,7 +321,7 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
                                 y7t_stream stream) {
     Y7T_ARG_CHECK(state && out_rows && out_count && out_cap >= 0);
     Y7T_ARG_CHECK(n <= 0 || dets);
-    const int nt = step_threads(threads);
+    const int nt = step_threads(threads, n);
     Y7T_ARG_CHECK(nt > 0);
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }

@@ -1,0 +1,160 @@
+"""`tracker/track.py` of the reference (/root/reference/tracker/track.py:53-386) with the same flags, config-file
+format and result-file format, driving the MI355X hot path: detector forward + decode/NMS (liby7t.so) and the
+device-resident SORT / ByteTrack trackers.
+
+    python tracker/track.py --dataset visdrone --tracker bytetrack --model_path weights/best.pt
+    python tracker/track.py --dataset synthetic --tracker bytetrack --model_path random:yolov7-w6 --synthetic_dets
+
+Extra flags (defaults reproduce the reference's behaviour): --model_cfg (yaml / arch name for state-dict checkpoints),
+--nc, --synthetic_dets, --synthetic_frames/--synthetic_objs/--synthetic_seqs, --results_root.
+"""
+import argparse
+import os
+from time import gmtime, strftime
+
+import numpy as np
+import torch
+import yaml
+
+from . import tracker_dataloader
+from .basetrack import BaseTracker
+from .bytetrack import ByteTrack
+from .timer import Timer
+from ..detector import attempt_load, check_img_size, non_max_suppression, scale_coords
+
+TRACKER_DICT = {'sort': BaseTracker, 'bytetrack': ByteTrack}   # track.py:56-65; the other six trackers are out of scope
+
+timer = Timer()
+seq_fps = []
+
+
+def post_process_v7(out, img_size, ori_img_size, conf_thres=0.01):
+    """track.py:234-244"""
+    out = non_max_suppression(out, conf_thres=conf_thres)[0]
+    out[:, :4] = scale_coords(img_size, out[:, :4], ori_img_size, ratio_pad=None).round()
+    return out
+
+
+def save_results(results_root, folder_name, seq_name, results, data_type='mot17'):
+    """track.py:247-273: `frame,id,x,y,w,h,1.0,-1,-1,-1` with %.2f"""
+    assert len(results)
+    os.makedirs(os.path.join(results_root, folder_name), exist_ok=True)
+    with open(os.path.join(results_root, folder_name, seq_name + '.txt'), 'w') as f:
+        for frame_id, target_ids, tlwhs, clses in results:
+            for id, tlwh, cls in zip(target_ids, tlwhs, clses):
+                if data_type == 'default':
+                    f.write(f'{frame_id},{id},{tlwh[0]:.2f},{tlwh[1]:.2f},{tlwh[2]:.2f},{tlwh[3]:.2f},{int(cls)}\n')
+                else:
+                    f.write(f'{frame_id},{id},{tlwh[0]:.2f},{tlwh[1]:.2f},{tlwh[2]:.2f},{tlwh[3]:.2f},1.0,-1,-1,-1\n')
+    return folder_name
+
+
+def main(opts, cfgs):
+    DATASET_ROOT, CERTAIN_SEQS, IGNORE_SEQS = cfgs['DATASET_ROOT'], cfgs['CERTAIN_SEQS'], cfgs['IGNORE_SEQS']
+    if opts.tracker not in TRACKER_DICT:
+        raise NotImplementedError("tracker %r: only %s run on the device path" % (opts.tracker, sorted(TRACKER_DICT)))
+    img_size = opts.img_size[0] if isinstance(opts.img_size, (list, tuple)) else opts.img_size
+    model = attempt_load(opts.model_path, cfg=opts.model_cfg, nc=opts.nc, img_size=img_size)
+    stride = int(model.stride.max())
+    opts.img_size = check_img_size(img_size, s=stride)
+    synthetic = opts.dataset == 'synthetic'
+    if synthetic:
+        seqs = ['synthetic-%03d' % i for i in range(opts.synthetic_seqs)]
+    else:
+        if opts.data_format != 'origin':
+            raise NotImplementedError
+        DATA_ROOT = os.path.join(DATASET_ROOT, cfgs.get('SEQ_SUBDIR', 'VisDrone2019-MOT-test-dev/sequences'))
+        seqs = sorted(os.listdir(DATA_ROOT))
+        seqs = [s for s in seqs if s not in IGNORE_SEQS]
+        if None not in CERTAIN_SEQS:
+            seqs = CERTAIN_SEQS
+    print(f'Seqs will be evalueated, total{len(seqs)}:')
+    print(seqs)
+    folder_name = strftime("%Y-%d-%m %H:%M:%S", gmtime())[5:-3].replace('-', '_').replace(' ', '_').replace(':', '_')
+    folder_name = opts.tracker + '_' + folder_name
+    for si, seq in enumerate(seqs):
+        print(f'--------------tracking seq {seq}--------------')
+        if synthetic:
+            loader = tracker_dataloader.SyntheticLoader(opts.synthetic_frames, opts.synthetic_objs, opts.img_size, si)
+        else:
+            loader = tracker_dataloader.TrackerLoader(os.path.join(DATA_ROOT, seq), opts.img_size, opts.data_format, seq,
+                                                      pre_process_method='v7', model_stride=stride)
+        data_loader = torch.utils.data.DataLoader(loader, batch_size=1)
+        tracker = TRACKER_DICT[opts.tracker](opts, frame_rate=30, gamma=opts.gamma)
+        results, frame_id, i = [], 0, 0
+        for i, (img, img0) in enumerate(data_loader):
+            timer.tic()
+            if not i % opts.detect_per_frame:
+                out = model(img.cuda())[0]
+                img0 = img0.squeeze(0)
+                out = post_process_v7(out, img_size=img.shape[2:], ori_img_size=img0.shape)
+                if opts.synthetic_dets and synthetic:
+                    out = torch.from_numpy(loader.dets[i])          # the scene's detections stand in for a trained detector
+                current_tracks = tracker.update(out, img0)
+            else:
+                current_tracks = tracker.update_without_detection(None, img0)
+            cur_tlwh, cur_id, cur_cls = [], [], []
+            for trk in current_tracks:
+                bbox = trk.tlwh
+                if bbox[2] * bbox[3] > opts.min_area:
+                    cur_tlwh.append(bbox)
+                    cur_id.append(trk.track_id)
+                    cur_cls.append(trk.cls)
+            results.append((frame_id + 1, cur_id, cur_tlwh, cur_cls))
+            timer.toc()
+            frame_id += 1
+        seq_fps.append(i / timer.total_time)   # track.py:181 (sic: last index, not the frame count)
+        timer.clear()
+        save_results(opts.results_root, folder_name, seq, results)
+    print(f'average fps: {np.mean(seq_fps)}')
+    return os.path.join(opts.results_root, folder_name)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--dataset', type=str, default='visdrone', help='visdrone, or mot')
+    parser.add_argument('--data_format', type=str, default='origin', help='format of reading dataset')
+    parser.add_argument('--det_output_format', type=str, default='yolo', help='data format of output of detector, yolo or other')
+    parser.add_argument('--tracker', type=str, default='sort', help='sort, deepsort, etc')
+    parser.add_argument('--model_path', type=str, default='./weights/best.pt', help='model path')
+    parser.add_argument('--trace', type=bool, default=False, help='traced model of YOLO v7')
+    parser.add_argument('--img_size', nargs='+', type=int, default=1280, help='[train, test] image sizes')
+    parser.add_argument('--reid_model_path', type=str, default='./weights/ckpt.t7', help='path for reid model path')
+    parser.add_argument('--dhn_path', type=str, default='./weights/DHN.pth', help='path of DHN path for DeepMOT')
+    parser.add_argument('--conf_thresh', type=float, default=0.2, help='filter tracks')
+    parser.add_argument('--nms_thresh', type=float, default=0.7, help='thresh for NMS')
+    parser.add_argument('--iou_thresh', type=float, default=0.5, help='IOU thresh to filter tracks')
+    parser.add_argument('--track_buffer', type=int, default=30, help='tracking buffer')
+    parser.add_argument('--gamma', type=float, default=0.1, help='param to control fusing motion and apperance dist')
+    parser.add_argument('--kalman_format', type=str, default='default', help='use what kind of Kalman, default, naive, strongsort or bot-sort like')
+    parser.add_argument('--min_area', type=float, default=150, help='use to filter small bboxs')
+    parser.add_argument('--save_images', action='store_true', help='save tracking results (image)')
+    parser.add_argument('--save_videos', action='store_true', help='save tracking results (video)')
+    parser.add_argument('--detect_per_frame', type=int, default=1, help='choose how many frames per detect')
+    parser.add_argument('--track_eval', type=bool, default=True, help='Use TrackEval to evaluate')
+    # additions (defaults keep the reference's behaviour)
+    parser.add_argument('--model_cfg', type=str, default=None, help='model yaml / arch name for state-dict checkpoints')
+    parser.add_argument('--nc', type=int, default=None)
+    parser.add_argument('--synthetic_dets', action='store_true', help='--dataset synthetic: feed the scene detections to the tracker')
+    parser.add_argument('--synthetic_frames', type=int, default=100)
+    parser.add_argument('--synthetic_objs', type=int, default=80)
+    parser.add_argument('--synthetic_seqs', type=int, default=1)
+    parser.add_argument('--results_root', type=str, default='./tracker/results')
+    return parser
+
+
+def cli(argv=None):
+    opts = build_parser().parse_args(argv)
+    if opts.dataset == 'synthetic':
+        cfgs = {'DATASET_ROOT': '', 'CERTAIN_SEQS': [None], 'IGNORE_SEQS': [None], 'CATEGORY_DICT': {}, 'YAML_DICT': ''}
+    else:
+        path = f'./tracker/config_files/{opts.dataset}.yaml'
+        if not os.path.isfile(path):
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'config_files', f'{opts.dataset}.yaml')
+        with open(path, 'r') as f:
+            cfgs = yaml.load(f, Loader=yaml.FullLoader)
+    return main(opts, cfgs)
+
+
+if __name__ == '__main__':
+    cli()
