@@ -1,0 +1,43 @@
+"""per-layer micro-benchmark of the conv launch list (w6 @ 1280, B frames): time every distinct conv shape in isolation
+(HIP events, N reps), print TFLOP/s and algorithmic GB/s."""
+import sys, ctypes, collections
+import numpy as np, torch
+sys.path.insert(0, ".")
+from yolov7_tracker_amd import _lib
+from yolov7_tracker_amd.detector import arch, graph
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+L = _lib.load()
+plan = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, B)
+shapes = collections.OrderedDict()
+for op in plan.ops:
+    if op["type"] != 0: continue
+    key = tuple(int(op[k]) for k in ("H", "W", "Cin", "Cout", "Cout_pad", "KH", "stride", "pad", "out_f32", "in_ld", "out_ld"))
+    shapes.setdefault(key, 0); shapes[key] += 1
+zeros = torch.zeros(256, dtype=torch.float16, device="cuda")
+tot_t = tot_f = 0.0
+print("%-34s %3s %9s %8s %8s %8s" % ("shape (HxW Cin->Cout k/s)", "x", "us", "TF/s", "GB/s", "blocks"))
+for key, cnt in shapes.items():
+    H, W, Cin, Cout, Cout_pad, k, s, pad, f32, in_ld, out_ld = key
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    K = k * k * Cin; K_pad = (K + 63) // 64 * 64
+    x = torch.randn((B, H, W, in_ld), device="cuda").half()
+    w = (torch.randn((Cout_pad, K_pad), device="cuda") / K ** 0.5).half()
+    b = torch.randn(Cout_pad, device="cuda")
+    out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
+    def run():
+        _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), in_ld, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), out_ld, 0, f32, Cout, Cout_pad,
+                                         k, k, s, pad, 1, _lib.ptr(zeros), _lib.stream_ptr()))
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 2.0 * B * Ho * Wo * Cout * k * k * Cin
+    byts = B * (H * W * Cin * 2 + Ho * Wo * Cout * (4 if f32 else 2)) + Cout * K * 2
+    bn = 128 if Cout_pad % 128 == 0 else 64
+    blocks = ((B * Ho * Wo + 127) // 128) * (Cout_pad // bn)
+    tot_t += us * cnt; tot_f += flops * cnt
+    print("%4dx%-4d %4d->%-4d %d/%d ld%d->%d %3d %9.1f %8.1f %8.0f %8d" % (H, W, Cin, Cout, k, s, in_ld, out_ld, cnt, us, flops / us / 1e6, byts / us / 1e3, blocks))
+print("TOTAL %.3f ms per %d frames  ->  %.1f TFLOP/s" % (tot_t / 1e3, B, tot_f / tot_t / 1e6))

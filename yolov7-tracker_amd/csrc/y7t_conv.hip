@@ -6,12 +6,14 @@
 //
 // GEMM view:  D[n][m] = sum_k Wp[n][k] * X[m][k]      n = output channel, m = output pixel (b, ho, wo),
 //             k = (kh*KW + kw)*Cin + ci  -- the im2col matrix X is never built: each 16-byte K-chunk of a
-//             pixel row is fetched straight from the NHWC tensor (8 consecutive channels of one tap), or from a
-//             zero page when the tap falls into the padding / the row is past M / k is past K.
+//             pixel row is fetched straight from the NHWC tensor (8 consecutive channels of one tap); a chunk whose tap
+//             falls into the padding / whose row is past M / whose k is past K is an out-of-range buffer offset.
 // Tiling:     256 threads = 4 waves (2 along n x 2 along m); block tile BN x BM, K-step 64 (128-byte rows);
-//             both operands staged through LDS with `global_load_lds` (16 B per lane, lane-linear destination),
+//             both operands staged through LDS with `buffer_load_dwordx4 ... lds` (16 B per lane DMA, lane-linear
+//             destination, hardware range check supplies the zeros of padding taps / ragged edges),
 //             double-buffered: the loads of K-step t+1 are in flight while the MFMAs of step t run; one barrier
-//             per K-step.  LDS rows are XOR-swizzled at 16-byte granularity (slot = chunk ^ (row & 7)) -- applied
+//             per K-step.  LDS rows are XOR-swizzled at 16-byte granularity (slot = chunk ^ ((row >> 1) & 7): two 128-byte rows
+//             fill one 256-byte bank row, so every 16-lane service group of ds_read_b128 touches 16 distinct slots) -- applied
 //             to the per-lane SOURCE address on the way in and to the ds_read address on the way out.
 //             The weight operand goes to MFMA's A side so that each lane ends up holding 4 consecutive output
 //             channels of ONE pixel: the epilogue (bias + SiLU/LeakyReLU) packs them into one 8-byte NHWC store.
@@ -19,6 +21,7 @@
 //             so producers write straight into their slot of a concat buffer and consumers read slices.
 #include "y7t_common.h"
 #include "y7t_det.h"
+#include <stdlib.h>
 
 typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
@@ -28,79 +31,113 @@ typedef __attribute__((ext_vector_type(16))) float floatx16;
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-__device__ __forceinline__ void load16_to_lds(const void* gptr, void* lds_wave_base) {
-    // global -> LDS DMA, 16 bytes per lane; destination = wave-uniform base + lane*16
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gptr, (LDS_AS void*)lds_wave_base, 16, 0, 0);
-}
-
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == Y7T_ACT_SILU) return v / (1.0f + __expf(-v));
     if (act == Y7T_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
     return v;
 }
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256) k_conv_igemm(const Y7TConvArgs p) {
-    constexpr int BK = 64;                       // halfs per K-step (128-byte LDS rows)
+template <int BM, int BN, int BK, int NST, bool UT>
+__global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
+    constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
+    constexpr int CPR = BK / 8;                  // 16-byte chunks per row (8 or 4)
+    constexpr int RPW = 64 / CPR;                // rows covered by one wave-wide 1 KiB DMA (8 or 16)
+    constexpr int RPR = RPW * 4;                 // rows per load round over the 4 waves (32 or 64)
     constexpr int WTN = BN / 2, WTM = BM / 2;    // wave tile
     constexpr int TN = WTN / 32, TM = WTM / 32;  // 32x32 MFMA tiles per wave
-    constexpr int RM = BM / 32, RN = BN / 32;    // load rounds (32 rows per round over 4 waves)
-    constexpr int STAGE = (BM + BN) * 128;       // bytes per LDS stage
+    constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
+    constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
+    constexpr int STAGE = (BM + BN) * ROWB;      // bytes per LDS stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
-    // XCD-aware tile order: consecutive blocks of one XCD walk the m-tiles of one n-panel (weights stay in that L2)
     const int n_tiles_m = (p.M + BM - 1) / BM;
-    const int bid = blockIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order), so give every XCD a CONTIGUOUS range of
+    // tiles -- neighbouring pixel tiles share halo rows and the same weight panel in that XCD's private 4 MiB L2
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tile_m = bid % n_tiles_m, tile_n = bid / n_tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread load geometry ----
-    const int lrow = wave * 8 + (lane >> 3);       // row inside a 32-row round
-    const int gchunk = (lane & 7) ^ (lane >> 3);   // global 16-byte chunk this lane fetches (XOR swizzle)
-    long long xbase[RM];                           // element offset of (b, hi0, wi0, cin_off) or < 0 when the row is invalid
-    int xhi0[RM], xwi0[RM];
+    // Buffer descriptors (raw, 32-bit byte offsets): a lane whose tap falls into the padding, whose row is past M
+    // or whose k is past K gets offset 0xffffffff -> the hardware range check returns zeros into LDS, so there is
+    // no zero page and no 64-bit address arithmetic in the K loop.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---- per-thread load geometry.  LDS slot of logical chunk c in row r:  c ^ sw(r),
+    //      sw(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows (conflict-free ds_read_b128) ----
+    const int lrow = wave * RPW + lane / CPR;      // row inside a load round
+    const int gchunk = (lane % CPR) ^ (BK == 64 ? ((lrow >> 1) & 7) : ((lrow >> 2) & 3));
+    int xoff[RM];          // byte offset of (b, hi0, wi0, cin_off [+ this lane's chunk]) -- may be negative before the tap is added
+    unsigned vmask[RM];    // bit t: tap t of this row is inside the image
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
-        const int m = m0 + r * 32 + lrow;
+        const int m = m0 + r * RPR + lrow;
+        vmask[r] = 0;
+        xoff[r] = 0;
         if (m < p.M) {
-            const int b = m / (p.Ho * p.Wo), rem = m - b * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            xhi0[r] = ho * p.stride - p.pad;
-            xwi0[r] = wo * p.stride - p.pad;
-            xbase[r] = (((long long)b * p.H + xhi0[r]) * p.W + xwi0[r]) * p.ldin + p.cin_off;
-        } else {
-            xhi0[r] = -(1 << 28); xwi0[r] = -(1 << 28); xbase[r] = 0;
+            // m -> (b, ho, wo) with a float reciprocal + one-step fix-up (M < 2^24), no integer division
+            int b = (int)((float)m * inv_howo);
+            b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
+            const int rem = m - b * HoWo;
+            int ho = (int)((float)rem * inv_wo);
+            ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
+            const int wo = rem - ho * p.Wo;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + (UT ? gchunk * 8 : 0)) * 2;
+            // taps inside the image: kh in [klo, khi], kw in [wlo, whi]
+            const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
+            const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
+            const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                if (kh >= klo && kh <= khi) vmask[r] |= colbits << (kh * p.KW);
         }
     }
-    const half_t* wrow[RN];
+    int woff[RN];
 #pragma unroll
-    for (int r = 0; r < RN; ++r) wrow[r] = p.w + (size_t)(n0 + r * 32 + lrow) * p.K_pad + gchunk * 8;
+    for (int r = 0; r < RN; ++r) woff[r] = ((n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
 
-    int k = gchunk * 8;          // this lane's k index for the current K-step
+    // k bookkeeping of the next stage to load: uniform (scalar) when every K-step lies inside one tap (Cin % BK == 0)
+    int k = UT ? 0 : gchunk * 8;
     int tap = k / p.Cin, ci = k - tap * p.Cin;
     const int nk = p.K_pad / BK;
 
-    auto issue_loads = [&](int stage, int kt) {
+    // one DMA of the stage being filled: idx in [0, NLD): first the RM pixel-row rounds, then the RN weight rounds.
+    // tap/ci/k describe that stage; advance_k() moves them to the following stage.
+    auto issue_one = [&](int stage, int kt, int idx) {
         char* xs = smem + stage * STAGE;
-        char* ws = xs + BM * 128;
-        const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;   // tap / 3 for tap < 128
-        const int kw = tap - kh * p.KW;
-        const bool kvalid = (k < p.K);
-        const long long tapoff = ((long long)kh * p.W + kw) * p.ldin + ci;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int hi = xhi0[r] + kh, wi = xwi0[r] + kw;
-            const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const half_t* src = ok ? p.in + xbase[r] + tapoff : p.zeros;
-            load16_to_lds(src, xs + (r * 32 + wave * 8) * 128);
+        char* ws = xs + BM * ROWB;
+        if (idx < RM) {
+            const int r = idx;
+            const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;   // tap / 3 for tap < 128
+            const int kw = tap - kh * p.KW;
+            const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
+            const bool kvalid = UT ? true : (k < p.K);            // UT: a tap index past KH*KW has no mask bit
+            const bool ok = kvalid && ((vmask[r] >> tap) & 1u);
+            const int voff = ok ? xoff[r] + tapoff : -1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * RPR + wave * RPW) * ROWB), 16, voff, 0, 0, 0);
+        } else {
+            const int r = idx - RM;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r], kt * BK * 2, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < RN; ++r) load16_to_lds(wrow[r] + (size_t)kt * BK, ws + (r * 32 + wave * 8) * 128);
-        // advance this lane's k by one K-step
+    };
+    auto advance_k = [&]() {
         k += BK; ci += BK;
         while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+    };
+    auto issue_loads = [&](int stage, int kt) {
+#pragma unroll
+        for (int idx = 0; idx < NLD; ++idx) issue_one(stage, kt, idx);
+        advance_k();
     };
 
     floatx16 acc[TN][TM];
@@ -111,60 +148,95 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const Y7TConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue_loads(0, 0);
-    const int l31 = lane & 31, hi32 = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        __syncthreads();   // (vmcnt(0) + barrier): stage `cur` has landed for everyone, stage cur^1 is free
-        if (kt + 1 < nk) issue_loads(cur ^ 1, kt + 1);
-        const char* xs = smem + cur * STAGE;
-        const char* ws = xs + BM * 128;
+    // prologue: NST-1 stages in flight
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+    for (int s = 0; s < NST - 1; ++s) if (s < nk) issue_loads(s, s);
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    int cur = 0, nxt = NST - 1;      // ring positions of stage kt and of stage kt+NST-1
+    for (int kt = 0; kt < nk; ++kt) {
+        // wait until THIS wave's DMAs of stage kt have landed (the younger stages stay in flight), then barrier:
+        // after it every wave's part of stage kt is visible and nobody still reads the buffer we are about to refill
+        const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+        if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool do_load = (kt + NST - 1 < nk) && !(p.ablate & 1);
+        const char* xs = smem + cur * STAGE;
+        const char* ws = xs + BM * ROWB;
+        if (p.ablate & 4) { if (do_load) issue_loads(nxt, kt + NST - 1); cur = (cur + 1 == NST) ? 0 : cur + 1; nxt = (nxt + 1 == NST) ? 0 : nxt + 1; continue; }
+        constexpr int KS = BK / 16;                 // MFMA k-substeps per stage
+        constexpr int LPK = (NLD + KS - 1) / KS;    // DMAs issued behind each substep's MFMAs (spreads them over the stage)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
             const int q = ks * 2 + hi32;   // logical 16-byte chunk of this lane group
             half8 wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int row = wn * WTN + i * 32 + l31;
-                wf[i] = *(const half8*)(ws + row * 128 + ((q ^ (row & 7)) << 4));
+                const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                wf[i] = *(const half8*)(ws + row * ROWB + (sl << 4));
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int row = wm * WTM + j * 32 + l31;
-                xf[j] = *(const half8*)(xs + row * 128 + ((q ^ (row & 7)) << 4));
+                const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                xf[j] = *(const half8*)(xs + row * ROWB + (sl << 4));
             }
+            if (p.ablate & 2) {   // ablation: keep the fragment reads alive, skip the MFMAs
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[i]));
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+            if (do_load) {
+#pragma unroll
+                for (int t = 0; t < LPK; ++t)
+                    if (ks * LPK + t < NLD) issue_one(nxt, kt + NST - 1, ks * LPK + t);
+            }
         }
+        if (do_load) advance_k();
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
 
-    // ---- epilogue: bias + activation, 4 consecutive channels per lane -> one NHWC store ----
+    if (p.ablate & 8) {   // ablation: no epilogue (keep the accumulators alive)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // ---- epilogue: bias + activation.  A lane holds channels n..n+3 of its pixel for each group g (n = 8g + 4*hi32);
+    // v_permlane32_swap between groups g and g+1 gives lanes 0-31 channels 8g..8g+7 and lanes 32-63 channels
+    // 8(g+1)..8(g+1)+7 of their pixel -> one 16-byte NHWC store per lane per group pair ----
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm * WTM + j * 32 + l31;
-        if (m >= p.M) continue;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
+            const int nb = n0 + wn * WTN + i * 32;
+            if (p.out_f32 || (p.Cout & 7) || (p.ldout & 7) || (p.cout_off & 7)) {   // direct path (Detect heads: fp32, Cout = 3*(5+nc))
+                if (m >= p.M) continue;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi32;
-                if (n >= p.Cout) continue;
-                float v[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g + 4 * hi32;
+                    if (n >= p.Cout) continue;
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
-                const size_t o = (size_t)m * p.ldout + p.cout_off + n;
-                if (p.out_f32) {
-                    float* op = (float*)p.out + o;
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    const size_t o = (size_t)m * p.ldout + p.cout_off + n;
+                    if (p.out_f32) {
+                        float* op = (float*)p.out + o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < p.Cout) op[e] = v[e];
-                } else {
-                    half_t* op = (half_t*)p.out + o;
-                    if (n + 3 < p.Cout) {
-                        half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *(half4*)op = h;
+                        for (int e = 0; e < 4; ++e) if (n + e < p.Cout) op[e] = v[e];
                     } else {
+                        half_t* op = (half_t*)p.out + o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) if (n + e < p.Cout) op[e] = (half_t)v[e];
                     }
@@ -172,21 +244,88 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const Y7TConvArgs p) {
             }
         }
     }
+    if (p.out_f32 || (p.Cout & 7) || (p.ldout & 7) || (p.cout_off & 7)) return;
+    // fp16 path: transpose the tile through LDS so that every pixel's BN channels leave as full 128/256-byte lines.
+    // Row stride BN*2 + 16 bytes: the 8-lane service groups of ds_write_b128 land on disjoint banks.
+    constexpr int OROW = BN * 2 + 16;
+    __syncthreads();          // every wave is done with the staging buffers
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int pix = wm * WTM + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nl = wn * WTN + i * 32;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned w[2][2];   // [group of the pair][2 packed half2]
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = gp * 2 + gg;
+                    const int n = n0 + nl + 8 * g + 4 * hi32;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                    w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                    w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                }
+                // v_permlane32_swap: lanes 0-31 end up with channels 8gA..8gA+7, lanes 32-63 with 8gB..8gB+7 of their pixel
+                auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+                uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                *(uint4v*)(smem + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+        constexpr int CPP = BN / 8;                 // 16-byte chunks per pixel
+        constexpr int NCH = BM * CPP;
+        half_t* outp = (half_t*)p.out;
+#pragma unroll 4
+        for (int c = tid; c < NCH; c += 256) {
+            const int pix = c / CPP, ch = c - pix * CPP;
+            const int m = m0 + pix, n = n0 + ch * 8;
+            if (m < p.M && n < p.Cout) {
+                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
+                *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+            }
+        }
+    }
+#endif
 }
 
-template <int BM, int BN>
-static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
-    constexpr unsigned lds = 2 * (BM + BN) * 128;
+template <int BM, int BN, int BK, int NST, bool UT>
+static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
+    constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
+    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
+
+template <int BM, int BN, int BK, int NST>
+static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
+    // uniform-tap specialisation: every K-step of BK channels lies inside one filter tap
+    return (a.Cin % BK == 0) ? launch_conv_ut<BM, BN, BK, NST, true>(a, s) : launch_conv_ut<BM, BN, BK, NST, false>(a, s);
+}
+
+static int conv_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("Y7T_CONV_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s);
 
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     if (a.Cin % 8 || a.ldin % 8 || a.cin_off % 8 || a.K_pad % 64 || a.Cout_pad % 64 || (!a.out_f32 && (a.ldout % 4 || a.cout_off % 4))) {
@@ -195,6 +334,27 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
         return Y7T_E_ARG;
     }
     if (a.KW != 1 && a.KW != 3) { y7t_set_error("conv: kernel width %d unsupported (1 or 3)", a.KW); return Y7T_E_ARG; }
-    if (a.Cout_pad % 128 == 0) return launch_conv<128, 128>(a, s);
-    return launch_conv<128, 64>(a, s);
+    if ((long long)a.B * a.H * a.W * a.ldin * 2 >= (1ll << 31) || (long long)a.Cout_pad * a.K_pad * 2 >= (1ll << 31)) {
+        y7t_set_error("conv: tensor exceeds the 2 GiB range of 32-bit buffer offsets (B=%d H=%d W=%d ld=%d)", a.B, a.H, a.W, a.ldin);
+        return Y7T_E_ARG;
+    }
+    Y7TConvArgs b = a;
+    b.in_bytes = (unsigned)((long long)a.B * a.H * a.W * a.ldin * 2);
+    b.w_bytes = (unsigned)((long long)a.Cout_pad * a.K_pad * 2);
+    { static int xs = -1; if (xs < 0) { const char* e = getenv("Y7T_CONV_XCD"); xs = e ? atoi(e) : 1; } b.xcd_swizzle = xs; }
+    { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
+    return conv_dispatch(b, s);
+}
+
+static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+    const bool wide = a.Cout_pad % 128 == 0;
+    switch (conv_variant()) {
+    case 1: return wide ? launch_conv<128, 128, 64, 3>(a, s) : launch_conv<128, 64, 64, 3>(a, s);
+    case 2: return wide ? launch_conv<128, 128, 32, 3>(a, s) : launch_conv<128, 64, 32, 3>(a, s);
+    case 3: return wide ? launch_conv<128, 128, 32, 4>(a, s) : launch_conv<128, 64, 32, 4>(a, s);
+    case 4: return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+    case 5: return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
+    case 6: return wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
+    default: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
+    }
 }

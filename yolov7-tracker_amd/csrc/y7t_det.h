@@ -18,7 +18,10 @@ struct Y7TConvArgs {
     int K, K_pad;        // K = KH*KW*Cin, K_pad = round_up(K, 64)
     int M;               // B*Ho*Wo
     int act;
-    const _Float16* zeros;  // >= 16 bytes of zeros (padding taps read from here)
+    const _Float16* zeros;  // unused (kept for ABI stability of y7t_conv2d_nhwc_f16)
+    unsigned in_bytes, w_bytes;
+    int xcd_swizzle;
+    int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)
 };
 
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);
