@@ -27,3 +27,23 @@ for nobj, nf in ((80, 300), (500, 60)):
         for d in ddev: t._launch(d)
         e1.record(); torch.cuda.synchronize()
         print("n_obj=%d threads=%d  update() latency %.1f us/frame   kernel-only %.1f us/frame" % (nobj, threads, lat * 1e6, e0.elapsed_time(e1) * 1e3 / nf))
+
+# phase breakdown of one step (shader-clock stamps written by thread 0)
+names = ["setup+lists", "multi_predict", "dets+gather", "assoc1 (IoU+LAP)", "apply1", "lists2", "assoc2", "apply2+lists", "assoc3", "apply3+new+age", "finish"]
+for nobj in (80, 500):
+    dets = synth.make_detections(40, nobj, seq_idx=0)
+    BaseTrack._count = 0
+    t = ByteTrack(opts(max_tracks=1024, max_dets=1024))
+    acc = np.zeros(11)
+    for i, d in enumerate(dets):
+        t.update(d, None)
+        off = t._layout["hdr_prof"]
+        p = t._state[off:off + 32 * 8].view(torch.int64).cpu().numpy()
+        if i >= 10:
+            acc += np.diff(p[:12])
+            lap = lap + np.r_[np.diff(p[16:21]), p[22]] if i > 10 else np.r_[np.diff(p[16:21]), p[22]].astype(float)
+    acc /= (len(dets) - 10)
+    print("n_obj=%d  total %.0f kcycles: " % (nobj, acc.sum() / 1e3) + ", ".join("%s %.0f" % (n, v / 1e3) for n, v in zip(names, acc)))
+    lap /= (len(dets) - 10)
+    print("   assoc1 raw stamps (kcycles rel. to PROF3): cost-start %.0f cost-end %.0f solve-start %.0f solve-end %.0f post %.0f | assoc end %.0f" % tuple((pp - p[3]) / 1e3 for pp in (p[24], p[25], p[16], p[20], p[26], p[4])))
+    print("   (LAP#1 = solve-end - solve-start of the reduced shortest-augmenting-path solver)")

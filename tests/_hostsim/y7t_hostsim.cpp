@@ -30,10 +30,21 @@ int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
 
 void hs_lapjv(const double* cost, int nr, int nc, double limit, int* x, int* y) {
     Y7TLap L;
-    L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0;
+    L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0; L.prof = nullptr;
     void* ws = malloc(y7t_lap_ws_bytes(L.n) + 64);
     y7t_lap_bind(L, ws, L.n);
     y7t_lap_solve(hs_ex(), L);
+    for (int i = 0; i < nr; ++i) x[i] = L.x[i] >= nc ? -1 : L.x[i];
+    for (int j = 0; j < nc; ++j) y[j] = L.y[j] >= nr ? -1 : L.y[j];
+    free(ws);
+}
+
+void hs_lapsap(const double* cost, int nr, int nc, double limit, int* x, int* y) {
+    Y7TLap L;
+    L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0; L.prof = nullptr;
+    void* ws = malloc(y7t_lap_ws_bytes(L.n + 1) + 64);
+    y7t_lap_bind(L, ws, L.n + 1);
+    y7t_lap_solve_sap(hs_ex(), L);
     for (int i = 0; i < nr; ++i) x[i] = L.x[i] >= nc ? -1 : L.x[i];
     for (int j = 0; j < nc; ++j) y[j] = L.y[j] >= nr ? -1 : L.y[j];
     free(ws);

@@ -32,6 +32,29 @@ def test_hostsim_lapjv_equals_oracle():
         np.testing.assert_array_equal(y0, y1)
 
 
+def test_hostsim_reduced_sap_solver_equals_oracle():
+    """the reduced shortest-augmenting-path solver (the one the device uses) returns lap's assignment on problems with a
+    unique optimum -- random costs, IoU-like sparse costs, degenerate shapes"""
+    rng = np.random.default_rng(1)
+    for t in range(400):
+        nr, nc = rng.integers(1, 60, 2)
+        c = rng.random((nr, nc))
+        if t % 3 == 0:
+            c = np.where(rng.random((nr, nc)) < 0.8, 1.0, c)
+        if t % 7 == 0:
+            c = c * 0.3          # everything below the limit: dense competition
+        lim = [0.9, 0.5, 0.7][t % 3]
+        _, x0, y0 = cnative.lapjv(c, extend_cost=True, cost_limit=lim)
+        x1, y1 = hs.lapjv(c, lim, sap=True)
+        np.testing.assert_array_equal(x0, x1)
+        np.testing.assert_array_equal(y0, y1)
+    g = np.load(util.GOLDEN + "/lap_iou.npz")
+    for k in range(int(g["n_cases"])):
+        x1, y1 = hs.lapjv(1 - g["iou%d" % k], float(g["lim%d" % k]), sap=True)
+        np.testing.assert_array_equal(x1, g["x%d" % k])
+        np.testing.assert_array_equal(y1, g["y%d" % k])
+
+
 def test_hostsim_kalman_matches_reference_golden():
     kal = np.load(util.GOLDEN + "/kalman.npz")
     L = hs.lib()

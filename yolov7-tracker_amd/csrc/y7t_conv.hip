@@ -167,32 +167,40 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         if (p.ablate & 4) { if (do_load) issue_loads(nxt, kt + NST - 1); cur = (cur + 1 == NST) ? 0 : cur + 1; nxt = (nxt + 1 == NST) ? 0 : nxt + 1; continue; }
         constexpr int KS = BK / 16;                 // MFMA k-substeps per stage
         constexpr int LPK = (NLD + KS - 1) / KS;    // DMAs issued behind each substep's MFMAs (spreads them over the stage)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        // fragments are double-buffered in registers: the ds_reads of substep ks+1 are issued before the MFMAs of substep ks
+        half8 wf[2][TN], xf[2][TM];
+        auto read_frags = [&](int ks, int buf) {
             const int q = ks * 2 + hi32;   // logical 16-byte chunk of this lane group
-            half8 wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int row = wn * WTN + i * 32 + l31;
                 const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                wf[i] = *(const half8*)(ws + row * ROWB + (sl << 4));
+                wf[buf][i] = *(const half8*)(ws + row * ROWB + (sl << 4));
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int row = wm * WTM + j * 32 + l31;
                 const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                xf[j] = *(const half8*)(xs + row * ROWB + (sl << 4));
+                xf[buf][j] = *(const half8*)(xs + row * ROWB + (sl << 4));
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cb = ks & 1;
+            if (ks + 1 < KS) read_frags(ks + 1, cb ^ 1);
             if (p.ablate & 2) {   // ablation: keep the fragment reads alive, skip the MFMAs
 #pragma unroll
-                for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[i]));
+                for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[cb][i]));
 #pragma unroll
-                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[j]));
+                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[cb][j]));
             } else {
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
             if (do_load) {
 #pragma unroll
@@ -355,6 +363,11 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     case 4: return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
     case 5: return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
     case 6: return wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
-    default: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
+    case 7: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
+    default:
+        // measured per-layer (scripts/bench_conv.py): the HBM-bound 1x1 layers prefer the lighter 32-deep stages (4 blocks/CU),
+        // the 3x3 layers the 64-deep ones
+        if (a.KH == 1) return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+        return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     }
 }

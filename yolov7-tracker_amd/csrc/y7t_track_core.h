@@ -66,13 +66,52 @@ Y7T_FN void y7t_sync(const Y7TExec&) {
 
 Y7T_FN bool y7t_lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }
 
+#if Y7T_DEVICE
+// ---- wave64 reductions on the DPP crossbar (no LDS round trips): row_shr 1/2/4/8 inside each 16-lane row, then
+//      row_bcast:15 / row_bcast:31 carry the row totals up; lane 63 ends with the full result, broadcast by readlane ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int y7t_dpp_i(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double y7t_dpp_d(double identity, double v) {
+    const long long iv = __builtin_bit_cast(long long, v), id = __builtin_bit_cast(long long, identity);
+    const int lo = __builtin_amdgcn_update_dpp((int)id, (int)iv, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(id >> 32), (int)(iv >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double y7t_wave_min_d(double v) {
+    const double inf = HUGE_VAL;
+    v = fmin(v, y7t_dpp_d<0x111, 0xf>(inf, v));
+    v = fmin(v, y7t_dpp_d<0x112, 0xf>(inf, v));
+    v = fmin(v, y7t_dpp_d<0x114, 0xf>(inf, v));
+    v = fmin(v, y7t_dpp_d<0x118, 0xf>(inf, v));
+    v = fmin(v, y7t_dpp_d<0x142, 0xa>(inf, v));
+    v = fmin(v, y7t_dpp_d<0x143, 0xc>(inf, v));
+    const long long r = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)r, 63), hi = __builtin_amdgcn_readlane((int)(r >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int y7t_wave_min_i(int v) {
+    const int big = 0x7fffffff;
+    int t;
+    t = y7t_dpp_i<0x111, 0xf>(big, v); v = t < v ? t : v;
+    t = y7t_dpp_i<0x112, 0xf>(big, v); v = t < v ? t : v;
+    t = y7t_dpp_i<0x114, 0xf>(big, v); v = t < v ? t : v;
+    t = y7t_dpp_i<0x118, 0xf>(big, v); v = t < v ? t : v;
+    t = y7t_dpp_i<0x142, 0xa>(big, v); v = t < v ? t : v;
+    t = y7t_dpp_i<0x143, 0xc>(big, v); v = t < v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
+
 // all-reduce: lexicographic minimum of (v, i) over the workgroup; every thread gets the result
 Y7T_FN void y7t_argmin(const Y7TExec& ex, double& v, int& i) {
 #if Y7T_DEVICE
-    for (int off = 32; off; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(i, off);
-        if (y7t_lex_less(ov, oi, v, i)) { v = ov; i = oi; }
+    {
+        const double m = y7t_wave_min_d(v);
+        const int mi = y7t_wave_min_i(v == m ? i : 0x7fffffff);
+        v = m; i = mi;
     }
     if (ex.nt > 64) {
         const int w = ex.tid >> 6, nw = ex.nt >> 6;
@@ -99,11 +138,16 @@ Y7T_FN void y7t_min2_push(Y7TMin2& m, double v, int i) {
 }
 Y7T_FN void y7t_min2(const Y7TExec& ex, Y7TMin2& m) {
 #if Y7T_DEVICE
-    for (int off = 32; off; off >>= 1) {
-        const double a1 = __shfl_xor(m.v1, off), a2 = __shfl_xor(m.v2, off);
-        const int b1 = __shfl_xor(m.i1, off), b2 = __shfl_xor(m.i2, off);
-        y7t_min2_push(m, a1, b1);
-        y7t_min2_push(m, a2, b2);
+    {
+        // best pair of the wave, then the best pair once the winner is removed from the lane that owned it
+        const double b1 = y7t_wave_min_d(m.v1);
+        const int j1 = y7t_wave_min_i(m.v1 == b1 ? m.i1 : 0x7fffffff);
+        const bool own = (m.i1 == j1) && (m.v1 == b1);
+        const double c = own ? m.v2 : m.v1;
+        const int ci = own ? m.i2 : m.i1;
+        const double b2 = y7t_wave_min_d(c);
+        const int j2 = y7t_wave_min_i(c == b2 ? ci : 0x7fffffff);
+        m.v1 = b1; m.i1 = j1; m.v2 = b2; m.i2 = j2;
     }
     if (ex.nt > 64) {
         const int w = ex.tid >> 6, nw = ex.nt >> 6;
@@ -122,11 +166,8 @@ Y7T_FN void y7t_min2(const Y7TExec& ex, Y7TMin2& m) {
 // all-reduce of two independent integer minima
 Y7T_FN void y7t_imin2(const Y7TExec& ex, int& a, int& b) {
 #if Y7T_DEVICE
-    for (int off = 32; off; off >>= 1) {
-        const int oa = __shfl_xor(a, off), ob = __shfl_xor(b, off);
-        a = oa < a ? oa : a;
-        b = ob < b ? ob : b;
-    }
+    a = y7t_wave_min_i(a);
+    b = y7t_wave_min_i(b);
     if (ex.nt > 64) {
         const int w = ex.tid >> 6, nw = ex.nt >> 6;
         __syncthreads();
@@ -382,6 +423,7 @@ struct Y7TLap {
     double half;
     int *x, *y, *fr, *pred, *st, *cnt;  // n each
     double *v, *d;                      // n each
+    long long* prof;                    // optional phase stamps (diagnostics)
 };
 
 Y7T_FN double y7t_lap_cost(const Y7TLap& L, int i, int j) {
@@ -400,9 +442,16 @@ Y7T_FN void y7t_lap_bind(Y7TLap& L, void* ws, int n) {
 }
 
 // returns nothing; fills L.x[0..n), L.y[0..n) with the square solution of the extended problem
+#if Y7T_DEVICE
+#define Y7T_LPROF(i) do { if (L.prof && ex.tid == 0) L.prof[i] = clock64(); } while (0)
+#else
+#define Y7T_LPROF(i) do { } while (0)
+#endif
+
 Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
     const int n = L.n, tid = ex.tid, nt = ex.nt;
     if (n <= 0) return;
+    Y7T_LPROF(0);
     // ---- column reduction (lap: _ccrrt_dense) ----
     for (int j = tid; j < n; j += nt) {
         double best = Y7T_LARGE;
@@ -419,6 +468,7 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
     y7t_sync(ex);
     for (int j = tid; j < n; j += nt) if (L.x[L.y[j]] != j) L.y[j] = -1;
     y7t_sync(ex);
+    Y7T_LPROF(1);
     // free rows, ascending
     int n_free = y7t_compact(ex, n, [&](int i) { return L.x[i] < 0; }, L.fr, 0);
     // reduction transfer: rows assigned to a column that only they claimed
@@ -437,6 +487,7 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
         if (tid == 0) L.v[j] -= m;
         y7t_sync(ex);
     }
+    Y7T_LPROF(2);
     // ---- augmenting row reduction, two passes (lap: _carr_dense) ----
     for (int pass = 0; pass < 2 && n_free > 0; ++pass) {
         unsigned current = 0, rr_cnt = 0;
@@ -472,6 +523,8 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
         }
         n_free = new_free;
     }
+    Y7T_LPROF(3);
+    if (L.prof && ex.tid == 0) L.prof[6] = n_free;
     // ---- augmentation: shortest augmenting paths (lap: _ca_dense / _find_path_dense) ----
     for (int f = 0; f < n_free; ++f) {
         const int start = L.fr[f];
@@ -545,4 +598,98 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
         }
         y7t_sync(ex);
     }
+    Y7T_LPROF(4);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same optimisation problem without the dummy rows/columns.  lap's extended matrix prices every unmatched row and
+// column at limit/2, so its objective is  const + sum over matched pairs of (c_ij - limit):  a rectangular assignment
+// where a row may also take a "null" column of cost 0 that never fills up.  Shortest augmenting paths (the augmentation
+// phase of Jonker-Volgenant, started from the empty assignment with zero duals) over nr rows x (nc + 1) columns solve it
+// exactly with O(nr) Dijkstra searches that usually end after one scan -- instead of the (nr+nc)^2 problem whose
+// column/row-reduction phases are defeated by the ties among the dummies (measured on MI355X: ~10x fewer cycles).
+// Same optimum as y7t_lap_solve; identical assignment whenever that optimum is unique.
+// Work arrays: v, d (nc + 1), y, pred, st (nc + 1), x (nr) -- y7t_lap_bind(L, ws, nr + nc + 1) is large enough.
+// ---------------------------------------------------------------------------------------------
+Y7T_FN double y7t_sap_cost(const Y7TLap& L, int i, int j) { return j < L.nc ? L.c[(size_t)i * L.ld + j] - 2.0 * L.half : 0.0; }
+
+Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
+    const int nr = L.nr, nc = L.nc, ncol = nc + 1, tid = ex.tid, nt = ex.nt;
+    Y7T_LPROF(0);
+    for (int j = tid; j < ncol; j += nt) { L.v[j] = 0.0; L.y[j] = -1; }
+    for (int i = tid; i < nr; i += nt) L.x[i] = -1;
+    y7t_sync(ex);
+    for (int start = 0; start < nr; ++start) {
+        for (int j = tid; j < ncol; j += nt) {
+            L.st[j] = 0;
+            L.pred[j] = start;
+            L.d[j] = y7t_sap_cost(L, start, j) - L.v[j];
+        }
+        y7t_sync(ex);
+        int final_j = -1;
+        double mind = 0.0;
+        while (final_j < 0) {
+            double mv = HUGE_VAL;
+            int mj = 0x7fffffff;
+            for (int j = tid; j < ncol; j += nt) {
+                if (L.st[j] == 3) L.st[j] = 2;
+                if (L.st[j] == 0 && y7t_lex_less(L.d[j], j, mv, mj)) { mv = L.d[j]; mj = j; }
+            }
+            y7t_argmin(ex, mv, mj);
+            mind = mv;
+            int fin = 0x7fffffff, nxt = 0x7fffffff;
+            for (int j = tid; j < ncol; j += nt) {
+                if (L.st[j] == 0 && L.d[j] == mind) {
+                    L.st[j] = 1;
+                    if (j == nc || L.y[j] < 0) { if (j < fin) fin = j; }
+                    else if (j < nxt) nxt = j;
+                }
+            }
+            y7t_imin2(ex, fin, nxt);
+            y7t_sync(ex);
+            if (fin != 0x7fffffff) { final_j = fin; break; }
+            while (nxt != 0x7fffffff) {
+                const int jc = nxt, i = L.y[jc];
+                const double h = y7t_sap_cost(L, i, jc) - L.v[jc] - mind;
+                fin = 0x7fffffff; nxt = 0x7fffffff;
+                for (int j = tid; j < ncol; j += nt) {
+                    int sj = L.st[j];
+                    if (j == jc) { L.st[j] = 3; continue; }
+                    if (sj == 0) {
+                        const double cred = y7t_sap_cost(L, i, j) - L.v[j] - h;
+                        if (cred < L.d[j]) {
+                            L.d[j] = cred;
+                            L.pred[j] = i;
+                            if (cred == mind) {
+                                if (j == nc || L.y[j] < 0) { if (j < fin) fin = j; }
+                                else { L.st[j] = 1; sj = 1; }
+                            }
+                        }
+                    }
+                    if (sj == 1 && j < nxt) nxt = j;
+                }
+                y7t_imin2(ex, fin, nxt);
+                y7t_sync(ex);
+                if (fin != 0x7fffffff) { final_j = fin; break; }
+            }
+        }
+        for (int j = tid; j < ncol; j += nt) if (L.st[j] == 2) L.v[j] += L.d[j] - mind;
+        y7t_sync(ex);
+        if (tid == 0) {
+            int i = -1, j = final_j;
+            while (i != start) {
+                i = L.pred[j];
+                if (j != nc) L.y[j] = i;      // the null column never fills up
+                const int t = j;
+                j = L.x[i];
+                L.x[i] = t;
+            }
+        }
+        y7t_sync(ex);
+    }
+    // report like lap: x[i] = column or -1 (x == nc means "took the null column")
+    for (int i = tid; i < nr; i += nt) if (L.x[i] >= nc) L.x[i] = nc + nr;   // >= nc reads as unmatched for the callers
+    y7t_sync(ex);
+    Y7T_LPROF(4);
+}
+

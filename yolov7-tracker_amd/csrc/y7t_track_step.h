@@ -32,6 +32,7 @@ struct Y7TTrkHdr {
     int pad0, pad1;
     unsigned long long id_counter_ptr;  // device int* shared by every tracker of the process
     Y7TTrkCfg cfg;
+    long long prof[32];                 // shader-clock stamps of the last step's phases (thread 0; diagnostics)
 };
 
 // byte offsets of every array inside the state blob
@@ -104,6 +105,15 @@ Y7T_FN Y7TTrk y7t_trk_bind(void* blob, int cap_t, int cap_d) {
 
 enum { Y7T_ERR_CAP_T = 1, Y7T_ERR_CAP_D = 2, Y7T_ERR_OUT = 4 };
 
+#if !Y7T_DEVICE
+static inline long long clock64() { return 0; }
+#endif
+#if Y7T_DEVICE
+#define Y7T_PROF(h, i) do { if (ex.tid == 0) (h)->prof[i] = clock64(); } while (0)
+#else
+#define Y7T_PROF(h, i) do { } while (0)
+#endif
+
 // ---- STrack geometry -----------------------------------------------------------------------
 // tlwh of a pool track from its Kalman mean, basetrack.py:183-211 (xyah: w = a*h; tl = c - wh/2).
 // f32m: the mean still has the float32 dtype it gets from initiate under numpy>=2, so the
@@ -161,16 +171,20 @@ Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double
     }
     Y7TLap L;
     L.nr = na; L.nc = nb; L.ld = nb; L.n = na + nb; L.half = thresh / 2.0;
+    L.prof = (thresh == 0.9) ? s.h->prof + 16 : nullptr;   // stamp the first association
     const size_t ws = y7t_al(y7t_lap_ws_bytes(L.n)), cb = (size_t)na * nb * sizeof(double);
     void* lapws = s.lapws;
     double* cost = s.cost;
     size_t off = 0;
     if (ex.fast && ws <= ex.fast_bytes) { lapws = ex.fast; off = ws; }
     if (ex.fast && off + cb <= ex.fast_bytes) cost = (double*)(ex.fast + off);
+    if (L.prof && ex.tid == 0) L.prof[8] = clock64();
     y7t_cost_matrix(ex, s.ttlbr, na, s.dtlbr, nb, cost, nb);
+    if (L.prof && ex.tid == 0) L.prof[9] = clock64();
     L.c = cost;
     y7t_lap_bind(L, lapws, L.n);
-    y7t_lap_solve(ex, L);
+    y7t_lap_solve_sap(ex, L);
+    if (L.prof && ex.tid == 0) L.prof[10] = clock64();
     for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
     for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];
     y7t_sync(ex);
@@ -382,6 +396,7 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
     const int kf = cfg.kf;
     y7t_sync(ex);
+    Y7T_PROF(h, 0);
     if (ex.tid == 0) {
         h->frame_id += 1;
         h->n_act_last = h->n_refind_last = h->n_lostn_last = h->n_removed_last = 0;
@@ -400,7 +415,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     for (int k = ex.tid; k < nl0; k += ex.nt) s.pool[n_conf + k] = s.lost[k];
     y7t_sync(ex);
     const int n_pool = n_conf + nl0;
+    Y7T_PROF(h, 1);
     y7t_multi_predict(ex, s, s.pool, n_pool);
+    Y7T_PROF(h, 2);
     if (n < 0) {  // update_without_detection (basetrack.py:489-537)
         y7t_finish(ex, s, out_rows, out_cap, out_count);
         return;
@@ -428,8 +445,11 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     y7t_gather_track_tlbr(ex, s, s.pool, n_pool);
     y7t_gather_det_tlbr(ex, s, s.dhi, n_hi);
     y7t_sync(ex);
+    Y7T_PROF(h, 3);
     y7t_assoc(ex, s, n_pool, n_hi, cfg.tracker == Y7T_SORT ? cfg.iou_thresh : 0.9);
+    Y7T_PROF(h, 4);
     y7t_apply_matches(ex, s, s.pool, n_pool, s.dhi, dets, cfg.tracker == Y7T_SORT ? 1 : 0, na, nr);
+    Y7T_PROF(h, 5);
     // unmatched detections, in detection order: left = [D_high[i] for i in u_dets]
     int n_left = y7t_compact(ex, n_hi, [&](int j) { return s.ycol[j] < 0; }, s.tmpa, 0);
     for (int k = ex.tid; k < n_left; k += ex.nt) s.left[k] = s.dhi[s.tmpa[k]];
@@ -450,7 +470,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
         y7t_gather_track_tlbr(ex, s, s.rem, n_rem);
         y7t_gather_det_tlbr(ex, s, s.dlo, n_lo);
         y7t_sync(ex);
+        Y7T_PROF(h, 6);
         y7t_assoc(ex, s, n_rem, n_lo, 0.5);
+        Y7T_PROF(h, 7);
         y7t_apply_matches(ex, s, s.rem, n_rem, s.dlo, dets, 0, na, nr);
         const int nl_new = y7t_compact(ex, n_rem, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
         for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.rem[s.tmpa[k]]; s.lostn[k] = sl; s.state[sl] = Y7T_LOST; }
@@ -461,7 +483,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     y7t_gather_track_tlbr(ex, s, s.unconf, n_unc);
     y7t_gather_det_tlbr(ex, s, s.left, n_left);
     y7t_sync(ex);
+    Y7T_PROF(h, 8);
     y7t_assoc(ex, s, n_unc, n_left, cfg.tracker == Y7T_SORT ? cfg.iou_thresh + 0.1 : 0.7);
+    Y7T_PROF(h, 9);
     y7t_apply_matches(ex, s, s.unconf, n_unc, s.left, dets, cfg.tracker == Y7T_SORT ? 1 : 2, na, nr);
     {
         const int n_rm = y7t_compact(ex, n_unc, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
@@ -514,7 +538,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
         if (ex.tid == 0) h->n_removed_last = base + n_old;
         y7t_sync(ex);
     }
+    Y7T_PROF(h, 10);
     y7t_finish(ex, s, out_rows, out_cap, out_count);
+    Y7T_PROF(h, 11);
 }
 
 // initialise a state blob (single thread is enough; called once)

@@ -8,6 +8,7 @@
 #include "y7t_common.h"
 #include "y7t_track_step.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void y7t_set_error(const char* fmt, ...) {
@@ -117,10 +118,10 @@ __device__ __forceinline__ Y7TExec make_exec(unsigned fast_bytes) {
 }
 
 __global__ void k_lapjv(const double* __restrict__ cost, int nr, int nc, double limit, int* x, int* y, double* opt, void* ws_g,
-                        unsigned fast_bytes) {
+                        unsigned fast_bytes, int jv_extended) {
     const Y7TExec ex = make_exec(fast_bytes);
     Y7TLap L;
-    L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0;
+    L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0; L.prof = nullptr;
     const size_t ws = y7t_al(y7t_lap_ws_bytes(L.n)), cb = (size_t)nr * nc * sizeof(double);
     void* lapws = ws_g;
     size_t off = 0;
@@ -134,7 +135,7 @@ __global__ void k_lapjv(const double* __restrict__ cost, int nr, int nc, double 
     __syncthreads();
     L.c = c;
     y7t_lap_bind(L, lapws, L.n);
-    y7t_lap_solve(ex, L);
+    if (jv_extended) y7t_lap_solve(ex, L); else y7t_lap_solve_sap(ex, L);
     for (int i = ex.tid; i < nr; i += ex.nt) x[i] = (L.x[i] >= nc) ? -1 : L.x[i];
     for (int j = ex.tid; j < nc; j += ex.nt) y[j] = (L.y[j] >= nr) ? -1 : L.y[j];
     if (opt && ex.tid == 0) {
@@ -264,8 +265,10 @@ extern "C" int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit
     if (!attr_done) { if (int e = ensure_lds(k_lapjv, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     const int nn = n + m;
     const int threads = nn <= 128 ? 64 : (nn <= 512 ? 256 : 1024);
+    static int jv = -1;
+    if (jv < 0) { const char* e = getenv("Y7T_LAP_JV_EXTENDED"); jv = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k_lapjv, dim3(1), dim3(threads), kFastBytes + Y7T_LDS_HDR, S(stream), cost, n, m, cost_limit, x, y, opt,
-                       workspace, kFastBytes);
+                       workspace, kFastBytes, jv);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
@@ -333,7 +336,7 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
 
 static const char* kFieldNames[] = {"mean", "cov", "box", "score", "cls", "tid", "start", "frame", "tsu", "state", "act", "len",
                                     "inrem", "f32m", "tracked", "lost", "hdr_frame_id", "hdr_n_tracked", "hdr_n_lost",
-                                    "hdr_status", "hdr_n_out", "hdr_n_removed_total", "total"};
+                                    "hdr_status", "hdr_n_out", "hdr_n_removed_total", "hdr_prof", "total"};
 
 extern "C" const char* y7t_tracker_field_name(int i) {
     const int n = (int)(sizeof(kFieldNames) / sizeof(kFieldNames[0]));
@@ -346,7 +349,7 @@ extern "C" int y7t_tracker_layout(int cap_t, int cap_d, int64_t* offsets, int ma
     const Y7TTrkLayout L = y7t_trk_layout(cap_t, cap_d);
     const size_t v[] = {L.mean, L.cov, L.box, L.score, L.cls, L.tid, L.start, L.frame, L.tsu, L.state, L.act, L.len, L.inrem, L.f32m,
                         L.tracked, L.lost, offsetof(Y7TTrkHdr, frame_id), offsetof(Y7TTrkHdr, n_tracked), offsetof(Y7TTrkHdr, n_lost),
-                        offsetof(Y7TTrkHdr, status), offsetof(Y7TTrkHdr, n_out), offsetof(Y7TTrkHdr, n_removed_total), L.total};
+                        offsetof(Y7TTrkHdr, status), offsetof(Y7TTrkHdr, n_out), offsetof(Y7TTrkHdr, n_removed_total), offsetof(Y7TTrkHdr, prof), L.total};
     for (int i = 0; i < n; ++i) offsets[i] = (int64_t)v[i];
     return n;
 }
