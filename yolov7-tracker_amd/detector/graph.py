@@ -239,6 +239,26 @@ def lower(nodes, H, W, max_batch=1):
         op["KH"], op["KW"], op["stride"], op["pad"] = k, k, s, p
         ops.append(op)
 
+    # ---- twin 1x1 branches (every ELAN block starts with two 1x1 convs of the SAME tensor, cfg/deploy/yolov7-w6.yaml:20-21,
+    # 79-80, ...): their outputs sit next to each other in the concat buffer, so they run as ONE conv with stacked weights
+    # -- the largest activations are read once instead of twice ----
+    fused_into = {}     # node idx of the second twin -> first twin
+    twins = {}          # first twin idx -> [first, second] in channel order
+    by_src = {}
+    for n in nodes:
+        if n.idx in live and n.kind == "conv" and n.k == 1 and n.s == 1 and n.home is not None:
+            by_src.setdefault((n.src[0], n.act, n.home), []).append(n)
+    for key, group in by_src.items():
+        if len(group) == 2:
+            a, b = sorted(group, key=lambda t: t.coff)
+            if a.coff + a.c == b.coff and a.ld == b.ld and a.c % 8 == 0:
+                tw_first = a if a.idx < b.idx else b
+                second = b if tw_first is a else a
+                # the fused op is emitted at the position of the EARLIER node; the later one must not be consumed in between
+                # by anything that is emitted before it -- true for ELAN (its consumers come after both)
+                twins[tw_first.idx] = [a, b]
+                fused_into[second.idx] = tw_first.idx
+
     pending_copies = {}
     for j, cidx, off in extra_copies:
         pending_copies.setdefault(j, []).append((cidx, off))
@@ -248,7 +268,15 @@ def lower(nodes, H, W, max_batch=1):
         if n.kind in ("input", "reorg", "concat"):
             pass
         elif n.kind == "conv":
-            emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
+            if n.idx in fused_into:
+                continue
+            if n.idx in twins:
+                a, b = twins[n.idx]
+                fn = Node("conv", n.src, a.c + b.c, 1, 1, 0, n.act)
+                fn.h, fn.w = n.h, n.w
+                emit_conv(fn, nodes[n.src[0]], a.home, a.ld, a.coff, 0, a.c + b.c, n.act, (a.wkey, b.wkey))
+            else:
+                emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
         elif n.kind == "up":
             emit_simple(1, n, nodes[n.src[0]])
         elif n.kind == "pool":

@@ -12,11 +12,13 @@ GAIN_SILU, GAIN_LEAKY = 1.75, 1.40   # keep activation std ~O(1) through the dep
 def random_state_dict(wlayout, seed=0, fused=False):
     """Reference-style state dict ({wkey}.conv.weight / {wkey}.bn.* / model.N.m.L.{weight,bias}) with seeded values that
     keep activations O(1) through ~100 layers (so that fp16 storage is meaningful)."""
-    rng = np.random.default_rng(seed)
+    import zlib
     sd = {}
-    for w in wlayout:
+    for w0 in wlayout:
+      for w in ([dict(w0, wkey=k, cout=w0["cout"] // len(w0["wkey"])) for k in w0["wkey"]] if isinstance(w0["wkey"], tuple) else [w0]):
         cout, cin, k = w["cout"], w["cin"], w["k"]
         fan_in = cin * k * k
+        rng = np.random.default_rng([seed, zlib.crc32(w["wkey"].encode())])   # per-layer stream: independent of plan order / fusion
         if w["kind"] != "conv":   # Detect 1x1 conv: plain conv with bias
             sd[w["wkey"] + ".weight"] = torch.from_numpy(rng.normal(0, 1.0 / np.sqrt(fan_in), (cout, cin, 1, 1)).astype(np.float32))
             sd[w["wkey"] + ".bias"] = torch.from_numpy(rng.normal(0, 0.5, cout).astype(np.float32))
@@ -75,6 +77,9 @@ def calibrate_bn(nodes, sd, hw=(640, 640), seed=0):
 def folded(w, sd):
     """-> (W' float64 (cout, cin, k, k), b' float64 (cout,)) of one conv of the plan"""
     key = w["wkey"]
+    if isinstance(key, tuple):   # fused twin 1x1 convs: stack the folded weights in channel order
+        parts = [folded(dict(w, wkey=k), sd) for k in key]
+        return np.concatenate([p[0] for p in parts], 0), np.concatenate([p[1] for p in parts], 0)
     if w["kind"] == "conv":
         W = sd[key + ".conv.weight"].detach().double().cpu().numpy()
         if key + ".bn.weight" in sd:
