@@ -39,13 +39,14 @@ GFLOP_PER_FRAME_W6 = 354.9   # 177.45 GMAC x 2, yolov7-w6 deploy g
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (consecutive frames of the sequence)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step (consecutive frames of the sequence)")
     ap.add_argument("--n_obj", type=int, default=80)
     ap.add_argument("--img", type=int, default=1280)
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as a captured hipGraph")
     ap.add_argument("--cpu_frames", type=int, default=3)
     return ap.parse_args()
 
@@ -145,12 +146,21 @@ def main():
     ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
     ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
 
+    graph = None
+    if args.hipgraph:
+        with torch.cuda.stream(sA):
+            graph, _, _ = det.capture(frames, 0.01, 0.45, None)
+
     def step(s):
         with torch.cuda.stream(sA):
             ev_fwd0[s].record(sA)
-            out = det(frames)[0]
-            ev_fwd1[s].record(sA)
-            det.postprocess(out, 0.01, 0.45, None)
+            if graph is not None:
+                graph.replay()                 # input layout + 96 conv launches + pools/upsamples + decode/NMS as one hipGraph
+                ev_fwd1[s].record(sA)
+            else:
+                out = det(frames)[0]
+                ev_fwd1[s].record(sA)
+                det.postprocess(out, 0.01, 0.45, None)
             ev_nms[s].record(sA)
         with torch.cuda.stream(sB):
             sB.wait_event(ev_nms[s])       # a frame's detections exist before its tracker step runs

@@ -127,7 +127,8 @@ typedef struct y7t_op {
     int32_t KH, KW, stride, pad;        /* conv / pool window */
     int32_t K, K_pad;
     int32_t act;                        /* 0 none, 1 SiLU, 2 LeakyReLU(0.1) */
-    int32_t reserved0, reserved1;       /* keeps the int64 fields 8-byte aligned: sizeof(y7t_op) == 112 */
+    int32_t reserved0, reserved1;       /* reserved0 = korder: 1 when the weights are packed in (kh, 64-ch chunk, kw) K order;
+                                           keeps the int64 fields 8-byte aligned: sizeof(y7t_op) == 112 */
     int64_t w_off;                      /* element offset into the fp16 weight blob */
     int64_t bias_off;                   /* element offset into the fp32 bias blob */
 } y7t_op;

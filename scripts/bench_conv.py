@@ -7,6 +7,8 @@ from yolov7_tracker_amd import _lib
 from yolov7_tracker_amd.detector import arch, graph
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+import os
+KORDER = int(os.environ.get('KORDER', '1'))
 L = _lib.load()
 plan = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, B)
 shapes = collections.OrderedDict()
@@ -27,7 +29,7 @@ for key, cnt in shapes.items():
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
     def run():
         _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), in_ld, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), out_ld, 0, f32, Cout, Cout_pad,
-                                         k, k, s, pad, 1, _lib.ptr(zeros), _lib.stream_ptr()))
+                                         k, k, s, pad, 1 | (KORDER << 8 if (k == 3 and Cin % 64 == 0) else 0), _lib.ptr(zeros), _lib.stream_ptr()))
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

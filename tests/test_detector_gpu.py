@@ -19,12 +19,14 @@ def L():
     return _lib.load()
 
 
-def pack_w(W, cin_pad, cout_pad):
+def pack_w(W, cin_pad, cout_pad, korder=False):
     cout, cin, k, _ = W.shape
     K = k * k * cin_pad
     K_pad = (K + 63) // 64 * 64
     Wt = np.zeros((cout, k, k, cin_pad), np.float32)
     Wt[..., :cin] = W.transpose(0, 2, 3, 1)
+    if korder:   # (kh, 64-channel chunk, kw) K order
+        Wt = Wt.reshape(cout, k, k, cin_pad // 64, 64).transpose(0, 1, 3, 2, 4)
     blk = np.zeros((cout_pad, K_pad), np.float16)
     blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
     return blk
@@ -40,6 +42,8 @@ CONV_CASES = [
     (1, 16, 16, 256, 45, 1, 1, 0, 256, 0, 45, 0, 1),        # Detect head: fp32 out, Cout not a multiple of 4
     (3, 9, 9, 512, 512, 3, 1, 1, 512, 0, 512, 0, 0),        # small map, deep K
     (1, 130, 130, 32, 64, 3, 2, 1, 32, 0, 64, 0, 0),        # M not a multiple of the tile
+    (2, 24, 40, 128, 128, 3, 1, 1 | 256, 128, 0, 128, 0, 0),  # weights in the (kh, chunk, kw) K order (act bit 8)
+    (1, 33, 31, 192, 64, 3, 2, 1 | 256, 256, 64, 64, 0, 0),   # same, stride 2, input slice of a wider buffer
 ]
 
 
@@ -52,7 +56,10 @@ def test_conv_layer_matches_torch_fp32(L, case):
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
     cout_pad = (Cout + 63) // 64 * 64
-    wp = pack_w(Wt, Cin, cout_pad)
+    korder = bool(act & 256)
+    act_code = act
+    act = act & 255
+    wp = pack_w(Wt, Cin, cout_pad, korder)
     bp = np.zeros(cout_pad, np.float32); bp[:Cout] = bias
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
@@ -60,7 +67,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     out = torch.full((B, Ho, Wo, out_ld), 7.0, dtype=torch.float32 if out_f32 else torch.float16, device="cuda")
     zeros = torch.zeros(128, dtype=torch.float16, device="cuda")
     _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(xd), in_ld, in_coff, B, H, W, Cin, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), out_ld, out_coff,
-                                     out_f32, Cout, cout_pad, k, k, s, pad, act, _lib.ptr(zeros), _lib.stream_ptr()))
+                                     out_f32, Cout, cout_pad, k, k, s, pad, act_code, _lib.ptr(zeros), _lib.stream_ptr()))
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     xs = torch.from_numpy(x[..., in_coff:in_coff + Cin].astype(np.float32)).permute(0, 3, 1, 2)

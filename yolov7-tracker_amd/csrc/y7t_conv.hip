@@ -61,7 +61,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid % n_tiles_m, tile_n = bid / n_tiles_m;
+    // channel tiles fastest: the blocks that share one pixel tile (and therefore all its input lines) run next to each
+    // other on the same XCD; the weight panels are small and stay cached anyway
+    const int n_tiles_n = p.Cout_pad / BN;
+    const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // Buffer descriptors (raw, 32-bit byte offsets): a lane whose tap falls into the padding, whose row is past M
@@ -130,7 +133,19 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r], kt * BK * 2, 0, 0);
         }
     };
+    // K order.  Default: k = tap*Cin + ci (taps outermost).  korder = 1 (3x3, Cin % 64 == 0, weights packed to match):
+    // (kh, 64-channel chunk, kw) -- the three kw taps of one chunk are consecutive K-steps and touch the same input lines
+    // shifted by one pixel, so they hit in L1/L2 instead of coming back from the Infinity Cache a dozen steps later.
+    int o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
+    const int nchunk = p.Cin >> 6;
     auto advance_k = [&]() {
+        if (UT && p.korder) {
+            if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
+            o_sub = 0;
+            if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
+            tap = o_kh * p.KW + o_kw; ci = o_c << 6;
+            return;
+        }
         k += BK; ci += BK;
         while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
     };
@@ -148,6 +163,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    if ((p.ablate & 16) && ((blockIdx.x >> 8) & 1)) {   // experiment: de-phase the two co-resident blocks of a CU
+#pragma unroll 1
+        for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(20);
+    }
     // prologue: NST-1 stages in flight
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) if (s < nk) issue_loads(s, s);
@@ -306,6 +325,227 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant (uniform-tap layers): 4 consumer waves (2x2, as above) + 1 LOADER wave per workgroup.
+// The loader issues every buffer->LDS DMA of the ring (NST stages), so the consumers' instruction streams hold nothing
+// but ds_read_b128 + MFMA + one barrier per K-step -- the DMA issue / address arithmetic runs beside them instead of in
+// front of them.  One s_barrier per K-step for all 5 waves: the loader arrives after `s_waitcnt vmcnt(..)` proved stage kt
+// landed, the consumers after they finished stage kt-1; behind it the loader refills the buffer stage kt-1 occupied.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int NST>
+__global__ void __launch_bounds__(320, 2) k_conv_ws(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ROWB = BK * 2, CPR = BK / 8, RPW = 64 / CPR;
+    constexpr int WTN = BN / 2, WTM = BM / 2, TN = WTN / 32, TM = WTM / 32;
+    constexpr int NA = BM / RPW, NB = BN / RPW, NLD = NA + NB;   // wave-wide DMAs per stage, all issued by the loader wave
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert((NST - 2) * NLD <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles_m = (p.M + BM - 1) / BM;
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // channel tiles fastest: the blocks that share one pixel tile (and therefore all its input lines) run next to each
+    // other on the same XCD; the weight panels are small and stay cached anyway
+    const int n_tiles_n = p.Cout_pad / BN;
+    const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K_pad / BK;
+    const int wn = (wave >> 1) & 1, wm = wave & 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    floatx16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (wave == 4) {
+        // ------------------------------------------------ loader wave ------------------------------------------------
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+        const int lr = lane / CPR, lc = lane % CPR;
+        int xoff[NA];
+        unsigned vmask[NA];
+        const int HoWo = p.Ho * p.Wo;
+        const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int row = a * RPW + lr;
+            const int gch = lc ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+            const int m = m0 + row;
+            vmask[a] = 0; xoff[a] = 0;
+            if (m < p.M) {
+                int b = (int)((float)m * inv_howo);
+                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
+                const int rem = m - b * HoWo;
+                int ho = (int)((float)rem * inv_wo);
+                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
+                const int wo = rem - ho * p.Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                xoff[a] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gch * 8) * 2;
+                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
+                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
+                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh >= klo && kh <= khi) vmask[a] |= colbits << (kh * p.KW);
+            }
+        }
+        int woff[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int row = b * RPW + lr;
+            const int gch = lc ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+            woff[b] = ((n0 + row) * p.K_pad + gch * 8) * 2;
+        }
+        int tap = 0, ci = 0, o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
+        const int nchunk = p.Cin >> 6;
+        auto issue_stage = [&](int stage, int kt) {
+            char* xs = smem + stage * STAGE;
+            char* ws = xs + BM * ROWB;
+            const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
+            const int kw = tap - kh * p.KW;
+            const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int voff = ((vmask[a] >> tap) & 1u) ? xoff[a] + tapoff : -1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + a * RPW * ROWB), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + b * RPW * ROWB), 16, woff[b], kt * BK * 2, 0, 0);
+            if (p.korder) {
+                if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
+                o_sub = 0;
+                if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
+                tap = o_kh * p.KW + o_kw; ci = o_c << 6;
+                return;
+            }
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) if (s < nk) issue_stage(s, s);
+        int nxt = NST - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 4 ? 2 : 0) * NLD) : "memory");
+            else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 3 ? 1 : 0) * NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST - 1 < nk) issue_stage(nxt, kt + NST - 1);
+            nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+        }
+    } else {
+        // ------------------------------------------------ consumer waves ------------------------------------------------
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* xs = smem + cur * STAGE;
+            const char* ws = xs + BM * ROWB;
+            constexpr int KS = BK / 16;
+            half8 wf[2][TN], xf[2][TM];
+            auto read_frags = [&](int ks, int buf) {
+                const int q = ks * 2 + hi32;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int row = wn * WTN + i * 32 + l31;
+                    const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                    wf[buf][i] = *(const half8*)(ws + row * ROWB + (sl << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int row = wm * WTM + j * 32 + l31;
+                    const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                    xf[buf][j] = *(const half8*)(xs + row * ROWB + (sl << 4));
+                }
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cb = ks & 1;
+                if (ks + 1 < KS) read_frags(ks + 1, cb ^ 1);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this stage retired before the next barrier
+            cur = (cur + 1 == NST) ? 0 : cur + 1;
+        }
+    }
+    // ---- epilogue (fp16, 8-aligned slices only: the dispatcher guarantees it): LDS-transposed full-line stores ----
+    constexpr int OROW = BN * 2 + 16;
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int pix = wm * WTM + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int nl = wn * WTN + i * 32;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned w[2][2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = gp * 2 + gg;
+                        const int n = n0 + nl + 8 * g + 4 * hi32;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                        typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                        half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                        w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                        w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                    }
+                    auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+                    uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                    *(uint4v*)(smem + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+        constexpr int CPP = BN / 8, NCH = BM * CPP;
+        half_t* outp = (half_t*)p.out;
+        for (int c = tid; c < NCH; c += 320) {
+            const int pix = c / CPP, ch = c - pix * CPP;
+            const int m = m0 + pix, n = n0 + ch * 8;
+            if (m < p.M && n < p.Cout) {
+                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
+                *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+            }
+        }
+    }
+#endif
+}
+
+template <int BM, int BN, int BK, int NST>
+static int launch_conv_ws(const Y7TConvArgs& a, hipStream_t s) {
+    constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
+    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static bool attr = false;
+    if (!attr) {
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_ws<BM, BN, BK, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
+    hipLaunchKernelGGL((k_conv_ws<BM, BN, BK, NST>), dim3(tiles_m * tiles_n), dim3(320), lds, s, a);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
@@ -350,13 +590,19 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     b.in_bytes = (unsigned)((long long)a.B * a.H * a.W * a.ldin * 2);
     b.w_bytes = (unsigned)((long long)a.Cout_pad * a.K_pad * 2);
     { static int xs = -1; if (xs < 0) { const char* e = getenv("Y7T_CONV_XCD"); xs = e ? atoi(e) : 1; } b.xcd_swizzle = xs; }
+    { static int to = -1; if (to < 0) { const char* e = getenv("Y7T_CONV_TILE_ORDER"); to = e ? atoi(e) : 1; } b.tile_order = to; }
     { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
     return conv_dispatch(b, s);
 }
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     const bool wide = a.Cout_pad % 128 == 0;
-    switch (conv_variant()) {
+    const bool ws_ok = !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) && !(a.cout_off & 7);
+    const int var = conv_variant();
+    if (var == 8 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ws<128, 128, 64, 2>(a, s) : launch_conv_ws<128, 64, 64, 2>(a, s);
+    if (var == 9 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 3>(a, s) : launch_conv_ws<128, 64, 32, 3>(a, s);
+    if (var == 10 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 4>(a, s) : launch_conv_ws<128, 64, 32, 4>(a, s);
+    switch (var > 7 ? 0 : var) {
     case 1: return wide ? launch_conv<128, 128, 64, 3>(a, s) : launch_conv<128, 64, 64, 3>(a, s);
     case 2: return wide ? launch_conv<128, 128, 32, 3>(a, s) : launch_conv<128, 64, 32, 3>(a, s);
     case 3: return wide ? launch_conv<128, 128, 32, 4>(a, s) : launch_conv<128, 64, 32, 4>(a, s);

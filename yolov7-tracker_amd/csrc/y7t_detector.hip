@@ -62,7 +62,7 @@ extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) {
             a.out = outp; a.ldout = op.out_ld; a.cout_off = op.out_coff; a.out_f32 = op.out_f32;
             a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.Cout_pad = op.Cout_pad;
             a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
-            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros;
+            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.reserved0;
             rc = y7t_conv_launch(a, s);
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
             rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
@@ -103,6 +103,7 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
     a.w = (const _Float16*)w; a.bias = bias; a.out = out; a.ldout = out_ld; a.cout_off = out_coff; a.out_f32 = out_f32;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Cout = Cout; a.Cout_pad = Cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-    a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act; a.zeros = (const _Float16*)zeros16;
+    a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act & 0xff; a.zeros = (const _Float16*)zeros16;
+    a.korder = (act >> 8) & 1;   // bit 8 of `act`: weights are packed in the (kh, chunk, kw) K order
     return y7t_conv_launch(a, (hipStream_t)stream);
 }

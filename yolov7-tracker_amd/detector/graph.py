@@ -222,9 +222,10 @@ def lower(nodes, H, W, max_batch=1):
         op["out_buf"], op["out_ld"], op["out_coff"], op["out_f32"] = out_buf, out_ld, out_coff, out_f32
         op["Ho"], op["Wo"], op["Cout"], op["Cout_pad"] = n.h, n.w, cout, cout_pad
         op["KH"], op["KW"], op["stride"], op["pad"], op["K"], op["K_pad"], op["act"] = n.k, n.k, n.s, n.p, K, K_pad, act
-        op["w_off"], op["bias_off"] = w_off, b_off
+        korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
+        op["w_off"], op["bias_off"], op["reserved0"] = w_off, b_off, korder
         ops.append(op)
-        wlayout.append(dict(wkey=wkey, cin=cin_real, cin_pad=cin, cout=cout, cout_pad=cout_pad, k=n.k, K=K, K_pad=K_pad, w_off=w_off,
+        wlayout.append(dict(korder=korder, wkey=wkey, cin=cin_real, cin_pad=cin, cout=cout, cout_pad=cout_pad, k=n.k, K=K, K_pad=K_pad, w_off=w_off,
                             b_off=b_off, kind=kind, act=act, macs=n.h * n.w * cout * n.k * n.k * cin_real))
         w_off += cout_pad * K_pad
         b_off += cout_pad

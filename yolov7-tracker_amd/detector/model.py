@@ -189,6 +189,20 @@ class Detector:
                                                p.ws.numel(), _lib.stream_ptr()))
         return p.dets, p.ndets
 
+    def capture(self, img, conf_thres=0.01, iou_thres=0.45, ori_shapes=None):
+        """Capture input layout + the whole conv launch list + decode/NMS for the (fixed) device buffer `img` into a
+        hipGraph (torch.cuda.CUDAGraph drives the capture; every launch of liby7t.so goes to the capturing stream, and
+        nothing in the list allocates or synchronises).  Returns (graph, dets, ndets): `graph.replay()` re-runs the chain
+        on whatever `img` holds, with no per-launch host cost."""
+        out = self.forward(img)                      # warm-up: plan selection, attribute setup, letterbox upload
+        self.postprocess(out, conf_thres, iou_thres, ori_shapes)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.forward(img)
+            dets, nd = self.postprocess(out, conf_thres, iou_thres, ori_shapes)
+        return g, dets, nd
+
     def check_overflow(self):
         c = int(self.plan.cand.max().item())
         if c > self.max_cand:

@@ -114,6 +114,8 @@ def pack(wlayout, sd, w_elems, b_elems):
         assert W.shape == (cout, cin, k, k), (w["wkey"], W.shape, (cout, cin, k, k))
         Wt = np.zeros((cout, k, k, w["cin_pad"]), np.float64)
         Wt[..., :cin] = W.transpose(0, 2, 3, 1)
+        if w.get("korder"):   # (cout, kh, kw, chunk, 64) -> (cout, kh, chunk, kw, 64)
+            Wt = Wt.reshape(cout, k, k, w["cin_pad"] // 64, 64).transpose(0, 1, 3, 2, 4)
         blk = np.zeros((w["cout_pad"], w["K_pad"]), np.float16)
         blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
