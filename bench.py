@@ -201,6 +201,10 @@ def main():
     nms_ms = [ev_fwd1[s].elapsed_time(ev_nms[s]) for s in range(Wm, Wm + K)]
     gflop_frame = det.gflop_per_frame
     conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
+    if os.path.exists(tpath):      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed
+        traffic = json.load(open(tpath))["hbm_bytes_per_frame"] * B
     if rank == 0:
         # sanity: the tracker produced tracks
         last = results[(Wm + K) * B - 1].cpu().numpy()
@@ -215,8 +219,10 @@ def main():
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
                        "parallelism": "sequence-sharded x%d" % world},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
-                         "kernel": "k_conv_igemm<BM,BN> (all 107 conv launches of one forward)",
+                         "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch list from profiles/r01_conv_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
+                                         "algorithmic = 1.217 GB/frame",
+                         "kernel": "k_conv_igemm<BM,BN,BK,NST> (the conv launch list of one forward: 107 convs in 96 launches)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3)},

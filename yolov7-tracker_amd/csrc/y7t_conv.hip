@@ -32,7 +32,9 @@ typedef __attribute__((ext_vector_type(16))) float floatx16;
 #define LDS_AS __attribute__((address_space(3)))
 
 __device__ __forceinline__ float act_fn(float v, int act) {
-    if (act == Y7T_ACT_SILU) return v / (1.0f + __expf(-v));
+    // SiLU = v * sigmoid(v) with the hardware exp2 / rcp (1 ulp each; the result is rounded to fp16 anyway): the IEEE
+    // division + expf of the naive form made the epilogue's VALU work 27 % of the whole forward (Y7T_CONV_ABLATE=8)
+    if (act == Y7T_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
     if (act == Y7T_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
     return v;
 }
@@ -546,6 +548,216 @@ static int launch_conv_ws(const Y7TConvArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Anti-phase variant (uniform-tap layers, fp16 output): 512 threads = two GROUPS of 4 waves, one wave of each group per
+// SIMD.  Each group owns a 128-pixel half of a 256 x BN block tile and runs the classic two-step cycle
+//      P: issue the DMAs of stage k+1, ds_read ALL fragments of stage k into registers      (memory pipes)
+//      C: 16 (or 8) back-to-back MFMAs from registers                                           (matrix pipe)
+// with one workgroup barrier after each step -- and group 1 starts one barrier late.  The barriers therefore pin the two
+// groups in ANTI-PHASE: whenever group 0 is in C, group 1 is in P and vice versa, so every SIMD always has exactly one
+// wave feeding its matrix pipe while the other wave of that SIMD feeds the LDS / buffer pipes.  (Measured problem of the
+// plain structure, scripts/bench_conv.py + Y7T_CONV_ABLATE: loads-only 42 us + MFMA-only 45 us -> 67 us together.)
+// The weight tile is shared (group 0 loads it), each group stages its own pixel half; hazards: see DESIGN.md section 3.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ void __launch_bounds__(512, 2) k_conv_ap(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BK = 64, ROWB = 128, GM = 128, BM = 2 * GM;
+    constexpr int WTN = BN / 2, WTM = GM / 2, TN = WTN / 32, TM = WTM / 32;
+    constexpr int RM = GM / 32, RN = BN / 32;           // DMA rounds per thread: pixel half (both groups), weights (group 0)
+    constexpr int STAGE = (BM + BN) * ROWB;             // [pixels g0 | pixels g1 | weights]
+    constexpr int KS = BK / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3, wn = w4 >> 1, wm = w4 & 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    const int n_tiles_m = (p.M + BM - 1) / BM, n_tiles_n = p.Cout_pad / BN;
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
+    const int m0 = tile_m * BM + grp * GM, n0 = tile_n * BN;
+    const int nk = p.K_pad / BK;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // ---- load geometry (per group: 256 threads cover 32 rows x 8 chunks per round) ----
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int gchunk = (lane & 7) ^ ((lrow >> 1) & 7);
+    int xoff[RM];
+    unsigned vmask[RM];
+    {
+        const int HoWo = p.Ho * p.Wo;
+        const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int m = m0 + r * 32 + lrow;
+            vmask[r] = 0; xoff[r] = 0;
+            if (m < p.M) {
+                int b = (int)((float)m * inv_howo);
+                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
+                const int rem = m - b * HoWo;
+                int ho = (int)((float)rem * inv_wo);
+                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
+                const int wo = rem - ho * p.Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gchunk * 8) * 2;
+                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
+                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
+                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh >= klo && kh <= khi) vmask[r] |= colbits << (kh * p.KW);
+            }
+        }
+    }
+    int woff[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) woff[r] = ((n0 + r * 32 + lrow) * p.K_pad + gchunk * 8) * 2;
+
+    int tap = 0, ci = 0, o_kw = 0, o_c = 0, o_kh = 0;
+    const int nchunk = p.Cin >> 6;
+    auto issue_loads = [&](int stage, int kt) {
+        char* xs = smem + stage * STAGE + grp * (GM * ROWB);
+        char* ws = smem + stage * STAGE + BM * ROWB;
+        const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
+        const int kw = tap - kh * p.KW;
+        const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int voff = ((vmask[r] >> tap) & 1u) ? xoff[r] + tapoff : -1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * 32 + w4 * 8) * ROWB), 16, voff, 0, 0, 0);
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * 32 + w4 * 8) * ROWB), 16, woff[r], kt * BK * 2, 0, 0);
+        }
+        if (p.korder) {
+            if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
+            tap = o_kh * p.KW + o_kw; ci = o_c << 6;
+        } else {
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        }
+    };
+
+    floatx16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_loads(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // B0: stage 0 visible to everyone
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 starts one interval late -> anti-phase
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // ---- P: DMAs of the next stage, then every fragment of this stage into registers ----
+        if (kt + 1 < nk) issue_loads(cur ^ 1, kt + 1);
+        const char* xs = smem + cur * STAGE + grp * (GM * ROWB);
+        const char* ws = smem + cur * STAGE + BM * ROWB;
+        half8 wf[KS][TN], xf[KS][TM];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = ks * 2 + hi32;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = wn * WTN + i * 32 + l31;
+                wf[ks][i] = *(const half8*)(ws + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * WTM + j * 32 + l31;
+                xf[ks][j] = *(const half8*)(xs + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- C: the MFMA cluster, registers only ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of stage kt+1 have landed
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // match group 1's extra barrier
+
+    // ---- epilogue: bias + act, LDS transpose, full-line NHWC stores (all 512 threads) ----
+    constexpr int OROW = BN * 2 + 16;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int pix = grp * GM + wm * WTM + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nl = wn * WTN + i * 32;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned w[2][2];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = gp * 2 + gg;
+                    const int n = n0 + nl + 8 * g + 4 * hi32;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                    w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                    w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                }
+                auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+                uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                *(uint4v*)(smem + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+        constexpr int CPP = BN / 8, NCH = BM * CPP;
+        half_t* outp = (half_t*)p.out;
+        const int mb = tile_m * BM;
+        for (int c = tid; c < NCH; c += 512) {
+            const int pix = c / CPP, ch = c - pix * CPP;
+            const int m = mb + pix, n = n0 + ch * 8;
+            if (m < p.M && n < p.Cout) {
+                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
+                *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+            }
+        }
+    }
+#endif
+}
+
+template <int BN>
+static int launch_conv_ap(const Y7TConvArgs& a, hipStream_t s) {
+    constexpr unsigned lds_stage = 2 * (256 + BN) * 128, lds_epi = 256 * (BN * 2 + 16);
+    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static bool attr = false;
+    if (!attr) {
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_ap<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int tiles_m = (a.M + 255) / 256, tiles_n = a.Cout_pad / BN;
+    hipLaunchKernelGGL((k_conv_ap<BN>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
@@ -599,6 +811,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     const bool wide = a.Cout_pad % 128 == 0;
     const bool ws_ok = !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) && !(a.cout_off & 7);
     const int var = conv_variant();
+    if (var == 11 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ap<128>(a, s) : launch_conv_ap<64>(a, s);
     if (var == 8 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ws<128, 128, 64, 2>(a, s) : launch_conv_ws<128, 64, 64, 2>(a, s);
     if (var == 9 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 3>(a, s) : launch_conv_ws<128, 64, 32, 3>(a, s);
     if (var == 10 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 4>(a, s) : launch_conv_ws<128, 64, 32, 4>(a, s);
