@@ -59,6 +59,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order), so give every XCD a CONTIGUOUS range of
     // tiles -- neighbouring pixel tiles share halo rows and the same weight panel in that XCD's private 4 MiB L2
     int bid = blockIdx.x;
+    // split-K: `splitk` consecutive workgroups share one output tile, each reduces a contiguous range of K-steps into its own
+    // fp32 slab (k_splitk_reduce sums the slabs in a fixed order -> deterministic); used when a layer has too few tiles to fill
+    // 256 CUs (the 20x20 / 40x40 maps, batch-1 latency mode)
     if (p.xcd_swizzle) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -66,6 +69,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // channel tiles fastest: the blocks that share one pixel tile (and therefore all its input lines) run next to each
     // other on the same XCD; the weight panels are small and stay cached anyway
     const int n_tiles_n = p.Cout_pad / BN;
+    const int split = bid % p.splitk;
+    bid /= p.splitk;
     const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -112,9 +117,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     for (int r = 0; r < RN; ++r) woff[r] = ((n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
 
     // k bookkeeping of the next stage to load: uniform (scalar) when every K-step lies inside one tap (Cin % BK == 0)
-    int k = UT ? 0 : gchunk * 8;
+    const int nk_all = p.K_pad / BK;
+    const int kt0 = split * p.ksteps, nk = (kt0 + p.ksteps < nk_all ? kt0 + p.ksteps : nk_all) - kt0;   // this split's K-steps
+    int k = (UT ? 0 : gchunk * 8) + kt0 * BK;
     int tap = k / p.Cin, ci = k - tap * p.Cin;
-    const int nk = p.K_pad / BK;
 
     // one DMA of the stage being filled: idx in [0, NLD): first the RM pixel-row rounds, then the RN weight rounds.
     // tap/ci/k describe that stage; advance_k() moves them to the following stage.
@@ -132,14 +138,19 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * RPR + wave * RPW) * ROWB), 16, voff, 0, 0, 0);
         } else {
             const int r = idx - RM;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r], kt * BK * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r], (kt0 + kt) * BK * 2, 0, 0);
         }
     };
     // K order.  Default: k = tap*Cin + ci (taps outermost).  korder = 1 (3x3, Cin % 64 == 0, weights packed to match):
     // (kh, 64-channel chunk, kw) -- the three kw taps of one chunk are consecutive K-steps and touch the same input lines
     // shifted by one pixel, so they hit in L1/L2 instead of coming back from the Infinity Cache a dozen steps later.
-    int o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
     const int nchunk = p.Cin >> 6;
+    int o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
+    if (UT && p.korder) {   // decode the (kh, chunk, kw) odometer at this split's first K-step
+        const int g = (kt0 * BK) >> 6;
+        o_kw = g % p.KW; o_c = (g / p.KW) % nchunk; o_kh = g / (p.KW * nchunk); o_sub = ((kt0 * BK) & 63) / BK;
+        tap = o_kh * p.KW + o_kw; ci = (o_c << 6) + o_sub * BK;
+    }
     auto advance_k = [&]() {
         if (UT && p.korder) {
             if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
@@ -239,6 +250,24 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (p.splitk > 1) {   // raw fp32 partial sums of this K range: slab[split][m][Cout_pad]
+        float* slab = p.partial + (size_t)split * p.M * p.Cout_pad;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WTM + j * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi32;
+                    typedef __attribute__((ext_vector_type(4))) float float4v;
+                    float4v v = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+                    *(float4v*)(slab + (size_t)m * p.Cout_pad + n) = v;
+                }
+        }
         return;
     }
     // ---- epilogue: bias + activation.  A lane holds channels n..n+3 of its pixel for each group g (n = 8g + 4*hi32);
@@ -758,6 +787,33 @@ static int launch_conv_ap(const Y7TConvArgs& a, hipStream_t s) {
     return 0;
 }
 
+// sum the split-K slabs in split order, add bias, activate, store (fp16 NHWC slice or fp32)
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int S, int M, int Cout_pad, int Cout, const float* __restrict__ bias,
+                                                       int act, void* out, int ldout, int cout_off, int out_f32) {
+    const int c4 = Cout_pad / 4;
+    const long long tot = (long long)M * c4;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t / c4), n = (int)(t - (long long)m * c4) * 4;
+        if (n >= Cout) continue;
+        typedef __attribute__((ext_vector_type(4))) float float4v;
+        float4v a = *(const float4v*)(partial + (size_t)m * Cout_pad + n);
+        for (int s = 1; s < S; ++s) {
+            const float4v b = *(const float4v*)(partial + ((size_t)s * M + m) * Cout_pad + n);
+            a += b;
+        }
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fn(a[e] + bias[n + e], act);
+        const size_t o = (size_t)m * ldout + cout_off + n;
+        if (out_f32) { for (int e = 0; e < 4; ++e) if (n + e < Cout) ((float*)out)[o + e] = v[e]; }
+        else if (n + 3 < Cout) { half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; *(half4*)((half_t*)out + o) = h; }
+        else { for (int e = 0; e < 4; ++e) if (n + e < Cout) ((half_t*)out)[o + e] = (half_t)v[e]; }
+    }
+}
+
+static float* g_splitk_ws = nullptr;
+static const size_t kSplitKWsBytes = 128ull << 20;
+
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
@@ -767,9 +823,31 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT>), dim3(tiles_m * tiles_n), dim3(256), lds, s, a);
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN, tiles = tiles_m * tiles_n;
+    Y7TConvArgs b = a;
+    const int nk = a.K_pad / BK;
+    int S = 1;
+    if (a.allow_splitk && tiles < 256 && nk >= 8) {
+        S = (512 + tiles - 1) / tiles;
+        if (S > nk / 4) S = nk / 4;
+        if (S > 16) S = 16;
+        while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes) --S;
+    }
+    b.splitk = S; b.ksteps = (nk + S - 1) / S; b.partial = nullptr;
+    if (S > 1) {
+        if (!g_splitk_ws) Y7T_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, kSplitKWsBytes));
+        b.partial = g_splitk_ws;
+        b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
+    }
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
     Y7T_LAUNCH_CHECK();
+    if (b.splitk > 1) {
+        const long long tot = (long long)a.M * (a.Cout_pad / 4);
+        int blocks = (int)((tot + 255) / 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)b.partial, b.splitk, a.M, a.Cout_pad, a.Cout, a.bias, a.act, a.out,
+                           a.ldout, a.cout_off, a.out_f32);
+        Y7T_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -802,6 +880,8 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     b.in_bytes = (unsigned)((long long)a.B * a.H * a.W * a.ldin * 2);
     b.w_bytes = (unsigned)((long long)a.Cout_pad * a.K_pad * 2);
     { static int xs = -1; if (xs < 0) { const char* e = getenv("Y7T_CONV_XCD"); xs = e ? atoi(e) : 1; } b.xcd_swizzle = xs; }
+    { static int sk = -1; if (sk < 0) { const char* e = getenv("Y7T_CONV_SPLITK"); sk = e ? atoi(e) : 1; } b.allow_splitk = sk; }
+    b.splitk = 1; b.ksteps = b.K_pad; b.partial = nullptr;
     { static int to = -1; if (to < 0) { const char* e = getenv("Y7T_CONV_TILE_ORDER"); to = e ? atoi(e) : 1; } b.tile_order = to; }
     { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
     return conv_dispatch(b, s);

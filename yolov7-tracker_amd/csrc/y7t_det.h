@@ -21,6 +21,8 @@ struct Y7TConvArgs {
     const _Float16* zeros;  // unused (kept for ABI stability of y7t_conv2d_nhwc_f16)
     unsigned in_bytes, w_bytes;
     int xcd_swizzle, tile_order;
+    int splitk, ksteps, allow_splitk;   // split-K: workgroups per output tile, K-steps per split
+    float* partial;                     // fp32 slabs [splitk][M][Cout_pad]
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0)
     int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)
 };
