@@ -30,7 +30,7 @@ enum { Y7T_OK = 0, Y7T_E_ARG = -1, Y7T_E_HIP = -2, Y7T_E_CAPACITY = -3, Y7T_E_ST
 /* Kalman filter kinds == KALMAN_DICT keys, tracker/basetrack.py:64-69 */
 enum { Y7T_KALMAN_DEFAULT = 0, Y7T_KALMAN_NAIVE = 1, Y7T_KALMAN_BOTSORT = 2, Y7T_KALMAN_STRONGSORT = 3 };
 /* tracker kinds == TRACKER_DICT keys implemented on the device, tracker/track.py:56-65 */
-enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1 };
+enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1, Y7T_TRACKER_BOTSORT = 2 };
 
 const char* y7t_last_error(void);
 int y7t_version(void);
@@ -98,13 +98,20 @@ int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kind, int kalm
  *   n_dets[b]   row count, read ON THE DEVICE (so it can come straight from NMS); < 0 = update_without_detection
  *   out_rows[b] out_cap x 8 float64 rows (track_id, x, y, w, h, cls, score, slot) of the returned tracks
  *   out_count[b] number of returned tracks
- * states/dets/n_dets/out_rows/out_count are DEVICE arrays of `batch` entries. threads: 0 = default. */
+ * states/dets/n_dets/out_rows/out_count (and gmc_warps, may be NULL) are DEVICE arrays of `batch` entries. threads: 0 = default. */
 int y7t_tracker_step_batch(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
-                           int* out_count, int out_cap, int batch, int threads, y7t_stream stream);
+                           int* out_count, int out_cap, int batch, int threads, const double* const* gmc_warps,
+                           y7t_stream stream);
 
 /* convenience for batch == 1 with host-known n (n < 0: update_without_detection, basetrack.py:489-537) */
 int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count, int threads,
-                     y7t_stream stream);
+                     const double* gmc_warp, y7t_stream stream);
+
+/* BoT-SORT (tracker/botsort.py:313-493, tracker kind Y7T_TRACKER_BOTSORT, Kalman kind botsort): `gmc_warp` / `gmc_warps[b]` is the
+ * 2x3 camera-motion matrix of the frame (row-major, 6 doubles in DEVICE memory; NULL = no compensation) that the reference's
+ * GMC.apply returns (botsort.py:13-248 -- OpenCV ORB/RANSAC estimation, out of scope); the step applies multi_gmc
+ * (botsort.py:250-269) to the predicted pool and the unconfirmed tracks.  Same op on its own: */
+int y7t_kf_multi_gmc_f64(double* mean, double* cov, const double* warp, int N, y7t_stream stream);
 
 /* byte offsets of the arrays inside a state blob, for host-side views (tracked_stracks, lost_stracks, ...).
  * names/offsets: see y7t_tracker_field_name(i); returns the number of fields. */

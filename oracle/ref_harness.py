@@ -62,7 +62,7 @@ def _stub(name, **attrs):
     return m
 
 
-_TRACKER_MODS = ["kalman_filter", "matching", "basetrack", "bytetrack"]
+_TRACKER_MODS = ["kalman_filter", "matching", "basetrack", "bytetrack", "botsort"]
 _STUB_NAMES = ["torchvision", "torchvision.ops", "torchvision.utils", "torchvision.transforms", "cv2", "seaborn",
                "reid_models", "reid_models.deepsort_reid", "lap", "cython_bbox", "thop"]
 
@@ -137,6 +137,7 @@ def load_tracker():
     ns.matching.np = _NumpyWithFloat()
     ns.basetrack.matching = ns.matching
     ns.bytetrack.matching = ns.matching
+    ns.botsort.matching = ns.matching
     _tracker_ns = ns
     return ns
 
@@ -156,7 +157,7 @@ def make_opts(**kw):
     return o
 
 
-def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, collect_all=False):
+def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, collect_all=False, warps=None):
     """Run the reference SORT/ByteTrack over a list of (N,6) float32 arrays.
 
     Returns per-frame lists of (track_id, tlwh[4] float64, cls, score) for the tracks the
@@ -166,10 +167,14 @@ def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, colle
     opts = opts or make_opts()
     if reset_ids:
         ns.basetrack.BaseTrack._count = 0
-    cls = {"sort": ns.basetrack.BaseTracker, "bytetrack": ns.bytetrack.ByteTrack}[name]
+    cls = {"sort": ns.basetrack.BaseTracker, "bytetrack": ns.bytetrack.ByteTrack, "botsort": ns.botsort.BoTSORT}[name]
     trk = cls(opts, frame_rate=30, gamma=opts.gamma)
     out = []
-    for det in dets_per_frame:
+    for fi, det in enumerate(dets_per_frame):
+        if name == "botsort":
+            # GMC.apply (botsort.py:13-248) is OpenCV ORB/RANSAC -- out of scope; feed the frame's synthetic 2x3 warp instead
+            w = np.eye(2, 3) if warps is None else np.asarray(warps[fi], dtype=np.float64).reshape(2, 3)
+            trk.gmc.apply = (lambda raw_frame, detections=None, _w=w: _w)
         if det is None:
             cur = trk.update_without_detection(None, np.zeros((1, 1, 3), np.uint8))
         else:

@@ -133,7 +133,7 @@ def _dedup(a, b):
 class TrackerNP:
     def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
                  frame_rate=30, ids=None):
-        assert kind in ("sort", "bytetrack")
+        assert kind in ("sort", "bytetrack", "botsort")
         self.kind, self.fmt = kind, kalman_format
         self.det_thresh = conf_thresh
         self.iou_thresh = iou_thresh
@@ -212,7 +212,18 @@ class TrackerNP:
                 refind.append(t)
 
     # --- frame step -----------------------------------------------------------
-    def update(self, det):
+    @staticmethod
+    def _multi_gmc(tracks, H):
+        """botsort.py:250-269"""
+        R = H[:2, :2]
+        R8 = np.kron(np.eye(4, dtype=float), R)
+        t = H[:2, 2]
+        for tr in tracks:
+            m = R8.dot(tr.mean.copy())
+            m[:2] += t
+            tr.mean, tr.cov = m, R8.dot(tr.cov).dot(R8.transpose())
+
+    def update(self, det, warp=None):
         det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
         self.frame_id += 1
         act, refind, lost, removed = [], [], [], []
@@ -238,9 +249,14 @@ class TrackerNP:
             d_hi, d_lo = self._mk(det[hi]), self._mk(det[lo])
             pool = _joint(conf, self.lost)
             self._multi_predict(pool)
+            if self.kind == "botsort" and warp is not None:      # botsort.py:383-386
+                H = np.asarray(warp, dtype=np.float64).reshape(2, 3)
+                self._multi_gmc(pool, H)
+                self._multi_gmc(unconf, H)
             m, ut, ud = _assign(_iou_dist(pool, d_hi), 0.9)
             self._match_apply(pool, d_hi, m, act, refind)
-            rem = [pool[i] for i in ut if pool[i].state == TRACKED]
+            # bytetrack.py:131 keeps only still-Tracked leftovers; botsort.py:411 keeps all of them
+            rem = [pool[i] for i in ut if self.kind == "botsort" or pool[i].state == TRACKED]
             left = [d_hi[i] for i in ud]
             m, ut2, _ = _assign(_iou_dist(rem, d_lo), 0.5)
             self._match_apply(rem, d_lo, m, act, refind)
@@ -253,7 +269,7 @@ class TrackerNP:
         for i in ut:
             unconf[i].state = REMOVED
             removed.append(unconf[i])
-        for i in ud:
+        for i in (range(len(left)) if self.kind == "botsort" else ud):     # botsort.py:462-466 iterates u_dets0_idx (sic)
             if left[i].score > gate:
                 self._activate(left[i])
                 act.append(left[i])
@@ -270,12 +286,12 @@ class TrackerNP:
         return self._finish([], [], [], [])
 
 
-def run(kind, dets_per_frame, ids=None, **kw):
+def run(kind, dets_per_frame, ids=None, warps=None, **kw):
     """-> per-frame list of (track_id, tlwh float64[4], cls, score), like ref_harness.run_reference_tracker."""
     trk = TrackerNP(kind, ids=ids if ids is not None else IdCounter(), **kw)
     out = []
-    for det in dets_per_frame:
-        cur = trk.update_without_detection() if det is None else trk.update(det)
+    for fi, det in enumerate(dets_per_frame):
+        cur = trk.update_without_detection() if det is None else trk.update(det, None if warps is None else warps[fi])
         out.append([(int(t.tid), np.asarray(t.tlwh, dtype=np.float64).copy(), float(t.cls), float(t.score))
                     for t in cur])
     return out

@@ -30,7 +30,8 @@ def lib():
         L.hs_tracker_bytes.restype = ctypes.c_size_t
         L.hs_tracker_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.hs_tracker_init.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_double] * 3 + [ctypes.c_void_p]
-        L.hs_tracker_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.hs_tracker_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.hs_kf_gmc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_tracker_status.argtypes = [ctypes.c_void_p]
         L.hs_lapjv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_lapsap.argtypes = L.hs_lapjv.argtypes
@@ -60,7 +61,7 @@ def lapjv(cost, limit, sap=False):
 
 
 class HostSimTracker:
-    TRACKERS = {"sort": 0, "bytetrack": 1}
+    TRACKERS = {"sort": 0, "bytetrack": 1, "botsort": 2}
     KINDS = {"default": 0, "naive": 1, "botsort": 2, "strongsort": 3}
 
     def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
@@ -74,19 +75,23 @@ class HostSimTracker:
                               iou_thresh, self.ids.ctypes.data)
         self.out = np.zeros((cap_t, 8), np.float64)
 
-    def update(self, det):
+    def update(self, det, warp=None):
+        wp = None
+        if warp is not None:
+            self._warp = np.ascontiguousarray(warp, dtype=np.float64).reshape(6)
+            wp = self._warp.ctypes.data
         if det is None:
             n, ptr = -1, None
         else:
             det = np.ascontiguousarray(det, dtype=np.float32).reshape(-1, 6)
             n, ptr = det.shape[0], det.ctypes.data
-        cnt = lib().hs_tracker_step(self.blob.ctypes.data, ptr, n, self.out.ctypes.data, self.cap_t)
+        cnt = lib().hs_tracker_step(self.blob.ctypes.data, ptr, n, self.out.ctypes.data, self.cap_t, wp)
         st = lib().hs_tracker_status(self.blob.ctypes.data)
         if st:
             raise RuntimeError("tracker capacity exceeded (status %d)" % st)
         return [(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in self.out[:cnt]]
 
 
-def run(kind, dets_per_frame, **kw):
+def run(kind, dets_per_frame, warps=None, **kw):
     trk = HostSimTracker(kind, **kw)
-    return [trk.update(d) for d in dets_per_frame]
+    return [trk.update(d, None if warps is None else warps[i]) for i, d in enumerate(dets_per_frame)]

@@ -20,11 +20,12 @@ void hs_tracker_init(void* blob, int tracker, int kf, int cap_t, int cap_d, int 
     y7t_tracker_init(hs_ex(), blob, c, (unsigned long long)(uintptr_t)id_counter);
 }
 
-int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int out_cap) {
+int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int out_cap, const double* warp) {
     int cnt = 0;
-    y7t_tracker_step(hs_ex(), blob, dets, n, out_rows, out_cap, &cnt);
+    y7t_tracker_step(hs_ex(), blob, dets, n, out_rows, out_cap, &cnt, warp);
     return cnt;
 }
+void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(H, mean, cov); }
 
 int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
 

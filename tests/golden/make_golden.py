@@ -89,6 +89,9 @@ TRACKER_CASES = [
     ("bytetrack_botsort", "bytetrack", "botsort", 60, 60, 2, 0),
     ("sort_strongsort", "sort", "strongsort", 60, 60, 3, 17),
     ("bytetrack_crowd", "bytetrack", "default", 20, 500, 4, 0),
+    # BoT-SORT state path (BASELINE config 3): xywh Kalman + multi_gmc with synthetic 2x3 warps; appearance model off
+    ("botsort_gmc", "botsort", "botsort", 80, 80, 6, 11),
+    ("botsort_crowd", "botsort", "botsort", 12, 500, 7, 0),
 ]
 
 
@@ -107,12 +110,14 @@ def golden_tracker():
         dets = synth.make_detections(nf, nobj, seq_idx=seq)
         if drop:
             dets = [None if (i % drop == drop - 1) else d for i, d in enumerate(dets)]
-        ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt))
+        warps = synth.make_warps(nf, seq_idx=seq) if trk == "botsort" else None
+        ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps)
         fr, ids, tlwh, cls, score = pack_tracks(ref)
         counts = np.array([-1 if d is None else len(d) for d in dets], np.int32)
         flat = np.concatenate([d for d in dets if d is not None], 0).astype(np.float32)
         np.savez_compressed(os.path.join(HERE, "tracker_%s.npz" % name), tracker=np.array(trk), kalman_format=np.array(fmt),
                             det_counts=counts, dets=flat, frame=fr, track_id=ids, tlwh=tlwh, cls=cls, score=score,
+                            warps=np.zeros((0, 2, 3)) if warps is None else warps,
                             numpy_version=np.array(np.__version__))
         print(name, "rows", len(ids), "max id", ids.max())
 

@@ -14,7 +14,7 @@ from tests import util
 @pytest.mark.parametrize("name", util.TRACKER_CASES)
 def test_hostsim_tracker_matches_reference_golden(name):
     trk, fmt, dets, want = util.load_tracker_case(name)
-    got = hs.run(trk, dets, kalman_format=fmt)
+    got = hs.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name))
     util.assert_same_tracks(got, want, name)
 
 

@@ -43,7 +43,7 @@ def test_kalman_np_matches_reference_golden(kal, kind):
 @pytest.mark.parametrize("name", util.TRACKER_CASES)
 def test_tracker_np_matches_reference_golden(name):
     trk, fmt, dets, want = util.load_tracker_case(name)
-    got = tracker_np.run(trk, dets, kalman_format=fmt)
+    got = tracker_np.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name))
     util.assert_same_tracks(got, want, name)
 
 

@@ -27,15 +27,21 @@ def make_opts(**kw):
     return o
 
 
-def run_device_tracker(trk, fmt, dets, **kw):
+def run_device_tracker(trk, fmt, dets, warps=None, **kw):
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack, BaseTracker
+    from yolov7_tracker_amd.tracker.botsort import BoTSORT
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
     BaseTrack._count = 0
-    cls = {"sort": BaseTracker, "bytetrack": ByteTrack}[trk]
+    cls = {"sort": BaseTracker, "bytetrack": ByteTrack, "botsort": BoTSORT}[trk]
     t = cls(make_opts(kalman_format=fmt, **kw), frame_rate=30)
     out = []
-    for d in dets:
-        cur = t.update_without_detection(None, None) if d is None else t.update(d, None)
+    for fi, d in enumerate(dets):
+        if d is None:
+            cur = t.update_without_detection(None, None)
+        elif trk == "botsort":
+            cur = t.update(d, None, warp=None if warps is None else warps[fi])
+        else:
+            cur = t.update(d, None)
         out.append([(tr.track_id, tr.tlwh, float(tr.cls), float(tr.score)) for tr in cur])
     return out, t
 
@@ -43,7 +49,7 @@ def run_device_tracker(trk, fmt, dets, **kw):
 @pytest.mark.parametrize("name", util.TRACKER_CASES)
 def test_fused_tracker_matches_reference_golden(name):
     trk, fmt, dets, want = util.load_tracker_case(name)
-    got, _ = run_device_tracker(trk, fmt, dets)
+    got, _ = run_device_tracker(trk, fmt, dets, warps=util.load_tracker_warps(name))
     util.assert_same_tracks(got, want, name)
 
 
@@ -187,6 +193,23 @@ def test_kalman_kernels_match_reference_golden(kind):
         if kind != "botsort":
             np.testing.assert_allclose(f.gating_distance(mean[i], cov[i], z), kal[kind + "_gate4"][i], rtol=1e-9)
             np.testing.assert_allclose(f.gating_distance(mean[i], cov[i], z, True), kal[kind + "_gate2"][i], rtol=1e-9)
+
+
+def test_multi_gmc_kernel_matches_numpy(L):
+    """botsort.py:250-269 on 500 tracks through the C ABI"""
+    from yolov7_tracker_amd import _lib
+    rng = np.random.default_rng(12)
+    n = 500
+    mean = rng.normal(0, 50, (n, 8))
+    A = rng.normal(0, 1, (n, 8, 8)); cov = np.einsum("nij,nkj->nik", A, A) + np.eye(8)
+    H = np.array([[1.002, -0.004, 3.5], [0.003, 0.997, -1.25]])
+    m, c, h = torch.from_numpy(mean).cuda(), torch.from_numpy(cov.reshape(n, 64)).cuda(), torch.from_numpy(H.reshape(6)).cuda()
+    _lib.check(L.y7t_kf_multi_gmc_f64(_lib.ptr(m), _lib.ptr(c), _lib.ptr(h), n, _lib.stream_ptr()))
+    R8 = np.kron(np.eye(4), H[:, :2])
+    m0 = mean @ R8.T; m0[:, :2] += H[:, 2]
+    c0 = R8 @ cov @ R8.T
+    np.testing.assert_allclose(m.cpu().numpy(), m0, rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(c.cpu().numpy().reshape(n, 8, 8), c0, rtol=1e-12, atol=1e-11)
 
 
 def test_kalman_batch_500_tracks_roundtrip_properties(L):

@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRACKER_CASES = ["sort_default", "bytetrack_default", "bytetrack_default_gaps", "bytetrack_botsort", "sort_strongsort",
-                 "bytetrack_crowd"]
+                 "bytetrack_crowd", "botsort_gmc", "botsort_crowd"]
 # stated tolerance: ids / cls identical, tlwh within 1e-6 relative (scale: image size ~1e3 px)
 TLWH_RTOL, TLWH_ATOL = 1e-6, 1e-5
 
@@ -24,6 +24,13 @@ def load_tracker_case(name):
     for f, i, b, c, s in zip(g["frame"], g["track_id"], g["tlwh"], g["cls"], g["score"]):
         frames[f].append((int(i), b, float(c), float(s)))
     return str(g["tracker"]), str(g["kalman_format"]), dets, frames
+
+
+def load_tracker_warps(name):
+    """(n_frames, 2, 3) camera-motion matrices of a BoT-SORT case, or None"""
+    g = np.load(os.path.join(GOLDEN, "tracker_%s.npz" % name))
+    w = g["warps"] if "warps" in g.files else np.zeros((0, 2, 3))
+    return w if len(w) else None
 
 
 def assert_same_tracks(got, want, what=""):

@@ -27,8 +27,9 @@ SIGNATURES = {
     "y7t_tracker_state_bytes": (c_size_t, [c_int, c_int]),
     "y7t_tracker_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p,
                                  c_void_p]),
-    "y7t_tracker_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "y7t_tracker_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "y7t_tracker_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "y7t_tracker_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "y7t_kf_multi_gmc_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "y7t_tracker_layout": (c_int, [c_int, c_int, c_void_p, c_int]),
     "y7t_tracker_field_name": (ctypes.c_char_p, [c_int]),
     "y7t_det_create": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),

@@ -37,7 +37,7 @@
 
 enum { Y7T_KF_XYAH = 0, Y7T_KF_NAIVE = 1, Y7T_KF_XYWH = 2, Y7T_KF_NSA = 3 };
 enum { Y7T_NEW = 0, Y7T_TRACKED = 1, Y7T_LOST = 2, Y7T_REMOVED = 3 };
-enum { Y7T_SORT = 0, Y7T_BYTETRACK = 1 };
+enum { Y7T_SORT = 0, Y7T_BYTETRACK = 1, Y7T_BOTSORT = 2 };
 
 // ---------------------------------------------------------------------------------------------
 // execution context: one workgroup; rv/ri are >=32-entry cross-wave scratch arrays (LDS on device)
@@ -360,6 +360,32 @@ Y7T_FN void y7t_kf_update(int kind, double* mean, double* cov, const double* z, 
             double s = 0.0;
             for (int a = 0; a < 4; ++a) s += K[r * 4 + a] * W[a * 8 + c];
             cov[r * 8 + c] = cov[r * 8 + c] - s;
+        }
+}
+
+// botsort.py:250-269 multi_gmc: camera-motion compensation of one track.  H = [R | t] (2x3, row-major);
+// R8 = kron(I4, R):  mean <- R8 mean, mean[:2] += t,  cov <- R8 cov R8^T
+Y7T_FN void y7t_kf_gmc(const double* H, double* mean, double* cov) {
+    const double r00 = H[0], r01 = H[1], tx = H[2], r10 = H[3], r11 = H[4], ty = H[5];
+    for (int b = 0; b < 4; ++b) {
+        const double a = mean[2 * b], c = mean[2 * b + 1];
+        mean[2 * b] = r00 * a + r01 * c;
+        mean[2 * b + 1] = r10 * a + r11 * c;
+    }
+    mean[0] = mean[0] + tx; mean[1] = mean[1] + ty;
+    // left multiply: rows (2b, 2b+1) <- R rows
+    for (int b = 0; b < 4; ++b)
+        for (int c = 0; c < 8; ++c) {
+            const double a = cov[(2 * b) * 8 + c], d = cov[(2 * b + 1) * 8 + c];
+            cov[(2 * b) * 8 + c] = r00 * a + r01 * d;
+            cov[(2 * b + 1) * 8 + c] = r10 * a + r11 * d;
+        }
+    // right multiply by R8^T: columns (2b, 2b+1)
+    for (int r = 0; r < 8; ++r)
+        for (int b = 0; b < 4; ++b) {
+            const double a = cov[r * 8 + 2 * b], d = cov[r * 8 + 2 * b + 1];
+            cov[r * 8 + 2 * b] = a * r00 + d * r01;
+            cov[r * 8 + 2 * b + 1] = a * r10 + d * r11;
         }
 }
 

@@ -16,7 +16,7 @@
 #include "y7t_track_core.h"
 
 struct Y7TTrkCfg {
-    int tracker;        // Y7T_SORT / Y7T_BYTETRACK
+    int tracker;        // Y7T_SORT / Y7T_BYTETRACK / Y7T_BOTSORT
     int kf;             // Kalman kind
     int cap_t, cap_d;   // capacities: live tracks (tracked+lost), detections per frame
     int max_time_lost;  // int(frame_rate / 30 * track_buffer)
@@ -311,9 +311,12 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
     int n2 = y7t_compact(ex, nl, [&](int i) { return !s.mark[s.lost[i]] && !s.inrem[s.lost[i]]; }, s.tmpa, 0);
     for (int k = ex.tid; k < n2; k += ex.nt) s.tmpb[k] = s.lost[s.tmpa[k]];
     y7t_sync(ex);
-    for (int k = ex.tid; k < n2; k += ex.nt) s.lost[k] = s.tmpb[k];
+    for (int k = ex.tid; k < n2; k += ex.nt) { s.lost[k] = s.tmpb[k]; s.mark[s.tmpb[k]] |= 2; }
+    y7t_sync(ex);
     {
-        const int a = y7t_compact(ex, n_lostn, [&](int k) { return !s.inrem[s.lostn[k]]; }, s.tmpa, 0);
+        // sub_stracks builds a dict keyed by id, so a track that is already in `lost` (BoT-SORT re-marks unmatched Lost tracks as
+        // lost, botsort.py:432-435) is not appended twice
+        const int a = y7t_compact(ex, n_lostn, [&](int k) { return !s.inrem[s.lostn[k]] && !(s.mark[s.lostn[k]] & 2); }, s.tmpa, 0);
         for (int k = ex.tid; k < a; k += ex.nt) s.lost[n2 + k] = s.lostn[s.tmpa[k]];
         n2 += a;
         y7t_sync(ex);
@@ -390,7 +393,7 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
 
 // One frame.  dets: n x 6 float32 rows [x1, y1, x2, y2, conf, cls] (n < 0: update_without_detection)
 Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets, int n, double* out_rows, int out_cap,
-                                int* out_count) {
+                                int* out_count, const double* gmc_warp) {
     Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
     const Y7TTrkCfg cfg = h->cfg;
     const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
@@ -417,6 +420,16 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     const int n_pool = n_conf + nl0;
     Y7T_PROF(h, 1);
     y7t_multi_predict(ex, s, s.pool, n_pool);
+    if (cfg.tracker == Y7T_BOTSORT && gmc_warp && n >= 0) {   // botsort.py:383-386: multi_gmc(strack_pool), multi_gmc(unconfirmed)
+        double Hm[6];
+        for (int c = 0; c < 6; ++c) Hm[c] = gmc_warp[c];
+        for (int i = ex.tid; i < n_pool + n_unc; i += ex.nt) {
+            const int sl = i < n_pool ? s.pool[i] : s.unconf[i - n_pool];
+            y7t_kf_gmc(Hm, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl);
+            s.f32m[sl] = 0;
+        }
+        y7t_sync(ex);
+    }
     Y7T_PROF(h, 2);
     if (n < 0) {  // update_without_detection (basetrack.py:489-537)
         y7t_finish(ex, s, out_rows, out_cap, out_count);
@@ -464,7 +477,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
         y7t_sync(ex);
     } else {
         // ---- second association: remaining Tracked pool tracks vs low-score detections ----
-        const int n_rem = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && s.state[s.pool[i]] == Y7T_TRACKED; }, s.tmpa, 0);
+        // ByteTrack keeps only the still-Tracked leftovers (bytetrack.py:131); BoT-SORT takes every unmatched pool track (botsort.py:411)
+        const bool only_tracked = cfg.tracker != Y7T_BOTSORT;
+        const int n_rem = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && (!only_tracked || s.state[s.pool[i]] == Y7T_TRACKED); }, s.tmpa, 0);
         for (int k = ex.tid; k < n_rem; k += ex.nt) s.rem[k] = s.pool[s.tmpa[k]];
         y7t_sync(ex);
         y7t_gather_track_tlbr(ex, s, s.rem, n_rem);
@@ -495,7 +510,9 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     }
     // ---- new tracks from still-unmatched detections above the gate (activate; ids in order) ----
     {
-        const int n_new = y7t_compact(ex, n_left, [&](int j) { return s.ycol[j] < 0 && dets[6 * (size_t)s.left[j] + 4] > new_gate; }, s.tmpa, 0);
+        // botsort.py:462-466 spawns from u_dets0_idx (every detection left after the FIRST association) -- reference quirk, kept
+        const bool any_left = cfg.tracker == Y7T_BOTSORT;
+        const int n_new = y7t_compact(ex, n_left, [&](int j) { return (any_left || s.ycol[j] < 0) && dets[6 * (size_t)s.left[j] + 4] > new_gate; }, s.tmpa, 0);
         int* idc = (int*)(uintptr_t)h->id_counter_ptr;
         if (ex.tid == 0) {
             int nf = h->n_free, base = h->n_act_last, made = 0;

@@ -152,16 +152,28 @@ __global__ void k_tracker_init(void* blob, Y7TTrkCfg cfg, unsigned long long idc
 }
 
 __global__ void k_tracker_step(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
-                               int* out_count, int out_cap, unsigned fast_bytes) {
+                               int* out_count, int out_cap, unsigned fast_bytes, const double* const* warps) {
     const int b = blockIdx.x;
     const Y7TExec ex = make_exec(fast_bytes);
-    y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b);
+    y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b, warps ? warps[b] : nullptr);
 }
 
 __global__ void k_tracker_step1(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count,
-                                unsigned fast_bytes) {
+                                unsigned fast_bytes, const double* warp) {
     const Y7TExec ex = make_exec(fast_bytes);
-    y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count);
+    y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
+}
+
+__global__ void __launch_bounds__(64) k_kf_gmc(double* mean, double* cov, const double* __restrict__ warp, int N) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    double m[8], P[64], H[6];
+    for (int c = 0; c < 6; ++c) H[c] = warp[c];
+    for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)k + c];
+    for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)k + c];
+    y7t_kf_gmc(H, m, P);
+    for (int c = 0; c < 8; ++c) mean[8 * (size_t)k + c] = m[c];
+    for (int c = 0; c < 64; ++c) cov[64 * (size_t)k + c] = P[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -282,7 +294,7 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
                                 double conf_thresh, double iou_thresh, int max_time_lost, int flags, int* id_counter,
                                 y7t_stream stream) {
     Y7T_ARG_CHECK(state && id_counter && cap_t > 0 && cap_d > 0);
-    Y7T_ARG_CHECK(tracker_kind == Y7T_SORT || tracker_kind == Y7T_BYTETRACK);
+    Y7T_ARG_CHECK(tracker_kind == Y7T_SORT || tracker_kind == Y7T_BYTETRACK || tracker_kind == Y7T_BOTSORT);
     if (!kind_ok(kalman_kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kalman_kind); return Y7T_E_ARG; }
     Y7T_ARG_CHECK(state_bytes >= y7t_trk_layout(cap_t, cap_d).total);
     Y7TTrkCfg c;
@@ -305,8 +317,18 @@ static int step_threads(int threads, int n_hint = -1) {
     return threads;
 }
 
+extern "C" int y7t_kf_multi_gmc_f64(double* mean, double* cov, const double* warp, int N, y7t_stream stream) {
+    Y7T_ARG_CHECK(N >= 0);
+    if (N == 0) return 0;
+    Y7T_ARG_CHECK(mean && cov && warp);
+    hipLaunchKernelGGL(k_kf_gmc, dim3((N + 63) / 64), dim3(64), 0, S(stream), mean, cov, warp, N);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int y7t_tracker_step_batch(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
-                                      int* out_count, int out_cap, int batch, int threads, y7t_stream stream) {
+                                      int* out_count, int out_cap, int batch, int threads, const double* const* gmc_warps,
+                                      y7t_stream stream) {
     Y7T_ARG_CHECK(batch >= 0 && out_cap >= 0);
     if (batch == 0) return 0;
     Y7T_ARG_CHECK(states && dets && n_dets && out_rows && out_count);
@@ -315,13 +337,13 @@ extern "C" int y7t_tracker_step_batch(void* const* states, const float* const* d
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     hipLaunchKernelGGL(k_tracker_step, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows,
-                       out_count, out_cap, kFastBytes);
+                       out_count, out_cap, kFastBytes, gmc_warps);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count, int threads,
-                                y7t_stream stream) {
+                                const double* gmc_warp, y7t_stream stream) {
     Y7T_ARG_CHECK(state && out_rows && out_count && out_cap >= 0);
     Y7T_ARG_CHECK(n <= 0 || dets);
     const int nt = step_threads(threads, n);
@@ -329,7 +351,7 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
-                       out_count, kFastBytes);
+                       out_count, kFastBytes, gmc_warp);
     Y7T_LAUNCH_CHECK();
     return 0;
 }

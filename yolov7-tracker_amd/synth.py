@@ -88,3 +88,13 @@ def make_frames(n_frames=4, n_obj=80, size=1280, seq_idx=0):
             img[y1:y2, x1:x2] = colors[i]
         frames[t] = img.astype(np.uint8)
     return frames
+
+
+def make_warps(n_frames=100, seq_idx=0, rot=0.002, shift=2.0):
+    """-> (n_frames, 2, 3) float64 camera-motion matrices near the identity (what BoT-SORT's GMC.apply would estimate from
+    ORB matches, /root/reference/tracker/botsort.py:13-248 -- the estimation itself is OpenCV and out of scope)."""
+    rng = np.random.default_rng(BASE_SEED + 5000 + seq_idx)
+    H = np.zeros((n_frames, 2, 3))
+    H[:, :2, :2] = np.eye(2) + rng.normal(0, rot, (n_frames, 2, 2))
+    H[:, :, 2] = rng.normal(0, shift, (n_frames, 2))
+    return H

@@ -246,7 +246,7 @@ class BaseTracker(object):
         self._det_keep = None
 
     # ------------------------------------------------------------------------------------------
-    def _launch(self, det_results, out=None, n_dev=None):
+    def _launch(self, det_results, out=None, n_dev=None, warp=None):
         """enqueue one frame step (asynchronous).  out: optional (cap_t + 1, 8) float64 device tensor that receives the
         returned rows (row cap_t holds the count) instead of the tracker's own buffer -- lets a pipeline keep every
         frame's result on the device without a per-frame host round trip."""
@@ -268,7 +268,8 @@ class BaseTracker(object):
             optr, cptr = _lib.ptr(self._out), self._count_ptr
         else:
             optr, cptr = _lib.ptr(out), ctypes.c_void_p(out.data_ptr() + self.cap_t * 8 * 8)
-        _lib.check(self._L.y7t_tracker_step(_lib.ptr(self._state), dptr, n, optr, self.cap_t, cptr, self.threads, _lib.stream_ptr()))
+        _lib.check(self._L.y7t_tracker_step(_lib.ptr(self._state), dptr, n, optr, self.cap_t, cptr, self.threads, _lib.ptr(warp),
+                                            _lib.stream_ptr()))
         self.frame_id += 1
         self._snap_cache = None
 

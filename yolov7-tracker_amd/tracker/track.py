@@ -19,10 +19,11 @@ import yaml
 from . import tracker_dataloader
 from .basetrack import BaseTracker
 from .bytetrack import ByteTrack
+from .botsort import BoTSORT
 from .timer import Timer
 from ..detector import attempt_load, check_img_size, non_max_suppression, scale_coords
 
-TRACKER_DICT = {'sort': BaseTracker, 'bytetrack': ByteTrack}   # track.py:56-65; the other six trackers are out of scope
+TRACKER_DICT = {'sort': BaseTracker, 'bytetrack': ByteTrack, 'botsort': BoTSORT}   # track.py:56-65; the other trackers are out of scope
 
 timer = Timer()
 seq_fps = []
@@ -53,6 +54,8 @@ def main(opts, cfgs):
     DATASET_ROOT, CERTAIN_SEQS, IGNORE_SEQS = cfgs['DATASET_ROOT'], cfgs['CERTAIN_SEQS'], cfgs['IGNORE_SEQS']
     if opts.tracker not in TRACKER_DICT:
         raise NotImplementedError("tracker %r: only %s run on the device path" % (opts.tracker, sorted(TRACKER_DICT)))
+    if opts.tracker == 'botsort':
+        opts.kalman_format = 'botsort'      # track.py:68-69
     img_size = opts.img_size[0] if isinstance(opts.img_size, (list, tuple)) else opts.img_size
     model = attempt_load(opts.model_path, cfg=opts.model_cfg, nc=opts.nc, img_size=img_size)
     stride = int(model.stride.max())
