@@ -115,12 +115,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
+    share = os.environ.get("Y7T_BENCH_SHARE_GPU") == "1"     # smoke-test the N>1 code path on a 1-GPU box (with the gloo backend)
+    backend = os.environ.get("Y7T_BENCH_BACKEND", "nccl")    # 'nccl' == RCCL on ROCm
+    torch.cuda.set_device(0 if share else local)
     dist = None
+    cdev = "cuda" if backend == "nccl" else "cpu"            # where the (tiny) collective payloads live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from yolov7_tracker_amd import synth
     from yolov7_tracker_amd.detector import arch, model
@@ -183,17 +189,23 @@ def main():
     barrier()
     dt_s = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_s = float(tmax.item())
-        # result gather (the only collective): per-rank id counts -> exclusive prefix (id re-basing), rows to rank 0
-        cnt = torch.tensor([BaseTrack._count], dtype=torch.int64, device="cuda")
+        # result gather (the only collective, after the timed steps): per-rank id counts -> exclusive prefix (id re-basing so
+        # the ids equal a single-process run with the reference's global BaseTrack._count), rows to rank 0
+        cnt = torch.tensor([BaseTrack._count], dtype=torch.int64, device=cdev)
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
         base = int(sum(int(c.item()) for c in allc[:rank]))
-        results[..., 0] += base * (results[..., 0] > 0)
-        gathered = [torch.empty_like(results) for _ in range(world)] if rank == 0 else None
-        dist.gather(results, gathered, dst=0)
+        ids = results[:, :trk.cap_t, 0]                      # row cap_t of every frame holds the row count, not a track
+        ids += base * (ids > 0)
+        payload = results if cdev == "cuda" else results.cpu()
+        gathered = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, gathered, dst=0)
+        if rank == 0:
+            n_rows = [int((g[:, :trk.cap_t, 0] > 0).sum().item()) for g in gathered]
+            gathered_info = {"rows_per_rank": n_rows, "id_base_per_rank": [int(sum(int(c.item()) for c in allc[:r])) for r in range(world)]}
     torch.cuda.synchronize()
     det.check_overflow()
 
@@ -217,7 +229,8 @@ def main():
             "config": {"workload": "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack, 1 synthetic VisDrone-shape sequence per GPU, ~%d dets/frame"
                                    % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
-                       "parallelism": "sequence-sharded x%d" % world},
+                       "parallelism": "sequence-sharded x%d" % world, "collective_backend": backend if world > 1 else None,
+                       "result_gather": gathered_info if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch list from profiles/r01_conv_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
@@ -227,7 +240,7 @@ def main():
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, det, frames_host, dets_seq)
         print(json.dumps(line))
     if dist is not None:

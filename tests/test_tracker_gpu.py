@@ -79,6 +79,52 @@ def test_fused_tracker_accepts_device_tensor_and_views():
     assert t.frame_id == 12
 
 
+def test_batched_step_equals_single_trackers(L):
+    """y7t_tracker_step_batch: 4 independent sequences step together in ONE launch (one workgroup each, detection counts read
+    on the device) and produce exactly what 4 separately stepped trackers produce (BASELINE config 5 inside one GPU)."""
+    import ctypes
+    from yolov7_tracker_amd import _lib, synth
+    nseq, nfr, cap = 4, 25, 256
+    seqs = [synth.make_detections(nfr, 40 + 10 * s, seq_idx=20 + s) for s in range(nseq)]
+    nbytes = int(L.y7t_tracker_state_bytes(cap, cap))
+
+    def mk():
+        st = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nseq)]
+        ids = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(nseq)]      # one id counter per sequence
+        for s in range(nseq):
+            _lib.check(L.y7t_tracker_init(_lib.ptr(st[s]), nbytes, 1, 0, cap, cap, 0.2, 0.5, 30, 1, _lib.ptr(ids[s]), _lib.stream_ptr()))
+        return st, ids
+    outs = torch.zeros((nseq, cap + 1, 8), dtype=torch.float64, device="cuda")
+    # (a) one tracker at a time
+    st, _ = mk()
+    single = [[] for _ in range(nseq)]
+    for f in range(nfr):
+        for s in range(nseq):
+            d = torch.from_numpy(seqs[s][f]).cuda()
+            _lib.check(L.y7t_tracker_step(_lib.ptr(st[s]), _lib.ptr(d), d.shape[0], _lib.ptr(outs[s]), cap,
+                                          ctypes.c_void_p(outs[s].data_ptr() + cap * 64), 0, None, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            h = outs[s].cpu().numpy()
+            single[s].append(h[:int(h[cap].view(np.int32)[0])].copy())
+    # (b) all four in one launch per frame
+    st, _ = mk()
+    state_ptrs = torch.tensor([t.data_ptr() for t in st], dtype=torch.int64, device="cuda")
+    out_ptrs = torch.tensor([outs[s].data_ptr() for s in range(nseq)], dtype=torch.int64, device="cuda")
+    counts = torch.zeros(nseq, dtype=torch.int32, device="cuda")
+    for f in range(nfr):
+        dd = [torch.from_numpy(seqs[s][f]).cuda() for s in range(nseq)]
+        det_ptrs = torch.tensor([d.data_ptr() for d in dd], dtype=torch.int64, device="cuda")
+        n_dev = torch.tensor([d.shape[0] for d in dd], dtype=torch.int32, device="cuda")
+        _lib.check(L.y7t_tracker_step_batch(_lib.ptr(state_ptrs), _lib.ptr(det_ptrs), _lib.ptr(n_dev), _lib.ptr(out_ptrs), _lib.ptr(counts), cap,
+                                            nseq, 0, None, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy()
+        h = outs.cpu().numpy()
+        for s in range(nseq):
+            np.testing.assert_array_equal(h[s, :c[s]], single[s][f])
+            assert c[s] == len(single[s][f])
+
+
 def test_empty_and_ragged_frames():
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
