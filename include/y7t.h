@@ -162,8 +162,9 @@ int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg,
  * head[l]: NHWC fp32 output of the l-th Detect 1x1 conv, [B][ny][nx][na*no].  anchors: [nl][na][2] pixels (host).
  * letterbox: DEVICE [B][5] = gain, pad_w, pad_h, H0, W0.  dets: [B][max_det][6]; ndets: [B];
  * cand_count (may be NULL): [B] candidates above conf_thres (> cap == overflow, caller must check).
- * workspace: y7t_det_postprocess_workspace_bytes(B, cap). */
-size_t y7t_det_postprocess_workspace_bytes(int B, int cap);
+ * cap: candidate capacity per image (the number of anchors can never overflow it); the NMS itself runs on the top
+ * min(cap, max_nms) candidates like the reference.  workspace: y7t_det_postprocess_workspace_bytes(B, cap, max_nms). */
+size_t y7t_det_postprocess_workspace_bytes(int B, int cap, int max_nms);
 int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const int* ny, const int* nx, const float* strides,
                         const float* anchors, int nl, int na, int no, int B, float conf_thres, float iou_thres, int max_det,
                         int max_nms, int cap, const float* letterbox, float* dets, int* ndets, int* keep_idx, int* cand_count,

@@ -49,5 +49,5 @@ struct Y7TPostArgs {
     int* count_out;         // [B] number of candidates found (> cap means overflow) or null
     void* ws; size_t ws_bytes;
 };
-size_t y7t_post_ws_bytes(int B, int cap);
+size_t y7t_post_ws_bytes(int B, int cap, int max_nms);
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s);

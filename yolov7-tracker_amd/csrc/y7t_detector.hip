@@ -75,7 +75,9 @@ extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) {
     return 0;
 }
 
-extern "C" size_t y7t_det_postprocess_workspace_bytes(int B, int cap) { return (B > 0 && cap > 0) ? y7t_post_ws_bytes(B, cap) : 0; }
+extern "C" size_t y7t_det_postprocess_workspace_bytes(int B, int cap, int max_nms) {
+    return (B > 0 && cap > 0 && max_nms > 0) ? y7t_post_ws_bytes(B, cap, max_nms) : 0;
+}
 
 extern "C" int y7t_det_postprocess(const float* const* head, const int* ny, const int* nx, const float* strides, const float* anchors, int nl,
                                    int na, int no, int B, float conf_thres, float iou_thres, int max_det, int max_nms, int cap,

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_decode_filter(const DecodeArgs a, int l
 // rank by (score desc, row index asc); scatter class-offset boxes (x[:, :4] + cls*4096) into sorted order
 __global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbox, const float* __restrict__ cscore, const float* __restrict__ ccls,
                                                    const int* __restrict__ cidx, const int* __restrict__ count, int cap, int max_nms,
-                                                   float* __restrict__ sbox, int* __restrict__ sorder, int* __restrict__ nsorted) {
+                                                   float* __restrict__ sbox, int* __restrict__ sorder, int* __restrict__ nsorted, int mcap) {
     __shared__ float ss[256];
     __shared__ int si[256];
     const int b = blockIdx.y;
@@ -198,9 +198,9 @@ __global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbo
     if (i < n && rank < max_nms) {
         const float off = ccls[(size_t)b * cap + i] * 4096.f;
         const float* bo = cbox + ((size_t)b * cap + i) * 4;
-        float* so = sbox + ((size_t)b * cap + rank) * 4;
+        float* so = sbox + ((size_t)b * mcap + rank) * 4;
         so[0] = bo[0] + off; so[1] = bo[1] + off; so[2] = bo[2] + off; so[3] = bo[3] + off;
-        sorder[(size_t)b * cap + rank] = i;
+        sorder[(size_t)b * mcap + rank] = i;
     }
     if (i == 0) nsorted[b] = n < max_nms ? n : max_nms;
 }
@@ -250,15 +250,16 @@ __global__ void __launch_bounds__(64) k_nms_mask(const float* __restrict__ sbox,
 __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* __restrict__ mask, int words, const int* __restrict__ nsorted,
                                                  const int* __restrict__ sorder, const float* __restrict__ cbox, const float* __restrict__ cscore,
                                                  const float* __restrict__ ccls, int cap, int max_det, const float* __restrict__ lb /*[B][5] gain,padw,padh,H0,W0*/,
-                                                 float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/) {
+                                                 float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/,
+                                                 int mcap) {
     extern __shared__ unsigned long long removed[];   // words
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = nsorted[b];
     const int nw = (n + 63) / 64;
     for (int w = lane; w < nw; w += 64) removed[w] = 0ull;
     __syncthreads();
-    const unsigned long long* mk = mask + (size_t)b * cap * words;
-    const int* so = sorder + (size_t)b * cap;
+    const unsigned long long* mk = mask + (size_t)b * mcap * words;
+    const int* so = sorder + (size_t)b * mcap;
     int nkeep = 0;
     for (int c = 0; c < nw && nkeep < max_det; ++c) {
         const int i = c * 64 + lane;
@@ -310,21 +311,23 @@ __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* __res
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-size_t y7t_post_ws_bytes(int B, int cap) {
-    const size_t words = (size_t)(cap + 63) / 64;
+size_t y7t_post_ws_bytes(int B, int cap, int max_nms) {
+    const size_t mcap = (size_t)(cap < max_nms ? cap : max_nms);    // NMS runs on the top max_nms candidates only (general.py:664-665)
+    const size_t words = (mcap + 63) / 64;
     size_t o = 0;
     auto take = [&](size_t bytes) { o = (o + bytes + 255) & ~(size_t)255; };
     take((size_t)B * cap * 16); take((size_t)B * cap * 4); take((size_t)B * cap * 4); take((size_t)B * cap * 4);  // cbox cscore ccls cidx
     take((size_t)B * 4); take((size_t)B * 4);                                                                    // count nsorted
-    take((size_t)B * cap * 16); take((size_t)B * cap * 4);                                                       // sbox sorder
-    take((size_t)B * cap * words * 8);                                                                           // mask
+    take((size_t)B * mcap * 16); take((size_t)B * mcap * 4);                                                     // sbox sorder
+    take((size_t)B * mcap * words * 8);                                                                          // mask
     take((size_t)B * 5 * 4);                                                                                     // letterbox params
     return o + 256;
 }
 
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     const int B = a.B, cap = a.cap;
-    const size_t words = (size_t)(cap + 63) / 64;
+    const size_t mcap = (size_t)(cap < a.max_nms ? cap : a.max_nms);
+    const size_t words = (mcap + 63) / 64;
     char* base = (char*)a.ws;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base + o; o = (o + bytes + 255) & ~(size_t)255; return p; };
@@ -334,9 +337,9 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     int* cidx = (int*)take((size_t)B * cap * 4);
     int* count = (int*)take((size_t)B * 4);
     int* nsorted = (int*)take((size_t)B * 4);
-    float* sbox = (float*)take((size_t)B * cap * 16);
-    int* sorder = (int*)take((size_t)B * cap * 4);
-    unsigned long long* mask = (unsigned long long*)take((size_t)B * cap * words * 8);
+    float* sbox = (float*)take((size_t)B * mcap * 16);
+    int* sorder = (int*)take((size_t)B * mcap * 4);
+    unsigned long long* mask = (unsigned long long*)take((size_t)B * mcap * words * 8);
     float* lb = (float*)take((size_t)B * 5 * 4);
     if (o + 256 > a.ws_bytes) { y7t_set_error("postprocess workspace too small (%zu < %zu)", a.ws_bytes, o + 256); return Y7T_E_ARG; }
     Y7T_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int) * B, s));
@@ -357,12 +360,12 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k_decode_filter, dim3(blocks), dim3(256), 0, s, d, l);
         Y7T_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rank_sort, dim3((cap + 255) / 256, B), dim3(256), 0, s, cbox, cscore, ccls, cidx, count, cap, a.max_nms, sbox, sorder, nsorted);
+    hipLaunchKernelGGL(k_rank_sort, dim3((cap + 255) / 256, B), dim3(256), 0, s, cbox, cscore, ccls, cidx, count, cap, a.max_nms, sbox, sorder, nsorted, (int)mcap);
     Y7T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_mask, dim3(1024, B), dim3(64), 0, s, sbox, nsorted, cap, a.iou_thres, mask, (int)words);
+    hipLaunchKernelGGL(k_nms_mask, dim3(1024, B), dim3(64), 0, s, sbox, nsorted, (int)mcap, a.iou_thres, mask, (int)words);
     Y7T_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(64), words * 8, s, mask, (int)words, nsorted, sorder, cbox, cscore, ccls, cap, a.max_det, lb, a.dets,
-                       a.ndets, a.keep_idx);
+                       a.ndets, a.keep_idx, (int)mcap);
     Y7T_LAUNCH_CHECK();
     if (a.count_out) Y7T_HIP_CHECK(hipMemcpyAsync(a.count_out, count, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
     return 0;

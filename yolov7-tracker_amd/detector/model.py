@@ -72,12 +72,13 @@ class HeadOutput:
 class Detector:
     """spec: arch dict; state_dict: reference-style names (see detector/weights.py)."""
 
-    def __init__(self, spec, state_dict=None, img_size=(1280, 1280), max_batch=1, max_cand=16384, seed=0):
+    def __init__(self, spec, state_dict=None, img_size=(1280, 1280), max_batch=1, max_cand=None, seed=0):
         _lib.require_gpu()
         self._L = _lib.load()
         self.spec = spec
         self.nodes, self.layer_out = graph.parse(spec)
-        self.max_batch, self.max_cand = int(max_batch), int(max_cand)
+        self.max_batch, self._max_cand_arg = int(max_batch), max_cand
+        self.max_cand = 0
         self.names = [str(i) for i in range(spec["nc"])]
         self._sd, self._seed = state_dict, seed
         self._plans = {}
@@ -110,8 +111,11 @@ class Detector:
                                               _lib.ptr(plan.arena), plan.arena_bytes, _lib.ptr(plan.w_dev), _lib.ptr(plan.b_dev),
                                               self.max_batch, ctypes.byref(h)))
             plan.handle = h
-            B, cap = self.max_batch, self.max_cand
-            plan.ws = torch.zeros(int(self._L.y7t_det_postprocess_workspace_bytes(B, cap)), dtype=torch.uint8, device="cuda")
+            n_anchors = sum(plan.det["na"] * hd["ny"] * hd["nx"] for hd in plan.heads)
+            # candidate capacity: every anchor fits (no overflow, like the reference); NMS works on the top MAX_NMS of them
+            plan.cap = int(self._max_cand_arg) if self._max_cand_arg else (n_anchors + 63) // 64 * 64
+            B, cap = self.max_batch, plan.cap
+            plan.ws = torch.zeros(int(self._L.y7t_det_postprocess_workspace_bytes(B, cap, MAX_NMS)), dtype=torch.uint8, device="cuda")
             plan.dets = torch.zeros((B, MAX_DET, 6), dtype=torch.float32, device="cuda")
             plan.ndets = torch.zeros(B, dtype=torch.int32, device="cuda")
             plan.keep = torch.zeros((B, MAX_DET), dtype=torch.int32, device="cuda")
@@ -126,6 +130,7 @@ class Detector:
             plan.anchors = (ctypes.c_float * 24)(*(flat + [0.0] * (24 - len(flat))))
             self._plans[hw] = plan
         self.plan = self._plans[hw]
+        self.max_cand = self.plan.cap
 
     def head_tensor(self, level, B):
         p = self.plan
