@@ -814,6 +814,216 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = 128ull << 20;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent, cross-tile pipelined variant (uniform-tap layers, fp16 output).  Y7T_CONV_ABLATE shows that for most layers of
+// the network the per-tile fixed costs -- index set-up, the latency of a tile's first DMA stage, the epilogue -- are as large
+// as the K loop itself (K = 576 is 9 steps).  Here at most 2 workgroups per CU stay resident and walk over the tiles; the
+// 2-stage LDS ring runs CONTINUOUSLY through the tile boundaries: while the last K-step of tile t is being multiplied the DMAs
+// of tile t+1's first K-step are already in flight (its geometry was computed during tile t), and tile t's epilogue
+// (bias + SiLU + LDS transpose in its OWN LDS region + full-line stores) overlaps those DMAs and the co-resident workgroup's
+// MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ void __launch_bounds__(256, 2) k_conv_persist(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, BK = 32, ROWB = 64, CPR = 4, RPW = 16, RPR = 64;
+    constexpr int WTN = BN / 2, WTM = BM / 2, TN = WTN / 32, TM = WTM / 32;
+    constexpr int RM = BM / RPR, RN = (BN + RPR - 1) / RPR;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int OROW = BN * 2 + 16;
+    constexpr int EPI_OFF = 2 * STAGE;                        // the epilogue transposes in its own LDS region
+    constexpr int KS = BK / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi32 = lane >> 5;
+    const int n_tiles_m = (p.M + BM - 1) / BM, n_tiles_n = p.Cout_pad / BN, n_tiles = n_tiles_m * n_tiles_n;
+    const int G = gridDim.x;
+    // XCD-aware: workgroup b runs on XCD b % 8 -> give every XCD a contiguous chunk of each window of G tiles
+    const int b0 = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    const int nk = p.K_pad / BK;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const int lrow = wave * RPW + lane / CPR;
+    const int gchunk = (lane % CPR) ^ ((lrow >> 2) & 3);
+    const int HoWo = p.Ho * p.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    const int nchunk = p.Cin >> 6;
+
+    // geometry of one tile: DMA offsets / tap masks of this lane's rows
+    struct Geo { int xoff[RM]; unsigned vmask[RM]; int woff[RN]; int m0, n0; };
+    auto make_geo = [&](int tile, Geo& g) {
+        const int tile_n = tile % n_tiles_n, tile_m = tile / n_tiles_n;
+        g.m0 = tile_m * BM; g.n0 = tile_n * BN;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int m = g.m0 + r * RPR + lrow;
+            g.vmask[r] = 0; g.xoff[r] = 0;
+            if (m < p.M) {
+                int b = (int)((float)m * inv_howo);
+                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
+                const int rem = m - b * HoWo;
+                int ho = (int)((float)rem * inv_wo);
+                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
+                const int wo = rem - ho * p.Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                g.xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gchunk * 8) * 2;
+                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
+                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
+                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh >= klo && kh <= khi) g.vmask[r] |= colbits << (kh * p.KW);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RN; ++r) g.woff[r] = ((g.n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
+    };
+    // DMAs of K-step kt of the tile described by g into ring slot `stage`
+    auto issue_stage = [&](const Geo& g, int stage, int kt) {
+        char* xs = smem + stage * STAGE;
+        char* ws = xs + BM * ROWB;
+        int tap, ci;
+        if (p.korder) {      // (kh, 64-channel chunk, kw) K order
+            const int grp = kt >> 1, sub = kt & 1;
+            const int kw = grp % p.KW, c = (grp / p.KW) % nchunk, kh = grp / (p.KW * nchunk);
+            tap = kh * p.KW + kw; ci = (c << 6) + sub * BK;
+        } else {
+            const int k = kt * BK;
+            tap = k / p.Cin; ci = k - tap * p.Cin;
+        }
+        const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
+        const int kw = tap - kh * p.KW;
+        const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int voff = ((g.vmask[r] >> tap) & 1u) ? g.xoff[r] + tapoff : -1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * RPR + wave * RPW) * ROWB), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RN; ++r)
+            if (BN >= RPR || (r * RPR + lrow) < BN)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, g.woff[r], kt * BK * 2, 0, 0);
+    };
+
+    Geo cur, nxt;
+    int tile = b0;
+    if (tile >= n_tiles) return;
+    make_geo(tile, cur);
+    issue_stage(cur, 0, 0);
+    int slot = 0;                       // ring slot that holds the stage about to be consumed
+    while (true) {
+        const int next_tile = tile + G;
+        const bool has_next = next_tile < n_tiles;
+        floatx16 acc[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // refill the other slot: next K-step of this tile, or the first K-step of the next tile
+            if (kt + 1 < nk) issue_stage(cur, slot ^ 1, kt + 1);
+            else if (has_next) issue_stage(nxt, slot ^ 1, 0);
+            const char* xs = smem + slot * STAGE;
+            const char* ws = xs + BM * ROWB;
+            half8 wf[KS][TN], xf[KS][TM];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int q = ks * 2 + hi32;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int row = wn * WTN + i * 32 + l31;
+                    wf[ks][i] = *(const half8*)(ws + row * ROWB + ((q ^ ((row >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int row = wm * WTM + j * 32 + l31;
+                    xf[ks][j] = *(const half8*)(xs + row * ROWB + ((q ^ ((row >> 2) & 3)) << 4));
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+            if (kt == 0 && has_next) make_geo(next_tile, nxt);     // the next tile's index math rides behind the first MFMAs
+            slot ^= 1;
+        }
+        // ---- epilogue of `tile` in its own LDS region; the next tile's first DMA stage is already in flight ----
+        {
+            char* eb = smem + EPI_OFF;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int pix = wm * WTM + j * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int nl = wn * WTN + i * 32;
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int g = gp * 2 + gg;
+                            const int n = cur.n0 + nl + 8 * g + 4 * hi32;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                            half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                            w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                            w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                        }
+                        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+                        uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                        *(uint4v*)(eb + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // tile staged in LDS (the DMAs in flight are not drained: raw barrier)
+            typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+            constexpr int CPP = BN / 8, NCH = BM * CPP;
+            half_t* outp = (half_t*)p.out;
+#pragma unroll 4
+            for (int c = tid; c < NCH; c += 256) {
+                const int pix = c / CPP, ch = c - pix * CPP;
+                const int m = cur.m0 + pix, n = cur.n0 + ch * 8;
+                if (m < p.M && n < p.Cout) {
+                    const uint4v v = *(const uint4v*)(eb + pix * OROW + ch * 16);
+                    *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // the epilogue region may be overwritten by the next tile's epilogue
+        }
+        if (!has_next) break;
+        tile = next_tile;
+        cur = nxt;
+    }
+#endif
+}
+
+template <int BN>
+static int launch_conv_persist(const Y7TConvArgs& a, hipStream_t s) {
+    constexpr unsigned lds = 2 * (128 + BN) * 64 + 128 * (BN * 2 + 16);
+    static bool attr = false;
+    if (!attr) {
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_persist<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int tiles = ((a.M + 127) / 128) * (a.Cout_pad / BN);
+    const int grid = tiles < 512 ? tiles : 512;     // 2 resident workgroups per CU
+    hipLaunchKernelGGL((k_conv_persist<BN>), dim3(grid), dim3(256), lds, s, a);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
@@ -891,6 +1101,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     const bool wide = a.Cout_pad % 128 == 0;
     const bool ws_ok = !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) && !(a.cout_off & 7);
     const int var = conv_variant();
+    if (var == 12 && ws_ok && a.Cin % 32 == 0 && (!a.korder || a.Cin % 64 == 0)) return wide ? launch_conv_persist<128>(a, s) : launch_conv_persist<64>(a, s);
     if (var == 11 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ap<128>(a, s) : launch_conv_ap<64>(a, s);
     if (var == 8 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ws<128, 128, 64, 2>(a, s) : launch_conv_ws<128, 64, 64, 2>(a, s);
     if (var == 9 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 3>(a, s) : launch_conv_ws<128, 64, 32, 3>(a, s);
