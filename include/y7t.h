@@ -157,6 +157,13 @@ int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
  * out: NHWC fp16 with ldout channels (16 with reorg: 12 + 4 zero; 8 without: 3 + 5 zero). */
 int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg, void* out_f16, int ldout, y7t_stream stream);
 
+/* TrackerLoader._letterbox (tracker/tracker_dataloader.py:100-130) fused with the layout above, for raw (B,H0,W0,3) uint8 BGR
+ * frames: bilinear resize (cv2.INTER_LINEAR geometry: half-pixel centres; float arithmetic, rounded to uint8) to new_w x new_h,
+ * placed at (top, left) of the H x W letterboxed image, pad colour 114.  The host computes new_h/new_w/top/left exactly like
+ * the reference (auto=True: pad only to the stride multiple). */
+int y7t_letterbox_layout_u8(const void* img, int B, int H0, int W0, int H, int W, int new_h, int new_w, int top, int left, int reorg,
+                            void* out_f16, int ldout, y7t_stream stream);
+
 /* Detect.forward decode (models/yolo.py:39-57) + non_max_suppression (utils/general.py:607-695, multi_label=False,
  * agnostic=False) + scale_coords/clip/round (general.py:319-340, tracker/track.py:234-244), all on the device.
  * head[l]: NHWC fp32 output of the l-th Detect 1x1 conv, [B][ny][nx][na*no].  anchors: [nl][na][2] pixels (host).

@@ -124,6 +124,28 @@ def test_u8_bgr_input_equals_float_input():
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("shape", [(540, 960), (1280, 1280), (300, 500)])
+def test_letterbox_layout_matches_oracle(shape):
+    """raw uint8 BGR frame -> device letterbox (resize + pad 114) + BGR->RGB,/255,ReOrg,fp16 == oracle letterbox + layout"""
+    from oracle import letterbox_np as lb
+    det = build("yolov7-w6", 10, (256, 256), 1)
+    rng = np.random.default_rng(4)
+    # smooth-ish image so that bilinear taps are not pure noise
+    small = rng.integers(0, 256, (shape[0] // 8 + 2, shape[1] // 8 + 2, 3)).astype(np.float32)
+    frame = np.kron(small, np.ones((8, 8, 1), np.float32))[:shape[0], :shape[1]].astype(np.uint8)
+    out, (H, W) = det.forward_frames(torch.from_numpy(frame), img_size=256)
+    torch.cuda.synchronize()
+    ref = lb.letterbox(frame, new_shape=(256, 256), stride=64)
+    assert ref.shape[:2] == (H, W)
+    x = lb.to_model_input(ref)                                   # (3, H, W) RGB
+    want = np.concatenate([x[:, ::2, ::2], x[:, 1::2, ::2], x[:, ::2, 1::2], x[:, 1::2, 1::2]], 0).transpose(1, 2, 0)   # ReOrg, HWC
+    got = det.buffer_view(0, 1, 16).view(1, H // 2, W // 2, 16)[0, :, :, :12].float().cpu().numpy()
+    diff = np.abs(got - want.astype(np.float16).astype(np.float32))
+    # identical except where the float bilinear lands within rounding distance of a .5 tie (one grey level = 1/255)
+    assert diff.max() <= 1.0 / 255 + 1e-3
+    assert (diff > 1e-3).mean() < 0.01
+
+
 def test_decode_nms_matches_oracle():
     """plant head logits, run the device decode+NMS chain, compare with the oracle's non_max_suppression +
     scale_coords + round on the decoded tensor of the SAME logits."""

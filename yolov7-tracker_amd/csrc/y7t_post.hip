@@ -42,6 +42,52 @@ __global__ void __launch_bounds__(256) k_input_layout(const void* __restrict__ i
     }
 }
 
+// letterbox (tracker_dataloader.py:100-130: resize INTER_LINEAR to `new_unpad`, pad 114 to the stride multiple) fused with the
+// layout above: out pixel (y, x) of the H x W letterboxed image samples the H0 x W0 frame bilinearly (half-pixel centres,
+// clamped taps, result rounded to uint8 like the resized image the reference feeds on) or is the pad colour.
+__global__ void __launch_bounds__(256) k_letterbox_layout(const uint8_t* __restrict__ img, int B, int H0, int W0, int H, int W, int new_h, int new_w,
+                                                          int top, int left, int reorg, half_t* __restrict__ out, int ldout) {
+    const int Ho = reorg ? H / 2 : H, Wo = reorg ? W / 2 : W;
+    const long long tot = (long long)B * Ho * Wo;
+    const float sy = (float)H0 / (float)new_h, sx = (float)W0 / (float)new_w;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < tot; p += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(p / ((long long)Ho * Wo));
+        const int rem = (int)(p - (long long)b * Ho * Wo);
+        const int yo = rem / Wo, xo = rem - yo * Wo;
+        half_t v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = (half_t)0.f;
+        const int ng = reorg ? 4 : 1;
+        for (int g = 0; g < ng; ++g) {
+            const int y = reorg ? 2 * yo + (g & 1) : yo, x = reorg ? 2 * xo + (g >> 1) : xo;
+            const int yy = y - top, xx = x - left;
+            float px[3] = {114.f, 114.f, 114.f};   // BGR pad colour
+            if ((unsigned)yy < (unsigned)new_h && (unsigned)xx < (unsigned)new_w) {
+                if (new_h == H0 && new_w == W0) {
+                    const uint8_t* s = img + (((size_t)b * H0 + yy) * W0 + xx) * 3;
+                    px[0] = s[0]; px[1] = s[1]; px[2] = s[2];
+                } else {
+                    float fy = ((float)yy + 0.5f) * sy - 0.5f, fx = ((float)xx + 0.5f) * sx - 0.5f;
+                    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+                    const float wy = fy - (float)y0, wx = fx - (float)x0;
+                    const int y1 = min(max(y0 + 1, 0), H0 - 1), x1 = min(max(x0 + 1, 0), W0 - 1);
+                    y0 = min(max(y0, 0), H0 - 1); x0 = min(max(x0, 0), W0 - 1);
+                    const uint8_t* r0 = img + ((size_t)b * H0 + y0) * W0 * 3;
+                    const uint8_t* r1 = img + ((size_t)b * H0 + y1) * W0 * 3;
+                    for (int c = 0; c < 3; ++c) {
+                        const float t0 = (1.f - wx) * r0[x0 * 3 + c] + wx * r0[x1 * 3 + c];
+                        const float t1 = (1.f - wx) * r1[x0 * 3 + c] + wx * r1[x1 * 3 + c];
+                        px[c] = rintf((1.f - wy) * t0 + wy * t1);
+                    }
+                }
+            }
+            for (int ch = 0; ch < 3; ++ch) v[g * 3 + ch] = (half_t)(px[2 - ch] / 255.0f);   // BGR -> RGB, /255
+        }
+        half_t* o = out + (size_t)p * ldout;
+        for (int c = 0; c < ldout; c += 8) *(half8*)(o + c) = *(half8*)(v + c);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ upsample / pool
 // out[b][y][x][coff + c] = in[b][y/2][x/2][cin_off + c]; 8 channels (16 B) per thread
 __global__ void __launch_bounds__(256) k_upsample2x(const half_t* __restrict__ in, int ldin, int cin_off, int B, int H, int W, int C,
@@ -114,6 +160,20 @@ extern "C" int y7t_input_layout(const void* img, int is_u8, int B, int H, int W,
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
     if (is_u8) hipLaunchKernelGGL(k_input_layout<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, B, H, W, reorg, (half_t*)out_f16, ldout);
     else hipLaunchKernelGGL(k_input_layout<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, B, H, W, reorg, (half_t*)out_f16, ldout);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_letterbox_layout_u8(const void* img, int B, int H0, int W0, int H, int W, int new_h, int new_w, int top, int left, int reorg,
+                                       void* out_f16, int ldout, y7t_stream stream) {
+    Y7T_ARG_CHECK(img && out_f16 && B > 0 && H0 > 0 && W0 > 0 && H > 0 && W > 0 && new_h > 0 && new_w > 0 && top >= 0 && left >= 0);
+    Y7T_ARG_CHECK(top + new_h <= H && left + new_w <= W);
+    Y7T_ARG_CHECK(ldout == 8 || ldout == 16);
+    Y7T_ARG_CHECK(reorg ? (ldout == 16 && H % 2 == 0 && W % 2 == 0) : 1);
+    const long long tot = (long long)B * (reorg ? H / 2 : H) * (reorg ? W / 2 : W);
+    int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_letterbox_layout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img, B, H0, W0, H, W, new_h, new_w, top, left,
+                       reorg, (half_t*)out_f16, ldout);
     Y7T_LAUNCH_CHECK();
     return 0;
 }

@@ -171,6 +171,42 @@ class Detector:
         self._img_keep = img
         return HeadOutput(self, B, (H, W))
 
+    @staticmethod
+    def letterbox_params(shape, new_shape, stride, auto=True, scaleup=True):
+        """tracker_dataloader.py:100-130 -> (H, W of the letterboxed image, new_h, new_w, top, left)"""
+        if isinstance(new_shape, int):
+            new_shape = (new_shape, new_shape)
+        r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+        if not scaleup:
+            r = min(r, 1.0)
+        new_w, new_h = int(round(shape[1] * r)), int(round(shape[0] * r))
+        dw, dh = new_shape[1] - new_w, new_shape[0] - new_h
+        if auto:
+            dw, dh = np.mod(dw, stride), np.mod(dh, stride)
+        dw /= 2
+        dh /= 2
+        top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+        left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+        return new_h + top + bottom, new_w + left + right, new_h, new_w, top, left
+
+    def forward_frames(self, frames, img_size=1280):
+        """raw (B,H0,W0,3) uint8 BGR frames (device or host) -> letterbox + layout on the device + forward.
+        -> (HeadOutput, letterboxed (H, W)).  What TrackerLoader.__getitem__ + model(img) do in the reference."""
+        if frames.dim() == 3:
+            frames = frames[None]
+        frames = frames.cuda(non_blocking=True).contiguous()
+        B, H0, W0 = frames.shape[0], frames.shape[1], frames.shape[2]
+        stride = int(self.stride.max())
+        H, W, new_h, new_w, top, left = self.letterbox_params((H0, W0), img_size, stride)
+        self._select((H, W))
+        p = self.plan
+        s = _lib.stream_ptr()
+        _lib.check(self._L.y7t_letterbox_layout_u8(_lib.ptr(frames), B, H0, W0, H, W, new_h, new_w, top, left, int(p.reorg), _lib.ptr(p.arena),
+                                                   p.in_ld, s))
+        _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+        self._img_keep = frames
+        return HeadOutput(self, B, (H, W)), (H, W)
+
     def __call__(self, img, augment=False):
         return (self.forward(img),)
 

@@ -78,19 +78,24 @@ def main(opts, cfgs):
     for si, seq in enumerate(seqs):
         print(f'--------------tracking seq {seq}--------------')
         if synthetic:
-            loader = tracker_dataloader.SyntheticLoader(opts.synthetic_frames, opts.synthetic_objs, opts.img_size, si)
+            loader = tracker_dataloader.SyntheticLoader(opts.synthetic_frames, opts.synthetic_objs, opts.img_size, si,
+                                                        device_preprocess=opts.device_preprocess)
         else:
             loader = tracker_dataloader.TrackerLoader(os.path.join(DATA_ROOT, seq), opts.img_size, opts.data_format, seq,
-                                                      pre_process_method='v7', model_stride=stride)
+                                                      pre_process_method='v7', model_stride=stride,
+                                                      device_preprocess=opts.device_preprocess)
         data_loader = torch.utils.data.DataLoader(loader, batch_size=1)
         tracker = TRACKER_DICT[opts.tracker](opts, frame_rate=30, gamma=opts.gamma)
         results, frame_id, i = [], 0, 0
         for i, (img, img0) in enumerate(data_loader):
             timer.tic()
             if not i % opts.detect_per_frame:
-                out = model(img.cuda())[0]
+                if opts.device_preprocess:      # raw uint8 frame -> letterbox + layout on the GPU
+                    out, lb_size = model.forward_frames(img0, img_size=opts.img_size)
+                else:
+                    out, lb_size = model(img.cuda())[0], img.shape[2:]
                 img0 = img0.squeeze(0)
-                out = post_process_v7(out, img_size=img.shape[2:], ori_img_size=img0.shape)
+                out = post_process_v7(out, img_size=lb_size, ori_img_size=img0.shape)
                 if opts.synthetic_dets and synthetic:
                     out = torch.from_numpy(loader.dets[i])          # the scene's detections stand in for a trained detector
                 current_tracks = tracker.update(out, img0)
@@ -130,6 +135,7 @@ def build_parser():
     parser.add_argument('--track_buffer', type=int, default=30, help='tracking buffer')
     parser.add_argument('--gamma', type=float, default=0.1, help='param to control fusing motion and apperance dist')
     parser.add_argument('--kalman_format', type=str, default='default', help='use what kind of Kalman, default, naive, strongsort or bot-sort like')
+    parser.add_argument('--device_preprocess', action='store_true', help='(extension) letterbox raw frames on the GPU instead of in the loader')
     parser.add_argument('--min_area', type=float, default=150, help='use to filter small bboxs')
     parser.add_argument('--save_images', action='store_true', help='save tracking results (image)')
     parser.add_argument('--save_videos', action='store_true', help='save tracking results (video)')

@@ -37,8 +37,9 @@ def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scale
 
 
 class TrackerLoader(torch.utils.data.Dataset):
-    def __init__(self, path, img_size=1280, format='origin', seq=None, pre_process_method='v7', model_stride=32):
+    def __init__(self, path, img_size=1280, format='origin', seq=None, pre_process_method='v7', model_stride=32, device_preprocess=False):
         super().__init__()
+        self.device_preprocess = device_preprocess   # True: hand over only the raw frame; letterbox runs on the GPU (Detector.forward_frames)
         self.DATA_ROOT = path
         self.format, self.pre_process_method, self.model_stride = format, pre_process_method, model_stride
         if format != 'origin':
@@ -54,6 +55,8 @@ class TrackerLoader(torch.utils.data.Dataset):
         from PIL import Image
         p = os.path.join(self.DATA_ROOT, self.img_files[index])
         ori_img = np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1].copy()   # (H, W, C) BGR like cv2.imread
+        if self.device_preprocess:
+            return torch.empty(0), torch.from_numpy(ori_img)
         img = letterbox(ori_img, new_shape=(self.height, self.width), stride=self.model_stride)[0]
         img = np.ascontiguousarray(img[:, :, ::-1].transpose(2, 0, 1))         # BGR to RGB, HWC to CHW
         img = torch.from_numpy(img).float()
@@ -68,13 +71,16 @@ class SyntheticLoader(torch.utils.data.Dataset):
     """seeded synthetic sequence: frames rendered by synth.make_frames, plus the scene's detections (used as the
     tracker's input with --synthetic_dets, since random detector weights do not detect anything meaningful)."""
 
-    def __init__(self, n_frames, n_obj, size, seq_idx):
+    def __init__(self, n_frames, n_obj, size, seq_idx, device_preprocess=False):
         from .. import synth
+        self.device_preprocess = device_preprocess
         self.frames = synth.make_frames(n_frames, n_obj, size, seq_idx)
         self.dets = synth.make_detections(n_frames, n_obj, size, seq_idx)
 
     def __getitem__(self, i):
         ori = self.frames[i]
+        if self.device_preprocess:
+            return torch.empty(0), torch.from_numpy(ori)
         img = torch.from_numpy(np.ascontiguousarray(ori[:, :, ::-1].transpose(2, 0, 1))).float()
         img /= 255.0
         return img, torch.from_numpy(ori)
