@@ -4,6 +4,8 @@ pinned against the reference's models.yolo.Model in tests/test_detector_oracle.p
 Stated tolerances (fp16 activations / fp32 accumulate vs the fp32 oracle): see each test."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -44,6 +46,15 @@ CONV_CASES = [
     (1, 130, 130, 32, 64, 3, 2, 1, 32, 0, 64, 0, 0),        # M not a multiple of the tile
     (2, 24, 40, 128, 128, 3, 1, 1 | 256, 128, 0, 128, 0, 0),  # weights in the (kh, chunk, kw) K order (act bit 8)
     (1, 33, 31, 192, 64, 3, 2, 1 | 256, 256, 64, 64, 0, 0),   # same, stride 2, input slice of a wider buffer
+    # LDS-patch kernel (3x3 / stride 1, Cin % 64 == 0): 16x16 tiles, 32x8 tiles, 64- and 128-channel panels, both K orders,
+    # ragged image edges (act bit 9 forces the kernel when the tile efficiency is below its dispatch threshold), slices
+    (2, 80, 80, 128, 128, 3, 1, 1 | 256, 128, 0, 128, 0, 0),
+    (1, 64, 96, 64, 64, 3, 1, 1, 256, 128, 192, 64, 0),
+    (1, 24, 64, 64, 128, 3, 1, 2, 64, 0, 128, 0, 0),
+    (2, 24, 64, 192, 64, 3, 1, 1 | 256, 192, 0, 64, 0, 0),
+    (2, 37, 53, 192, 256, 3, 1, 1 | 256 | 512, 256, 64, 320, 64, 0),
+    (1, 37, 70, 128, 64, 3, 1, 1 | 512, 128, 0, 64, 0, 0),
+    (3, 20, 20, 512, 512, 3, 1, 1 | 256 | 512, 512, 0, 512, 0, 0),
 ]
 
 
@@ -59,6 +70,8 @@ def test_conv_layer_matches_torch_fp32(L, case):
     korder = bool(act & 256)
     act_code = act
     act = act & 255
+    if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful
+        assert os.environ.get("Y7T_CONV_PATCH", "1") != "0"
     wp = pack_w(Wt, Cin, cout_pad, korder)
     bp = np.zeros(cout_pad, np.float32); bp[:Cout] = bias
     pad = k // 2

@@ -23,21 +23,7 @@
 #include "y7t_det.h"
 #include <stdlib.h>
 
-typedef _Float16 half_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 half8;
-typedef __attribute__((ext_vector_type(4))) _Float16 half4;
-typedef __attribute__((ext_vector_type(16))) float floatx16;
-
-#define GLOBAL_AS __attribute__((address_space(1)))
-#define LDS_AS __attribute__((address_space(3)))
-
-__device__ __forceinline__ float act_fn(float v, int act) {
-    // SiLU = v * sigmoid(v) with the hardware exp2 / rcp (1 ulp each; the result is rounded to fp16 anyway): the IEEE
-    // division + expf of the naive form made the epilogue's VALU work 27 % of the whole forward (Y7T_CONV_ABLATE=8)
-    if (act == Y7T_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
-    if (act == Y7T_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
-    return v;
-}
+#include "y7t_conv_common.h"
 
 template <int BM, int BN, int BK, int NST, bool UT>
 __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
@@ -1097,7 +1083,13 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     return conv_dispatch(b, s);
 }
 
+int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
+
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+    if (conv_variant() == 0) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
+        const int rc = y7t_conv_patch_try(a, s);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     const bool wide = a.Cout_pad % 128 == 0;
     const bool ws_ok = !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) && !(a.cout_off & 7);
     const int var = conv_variant();

@@ -62,7 +62,7 @@ extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) {
             a.out = outp; a.ldout = op.out_ld; a.cout_off = op.out_coff; a.out_f32 = op.out_f32;
             a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.Cout_pad = op.Cout_pad;
             a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
-            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.reserved0;
+            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.reserved0; a.force_patch = 0;
             rc = y7t_conv_launch(a, s);
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
             rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
@@ -107,5 +107,6 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
     a.Cout = Cout; a.Cout_pad = Cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act & 0xff; a.zeros = (const _Float16*)zeros16;
     a.korder = (act >> 8) & 1;   // bit 8 of `act`: weights are packed in the (kh, chunk, kw) K order
+    a.force_patch = (act >> 9) & 1;   // bit 9: force the LDS-patch kernel for an eligible 3x3/s1 layer (tests)
     return y7t_conv_launch(a, (hipStream_t)stream);
 }
