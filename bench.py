@@ -233,9 +233,12 @@ def main():
                        "result_gather": gathered_info if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic,
+                         "sustained_peak": 1550.0,
+                         "sustained_peak_note": "register-only v_mfma_f32_32x32x16_f16 loop with random operands (power-limited clock; "
+                                                "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
                          "traffic_note": "HBM bytes per launch list from profiles/r01_conv_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
                                          "algorithmic = 1.217 GB/frame",
-                         "kernel": "k_conv_igemm<BM,BN,BK,NST> (the conv launch list of one forward: 107 convs in 96 launches)",
+                         "kernel": "k_conv_igemm<BM,BN,BK,NST> + k_conv3x3_patch<TW,TH,BN> (the conv launch list of one forward: 107 convs in 96 launches)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3)},

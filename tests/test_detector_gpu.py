@@ -27,10 +27,13 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     K_pad = (K + 63) // 64 * 64
     Wt = np.zeros((cout, k, k, cin_pad), np.float32)
     Wt[..., :cin] = W.transpose(0, 2, 3, 1)
-    if korder:   # (kh, 64-channel chunk, kw) K order
+    if korder == 1:   # (kh, 64-channel chunk, kw) K order
         Wt = Wt.reshape(cout, k, k, cin_pad // 64, 64).transpose(0, 1, 3, 2, 4)
     blk = np.zeros((cout_pad, K_pad), np.float16)
     blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
+    if korder == 2:   # patch-kernel panel order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack(blk, cin_pad)
     return blk
 
 
@@ -55,6 +58,10 @@ CONV_CASES = [
     (2, 37, 53, 192, 256, 3, 1, 1 | 256 | 512, 256, 64, 320, 64, 0),
     (1, 37, 70, 128, 64, 3, 1, 1 | 512, 128, 0, 64, 0, 0),
     (3, 20, 20, 512, 512, 3, 1, 1 | 256 | 512, 512, 0, 512, 0, 0),
+    # the same kernel fed with panel-packed weights (act bit 10; what detector/graph.py chooses for eligible layers)
+    (2, 80, 80, 128, 128, 3, 1, 1 | 1024, 128, 0, 128, 0, 0),
+    (1, 24, 64, 192, 64, 3, 1, 2 | 1024, 256, 64, 64, 0, 0),
+    (2, 37, 53, 64, 256, 3, 1, 1 | 1024, 64, 0, 320, 64, 0),
 ]
 
 
@@ -67,7 +74,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
     cout_pad = (Cout + 63) // 64 * 64
-    korder = bool(act & 256)
+    korder = 2 if act & 1024 else int(bool(act & 256))
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful

@@ -1080,13 +1080,14 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     b.splitk = 1; b.ksteps = b.K_pad; b.partial = nullptr;
     { static int to = -1; if (to < 0) { const char* e = getenv("Y7T_CONV_TILE_ORDER"); to = e ? atoi(e) : 1; } b.tile_order = to; }
     { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
+    { static int dp = -2; if (dp == -2) { const char* e = getenv("Y7T_CONV_DEPHASE"); dp = e ? atoi(e) : -1; } b.dephase = dp; }
     return conv_dispatch(b, s);
 }
 
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
-    if (conv_variant() == 0) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
+    if (conv_variant() == 0 || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;
     }

@@ -26,15 +26,18 @@ constexpr unsigned kOOB = 0xFF000000u;   // voffset of a zero-filled lane: out o
 
 template <int TW, int TH, int BN>
 struct PatchCfg {
-    static constexpr int PIXB = 80;                                       // bytes per patch pixel / weight row in LDS (64 data + 16 pad)
+    static constexpr int PIXB = 80;                                       // bytes per patch pixel in LDS (64 data + 16 pad)
     static constexpr int RP = (TW == 16) ? 1536 : (TW + 2) * PIXB;        // patch row pitch
     static constexpr int PATCH_DMA = ((TH + 2) * RP + 1023) / 1024;       // wave-wide 1 KiB DMAs per patch
-    static constexpr int NPX = (PATCH_DMA + 3) / 4;                       // patch DMAs per wave
-    static constexpr int PATCH_BYTES = NPX * 4 * 1024;                    // every wave issues NPX DMAs; the tail ones zero-fill
-    static constexpr int W_DMA = (BN * PIXB + 1023) / 1024;               // 10 (BN=128) / 5 (BN=64)
-    static constexpr int NWX = (W_DMA + 3) / 4;                           // weight DMAs per wave per K-step
-    static constexpr int W_BYTES = NWX * 4 * 1024;
-    static constexpr int W_OFF = 0, P_OFF = 2 * W_BYTES;                  // LDS map: W ring (2 stages) | patch A | patch B
+    static constexpr int NPX = (PATCH_DMA + 1) / 2;                       // patch DMAs per PATCH wave (waves 2, 3; a slot past the patch
+    static constexpr int PATCH_BYTES = PATCH_DMA * 1024;                  //  repeats the patch's last KiB: same bytes to the same place)
+    static constexpr int PPT = (NPX + 6) / 7;                             // pieces per patch wave per tap (taps 0..6)
+    static constexpr int WROWB = 64;                                      // weight rows: 64 B, 16-byte slots XOR-swizzled with (row >> 2) & 3
+    static constexpr int W_DMA = BN * WROWB / 1024;                       // 8 (BN=128) / 4 (BN=64)
+    static constexpr int NWX = W_DMA / 2;                                 // weight DMAs per WEIGHT wave (waves 0, 1) per K-step
+    static constexpr int W_BYTES = W_DMA * 1024;
+    static constexpr int NWS = 3;                                         // weight ring: K-step u+2 is in flight while u is multiplied
+    static constexpr int W_OFF = 0, P_OFF = NWS * W_BYTES;                // LDS map: W ring | patch A | patch B
     static constexpr int LDS_LOOP = P_OFF + 2 * PATCH_BYTES;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int LDS_EPI = 256 * OROW;
@@ -44,7 +47,9 @@ struct PatchCfg {
     static constexpr int RPT = (TW == 16) ? 2 : 1;                        // image rows per MFMA tile
 };
 
-template <int TW, int TH, int BN>
+// ABL: compile-time ablation bits for scripts/sweep_conv.py (Y7T_CONV_ABLATE): 1 zero-filling DMAs only, 2 no MFMAs, 4 no fragment
+// reads, 8 no epilogue.  (Run-time switches inside the K loop change its schedule by tens of percent -- hence template instances.)
+template <int TW, int TH, int BN, int ABL>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = PatchCfg<TW, TH, BN>;
@@ -73,47 +78,66 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-    // ---- per-lane DMA sources (computed once) ----
-    unsigned xoff[C::NPX], woff[C::NWX];
+    // ---- per-lane DMA sources (computed once).  The DMA streams are split by wave: waves 0/1 fetch the weight panels, waves 2/3 the
+    // patch.  vmcnt retires in order, so a wave that mixed both would have to see its (HBM-latency) patch pieces land before it
+    // could prove a younger (L2-latency) weight panel complete -- Y7T_CONV_ABLATE=32 showed that costing 20 % of the layer. ----
+    const bool wrole = wave < 2;
+    constexpr int NOFF = C::NPX > C::NWX ? C::NPX : C::NWX;
+    unsigned off[NOFF];
 #pragma unroll
-    for (int i = 0; i < C::NPX; ++i) {
-        const int I = wave + 4 * i;
-        const int byte = I * 1024 + lane * 16;
-        const int r = byte / RP, rb = byte - r * RP;
-        const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
-        const int gy = h0 + r - 1, gx = w0 + x - 1;
-        const bool ok = I < C::PATCH_DMA && r < TH + 2 && x < TW + 2 && cs < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        xoff[i] = ok ? (unsigned)(((((b * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2) : kOOB;
-    }
-#pragma unroll
-    for (int i = 0; i < C::NWX; ++i) {
-        const int I = wave + 4 * i;
-        const int byte = I * 1024 + lane * 16;
-        const int row = byte / PIXB, cs = (byte - row * PIXB) >> 4;
-        const bool ok = I < C::W_DMA && row < BN && cs < 4;
-        woff[i] = ok ? (unsigned)(((n0 + row) * p.K_pad + cs * 8) * 2) : kOOB;
+    for (int i = 0; i < NOFF; ++i) {
+        unsigned v = kOOB;
+        if (wrole) {
+            if (i < C::NWX) {
+                const int byte = (wave * C::NWX + i) * 1024 + lane * 16;
+                const int row = byte >> 6, slot = (byte >> 4) & 3;
+                if (p.korder == 2) v = (unsigned)(tile_n * (p.K_pad >> 5) * C::W_BYTES + byte);   // panel order: memory image == LDS image
+                else v = (unsigned)(((n0 + row) * p.K_pad + ((slot ^ ((row >> 2) & 3)) << 3)) * 2);
+            }
+        } else if (i < C::NPX) {
+            int I = (wave - 2) + 2 * i;
+            if (I >= C::PATCH_DMA) I = C::PATCH_DMA - 1;
+            const int byte = I * 1024 + lane * 16;
+            const int r = byte / RP, rb = byte - r * RP;
+            int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
+            if (ABL & 128) { x = (rb >> 6) % (TW + 2); cs = (rb >> 4) & 3; }   // diagnostics: lane quads = whole 64-byte pixel rows (wrong data)
+            const int gy = ((ABL & 64) ? 0 : h0) + r - 1, gx = ((ABL & 64) ? 0 : w0) + x - 1;   // 64: every workgroup reads image 0's first patch
+            const bool ok = r < TH + 2 && x < TW + 2 && cs < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            if (ABL & 256) v = (unsigned)(byte & 0xffff);   // diagnostics: contiguous, cache-resident source (wrong data)
+            else if (ok) v = (unsigned)(((((((ABL & 64) ? 0 : b) * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2);
+        }
+        off[i] = v;
     }
 
     // ---- fragment read bases ----
-    const char* wlane = smem + C::W_OFF + (wn * 64 + l31) * PIXB + hi32 * 16;
+    // weights: row = wn*64 + i*32 + l31, logical chunk q = ks*2 + hi32 sits in slot q ^ ((row >> 2) & 3) = q ^ ((l31 >> 2) & 3): per-lane constant
+    const int wsw = (l31 >> 2) & 3;
+    const char* wlane0 = smem + C::W_OFF + (wn * 64 + l31) * C::WROWB + (((0 + hi32) ^ wsw) << 4);
+    const char* wlane1 = smem + C::W_OFF + (wn * 64 + l31) * C::WROWB + (((2 + hi32) ^ wsw) << 4);
     const char* plane = smem + C::P_OFF + (wm * TM * RPT + (TW == 16 ? (l31 >> 4) : 0)) * RP + (TW == 16 ? (l31 & 15) : l31) * PIXB + hi32 * 16;
 
     const int nc32 = p.Cin >> 5;
     // byte offset (in a weight row) of K-step (chunk c, tap kh,kw) = kh * s_kh + kw * s_kw + chunk part; the chunk part of an even
     // chunk c0 is `cbase`, of c0 + 1 it is cbase + 64 in both packings, and a chunk pair advances it by s_pair
-    const int s_kh = p.korder ? (p.Cin >> 6) * 3 * 128 : 3 * p.Cin * 2;
-    const int s_kw = p.korder ? 128 : p.Cin * 2;
-    const int s_pair = p.korder ? 3 * 128 : 128;
+    // korder 2 (panel order, detector/weights.py): the BN x 32 panel of K-step (c, tap) is one contiguous, pre-swizzled W_BYTES block
+    // at [tile_n][c * 9 + tap] -- 8 full cache lines per DMA instead of 16 half lines from 16 different weight rows, which the
+    // vector L1 serves almost 3x faster (scripts/ubench/dma_patterns.hip: 17 vs 46 clocks per wave-DMA)
+    const int s_kh = p.korder == 2 ? 3 * C::W_BYTES : p.korder ? (p.Cin >> 6) * 3 * 128 : 3 * p.Cin * 2;
+    const int s_kw = p.korder == 2 ? C::W_BYTES : p.korder ? 128 : p.Cin * 2;
+    const int s_odd = p.korder == 2 ? 9 * C::W_BYTES : 64;                  // odd chunk of a pair relative to the even one
+    const int s_pair = p.korder == 2 ? 18 * C::W_BYTES : p.korder ? 3 * 128 : 128;
     int cbase = 0;
-    auto issue_w = [&](int stage, int coff, int kh, int kw) {
+    auto issue_w = [&](int slot, int coff, int kh, int kw, bool real) {
         const int so = kh * s_kh + kw * s_kw + coff;
 #pragma unroll
-        for (int i = 0; i < C::NWX; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(smem + C::W_OFF + stage * C::W_BYTES + (wave + 4 * i) * 1024), 16, woff[i], so, 0, 0);
+        for (int i = 0; i < C::NWX; ++i)   // weight waves only
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(smem + C::W_OFF + slot * C::W_BYTES + (wave * C::NWX + i) * 1024), 16,
+                                                     real ? off[i] : kOOB, real ? so : 0, 0, 0);
     };
-    auto issue_patch_piece = [&](int pb, int c, int i, bool real) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + C::P_OFF + pb * C::PATCH_BYTES + (wave + 4 * i) * 1024), 16,
-                                                 real ? xoff[i] : kOOB, c << 6, 0, 0);
+    auto issue_patch_piece = [&](int pb, int c, int i, bool real) {   // patch waves only
+        const int I = ((wave - 2) + 2 * i < C::PATCH_DMA) ? (wave - 2) + 2 * i : C::PATCH_DMA - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + C::P_OFF + pb * C::PATCH_BYTES + I * 1024), 16,
+                                                 real ? off[i] : kOOB, c << 6, 0, 0);
     };
 
     floatx16 acc[2][TM];
@@ -124,54 +148,116 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // prologue: patch of chunk 0 and the weights of K-step 0
+    // De-phasing: the first 512 workgroups of a launch start together, two per CU, and would run prologue, K loop and epilogue in
+    // lock step (exposed read / write bursts, idle matrix pipe).  The second 256 (the second slot of every CU) wait about half a
+    // tile once; every later workgroup inherits the shift from the slot it takes over.
+    if (p.dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int z = 0; z < p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
+    }
+    // prologue: patch of chunk 0 and the weights of K-steps 0..2, then the fragments of K-step 0
+    if (wrole) {
+        issue_w(0, 0, 0, 0, true);
+        issue_w(1, 0, 0, 1, true);
+        issue_w(2, 0, 0, 2, true);
+    } else {
 #pragma unroll
-    for (int i = 0; i < C::NPX; ++i) issue_patch_piece(0, 0, i, true);
-    issue_w(0, 0, 0, 0);
+        for (int i = 0; i < C::NPX; ++i) issue_patch_piece(0, 0, i, true);
+    }
 
-    static_assert(C::NPX <= 8, "one patch piece per tap, taps 0..7");
+    static_assert(C::PPT * 7 >= C::NPX, "patch pieces fit into taps 0..6");
     static_assert(C::LDS_LOOP <= 81920, "two workgroups per CU");
+    half8 wf[2][2][2], xf[2][2][TM];   // [register buffer][k-substep][tile]
+    auto read_frags = [&](int buf, int slot, int pb, int kh, int kw) {
+        const char* ws0 = wlane0 + slot * C::W_BYTES;
+        const char* ws1 = wlane1 + slot * C::W_BYTES;
+        const char* ps = plane + pb * C::PATCH_BYTES + kh * RP + kw * PIXB;
+        if (ABL & 4) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(wf[buf][ks][i]));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" : "=v"(xf[buf][ks][j]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[buf][ks][i] = *(const half8*)((ks ? ws1 : ws0) + i * 32 * C::WROWB);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[buf][ks][j] = *(const half8*)(ps + j * RPT * RP + ks * 32);
+        }
+    };
+    auto mfma_half = [&](int buf, int ks) {
+        if (ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wf[buf][ks][i]));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[buf][ks][j]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][ks][i], xf[buf][ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NWX) : "memory");   // W(0) landed (W(1), W(2) may be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // patch(0) landed
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, 0, 0);
+
+    // Software pipeline, K-step u = (chunk c, tap t); the workgroup barrier sits in the MIDDLE of the step's MFMAs:
+    //     MFMAs of k-substep 0 (fragments were read during step u-1)
+    //     wait until W(u+1) landed, barrier      -- behind it W(u+1) and, at a chunk's last tap, the next patch are visible to all,
+    //                                               and every wave is done reading W(u) and the fragments of step u
+    //     issue the DMAs of W(u+3) (ring slot of W(u)) and one piece of patch(c+1); read ALL fragments of step u+1
+    //     MFMAs of k-substep 1                   -- they cover the latency of those reads and of the barrier
+    // A weight wave always has exactly W(u+2) younger than the panel it waits for (tail steps issue zero-filling DMAs); a patch
+    // wave waits only at a chunk's last tap, for everything.
     for (int c0 = 0; c0 < nc32; c0 += 2) {
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
-            const int cc = u / 9, t = u % 9, kh = t / 3, kw = t % 3;   // compile-time after unrolling
-            const int c = c0 + cc;
-            const int stage = u & 1, pb = cc;
-            // everything older than the (at most one) patch piece issued behind this step's weights has landed
-            const bool piece_prev = (u > 0) ? (((u - 1) % 9) < C::NPX) : false;   // step u-1 issued a piece after W(u)
-            if (piece_prev) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int cc = u / 9, t = u % 9;   // compile-time after unrolling
+            const int c = c0 + cc, cur = u & 1;
+            mfma_half(cur, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NWX) : "memory");
+            else if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // next K-step's weights, then one piece of the next chunk's patch
             {
-                const int un = u + 1, ccn = (un / 9) & 1, tn = un % 9;
-                const int cn = (un == 18) ? c0 + 2 : c0 + ccn;
-                if (cn < nc32) issue_w(stage ^ 1, (un == 18) ? cbase + s_pair : cbase + ccn * 64, tn / 3, tn % 3);
-                if (t < C::NPX) issue_patch_piece(pb ^ 1, c + 1, t, c + 1 < nc32);
+                constexpr bool live = !(ABL & 1);
+                if (wrole) {
+                    const int un = u + 3;                              // K-step whose weights go out now
+                    const int ccn = (un / 9), tn = un % 9;             // ccn = 2: first chunk of the next pair
+                    const int cn = c0 + ccn;
+                    if (ABL & 16) issue_w(u % 3, 0, 0, 0, true);        // diagnostics: the same (L1-resident) panel every step
+                    else issue_w(u % 3, ccn == 2 ? cbase + s_pair : cbase + ccn * s_odd, tn / 3, tn % 3, cn < nc32 && live);
+                } else if (t < 7) {
+#pragma unroll
+                    for (int q = 0; q < C::PPT; ++q)
+                        if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc32 && live && !(ABL & 32));
+                }
             }
-            const char* ws = wlane + stage * C::W_BYTES;
-            const char* ps = plane + pb * C::PATCH_BYTES + kh * RP + kw * PIXB;
-            half8 wf[2][2], xf[2][TM];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) wf[ks][i] = *(const half8*)(ws + i * 32 * PIXB + ks * 32);
-#pragma unroll
-                for (int j = 0; j < TM; ++j) xf[ks][j] = *(const half8*)(ps + j * RPT * RP + ks * 32);
+            {
+                const int un = u + 1, tn = un % 9;
+                read_frags(cur ^ 1, un % 3, (un / 9) & 1, tn / 3, tn % 3);
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            }
+            mfma_half(cur, 1);
         }
         cbase += s_pair;
     }
 
+    if (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     // ---- epilogue: bias + activation, transpose through LDS, full-line NHWC stores ----
     constexpr int OROW = C::OROW;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,16 +310,16 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #endif
 }
 
-template <int TW, int TH, int BN>
+template <int TW, int TH, int BN, int ABL = 0>
 int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     using C = PatchCfg<TW, TH, BN>;
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch<TW, TH, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch<TW, TH, BN, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW) * (a.Cout_pad / BN);
-    hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN>), dim3(tiles), dim3(256), C::LDS, s, a);
+    hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
@@ -244,9 +330,13 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("Y7T_CONV_PATCH"); mode = e ? atoi(e) : 1; }
-    if (!mode) return 0;
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % 64 || a.out_f32 || (a.Cout & 7) || (a.ldout & 7) || (a.cout_off & 7)) return 0;
-    if (a.Ho != a.H || a.Wo != a.W || a.in_bytes > kOOB - (1u << 24) || a.ablate) return 0;
+    const bool eligible = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 64 == 0 && !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) &&
+                          !(a.cout_off & 7) && a.Ho == a.H && a.Wo == a.W && a.in_bytes <= kOOB - (1u << 24) && a.w_bytes <= kOOB - (1u << 24);
+    if (a.korder == 2 && (!eligible || !mode)) {   // panel-packed weights only make sense to this kernel
+        y7t_set_error("conv: weights are in panel order (korder 2) but the layer cannot run on the patch kernel");
+        return Y7T_E_ARG;
+    }
+    if (!mode || !eligible) return 0;
     // tile shape: the one that wastes fewer computed pixels; below 80 % useful pixels the linear-M kernel wins
     auto eff = [&](int tw, int th) {
         const int tx = (a.W + tw - 1) / tw, ty = (a.H + th - 1) / th;
@@ -254,9 +344,31 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     };
     const double e16 = eff(16, 16), e32 = eff(32, 8);
     const bool use16 = e16 >= e32;
-    if (!a.force_patch && (use16 ? e16 : e32) < 0.8) return 0;
+    if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     const bool wide = a.Cout_pad % 128 == 0;
     int rc;
+    if (a.ablate && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
+        switch (a.ablate) {
+        case 1: return launch_patch<16, 16, 128, 1>(a, s) ? -1 : 1;
+        case 2: return launch_patch<16, 16, 128, 2>(a, s) ? -1 : 1;
+        case 3: return launch_patch<16, 16, 128, 3>(a, s) ? -1 : 1;
+        case 4: return launch_patch<16, 16, 128, 4>(a, s) ? -1 : 1;
+        case 5: return launch_patch<16, 16, 128, 5>(a, s) ? -1 : 1;
+        case 6: return launch_patch<16, 16, 128, 6>(a, s) ? -1 : 1;
+        case 7: return launch_patch<16, 16, 128, 7>(a, s) ? -1 : 1;
+        case 8: return launch_patch<16, 16, 128, 8>(a, s) ? -1 : 1;
+        case 15: return launch_patch<16, 16, 128, 15>(a, s) ? -1 : 1;
+        case 16: return launch_patch<16, 16, 128, 16>(a, s) ? -1 : 1;
+        case 32: return launch_patch<16, 16, 128, 32>(a, s) ? -1 : 1;
+        case 48: return launch_patch<16, 16, 128, 48>(a, s) ? -1 : 1;
+        case 64: return launch_patch<16, 16, 128, 64>(a, s) ? -1 : 1;
+        case 128: return launch_patch<16, 16, 128, 128>(a, s) ? -1 : 1;
+        case 256: return launch_patch<16, 16, 128, 256>(a, s) ? -1 : 1;
+        case 272: return launch_patch<16, 16, 128, 272>(a, s) ? -1 : 1;
+        case 80: return launch_patch<16, 16, 128, 80>(a, s) ? -1 : 1;
+        default: break;
+        }
+    }
     if (use16) rc = wide ? launch_patch<16, 16, 128>(a, s) : launch_patch<16, 16, 64>(a, s);
     else rc = wide ? launch_patch<32, 8, 128>(a, s) : launch_patch<32, 8, 64>(a, s);
     return rc ? rc : 1;

@@ -24,6 +24,7 @@ struct Y7TConvArgs {
     int splitk, ksteps, allow_splitk;   // split-K: workgroups per output tile, K-steps per split
     float* partial;                     // fp32 slabs [splitk][M][Cout_pad]
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0)
+    int dephase;       // patch kernel: start delay of workgroups 256..511 in units of 4096 clocks (0 = off)
     int force_patch;   // tests: run an eligible 3x3/s1 layer on k_conv3x3_patch whatever its tile efficiency
     int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)
 };

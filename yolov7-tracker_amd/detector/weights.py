@@ -103,6 +103,23 @@ def folded(w, sd):
     return W, b
 
 
+def panel_pack(blk, cin_pad):
+    """[Cout_pad][K_pad] block with k = (kh*3 + kw)*Cin + ci  ->  the patch kernel's PANEL order (csrc/y7t_conv_patch.hip, korder 2):
+    [n-tile of BN rows][K-step = 32-channel chunk * 9 + tap][row][four 16-byte slots], slot s of row r holding channel octet
+    s ^ ((r >> 2) & 3) of the chunk -- byte for byte the image the kernel's buffer->LDS DMA leaves in LDS, so each K-step's
+    panel is one contiguous run of full cache lines.  BN = 128 when Cout_pad allows, else 64."""
+    cout_pad, K = blk.shape
+    assert K == 9 * cin_pad and cin_pad % 64 == 0
+    BN = 128 if cout_pad % 128 == 0 else 64
+    nc32 = cin_pad // 32
+    a = blk.reshape(cout_pad // BN, BN, 9, nc32, 4, 8)           # [tile][row][tap][chunk][octet][8]
+    a = a.transpose(0, 3, 2, 1, 4, 5)                            # [tile][chunk][tap][row][octet][8]
+    r = np.arange(BN)
+    src = np.arange(4)[None, :] ^ ((r[:, None] >> 2) & 3)        # slot s of row r <- octet s ^ ((r >> 2) & 3)
+    a = np.take_along_axis(a, src[None, None, None, :, :, None], axis=4)
+    return np.ascontiguousarray(a).reshape(cout_pad, K)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -114,10 +131,12 @@ def pack(wlayout, sd, w_elems, b_elems):
         assert W.shape == (cout, cin, k, k), (w["wkey"], W.shape, (cout, cin, k, k))
         Wt = np.zeros((cout, k, k, w["cin_pad"]), np.float64)
         Wt[..., :cin] = W.transpose(0, 2, 3, 1)
-        if w.get("korder"):   # (cout, kh, kw, chunk, 64) -> (cout, kh, chunk, kw, 64)
+        if w.get("korder") == 1:   # (cout, kh, kw, chunk, 64) -> (cout, kh, chunk, kw, 64)
             Wt = Wt.reshape(cout, k, k, w["cin_pad"] // 64, 64).transpose(0, 1, 3, 2, 4)
         blk = np.zeros((w["cout_pad"], w["K_pad"]), np.float16)
         blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
+        if w.get("korder") == 2:
+            blk = panel_pack(blk, w["cin_pad"])
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
