@@ -62,6 +62,11 @@ CONV_CASES = [
     (2, 80, 80, 128, 128, 3, 1, 1 | 1024, 128, 0, 128, 0, 0),
     (1, 24, 64, 192, 64, 3, 1, 2 | 1024, 256, 64, 64, 0, 0),
     (2, 37, 53, 64, 256, 3, 1, 1 | 1024, 64, 0, 320, 64, 0),
+    # strip tiling of the narrow maps (W = 40, 20): padded images laid end to end, 256 consecutive positions per workgroup
+    (3, 40, 40, 128, 128, 3, 1, 1 | 1024, 128, 0, 128, 0, 0),
+    (2, 24, 40, 64, 64, 3, 1, 2 | 256, 128, 64, 192, 128, 0),
+    (5, 20, 20, 192, 256, 3, 1, 1 | 1024, 192, 0, 256, 0, 0),
+    (1, 7, 20, 64, 64, 3, 1, 1, 64, 0, 64, 0, 0),
 ]
 
 

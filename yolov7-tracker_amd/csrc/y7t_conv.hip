@@ -1111,6 +1111,8 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         // measured per-layer (scripts/bench_conv.py): the HBM-bound 1x1 layers prefer the lighter 32-deep stages (4 blocks/CU),
         // the 3x3 layers the 64-deep ones
         if (a.KH == 1) return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+        // stem (Cin = 16, K = 144): three K-steps per tile -- 256-pixel tiles halve the per-tile set-up and epilogue count
+        if (a.Cin <= 16 && !wide && a.M >= (1 << 16)) return launch_conv<256, 64, 32, 2>(a, s);
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     }
 }

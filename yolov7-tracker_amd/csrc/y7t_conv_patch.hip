@@ -27,8 +27,15 @@ constexpr unsigned kOOB = 0xFF000000u;   // voffset of a zero-filled lane: out o
 template <int TW, int TH, int BN>
 struct PatchCfg {
     static constexpr int PIXB = 80;                                       // bytes per patch pixel in LDS (64 data + 16 pad)
-    static constexpr int RP = (TW == 16) ? 1536 : (TW + 2) * PIXB;        // patch row pitch
-    static constexpr int PATCH_DMA = ((TH + 2) * RP + 1023) / 1024;       // wave-wide 1 KiB DMAs per patch
+    // TW == 0: FLAT tiling for narrow maps (W = 20, 40).  The batch is one long strip of zero-padded images, (H+2) rows of
+    // PW = W+2 positions each; a workgroup owns 256 CONSECUTIVE positions of the strip (padding positions are computed and dropped:
+    // W*H / ((W+2)*(H+2)) useful, 91 % at 40x40, where 16x16 tiles would be 69 %), its patch is the same strip PW+1 positions
+    // longer at both ends, and tap (kh, kw) is the shift kh*PW + kw.  TH carries PW.
+    static constexpr bool FLAT = (TW == 0);
+    static constexpr int PW = TH;
+    static constexpr int NPOS = 256 + 2 * PW + 2;                         // FLAT: patch positions
+    static constexpr int RP = FLAT ? PW * PIXB : (TW == 16) ? 1536 : (TW + 2) * PIXB;   // patch row pitch (= tap row shift)
+    static constexpr int PATCH_DMA = FLAT ? (NPOS * PIXB + 1023) / 1024 : ((TH + 2) * RP + 1023) / 1024;   // wave-wide 1 KiB DMAs per patch
     static constexpr int NPX = (PATCH_DMA + 1) / 2;                       // patch DMAs per PATCH wave (waves 2, 3; a slot past the patch
     static constexpr int PATCH_BYTES = PATCH_DMA * 1024;                  //  repeats the patch's last KiB: same bytes to the same place)
     static constexpr int PPT = (NPX + 6) / 7;                             // pieces per patch wave per tap (taps 0..6)
@@ -41,10 +48,11 @@ struct PatchCfg {
     static constexpr int LDS_LOOP = P_OFF + 2 * PATCH_BYTES;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int LDS_EPI = 256 * OROW;
-    static constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+    static constexpr int LDS = LDS_LOOP > LDS_EPI + 1024 ? LDS_LOOP : LDS_EPI + 1024;   // + the FLAT epilogue's 256-entry pixel table
     static constexpr int WN = BN / 64, WM = 4 / WN;                       // waves along channels / pixels
     static constexpr int TM = 8 / WM;                                     // 32-pixel MFMA tiles per wave (4 or 2)
     static constexpr int RPT = (TW == 16) ? 2 : 1;                        // image rows per MFMA tile
+    static constexpr int JOFF = FLAT ? 32 * PIXB : RPT * RP;              // LDS distance between a wave's consecutive 32-pixel MFMA tiles
 };
 
 // ABL: compile-time ablation bits for scripts/sweep_conv.py (Y7T_CONV_ABLATE): 1 zero-filling DMAs only, 2 no MFMAs, 4 no fragment
@@ -53,8 +61,9 @@ template <int TW, int TH, int BN, int ABL>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = PatchCfg<TW, TH, BN>;
-    static_assert(TW * TH == 256, "256 output pixels per workgroup");
+    static_assert(C::FLAT || TW * TH == 256, "256 output pixels per workgroup");
     constexpr int PIXB = C::PIXB, RP = C::RP, TM = C::TM, RPT = C::RPT;
+    constexpr bool FLAT = C::FLAT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR: DMA destinations are scalar
     const int wn = (C::WN == 2) ? (wave >> 1) : 0, wm = (C::WN == 2) ? (wave & 1) : wave;
@@ -69,11 +78,17 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     const int n_tiles_n = p.Cout_pad / BN;
     const int tile_n = bid % n_tiles_n;
     int pt = bid / n_tiles_n;
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    const int txi = pt % tiles_x; pt /= tiles_x;
-    const int tyi = pt % tiles_y;
-    const int b = pt / tiles_y;
-    const int h0 = tyi * TH, w0 = txi * TW, n0 = tile_n * BN;
+    int b = 0, h0 = 0, w0 = 0;
+    const int g0 = pt * 256;                                   // FLAT: first strip position of this workgroup
+    const int img_pos = (p.H + 2) * C::PW, strip = p.B * img_pos;
+    if (!FLAT) {
+        constexpr int TWd = FLAT ? 1 : TW;
+        const int tiles_x = (p.W + TWd - 1) / TWd, tiles_y = (p.H + TH - 1) / TH;
+        const int txi = pt % tiles_x; pt /= tiles_x;
+        const int tyi = pt % tiles_y;
+        b = pt / tiles_y; h0 = tyi * TH; w0 = txi * TWd;
+    }
+    const int n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -98,6 +113,16 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
             int I = (wave - 2) + 2 * i;
             if (I >= C::PATCH_DMA) I = C::PATCH_DMA - 1;
             const int byte = I * 1024 + lane * 16;
+            if (FLAT) {
+                const int q = byte / PIXB, cs = (byte - q * PIXB) >> 4;
+                const int g = g0 - C::PW - 1 + q;                   // strip position of patch slot q
+                if (cs < 4 && q < C::NPOS && g >= 0 && g < strip) {
+                    const int bb = g / img_pos, rem = g - bb * img_pos;
+                    const int yy = rem / C::PW, xx = rem - yy * C::PW;
+                    if (yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W)
+                        v = (unsigned)(((((bb * p.H + yy - 1) * p.W + xx - 1) * p.ldin + p.cin_off) + cs * 8) * 2);
+                }
+            } else {
             const int r = byte / RP, rb = byte - r * RP;
             int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
             if (ABL & 128) { x = (rb >> 6) % (TW + 2); cs = (rb >> 4) & 3; }   // diagnostics: lane quads = whole 64-byte pixel rows (wrong data)
@@ -105,6 +130,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
             const bool ok = r < TH + 2 && x < TW + 2 && cs < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             if (ABL & 256) v = (unsigned)(byte & 0xffff);   // diagnostics: contiguous, cache-resident source (wrong data)
             else if (ok) v = (unsigned)(((((((ABL & 64) ? 0 : b) * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2);
+            }
         }
         off[i] = v;
     }
@@ -114,7 +140,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     const int wsw = (l31 >> 2) & 3;
     const char* wlane0 = smem + C::W_OFF + (wn * 64 + l31) * C::WROWB + (((0 + hi32) ^ wsw) << 4);
     const char* wlane1 = smem + C::W_OFF + (wn * 64 + l31) * C::WROWB + (((2 + hi32) ^ wsw) << 4);
-    const char* plane = smem + C::P_OFF + (wm * TM * RPT + (TW == 16 ? (l31 >> 4) : 0)) * RP + (TW == 16 ? (l31 & 15) : l31) * PIXB + hi32 * 16;
+    const char* plane = FLAT ? smem + C::P_OFF + (wm * TM * 32 + l31) * PIXB + hi32 * 16
+                             : smem + C::P_OFF + (wm * TM * RPT + (TW == 16 ? (l31 >> 4) : 0)) * RP + (TW == 16 ? (l31 & 15) : l31) * PIXB + hi32 * 16;
 
     const int nc32 = p.Cin >> 5;
     // byte offset (in a weight row) of K-step (chunk c, tap kh,kw) = kh * s_kh + kw * s_kw + chunk part; the chunk part of an even
@@ -187,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) wf[buf][ks][i] = *(const half8*)((ks ? ws1 : ws0) + i * 32 * C::WROWB);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[buf][ks][j] = *(const half8*)(ps + j * RPT * RP + ks * 32);
+            for (int j = 0; j < TM; ++j) xf[buf][ks][j] = *(const half8*)(ps + j * C::JOFF + ks * 32);
         }
     };
     auto mfma_half = [&](int buf, int ks) {
@@ -291,6 +318,17 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
             }
         }
     }
+    int* otab = (int*)(smem + C::LDS_EPI);   // FLAT: output pixel index of each of the 256 positions (-1: padding / past the strip)
+    if (FLAT) {
+        const int g = g0 + tid;
+        int o = -1;
+        if (g < strip) {
+            const int bb = g / img_pos, rem = g - bb * img_pos;
+            const int yy = rem / C::PW, xx = rem - yy * C::PW;
+            if (yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W) o = (bb * p.H + yy - 1) * p.W + xx - 1;
+        }
+        otab[tid] = o;
+    }
     __syncthreads();
     {
         typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
@@ -299,11 +337,18 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #pragma unroll 4
         for (int cidx = tid; cidx < 256 * CPP; cidx += 256) {
             const int pix = cidx / CPP, ch = cidx - pix * CPP;
-            const int r = pix / TW, x = pix - r * TW;
-            const int gy = h0 + r, gx = w0 + x, n = n0 + ch * 8;
-            if (gy < p.H && gx < p.W && n < p.Cout) {
+            const int n = n0 + ch * 8;
+            long long opix;
+            if (FLAT) opix = otab[pix];
+            else {
+                constexpr int TWd = FLAT ? 1 : TW;
+                const int r = pix / TWd, x = pix - r * TWd;
+                const int gy = h0 + r, gx = w0 + x;
+                opix = (gy < p.H && gx < p.W) ? (long long)(b * p.H + gy) * p.W + gx : -1;
+            }
+            if (opix >= 0 && n < p.Cout) {
                 const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
-                *(uint4v*)(outp + ((size_t)(b * p.H + gy) * p.W + gx) * p.ldout + p.cout_off + n) = v;
+                *(uint4v*)(outp + (size_t)opix * p.ldout + p.cout_off + n) = v;
             }
         }
     }
@@ -318,7 +363,8 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch<TW, TH, BN, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
-    const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW) * (a.Cout_pad / BN);
+    const int ptiles = C::FLAT ? (a.B * (a.H + 2) * C::PW + 255) / 256 : a.B * ((a.H + TH - 1) / TH) * ((a.W + (C::FLAT ? 1 : TW) - 1) / (C::FLAT ? 1 : TW));
+    const int tiles = ptiles * (a.Cout_pad / BN);
     hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     return 0;
@@ -344,8 +390,15 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     };
     const double e16 = eff(16, 16), e32 = eff(32, 8);
     const bool use16 = e16 >= e32;
-    if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     const bool wide = a.Cout_pad % 128 == 0;
+    const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
+    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && !a.ablate) {
+        int rcf;
+        if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
+        else rcf = wide ? launch_patch<0, 22, 128>(a, s) : launch_patch<0, 22, 64>(a, s);
+        return rcf ? rcf : 1;
+    }
+    if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     int rc;
     if (a.ablate && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
         switch (a.ablate) {

@@ -141,7 +141,8 @@ def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32):
     if not (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0 and out_coff % 8 == 0):
         return False
     eff = lambda tw, th: (W * H) / float(-(-W // tw) * tw * -(-H // th) * th)
-    return max(eff(16, 16), eff(32, 8)) >= 0.8
+    eflat = (W * H) / float((W + 2) * (H + 2)) if W in (20, 40) else 0.0      # strip tiling of narrow maps
+    return max(eff(16, 16), eff(32, 8), eflat) >= 0.8
 
 
 def lower(nodes, H, W, max_batch=1):
