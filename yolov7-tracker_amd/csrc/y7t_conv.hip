@@ -1113,6 +1113,8 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         if (a.KH == 1) return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
         // stem (Cin = 16, K = 144): three K-steps per tile -- 256-pixel tiles halve the per-tile set-up and epilogue count
         if (a.Cin <= 16 && !wide && a.M >= (1 << 16)) return launch_conv<256, 64, 32, 2>(a, s);
+        // stride-2 3x3 on the large maps: 256-pixel tiles with 32-deep stages measured 5-7 % ahead (profiles/r01_conv_variants.txt)
+        if (a.stride == 2 && a.M >= (1 << 15)) return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     }
 }
