@@ -84,5 +84,8 @@ class NSAKalmanFilter(KalmanFilter):
 
 class NaiveKalmanFilter(object):
     def __init__(self):
-        raise NotImplementedError("kalman_format 'naive' (7-d filter, kalman_filter.py:23-155) is outside the "
-                                  "ByteTrack/SORT hot path this package implements")
+        # the reference's own NaiveKalmanFilter.multi_predict (kalman_filter.py:92-121) builds a ragged list (N-vectors and the
+        # scalar 1e-5) and raises ValueError at :110 under numpy >= 1.24 (oracle/ref_harness.py reproduces it; older numpy
+        # produced an (N,N) diag per state), so `--kalman_format naive` never gets past the first frame with a live track
+        raise NotImplementedError("kalman_format 'naive': the reference's 7-d filter fails in multi_predict "
+                                  "(kalman_filter.py:110, ragged np.array) -- there is no behaviour to reproduce")
