@@ -181,10 +181,38 @@ def golden_detector():
     np.savez_compressed(os.path.join(HERE, "detector.npz"), **out)
 
 
+def golden_trackeval():
+    """the REFERENCE's TrackEval classes (MotChallenge2DBox pre-processing, HOTA / CLEAR / Identity) on the scenario of
+    tests/trackeval_case.py -> per-sequence and combined metric fields.  Pins yolov7_tracker_amd.tracker.trackeval."""
+    import json
+    import tempfile
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from tests import trackeval_case
+    from oracle import ref_trackeval
+    ns = ref_trackeval.load()
+    with tempfile.TemporaryDirectory() as root:
+        cfg = trackeval_case.build(root)
+        ds = ns.MotChallenge2DBox({**ns.MotChallenge2DBox.get_default_dataset_config(), **cfg})
+        metrics = [ns.HOTA(), ns.CLEAR({"THRESHOLD": 0.5, "PRINT_CONFIG": False}), ns.Identity({"THRESHOLD": 0.5, "PRINT_CONFIG": False})]
+        out, per_seq = {}, {m.get_name(): {} for m in metrics}
+        for seq in sorted(cfg["SEQ_INFO"]):
+            raw = ds.get_raw_seq_data("bytetrack_oracle", seq)
+            data = ds.get_preprocessed_seq_data(raw, "pedestrian")
+            res = {m.get_name(): m.eval_sequence(data) for m in metrics}
+            for m in metrics:
+                per_seq[m.get_name()][seq] = res[m.get_name()]
+            out[seq] = trackeval_case.flatten(res)
+            out[seq]["counts"] = [data["num_gt_dets"], data["num_tracker_dets"], data["num_gt_ids"], data["num_tracker_ids"]]
+        out["COMBINED_SEQ"] = trackeval_case.flatten({m.get_name(): m.combine_sequences(per_seq[m.get_name()]) for m in metrics})
+    with open(os.path.join(HERE, "trackeval_metrics.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     assert ref_harness.available(), "needs /root/reference"
     golden_kalman()
     golden_tracker()
     golden_lap_iou()
     golden_detector()
+    golden_trackeval()
     print("golden vectors written to", HERE)

@@ -42,6 +42,10 @@ def test_track_cli_synthetic(tmp_path, tracker, model, size, frames, objs):
         a, b = gl[i].split(","), wl[i].split(",")
         assert a[:2] == b[:2] and np.allclose([float(v) for v in a[2:6]], [float(v) for v in b[2:6]], atol=0.011)
     assert len(diff) <= max(2, len(gl) // 500)
+    # --track_eval (default on): ground truth written next to the results, HOTA / CLEAR / Identity summary next to the result file
+    summary = open(os.path.join(folder, "pedestrian_summary.txt")).read().split("\n")
+    vals = dict(zip(summary[0].split(), summary[1].split()))
+    assert float(vals["MOTA"]) > 50 and float(vals["IDF1"]) > 50 and float(vals["HOTA"]) > 40
 
 
 def test_track_cli_image_folder_device_preprocess(tmp_path):

@@ -26,14 +26,22 @@ def _tracks(rng, n_obj, size):
     return cx, cy, w, h, vx, vy, cls, conf0
 
 
-def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=0.05, conf_jitter=0.05):
-    """-> list of float32 (N_t, 6) arrays, one per frame."""
+def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=0.05, conf_jitter=0.05, ground_truth=None):
+    """-> list of float32 (N_t, 6) arrays, one per frame.  `ground_truth`: a list that receives, per frame, the float64
+    (n, 7) rows `[id (1-based), x, y, w, h, cls, detected]` of the true rectangles (clipped to the image; objects that left it
+    are dropped) -- what make_ground_truth returns."""
     rng = np.random.default_rng(BASE_SEED + seq_idx)
     cx, cy, w, h, vx, vy, cls, conf0 = _tracks(rng, n_obj, size)
     out = []
     for _ in range(n_frames):
         cx = cx + vx
         cy = cy + vy
+        if ground_truth is not None:
+            gx1, gy1 = np.clip(cx - w / 2, 0, size), np.clip(cy - h / 2, 0, size)
+            gx2, gy2 = np.clip(cx + w / 2, 0, size), np.clip(cy + h / 2, 0, size)
+            vis = (gx2 - gx1 >= 2) & (gy2 - gy1 >= 2)
+            gt_rows = np.stack([np.arange(1, n_obj + 1, dtype=np.float64), gx1, gy1, gx2 - gx1, gy2 - gy1, cls.astype(np.float64),
+                                np.zeros(n_obj)], 1)
         jx = rng.normal(0, 0.5, n_obj)
         jy = rng.normal(0, 0.5, n_obj)
         keep = rng.random(n_obj) >= miss
@@ -43,6 +51,9 @@ def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=
         y2 = y1 + h
         conf = np.clip(conf0 + rng.normal(0, conf_jitter, n_obj), 0.02, 0.99)
         rows = np.stack([x1, y1, x2, y2, conf, cls.astype(np.float64)], 1)[keep]
+        if ground_truth is not None:
+            gt_rows[:, 6] = keep
+            ground_truth.append(gt_rows[vis])
         n_fp = rng.binomial(n_obj, fp)
         if n_fp:
             fw = np.clip(rng.lognormal(np.log(30.0), 0.5, n_fp), 8, 300)
@@ -62,6 +73,21 @@ def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=
         rows = rows[np.argsort(-rows[:, 4], kind="stable")]
         out.append(rows.astype(np.float32))
     return out
+
+
+def make_ground_truth(n_frames=100, n_obj=80, size=1280, seq_idx=0, **kw):
+    """ground truth of the sequence make_detections(...) observes: per frame float64 (n, 7) `[id, x, y, w, h, cls, detected]`"""
+    gt = []
+    make_detections(n_frames, n_obj, size, seq_idx, ground_truth=gt, **kw)
+    return gt
+
+
+def write_mot_gt(path, gt, single_class=True):
+    """MOTChallenge gt.txt: frame,id,x,y,w,h,conf(1 = evaluate),class,visibility (class 1 = pedestrian when single_class)"""
+    with open(path, "w") as f:
+        for t, rows in enumerate(gt):
+            for r in rows:
+                f.write("%d,%d,%.2f,%.2f,%.2f,%.2f,1,%d,1.0\n" % (t + 1, int(r[0]), r[1], r[2], r[3], r[4], 1 if single_class else int(r[5]) + 1))
 
 
 def make_frames(n_frames=4, n_obj=80, size=1280, seq_idx=0):

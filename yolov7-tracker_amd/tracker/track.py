@@ -115,7 +115,40 @@ def main(opts, cfgs):
         timer.clear()
         save_results(opts.results_root, folder_name, seq, results)
     print(f'average fps: {np.mean(seq_fps)}')
+    if opts.track_eval and (synthetic or cfgs.get('TRACK_EVAL')):
+        evaluate_results(opts, cfgs, seqs, folder_name, synthetic)
     return os.path.join(opts.results_root, folder_name)
+
+
+def evaluate_results(opts, cfgs, seqs, folder_name, synthetic):
+    """track.py:196-227: HOTA / CLEAR / Identity of the result files just written, through the TrackEval-style harness
+    (tracker/trackeval).  Real datasets take their `TRACK_EVAL` block from the dataset yaml like the reference; the synthetic
+    dataset writes its ground truth (synth.make_ground_truth) next to the results first."""
+    from . import trackeval
+    eval_config = trackeval.Evaluator.get_default_eval_config()
+    if synthetic:
+        from .. import synth
+        gt_folder = os.path.join(opts.results_root, folder_name + '_gt')
+        os.makedirs(gt_folder, exist_ok=True)
+        for si, seq in enumerate(seqs):
+            synth.write_mot_gt(os.path.join(gt_folder, seq + '.txt'),
+                               synth.make_ground_truth(opts.synthetic_frames, opts.synthetic_objs, opts.img_size, si))
+        yaml_cfg = {'GT_FOLDER': gt_folder, 'TRACKERS_FOLDER': opts.results_root, 'TRACKERS_TO_EVAL': [folder_name], 'SKIP_SPLIT_FOL': True,
+                    'TRACKER_SUB_FOLDER': '', 'SEQ_INFO': {seq: opts.synthetic_frames for seq in seqs}, 'GT_LOC_FORMAT': '{gt_folder}/{seq}.txt'}
+        dataset_cls = trackeval.datasets.MotChallenge2DBox
+    else:
+        yaml_cfg = dict(cfgs['TRACK_EVAL'])
+        yaml_cfg['SEQ_INFO'] = {k: v for k, v in yaml_cfg['SEQ_INFO'].items() if k in seqs}      # track.py:203-207
+        assert len(yaml_cfg['SEQ_INFO']) == len(seqs)
+        yaml_cfg.setdefault('TRACKERS_TO_EVAL', [folder_name])
+        dataset_cls = trackeval.datasets.MotChallenge2DBox if opts.dataset in ['mot', 'uavdt'] else trackeval.datasets.VisDrone2DBox
+    dataset_config = dataset_cls.get_default_dataset_config()
+    dataset_config.update({k: v for k, v in yaml_cfg.items() if k in dataset_config})
+    eval_config.update({k: v for k, v in yaml_cfg.items() if k in eval_config})
+    metrics_config = {'METRICS': ['HOTA', 'CLEAR', 'Identity'], 'THRESHOLD': 0.5}
+    metrics_list = [m(metrics_config) for m in (trackeval.metrics.HOTA, trackeval.metrics.CLEAR, trackeval.metrics.Identity)
+                    if m.get_name() in metrics_config['METRICS']]
+    return trackeval.Evaluator(eval_config).evaluate([dataset_cls(dataset_config)], metrics_list)
 
 
 def build_parser():
