@@ -1107,14 +1107,17 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     case 5: return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
     case 6: return wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
     case 7: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
-    default:
+    default: {
+        const bool big256 = (long long)(a.M / 256) * (a.Cout_pad / (wide ? 128 : 64)) >= 2048;   // enough 256-pixel tiles to fill the chip 4x
         // measured per-layer (scripts/bench_conv.py): the HBM-bound 1x1 layers prefer the lighter 32-deep stages (4 blocks/CU),
         // the 3x3 layers the 64-deep ones
         if (a.KH == 1) return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+        // (both rules were measured at 32 frames per forward; at small batch the 128-pixel tiles' larger grid wins)
         // stem (Cin = 16, K = 144): three K-steps per tile -- 256-pixel tiles halve the per-tile set-up and epilogue count
-        if (a.Cin <= 16 && !wide && a.M >= (1 << 16)) return launch_conv<256, 64, 32, 2>(a, s);
+        if (a.Cin <= 16 && !wide && big256) return launch_conv<256, 64, 32, 2>(a, s);
         // stride-2 3x3 on the large maps: 256-pixel tiles with 32-deep stages measured 5-7 % ahead (profiles/r01_conv_variants.txt)
-        if (a.stride == 2 && a.M >= (1 << 15)) return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
+        if (a.stride == 2 && big256) return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
+    }
     }
 }

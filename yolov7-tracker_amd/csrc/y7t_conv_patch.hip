@@ -392,6 +392,8 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     const bool use16 = e16 >= e32;
     const bool wide = a.Cout_pad % 128 == 0;
     const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
+    // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
+    if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;
     if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && !a.ablate) {
         int rcf;
         if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);

@@ -133,9 +133,13 @@ class Plan:
     """result of `lower`: ops (structured array), buffer table, weight layout, head description"""
 
 
-def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32):
+def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 20):
     """mirror of y7t_conv_patch_try (csrc/y7t_conv_patch.hip): 3x3 / stride 1 / pad 1, Cin % 64 == 0, 16-byte aligned fp16 output,
-    and a 16x16 or 32x8 pixel tiling that computes at least 80 % useful pixels"""
+    a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 256 workgroups of 256 pixels x 128 (64)
+    channels at batch B (below that -- batch-1 latency mode -- the generic kernel with split-K fills the chip better)"""
+    cout_pad = -(-cout // 64) * 64
+    if B * H * W * (cout_pad // (128 if cout_pad % 128 == 0 else 64)) < 256 * 256:
+        return False
     if os.environ.get("Y7T_CONV_PATCH", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
     if not (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0 and out_coff % 8 == 0):
@@ -237,7 +241,7 @@ def lower(nodes, H, W, max_batch=1):
         op["Ho"], op["Wo"], op["Cout"], op["Cout_pad"] = n.h, n.w, cout, cout_pad
         op["KH"], op["KW"], op["stride"], op["pad"], op["K"], op["K_pad"], op["act"] = n.k, n.k, n.s, n.p, K, K_pad, act
         korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
-        if patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32):
+        if patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         op["w_off"], op["bias_off"], op["reserved0"] = w_off, b_off, korder
         ops.append(op)
