@@ -171,6 +171,26 @@ def test_letterbox_layout_matches_oracle(shape):
     assert (diff > 1e-3).mean() < 0.01
 
 
+def test_staged_heads_give_identical_detections():
+    """Detector.stage_heads: decode+NMS from a private copy of the head buffers (so that it can overlap the next forward)
+    returns exactly what decode+NMS on the arena returns -- also after the arena has been overwritten"""
+    det = build("yolov7-tiny", 80, (128, 192), 2)
+    g = torch.Generator().manual_seed(5)
+    out = det(torch.rand((2, 3, 128, 192), generator=g))[0]
+    for l in range(len(det.plan.heads)):
+        t = det.head_tensor(l, 2)
+        t.copy_((torch.randn(t.shape, generator=g) * 1.5).cuda())
+    d0, n0 = det.postprocess(out, 0.01, 0.45, None)
+    d0, n0 = d0.clone(), n0.clone()
+    staged = det.stage_heads(out)
+    det(torch.rand((2, 3, 128, 192), generator=g))           # the next forward rewrites the arena
+    d1, n1 = det.postprocess(staged, 0.01, 0.45, None)
+    torch.cuda.synchronize()
+    assert torch.equal(n0, n1) and int(n0.sum()) > 10
+    for b in range(2):
+        assert torch.equal(d0[b, :n0[b]], d1[b, :n1[b]])
+
+
 def test_decode_nms_matches_oracle():
     """plant head logits, run the device decode+NMS chain, compare with the oracle's non_max_suppression +
     scale_coords + round on the decoded tensor of the SAME logits."""

@@ -33,8 +33,9 @@ def check_img_size(img_size, s=32):
 class HeadOutput:
     """what `model(img)[0]` stands for: the raw Detect conv outputs of one forward, still on the device"""
 
-    def __init__(self, det, B, img_shape):
+    def __init__(self, det, B, img_shape, staged=None):
         self.det, self.B, self.img_shape = det, B, img_shape
+        self.staged = staged        # (tensors, ctypes pointer array) of a private copy of the head buffers, or None = the arena
 
     @property
     def shape(self):
@@ -224,11 +225,25 @@ class Detector:
         if getattr(p, "_lb_key", None) != key:
             p.lb[:B].copy_(torch.from_numpy(lb))
             p._lb_key = key
-        _lib.check(self._L.y7t_det_postprocess(p.head_ptrs, p.ny, p.nx, p.strides, p.anchors, len(p.heads), p.det["na"], p.det["no"], B,
+        head_ptrs = out.staged[1] if getattr(out, "staged", None) is not None else p.head_ptrs
+        _lib.check(self._L.y7t_det_postprocess(head_ptrs, p.ny, p.nx, p.strides, p.anchors, len(p.heads), p.det["na"], p.det["no"], B,
                                                float(conf_thres), float(iou_thres), MAX_DET, MAX_NMS, self.max_cand, _lib.ptr(p.lb),
                                                _lib.ptr(p.dets), _lib.ptr(p.ndets), _lib.ptr(p.keep), _lib.ptr(p.cand), _lib.ptr(p.ws),
                                                p.ws.numel(), _lib.stream_ptr()))
         return p.dets, p.ndets
+
+    def stage_heads(self, out):
+        """Copy the four raw head buffers of `out` (a few MB per frame, device to device, on the current stream) into a staging
+        set owned by the plan and return a HeadOutput that reads from it.  With it decode+NMS of batch n can run on another
+        stream while the forward of batch n+1 already rewrites the arena; the caller orders re-use of the staging set (the next
+        stage_heads must come after the postprocess that read it -- bench.py does it with one event)."""
+        p = self.plan
+        if not hasattr(p, "_stage"):
+            ts = [torch.empty_like(self.head_tensor(l, self.max_batch)) for l in range(len(p.heads))]
+            p._stage = (ts, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts] + [None] * (4 - len(ts))))
+        for l, t in enumerate(p._stage[0]):
+            t[:out.B].copy_(self.head_tensor(l, out.B), non_blocking=True)
+        return HeadOutput(self, out.B, out.img_shape, staged=p._stage)
 
     def capture(self, img, conf_thres=0.01, iou_thres=0.45, ori_shapes=None):
         """Capture input layout + the whole conv launch list + decode/NMS for the (fixed) device buffer `img` into a
