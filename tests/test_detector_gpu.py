@@ -34,6 +34,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 2:   # patch-kernel panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack(blk, cin_pad)
+    if korder == 3:   # 1x1 panel order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_linear(blk)
     return blk
 
 
@@ -67,6 +70,11 @@ CONV_CASES = [
     (2, 24, 40, 64, 64, 3, 1, 2 | 256, 128, 64, 192, 128, 0),
     (5, 20, 20, 192, 256, 3, 1, 1 | 1024, 192, 0, 256, 0, 0),
     (1, 7, 20, 64, 64, 3, 1, 1, 64, 0, 64, 0, 0),
+    # 1x1 layers with panel-packed weights (act bit 11): 128- and 64-row panels, Cin % 64 == 32, split-K on a small map, fp32 head
+    (2, 40, 40, 256, 256, 1, 1, 1 | 2048, 256, 0, 256, 0, 0),
+    (1, 24, 24, 96, 192, 1, 1, 2 | 2048, 256, 64, 384, 192, 0),
+    (1, 20, 20, 1024, 512, 1, 1, 1 | 2048, 1024, 0, 512, 0, 0),
+    (1, 16, 16, 256, 45, 1, 1, 0 | 2048, 256, 0, 45, 0, 1),
 ]
 
 
@@ -79,7 +87,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
     cout_pad = (Cout + 63) // 64 * 64
-    korder = 2 if act & 1024 else int(bool(act & 256))
+    korder = 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful

@@ -98,9 +98,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
                 if (kh >= klo && kh <= khi) vmask[r] |= colbits << (kh * p.KW);
         }
     }
+    // korder 3 (1x1 layers, BK = 32; detector/weights.py::panel_pack_linear): the BN x 32 weight panel of every K-step is stored as one
+    // contiguous block that already is the swizzled LDS image -> a wave's DMA reads 1 KiB of consecutive bytes (8 full cache lines)
+    // instead of 16 half lines from 16 weight rows (17 vs 46 clocks in the vector L1, scripts/ubench/dma_patterns.hip)
+    const bool wpanel = (p.korder == 3);
     int woff[RN];
 #pragma unroll
-    for (int r = 0; r < RN; ++r) woff[r] = ((n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
+    for (int r = 0; r < RN; ++r)
+        woff[r] = wpanel ? tile_n * (p.K_pad / BK) * (BN * ROWB) + (r * RPR + wave * RPW) * ROWB + lane * 16
+                         : ((n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
 
     // k bookkeeping of the next stage to load: uniform (scalar) when every K-step lies inside one tap (Cin % BK == 0)
     const int nk_all = p.K_pad / BK;
@@ -124,7 +130,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * RPR + wave * RPW) * ROWB), 16, voff, 0, 0, 0);
         } else {
             const int r = idx - RM;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r], (kt0 + kt) * BK * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, woff[r],
+                                                     wpanel ? (kt0 + kt) * (BN * ROWB) : (kt0 + kt) * BK * 2, 0, 0);
         }
     };
     // K order.  Default: k = tap*Cin + ci (taps outermost).  korder = 1 (3x3, Cin % 64 == 0, weights packed to match):
@@ -132,13 +139,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // shifted by one pixel, so they hit in L1/L2 instead of coming back from the Infinity Cache a dozen steps later.
     const int nchunk = p.Cin >> 6;
     int o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
-    if (UT && p.korder) {   // decode the (kh, chunk, kw) odometer at this split's first K-step
+    if (UT && p.korder == 1) {   // decode the (kh, chunk, kw) odometer at this split's first K-step
         const int g = (kt0 * BK) >> 6;
         o_kw = g % p.KW; o_c = (g / p.KW) % nchunk; o_kh = g / (p.KW * nchunk); o_sub = ((kt0 * BK) & 63) / BK;
         tap = o_kh * p.KW + o_kw; ci = (o_c << 6) + o_sub * BK;
     }
     auto advance_k = [&]() {
-        if (UT && p.korder) {
+        if (UT && p.korder == 1) {
             if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
             o_sub = 0;
             if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
@@ -1087,6 +1094,10 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+    if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
+        if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
+        return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+    }
     if (conv_variant() == 0 || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;

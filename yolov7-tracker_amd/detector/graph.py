@@ -243,6 +243,8 @@ def lower(nodes, H, W, max_batch=1):
         korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
         if patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
+        elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
+            korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
         op["w_off"], op["bias_off"], op["reserved0"] = w_off, b_off, korder
         ops.append(op)
         wlayout.append(dict(korder=korder, wkey=wkey, cin=cin_real, cin_pad=cin, cout=cout, cout_pad=cout_pad, k=n.k, K=K, K_pad=K_pad, w_off=w_off,

@@ -120,6 +120,19 @@ def panel_pack(blk, cin_pad):
     return np.ascontiguousarray(a).reshape(cout_pad, K)
 
 
+def panel_pack_linear(blk):
+    """[Cout_pad][K_pad] block of a 1x1 layer -> panel order of the 32-deep generic kernel (csrc/y7t_conv.hip, korder 3):
+    [n-tile of BN rows][K-step of 32 channels][row][four 16-byte slots], slot s of row r = channel octet s ^ ((r >> 2) & 3)."""
+    cout_pad, K = blk.shape
+    assert K % 32 == 0
+    BN = 128 if cout_pad % 128 == 0 else 64
+    a = blk.reshape(cout_pad // BN, BN, K // 32, 4, 8).transpose(0, 2, 1, 3, 4)      # [tile][kstep][row][octet][8]
+    r = np.arange(BN)
+    src = np.arange(4)[None, :] ^ ((r[:, None] >> 2) & 3)
+    a = np.take_along_axis(a, src[None, None, :, :, None], axis=3)
+    return np.ascontiguousarray(a).reshape(cout_pad, K)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -137,6 +150,8 @@ def pack(wlayout, sd, w_elems, b_elems):
         blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
         if w.get("korder") == 2:
             blk = panel_pack(blk, w["cin_pad"])
+        elif w.get("korder") == 3:
+            blk = panel_pack_linear(blk)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
