@@ -644,8 +644,41 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
     Y7T_LPROF(0);
     for (int j = tid; j < ncol; j += nt) { L.v[j] = 0.0; L.y[j] = -1; }
     for (int i = tid; i < nr; i += nt) L.x[i] = -1;
+    // ---- census of the CANDIDATE edges (c <= cost_limit, i.e. reduced cost <= 0): IoU cost matrices are sparse -- a track
+    // overlaps a handful of detections -- so most rows can be settled without a search:
+    //   * a row without candidates takes the null column;
+    //   * a row whose only candidate column has no other candidate row is matched to it (strictly negative reduced cost), with
+    //     the column price v = c - cost_limit that makes the edge tight.
+    // Both are forced in every optimal solution (the objective separates over connected components of the candidate graph) and
+    // leave a feasible dual with complementary slackness, so the shortest-augmenting-path loop below simply skips those rows.
+    const double lim = 2.0 * L.half;
+    int* rowcnt = L.cnt;          // [nr]
+    int* colcnt = L.cnt + nr;     // [nc]
+    int* rowcand = L.fr;          // [nr]
+    for (int j = tid; j < nc; j += nt) {
+        int k = 0;
+        for (int i = 0; i < nr; ++i) k += (L.c[(size_t)i * L.ld + j] <= lim);
+        colcnt[j] = k;
+    }
+    for (int i = tid; i < nr; i += nt) {
+        int k = 0, cand = -1;
+        for (int j = 0; j < nc; ++j)
+            if (L.c[(size_t)i * L.ld + j] <= lim) { ++k; cand = j; }
+        rowcnt[i] = k;
+        rowcand[i] = cand;
+    }
+    y7t_sync(ex);
+    for (int i = tid; i < nr; i += nt) {
+        if (rowcnt[i] == 0) L.x[i] = nc;
+        else if (rowcnt[i] == 1 && colcnt[rowcand[i]] == 1) {
+            const int j = rowcand[i];
+            const double red = L.c[(size_t)i * L.ld + j] - lim;
+            if (red < 0.0) { L.x[i] = j; L.y[j] = i; L.v[j] = red; }
+        }
+    }
     y7t_sync(ex);
     for (int start = 0; start < nr; ++start) {
+        if (L.x[start] != -1) continue;   // settled by the census (uniform: every thread reads the same word)
         for (int j = tid; j < ncol; j += nt) {
             L.st[j] = 0;
             L.pred[j] = start;

@@ -150,10 +150,12 @@ Y7T_FN void y7t_meas(int kf, const float* tlwh, double* z) {
 // ---- building blocks -----------------------------------------------------------------------
 // cost[i*ld + j] = 1 - IoU+1(track tlbr i, det tlbr j)
 Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const double* b, int nb, double* cost, int ld) {
-    const int tot = na * nb;
-    for (int k = ex.tid; k < tot; k += ex.nt) {
-        const int i = k / nb, j = k - i * nb;
-        cost[(size_t)i * ld + j] = y7t_iou_dist(a + 4 * i, b + 4 * j);
+    // a lane owns a column (its detection box stays in registers), a wave a residue class of rows (the track box is wave-uniform:
+    // scalar loads); consecutive lanes store consecutive doubles.  No integer division, one box load per element instead of two.
+    const int lanes = ex.nt < 64 ? ex.nt : 64, nw = ex.nt / lanes, wave = ex.tid / lanes, lane = ex.tid - wave * lanes;
+    for (int j = lane; j < nb; j += lanes) {
+        const double q[4] = {b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3]};
+        for (int i = wave; i < na; i += nw) cost[(size_t)i * ld + j] = y7t_iou_dist(a + 4 * i, q);
     }
     y7t_sync(ex);
 }
