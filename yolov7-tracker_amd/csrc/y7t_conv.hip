@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
     constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
     constexpr int STAGE = (BM + BN) * ROWB;      // bytes per LDS stage
+    constexpr int LDS_EPI_BYTES = BM * (BN * 2 + 16);
+    constexpr int BIAS_OFF = NST * STAGE > LDS_EPI_BYTES ? NST * STAGE : LDS_EPI_BYTES;   // BN biases behind everything else
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,6 +61,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     bid /= p.splitk;
     const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // the epilogue's biases: fetched now into an LDS corner no stage touches (a global load at the end of a short workgroup is exposed latency)
+    if (tid < BN) ((float*)(smem + BIAS_OFF))[tid] = p.bias[n0 + tid];
+    const float* lbias = (const float*)(smem + BIAS_OFF);
 
     // Buffer descriptors (raw, 32-bit byte offsets): a lane whose tap falls into the padding, whose row is past M
     // or whose k is past K gets offset 0xffffffff -> the hardware range check returns zeros into LDS, so there is
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
                     if (n >= p.Cout) continue;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[n - n0 + e], p.act);
                     const size_t o = (size_t)m * p.ldout + p.cout_off + n;
                     if (p.out_f32) {
                         float* op = (float*)p.out + o;
@@ -315,7 +320,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
                     const int n = n0 + nl + 8 * g + 4 * hi32;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[n - n0 + e], p.act);
                     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                     half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
                     w[gg][0] = __builtin_bit_cast(unsigned, h0);
@@ -1020,7 +1025,7 @@ static int launch_conv_persist(const Y7TConvArgs& a, hipStream_t s) {
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
-    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    constexpr unsigned lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + BN * 4;   // + the bias corner
     static bool attr = false;
     if (!attr) {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -48,7 +48,8 @@ struct PatchCfg {
     static constexpr int LDS_LOOP = P_OFF + 2 * PATCH_BYTES;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int LDS_EPI = 256 * OROW;
-    static constexpr int LDS = LDS_LOOP > LDS_EPI + 1024 ? LDS_LOOP : LDS_EPI + 1024;   // + the FLAT epilogue's 256-entry pixel table
+    static constexpr int BIAS_OFF = LDS_LOOP > LDS_EPI + 1024 ? LDS_LOOP : LDS_EPI + 1024;   // (+ the FLAT epilogue's 256-entry pixel table)
+    static constexpr int LDS = BIAS_OFF + BN * 4;                         // this workgroup's BN biases, fetched in the prologue
     static constexpr int WN = BN / 64, WM = 4 / WN;                       // waves along channels / pixels
     static constexpr int TM = 8 / WM;                                     // 32-pixel MFMA tiles per wave (4 or 2)
     static constexpr int RPT = (TW == 16) ? 2 : 1;                        // image rows per MFMA tile
@@ -182,6 +183,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #pragma unroll 1
         for (int z = 0; z < p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
     }
+    // the epilogue's biases: fetched now, beside the first DMAs, into an LDS corner no stage ever touches (a global load at the
+    // end of a workgroup that lives for a few microseconds is pure exposed latency)
+    if (tid < BN) ((float*)(smem + C::BIAS_OFF))[tid] = p.bias[n0 + tid];
     // prologue: patch of chunk 0 and the weights of K-steps 0..2, then the fragments of K-step 0
     if (wrole) {
         issue_w(0, 0, 0, 0, true);
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     }
 
     static_assert(C::PPT * 7 >= C::NPX, "patch pieces fit into taps 0..6");
-    static_assert(C::LDS_LOOP <= 81920, "two workgroups per CU");
+    static_assert(C::LDS <= 81920, "two workgroups per CU");
     half8 wf[2][2][2], xf[2][2][TM];   // [register buffer][k-substep][tile]
     auto read_frags = [&](int buf, int slot, int pb, int kh, int kw) {
         const char* ws0 = wlane0 + slot * C::W_BYTES;
@@ -287,6 +291,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     }
     // ---- epilogue: bias + activation, transpose through LDS, full-line NHWC stores ----
     constexpr int OROW = C::OROW;
+    const float* lbias = (const float*)(smem + C::BIAS_OFF);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -304,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
                     const int n = n0 + nl + 8 * g + 4 * hi32;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[n - n0 + e], p.act);
                     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                     half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
                     w[gg][0] = __builtin_bit_cast(unsigned, h0);
@@ -402,6 +407,16 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     }
     if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     int rc;
+    if (a.ablate && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
+        switch (a.ablate) {
+        case 1: return launch_patch<16, 16, 64, 1>(a, s) ? -1 : 1;
+        case 2: return launch_patch<16, 16, 64, 2>(a, s) ? -1 : 1;
+        case 7: return launch_patch<16, 16, 64, 7>(a, s) ? -1 : 1;
+        case 8: return launch_patch<16, 16, 64, 8>(a, s) ? -1 : 1;
+        case 15: return launch_patch<16, 16, 64, 15>(a, s) ? -1 : 1;
+        default: break;
+        }
+    }
     if (a.ablate && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
         switch (a.ablate) {
         case 1: return launch_patch<16, 16, 128, 1>(a, s) ? -1 : 1;
