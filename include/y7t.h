@@ -151,6 +151,11 @@ int y7t_det_destroy(y7t_det* det);
 /* models/yolo.py:345 `x = m(x)` for every layer: runs the whole launch list for B images whose input layout
  * (y7t_input_layout) is already in arena buffer 0.  Asynchronous on `stream`. */
 int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
+/* the same launch list in pieces: ops [first, last) of the plan (last < 0: to the end), so that a caller can record an event between
+ * two parts of Model.forward_once (models/yolo.py:321-351) -- bench.py starts the previous batch's decode+NMS on another stream once
+ * the memory-bound high-resolution layers of the next forward are through.  y7t_det_num_ops: length of the list. */
+int y7t_det_num_ops(const y7t_det* det);
+int y7t_det_forward_ops(y7t_det* det, int B, int first, int last, y7t_stream stream);
 
 /* TrackerLoader.__getitem__ tail (tracker/tracker_dataloader.py:83-88) + ReOrg (models/common.py:48-53):
  * img: (B,3,H,W) float32 RGB in [0,1] (is_u8 = 0) or (B,H,W,3) uint8 BGR (is_u8 = 1: BGR->RGB and /255 fused);

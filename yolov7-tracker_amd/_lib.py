@@ -35,6 +35,8 @@ SIGNATURES = {
     "y7t_det_create": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
     "y7t_det_destroy": (c_int, [c_void_p]),
     "y7t_det_forward": (c_int, [c_void_p, c_int, c_void_p]),
+    "y7t_det_num_ops": (c_int, [c_void_p]),
+    "y7t_det_forward_ops": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "y7t_input_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y7t_letterbox_layout_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y7t_det_postprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

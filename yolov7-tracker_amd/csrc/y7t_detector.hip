@@ -48,10 +48,17 @@ extern "C" int y7t_det_destroy(y7t_det* d) {
     return 0;
 }
 
-extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) {
+extern "C" int y7t_det_num_ops(const y7t_det* d) { return d ? (int)d->ops.size() : Y7T_E_ARG; }
+
+extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) { return y7t_det_forward_ops(d, B, 0, -1, stream); }
+
+extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_stream stream) {
     Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
+    if (last < 0) last = (int)d->ops.size();
+    Y7T_ARG_CHECK(first >= 0 && first <= last && last <= (int)d->ops.size());
     hipStream_t s = (hipStream_t)stream;
-    for (const y7t_op& op : d->ops) {
+    for (int oi = first; oi < last; ++oi) {
+        const y7t_op& op = d->ops[oi];
         const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);
         void* outp = d->arena + d->bufs[op.out_buf];
         int rc = 0;

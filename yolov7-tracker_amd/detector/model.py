@@ -148,7 +148,7 @@ class Detector:
         return p.arena[off:off + 2 * elems * B].view(torch.float16).view(B, -1, C)
 
     # -- forward ---------------------------------------------------------------------------------------
-    def forward(self, img):
+    def forward(self, img, mid_hook=None):
         """img: (B,3,H,W) float32 RGB in [0,1] (the reference's input) or (B,H,W,3) uint8 BGR frames (fused
         BGR->RGB, /255).  -> HeadOutput."""
         if img.dim() == 3:
@@ -168,7 +168,13 @@ class Detector:
         p = self.plan
         s = _lib.stream_ptr()
         _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
-        _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+        if mid_hook is None:
+            _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+        else:   # (op index, callable): run the list up to that op, call the hook (e.g. record an event), run the rest
+            k = min(int(mid_hook[0]), int(self._L.y7t_det_num_ops(p.handle)))
+            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, 0, k, s))
+            mid_hook[1]()
+            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, k, -1, s))
         self._img_keep = img
         return HeadOutput(self, B, (H, W))
 
