@@ -354,437 +354,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant (uniform-tap layers): 4 consumer waves (2x2, as above) + 1 LOADER wave per workgroup.
-// The loader issues every buffer->LDS DMA of the ring (NST stages), so the consumers' instruction streams hold nothing
-// but ds_read_b128 + MFMA + one barrier per K-step -- the DMA issue / address arithmetic runs beside them instead of in
-// front of them.  One s_barrier per K-step for all 5 waves: the loader arrives after `s_waitcnt vmcnt(..)` proved stage kt
-// landed, the consumers after they finished stage kt-1; behind it the loader refills the buffer stage kt-1 occupied.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int NST>
-__global__ void __launch_bounds__(320, 2) k_conv_ws(const Y7TConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int ROWB = BK * 2, CPR = BK / 8, RPW = 64 / CPR;
-    constexpr int WTN = BN / 2, WTM = BM / 2, TN = WTN / 32, TM = WTM / 32;
-    constexpr int NA = BM / RPW, NB = BN / RPW, NLD = NA + NB;   // wave-wide DMAs per stage, all issued by the loader wave
-    constexpr int STAGE = (BM + BN) * ROWB;
-    static_assert((NST - 2) * NLD <= 63, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_tiles_m = (p.M + BM - 1) / BM;
-    int bid = blockIdx.x;
-    if (p.xcd_swizzle) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // channel tiles fastest: the blocks that share one pixel tile (and therefore all its input lines) run next to each
-    // other on the same XCD; the weight panels are small and stay cached anyway
-    const int n_tiles_n = p.Cout_pad / BN;
-    const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K_pad / BK;
-    const int wn = (wave >> 1) & 1, wm = wave & 1;
-    const int l31 = lane & 31, hi32 = lane >> 5;
-    floatx16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    if (wave == 4) {
-        // ------------------------------------------------ loader wave ------------------------------------------------
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-        const int lr = lane / CPR, lc = lane % CPR;
-        int xoff[NA];
-        unsigned vmask[NA];
-        const int HoWo = p.Ho * p.Wo;
-        const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const int row = a * RPW + lr;
-            const int gch = lc ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-            const int m = m0 + row;
-            vmask[a] = 0; xoff[a] = 0;
-            if (m < p.M) {
-                int b = (int)((float)m * inv_howo);
-                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
-                const int rem = m - b * HoWo;
-                int ho = (int)((float)rem * inv_wo);
-                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
-                const int wo = rem - ho * p.Wo;
-                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-                xoff[a] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gch * 8) * 2;
-                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
-                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
-                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-                    if (kh >= klo && kh <= khi) vmask[a] |= colbits << (kh * p.KW);
-            }
-        }
-        int woff[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int row = b * RPW + lr;
-            const int gch = lc ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-            woff[b] = ((n0 + row) * p.K_pad + gch * 8) * 2;
-        }
-        int tap = 0, ci = 0, o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
-        const int nchunk = p.Cin >> 6;
-        auto issue_stage = [&](int stage, int kt) {
-            char* xs = smem + stage * STAGE;
-            char* ws = xs + BM * ROWB;
-            const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
-            const int kw = tap - kh * p.KW;
-            const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const int voff = ((vmask[a] >> tap) & 1u) ? xoff[a] + tapoff : -1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + a * RPW * ROWB), 16, voff, 0, 0, 0);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + b * RPW * ROWB), 16, woff[b], kt * BK * 2, 0, 0);
-            if (p.korder) {
-                if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
-                o_sub = 0;
-                if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
-                tap = o_kh * p.KW + o_kw; ci = o_c << 6;
-                return;
-            }
-            ci += BK;
-            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
-        };
-#pragma unroll
-        for (int s = 0; s < NST - 1; ++s) if (s < nk) issue_stage(s, s);
-        int nxt = NST - 1;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int ahead = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
-            if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 4 ? 2 : 0) * NLD) : "memory");
-            else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 3 ? 1 : 0) * NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + NST - 1 < nk) issue_stage(nxt, kt + NST - 1);
-            nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
-        }
-    } else {
-        // ------------------------------------------------ consumer waves ------------------------------------------------
-        int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const char* xs = smem + cur * STAGE;
-            const char* ws = xs + BM * ROWB;
-            constexpr int KS = BK / 16;
-            half8 wf[2][TN], xf[2][TM];
-            auto read_frags = [&](int ks, int buf) {
-                const int q = ks * 2 + hi32;
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    const int row = wn * WTN + i * 32 + l31;
-                    const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                    wf[buf][i] = *(const half8*)(ws + row * ROWB + (sl << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int row = wm * WTM + j * 32 + l31;
-                    const int sl = q ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                    xf[buf][j] = *(const half8*)(xs + row * ROWB + (sl << 4));
-                }
-            };
-            read_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int cb = ks & 1;
-                if (ks + 1 < KS) read_frags(ks + 1, cb ^ 1);
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this stage retired before the next barrier
-            cur = (cur + 1 == NST) ? 0 : cur + 1;
-        }
-    }
-    // ---- epilogue (fp16, 8-aligned slices only: the dispatcher guarantees it): LDS-transposed full-line stores ----
-    constexpr int OROW = BN * 2 + 16;
-    __syncthreads();
-    if (wave < 4) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int pix = wm * WTM + j * 32 + l31;
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int nl = wn * WTN + i * 32;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    unsigned w[2][2];
-#pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const int g = gp * 2 + gg;
-                        const int n = n0 + nl + 8 * g + 4 * hi32;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
-                        typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                        half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-                        w[gg][0] = __builtin_bit_cast(unsigned, h0);
-                        w[gg][1] = __builtin_bit_cast(unsigned, h1);
-                    }
-                    auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                    typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-                    uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-                    *(uint4v*)(smem + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    {
-        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-        constexpr int CPP = BN / 8, NCH = BM * CPP;
-        half_t* outp = (half_t*)p.out;
-        for (int c = tid; c < NCH; c += 320) {
-            const int pix = c / CPP, ch = c - pix * CPP;
-            const int m = m0 + pix, n = n0 + ch * 8;
-            if (m < p.M && n < p.Cout) {
-                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
-                *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
-            }
-        }
-    }
-#endif
-}
-
-template <int BM, int BN, int BK, int NST>
-static int launch_conv_ws(const Y7TConvArgs& a, hipStream_t s) {
-    constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
-    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr = false;
-    if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_ws<BM, BN, BK, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN;
-    hipLaunchKernelGGL((k_conv_ws<BM, BN, BK, NST>), dim3(tiles_m * tiles_n), dim3(320), lds, s, a);
-    Y7T_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Anti-phase variant (uniform-tap layers, fp16 output): 512 threads = two GROUPS of 4 waves, one wave of each group per
-// SIMD.  Each group owns a 128-pixel half of a 256 x BN block tile and runs the classic two-step cycle
-//      P: issue the DMAs of stage k+1, ds_read ALL fragments of stage k into registers      (memory pipes)
-//      C: 16 (or 8) back-to-back MFMAs from registers                                           (matrix pipe)
-// with one workgroup barrier after each step -- and group 1 starts one barrier late.  The barriers therefore pin the two
-// groups in ANTI-PHASE: whenever group 0 is in C, group 1 is in P and vice versa, so every SIMD always has exactly one
-// wave feeding its matrix pipe while the other wave of that SIMD feeds the LDS / buffer pipes.  (Measured problem of the
-// plain structure, scripts/bench_conv.py + Y7T_CONV_ABLATE: loads-only 42 us + MFMA-only 45 us -> 67 us together.)
-// The weight tile is shared (group 0 loads it), each group stages its own pixel half; hazards: see DESIGN.md section 3.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ void __launch_bounds__(512, 2) k_conv_ap(const Y7TConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BK = 64, ROWB = 128, GM = 128, BM = 2 * GM;
-    constexpr int WTN = BN / 2, WTM = GM / 2, TN = WTN / 32, TM = WTM / 32;
-    constexpr int RM = GM / 32, RN = BN / 32;           // DMA rounds per thread: pixel half (both groups), weights (group 0)
-    constexpr int STAGE = (BM + BN) * ROWB;             // [pixels g0 | pixels g1 | weights]
-    constexpr int KS = BK / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = wave >> 2, w4 = wave & 3, wn = w4 >> 1, wm = w4 & 1;
-    const int l31 = lane & 31, hi32 = lane >> 5;
-    const int n_tiles_m = (p.M + BM - 1) / BM, n_tiles_n = p.Cout_pad / BN;
-    int bid = blockIdx.x;
-    if (p.xcd_swizzle) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = p.tile_order ? bid % n_tiles_n : bid / n_tiles_m, tile_m = p.tile_order ? bid / n_tiles_n : bid % n_tiles_m;
-    const int m0 = tile_m * BM + grp * GM, n0 = tile_n * BN;
-    const int nk = p.K_pad / BK;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-
-    // ---- load geometry (per group: 256 threads cover 32 rows x 8 chunks per round) ----
-    const int lrow = w4 * 8 + (lane >> 3);
-    const int gchunk = (lane & 7) ^ ((lrow >> 1) & 7);
-    int xoff[RM];
-    unsigned vmask[RM];
-    {
-        const int HoWo = p.Ho * p.Wo;
-        const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int m = m0 + r * 32 + lrow;
-            vmask[r] = 0; xoff[r] = 0;
-            if (m < p.M) {
-                int b = (int)((float)m * inv_howo);
-                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
-                const int rem = m - b * HoWo;
-                int ho = (int)((float)rem * inv_wo);
-                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
-                const int wo = rem - ho * p.Wo;
-                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-                xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gchunk * 8) * 2;
-                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
-                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
-                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-                    if (kh >= klo && kh <= khi) vmask[r] |= colbits << (kh * p.KW);
-            }
-        }
-    }
-    int woff[RN];
-#pragma unroll
-    for (int r = 0; r < RN; ++r) woff[r] = ((n0 + r * 32 + lrow) * p.K_pad + gchunk * 8) * 2;
-
-    int tap = 0, ci = 0, o_kw = 0, o_c = 0, o_kh = 0;
-    const int nchunk = p.Cin >> 6;
-    auto issue_loads = [&](int stage, int kt) {
-        char* xs = smem + stage * STAGE + grp * (GM * ROWB);
-        char* ws = smem + stage * STAGE + BM * ROWB;
-        const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
-        const int kw = tap - kh * p.KW;
-        const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int voff = ((vmask[r] >> tap) & 1u) ? xoff[r] + tapoff : -1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * 32 + w4 * 8) * ROWB), 16, voff, 0, 0, 0);
-        }
-        if (grp == 0) {
-#pragma unroll
-            for (int r = 0; r < RN; ++r)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * 32 + w4 * 8) * ROWB), 16, woff[r], kt * BK * 2, 0, 0);
-        }
-        if (p.korder) {
-            if (++o_kw == p.KW) { o_kw = 0; if (++o_c == nchunk) { o_c = 0; ++o_kh; } }
-            tap = o_kh * p.KW + o_kw; ci = o_c << 6;
-        } else {
-            ci += BK;
-            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
-        }
-    };
-
-    floatx16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    issue_loads(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // B0: stage 0 visible to everyone
-    if (grp == 1) __builtin_amdgcn_s_barrier();         // group 1 starts one interval late -> anti-phase
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // ---- P: DMAs of the next stage, then every fragment of this stage into registers ----
-        if (kt + 1 < nk) issue_loads(cur ^ 1, kt + 1);
-        const char* xs = smem + cur * STAGE + grp * (GM * ROWB);
-        const char* ws = smem + cur * STAGE + BM * ROWB;
-        half8 wf[KS][TN], xf[KS][TM];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int q = ks * 2 + hi32;
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int row = wn * WTN + i * 32 + l31;
-                wf[ks][i] = *(const half8*)(ws + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int row = wm * WTM + j * 32 + l31;
-                xf[ks][j] = *(const half8*)(xs + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- C: the MFMA cluster, registers only ----
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of stage kt+1 have landed
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();         // match group 1's extra barrier
-
-    // ---- epilogue: bias + act, LDS transpose, full-line NHWC stores (all 512 threads) ----
-    constexpr int OROW = BN * 2 + 16;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int pix = grp * GM + wm * WTM + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int nl = wn * WTN + i * 32;
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                unsigned w[2][2];
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int g = gp * 2 + gg;
-                    const int n = n0 + nl + 8 * g + 4 * hi32;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
-                    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-                    w[gg][0] = __builtin_bit_cast(unsigned, h0);
-                    w[gg][1] = __builtin_bit_cast(unsigned, h1);
-                }
-                auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-                uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-                *(uint4v*)(smem + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-        constexpr int CPP = BN / 8, NCH = BM * CPP;
-        half_t* outp = (half_t*)p.out;
-        const int mb = tile_m * BM;
-        for (int c = tid; c < NCH; c += 512) {
-            const int pix = c / CPP, ch = c - pix * CPP;
-            const int m = mb + pix, n = n0 + ch * 8;
-            if (m < p.M && n < p.Cout) {
-                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
-                *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
-            }
-        }
-    }
-#endif
-}
-
-template <int BN>
-static int launch_conv_ap(const Y7TConvArgs& a, hipStream_t s) {
-    constexpr unsigned lds_stage = 2 * (256 + BN) * 128, lds_epi = 256 * (BN * 2 + 16);
-    constexpr unsigned lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr = false;
-    if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_ap<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    const int tiles_m = (a.M + 255) / 256, tiles_n = a.Cout_pad / BN;
-    hipLaunchKernelGGL((k_conv_ap<BN>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a);
-    Y7T_LAUNCH_CHECK();
-    return 0;
-}
-
 // sum the split-K slabs in split order, add bias, activate, store (fp16 NHWC slice or fp32)
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int S, int M, int Cout_pad, int Cout, const float* __restrict__ bias,
                                                        int act, void* out, int ldout, int cout_off, int out_f32) {
@@ -811,216 +380,6 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = 128ull << 20;
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent, cross-tile pipelined variant (uniform-tap layers, fp16 output).  Y7T_CONV_ABLATE shows that for most layers of
-// the network the per-tile fixed costs -- index set-up, the latency of a tile's first DMA stage, the epilogue -- are as large
-// as the K loop itself (K = 576 is 9 steps).  Here at most 2 workgroups per CU stay resident and walk over the tiles; the
-// 2-stage LDS ring runs CONTINUOUSLY through the tile boundaries: while the last K-step of tile t is being multiplied the DMAs
-// of tile t+1's first K-step are already in flight (its geometry was computed during tile t), and tile t's epilogue
-// (bias + SiLU + LDS transpose in its OWN LDS region + full-line stores) overlaps those DMAs and the co-resident workgroup's
-// MFMAs.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ void __launch_bounds__(256, 2) k_conv_persist(const Y7TConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 128, BK = 32, ROWB = 64, CPR = 4, RPW = 16, RPR = 64;
-    constexpr int WTN = BN / 2, WTM = BM / 2, TN = WTN / 32, TM = WTM / 32;
-    constexpr int RM = BM / RPR, RN = (BN + RPR - 1) / RPR;
-    constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int OROW = BN * 2 + 16;
-    constexpr int EPI_OFF = 2 * STAGE;                        // the epilogue transposes in its own LDS region
-    constexpr int KS = BK / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi32 = lane >> 5;
-    const int n_tiles_m = (p.M + BM - 1) / BM, n_tiles_n = p.Cout_pad / BN, n_tiles = n_tiles_m * n_tiles_n;
-    const int G = gridDim.x;
-    // XCD-aware: workgroup b runs on XCD b % 8 -> give every XCD a contiguous chunk of each window of G tiles
-    const int b0 = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-    const int nk = p.K_pad / BK;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    const int lrow = wave * RPW + lane / CPR;
-    const int gchunk = (lane % CPR) ^ ((lrow >> 2) & 3);
-    const int HoWo = p.Ho * p.Wo;
-    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
-    const int nchunk = p.Cin >> 6;
-
-    // geometry of one tile: DMA offsets / tap masks of this lane's rows
-    struct Geo { int xoff[RM]; unsigned vmask[RM]; int woff[RN]; int m0, n0; };
-    auto make_geo = [&](int tile, Geo& g) {
-        const int tile_n = tile % n_tiles_n, tile_m = tile / n_tiles_n;
-        g.m0 = tile_m * BM; g.n0 = tile_n * BN;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int m = g.m0 + r * RPR + lrow;
-            g.vmask[r] = 0; g.xoff[r] = 0;
-            if (m < p.M) {
-                int b = (int)((float)m * inv_howo);
-                b += ((b + 1) * HoWo <= m) - (b * HoWo > m);
-                const int rem = m - b * HoWo;
-                int ho = (int)((float)rem * inv_wo);
-                ho += ((ho + 1) * p.Wo <= rem) - (ho * p.Wo > rem);
-                const int wo = rem - ho * p.Wo;
-                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-                g.xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + gchunk * 8) * 2;
-                const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
-                const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
-                const unsigned colbits = (whi >= wlo) ? (((2u << whi) - 1u) & ~((1u << wlo) - 1u)) : 0u;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-                    if (kh >= klo && kh <= khi) g.vmask[r] |= colbits << (kh * p.KW);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RN; ++r) g.woff[r] = ((g.n0 + r * RPR + lrow) * p.K_pad + gchunk * 8) * 2;
-    };
-    // DMAs of K-step kt of the tile described by g into ring slot `stage`
-    auto issue_stage = [&](const Geo& g, int stage, int kt) {
-        char* xs = smem + stage * STAGE;
-        char* ws = xs + BM * ROWB;
-        int tap, ci;
-        if (p.korder) {      // (kh, 64-channel chunk, kw) K order
-            const int grp = kt >> 1, sub = kt & 1;
-            const int kw = grp % p.KW, c = (grp / p.KW) % nchunk, kh = grp / (p.KW * nchunk);
-            tap = kh * p.KW + kw; ci = (c << 6) + sub * BK;
-        } else {
-            const int k = kt * BK;
-            tap = k / p.Cin; ci = k - tap * p.Cin;
-        }
-        const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;
-        const int kw = tap - kh * p.KW;
-        const int tapoff = ((kh * p.W + kw) * p.ldin + ci) * 2;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int voff = ((g.vmask[r] >> tap) & 1u) ? g.xoff[r] + tapoff : -1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (r * RPR + wave * RPW) * ROWB), 16, voff, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < RN; ++r)
-            if (BN >= RPR || (r * RPR + lrow) < BN)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(ws + (r * RPR + wave * RPW) * ROWB), 16, g.woff[r], kt * BK * 2, 0, 0);
-    };
-
-    Geo cur, nxt;
-    int tile = b0;
-    if (tile >= n_tiles) return;
-    make_geo(tile, cur);
-    issue_stage(cur, 0, 0);
-    int slot = 0;                       // ring slot that holds the stage about to be consumed
-    while (true) {
-        const int next_tile = tile + G;
-        const bool has_next = next_tile < n_tiles;
-        floatx16 acc[TN][TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // refill the other slot: next K-step of this tile, or the first K-step of the next tile
-            if (kt + 1 < nk) issue_stage(cur, slot ^ 1, kt + 1);
-            else if (has_next) issue_stage(nxt, slot ^ 1, 0);
-            const char* xs = smem + slot * STAGE;
-            const char* ws = xs + BM * ROWB;
-            half8 wf[KS][TN], xf[KS][TM];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int q = ks * 2 + hi32;
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    const int row = wn * WTN + i * 32 + l31;
-                    wf[ks][i] = *(const half8*)(ws + row * ROWB + ((q ^ ((row >> 2) & 3)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int row = wm * WTM + j * 32 + l31;
-                    xf[ks][j] = *(const half8*)(xs + row * ROWB + ((q ^ ((row >> 2) & 3)) << 4));
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
-            if (kt == 0 && has_next) make_geo(next_tile, nxt);     // the next tile's index math rides behind the first MFMAs
-            slot ^= 1;
-        }
-        // ---- epilogue of `tile` in its own LDS region; the next tile's first DMA stage is already in flight ----
-        {
-            char* eb = smem + EPI_OFF;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int pix = wm * WTM + j * 32 + l31;
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    const int nl = wn * WTN + i * 32;
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        unsigned w[2][2];
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const int g = gp * 2 + gg;
-                            const int n = cur.n0 + nl + 8 * g + 4 * hi32;
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + p.bias[n + e], p.act);
-                            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                            half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-                            w[gg][0] = __builtin_bit_cast(unsigned, h0);
-                            w[gg][1] = __builtin_bit_cast(unsigned, h1);
-                        }
-                        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-                        uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-                        *(uint4v*)(eb + pix * OROW + (nl + 8 * (gp * 2 + hi32)) * 2) = pk;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();            // tile staged in LDS (the DMAs in flight are not drained: raw barrier)
-            typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-            constexpr int CPP = BN / 8, NCH = BM * CPP;
-            half_t* outp = (half_t*)p.out;
-#pragma unroll 4
-            for (int c = tid; c < NCH; c += 256) {
-                const int pix = c / CPP, ch = c - pix * CPP;
-                const int m = cur.m0 + pix, n = cur.n0 + ch * 8;
-                if (m < p.M && n < p.Cout) {
-                    const uint4v v = *(const uint4v*)(eb + pix * OROW + ch * 16);
-                    *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();            // the epilogue region may be overwritten by the next tile's epilogue
-        }
-        if (!has_next) break;
-        tile = next_tile;
-        cur = nxt;
-    }
-#endif
-}
-
-template <int BN>
-static int launch_conv_persist(const Y7TConvArgs& a, hipStream_t s) {
-    constexpr unsigned lds = 2 * (128 + BN) * 64 + 128 * (BN * 2 + 16);
-    static bool attr = false;
-    if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_persist<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    const int tiles = ((a.M + 127) / 128) * (a.Cout_pad / BN);
-    const int grid = tiles < 512 ? tiles : 512;     // 2 resident workgroups per CU
-    hipLaunchKernelGGL((k_conv_persist<BN>), dim3(grid), dim3(256), lds, s, a);
-    Y7T_LAUNCH_CHECK();
-    return 0;
-}
 
 template <int BM, int BN, int BK, int NST, bool UT>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
@@ -1108,13 +467,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         if (rc) return rc < 0 ? rc : 0;
     }
     const bool wide = a.Cout_pad % 128 == 0;
-    const bool ws_ok = !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) && !(a.cout_off & 7);
     const int var = conv_variant();
-    if (var == 12 && ws_ok && a.Cin % 32 == 0 && (!a.korder || a.Cin % 64 == 0)) return wide ? launch_conv_persist<128>(a, s) : launch_conv_persist<64>(a, s);
-    if (var == 11 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ap<128>(a, s) : launch_conv_ap<64>(a, s);
-    if (var == 8 && ws_ok && a.Cin % 64 == 0) return wide ? launch_conv_ws<128, 128, 64, 2>(a, s) : launch_conv_ws<128, 64, 64, 2>(a, s);
-    if (var == 9 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 3>(a, s) : launch_conv_ws<128, 64, 32, 3>(a, s);
-    if (var == 10 && ws_ok && a.Cin % 32 == 0) return wide ? launch_conv_ws<128, 128, 32, 4>(a, s) : launch_conv_ws<128, 64, 32, 4>(a, s);
     switch (var > 7 ? 0 : var) {
     case 1: return wide ? launch_conv<128, 128, 64, 3>(a, s) : launch_conv<128, 64, 64, 3>(a, s);
     case 2: return wide ? launch_conv<128, 128, 32, 3>(a, s) : launch_conv<128, 64, 32, 3>(a, s);
