@@ -46,8 +46,12 @@ def parse():
     ap.add_argument("--img", type=int, default=1280)
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as a captured hipGraph")
+    ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
+                    "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
+    ap.add_argument("--mode", default="sequences", choices=["sequences", "frames"],
+                    help="sequences (default): one sequence per GPU, weak scaling, no data-path exchange.  frames: ONE sequence, batches of "
+                         "frames detected round-robin over the GPUs, detections sent to the tracker on rank 0 (strong scaling, SURVEY 8e)")
     return ap.parse_args()
 
 
@@ -108,6 +112,75 @@ def cpu_baseline(args, det, frames_host, dets_seq):
                       % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}
 
 
+def frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, results):
+    """single-stream mode: batch s of the ONE sequence is detected (forward + decode/NMS) by rank s % world; its detections go to
+    rank 0 with one point-to-point message (sharding.DetectionRelay); rank 0 runs every tracker frame step, in order.
+    Returns (seconds for the K timed batches, forward ms list of this rank's timed batches)."""
+    from yolov7_tracker_amd import sharding
+    from yolov7_tracker_amd.detector.model import MAX_DET
+    B, K, Wm = args.batch, args.steps, args.warmup
+    on_gpu = backend == "nccl"
+    relay = sharding.DetectionRelay(B, MAX_DET, device="cuda" if on_gpu else "cpu")
+    sA, sB, sC, sD = (torch.cuda.Stream() for _ in range(4))
+    ev = {}
+    fwd_ms_ev = []
+    last_own = [None]
+
+    def detect(s, timed):
+        with torch.cuda.stream(sA):
+            e0, e1, est = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+            e0.record(sA)
+            out = det.forward(frames)
+            e1.record(sA)
+            if timed:
+                fwd_ms_ev.append((e0, e1))
+            if last_own[0] is not None:
+                sA.wait_event(ev[last_own[0]])           # staging set free again
+            staged = det.stage_heads(out)
+            est.record(sA)
+        with torch.cuda.stream(sC):
+            sC.wait_event(est)
+            dets, nd = det.postprocess(staged, 0.01, 0.45, None)
+            if rank != 0:
+                if on_gpu:
+                    relay.send(dets, nd)                  # RCCL send, ordered behind the NMS on this stream
+                else:
+                    relay.send(dets.cpu(), nd.cpu())      # gloo smoke path
+            ev[s] = torch.cuda.Event()
+            ev[s].record(sC)
+        last_own[0] = s
+
+    def run(lo, hi, timed):
+        for s in range(lo, hi):
+            owner = sharding.batch_owner(s, world)
+            if owner == rank:
+                detect(s, timed)
+            if rank == 0:
+                if owner != 0:
+                    with torch.cuda.stream(sD):
+                        relay.recv(owner)                 # (B, 300, 6) + counts; the tracker below consumes the scene's detections
+                        ev[s] = torch.cuda.Event()
+                        ev[s].record(sD)
+                with torch.cuda.stream(sB):
+                    sB.wait_event(ev[s])
+                    for i in range(B):
+                        trk._launch(dets_dev[s * B + i], out=results[s * B + i])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, Wm, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(Wm, Wm + K, True)
+    barrier()
+    dt_s = time.perf_counter() - t0
+    return dt_s, [a.elapsed_time(b) for a, b in fwd_ms_ev]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,15 +211,43 @@ def main():
     nc = 10
     det = model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=B, seed=0)
     n_frames = (K + Wm) * B
-    frames_host = synth.make_frames(B, args.n_obj, H, seq_idx=rank)          # B distinct frames, reused every step
+    seq = 0 if args.mode == "frames" else rank                                # single-stream mode: every rank sees the same sequence
+    frames_host = synth.make_frames(B, args.n_obj, H, seq_idx=seq)           # B distinct frames, reused every step
     frames = torch.from_numpy(frames_host).cuda()
-    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=rank)  # the scene's detections, frame by frame
+    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=seq)   # the scene's detections, frame by frame
     dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
     plant_objectness_bias(det, frames)
 
     BaseTrack._count = 0
     trk = ByteTrack(make_opts(), frame_rate=30)
     results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    if args.mode == "frames":
+        dt_s, fwd_ms = frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, results)
+        if dist is not None:
+            tmax = torch.tensor([dt_s], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_s = float(tmax.item())
+        torch.cuda.synchronize()
+        det.check_overflow()
+        if rank == 0:
+            last = results[(Wm + K) * B - 1].cpu().numpy()
+            conv_tflops = det.gflop_per_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3 if fwd_ms else None
+            print(json.dumps({
+                "metric": "end-to-end fps (detect+track) YOLOv7-w6@1280 ByteTrack", "value": round(K * B / dt_s, 2), "unit": "frames/s",
+                "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": "configs[1], single-stream mode: ONE synthetic VisDrone-shape sequence, YOLOv7-w6 1280x1280 + ByteTrack",
+                           "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
+                           "tracks_alive_last_frame": int(last[trk.cap_t].view(np.int32)[0]),
+                           "parallelism": "detector frame-sharded x%d (batch s on rank s %% N), detections sent to the tracker on rank 0" % world,
+                           "collective_backend": backend if world > 1 else None},
+                "roofline": {"bound": "mfma", "achieved": None if conv_tflops is None else round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12,
+                             "unit": "TFLOP/s", "frac": None if conv_tflops is None else round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": None},
+                "cpu_baseline": None}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     sA, sB, sC = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     ev_staged = [torch.cuda.Event() for _ in range(K + Wm)]
     ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
@@ -154,7 +255,7 @@ def main():
     ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
 
     graph = None
-    if args.hipgraph:
+    if args.hipgraph == 1:
         with torch.cuda.stream(sA):
             graph, _, _ = det.capture(frames, 0.01, 0.45, None)
 
@@ -163,6 +264,18 @@ def main():
     k_mid = next((i for i, op in enumerate(det.plan.ops) if int(op["H"]) <= H // 8), 0)
     ev_mid = [torch.cuda.Event() for _ in range(K + Wm)]
     pending = []          # (step, staged heads) whose decode+NMS and tracker steps are not enqueued yet
+    fwd_graphs = fwd_out = None
+    if args.hipgraph == 2:    # the same launch list, captured in two pieces around the gate event
+        from yolov7_tracker_amd import _lib
+        with torch.cuda.stream(sA):
+            fwd_out = det.forward(frames)            # warm-up: plan selection, kernel attributes
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=sA):
+                det.forward_part(frames, 0, k_mid)
+            with torch.cuda.graph(g2, stream=sA):
+                det.forward_part(None, k_mid, -1)
+        fwd_graphs = (g1, g2)
 
     def finish(prev, gate):
         """decode + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
@@ -193,7 +306,13 @@ def main():
             return
         with torch.cuda.stream(sA):
             ev_fwd0[s].record(sA)
-            out = det.forward(frames, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)))
+            if fwd_graphs is not None:
+                fwd_graphs[0].replay()
+                ev_mid[s].record(sA)
+                fwd_graphs[1].replay()
+                out = fwd_out
+            else:
+                out = det.forward(frames, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)))
             ev_fwd1[s].record(sA)
         if pending:                            # the previous batch: decode+NMS starts once this forward has left the big maps
             finish(pending.pop(), ev_mid[s])

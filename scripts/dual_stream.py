@@ -44,3 +44,26 @@ with torch.cuda.stream(sa):
     da(frames[:h])
 t3 = timed(both, reps)
 print("two streams, staggered: %.2f ms  (%.0f frames/s detector only)" % (t3, B / t3 * 1e3), flush=True)
+
+# staggered with events: only one stream at a time is inside the memory-bound high-resolution ops [0, k_mid) of its forward
+k_mid = next((i for i, op in enumerate(da.plan.ops) if int(op["H"]) <= 160), 0)
+n_iter = reps
+
+
+def interleaved():
+    evs = []
+    prev_h = None
+    for it in range(n_iter):
+        for d, st, fr in ((da, sa, frames[:h]), (db, sb, frames[h:])):
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(st):
+                if prev_h is not None:
+                    st.wait_event(prev_h)          # the other stream has left its high-resolution part
+                d.forward(fr, mid_hook=(k_mid, lambda e=ev, s_=st: e.record(s_)))
+            prev_h = ev
+
+
+interleaved(); torch.cuda.synchronize()
+t0 = time.perf_counter(); interleaved(); torch.cuda.synchronize()
+t4 = (time.perf_counter() - t0) / n_iter * 1e3
+print("two streams, high-res parts serialised by events: %.2f ms per %d frames  (%.0f frames/s detector only)" % (t4, B, B / t4 * 1e3), flush=True)

@@ -74,3 +74,65 @@ def test_single_rank_path():
     rows = {0: torch.tensor([[1, 1, 0, 0, 1, 1, 0, .5]], dtype=torch.float64), 1: torch.tensor([[1, 1, 0, 0, 1, 1, 0, .5], [1, 2, 0, 0, 1, 1, 0, .5]], dtype=torch.float64)}
     res = sharding.rebase_and_gather(rows, {0: 3, 1: 2}, 2)
     assert res[0][0, 1] == 1 and res[1][0, 1] == 4 and res[1][1, 1] == 5
+
+
+# ---- single-stream mode: frame-sharded detection, tracker on rank 0 ----
+FS_BATCH, FS_STEPS, FS_MAXDET = 5, 6, 64
+
+
+def _batch_dets(s):
+    """the 'detector output' of batch s: the synthetic detections of its frames, padded to (B, max_det, 6) + counts"""
+    from yolov7_tracker_amd import synth
+    dets = synth.make_detections(FS_BATCH * FS_STEPS, N_OBJ, seq_idx=7)[s * FS_BATCH:(s + 1) * FS_BATCH]
+    out = torch.zeros((FS_BATCH, FS_MAXDET, 6), dtype=torch.float32)
+    nd = torch.zeros(FS_BATCH, dtype=torch.int32)
+    for i, d in enumerate(dets):
+        out[i, :len(d)] = torch.from_numpy(d)
+        nd[i] = len(d)
+    return out, nd
+
+
+def _fs_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _hostsim as hs
+    from yolov7_tracker_amd import sharding
+    relay = sharding.DetectionRelay(FS_BATCH, FS_MAXDET)
+    if rank == 0:
+        trk = hs.HostSimTracker("bytetrack", ids=np.zeros(1, np.int32), cap_t=256, cap_d=256)
+        rows = []
+        for s in range(FS_STEPS):
+            owner = sharding.batch_owner(s, world)
+            dets, nd = _batch_dets(s) if owner == 0 else relay.recv(owner)
+            for i in range(FS_BATCH):
+                for (tid, tlwh, cls, score) in trk.update(dets[i, :int(nd[i])].numpy().copy()):
+                    rows.append([s * FS_BATCH + i + 1, tid, tlwh[0], tlwh[1], tlwh[2], tlwh[3]])
+        q.put(np.asarray(rows))
+    else:
+        for s in range(FS_STEPS):
+            if sharding.batch_owner(s, world) == rank:
+                relay.send(*_batch_dets(s))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_detection_feeds_one_tracker_in_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from tests import _hostsim as hs
+    trk = hs.HostSimTracker("bytetrack", ids=np.zeros(1, np.int32), cap_t=256, cap_d=256)
+    want = []
+    for s in range(FS_STEPS):
+        dets, nd = _batch_dets(s)
+        for i in range(FS_BATCH):
+            for (tid, tlwh, cls, score) in trk.update(dets[i, :int(nd[i])].numpy().copy()):
+                want.append([s * FS_BATCH + i + 1, tid, tlwh[0], tlwh[1], tlwh[2], tlwh[3]])
+    np.testing.assert_array_equal(got, np.asarray(want))

@@ -178,6 +178,19 @@ class Detector:
         self._img_keep = img
         return HeadOutput(self, B, (H, W))
 
+    def forward_part(self, img, first, last):
+        """ops [first, last) of the current plan's launch list on the current stream (last < 0: to the end); with `img` (uint8
+        NHWC or float32 NCHW device tensor of the plan's size) the input layout runs first.  For callers that capture the
+        forward in pieces (bench.py --hipgraph 2); `forward` must have selected the plan before."""
+        p, s = self.plan, _lib.stream_ptr()
+        if img is not None:
+            is_u8 = img.dtype == torch.uint8
+            B = img.shape[0]
+            H, W = (img.shape[1], img.shape[2]) if is_u8 else (img.shape[2], img.shape[3])
+            _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
+            self._part_B = B
+        _lib.check(self._L.y7t_det_forward_ops(p.handle, self._part_B, int(first), int(last), s))
+
     @staticmethod
     def letterbox_params(shape, new_shape, stride, auto=True, scaleup=True):
         """tracker_dataloader.py:100-130 -> (H, W of the letterboxed image, new_h, new_w, top, left)"""

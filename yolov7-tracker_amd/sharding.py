@@ -61,3 +61,38 @@ def rebase_and_gather(rows_by_seq, n_ids_by_seq, n_seqs, group=None, device="cpu
             res[s] = out[r][o:o + n].clone()
             o += n
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Single-stream mode (second granularity): ONE sequence, the detector frame-sharded, the tracker on one rank.
+# Batch s (consecutive frames) is detected by rank s % world; its (B, max_det, 6) detections + counts travel to rank 0 with one
+# point-to-point message (RCCL send/recv over the direct xGMI link; ~7 KB per frame), where the tracker consumes the batches
+# in order.  Strong scaling, bounded by the serial tracker (~0.2 ms/frame).
+# ---------------------------------------------------------------------------------------------------------------------
+def batch_owner(s, world):
+    return s % world
+
+
+class DetectionRelay:
+    """one reusable message buffer per rank: rows [0, max_det) = detections, row max_det column 0 = the count"""
+
+    def __init__(self, batch, max_det, device="cpu", group=None):
+        self.max_det, self.group = max_det, group
+        self.buf = torch.zeros((batch, max_det + 1, 6), dtype=torch.float32, device=device)
+
+    def pack(self, dets, ndets):
+        B = dets.shape[0]
+        self.buf[:B, :self.max_det] = dets
+        self.buf[:B, self.max_det, 0] = ndets.to(torch.float32)
+        return self.buf
+
+    def unpack(self):
+        return self.buf[:, :self.max_det], self.buf[:, self.max_det, 0].to(torch.int32)
+
+    def send(self, dets, ndets, dst=0):
+        """stream-ordered on the current stream with the 'nccl' backend (enqueue behind the NMS that produced `dets`)"""
+        dist.send(self.pack(dets, ndets), dst=dst, group=self.group)
+
+    def recv(self, src):
+        dist.recv(self.buf, src=src, group=self.group)
+        return self.unpack()
