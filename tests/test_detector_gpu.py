@@ -70,6 +70,11 @@ CONV_CASES = [
     (2, 24, 40, 64, 64, 3, 1, 2 | 256, 128, 64, 192, 128, 0),
     (5, 20, 20, 192, 256, 3, 1, 1 | 1024, 192, 0, 256, 0, 0),
     (1, 7, 20, 64, 64, 3, 1, 1, 64, 0, 64, 0, 0),
+    # multi-tile workgroups of the 64-channel patch kernel (act bit 9 forces them on small problems): tile count not a multiple of 4,
+    # ragged edges, 2 and 6 chunks per tile, all three weight orders, output slice
+    (3, 48, 48, 64, 64, 3, 1, 1 | 512 | 1024, 64, 0, 64, 0, 0),
+    (1, 37, 70, 192, 64, 3, 1, 2 | 512 | 256, 256, 64, 192, 64, 0),
+    (2, 24, 64, 64, 192, 3, 1, 1 | 512, 64, 0, 192, 0, 0),
     # 1x1 layers with panel-packed weights (act bit 11): 128- and 64-row panels, Cin % 64 == 32, split-K on a small map, fp32 head
     (2, 40, 40, 256, 256, 1, 1, 1 | 2048, 256, 0, 256, 0, 0),
     (1, 24, 24, 96, 192, 1, 1, 2 | 2048, 256, 64, 384, 192, 0),

@@ -360,6 +360,246 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-tile variant for the 64-channel panels (Cout_pad % 128 != 0: the 64 -> 64 layers at 320x320 / 160x160, K = 576).  Such a
+// workgroup lives for 18 K-steps; Y7T_CONV_ABLATE on the single-tile kernel shows 38 % of the layer in the epilogue and 27 % in
+// launch + index set-up + the first HBM-latency patch, all exposed.  Here a workgroup walks MT consecutive pixel tiles and the
+// chunk stream simply continues across the tile boundary: while the last chunk of tile t is multiplied the first patch of tile t+1
+// is already landing (its per-lane sources are computed during tile t), the weight ring keeps turning, and the epilogue writes
+// its 16-byte pieces straight from registers to memory -- no LDS staging, so nothing it touches is in the way of those DMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TW, int TH, int MT>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_patch_mt(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BN = 64;
+    using C = PatchCfg<TW, TH, BN>;
+    static_assert(!C::FLAT && TW * TH == 256, "256 output pixels per tile");
+    constexpr int PIXB = C::PIXB, RP = C::RP, TM = C::TM, RPT = C::RPT;
+    // weight ring: NWS slots, K-step u+WD goes out at step u (WD = NWS reuses the slot whose fragments were read a step ago).
+    // A 6-slot ring with 5 steps of look-ahead was measured too: no faster (491 vs 460 us on the 320x320 64->64 layer) -- the loop
+    // is not waiting for weight panels.
+    constexpr int NWS = 3, WD = 3;
+    constexpr int P_OFF = NWS * C::W_BYTES, BIAS_OFF = P_OFF + 2 * C::PATCH_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;                       // BN = 64: the four waves split the pixels
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n_tiles_n = p.Cout_pad / BN;
+    const int tile_n = bid % n_tiles_n, n0 = tile_n * BN;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH, ptiles = p.B * tiles_y * tiles_x;
+    const int pt_first = (bid / n_tiles_n) * MT;
+    const int nt = (ptiles - pt_first) < MT ? (ptiles - pt_first) : MT;      // pixel tiles of this workgroup
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const bool wrole = wave < 2;               // waves 0/1 stream the weight panels, waves 2/3 the patches
+
+    // per-lane patch sources of pixel tile `pt` (patch waves) -- kOOB outside the image / past the last tile
+    auto patch_off = [&](int pt, unsigned (&o)[C::NPX]) {
+        int q = pt;
+        const int txi = q % tiles_x; q /= tiles_x;
+        const int tyi = q % tiles_y, b = q / tiles_y, h0 = tyi * TH, w0 = txi * TW;
+#pragma unroll
+        for (int i = 0; i < C::NPX; ++i) {
+            int I = (wave - 2) + 2 * i;
+            if (I >= C::PATCH_DMA) I = C::PATCH_DMA - 1;
+            const int byte = I * 1024 + lane * 16;
+            const int r = byte / RP, rb = byte - r * RP;
+            const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
+            const int gy = h0 + r - 1, gx = w0 + x - 1;
+            const bool ok = pt < ptiles && r < TH + 2 && x < TW + 2 && cs < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            o[i] = ok ? (unsigned)(((((b * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2) : kOOB;
+        }
+    };
+    unsigned pc[C::NPX], pn[C::NPX], woff[C::NWX];
+#pragma unroll
+    for (int i = 0; i < C::NPX; ++i) pc[i] = pn[i] = kOOB;
+#pragma unroll
+    for (int i = 0; i < C::NWX; ++i) woff[i] = kOOB;
+    if (wrole) {
+#pragma unroll
+        for (int i = 0; i < C::NWX; ++i) {
+            const int byte = (wave * C::NWX + i) * 1024 + lane * 16;
+            const int row = byte >> 6, slot = (byte >> 4) & 3;
+            woff[i] = p.korder == 2 ? (unsigned)(tile_n * (p.K_pad >> 5) * C::W_BYTES + byte)
+                                    : (unsigned)(((n0 + row) * p.K_pad + ((slot ^ ((row >> 2) & 3)) << 3)) * 2);
+        }
+    } else {
+        patch_off(pt_first, pc);
+        patch_off(pt_first + 1, pn);
+    }
+    const int wsw = (l31 >> 2) & 3;
+    const char* wlane0 = smem + C::W_OFF + l31 * C::WROWB + (((0 + hi32) ^ wsw) << 4);
+    const char* wlane1 = smem + C::W_OFF + l31 * C::WROWB + (((2 + hi32) ^ wsw) << 4);
+    const char* plane = smem + P_OFF + (wm * TM * RPT + (TW == 16 ? (l31 >> 4) : 0)) * RP + (TW == 16 ? (l31 & 15) : l31) * PIXB + hi32 * 16;
+
+    const int nc32 = p.Cin >> 5, total = nt * nc32;     // chunks of this workgroup
+    const int s_kh = p.korder == 2 ? 3 * C::W_BYTES : p.korder ? (p.Cin >> 6) * 3 * 128 : 3 * p.Cin * 2;
+    const int s_kw = p.korder == 2 ? C::W_BYTES : p.korder ? 128 : p.Cin * 2;
+    auto chunk_off = [&](int c) -> int {                // byte offset of chunk c (inside its tile) in a weight row / panel list
+        return p.korder == 2 ? c * 9 * C::W_BYTES : p.korder ? (c >> 1) * 3 * 128 + (c & 1) * 64 : c * 64;
+    };
+    auto issue_w = [&](int slot, int c_in_tile, int kh, int kw, bool real) {
+        const int so = kh * s_kh + kw * s_kw + chunk_off(c_in_tile);
+#pragma unroll
+        for (int i = 0; i < C::NWX; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(smem + C::W_OFF + slot * C::W_BYTES + (wave * C::NWX + i) * 1024), 16,
+                                                     real ? woff[i] : kOOB, real ? so : 0, 0, 0);
+    };
+    auto issue_piece = [&](int pb, int i, unsigned voff, int so) {
+        const int I = ((wave - 2) + 2 * i < C::PATCH_DMA) ? (wave - 2) + 2 * i : C::PATCH_DMA - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + P_OFF + pb * C::PATCH_BYTES + I * 1024), 16, voff, so, 0, 0);
+    };
+
+    floatx16 acc[2][TM];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (tid < BN) ((float*)(smem + BIAS_OFF))[tid] = p.bias[n0 + tid];
+    const float* lbias = (const float*)(smem + BIAS_OFF);
+    if (wrole) {
+#pragma unroll
+        for (int st = 0; st < WD; ++st) issue_w(st, st / 9, (st % 9) / 3, st % 3, st < total * 9);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C::NPX; ++i) issue_piece(0, i, pc[i], 0);
+    }
+    half8 wf[2][2][2], xf[2][2][TM];
+    auto read_frags = [&](int buf, int slot, int pb, int kh, int kw) {
+        const char* ws0 = wlane0 + slot * C::W_BYTES;
+        const char* ws1 = wlane1 + slot * C::W_BYTES;
+        const char* ps = plane + pb * C::PATCH_BYTES + kh * RP + kw * PIXB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[buf][ks][i] = *(const half8*)((ks ? ws1 : ws0) + i * 32 * C::WROWB);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[buf][ks][j] = *(const half8*)(ps + j * C::JOFF + ks * 32);
+        }
+    };
+    auto mfma_half = [&](int buf, int ks) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][ks][i], xf[buf][ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WD - 1) * C::NWX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, 0, 0);
+
+    half_t* outp = (half_t*)p.out;
+    int ct = 0, tcur = 0;                       // chunk index inside the current tile (even), tile counter
+    for (int c0 = 0; c0 < total; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int cc = u / 9, t = u % 9, cur = u & 1;
+            mfma_half(cur, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WD - 2) * C::NWX) : "memory");   // W(u+1) landed; W(u+2..u+WD-1) may fly
+            else if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wrole) {
+                const int un = u + WD, ccn = un / 9, tn = un % 9;
+                int cin = ct + ccn;              // chunk inside its tile of the K-step whose weights go out now
+                if (cin >= nc32) cin -= nc32;    // ... of the NEXT tile: the ring never drains
+                issue_w(un % NWS, cin, tn / 3, tn % 3, c0 + ccn < total);
+            } else if (t < 7) {
+                const int cin = ct + cc + 1;     // next chunk: same tile, or chunk 0 of the next tile
+                const bool nxt = cin == nc32;
+                const bool live = c0 + cc + 1 < total;
+#pragma unroll
+                for (int q = 0; q < C::PPT; ++q)
+                    if (t * C::PPT + q < C::NPX) {
+                        const int i = t * C::PPT + q;
+                        issue_piece(cc ^ 1, i, live ? (nxt ? pn[i] : pc[i]) : kOOB, nxt ? 0 : cin << 6);
+                    }
+            }
+            {
+                const int un = u + 1, tn = un % 9;
+                read_frags(cur ^ 1, un % NWS, (un / 9) & 1, tn / 3, tn % 3);
+            }
+            mfma_half(cur, 1);
+        }
+        ct += 2;
+        if (ct == nc32) {
+            // ---- tile done: bias + activation, 16-byte NHWC pieces straight from the registers ----
+            int q = pt_first + tcur;
+            const int txi = q % tiles_x; q /= tiles_x;
+            const int tyi = q % tiles_y, b = q / tiles_y, h0 = tyi * TH, w0 = txi * TW;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int pix = (wm * TM + j) * 32 + l31;
+                const int r = pix / TW, x = pix - r * TW;
+                const int gy = h0 + r, gx = w0 + x;
+                const bool okp = gy < p.H && gx < p.W;
+                half_t* orow = outp + ((size_t)(b * p.H + gy) * p.W + gx) * p.ldout + p.cout_off + n0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int g = gp * 2 + gg;
+                            const int nl = i * 32 + 8 * g + 4 * hi32;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[nl + e], p.act);
+                            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                            half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
+                            w[gg][0] = __builtin_bit_cast(unsigned, h0v);
+                            w[gg][1] = __builtin_bit_cast(unsigned, h1v);
+                        }
+                        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+                        const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                        const int nn = i * 32 + 8 * (gp * 2 + hi32);          // first of this lane's 8 channels
+                        if (okp && n0 + nn < p.Cout) *(uint4v*)(orow + nn) = pk;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                }
+            }
+            ct = 0;
+            ++tcur;
+            if (!wrole) {
+#pragma unroll
+                for (int i = 0; i < C::NPX; ++i) pc[i] = pn[i];
+                patch_off(pt_first + tcur + 1, pn);
+            }
+        }
+    }
+#endif
+}
+
+template <int TW, int TH, int MT>
+int launch_patch_mt(const Y7TConvArgs& a, hipStream_t s) {
+    using C0 = PatchCfg<TW, TH, 64>;
+    constexpr int lds = 3 * C0::W_BYTES + 2 * C0::PATCH_BYTES + 64 * 4;       // weight ring | patch A | patch B | biases
+    static_assert(lds <= 81920, "two workgroups per CU");
+    static bool attr = false;
+    if (!attr) {
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch_mt<TW, TH, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int ptiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    hipLaunchKernelGGL((k_conv3x3_patch_mt<TW, TH, MT>), dim3(((ptiles + MT - 1) / MT) * (a.Cout_pad / 64)), dim3(256), lds, s, a);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int TW, int TH, int BN, int ABL = 0>
 int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     using C = PatchCfg<TW, TH, BN>;
@@ -438,6 +678,13 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
         case 80: return launch_patch<16, 16, 128, 80>(a, s) ? -1 : 1;
         default: break;
         }
+    }
+    static int mt = -1;
+    if (mt < 0) { const char* e = getenv("Y7T_CONV_PATCH_MT"); mt = e ? atoi(e) : 1; }
+    const int ptiles = a.B * ((a.H + (use16 ? 15 : 7)) / (use16 ? 16 : 8)) * ((a.W + (use16 ? 15 : 31)) / (use16 ? 16 : 32));
+    if (!wide && mt && !a.ablate && (ptiles * (a.Cout_pad / 64) >= 4 * 2048 || a.force_patch)) {   // (force_patch: tests)   // 64-channel panels on big maps: multi-tile workgroups
+        rc = use16 ? launch_patch_mt<16, 16, 4>(a, s) : launch_patch_mt<32, 8, 4>(a, s);
+        return rc ? rc : 1;
     }
     if (use16) rc = wide ? launch_patch<16, 16, 128>(a, s) : launch_patch<16, 16, 64>(a, s);
     else rc = wide ? launch_patch<32, 8, 128>(a, s) : launch_patch<32, 8, 64>(a, s);
