@@ -1,0 +1,126 @@
+"""GPU, BASELINE-size inputs (YOLOv7-w6 @ 1280x1280; 500 objects per frame) checked through size-independent properties, where an
+oracle run would take minutes: batch permutation, linearity of a convolution layer, what an NMS result must look like, and the
+invariants of a tracker's output stream."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_w6_1280_batch_permutation_is_exact():
+    """the same two frames in the other order give the same heads, swapped, bit for bit (no cross-frame leakage anywhere in the
+    launch list: tiles that straddle two frames, strip tiling across images, split-K slabs, staging buffers)"""
+    from yolov7_tracker_amd.detector import arch, model
+    det = model.Detector(arch.ARCHS["yolov7-w6"](10), None, img_size=(1280, 1280), max_batch=2, seed=0)
+    f = torch.randint(0, 256, (2, 1280, 1280, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(11)).cuda()
+    a = [t.clone() for t in det(f)[0].raw()]
+    b = det(f.flip(0).contiguous())[0].raw()
+    for x, y in zip(a, b):
+        assert x.shape[0] == 2 and torch.isfinite(x).all()
+        assert torch.equal(x, y.flip(0))
+    assert sum(int(x[0].numel()) for x in a) == 102000 * 15            # (160^2 + 80^2 + 40^2 + 20^2) * 3 anchors * (5 + nc)
+
+
+@pytest.mark.parametrize("shape", [(320, 320, 64, 64), (80, 80, 256, 256), (40, 40, 384, 384), (320, 320, 256, 128)])
+def test_conv_layer_is_linear_at_full_size(shape):
+    """conv(2 x) == 2 conv(x) exactly (powers of two commute with every rounding) for full-size layers of the w6 list at 8 frames:
+    the 64-channel multi-tile patch kernel, the 128-channel patch kernel, the strip tiling, a 1x1 layer with panel-packed weights"""
+    from yolov7_tracker_amd import _lib
+    from yolov7_tracker_amd.detector import graph, weights
+    L = _lib.load()
+    H, W, Cin, Cout = shape
+    k = 1 if Cin == 256 and Cout == 128 else 3
+    B, pad = 8, k // 2
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn((B, H, W, Cin), generator=g) * 0.5).half()
+    blk = (torch.randn((Cout, k * k * Cin), generator=g) / (k * k * Cin) ** 0.5).half().numpy()
+    code = 0
+    if k == 3 and graph.patch_eligible(H, W, Cin, Cout, 3, 1, 1, Cout, 0, 0, B):
+        blk, code = weights.panel_pack(blk, Cin), 1024
+    elif k == 1:
+        blk, code = weights.panel_pack_linear(blk), 2048
+    w, bias = torch.from_numpy(blk).cuda(), torch.zeros(Cout, device="cuda")
+    zeros = torch.zeros(128, dtype=torch.float16, device="cuda")
+    outs = []
+    for scale in (1.0, 2.0):
+        xd = (x * scale).cuda()
+        out = torch.empty((B, H, W, Cout), dtype=torch.float16, device="cuda")
+        _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(xd), Cin, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), Cout, 0, 0, Cout, Cout, k, k, 1,
+                                         pad, code, _lib.ptr(zeros), _lib.stream_ptr()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0.1
+    a, b = outs[0].float() * 2, outs[1].float()
+    normal = outs[0].abs() >= 2.0 ** -13                      # below that the fp16 result is subnormal: the grid does not scale with the value
+    assert torch.equal(a[normal], b[normal]) and float(normal.float().mean()) > 0.99
+    assert (a - b).abs().max() <= 2.0 ** -23
+
+
+def test_nms_output_properties_at_w6_size():
+    """102 000 anchors per image, ~3 000 candidates: at most 300 rows, scores descending, every row above the confidence
+    threshold and inside the image, and no kept box suppressed by an earlier kept box of its class (IoU <= 0.45)"""
+    from yolov7_tracker_amd.detector import arch, model
+    det = model.Detector(arch.ARCHS["yolov7-w6"](10), None, img_size=(1280, 1280), max_batch=2, seed=0)
+    g = torch.Generator().manual_seed(3)
+    out = det(torch.randint(0, 256, (2, 1280, 1280, 3), dtype=torch.uint8, generator=g).cuda())[0]
+    for l in range(len(det.plan.heads)):
+        t = det.head_tensor(l, 2)
+        v = torch.randn(t.shape, generator=g) * 1.5
+        v.view(2, t.shape[1], t.shape[2], 3, 15)[..., 4] -= 4.5
+        t.copy_(v.cuda())
+    dets, nd = det.postprocess(out, 0.01, 0.45, None)
+    torch.cuda.synchronize()
+    det.check_overflow()
+    assert int(det.plan.cand.max()) > 1000
+    for b in range(2):
+        n = int(nd[b])
+        d = dets[b, :n].cpu()
+        assert 0 < n <= 300
+        assert (d[:-1, 4] >= d[1:, 4]).all() and (d[:, 4] > 0.01).all()
+        assert (d[:, :4] >= 0).all() and (d[:, [0, 2]] <= 1280).all() and (d[:, [1, 3]] <= 1280).all()
+        assert (d[:, :4] == d[:, :4].round()).all() and ((d[:, 5] >= 0) & (d[:, 5] < 10)).all()
+        off = d[:, :4] + d[:, 5:6] * 4096                      # class-aware: boxes of different classes never overlap
+        x1, y1 = torch.max(off[:, None, 0], off[None, :, 0]), torch.max(off[:, None, 1], off[None, :, 1])
+        x2, y2 = torch.min(off[:, None, 2], off[None, :, 2]), torch.min(off[:, None, 3], off[None, :, 3])
+        inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+        area = (off[:, 2] - off[:, 0]) * (off[:, 3] - off[:, 1])
+        iou = inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-9)
+        iou.fill_diagonal_(0)
+        # the rounded, rescaled boxes can move the IoU of a kept pair a little above the threshold it passed before rounding
+        assert iou.max() < 0.45 + 0.08
+
+
+@pytest.mark.parametrize("kind", ["bytetrack", "botsort"])
+def test_500_objects_300_frames_stream_invariants(kind):
+    """BASELINE config 3 size: ids unique inside a frame, never re-issued after they disappeared for longer than the buffer,
+    handed out in increasing order, boxes finite, and the tracker follows most of the 500 objects"""
+    import types
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    from yolov7_tracker_amd.tracker.botsort import BoTSORT
+    BaseTrack._count = 0
+    opts = types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="botsort" if kind == "botsort" else "default", img_size=1280,
+                                 iou_thresh=0.5, max_tracks=2048, max_dets=1024)
+    trk = (BoTSORT if kind == "botsort" else ByteTrack)(opts, frame_rate=30)
+    dets = synth.make_detections(300, 500, 1280, seq_idx=2)
+    first_seen, last_seen, max_id, sizes = {}, {}, 0, []
+    for f, d in enumerate(dets):
+        cur = trk.update(d, None)
+        ids = [t.track_id for t in cur]
+        assert len(ids) == len(set(ids))
+        for t in cur:
+            assert np.isfinite(t.tlwh).all() and t.tlwh[2] > 0 and t.tlwh[3] > 0
+            if t.track_id not in first_seen:
+                first_seen[t.track_id] = f
+            else:
+                assert f - last_seen[t.track_id] <= 31 + 1       # a track that was gone longer than the buffer is never revived
+            last_seen[t.track_id] = f
+        new_ids = sorted(i for i in ids if first_seen[i] == f)
+        if new_ids:
+            assert new_ids[0] > 0
+        max_id = max([max_id] + ids)
+        sizes.append(len(ids))
+    assert max_id <= BaseTrack._count
+    assert np.mean(sizes[50:]) > 200 and max(sizes) > 350          # the objects drift out of the image over 300 frames; early on most are followed
