@@ -23,13 +23,15 @@ def oracle_file(kind, n_frames, n_obj, size, fmt="default", min_area=150):
     return "".join(lines)
 
 
-@pytest.mark.parametrize("tracker,model,size,frames,objs", [("sort", "random:yolov7-tiny", 640, 100, 40), ("bytetrack", "random:yolov7-w6", 1280, 12, 80)])
-def test_track_cli_synthetic(tmp_path, tracker, model, size, frames, objs):
+@pytest.mark.parametrize("tracker,model,size,frames,objs,batch", [("sort", "random:yolov7-tiny", 640, 100, 40, 1), ("bytetrack", "random:yolov7-w6", 1280, 12, 80, 1),
+                                                                  ("bytetrack", "random:yolov7-tiny", 640, 50, 40, 8)])
+def test_track_cli_synthetic(tmp_path, tracker, model, size, frames, objs, batch):
     from yolov7_tracker_amd.tracker import track
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     BaseTrack._count = 0
     folder = track.cli(["--dataset", "synthetic", "--tracker", tracker, "--model_path", model, "--nc", "10", "--img_size", str(size),
-                        "--synthetic_dets", "--synthetic_frames", str(frames), "--synthetic_objs", str(objs), "--results_root", str(tmp_path)])
+                        "--synthetic_dets", "--synthetic_frames", str(frames), "--synthetic_objs", str(objs), "--results_root", str(tmp_path),
+                        "--batch", str(batch)])
     path = os.path.join(folder, "synthetic-000.txt")
     got = open(path).read()
     want = oracle_file(tracker, frames, objs, size)

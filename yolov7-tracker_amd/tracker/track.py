@@ -6,7 +6,7 @@ device-resident SORT / ByteTrack trackers.
     python tracker/track.py --dataset synthetic --tracker bytetrack --model_path random:yolov7-w6 --synthetic_dets
 
 Extra flags (defaults reproduce the reference's behaviour): --model_cfg (yaml / arch name for state-dict checkpoints),
---nc, --synthetic_dets, --synthetic_frames/--synthetic_objs/--synthetic_seqs, --results_root.
+--nc, --synthetic_dets, --synthetic_frames/--synthetic_objs/--synthetic_seqs, --results_root, --device_preprocess, --batch.
 """
 import argparse
 import os
@@ -29,11 +29,12 @@ timer = Timer()
 seq_fps = []
 
 
-def post_process_v7(out, img_size, ori_img_size, conf_thres=0.01):
-    """track.py:234-244"""
-    out = non_max_suppression(out, conf_thres=conf_thres)[0]
-    out[:, :4] = scale_coords(img_size, out[:, :4], ori_img_size, ratio_pad=None).round()
-    return out
+def post_process_v7(out, img_size, ori_img_size, conf_thres=0.01, all_images=False):
+    """track.py:234-244 (the reference keeps image 0 of the batch; all_images=True returns the list for every image)"""
+    res = non_max_suppression(out, conf_thres=conf_thres)
+    for o in res:
+        o[:, :4] = scale_coords(img_size, o[:, :4], ori_img_size, ratio_pad=None).round()
+    return res if all_images else res[0]
 
 
 def save_results(results_root, folder_name, seq_name, results, data_type='mot17'):
@@ -57,7 +58,7 @@ def main(opts, cfgs):
     if opts.tracker == 'botsort':
         opts.kalman_format = 'botsort'      # track.py:68-69
     img_size = opts.img_size[0] if isinstance(opts.img_size, (list, tuple)) else opts.img_size
-    model = attempt_load(opts.model_path, cfg=opts.model_cfg, nc=opts.nc, img_size=img_size)
+    model = attempt_load(opts.model_path, cfg=opts.model_cfg, nc=opts.nc, img_size=img_size, max_batch=max(1, opts.batch))
     stride = int(model.stride.max())
     opts.img_size = check_img_size(img_size, s=stride)
     synthetic = opts.dataset == 'synthetic'
@@ -84,33 +85,44 @@ def main(opts, cfgs):
             loader = tracker_dataloader.TrackerLoader(os.path.join(DATA_ROOT, seq), opts.img_size, opts.data_format, seq,
                                                       pre_process_method='v7', model_stride=stride,
                                                       device_preprocess=opts.device_preprocess)
-        data_loader = torch.utils.data.DataLoader(loader, batch_size=1)
+        data_loader = torch.utils.data.DataLoader(loader, batch_size=max(1, opts.batch))
         tracker = TRACKER_DICT[opts.tracker](opts, frame_rate=30, gamma=opts.gamma)
-        results, frame_id, i = [], 0, 0
-        for i, (img, img0) in enumerate(data_loader):
+        results, frame_id, i = [], 0, -1
+        for imgs, imgs0 in data_loader:
+            # --batch N (extension, default 1 = the reference's frame-at-a-time loop): the detector + decode/NMS run once over N
+            # consecutive frames (that is where the throughput of bench.py comes from), the tracker then takes them in order
+            nb = imgs0.shape[0]
             timer.tic()
-            if not i % opts.detect_per_frame:
-                if opts.device_preprocess:      # raw uint8 frame -> letterbox + layout on the GPU
-                    out, lb_size = model.forward_frames(img0, img_size=opts.img_size)
+            detect = [not (i + 1 + k) % opts.detect_per_frame for k in range(nb)]
+            outs = None
+            if any(detect):
+                if opts.device_preprocess:      # raw uint8 frames -> letterbox + layout on the GPU
+                    head, lb_size = model.forward_frames(imgs0, img_size=opts.img_size)
                 else:
-                    out, lb_size = model(img.cuda())[0], img.shape[2:]
-                img0 = img0.squeeze(0)
-                out = post_process_v7(out, img_size=lb_size, ori_img_size=img0.shape)
-                if opts.synthetic_dets and synthetic:
-                    out = torch.from_numpy(loader.dets[i])          # the scene's detections stand in for a trained detector
-                current_tracks = tracker.update(out, img0)
-            else:
-                current_tracks = tracker.update_without_detection(None, img0)
-            cur_tlwh, cur_id, cur_cls = [], [], []
-            for trk in current_tracks:
-                bbox = trk.tlwh
-                if bbox[2] * bbox[3] > opts.min_area:
-                    cur_tlwh.append(bbox)
-                    cur_id.append(trk.track_id)
-                    cur_cls.append(trk.cls)
-            results.append((frame_id + 1, cur_id, cur_tlwh, cur_cls))
-            timer.toc()
-            frame_id += 1
+                    head, lb_size = model(imgs.cuda())[0], imgs.shape[2:]
+                outs = post_process_v7(head, img_size=lb_size, ori_img_size=imgs0.shape[1:], all_images=True)
+            for k in range(nb):
+                if k:
+                    timer.tic()
+                i += 1
+                img0 = imgs0[k]
+                if detect[k]:
+                    out = outs[k]
+                    if opts.synthetic_dets and synthetic:
+                        out = torch.from_numpy(loader.dets[i])      # the scene's detections stand in for a trained detector
+                    current_tracks = tracker.update(out, img0)
+                else:
+                    current_tracks = tracker.update_without_detection(None, img0)
+                cur_tlwh, cur_id, cur_cls = [], [], []
+                for trk in current_tracks:
+                    bbox = trk.tlwh
+                    if bbox[2] * bbox[3] > opts.min_area:
+                        cur_tlwh.append(bbox)
+                        cur_id.append(trk.track_id)
+                        cur_cls.append(trk.cls)
+                results.append((frame_id + 1, cur_id, cur_tlwh, cur_cls))
+                timer.toc()
+                frame_id += 1
         seq_fps.append(i / timer.total_time)   # track.py:181 (sic: last index, not the frame count)
         timer.clear()
         save_results(opts.results_root, folder_name, seq, results)
@@ -168,6 +180,7 @@ def build_parser():
     parser.add_argument('--track_buffer', type=int, default=30, help='tracking buffer')
     parser.add_argument('--gamma', type=float, default=0.1, help='param to control fusing motion and apperance dist')
     parser.add_argument('--kalman_format', type=str, default='default', help='use what kind of Kalman, default, naive, strongsort or bot-sort like')
+    parser.add_argument('--batch', type=int, default=1, help='(extension) frames per detector forward; the tracker still steps frame by frame')
     parser.add_argument('--device_preprocess', action='store_true', help='(extension) letterbox raw frames on the GPU instead of in the loader')
     parser.add_argument('--min_area', type=float, default=150, help='use to filter small bboxs')
     parser.add_argument('--save_images', action='store_true', help='save tracking results (image)')
