@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
+    ap.add_argument("--halves", type=int, default=1, choices=[1, 2], help="2: experiment -- each step as two interleaved half-batch forwards")
     ap.add_argument("--mode", default="sequences", choices=["sequences", "frames"],
                     help="sequences (default): one sequence per GPU, weak scaling, no data-path exchange.  frames: ONE sequence, batches of "
                          "frames detected round-robin over the GPUs, detections sent to the tracker on rank 0 (strong scaling, SURVEY 8e)")
@@ -181,6 +182,74 @@ def frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, re
     return dt_s, [a.elapsed_time(b) for a, b in fwd_ms_ev]
 
 
+def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
+    """experiment (--halves 2): every step's B frames as two B/2-frame forwards on two streams with two detectors; a forward enters
+    its memory-bound high-resolution ops only when the other one has left them, so byte-bound and MFMA-bound layers of the two
+    halves overlap.  Same decode/NMS gating and tracker ordering as the default pipeline.  -> (seconds, forward spans in ms)"""
+    B, K, Wm = args.batch, args.steps, args.warmup
+    Bh = B // 2
+    dets = [det_factory(Bh), det_factory(Bh)]
+    for d in dets:
+        plant(d, frames[:Bh])
+    sAs = [torch.cuda.Stream(), torch.cuda.Stream()]
+    sB, sC = torch.cuda.Stream(), torch.cuda.Stream()
+    n = (K + Wm) * 2
+    ev_mid = [torch.cuda.Event() for _ in range(n)]
+    ev_staged = [torch.cuda.Event() for _ in range(n)]
+    ev_nms = [torch.cuda.Event() for _ in range(n)]
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    k_mid = next((i for i, op in enumerate(dets[0].plan.ops) if int(op["H"]) <= args.img // 8), 0)
+    pending = []
+
+    def finish(prev, gate):
+        m, staged = prev
+        with torch.cuda.stream(sC):
+            sC.wait_event(ev_staged[m])
+            if gate is not None:
+                sC.wait_event(gate)
+            dets[m % 2].postprocess(staged, 0.01, 0.45, None)
+            ev_nms[m].record(sC)
+        with torch.cuda.stream(sB):
+            sB.wait_event(ev_nms[m])
+            for i in range(Bh):
+                trk._launch(dets_dev[m * Bh + i], out=results[m * Bh + i])
+
+    def mini(m):
+        d, sA = dets[m % 2], sAs[m % 2]
+        fr = frames[(m % 2) * Bh:(m % 2 + 1) * Bh]
+        with torch.cuda.stream(sA):
+            if m > 0:
+                sA.wait_event(ev_mid[m - 1])           # the other half has left its high-resolution layers
+            ev0[m].record(sA)
+            out = d.forward(fr, mid_hook=(k_mid, lambda: ev_mid[m].record(sA)))
+            ev1[m].record(sA)
+        if pending:
+            finish(pending.pop(0), ev_mid[m])
+        with torch.cuda.stream(sA):
+            if m > 1:
+                sA.wait_event(ev_nms[m - 2])           # this detector's staging set is free again
+            staged = d.stage_heads(out)
+            ev_staged[m].record(sA)
+        pending.append((m, staged))
+
+    def run(lo, hi):
+        for m in range(lo, hi):
+            mini(m)
+        while pending:
+            finish(pending.pop(0), None)
+        torch.cuda.synchronize()
+
+    run(0, Wm * 2)
+    t0 = time.perf_counter()
+    run(Wm * 2, n)
+    dt_s = time.perf_counter() - t0
+    for d in dets:
+        d.check_overflow()
+    span = ev0[Wm * 2].elapsed_time(ev1[n - 1])        # first timed forward start -> last forward end (they overlap)
+    return dt_s, span / K, dets[0]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,6 +290,18 @@ def main():
     BaseTrack._count = 0
     trk = ByteTrack(make_opts(), frame_rate=30)
     results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    if args.halves == 2 and world == 1:
+        dt_s, fwd_ms_step, d0 = halves_mode(args, lambda b: model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=b, seed=0),
+                                           frames, dets_dev, trk, results, plant_objectness_bias)
+        tf = d0.gflop_per_frame * B / (fwd_ms_step * 1e-3) / 1e3
+        print(json.dumps({"metric": "end-to-end fps (detect+track) YOLOv7-w6@1280 ByteTrack", "value": round(K * B / dt_s, 2), "unit": "frames/s",
+                          "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "configs[1], two interleaved half-batch forwards per step (experiment)", "frames_per_step": B},
+                          "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
+                                       "frac": round(tf * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+                                       "note": "forward span of a step (two overlapping launch lists) = %.3f ms" % fwd_ms_step}, "cpu_baseline": None}))
+        return
     if args.mode == "frames":
         dt_s, fwd_ms = frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, results)
         if dist is not None:
