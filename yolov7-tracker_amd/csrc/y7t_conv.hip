@@ -305,6 +305,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // Row stride BN*2 + 16 bytes: the 8-lane service groups of ds_write_b128 land on disjoint banks.
     constexpr int OROW = BN * 2 + 16;
     __syncthreads();          // every wave is done with the staging buffers
+    typedef __attribute__((ext_vector_type(4))) float float4v;
+    act_dispatch(p.act, [&](auto act_c) {       // one branch on the activation, specialised bodies
+    constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int pix = wm * WTM + j * 32 + l31;
@@ -319,8 +322,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
                     const int g = gp * 2 + gg;
                     const int n = n0 + nl + 8 * g + 4 * hi32;
                     float v[4];
+                    const float4v bv = *(const float4v*)(lbias + (n - n0));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[n - n0 + e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bv[e]);
                     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                     half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
                     w[gg][0] = __builtin_bit_cast(unsigned, h0);
@@ -335,6 +339,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             }
         }
     }
+    });
     __syncthreads();
     {
         typedef __attribute__((ext_vector_type(4))) unsigned uint4v;

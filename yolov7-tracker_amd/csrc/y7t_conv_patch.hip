@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     const float* lbias = (const float*)(smem + C::BIAS_OFF);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    typedef __attribute__((ext_vector_type(4))) float float4v;
+    act_dispatch(p.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int pix = (wm * TM + j) * 32 + l31;   // tile-local pixel id: TW=16 -> row = pix >> 4, x = pix & 15; TW=32 -> row = pix >> 5
@@ -308,8 +311,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
                     const int g = gp * 2 + gg;
                     const int n = n0 + nl + 8 * g + 4 * hi32;
                     float v[4];
+                    const float4v bv = *(const float4v*)(lbias + (n - n0));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[n - n0 + e], p.act);
+                    for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bv[e]);
                     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                     half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
                     w[gg][0] = __builtin_bit_cast(unsigned, h0);
@@ -323,6 +327,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
             }
         }
     }
+    });
     int* otab = (int*)(smem + C::LDS_EPI);   // FLAT: output pixel index of each of the 256 positions (-1: padding / past the strip)
     if (FLAT) {
         const int g = g0 + tid;
@@ -537,6 +542,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch_mt(const Y7TConvArgs p
             int q = pt_first + tcur;
             const int txi = q % tiles_x; q /= tiles_x;
             const int tyi = q % tiles_y, b = q / tiles_y, h0 = tyi * TH, w0 = txi * TW;
+            act_dispatch(p.act, [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
+            typedef __attribute__((ext_vector_type(4))) float float4v;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int pix = (wm * TM + j) * 32 + l31;
@@ -554,8 +562,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch_mt(const Y7TConvArgs p
                             const int g = gp * 2 + gg;
                             const int nl = i * 32 + 8 * g + 4 * hi32;
                             float v[4];
+                            const float4v bv = *(const float4v*)(lbias + nl);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][g * 4 + e] + lbias[nl + e], p.act);
+                            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bv[e]);
                             typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                             half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
                             w[gg][0] = __builtin_bit_cast(unsigned, h0v);
@@ -572,6 +581,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch_mt(const Y7TConvArgs p
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                 }
             }
+            });
             ct = 0;
             ++tcur;
             if (!wrole) {
