@@ -25,7 +25,9 @@
 
 #include "y7t_conv_common.h"
 
-template <int BM, int BN, int BK, int NST, bool UT>
+// KM = 1: 1x1 / stride 1 / pad 0 with Cin % 64 == 0 -- no taps, no padding, no K tail: every pixel DMA is `row offset (or out of range)
+// + scalar channel offset`, so the K loop carries no address arithmetic and no control flow besides its own counter.
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0>
 __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     for (int r = 0; r < RM; ++r) {
         const int m = m0 + r * RPR + lrow;
         vmask[r] = 0;
-        xoff[r] = 0;
+        xoff[r] = KM == 1 ? (int)0xFF000000u : 0;      // KM 1: an offset that stays out of range with the (< 16 MiB) scalar channel offset added
         if (m < p.M) {
             // m -> (b, ho, wo) with a float reciprocal + one-step fix-up (M < 2^24), no integer division
             int b = (int)((float)m * inv_howo);
@@ -94,6 +96,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             const int wo = rem - ho * p.Wo;
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
             xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + (UT ? gchunk * 8 : 0)) * 2;
+            if (KM == 1) continue;      // (m past M keeps the out-of-range sentinel set below)
             // taps inside the image: kh in [klo, khi], kw in [wlo, whi]
             const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
             const int wlo = wi0 < 0 ? -wi0 : 0, whi = (p.W - 1 - wi0) < (p.KW - 1) ? (p.W - 1 - wi0) : (p.KW - 1);
@@ -124,7 +127,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     auto issue_one = [&](int stage, int kt, int idx) {
         char* xs = smem + stage * STAGE;
         char* ws = xs + BM * ROWB;
-        if (idx < RM) {
+        if (idx < RM && KM == 1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (idx * RPR + wave * RPW) * ROWB), 16, xoff[idx], ci * 2, 0, 0);
+        } else if (idx < RM) {
             const int r = idx;
             const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;   // tap / 3 for tap < 128
             const int kw = tap - kh * p.KW;
@@ -144,12 +149,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // shifted by one pixel, so they hit in L1/L2 instead of coming back from the Infinity Cache a dozen steps later.
     const int nchunk = p.Cin >> 6;
     int o_kw = 0, o_c = 0, o_kh = 0, o_sub = 0;
-    if (UT && p.korder == 1) {   // decode the (kh, chunk, kw) odometer at this split's first K-step
+    if (KM == 1) { tap = 0; ci = kt0 * BK; }
+    if (KM != 1 && UT && p.korder == 1) {   // decode the (kh, chunk, kw) odometer at this split's first K-step
         const int g = (kt0 * BK) >> 6;
         o_kw = g % p.KW; o_c = (g / p.KW) % nchunk; o_kh = g / (p.KW * nchunk); o_sub = ((kt0 * BK) & 63) / BK;
         tap = o_kh * p.KW + o_kw; ci = (o_c << 6) + o_sub * BK;
     }
     auto advance_k = [&]() {
+        if (KM == 1) { ci += BK; return; }
         if (UT && p.korder == 1) {
             if (BK < 64 && ++o_sub < 64 / BK) { ci += BK; return; }
             o_sub = 0;
@@ -174,10 +181,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if ((p.ablate & 16) && ((blockIdx.x >> 8) & 1)) {   // experiment: de-phase the two co-resident blocks of a CU
-#pragma unroll 1
-        for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(20);
-    }
     // prologue: NST-1 stages in flight
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) if (s < nk) issue_loads(s, s);
@@ -191,10 +194,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool do_load = (kt + NST - 1 < nk) && !(p.ablate & 1);
+        const bool do_load = kt + NST - 1 < nk;
         const char* xs = smem + cur * STAGE;
         const char* ws = xs + BM * ROWB;
-        if (p.ablate & 4) { if (do_load) issue_loads(nxt, kt + NST - 1); cur = (cur + 1 == NST) ? 0 : cur + 1; nxt = (nxt + 1 == NST) ? 0 : nxt + 1; continue; }
         constexpr int KS = BK / 16;                 // MFMA k-substeps per stage
         constexpr int LPK = (NLD + KS - 1) / KS;    // DMAs issued behind each substep's MFMAs (spreads them over the stage)
         // fragments are double-buffered in registers: the ds_reads of substep ks+1 are issued before the MFMAs of substep ks
@@ -219,19 +221,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         for (int ks = 0; ks < KS; ++ks) {
             const int cb = ks & 1;
             if (ks + 1 < KS) read_frags(ks + 1, cb ^ 1);
-            if (p.ablate & 2) {   // ablation: keep the fragment reads alive, skip the MFMAs
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[cb][i]));
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[cb][j]));
-            } else {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            }
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             if (do_load) {
 #pragma unroll
                 for (int t = 0; t < LPK; ++t)
@@ -243,13 +238,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
 
-    if (p.ablate & 8) {   // ablation: no epilogue (keep the accumulators alive)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
     if (p.splitk > 1) {   // raw fp32 partial sums of this K range: slab[split][m][Cout_pad]
         float* slab = p.partial + (size_t)split * p.M * p.Cout_pad;
 #pragma unroll
@@ -386,13 +374,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = 128ull << 20;
 
-template <int BM, int BN, int BK, int NST, bool UT>
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
     constexpr unsigned lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + BN * 4;   // + the bias corner
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN, tiles = tiles_m * tiles_n;
@@ -411,7 +399,7 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
         b.partial = g_splitk_ws;
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
     Y7T_LAUNCH_CHECK();
     if (b.splitk > 1) {
         const long long tot = (long long)a.M * (a.Cout_pad / 4);
@@ -425,7 +413,9 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int BK, int NST>
 static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
-    // uniform-tap specialisation: every K-step of BK channels lies inside one filter tap
+    // uniform-tap specialisation: every K-step of BK channels lies inside one filter tap; 1x1 fast path on top of it
+    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24))
+        return launch_conv_ut<BM, BN, BK, NST, true, 1>(a, s);
     return (a.Cin % BK == 0) ? launch_conv_ut<BM, BN, BK, NST, true>(a, s) : launch_conv_ut<BM, BN, BK, NST, false>(a, s);
 }
 
