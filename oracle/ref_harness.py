@@ -62,7 +62,7 @@ def _stub(name, **attrs):
     return m
 
 
-_TRACKER_MODS = ["kalman_filter", "matching", "basetrack", "bytetrack", "botsort"]
+_TRACKER_MODS = ["kalman_filter", "matching", "basetrack", "bytetrack", "botsort", "deepsort"]
 _STUB_NAMES = ["torchvision", "torchvision.ops", "torchvision.utils", "torchvision.transforms", "cv2", "seaborn",
                "reid_models", "reid_models.deepsort_reid", "lap", "cython_bbox", "thop"]
 
@@ -138,6 +138,7 @@ def load_tracker():
     ns.basetrack.matching = ns.matching
     ns.bytetrack.matching = ns.matching
     ns.botsort.matching = ns.matching
+    ns.deepsort.matching = ns.matching
     _tracker_ns = ns
     return ns
 
@@ -157,7 +158,7 @@ def make_opts(**kw):
     return o
 
 
-def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, collect_all=False, warps=None):
+def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, collect_all=False, warps=None, feature_fn=None):
     """Run the reference SORT/ByteTrack over a list of (N,6) float32 arrays.
 
     Returns per-frame lists of (track_id, tlwh[4] float64, cls, score) for the tracks the
@@ -167,8 +168,13 @@ def run_reference_tracker(name, dets_per_frame, opts=None, reset_ids=True, colle
     opts = opts or make_opts()
     if reset_ids:
         ns.basetrack.BaseTrack._count = 0
-    cls = {"sort": ns.basetrack.BaseTracker, "bytetrack": ns.bytetrack.ByteTrack, "botsort": ns.botsort.BoTSORT}[name]
+    cls = {"sort": ns.basetrack.BaseTracker, "bytetrack": ns.bytetrack.ByteTrack, "botsort": ns.botsort.BoTSORT,
+           "deepsort": ns.deepsort.DeepSORT}[name]
     trk = cls(opts, frame_rate=30, gamma=opts.gamma)
+    if name == "deepsort":
+        # the ReID network (reid_models/deepsort_reid.py, weights/ckpt.t7 -- not shipped) is replaced at its call site,
+        # DeepSORT.get_feature (deepsort.py:19-41), by the deterministic embedding both sides of the parity test use
+        trk.get_feature = lambda tlbrs, ori_img, _fn=feature_fn: _fn(tlbrs)
     out = []
     for fi, det in enumerate(dets_per_frame):
         if name == "botsort":

@@ -10,6 +10,9 @@ CPU baseline in bench.py:
   * STrack activate/update/re_activate/tlwh/tlbr, multi_predict  basetrack.py:74-339
   * joint/sub/remove_duplicate_stracks                            basetrack.py:540-576
   * iou_distance / linear_assignment                              matching.py:30-82
+  * DeepSORT.update, gate_cost_matrix, gated_metric               /root/reference/tracker/deepsort.py:43-224  (kind='deepsort')
+    matching_cascade / nearest_embedding_distance / cal_cosine_distance   matching.py:105-127,165-178,216-277
+    (the ReID network is replaced by a feature function at DeepSORT.get_feature, deepsort.py:19-41)
 
 It is pinned against the reference's own modules (imported through
 oracle/ref_harness.py) in tests/test_oracle_pinned.py and through tests/golden/.
@@ -40,10 +43,11 @@ GLOBAL_IDS = IdCounter()
 
 class T:
     __slots__ = ("cls", "box", "score", "activated", "tid", "start", "frame", "tsu", "state", "mean", "cov", "fmt",
-                 "len")
+                 "len", "features")
 
-    def __init__(self, cls, tlwh, score, fmt):
+    def __init__(self, cls, tlwh, score, fmt, feature=None):
         self.cls, self.score, self.fmt = cls, score, fmt
+        self.features = [] if feature is None else [feature]        # basetrack.py:97-103
         self.box = np.asarray(tlwh, dtype=np.float32)
         self.activated, self.tid, self.start, self.frame, self.tsu = False, None, None, None, None
         self.state, self.mean, self.cov, self.len = NEW, None, None, 0
@@ -133,7 +137,8 @@ def _dedup(a, b):
 class TrackerNP:
     def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
                  frame_rate=30, ids=None):
-        assert kind in ("sort", "bytetrack", "botsort")
+        assert kind in ("sort", "bytetrack", "botsort", "deepsort")
+        self.feature_fn = None            # deepsort: (N, 4) tlbr -> (N, D) appearance features (stands in for the ReID network)
         self.kind, self.fmt = kind, kalman_format
         self.det_thresh = conf_thresh
         self.iou_thresh = iou_thresh
@@ -165,6 +170,10 @@ class TrackerNP:
         t.len += 1
         t.score = det.score
         t.mean, t.cov = self._kf_update(t, det)
+        if det.features:                                  # basetrack.py:324-332, use_avg_of_feature=False (deepsort.py:111)
+            f = det.features[0] / np.linalg.norm(det.features[0])
+            t.features.append(f)
+            t.features = t.features[-100:]
         t.state, t.activated, t.tsu = TRACKED, True, 0
 
     def _reactivate(self, t, det):
@@ -223,9 +232,85 @@ class TrackerNP:
             m[:2] += t
             tr.mean, tr.cov = m, R8.dot(tr.cov).dot(R8.transpose())
 
+    # --- DeepSORT (deepsort.py:43-224) ---------------------------------------------
+    @staticmethod
+    def _cos(a, b):
+        """matching.py:165-178"""
+        a = a / np.linalg.norm(a, axis=1, keepdims=True)
+        b = b / np.linalg.norm(b, axis=1, keepdims=True)
+        return np.dot(a, b.T)
+
+    def _gated_metric(self, tracks, dets):
+        """nearest_embedding_distance (matching.py:105-127) + gate_cost_matrix (deepsort.py:43-66)"""
+        cost = np.zeros((len(tracks), len(dets)))
+        df = np.asarray([d.features[-1] for d in dets])
+        for r, t in enumerate(tracks):
+            cost[r, :] = (1. - self._cos(np.asarray(t.features), df)).min(axis=0)
+        zs = np.asarray([d.meas(d.tlwh) for d in dets])            # STrack.tlwh2xyah of every detection
+        cost[cost > 0.15] = 1e5
+        for r, t in enumerate(tracks):
+            cost[r, self.kf.gating_distance(t.mean, t.cov, zs, False) > 9.4877] = 1e5      # chi2inv95[4]
+        return cost
+
+    def _cascade(self, tracks, dets):
+        """matching.matching_cascade(gated_metric, 0.9, max_time_lost, tracks, dets) (matching.py:216-277)"""
+        to_match = list(range(len(dets)))
+        matches = []
+        for level in range(self.max_time_lost):
+            if not to_match:
+                break
+            tl = [k for k in range(len(tracks)) if tracks[k].tsu == 1 + level]
+            if not tl:
+                continue
+            m, _, ucol = _assign(self._gated_metric([tracks[k] for k in tl], [dets[k] for k in to_match]), 0.9)
+            matches += [(tl[r], to_match[c]) for r, c in m]
+            to_match = [to_match[c] for c in ucol]
+        um = list(set(range(len(tracks))) - set(k for k, _ in matches))
+        return matches, um, to_match
+
+    def _update_deepsort(self, det):
+        act, refind, lost, removed = [], [], [], []
+        rows = det[det[:, 4] > self.det_thresh]
+        dets = []
+        if len(rows):
+            feats = self.feature_fn(rows[:, :4])
+            dets = [T(r[5], np.array([r[0], r[1], r[2] - r[0], r[3] - r[1]], dtype=rows.dtype), r[4], self.fmt, feature=f)
+                    for r, f in zip(rows, feats)]
+        unconf = [t for t in self.tracked if not t.activated]
+        conf = [t for t in self.tracked if t.activated]
+        pool = _joint(conf, self.lost)
+        self._multi_predict(pool)
+        m, ut0, ud0 = self._cascade(pool, dets)
+        self._match_apply(pool, dets, m, act, refind)
+        tr0 = [pool[i] for i in ut0 if pool[i].state == TRACKED]
+        d0 = [dets[i] for i in ud0]
+        m, ut1, ud1 = _assign(_iou_dist(tr0, d0), 0.5)
+        d1 = [d0[i] for i in ud1]
+        self._match_apply(tr0, d0, m, act, refind)
+        for i in ut1:
+            t = pool[i]                                   # deepsort.py:171-173 indexes strack_pool with an index into u_tracks0 (sic)
+            t.state = LOST
+            lost.append(t)
+        m, ut2, ud2 = _assign(_iou_dist(unconf, d1), 0.9)
+        self._match_apply(unconf, d1, m, act, refind, only_update=True)
+        for i in ut2:
+            unconf[i].state = REMOVED
+            removed.append(unconf[i])
+        for i in ud2:
+            if d1[i].score > self.det_thresh:
+                self._activate(d1[i])
+                act.append(d1[i])
+        for t in self.lost:
+            if self.frame_id - t.frame > self.max_time_lost:       # end_frame == frame_id of the last update
+                t.state = REMOVED
+                removed.append(t)
+        return self._finish(act, refind, lost, removed)
+
     def update(self, det, warp=None):
         det = np.asarray(det, dtype=np.float32).reshape(-1, 6)
         self.frame_id += 1
+        if self.kind == "deepsort":
+            return self._update_deepsort(det)
         act, refind, lost, removed = [], [], [], []
         unconf = [t for t in self.tracked if not t.activated]
         conf = [t for t in self.tracked if t.activated]
@@ -286,9 +371,10 @@ class TrackerNP:
         return self._finish([], [], [], [])
 
 
-def run(kind, dets_per_frame, ids=None, warps=None, **kw):
+def run(kind, dets_per_frame, ids=None, warps=None, feature_fn=None, **kw):
     """-> per-frame list of (track_id, tlwh float64[4], cls, score), like ref_harness.run_reference_tracker."""
     trk = TrackerNP(kind, ids=ids if ids is not None else IdCounter(), **kw)
+    trk.feature_fn = feature_fn
     out = []
     for fi, det in enumerate(dets_per_frame):
         cur = trk.update_without_detection() if det is None else trk.update(det, None if warps is None else warps[fi])

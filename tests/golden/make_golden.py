@@ -92,6 +92,10 @@ TRACKER_CASES = [
     # BoT-SORT state path (BASELINE config 3): xywh Kalman + multi_gmc with synthetic 2x3 warps; appearance model off
     ("botsort_gmc", "botsort", "botsort", 80, 80, 6, 11),
     ("botsort_crowd", "botsort", "botsort", 12, 500, 7, 0),
+    # DeepSORT association (oracle only so far): matching cascade over appearance + Mahalanobis gate, IoU fallback.
+    # The ReID network is replaced at DeepSORT.get_feature by synth.make_features on both sides.
+    ("deepsort_default", "deepsort", "default", 80, 60, 8, 0),
+    ("deepsort_crowd", "deepsort", "default", 30, 250, 9, 0),
 ]
 
 
@@ -111,7 +115,8 @@ def golden_tracker():
         if drop:
             dets = [None if (i % drop == drop - 1) else d for i, d in enumerate(dets)]
         warps = synth.make_warps(nf, seq_idx=seq) if trk == "botsort" else None
-        ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps)
+        ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps,
+                                                feature_fn=synth.make_features if trk == "deepsort" else None)
         fr, ids, tlwh, cls, score = pack_tracks(ref)
         counts = np.array([-1 if d is None else len(d) for d in dets], np.int32)
         flat = np.concatenate([d for d in dets if d is not None], 0).astype(np.float32)

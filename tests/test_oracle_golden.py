@@ -40,10 +40,12 @@ def test_kalman_np_matches_reference_golden(kal, kind):
             np.testing.assert_allclose(f.gating_distance(mean[i], cov[i], z, True), kal[kind + "_gate2"][i], rtol=1e-9)
 
 
-@pytest.mark.parametrize("name", util.TRACKER_CASES)
+@pytest.mark.parametrize("name", util.TRACKER_CASES + util.ORACLE_ONLY_CASES)
 def test_tracker_np_matches_reference_golden(name):
     trk, fmt, dets, want = util.load_tracker_case(name)
-    got = tracker_np.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name))
+    from yolov7_tracker_amd import synth
+    got = tracker_np.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name),
+                         feature_fn=synth.make_features if trk == "deepsort" else None)
     util.assert_same_tracks(got, want, name)
 
 

@@ -75,6 +75,23 @@ def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=
     return out
 
 
+_FEAT_DIM = 128
+
+
+def make_features(boxes, seed=0):
+    """Deterministic stand-in for a ReID embedding at DeepSORT's `get_feature(tlbrs, ori_img)` seam (tracker/deepsort.py:19-41; no
+    ReID checkpoint ships with the reference, weights/ckpt.t7): a fixed random projection of what stays constant for an object in
+    these scenes -- its box width and height -- through a few non-linear terms to a unit vector of dimension 128, float32.
+    boxes: (N, >=4) [x1, y1, x2, y2, ...]."""
+    boxes = np.asarray(boxes, dtype=np.float32).reshape(len(boxes), -1)
+    rng = np.random.default_rng(BASE_SEED + 1000 + seed)
+    proj = rng.normal(0, 1, (6, _FEAT_DIM)).astype(np.float32)
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    code = np.stack([w / 32.0, h / 32.0, np.sqrt(np.maximum(w * h, 0)) / 32.0, w / np.maximum(h, 1.0), np.sin(w / 7.0), np.cos(h / 9.0)], 1).astype(np.float32)
+    f = code @ proj
+    return (f / np.maximum(np.linalg.norm(f, axis=1, keepdims=True), 1e-12)).astype(np.float32)
+
+
 def make_ground_truth(n_frames=100, n_obj=80, size=1280, seq_idx=0, **kw):
     """ground truth of the sequence make_detections(...) observes: per frame float64 (n, 7) `[id, x, y, w, h, cls, detected]`"""
     gt = []
