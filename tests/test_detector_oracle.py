@@ -93,3 +93,44 @@ def test_oracle_equals_live_reference_model(have_reference):
         br = np.concatenate([mods[k].conv.bias.detach().numpy() for k in keys], 0)
         np.testing.assert_allclose(W, Wr, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(b, br, rtol=1e-5, atol=1e-6)
+
+
+def test_weight_panel_packings_are_permutations_with_the_documented_layout():
+    """CPU: the two panel orders of detector/weights.py (korder 2: LDS-patch kernel; korder 3: 1x1 layers of the generic kernel)
+    are pure permutations of the [Cout_pad][K] block, and element (tile, K-step, row, slot) is where the kernels' DMA expects it:
+    slot s of row r holds channel octet s ^ ((r >> 2) & 3) of the step's 32 channels"""
+    import numpy as np
+    from yolov7_tracker_amd.detector import weights
+    rng = np.random.default_rng(0)
+    for cout_pad, cin in ((128, 64), (192, 128), (64, 192)):
+        blk = rng.permutation(cout_pad * 9 * cin).astype(np.float64).reshape(cout_pad, 9 * cin)
+        out = weights.panel_pack(blk, cin)
+        assert out.shape == blk.shape and np.array_equal(np.sort(out.ravel()), np.sort(blk.ravel()))
+        BN, nc32 = (128 if cout_pad % 128 == 0 else 64), cin // 32
+        flat = out.ravel()
+        for tile, c, tap, r, s in ((0, 0, 0, 0, 0), (cout_pad // BN - 1, nc32 - 1, 8, BN - 1, 3), (0, 1, 4, 37, 2), (0, nc32 - 1, 7, 21, 1)):
+            o = ((((tile * nc32 + c) * 9 + tap) * BN + r) * 4 + s) * 8
+            k = tap * cin + c * 32 + (s ^ ((r >> 2) & 3)) * 8
+            assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
+    for cout_pad, K in ((128, 256), (192, 128), (64, 1024)):
+        blk = rng.permutation(cout_pad * K).astype(np.float64).reshape(cout_pad, K)
+        out = weights.panel_pack_linear(blk)
+        assert np.array_equal(np.sort(out.ravel()), np.sort(blk.ravel()))
+        BN, nk = (128 if cout_pad % 128 == 0 else 64), K // 32
+        flat = out.ravel()
+        for tile, st, r, s in ((0, 0, 0, 0), (cout_pad // BN - 1, nk - 1, BN - 1, 3), (0, 2, 37, 2)):
+            o = (((tile * nk + st) * BN + r) * 4 + s) * 8
+            k = st * 32 + (s ^ ((r >> 2) & 3)) * 8
+            assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
+
+
+def test_patch_eligibility_rule():
+    """the Python mirror of the dispatcher's rule for the LDS-patch kernel (detector/graph.py::patch_eligible)"""
+    from yolov7_tracker_amd.detector import graph
+    ok = lambda H, W, ci, co, B, **kw: graph.patch_eligible(H, W, ci, co, kw.get("k", 3), kw.get("s", 1), kw.get("p", 1), co, 0, 0, B)
+    assert ok(80, 80, 256, 256, 32) and ok(320, 320, 64, 64, 32) and ok(40, 40, 384, 384, 32) and ok(20, 20, 512, 1024, 32)
+    assert not ok(20, 20, 512, 512, 32)                # 32 * 400 pixels * 4 channel tiles: below 256 workgroups' worth of 256-pixel tiles
+    assert not ok(80, 80, 256, 256, 1)                 # batch 1: too few workgroups, the split-K generic kernel is used
+    assert not ok(80, 80, 256, 256, 32, s=2) and not ok(80, 80, 256, 256, 32, k=1, p=0)
+    assert not ok(80, 80, 96, 256, 32)                 # Cin % 64
+    assert not ok(24, 24, 256, 256, 64)                # 24x24: 16x16 tiles 56 %, 32x8 tiles 75 %, no strip tiling for this width
