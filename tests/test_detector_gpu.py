@@ -252,3 +252,22 @@ def test_decode_nms_matches_oracle():
         boxes = (cbox[b, :n] + ccls[b, :n, None] * np.float32(4096)).astype(np.float32)[order]
         k = cnative.nms(boxes, cscore[b, :n][order], 0.45)[:300]
         np.testing.assert_array_equal(order[k], keep[b, :nd[b]])
+
+
+def test_attempt_load_state_dict_checkpoint(tmp_path):
+    """attempt_load (models/experimental.py:83-106 seam) on a state-dict checkpoint with reference-style parameter names
+    ({'model': state_dict} as the reference's training code saves, plus a bare state dict): same network, bit for bit"""
+    from yolov7_tracker_amd.detector import attempt_load
+    ref = build("yolov7-tiny", 80, (128, 128), 1, seed=3)
+    img = torch.rand((1, 3, 128, 128), generator=torch.Generator().manual_seed(4))
+    want = [t.clone() for t in ref(img)[0].raw()]
+    for name, payload in (("wrapped.pt", {"model": ref._sd, "epoch": 7}), ("bare.pt", dict(ref._sd))):
+        path = str(tmp_path / name)
+        torch.save(payload, path)
+        det = attempt_load(path, cfg="yolov7-tiny", nc=80, img_size=128)
+        got = det(img)[0].raw()
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), name
+    with pytest.raises(ValueError):
+        attempt_load(str(tmp_path / "bare.pt"), img_size=128)          # a bare state dict needs the architecture
+    with pytest.raises(FileNotFoundError):
+        attempt_load(str(tmp_path / "missing.pt"), cfg="yolov7-tiny")
