@@ -100,3 +100,25 @@ def test_hostsim_empty_and_ragged_frames():
     assert [r[0] for r in out] == [1]
     out = trk.update(np.zeros((0, 6), np.float32))
     assert out == []
+
+
+@pytest.mark.parametrize("kind,fmt", [("sort", "default"), ("bytetrack", "default"), ("bytetrack", "strongsort"), ("botsort", "botsort")])
+def test_hostsim_tracker_equals_oracle_on_random_scenes(kind, fmt):
+    """many short seeded scenes of random density (5..120 objects), miss / clutter rates, frame gaps and camera warps: the device
+    program (host build) and the numpy oracle -- itself pinned to the reference -- must agree on every id, in every frame"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    rng = np.random.default_rng(hash((kind, fmt)) % 2**32)
+    for scene in range(12):
+        n_obj = int(rng.integers(5, 120))
+        n_frames = int(rng.integers(15, 40))
+        dets = synth.make_detections(n_frames, n_obj, 640, seq_idx=100 + scene, miss=float(rng.uniform(0.0, 0.3)), fp=float(rng.uniform(0.0, 0.2)))
+        gap = int(rng.integers(0, 9))
+        if gap > 2:
+            dets = [None if (i % gap == gap - 1) else d for i, d in enumerate(dets)]
+        if scene % 4 == 3:
+            dets[n_frames // 2] = np.zeros((0, 6), np.float32)          # an empty frame in the middle
+        warps = synth.make_warps(n_frames, seq_idx=scene) if kind == "botsort" else None
+        want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
+        got = hs.run(kind, dets, kalman_format=fmt, warps=warps)
+        util.assert_same_tracks(got, want, "%s/%s scene %d (%d objects, %d frames, gap %d)" % (kind, fmt, scene, n_obj, n_frames, gap))

@@ -272,3 +272,25 @@ def test_kalman_batch_500_tracks_roundtrip_properties(L):
     np.testing.assert_allclose(mp, m0, rtol=1e-13)
     np.testing.assert_allclose(cp, c0, rtol=1e-12, atol=1e-12)
     assert np.abs(cp - cp.transpose(0, 2, 1)).max() < 1e-9
+
+
+@pytest.mark.parametrize("kind,fmt", [("sort", "default"), ("bytetrack", "default"), ("botsort", "botsort")])
+def test_fused_tracker_equals_oracle_on_random_scenes(kind, fmt):
+    """seeded scenes of random density, miss / clutter rates, frame gaps, empty frames and camera warps: the device step and the
+    numpy oracle (pinned to the reference) agree on every id in every frame"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    rng = np.random.default_rng(hash((kind, fmt)) % 2**32)
+    for scene in range(6):
+        n_obj = int(rng.integers(5, 150))
+        n_frames = int(rng.integers(15, 40))
+        dets = synth.make_detections(n_frames, n_obj, 640, seq_idx=200 + scene, miss=float(rng.uniform(0.0, 0.3)), fp=float(rng.uniform(0.0, 0.2)))
+        gap = int(rng.integers(0, 9))
+        if gap > 2:
+            dets = [None if (i % gap == gap - 1) else d for i, d in enumerate(dets)]
+        if scene % 3 == 2:
+            dets[n_frames // 2] = np.zeros((0, 6), np.float32)
+        warps = synth.make_warps(n_frames, seq_idx=scene) if kind == "botsort" else None
+        want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
+        got, _ = run_device_tracker(kind, fmt, dets, warps=warps)
+        util.assert_same_tracks(got, want, "%s scene %d (%d objects, %d frames, gap %d)" % (kind, scene, n_obj, n_frames, gap))
