@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--img", type=int, default=1280)
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_latency_mode", action="store_true")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
@@ -62,27 +63,14 @@ def make_opts():
 
 
 def plant_objectness_bias(det, frames, target=2000):
-    """shift the Detect objectness biases so that ~`target` anchors per frame exceed conf_thres=0.01"""
-    out = det(frames[:1])[0]
-    torch.cuda.synchronize()
-    p = det.plan
-    no, na = p.det["no"], p.det["na"]
-    logits = torch.cat([det.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) for l in range(len(p.heads))])
-    q = torch.quantile(logits.float().cpu(), 1.0 - target / logits.numel()).item()
-    shift = float(np.log(0.01 / 0.99)) - q
-    for w in p.wlayout:
-        if w["kind"] != "conv":
-            for a in range(na):
-                p.b_dev[w["b_off"] + a * no + 4] += shift
-            # class logits: make the best class pass too (conf = obj * cls must exceed 0.01)
-            for a in range(na):
-                p.b_dev[w["b_off"] + a * no + 5: w["b_off"] + (a + 1) * no] += 4.0
-    return shift
+    """~`target` anchors per frame above conf_thres = 0.01 (state dict and device blob both updated)"""
+    return det.plant_objectness_bias(frames, target)
 
 
-def cpu_baseline(args, det, frames_host, dets_seq):
+def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=None):
     """the oracle (CPU restatement of the reference path, kind='port') timed on this host's cores on a bounded sample:
-    `cpu_frames` frames through the torch-fp32 detector + NMS oracle, 100 frames through the numpy ByteTrack oracle."""
+    `cpu_frames` frames through the torch-fp32 detector + NMS oracle, 100 frames through the numpy ByteTrack oracle.
+    The oracle's output for frame 0 is also the checker of the timed GPU run: -> (cpu_baseline dict, parity dict)."""
     from oracle import detector_torch as dt, tracker_np
     ncores = min(os.cpu_count(), 32)      # torch's CPU conv stops scaling (and thrashes) beyond a few dozen threads
     torch.set_num_threads(ncores)
@@ -91,8 +79,24 @@ def cpu_baseline(args, det, frames_host, dets_seq):
     sd = {k: v for k, v in det._sd.items()}
     t0 = time.perf_counter()
     for _ in range(args.cpu_frames):
-        dec, _ = dt.forward(det.nodes, sd, img, det.spec["anchors"])
+        dec, raw_ref = dt.forward(det.nodes, sd, img, det.spec["anchors"])
     t_det = (time.perf_counter() - t0) / args.cpu_frames
+    parity = None
+    if gpu_heads0 is not None:      # the heads the timed launch list left for frame 0 vs the fp32 oracle's (same weights, same frame)
+        rel = [float((a - b).abs().mean() / b.std()) for a, b in zip(gpu_heads0, raw_ref)]
+        parity = {"checker": "oracle/detector_torch.py fp32 forward of frame 0 (same seeded weights)",
+                  "heads_mean_abs_err_over_logit_std": [round(r, 5) for r in rel]}
+        if gpu_dets0 is not None:
+            ref = dt.non_max_suppression(dec, 0.01, 0.45)[0]
+            rb = dt.scale_coords_round((args.img, args.img), ref[:, :4], (args.img, args.img))
+            d = gpu_dets0
+            used, m = torch.zeros(len(d), dtype=torch.bool), 0
+            for row, box in zip(ref, rb):
+                ok = (~used) & (d[:, 5] == row[5]) & ((d[:, :4] - box).abs().max(1).values <= 1.0)
+                if ok.any():
+                    used[int(torch.nonzero(ok)[0])] = True
+                    m += 1
+            parity.update({"boxes_oracle": int(len(ref)), "boxes_device": int(len(d)), "boxes_matched_same_class_within_1px": m})
     # NMS load comparable to the GPU run: plant ~2000 candidates
     dec = dec.clone()
     dec[..., 4] = 0.0
@@ -107,10 +111,46 @@ def cpu_baseline(args, det, frames_host, dets_seq):
     tracker_np.run("bytetrack", dets_seq[:n])
     t_trk = (time.perf_counter() - t0) / n
     fps = 1.0 / (t_det + t_nms + t_trk)
-    return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "%d frames 1280x1280 through the torch-fp32 detector oracle (%.2f s/frame, %d threads) + 1 NMS call on 2000 "
                       "candidates (%.1f ms) + %d frames through the numpy ByteTrack oracle (%.2f ms/frame, 1 thread)"
-                      % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}
+                      % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}, parity
+
+
+def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10):
+    """Reference `Timer` semantics (tracker/track.py:140-181, tracker/timer.py): batch 1, wall time from "frame tensor on the HOST" (the
+    loader's float32 RGB CHW tensor, tracker_dataloader.py:83-88) to "track list produced" (tracker.update returned, rows copied back,
+    device idle), one frame at a time, H2D copy inside the timer.  Also with the raw uint8 frame as the host input (device pre-processing).
+    -> dict for the JSON line."""
+    from yolov7_tracker_amd.detector import arch, model
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    H = W = args.img
+    det1 = model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=1, seed=0)
+    nf = min(8, len(frames_host))
+    u8 = [torch.from_numpy(frames_host[i]).pin_memory() for i in range(nf)]
+    f32 = [(torch.from_numpy(np.ascontiguousarray(frames_host[i][:, :, ::-1].transpose(2, 0, 1))).float() / 255.0).pin_memory() for i in range(nf)]
+    det1.plant_objectness_bias(u8[0][None].cuda())
+    res = {}
+    count0 = BaseTrack._count
+    for mode, src in (("f32_chw_host", f32), ("u8_hwc_host", u8)):
+        trk = ByteTrack(make_opts(), frame_rate=30)
+        tot = 0.0
+        for i in range(n_warm + n_timed):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()                                   # timer.tic()
+            out = det1(src[i % nf][None].cuda(non_blocking=True))[0]    # model(img.to(device))
+            det1.postprocess(out, 0.01, 0.45, None)                     # non_max_suppression + scale_coords + round
+            cur = trk.update(dets_seq[i], None)                         # tracker.update: rows come back to the host (syncs)
+            _ = [c.tlwh for c in cur]
+            torch.cuda.synchronize()
+            if i >= n_warm:
+                tot += time.perf_counter() - t0                         # timer.toc()
+        res[mode] = {"fps": round(n_timed / tot, 1), "ms_per_frame": round(tot / n_timed * 1e3, 3)}
+    BaseTrack._count = count0
+    res["note"] = ("batch 1, reference Timer semantics: host frame in -> track list out, H2D inside the timer, device sync every frame; "
+                   "%d timed frames after %d warm-up" % (n_timed, n_warm))
+    return res
 
 
 def frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, results):
@@ -283,7 +323,8 @@ def main():
     seq = 0 if args.mode == "frames" else rank                                # single-stream mode: every rank sees the same sequence
     frames_host = synth.make_frames(B, args.n_obj, H, seq_idx=seq)           # B distinct frames, reused every step
     frames = torch.from_numpy(frames_host).cuda()
-    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=seq)   # the scene's detections, frame by frame
+    n_frames *= 2 if (world == 1 and args.mode == "sequences" and args.halves == 1) else 1   # second pass: the same pipeline fed from host memory
+    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=seq, bounce=True)   # the scene's detections, frame by frame
     dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
     plant_objectness_bias(det, frames)
 
@@ -329,11 +370,13 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    sA, sB, sC = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    ev_staged = [torch.cuda.Event() for _ in range(K + Wm)]
-    ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
-    ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
-    ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(K + Wm)]
+    sA, sB, sC, sH = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    NS = 2 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory
+    ev_staged = [torch.cuda.Event() for _ in range(NS)]
+    ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+    ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+    ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+    ev_h2d = [torch.cuda.Event() for _ in range(NS)]
 
     graph = None
     if args.hipgraph == 1:
@@ -343,11 +386,10 @@ def main():
     # ops of the launch list that run on the 640^2 / 320^2 maps: memory-bound; the previous batch's decode+NMS (memory-bound too)
     # is held back until the forward is past them (an event recorded between two pieces of the list)
     k_mid = next((i for i, op in enumerate(det.plan.ops) if int(op["H"]) <= H // 8), 0)
-    ev_mid = [torch.cuda.Event() for _ in range(K + Wm)]
+    ev_mid = [torch.cuda.Event() for _ in range(NS)]
     pending = []          # (step, staged heads) whose decode+NMS and tracker steps are not enqueued yet
     fwd_graphs = fwd_out = None
     if args.hipgraph == 2:    # the same launch list, captured in two pieces around the gate event
-        from yolov7_tracker_amd import _lib
         with torch.cuda.stream(sA):
             fwd_out = det.forward(frames)            # warm-up: plan selection, kernel attributes
             torch.cuda.synchronize()
@@ -357,6 +399,7 @@ def main():
             with torch.cuda.graph(g2, stream=sA):
                 det.forward_part(None, k_mid, -1)
         fwd_graphs = (g1, g2)
+    host_feed = None      # pass 1: (pinned host batch, two device batches)
 
     def finish(prev, gate):
         """decode + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
@@ -385,15 +428,25 @@ def main():
                 for i in range(B):
                     trk._launch(dets_dev[s * B + i], out=results[s * B + i])
             return
+        src = frames
+        if host_feed is not None:              # this batch comes over PCIe: copy on its own stream into the buffer the forward two steps back used
+            src = host_feed[1][s % 2]
+            with torch.cuda.stream(sH):
+                if s >= 2:
+                    sH.wait_event(ev_fwd1[s - 2])
+                src.copy_(host_feed[0], non_blocking=True)
+                ev_h2d[s].record(sH)
         with torch.cuda.stream(sA):
+            if host_feed is not None:
+                sA.wait_event(ev_h2d[s])
             ev_fwd0[s].record(sA)
-            if fwd_graphs is not None:
+            if fwd_graphs is not None and host_feed is None:
                 fwd_graphs[0].replay()
                 ev_mid[s].record(sA)
                 fwd_graphs[1].replay()
                 out = fwd_out
             else:
-                out = det.forward(frames, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)))
+                out = det.forward(src, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)))
             ev_fwd1[s].record(sA)
         if pending:                            # the previous batch: decode+NMS starts once this forward has left the big maps
             finish(pending.pop(), ev_mid[s])
@@ -414,16 +467,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(Wm):
-        step(s)
-    flush()
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(Wm, Wm + K):
-        step(s)
-    flush()
-    barrier()
-    dt_s = time.perf_counter() - t0
+    def timed_pass(first):
+        for s in range(first, first + Wm):
+            step(s)
+        flush()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(first + Wm, first + Wm + K):
+            step(s)
+        flush()
+        barrier()
+        return time.perf_counter() - t0
+
+    dt_s = timed_pass(0)
+    dt_h2d = None
+    second_pass = n_frames == 2 * (K + Wm) * B and graph is None
+    if second_pass:       # PCIe-inclusive rate: never `value`, reported beside it
+        host_feed = (torch.from_numpy(frames_host).pin_memory(), [torch.empty_like(frames), torch.empty_like(frames)])
+        dt_h2d = timed_pass(K + Wm)
+        host_feed = None
     if dist is not None:
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -462,8 +524,8 @@ def main():
             "metric": "end-to-end fps (detect+track) YOLOv7-w6@1280 ByteTrack", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack, 1 synthetic VisDrone-shape sequence per GPU, ~%d dets/frame"
-                                   % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
+            "config": {"workload": "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack, 1 synthetic VisDrone-shape sequence per GPU, %d objects per frame "
+                                   "(10 %% missed, 5 %% false positives, reflected at the border)" % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
                        "parallelism": "sequence-sharded x%d" % world, "collective_backend": backend if world > 1 else None,
                        "result_gather": gathered_info if world > 1 else None},
@@ -481,8 +543,28 @@ def main():
                                    "note": "decode_nms = end of this batch's forward -> end of its NMS on stream C: it is held back until the NEXT forward has left "
                                            "the memory-bound 640^2/320^2 layers, then overlaps the rest of that forward (latency, not cost)"},
         }
-        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed on rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(args, det, frames_host, dets_seq)
+        timed = range(Wm * B, (Wm + K) * B)
+        line["config"]["dets_per_frame_timed_mean"] = round(float(np.mean([len(dets_seq[t]) for t in timed])), 2)
+        line["config"]["tracks_per_frame_timed_mean"] = round(float(np.mean([int(results[t, trk.cap_t].cpu().numpy().view(np.int32)[0]) for t in list(timed)[::8]])), 2)
+        if dt_h2d is not None:
+            line["fps_incl_h2d"] = {"value": round(K * B / dt_h2d, 2), "ms_per_step": round(dt_h2d / K * 1e3, 3),
+                                    "note": "same pipeline, every batch copied from pinned host memory (uint8 BGR, %.1f MB per frame) on a copy "
+                                            "stream, double-buffered; never `value`" % (H * W * 3 / 1e6)}
+        if world == 1:
+            hist = {}
+            for nme in det.launch_list(B):
+                hist[nme] = hist.get(nme, 0) + 1
+            line["config"]["launch_list"] = hist
+            with torch.cuda.stream(sA):
+                out0 = det.forward(frames)                       # the launch_list probe re-ran ops out of context: redo frame 0..B-1 cleanly
+                d0, n0 = det.postprocess(out0, 0.01, 0.45, None)
+            torch.cuda.synchronize()
+            heads0 = [r[:1].cpu() for r in out0.raw()]
+            dets0 = d0[0, :int(n0[0])].cpu()
+            if not args.no_latency_mode:
+                line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq)
+            if not args.no_cpu_baseline:                         # the CPU baseline is timed on rank 0 at N=1 only
+                line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -34,6 +34,10 @@ enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1, Y7T_TRACKER_BOTSORT = 2 
 
 const char* y7t_last_error(void);
 int y7t_version(void);
+/* diagnostics: name of the kernel variant the last launch made by this thread selected, e.g. "patch<16,16,128>", "igemm<128,128,32,2> 1x1",
+ * "patch_strip<42,128>" (the conv dispatch rules -- tile shape, LDS-patch vs generic, split-K -- live inside the library and depend on
+ * the batch size; tests and bench.py read the launch list of a plan back through y7t_det_forward_ops(i, i+1) + this) */
+const char* y7t_last_kernel(void);
 /* number of HIP devices visible (0 when there is none); host-synchronous */
 int y7t_device_count(void);
 

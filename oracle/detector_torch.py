@@ -21,7 +21,7 @@ from . import cnative
 BN_EPS = 1e-3
 
 
-def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False):
+def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False, round_out=True):
     if fp16:
         # storage-precision emulation of the HIP path: BN folded into the weights (utils/torch_utils.py:181-201), folded
         # weights rounded to fp16, fp32 accumulate + fp32 bias + activation, result rounded to fp16
@@ -33,7 +33,7 @@ def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False):
             b = (b - sd[key + ".bn.running_mean"].double()) * scale + sd[key + ".bn.bias"].double()
         y = F.conv2d(x, w.half().float(), b.float(), stride=s, padding=p)
         y = F.silu(y) if act == 1 else (F.leaky_relu(y, 0.1) if act == 2 else y)
-        return y.half().float()
+        return y.half().float() if round_out else y      # round_out=False: the exact fp32 value the fp16 store of the HIP path rounds
     w = sd[key + ".conv.weight"].float()
     b = sd.get(key + ".conv.bias")
     y = F.conv2d(x, w, None if b is None else b.float(), stride=s, padding=p)
@@ -84,19 +84,30 @@ def forward(nodes, sd, img, anchors, keep=False, fp16=False):
                 bs, _, ny, nx = x.shape
                 x = x.view(bs, ex["na"], ex["no"], ny, nx).permute(0, 1, 3, 4, 2).contiguous()
                 raw.append(x)
-                yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
-                grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
-                y = x.sigmoid()
-                stride = H / ny
-                y[..., 0:2] = (y[..., 0:2] * 2. - 0.5 + grid) * stride
-                y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * a[l].view(1, ex["na"], 1, 1, 2)
-                z.append(y.view(bs, -1, ex["no"]))
+            z = [decode_level(x, a[l], H / x.shape[2]) for l, x in enumerate(raw)]
             continue
         else:
             raise NotImplementedError(n.kind)
         vals[n.idx] = y
     out = (torch.cat(z, 1), raw)
     return out + (vals,) if keep else out
+
+
+def decode_level(x, anchors_l, stride):
+    """Detect.forward inference branch for one level (models/yolo.py:49-56): x (bs, na, ny, nx, no) raw conv output -> (bs, na*ny*nx, no)"""
+    bs, na, ny, nx, no = x.shape
+    yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()          # _make_grid, yolo.py:59-62
+    y = x.float().sigmoid()
+    y[..., 0:2] = (y[..., 0:2] * 2. - 0.5 + grid) * stride
+    y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * anchors_l.view(1, na, 1, 1, 2)
+    return y.view(bs, -1, no)
+
+
+def decode_heads(raw, anchors, H):
+    """the reference's `model(img)[0]` from the raw Detect conv outputs: cat over levels (yolo.py:57)"""
+    a = torch.tensor(anchors, dtype=torch.float32).view(len(raw), -1, 2)
+    return torch.cat([decode_level(x, a[l], H / x.shape[2]) for l, x in enumerate(raw)], 1)
 
 
 def xywh2xyxy(x):

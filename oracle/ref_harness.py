@@ -247,3 +247,26 @@ def build_reference_model(cfg_rel, nc, ch=3):
     finally:
         os.chdir(cwd)
     return m.eval()
+
+
+@contextlib.contextmanager
+def reference_pickle_context():
+    """While active, the reference's `models.*` / `utils.*` modules are importable by name, so that a reference Model can be pickled with
+    torch.save and unpickled with torch.load exactly like the reference's own checkpoints (models/experimental.py:88-89)."""
+    ns = load_detector()
+    mods = {"models.yolo": ns.yolo, "models.common": ns.common, "utils.general": ns.general, "utils.torch_utils": ns.torch_utils}
+    saved = {k: sys.modules.get(k) for k in list(mods) + ["models", "utils"]}
+    with _patched_modules([REF_ROOT]):
+        try:
+            pkg_m, pkg_u = types.ModuleType("models"), types.ModuleType("utils")
+            pkg_m.__path__, pkg_u.__path__ = [os.path.join(REF_ROOT, "models")], [os.path.join(REF_ROOT, "utils")]
+            pkg_m.yolo, pkg_m.common = ns.yolo, ns.common
+            sys.modules["models"], sys.modules["utils"] = pkg_m, pkg_u
+            sys.modules.update(mods)
+            yield
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v

@@ -50,33 +50,46 @@ def test_track_cli_synthetic(tmp_path, tracker, model, size, frames, objs, batch
     assert float(vals["MOTA"]) > 50 and float(vals["IDF1"]) > 50 and float(vals["HOTA"]) > 40
 
 
-def test_track_cli_image_folder_device_preprocess(tmp_path):
-    """a folder of non-square frames on disk (the reference's 'origin' data format): the loader letterboxes on the host, and with
-    --device_preprocess the raw frame is letterboxed on the GPU; both runs write the same result file (detections that survive
-    rounding differ only where the two bilinear filters do, so compare the tracker input instead of insisting on identical files)."""
+def _rows(txt):
+    return [tuple(l.split(",")[:2]) for l in txt.splitlines()]
+
+
+@pytest.mark.parametrize("shape,resampled", [((360, 640), False), ((540, 960), True)])
+def test_track_cli_image_folder_device_preprocess(tmp_path, shape, resampled):
+    """A folder of non-square frames on disk (the reference's 'origin' data format), the detector's REAL decode+NMS output feeding the
+    tracker: the loader letterboxes on the host (tracker_dataloader.py:100-130), with --device_preprocess the raw frame is letterboxed on
+    the GPU.  360x640 frames need padding only (both paths produce the same pixels): the two result files must be identical.  540x960
+    frames are resampled (the device filter differs from the host's in <1 % of the pixels by one grey level, test_detector_gpu): the
+    tracks must still agree -- same (frame, id) rows on >= 95 % of the rows."""
     from PIL import Image
-    import torch
     from yolov7_tracker_amd.tracker import track, tracker_dataloader
-    from yolov7_tracker_amd.detector import attempt_load
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from oracle import letterbox_np as lb
     seq = tmp_path / "data" / "seqs" / "uav0001"
     seq.mkdir(parents=True)
     rng = np.random.default_rng(0)
-    for i in range(3):
-        small = rng.integers(0, 256, (34, 60, 3)).astype(np.float32)
-        frame = np.kron(small, np.ones((16, 16, 1), np.float32)).astype(np.uint8)[:540, :960]
-        Image.fromarray(frame).save(seq / ("%07d.png" % (i + 1)))
+    small = rng.integers(0, 256, (shape[0] // 16 + 4, shape[1] // 16 + 4, 3)).astype(np.float32)
+    big = np.kron(small, np.ones((16, 16, 1), np.float32)).astype(np.uint8)
+    for i in range(4):                                     # a slowly panning scene
+        Image.fromarray(big[2 * i:2 * i + shape[0], 3 * i:3 * i + shape[1]]).save(seq / ("%07d.png" % (i + 1)))
     cfgs = {'DATASET_ROOT': str(tmp_path / "data"), 'SEQ_SUBDIR': 'seqs', 'CERTAIN_SEQS': [None], 'IGNORE_SEQS': [None],
             'CATEGORY_DICT': {}, 'YAML_DICT': ''}
     outs = []
     for extra in ([], ["--device_preprocess"]):
+        BaseTrack._count = 0
         opts = track.build_parser().parse_args(["--dataset", "visdrone", "--tracker", "sort", "--model_path", "random:yolov7-tiny", "--nc", "10",
                                                 "--img_size", "640", "--results_root", str(tmp_path / ("res%d" % len(outs)))] + extra)
         folder = track.main(opts, cfgs)
         outs.append(open(os.path.join(folder, "uav0001.txt")).read())
-    # the device letterbox of a frame equals the oracle letterbox (checked tightly in test_detector_gpu); here: geometry agrees with the loader
     loader = tracker_dataloader.TrackerLoader(str(seq), 640, model_stride=32)
     img, ori = loader[0]
     ref = lb.letterbox(ori.numpy(), new_shape=(640, 640), stride=32)
-    assert tuple(img.shape[1:]) == ref.shape[:2] == (384, 640)
-    assert isinstance(outs[0], str) and isinstance(outs[1], str)
+    assert tuple(img.shape[1:]) == ref.shape[:2] == (384, 640)          # auto=True: padded to the stride multiple only
+    host, dev = _rows(outs[0]), _rows(outs[1])
+    assert len(host) >= 20 and len(dev) >= 20, (len(host), len(dev))       # the tracker really was fed detections
+    if not resampled:
+        assert outs[0] == outs[1]
+    else:
+        common = len(set(host) & set(dev))
+        print("device-preprocess vs host-loader: %d / %d rows with the same (frame, id)" % (common, len(host)))
+        assert common >= 0.95 * max(len(host), len(dev))

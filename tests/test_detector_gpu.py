@@ -220,7 +220,8 @@ def test_decode_nms_matches_oracle():
     dets, nd = det.postprocess(out, 0.01, 0.45, ori_shapes=[(200, 300), (256, 320)])
     torch.cuda.synchronize()
     det.check_overflow()
-    dec = out.decoded().cpu()
+    dec = dt.decode_heads([r.cpu() for r in out.raw()], det.spec["anchors"], 256)      # the ORACLE's Detect decode of the planted logits
+    assert torch.allclose(out.decoded().cpu(), dec, rtol=1e-5, atol=1e-4)               # the product's convenience view agrees with it
     ref = dt.non_max_suppression(dec, 0.01, 0.45)
     nd = nd.cpu().numpy()
     for b, shp in enumerate([(200, 300), (256, 320)]):

@@ -95,6 +95,58 @@ def test_oracle_equals_live_reference_model(have_reference):
         np.testing.assert_allclose(b, br, rtol=1e-5, atol=1e-6)
 
 
+def test_load_checkpoint_pickled_reference_model_with_autoanchor_buffers(have_reference, tmp_path):
+    """attempt_load's host half on what the reference's training code saves: a PICKLED Model under 'model' (models/experimental.py:88-89),
+    whose Detect anchor buffers were rewritten the way train.py's autoanchor does (utils/autoanchor.py:40-60: anchor_grid in pixels,
+    anchors in stride units, model.yaml untouched).  The loaded spec must decode with the BUFFERS, and the oracle walk over the loaded
+    graph + state dict must reproduce the reference model's own forward."""
+    if not have_reference:
+        pytest.skip("/root/reference not present")
+    from oracle import ref_harness
+    from yolov7_tracker_amd.detector import load_checkpoint
+    m = ref_harness.build_reference_model("cfg/deploy/yolov7-tiny.yaml", 80)
+    g = torch.Generator().manual_seed(5)
+    for mod in m.modules():                                   # non-trivial BN statistics so the fold is exercised
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    det = m.model[-1]
+    scale = torch.tensor([1.3, 0.8]).view(1, 1, 2)
+    new_px = (det.anchors * det.stride.view(-1, 1, 1) * scale).round()
+    det.anchors[:] = new_px / det.stride.view(-1, 1, 1)
+    det.anchor_grid[:] = new_px.view(det.nl, 1, -1, 1, 1, 2)
+    assert m.yaml["anchors"] == arch.TINY_ANCHORS                      # the yaml still says the old anchors
+    img = torch.rand((1, 3, 64, 96), generator=g)
+    with torch.no_grad():
+        want = m(img)[0]
+    path = str(tmp_path / "best.pt")
+    with ref_harness.reference_pickle_context():
+        torch.save({"model": m, "epoch": 12, "optimizer": None}, path)
+        spec, sd, _ = load_checkpoint(path)
+    assert spec["anchors"] == [[float(v) for v in lvl.reshape(-1)] for lvl in new_px] != arch.TINY_ANCHORS
+    assert spec["nc"] == 80 and len(spec["layers"]) == len(arch.yolov7_tiny(80)["layers"])
+    nodes, _ = graph.parse(spec)
+    dec, _ = dt.forward(nodes, sd, img, spec["anchors"])
+    assert torch.allclose(dec, want, rtol=1e-5, atol=1e-5)
+    # a state-dict checkpoint that only carries `anchors` (stride units), with a yaml that gives an anchor COUNT (`anchors: 3`)
+    sd2 = {k: v for k, v in sd.items() if not k.endswith("anchor_grid")}
+    torch.save({"model": sd2}, str(tmp_path / "sd.pt"))
+    import yaml as _yaml
+    y = dict(m.yaml, anchors=3)
+    cfg = str(tmp_path / "m.yaml")
+    _yaml.safe_dump(y, open(cfg, "w"))
+    spec2, _, _ = load_checkpoint(str(tmp_path / "sd.pt"), cfg=cfg)
+    assert spec2["anchors"] == spec["anchors"]
+    with pytest.raises(ValueError):
+        load_checkpoint(_strip_anchor_buffers(sd2, tmp_path), cfg=cfg)
+
+
+def _strip_anchor_buffers(sd, tmp_path):
+    p = str(tmp_path / "noanchors.pt")
+    torch.save({k: v for k, v in sd.items() if not k.endswith(".anchors")}, p)
+    return p
+
+
 def test_weight_panel_packings_are_permutations_with_the_documented_layout():
     """CPU: the two panel orders of detector/weights.py (korder 2: LDS-patch kernel; korder 3: 1x1 layers of the generic kernel)
     are pure permutations of the [Cout_pad][K] block, and element (tile, K-step, row, slot) is where the kernels' DMA expects it:

@@ -125,6 +125,55 @@ def test_batched_step_equals_single_trackers(L):
             assert c[s] == len(single[s][f])
 
 
+def test_batched_step_with_one_shared_id_counter(L):
+    """BaseTrack._count is ONE counter for every tracker of the process (basetrack.py:22,43-46).  8 trackers stepped concurrently by
+    y7t_tracker_step_batch on the same counter: no id is handed out twice or skipped, every tracker's ids of one frame are a
+    consecutive block (the frame's activate() calls in order), and the counter ends at the number of tracks ever created."""
+    from yolov7_tracker_amd import _lib, synth
+    nseq, nfr, cap = 8, 20, 256
+    seqs = [synth.make_detections(nfr, 60, seq_idx=40 + s) for s in range(nseq)]
+    nbytes = int(L.y7t_tracker_state_bytes(cap, cap))
+    idc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nseq)]
+    for s in range(nseq):
+        _lib.check(L.y7t_tracker_init(_lib.ptr(st[s]), nbytes, 1, 0, cap, cap, 0.2, 0.5, 30, 1, _lib.ptr(idc), _lib.stream_ptr()))
+    outs = torch.zeros((nseq, cap + 1, 8), dtype=torch.float64, device="cuda")
+    state_ptrs = torch.tensor([t.data_ptr() for t in st], dtype=torch.int64, device="cuda")
+    out_ptrs = torch.tensor([outs[s].data_ptr() for s in range(nseq)], dtype=torch.int64, device="cuda")
+    counts = torch.zeros(nseq, dtype=torch.int32, device="cuda")
+    lay_n = L.y7t_tracker_layout(cap, cap, None, 0)
+    import ctypes
+    offs = (ctypes.c_int64 * lay_n)()
+    L.y7t_tracker_layout(cap, cap, offs, lay_n)
+    lay = {L.y7t_tracker_field_name(i).decode(): int(offs[i]) for i in range(lay_n)}
+    seen, n_new = {}, 0
+    for f in range(nfr):
+        before = int(idc.item())
+        dd = [torch.from_numpy(seqs[s][f]).cuda() for s in range(nseq)]
+        det_ptrs = torch.tensor([d.data_ptr() for d in dd], dtype=torch.int64, device="cuda")
+        n_dev = torch.tensor([d.shape[0] for d in dd], dtype=torch.int32, device="cuda")
+        _lib.check(L.y7t_tracker_step_batch(_lib.ptr(state_ptrs), _lib.ptr(det_ptrs), _lib.ptr(n_dev), _lib.ptr(out_ptrs), _lib.ptr(counts), cap,
+                                            nseq, 0, None, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        after = int(idc.item())
+        spans = []
+        for s in range(nseq):
+            raw = st[s].cpu().numpy()
+            tid = raw[lay["tid"]:lay["tid"] + 4 * cap].view(np.int32)
+            start = raw[lay["start"]:lay["start"] + 4 * cap].view(np.int32)
+            mine = sorted(int(t) for t, sf in zip(tid, start) if t > before and sf == f + 1)   # born this frame, still in the pool
+            for t in mine:
+                assert before < t <= after and t not in seen, "id %d handed out twice / out of range" % t
+                seen[t] = s
+            if mine:
+                spans.append((mine[0], mine[-1], s))
+        spans.sort()
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] < b[0], "id blocks of trackers %d and %d interleave: %r %r" % (a[2], b[2], a, b)   # one block per tracker and frame
+        n_new += after - before
+    assert int(idc.item()) == n_new >= len(seen) > nseq * 40
+
+
 def test_empty_and_ragged_frames():
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack

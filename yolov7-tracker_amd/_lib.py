@@ -15,6 +15,7 @@ c_void_p, c_int, c_double, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ct
 SIGNATURES = {
     "y7t_last_error": (ctypes.c_char_p, []),
     "y7t_version": (c_int, []),
+    "y7t_last_kernel": (ctypes.c_char_p, []),
     "y7t_device_count": (c_int, []),
     "y7t_iou_cost_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "y7t_kf_initiate_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -6,6 +6,7 @@
 #include "../../include/y7t.h"
 
 void y7t_set_error(const char* fmt, ...);
+void y7t_note_kernel(const char* fmt, ...);   // see y7t_last_kernel()
 
 #define Y7T_HIP_CHECK(expr)                                                                 \
     do {                                                                                    \

@@ -401,6 +401,7 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
     Y7T_LAUNCH_CHECK();
+    y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "");
     if (b.splitk > 1) {
         const long long tot = (long long)a.M * (a.Cout_pad / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 2048) blocks = 2048;

@@ -607,6 +607,7 @@ int launch_patch_mt(const Y7TConvArgs& a, hipStream_t s) {
     const int ptiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     hipLaunchKernelGGL((k_conv3x3_patch_mt<TW, TH, MT>), dim3(((ptiles + MT - 1) / MT) * (a.Cout_pad / 64)), dim3(256), lds, s, a);
     Y7T_LAUNCH_CHECK();
+    y7t_note_kernel("patch_mt<%d,%d,%d>", TW, TH, MT);
     return 0;
 }
 
@@ -622,6 +623,8 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     const int tiles = ptiles * (a.Cout_pad / BN);
     hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
+    if (C::FLAT) y7t_note_kernel("patch_strip<%d,%d>", C::PW, BN);
+    else y7t_note_kernel("patch<%d,%d,%d>", TW, TH, BN);
     return 0;
 }
 

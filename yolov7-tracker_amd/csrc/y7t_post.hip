@@ -171,6 +171,7 @@ int y7t_upsample_launch(const half_t* in, int ldin, int cin_off, int B, int H, i
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_upsample2x, dim3(blocks), dim3(256), 0, s, in, ldin, cin_off, B, H, W, C, out, ldout, cout_off);
     Y7T_LAUNCH_CHECK();
+    y7t_note_kernel("upsample2x");
     return 0;
 }
 
@@ -182,6 +183,7 @@ int y7t_maxpool_launch(const half_t* in, int ldin, int cin_off, int B, int H, in
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_maxpool, dim3(blocks), dim3(256), 0, s, in, ldin, cin_off, B, H, W, C, k, st, pd, out, ldout, cout_off, Ho, Wo);
     Y7T_LAUNCH_CHECK();
+    y7t_note_kernel("maxpool<%d,%d>", k, st);
     return 0;
 }
 

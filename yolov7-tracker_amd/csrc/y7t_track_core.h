@@ -59,9 +59,15 @@ Y7T_FN void y7t_sync(const Y7TExec&) {
 #if Y7T_DEVICE
 #define Y7T_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define Y7T_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define Y7T_FETCH_ADD(p, v) atomicAdd((p), (v))
 #else
+#define Y7T_FETCH_ADD(p, v) y7t_fetch_add_host((p), (v))
 #define Y7T_ATOMIC_MAX(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
 #define Y7T_ATOMIC_ADD(p, v) (*(p) += (v))
+#endif
+
+#if !Y7T_DEVICE
+static inline int y7t_fetch_add_host(int* p, int v) { const int o = *p; *p += v; return o; }
 #endif
 
 Y7T_FN bool y7t_lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }

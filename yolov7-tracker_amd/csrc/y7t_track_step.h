@@ -517,14 +517,18 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
         const int n_new = y7t_compact(ex, n_left, [&](int j) { return (any_left || s.ycol[j] < 0) && dets[6 * (size_t)s.left[j] + 4] > new_gate; }, s.tmpa, 0);
         int* idc = (int*)(uintptr_t)h->id_counter_ptr;
         if (ex.tid == 0) {
-            int nf = h->n_free, base = h->n_act_last, made = 0;
-            for (int k = 0; k < n_new; ++k) {
-                if (nf <= 0) { h->status |= Y7T_ERR_CAP_T; break; }
+            int nf = h->n_free;
+            const int base = h->n_act_last, made = n_new < nf ? n_new : nf;
+            if (n_new > nf) h->status |= Y7T_ERR_CAP_T;
+            // BaseTrack.next_id (basetrack.py:43-46): the counter is shared by every tracker of the process and y7t_tracker_step_batch
+            // steps several trackers concurrently, so the frame's ids are reserved with ONE atomic add -- consecutive inside a
+            // tracker (== the reference's order of activate() calls), never duplicated or lost across trackers
+            const int id0 = made > 0 ? Y7T_FETCH_ADD(idc, made) : 0;
+            for (int k = 0; k < made; ++k) {
                 const int sl = s.freel[--nf];
                 s.tmpb[k] = sl;
-                s.tid[sl] = ++(*idc);
+                s.tid[sl] = id0 + 1 + k;
                 s.actl[base + k] = sl;
-                ++made;
             }
             h->n_free = nf;
             h->n_act_last = base + made;

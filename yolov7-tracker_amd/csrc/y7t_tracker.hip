@@ -18,6 +18,16 @@ void y7t_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* y7t_last_error(void) { return g_err; }
+// diagnostics: name of the kernel the last launch helper of this thread chose (conv dispatch rules live on the host side of the
+// library, so "which kernel runs this layer at this batch" is a property tests and bench.py can read back)
+static thread_local char g_kernel[128] = "";
+void y7t_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* y7t_last_kernel(void) { return g_kernel; }
 extern "C" int y7t_version(void) { return 100; }
 extern "C" int y7t_device_count(void) {
     int n = 0;

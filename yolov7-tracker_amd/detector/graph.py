@@ -298,6 +298,10 @@ def lower(nodes, H, W, max_batch=1):
                 fn = Node("conv", n.src, a.c + b.c, 1, 1, 0, n.act)
                 fn.h, fn.w = n.h, n.w
                 emit_conv(fn, nodes[n.src[0]], a.home, a.ld, a.coff, 0, a.c + b.c, n.act, (a.wkey, b.wkey))
+                for t in (a, b):      # either twin may also sit in a second concat: its copy follows the fused launch
+                    for cidx, off in pending_copies.pop(t.idx, []):
+                        c = nodes[cidx]
+                        emit_simple(2, t, t, 1, 1, 0, out=(c.home, c.ld, off))
             else:
                 emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
         elif n.kind == "up":

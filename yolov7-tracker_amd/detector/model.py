@@ -100,6 +100,11 @@ class Detector:
                 raise ValueError("input %dx%d is not a multiple of the max stride %d" % (hw[0], hw[1], s))
             nodes, _ = graph.parse(self.spec)
             plan = graph.lower(nodes, hw[0], hw[1], self.max_batch)
+            big = max(e * isz for e, isz in plan.buf_elems) * self.max_batch
+            if big >= 1 << 31:      # the conv kernels address a tensor through 32-bit buffer offsets (csrc/y7t_conv.hip)
+                raise ValueError("max_batch=%d at %dx%d: the largest activation tensor would be %.1f GiB (limit 2 GiB per tensor); "
+                                 "split the batch (max_batch <= %d)" % (self.max_batch, hw[0], hw[1], big / 2 ** 30,
+                                                                         (1 << 31) // (big // self.max_batch + 1)))
             if self._sd is None:
                 self._sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, self._seed), seed=self._seed)
             wb, bb = weights.pack(plan.wlayout, self._sd, plan.w_elems, plan.b_elems)
@@ -190,6 +195,45 @@ class Detector:
             _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
             self._part_B = B
         _lib.check(self._L.y7t_det_forward_ops(p.handle, self._part_B, int(first), int(last), s))
+
+    def plant_objectness_bias(self, frames, target=2000):
+        """No trained checkpoint ships with the reference, and a randomly initialised Detect head fires on ~half of the 102 000
+        anchors.  SURVEY.md 8d: shift the Detect objectness biases so that ~`target` anchors of frames[0] exceed conf_thres = 0.01 (a
+        typical VisDrone candidate load) and raise the class logits so the best class passes too.  Updates the state dict AND the
+        device bias blob, so an oracle run on `self._sd` sees the same network.  -> the objectness shift."""
+        out = self(frames[:1])[0]
+        torch.cuda.synchronize()
+        p = self.plan
+        no, na = p.det["no"], p.det["na"]
+        logits = torch.cat([self.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) for l in range(len(p.heads))])
+        q = torch.quantile(logits.float().cpu(), 1.0 - target / logits.numel()).item()
+        shift = float(np.log(0.01 / 0.99)) - q
+        self._sd = dict(self._sd)
+        for pl in self._plans.values():
+            for w in pl.wlayout:
+                if w["kind"] == "conv":
+                    continue
+                delta = torch.zeros(na * no)
+                for a in range(na):
+                    delta[a * no + 4] = shift
+                    delta[a * no + 5:(a + 1) * no] = 4.0
+                if pl is p:
+                    self._sd[w["wkey"] + ".bias"] = self._sd[w["wkey"] + ".bias"].float() + delta
+                pl.b_dev[w["b_off"]:w["b_off"] + na * no] += delta.cuda()
+        return shift
+
+    def launch_list(self, B=None):
+        """Kernel variant of every op of the current plan at batch B (default: max_batch), in launch order: runs the ops one by one on
+        whatever the arena holds and reads y7t_last_kernel() back.  The dispatch rules (LDS-patch / strip / multi-tile / 256-pixel
+        tiles / split-K) depend on B, so this is how tests and bench.py state WHICH launch list they ran."""
+        p, s = self.plan, _lib.stream_ptr()
+        B = self.max_batch if B is None else int(B)
+        names = []
+        for i in range(int(self._L.y7t_det_num_ops(p.handle))):
+            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, i, i + 1, s))
+            names.append(self._L.y7t_last_kernel().decode())
+        torch.cuda.synchronize()
+        return names
 
     @staticmethod
     def letterbox_params(shape, new_shape, stride, auto=True, scaleup=True):
@@ -348,11 +392,28 @@ def _plan_raw_boxes(self, b, n):
 Detector.plan_raw_boxes = _plan_raw_boxes
 
 
-def attempt_load(weights_path, map_location=None, cfg=None, nc=None, img_size=1280, max_batch=1):
-    """models/experimental.py:83-106 seam.  `weights_path`: a .pt holding a state dict / {'model': state_dict} /
-    (when the reference's classes are importable) a pickled reference Model; or 'random:<arch>[:seed]' for seeded
-    random weights of a named architecture (no trained checkpoint ships with the reference).  Never touches the
-    network (the reference's attempt_download would)."""
+def checkpoint_anchors(sd, spec):
+    """Anchors the checkpoint's Detect module decodes with (models/yolo.py:54,100: `self.anchor_grid`), in pixels per level, or None.
+    train.py's autoanchor (utils/autoanchor.py:40-60) and check_anchor_order rewrite these BUFFERS without touching model.yaml, so a
+    trained checkpoint's buffers win over the yaml.  `model.N.anchor_grid` (nl,1,na,1,1,2) is in pixels; a checkpoint that only carries
+    `model.N.anchors` (nl,na,2) holds them divided by the level's stride (yolo.py:229-231)."""
+    grid = next((k for k in sd if k.endswith(".anchor_grid")), None)
+    if grid is not None:
+        a = sd[grid].detach().float().cpu().reshape(sd[grid].shape[0], -1)
+        return [[float(v) for v in lvl] for lvl in a]
+    anc = next((k for k in sd if k.endswith(".anchors") and sd[k].dim() == 3), None)
+    if anc is not None:
+        a = sd[anc].detach().float().cpu()
+        probe = dict(spec, anchors=[[0.0] * (2 * a.shape[1])] * a.shape[0])
+        strides = [h["stride"] for h in graph.lower(graph.parse(probe)[0], 256, 256, 1).heads]
+        return [[float(v) * st for v in lvl.reshape(-1)] for lvl, st in zip(a, strides)]
+    return None
+
+
+def load_checkpoint(weights_path, cfg=None, nc=None):
+    """Host half of attempt_load (models/experimental.py:83-106): -> (spec, state dict or None, seed).  `weights_path`: a .pt holding a
+    state dict / {'model': state_dict} / a pickled reference Model (its classes must be importable, as in the reference's own
+    `torch.load`; `ema` preferred like experimental.py:88-89), or 'random:<arch>[:seed]'."""
     if isinstance(weights_path, (list, tuple)):
         weights_path = weights_path[0]
     sd, seed = None, 0
@@ -360,23 +421,44 @@ def attempt_load(weights_path, map_location=None, cfg=None, nc=None, img_size=12
         parts = str(weights_path).split(":")
         name = parts[1]
         seed = int(parts[2]) if len(parts) > 2 else 0
-        spec = arch.ARCHS[name](nc if nc is not None else 80)
+        return arch.ARCHS[name](nc if nc is not None else 80), None, seed
+    if not os.path.isfile(weights_path):
+        raise FileNotFoundError(weights_path)
+    ck = torch.load(weights_path, map_location="cpu", weights_only=False)
+    m = (ck.get("ema") or ck.get("model")) if isinstance(ck, dict) and ("model" in ck or "ema" in ck) else ck
+    if hasattr(m, "state_dict"):
+        sd = {k: v.float() for k, v in m.float().state_dict().items()}
+        spec_yaml = getattr(m, "yaml", None)
     else:
-        if not os.path.isfile(weights_path):
-            raise FileNotFoundError(weights_path)
-        ck = torch.load(weights_path, map_location="cpu", weights_only=False)
-        m = ck.get("ema") or ck.get("model") if isinstance(ck, dict) and ("model" in ck or "ema" in ck) else ck
-        if hasattr(m, "state_dict"):
-            sd = {k: v.float() for k, v in m.float().state_dict().items()}
-            spec_yaml = getattr(m, "yaml", None)
-        else:
-            sd, spec_yaml = {k: v.float() for k, v in m.items()}, None
-        if cfg is not None:
-            spec = arch.load_yaml(cfg, nc) if os.path.isfile(str(cfg)) else arch.ARCHS[cfg](nc if nc is not None else 80)
-        elif spec_yaml is not None:
-            spec = {"nc": spec_yaml["nc"], "depth_multiple": spec_yaml.get("depth_multiple", 1.0), "width_multiple": spec_yaml.get("width_multiple", 1.0),
-                    "anchors": spec_yaml["anchors"], "layers": list(spec_yaml["backbone"]) + list(spec_yaml["head"])}
-        else:
-            raise ValueError("a state-dict checkpoint needs cfg=<yaml path or arch name>")
+        sd, spec_yaml = {k: v.float() for k, v in m.items()}, None
+    if cfg is not None:
+        spec = arch.load_yaml(cfg, nc) if os.path.isfile(str(cfg)) else arch.ARCHS[cfg](nc if nc is not None else 80)
+    elif spec_yaml is not None:
+        spec = {"nc": spec_yaml["nc"], "depth_multiple": spec_yaml.get("depth_multiple", 1.0), "width_multiple": spec_yaml.get("width_multiple", 1.0),
+                "anchors": spec_yaml["anchors"], "layers": list(spec_yaml["backbone"]) + list(spec_yaml["head"])}
+    else:
+        raise ValueError("a state-dict checkpoint needs cfg=<yaml path or arch name>")
+    spec = dict(spec)
+    if isinstance(spec["anchors"], int):          # `anchors: 3` = "let autoanchor decide" (models/yolo.py:449): only the buffers know
+        na = spec["anchors"]
+        nl = next((sd[k].shape[0] for k in sd if k.endswith(".anchors") and sd[k].dim() == 3), None)
+        if nl is None:
+            raise ValueError("the model yaml gives only an anchor COUNT and the checkpoint has no Detect anchor buffers")
+        spec["anchors"] = [[0.0] * (2 * na)] * nl
+    a = checkpoint_anchors(sd, spec)
+    if a is not None:
+        spec["anchors"] = a
+    elif any(v == 0 for lvl in spec["anchors"] for v in lvl):
+        raise ValueError("no anchors: the yaml has a count only and the checkpoint carries none")
+    return spec, sd, seed
+
+
+def attempt_load(weights_path, map_location=None, cfg=None, nc=None, img_size=1280, max_batch=1):
+    """models/experimental.py:83-106 seam.  `weights_path`: a .pt holding a state dict / {'model': state_dict} /
+    (when the reference's classes are importable) a pickled reference Model; or 'random:<arch>[:seed]' for seeded
+    random weights of a named architecture (no trained checkpoint ships with the reference).  Never touches the
+    network (the reference's attempt_download would).  Decode anchors: the checkpoint's Detect buffers when present
+    (`checkpoint_anchors`), else the yaml's."""
+    spec, sd, seed = load_checkpoint(weights_path, cfg, nc)
     size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
     return Detector(spec, sd, img_size=size, max_batch=max_batch, seed=seed)

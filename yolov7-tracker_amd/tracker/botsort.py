@@ -29,9 +29,17 @@ class BoTSORT(BaseTracker):
         self.theta_iou, self.theta_emb = 0.5, 0.25
         self._warp = torch.zeros(6, dtype=torch.float64, device="cuda")
 
+    _warned = False
+
     def update(self, det_results, ori_img=None, warp=None):
         if warp is None and self.use_GMC and self.gmc is not None:
             warp = self.gmc(ori_img, det_results)
+        if warp is None and self.use_GMC and not BoTSORT._warned:
+            import warnings
+            warnings.warn("BoTSORT: use_GMC is set but no camera-motion matrix was supplied (update(..., warp=H) or tracker.gmc = callable): "
+                          "the reference estimates one per frame with OpenCV (botsort.py:13-248, out of scope here); running WITHOUT "
+                          "compensation, results on moving-camera footage will differ from the reference", RuntimeWarning)
+            BoTSORT._warned = True
         w = None
         if warp is not None and self.use_GMC:
             self._warp.copy_(torch.as_tensor(np.ascontiguousarray(warp, dtype=np.float64).reshape(6)), non_blocking=True)

@@ -1,9 +1,11 @@
 """Per-sequence frame source with the reference's contract (/root/reference/tracker/tracker_dataloader.py:20-134):
 `__getitem__ -> (img (3,h',w') float32 RGB /255 letterboxed, ori_img (H,W,3) uint8 BGR)`.
 
-cv2 is not part of this environment, so files are decoded with PIL and the letterbox resize is PIL's bilinear filter
-(the reference: cv2.INTER_LINEAR -- same kernel, not bit-identical at the edges).  Native-size frames (the synthetic
-1280x1280 sequences of BASELINE configs) need neither resize nor padding and go through unchanged.
+cv2 is not part of this environment, so files are decoded with PIL and the letterbox resize is a numpy two-tap bilinear filter
+with cv2.INTER_LINEAR's geometry (half-pixel centres, edge-clamped taps, NO anti-aliasing when shrinking -- PIL's BILINEAR
+widens its support there and is a different filter); the same arithmetic as the device kernel k_letterbox_layout, so
+--device_preprocess and the host loader feed the network the same pixels.  Native-size frames (the synthetic 1280x1280
+sequences of BASELINE configs) need neither resize nor padding and go through unchanged.
 `SyntheticLoader` serves the seeded synthetic sequences (yolov7_tracker_amd.synth) without touching the disk."""
 import os
 
@@ -26,14 +28,31 @@ def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scale
     dw /= 2
     dh /= 2
     if shape[::-1] != new_unpad:
-        from PIL import Image
-        img = np.asarray(Image.fromarray(img).resize(new_unpad, Image.BILINEAR))
+        img = _resize_linear(img, new_unpad[1], new_unpad[0])
     top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
     left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
     out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, 3), np.uint8)
     out[...] = np.asarray(color, np.uint8)
     out[top:top + img.shape[0], left:left + img.shape[1]] = img
     return out, (r, r), (dw, dh)
+
+
+def _resize_linear(img, new_h, new_w):
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_LINEAR) geometry in float32: source coordinate (d + 0.5) * scale - 0.5,
+    taps clamped to the image, result rounded to uint8 (OpenCV's 8-bit path uses 11-bit fixed-point weights: +-1 grey level on ties)"""
+    h0, w0 = img.shape[:2]
+    one, half = np.float32(1), np.float32(0.5)
+    sy = (np.arange(new_h, dtype=np.float32) + half) * np.float32(np.float32(h0) / np.float32(new_h)) - half
+    sx = (np.arange(new_w, dtype=np.float32) + half) * np.float32(np.float32(w0) / np.float32(new_w)) - half
+    iy, ix = np.floor(sy).astype(np.int64), np.floor(sx).astype(np.int64)
+    ay = (sy - iy.astype(np.float32)).reshape(-1, 1, 1)
+    ax = (sx - ix.astype(np.float32)).reshape(1, -1, 1)
+    iy1, ix1 = np.clip(iy + 1, 0, h0 - 1), np.clip(ix + 1, 0, w0 - 1)
+    iy, ix = np.clip(iy, 0, h0 - 1), np.clip(ix, 0, w0 - 1)
+    src = img.astype(np.float32)
+    top = (one - ax) * src[iy][:, ix] + ax * src[iy][:, ix1]
+    bot = (one - ax) * src[iy1][:, ix] + ax * src[iy1][:, ix1]
+    return np.rint((one - ay) * top + ay * bot).astype(np.uint8)
 
 
 class TrackerLoader(torch.utils.data.Dataset):
