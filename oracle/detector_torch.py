@@ -47,6 +47,18 @@ def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False, round_out=True):
     return y
 
 
+def conv_abs_sum(x, sd, key, s, p):
+    """sum_k |w_k x_k| + |b| per output of the BN-folded fp16-weight conv `key` (pre-activation): the scale of the forward error bound of
+    its fp32 accumulation, |fl(sum) - sum| <= c u sum|w_k x_k| (Higham, Accuracy and Stability of Numerical Algorithms, section 4.2)"""
+    w = sd[key + ".conv.weight"].double()
+    b = sd[key + ".conv.bias"].double() if key + ".conv.bias" in sd else torch.zeros(w.shape[0], dtype=torch.float64)
+    if key + ".bn.weight" in sd:
+        scale = sd[key + ".bn.weight"].double() / torch.sqrt(sd[key + ".bn.running_var"].double() + BN_EPS)
+        w = w * scale[:, None, None, None]
+        b = (b - sd[key + ".bn.running_mean"].double()) * scale + sd[key + ".bn.bias"].double()
+    return F.conv2d(x.abs(), w.half().float().abs(), b.float().abs(), stride=s, padding=p)
+
+
 @torch.no_grad()
 def forward(nodes, sd, img, anchors, keep=False, fp16=False):
     """img (B,3,H,W) float32 -> (decoded (B,A,no), raw list of (B,na,ny,nx,no), {node idx: tensor} if keep).

@@ -6,8 +6,17 @@ default), i.e. the launch list bench.py times: LDS-patch / multi-tile / strip ke
       fp16 weights, fp32 accumulate -- /root/reference/models/common.py:99-111, utils/torch_utils.py:181-201) and compares with the op's
       actual output slice at the LAYER tolerance (rtol 6e-4 / atol 3e-4: half an fp16 ulp + summation order); pools, upsamples and
       concat copies must be bit-exact.  No chaos argument: every op is judged on identical inputs.
-  (b) raw Detect heads end to end (image -> 4 head tensors) against the oracle at storage precision and at fp32.
-  (c) image -> boxes: decode + NMS + scale_coords + round of the fp16 network against the fp32 oracle's, SURVEY.md 8a's box-level bar.
+      The tolerance is a forward error bound, not a fudge: |got - ref| <= half an fp16 ulp of the result (rtol 6e-4 / atol 3e-4 covers it)
+      + 2 sqrt(K) u32 * sum_k |w_k x_k| for the fp32 accumulation of K terms in another order (u32 = 2^-24; the probabilistic forward
+      error bound -- the worst-case one has K in place of 2 sqrt(K) -- matters only where the seeded network's activations are large).
+  (b) raw Detect heads end to end (image -> 4 head tensors) against the fp32 oracle.
+  (c) image -> boxes: decode + NMS + scale_coords + round of the fp16 network against the fp32 oracle's, at SURVEY.md 8a's box-level
+      bar (same count, same class, |dcoord| <= 1 px after round, |dconf| <= 5e-3).
+  (b) and (c) need a network that does not amplify rounding noise.  iid zero-mean random weights + BatchNorm sit on the chaotic side of
+  the order/chaos transition (relative perturbation x ~1.1 per SiLU layer, x ~300 over w6's depth: measured 3-7 % of the logit spread
+  at this size, test (b0) below keeps that as a loose sanity bound); BatchNorm shifts of ~ +2 (weights.random_state_dict bn_bias_mean)
+  put the SiLUs in their near-linear region, the growth factor drops to ~1.0 and the random network is as well-conditioned as a
+  trained one.  Same kernels, same launch list -- only the numbers in the weight blob differ.
 """
 import collections
 
@@ -31,6 +40,31 @@ def bench_det():
     frames = torch.from_numpy(frames_host).cuda()
     det.plant_objectness_bias(frames)                                    # as bench.py does
     out = det(frames)[0]                                                 # y7t_input_layout + y7t_det_forward: the timed launch list
+    torch.cuda.synchronize()
+    return det, frames_host, out
+
+
+@pytest.fixture(scope="module")
+def smooth_det():
+    """the same launch list on well-conditioned weights (BatchNorm shifts ~ +2, statistics calibrated on frame 0 of the scene) with a
+    VisDrone-like head: width/height logits damped (boxes of roughly anchor size, 40-120 px) and the candidates planted on the fine levels"""
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.detector import arch, graph, model, weights
+    spec = arch.ARCHS["yolov7-w6"](10)
+    frames_host = synth.make_frames(B_BENCH, 80, 1280, seq_idx=0)
+    cal = torch.from_numpy(frames_host[:1][..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0
+    nodes, _ = graph.parse(spec)
+    plan = graph.lower(graph.parse(spec)[0], 1280, 1280, 1)
+    sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0, bn_bias_mean=2.0), seed=0, image=cal)
+    for k in list(sd):
+        if ".m." in k and k.endswith(".weight"):                 # Detect 1x1 convs: rows (anchor, [x, y, w, h, obj, cls...])
+            w = sd[k].clone().view(3, 15, -1)
+            w[:, 2:4] *= 0.25
+            sd[k] = w.view(45, -1, 1, 1)
+    det = model.Detector(spec, sd, img_size=(1280, 1280), max_batch=B_BENCH)
+    frames = torch.from_numpy(frames_host).cuda()
+    det.plant_objectness_bias(frames, level_offsets=(0, 0, -3, -6))
+    out = det(frames)[0]
     torch.cuda.synchronize()
     return det, frames_host, out
 
@@ -83,18 +117,20 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             if wl["kind"] == "conv":
                 keys = wl["wkey"] if isinstance(wl["wkey"], tuple) else (wl["wkey"],)
                 ref = torch.cat([dt._conv_bn_act(x, sd, key, k, s_, pd, wl["act"], fp16=True, round_out=False) for key in keys], 1)
+                absum = torch.cat([dt.conv_abs_sum(x, sd, key, s_, pd) for key in keys], 1)      # sum_k |w_k x_k| (+ |b|) per output
                 got = _slice(det, int(op["out_buf"]), int(op["out_ld"]), int(op["out_coff"]), int(op["Cout"]), int(op["Ho"]), int(op["Wo"]), fr)
                 got = got.float().cpu()
             else:                                                   # Detect 1x1 (models/yolo.py:46): fp16 weights, fp32 bias, fp32 output
                 ref = F.conv2d(x, sd[wl["wkey"] + ".weight"].half().float(), sd[wl["wkey"] + ".bias"].float())
+                absum = F.conv2d(x.abs(), sd[wl["wkey"] + ".weight"].half().float().abs(), sd[wl["wkey"] + ".bias"].float().abs())
                 got = det.head_tensor(wl["level"], B_BENCH)[fr].cpu()
-            ref = ref.permute(0, 2, 3, 1)
+            ref, absum = ref.permute(0, 2, 3, 1), absum.permute(0, 2, 3, 1)
             err = (got - ref).abs()
-            tol = 3e-4 + 6e-4 * ref.abs()
+            tol = 3e-4 + 6e-4 * ref.abs() + 2 * float(Cin * k * k) ** 0.5 * 2.0 ** -24 * absum      # |SiLU'| <= 1.1: the pre-activation bound carries over
             bad = err > tol
-            assert not bool(bad.any()), "op %d %s (%s, %dx%d %d->%d k%d s%d): %d values off, max err %.3e" % (
-                oi, names[oi], wl["wkey"], H, W, Cin, int(op["Cout"]), k, s_, int(bad.sum()), float(err.max()))
-            worst[names[oi]] = max(worst[names[oi]], float((err / (3e-4 + ref.abs())).max()))
+            assert not bool(bad.any()), "op %d %s (%s, %dx%d %d->%d k%d s%d): %d values off, worst err/tol %.2f" % (
+                oi, names[oi], wl["wkey"], H, W, Cin, int(op["Cout"]), k, s_, int(bad.sum()), float((err / tol).max()))
+            worst[names[oi]] = max(worst[names[oi]], float((err / tol).max()))
             n_conv += 1
         else:
             if int(op["type"]) == 1:
@@ -105,59 +141,73 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             assert torch.equal(got, ref.permute(0, 2, 3, 1)), "op %d %s" % (oi, names[oi])
             n_other += 1
     assert ci == len(p.wlayout) and n_conv >= 96 and n_other >= 6
-    print("per-op worst |err| / (3e-4 + |ref|) by kernel:", {k: "%.2e" % v for k, v in sorted(worst.items())})
+    print("per-op worst err / tol by kernel:", {k: "%.2e" % v for k, v in sorted(worst.items())})
 
 
-def test_heads_end_to_end_against_oracle(bench_det):
-    """image -> raw Detect outputs for two frames.  Against the oracle at storage precision only the summation order differs (rare one-ulp
-    fp16 flips that ~60 layers of a random-weight network amplify); against fp32 the fp16 storage itself (2^-11 per tensor) adds."""
+def _imgs(frames_host, fr):
+    return torch.from_numpy(frames_host[fr][..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0      # tracker_dataloader.py:83-88
+
+
+def test_heads_end_to_end_chaotic_weights_sanity(bench_det):
+    """(b0) iid random weights: image -> raw Detect outputs of two frames vs the fp32 oracle.  Loose by nature (see the module docstring);
+    the same numbers go into bench.py's JSON line (`parity`)."""
     from oracle import detector_torch as dt
     det, frames_host, out = bench_det
     fr = [0, 31]
-    img = torch.from_numpy(frames_host[fr][..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0
     raw = [r[fr].cpu() for r in out.raw()]
-    _, ref32 = dt.forward(det.nodes, det._sd, img, det.spec["anchors"])
-    _, ref16 = dt.forward(det.nodes, det._sd, img, det.spec["anchors"], fp16=True)
-    for l, (a, b, q) in enumerate(zip(raw, ref32, ref16)):
-        scale = b.std().item()
-        e16, e32 = (a - q).abs(), (a - b).abs()
-        print("level %d  vs fp16-storage oracle mean/max %.3e %.3e   vs fp32 oracle mean/max %.3e %.3e   (logit std %.2f)" % (
-            l, e16.mean().item(), e16.max().item(), e32.mean().item(), e32.max().item(), scale))
-        assert e16.mean().item() < 0.03 * scale and e16.max().item() < 0.5 * scale, l
-        assert e32.mean().item() < 0.06 * scale and e32.max().item() < 1.0 * scale, l
+    _, ref32 = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
+    for l, (a, b) in enumerate(zip(raw, ref32)):
+        scale, e32 = b.std().item(), (a - b).abs()
+        print("chaotic weights, level %d: mean/max |err| = %.3e %.3e (logit std %.2f)" % (l, e32.mean().item(), e32.max().item(), scale))
+        assert e32.mean().item() < 0.12 * scale and torch.isfinite(a).all(), l
 
 
-def test_boxes_end_to_end_against_fp32_oracle(bench_det):
-    """image -> (n, 6) rows [x1, y1, x2, y2, conf, cls]: device decode + NMS + scale_coords + round on the fp16 network's heads vs
-    oracle/detector_torch (fp32 network, utils/general.py:607-695 NMS, general.py:319-340, track.py:240) on the same frames."""
+def test_heads_end_to_end_against_fp32_oracle(smooth_det):
+    """(b) well-conditioned weights: the raw head values of two full-size frames against the fp32 oracle's: mean |err| below 0.4 % of the
+    logit spread (fp16 storage of ~60 tensors in a row without amplification: sqrt(60) * 2^-11 / sqrt(3) = 0.2 %), no value off by more
+    than 4 %."""
     from oracle import detector_torch as dt
-    det, frames_host, out = bench_det
+    det, frames_host, out = smooth_det
+    fr = [0, 31]
+    raw = [r[fr].cpu() for r in out.raw()]
+    _, ref32 = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
+    for l, (a, b) in enumerate(zip(raw, ref32)):
+        scale, e32 = b.std().item(), (a - b).abs()
+        print("level %d: mean/max |err| = %.3e %.3e (logit std %.2f)" % (l, e32.mean().item(), e32.max().item(), scale))
+        assert 0.2 < scale < 20, (l, scale)                        # calibrated: logits O(1), the sigmoid is not saturated
+        assert e32.mean().item() < 4e-3 * scale and e32.max().item() < 4e-2 * scale, l
+
+
+def test_boxes_end_to_end_against_fp32_oracle(smooth_det):
+    """(c) image -> (n, 6) rows [x1, y1, x2, y2, conf, cls]: device decode + NMS + scale_coords + round on the fp16 network's heads vs
+    oracle/detector_torch (fp32 network, utils/general.py:607-695 NMS, general.py:319-340, track.py:240) on the same frames, at the
+    bar SURVEY.md 8a states: same count, same class, |dcoord| <= 1 px after .round(), |dconf| <= 5e-3, matched one to one as SETS (the
+    scores of the 300 survivors of ~2000 candidates are spaced closer than the fp16 noise, so rank order is not comparable).  At most
+    3 % of the boxes may fail to find their partner: greedy-NMS decisions and the 300-cut flip where two scores tie within that noise."""
+    from oracle import detector_torch as dt
+    det, frames_host, out = smooth_det
     fr = [0, 31]
     dets, nd = det.postprocess(out, 0.01, 0.45, None)
     torch.cuda.synchronize()
     det.check_overflow()
-    img = torch.from_numpy(frames_host[fr][..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0
-    dec, _ = dt.forward(det.nodes, det._sd, img, det.spec["anchors"])
+    assert 1000 < int(det.plan.cand[fr].min()) and int(det.plan.cand[fr].max()) < 8000          # a VisDrone-like candidate load
+    dec, _ = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
     ref = dt.non_max_suppression(dec, 0.01, 0.45)
-    stats = []
     for i, b in enumerate(fr):
         d = dets[b, :int(nd[b])].cpu()
         r = ref[i].clone()
         r[:, :4] = dt.scale_coords_round((1280, 1280), r[:, :4], (1280, 1280))
-        assert len(r) > 50 and len(d) > 50
-        # greedy one-to-one matching in the oracle's score order: same class, all four corners within 1 px
+        assert len(r) >= 100 and len(d) == len(r), (len(d), len(r))
         used = torch.zeros(len(d), dtype=torch.bool)
-        matched, dconf = 0, []
+        matched, dconf, dcoord = 0, 0.0, 0.0
         for row in r:
-            ok = (~used) & (d[:, 5] == row[5]) & ((d[:, :4] - row[:4]).abs().max(1).values <= 1.0)
+            ok = (~used) & (d[:, 5] == row[5]) & ((d[:, :4] - row[:4]).abs().max(1).values <= 1.0) & ((d[:, 4] - row[4]).abs() <= 5e-3)
             if ok.any():
                 j = int(torch.nonzero(ok)[0])
                 used[j] = True
                 matched += 1
-                dconf.append(abs(float(d[j, 4] - row[4])))
-        stats.append((len(r), len(d), matched, float(np.max(dconf)) if dconf else 0.0, float(np.mean(dconf)) if dconf else 0.0))
-    print("boxes (oracle n, device n, matched <=1px same class, max |dconf|, mean |dconf|):", stats)
-    for n_ref, n_dev, matched, dc_max, dc_mean in stats:
-        assert abs(n_ref - n_dev) <= 0.02 * n_ref + 1
-        assert matched >= 0.9 * n_ref
-        assert dc_mean <= 5e-3
+                dconf, dcoord = max(dconf, abs(float(d[j, 4] - row[4]))), max(dcoord, float((d[j, :4] - row[:4]).abs().max()))
+        size = (r[:, 2:4] - r[:, :2]).max(1).values
+        print("frame %d: %d boxes (sides %.0f..%.0f px, %d classes), %d matched at the 8a bar, max |dconf| %.2e, max |dcoord| %.0f px" % (
+            b, len(r), float(size.min()), float(size.max()), len(torch.unique(r[:, 5])), matched, dconf, dcoord))
+        assert matched >= 0.97 * len(r)

@@ -73,7 +73,7 @@ class HeadOutput:
 class Detector:
     """spec: arch dict; state_dict: reference-style names (see detector/weights.py)."""
 
-    def __init__(self, spec, state_dict=None, img_size=(1280, 1280), max_batch=1, max_cand=None, seed=0):
+    def __init__(self, spec, state_dict=None, img_size=(1280, 1280), max_batch=1, max_cand=None, seed=0, bn_bias_mean=0.0, calib_image=None):
         _lib.require_gpu()
         self._L = _lib.load()
         self.spec = spec
@@ -82,6 +82,8 @@ class Detector:
         self.max_cand = 0
         self.names = [str(i) for i in range(spec["nc"])]
         self._sd, self._seed = state_dict, seed
+        # seeded random weights only (state_dict None): see weights.random_state_dict / calibrate_bn
+        self._bn_bias_mean, self._calib_image = float(bn_bias_mean), calib_image
         self._plans = {}
         self.plan = None
         self._handle = None
@@ -106,7 +108,8 @@ class Detector:
                                  "split the batch (max_batch <= %d)" % (self.max_batch, hw[0], hw[1], big / 2 ** 30,
                                                                          (1 << 31) // (big // self.max_batch + 1)))
             if self._sd is None:
-                self._sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, self._seed), seed=self._seed)
+                self._sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, self._seed, bn_bias_mean=self._bn_bias_mean),
+                                                seed=self._seed, image=self._calib_image)
             wb, bb = weights.pack(plan.wlayout, self._sd, plan.w_elems, plan.b_elems)
             plan.w_dev = torch.from_numpy(wb.view(np.int16)).cuda()
             plan.b_dev = torch.from_numpy(bb).cuda()
@@ -196,16 +199,18 @@ class Detector:
             self._part_B = B
         _lib.check(self._L.y7t_det_forward_ops(p.handle, self._part_B, int(first), int(last), s))
 
-    def plant_objectness_bias(self, frames, target=2000):
+    def plant_objectness_bias(self, frames, target=2000, level_offsets=None):
         """No trained checkpoint ships with the reference, and a randomly initialised Detect head fires on ~half of the 102 000
         anchors.  SURVEY.md 8d: shift the Detect objectness biases so that ~`target` anchors of frames[0] exceed conf_thres = 0.01 (a
         typical VisDrone candidate load) and raise the class logits so the best class passes too.  Updates the state dict AND the
-        device bias blob, so an oracle run on `self._sd` sees the same network.  -> the objectness shift."""
+        device bias blob, so an oracle run on `self._sd` sees the same network.  level_offsets: extra objectness shift per Detect level
+        (e.g. (0, 0, -3, -6): candidates mostly from the fine levels, the small-object regime of VisDrone).  -> the objectness shift."""
         out = self(frames[:1])[0]
         torch.cuda.synchronize()
         p = self.plan
         no, na = p.det["no"], p.det["na"]
-        logits = torch.cat([self.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) for l in range(len(p.heads))])
+        lo = [0.0] * len(p.heads) if level_offsets is None else [float(v) for v in level_offsets]
+        logits = torch.cat([self.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) + lo[l] for l in range(len(p.heads))])
         q = torch.quantile(logits.float().cpu(), 1.0 - target / logits.numel()).item()
         shift = float(np.log(0.01 / 0.99)) - q
         self._sd = dict(self._sd)
@@ -214,8 +219,10 @@ class Detector:
                 if w["kind"] == "conv":
                     continue
                 delta = torch.zeros(na * no)
+                if w["kind"] != "Detect":
+                    raise NotImplementedError("plant_objectness_bias: plain Detect heads only (implicit layers are folded into the blob)")
                 for a in range(na):
-                    delta[a * no + 4] = shift
+                    delta[a * no + 4] = shift + lo[w["level"]]
                     delta[a * no + 5:(a + 1) * no] = 4.0
                 if pl is p:
                     self._sd[w["wkey"] + ".bias"] = self._sd[w["wkey"] + ".bias"].float() + delta

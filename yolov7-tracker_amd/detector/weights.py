@@ -9,9 +9,16 @@ BN_EPS = 1e-3
 GAIN_SILU, GAIN_LEAKY = 1.75, 1.40   # keep activation std ~O(1) through the depth of w6 / tiny
 
 
-def random_state_dict(wlayout, seed=0, fused=False):
+def random_state_dict(wlayout, seed=0, fused=False, bn_bias_mean=0.0):
     """Reference-style state dict ({wkey}.conv.weight / {wkey}.bn.* / model.N.m.L.{weight,bias}) with seeded values that
-    keep activations O(1) through ~100 layers (so that fp16 storage is meaningful)."""
+    keep activations O(1) through ~100 layers (so that fp16 storage is meaningful).
+
+    bn_bias_mean: mean of the BatchNorm shifts beta (default 0: beta ~ N(0, 0.1)).  With beta ~ 0 every SiLU sees zero-mean unit-variance
+    input and the random network sits on the chaotic side of the order/chaos transition: a perturbation grows relative to the signal by
+    sqrt(E[silu'(z)^2] / Var[silu(z)]) = sqrt(0.38 / 0.31) ~ 1.1 per layer, ~300x over w6's depth, so fp16 rounding noise reaches 3-17 % of
+    the head logits' spread.  beta ~ +2 moves the SiLUs into their near-linear region: the factor drops to ~1.0, the network keeps
+    rich iid features with O(1) statistics, and fp16-vs-fp32 differences stay at the 0.2 % level -- the conditioning a trained detector
+    has, which is what an end-to-end comparison against the fp32 oracle needs (tests/test_detector_pinned_gpu.py)."""
     import zlib
     sd = {}
     for w0 in wlayout:
@@ -26,7 +33,7 @@ def random_state_dict(wlayout, seed=0, fused=False):
         gain = {0: 1.0, 1: GAIN_SILU, 2: GAIN_LEAKY}[w.get('act', 1)]
         W = rng.normal(0, gain / np.sqrt(fan_in), (cout, cin, k, k)).astype(np.float32)
         g = rng.uniform(0.7, 1.3, cout).astype(np.float32)
-        b = rng.normal(0, 0.1, cout).astype(np.float32)
+        b = (rng.normal(0, 0.1, cout) + bn_bias_mean).astype(np.float32)
         mu = rng.normal(0, 0.1, cout).astype(np.float32)
         var = rng.uniform(0.8, 1.2, cout).astype(np.float32)
         if fused:
@@ -41,14 +48,14 @@ def random_state_dict(wlayout, seed=0, fused=False):
 
 
 @torch.no_grad()
-def calibrate_bn(nodes, sd, hw=(640, 640), seed=0):
+def calibrate_bn(nodes, sd, hw=(640, 640), seed=0, image=None):
     """Data-dependent initialisation (host, once): set every BatchNorm's running statistics to the batch statistics its
-    conv produces on a random low-resolution image, layer by layer -- what a BN layer converges to in training -- so the
-    randomly initialised network keeps O(1) activations at any depth.  Weight INITIALISATION only; the hot path never
-    runs through torch."""
+    conv produces on a random low-resolution image (or on `image`, a (B,3,H,W) float tensor in [0,1]: statistics of the data the
+    network will see, what a BN layer converges to in training), layer by layer, so the randomly initialised network keeps
+    O(1) activations at any depth.  Weight INITIALISATION only; the hot path never runs through torch."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(seed)
-    vals = {0: torch.rand((1, 3) + tuple(hw), generator=g)}
+    vals = {0: torch.rand((1, 3) + tuple(hw), generator=g) if image is None else image.float()}
     for n in nodes[1:]:
         if n.kind == "detect" or any(j not in vals for j in n.src):
             continue
