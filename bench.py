@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_latency_mode", action="store_true")
+    ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain)")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
@@ -139,7 +140,7 @@ def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10):
         for i in range(n_warm + n_timed):
             torch.cuda.synchronize()
             t0 = time.perf_counter()                                   # timer.tic()
-            out = det1(src[i % nf][None].cuda(non_blocking=True))[0]    # model(img.to(device))
+            out = det1.forward(src[i % nf][None].cuda(non_blocking=True), fuse_decode=0.01)    # model(img.to(device))
             det1.postprocess(out, 0.01, 0.45, None)                     # non_max_suppression + scale_coords + round
             cur = trk.update(dets_seq[i], None)                         # tracker.update: rows come back to the host (syncs)
             _ = [c.tlwh for c in cur]
@@ -370,7 +371,9 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    sA, sB, sC, sH = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    # the forward's stream gets the high hardware priority: its workgroups are dispatched ahead of the NMS / tracker kernels that run beside it
+    sA = torch.cuda.Stream(priority=-1) if args.prio else torch.cuda.Stream()
+    sB, sC, sH = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     NS = 2 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory
     ev_staged = [torch.cuda.Event() for _ in range(NS)]
     ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -378,10 +381,11 @@ def main():
     ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev_h2d = [torch.cuda.Event() for _ in range(NS)]
 
+    CONF = 0.01                 # tracker/track.py:239
     graph = None
     if args.hipgraph == 1:
         with torch.cuda.stream(sA):
-            graph, _, _ = det.capture(frames, 0.01, 0.45, None)
+            graph, _, _ = det.capture(frames, CONF, 0.45, None)
 
     # ops of the launch list that run on the 640^2 / 320^2 maps: memory-bound; the previous batch's decode+NMS (memory-bound too)
     # is held back until the forward is past them (an event recorded between two pieces of the list)
@@ -389,26 +393,28 @@ def main():
     ev_mid = [torch.cuda.Event() for _ in range(NS)]
     pending = []          # (step, staged heads) whose decode+NMS and tracker steps are not enqueued yet
     fwd_graphs = fwd_out = None
-    if args.hipgraph == 2:    # the same launch list, captured in two pieces around the gate event
+    if args.hipgraph == 2:    # the same launch list, captured in two pieces around the gate event, once per candidate set
+        fwd_graphs, fwd_out = [], []
         with torch.cuda.stream(sA):
-            fwd_out = det.forward(frames)            # warm-up: plan selection, kernel attributes
-            torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=sA):
-                det.forward_part(frames, 0, k_mid)
-            with torch.cuda.graph(g2, stream=sA):
-                det.forward_part(None, k_mid, -1)
-        fwd_graphs = (g1, g2)
+            for ps_i in range(2):
+                fwd_out.append(det.forward(frames, fuse_decode=CONF, pset=ps_i))   # warm-up: plan selection, kernel attributes
+                torch.cuda.synchronize()
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=sA):
+                    det.forward_part(frames, 0, k_mid, fuse_decode=CONF, pset=ps_i)
+                with torch.cuda.graph(g2, stream=sA):
+                    det.forward_part(None, k_mid, -1, fuse_decode=CONF, pset=ps_i)
+                fwd_graphs.append((g1, g2))
     host_feed = None      # pass 1: (pinned host batch, two device batches)
 
     def finish(prev, gate):
-        """decode + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
-        ps, staged = prev
+        """rank sort + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
+        ps, out = prev
         with torch.cuda.stream(sC):
             sC.wait_event(ev_staged[ps])
             if gate is not None:
                 sC.wait_event(gate)
-            det.postprocess(staged, 0.01, 0.45, None)
+            det.postprocess(out, CONF, 0.45, None)
             ev_nms[ps].record(sC)
         with torch.cuda.stream(sB):
             sB.wait_event(ev_nms[ps])      # a frame's detections exist before its tracker step runs
@@ -420,7 +426,7 @@ def main():
         if graph is not None:
             with torch.cuda.stream(sA):
                 ev_fwd0[s].record(sA)
-                graph.replay()                 # input layout + conv launches + pools/upsamples + decode/NMS as one hipGraph
+                graph.replay()                 # input layout + conv launches + pools + decode/NMS as one hipGraph
                 ev_fwd1[s].record(sA)
                 ev_nms[s].record(sA)
             with torch.cuda.stream(sB):
@@ -439,23 +445,21 @@ def main():
         with torch.cuda.stream(sA):
             if host_feed is not None:
                 sA.wait_event(ev_h2d[s])
+            if s >= 2:
+                sA.wait_event(ev_nms[s - 2])   # the Detect epilogues of this forward refill candidate set s % 2: its last NMS must be through
             ev_fwd0[s].record(sA)
             if fwd_graphs is not None and host_feed is None:
-                fwd_graphs[0].replay()
+                fwd_graphs[s % 2][0].replay()
                 ev_mid[s].record(sA)
-                fwd_graphs[1].replay()
-                out = fwd_out
+                fwd_graphs[s % 2][1].replay()
+                out = fwd_out[s % 2]
             else:
-                out = det.forward(src, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)))
+                out = det.forward(src, mid_hook=(k_mid, lambda: ev_mid[s].record(sA)), fuse_decode=CONF, pset=s % 2)
             ev_fwd1[s].record(sA)
-        if pending:                            # the previous batch: decode+NMS starts once this forward has left the big maps
+            ev_staged[s].record(sA)            # the candidates of batch s are in set s % 2
+        if pending:                            # the previous batch: NMS starts once this forward has left the big maps
             finish(pending.pop(), ev_mid[s])
-        with torch.cuda.stream(sA):
-            if s > 0:
-                sA.wait_event(ev_nms[s - 1])   # the staging set is free again
-            staged = det.stage_heads(out)      # ~6 MB per frame, device to device
-            ev_staged[s].record(sA)
-        pending.append((s, staged))
+        pending.append((s, out))
 
     def flush():
         while pending:
@@ -536,12 +540,14 @@ def main():
                                                 "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
                          "traffic_note": "HBM bytes per launch list from profiles/r01_conv_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
                                          "algorithmic = 1.217 GB/frame",
-                         "kernel": "k_conv_igemm<BM,BN,BK,NST> + k_conv3x3_patch<TW,TH,BN> (the conv launch list of one forward: 107 convs in 96 launches)",
+                         "kernel": "k_conv_igemm<BM,BN,BK,NST> + k_conv3x3_patch<TW,TH,BN> (the conv launch list of one forward: 107 convs in 96 launches; "
+                                   "nearest-x2 upsamples folded into their consumers' loaders, Detect decode + candidate filter in the Detect convs' epilogues)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3),
-                                   "note": "decode_nms = end of this batch's forward -> end of its NMS on stream C: it is held back until the NEXT forward has left "
-                                           "the memory-bound 640^2/320^2 layers, then overlaps the rest of that forward (latency, not cost)"},
+                                   "note": "decode_nms = end of this batch's forward (its Detect epilogues have already decoded + filtered) -> end of its rank sort + "
+                                           "NMS on stream C: held back until the NEXT forward has left the memory-bound 640^2/320^2 layers, then overlaps the "
+                                           "rest of that forward (latency, not cost)"},
         }
         timed = range(Wm * B, (Wm + K) * B)
         line["config"]["dets_per_frame_timed_mean"] = round(float(np.mean([len(dets_seq[t]) for t in timed])), 2)
@@ -556,8 +562,8 @@ def main():
                 hist[nme] = hist.get(nme, 0) + 1
             line["config"]["launch_list"] = hist
             with torch.cuda.stream(sA):
-                out0 = det.forward(frames)                       # the launch_list probe re-ran ops out of context: redo frame 0..B-1 cleanly
-                d0, n0 = det.postprocess(out0, 0.01, 0.45, None)
+                out0 = det.forward(frames, fuse_decode=CONF)       # the launch_list probe re-ran ops out of context: redo frame 0..B-1 cleanly
+                d0, n0 = det.postprocess(out0, CONF, 0.45, None)
             torch.cuda.synchronize()
             heads0 = [r[:1].cpu() for r in out0.raw()]
             dets0 = d0[0, :int(n0[0])].cpu()

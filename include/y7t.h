@@ -138,11 +138,16 @@ typedef struct y7t_op {
     int32_t KH, KW, stride, pad;        /* conv / pool window */
     int32_t K, K_pad;
     int32_t act;                        /* 0 none, 1 SiLU, 2 LeakyReLU(0.1) */
-    int32_t reserved0, reserved1;       /* reserved0 = korder: 1 when the weights are packed in (kh, 64-ch chunk, kw) K order;
-                                           keeps the int64 fields 8-byte aligned: sizeof(y7t_op) == 112 */
+    int32_t korder;                     /* weight packing: 0 k = (kh*KW+kw)*Cin + ci; 1 (kh, 64-ch chunk, kw); 2 LDS-patch panels; 3 1x1 panels */
+    int32_t detect_level;               /* -1: ordinary layer.  l >= 0: the 1x1 conv of Detect level l (models/yolo.py:46); in a fused forward
+                                           (y7t_det_forward_fused) its epilogue decodes + filters instead of writing the head tensor */
     int64_t w_off;                      /* element offset into the fp16 weight blob */
     int64_t bias_off;                   /* element offset into the fp32 bias blob */
-} y7t_op;
+    /* upsample-on-read (1x1 / stride 1 convs; cfg/deploy/yolov7-w6.yaml:75,89,103: nn.Upsample feeds only a Concat whose consumers are
+     * 1x1 convs): channels [up_c0, up_c0 + up_C) of the input slice are not stored at this resolution -- pixel (y, x) reads
+     * buffer up_buf (H/2 x W/2, up_ld channels, slice starting at up_coff) at (y >> 1, x >> 1).  up_C == 0: off. */
+    int32_t up_buf, up_ld, up_coff, up_c0, up_C, pad0;
+} y7t_op;                               /* sizeof == 136 */
 
 typedef struct y7t_det y7t_det;
 
@@ -160,6 +165,17 @@ int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
  * the memory-bound high-resolution layers of the next forward are through.  y7t_det_num_ops: length of the list. */
 int y7t_det_num_ops(const y7t_det* det);
 int y7t_det_forward_ops(y7t_det* det, int B, int first, int last, y7t_stream stream);
+
+/* Fused Detect: describe the Detect levels once (strides / anchors in pixels, models/yolo.py:23-62), then y7t_det_forward_fused runs
+ * ops [first, last) like y7t_det_forward_ops, except that the Detect 1x1 convs do not write their (B, ny, nx, na*no) fp32 tensors:
+ * their epilogue applies sigmoid + decode (yolo.py:49-56) and the candidate filter of non_max_suppression (utils/general.py:629-662:
+ * obj > conf_thres, best class, conf > conf_thres) and appends the survivors to the candidate arrays at the start of `workspace`
+ * (layout of y7t_det_postprocess; `cap`, `max_nms` as there).  The candidate counters are zeroed when the range contains op 0.
+ * Afterwards call y7t_det_postprocess with head == NULL on the same workspace: it skips its own decode pass.  The (B, 102000, 5+nc)
+ * tensor of the reference and the four raw head tensors are never written. */
+int y7t_det_set_detect(y7t_det* det, int nl, int na, int no, const float* strides_host, const float* anchors_host);
+int y7t_det_forward_fused(y7t_det* det, int B, int first, int last, float conf_thres, int cap, int max_nms, void* workspace,
+                          size_t workspace_bytes, y7t_stream stream);
 
 /* TrackerLoader.__getitem__ tail (tracker/tracker_dataloader.py:83-88) + ReOrg (models/common.py:48-53):
  * img: (B,3,H,W) float32 RGB in [0,1] (is_u8 = 0) or (B,H,W,3) uint8 BGR (is_u8 = 1: BGR->RGB and /255 fused);
@@ -179,7 +195,8 @@ int y7t_letterbox_layout_u8(const void* img, int B, int H0, int W0, int H, int W
  * letterbox: DEVICE [B][5] = gain, pad_w, pad_h, H0, W0.  dets: [B][max_det][6]; ndets: [B];
  * cand_count (may be NULL): [B] candidates above conf_thres (> cap == overflow, caller must check).
  * cap: candidate capacity per image (the number of anchors can never overflow it); the NMS itself runs on the top
- * min(cap, max_nms) candidates like the reference.  workspace: y7t_det_postprocess_workspace_bytes(B, cap, max_nms). */
+ * min(cap, max_nms) candidates like the reference.  workspace: y7t_det_postprocess_workspace_bytes(B, cap, max_nms).
+ * head == NULL: the candidates are already in the workspace (y7t_det_forward_fused); ny/nx/strides/anchors are then unused. */
 size_t y7t_det_postprocess_workspace_bytes(int B, int cap, int max_nms);
 int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const int* ny, const int* nx, const float* strides,
                         const float* anchors, int nl, int na, int no, int B, float conf_thres, float iou_thres, int max_det,

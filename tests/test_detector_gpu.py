@@ -255,6 +255,67 @@ def test_decode_nms_matches_oracle():
         np.testing.assert_array_equal(order[k], keep[b, :nd[b]])
 
 
+def test_fused_detect_forward_equals_plain_forward():
+    """y7t_det_forward_fused: the Detect 1x1 convs decode + filter in their epilogue (the head tensors are never written) and
+    y7t_det_postprocess(head = NULL) starts at the rank sort -- candidate counts, detections and classes must equal the plain
+    forward + decode pass; the raw heads can still be materialised afterwards and equal the plain forward's bit for bit."""
+    det = build("yolov7-w6", 10, (256, 320), 2)
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand((2, 3, 256, 320), generator=g)
+    det.plant_objectness_bias(img.cuda(), target=800)
+    out_a = det(img)[0]
+    raw_a = [t.clone() for t in out_a.raw()]
+    d_a, n_a = det.postprocess(out_a, 0.01, 0.45, ori_shapes=[(200, 300), (256, 320)])
+    d_a, n_a, c_a = d_a.clone(), n_a.clone(), det.plan.post[0].cand.clone()
+    for t in range(len(det.plan.heads)):
+        det.head_tensor(t, 2).zero_()                                   # a fused forward must not need (or write) them
+    out_b = det.forward(img, fuse_decode=0.01, pset=1)
+    d_b, n_b = det.postprocess(out_b, 0.01, 0.45, ori_shapes=[(200, 300), (256, 320)])
+    torch.cuda.synchronize()
+    assert all(float(det.head_tensor(t, 2).abs().max()) == 0.0 for t in range(len(det.plan.heads)))
+    assert torch.equal(n_a, n_b) and int(n_a.min()) > 20 and torch.equal(c_a, det.plan.post[1].cand) and int(c_a.min()) > 300
+    for b in range(2):
+        # (at this size the plain Detect convs run split-K, the fused ones do not: the fp32 logits may differ in the last bit)
+        a, bb = d_a[b, :n_a[b]], d_b[b, :n_b[b]]
+        assert torch.equal(a[:, 5], bb[:, 5]) and (a[:, :4] - bb[:, :4]).abs().max() <= 1.0 and (a[:, 4] - bb[:, 4]).abs().max() <= 1e-5
+        assert ((a[:, :4] - bb[:, :4]).abs() > 0).float().mean() < 0.01
+    assert all(torch.equal(x, y) for x, y in zip(raw_a, out_b.raw()))      # lazily re-run Detect convs
+    with pytest.raises(ValueError):
+        det.postprocess(out_b, 0.25, 0.45, None)                          # the threshold was fixed at forward time
+    det(img)
+    with pytest.raises(Exception):
+        det._materialise_heads(out_b)                                     # the arena has moved on
+
+
+def test_upsample_on_read_equals_materialised_upsample(monkeypatch):
+    """nn.Upsample folded into the consuming 1x1 convs' loader (cfg/deploy/yolov7-w6.yaml:75,89,103) changes no value: heads bit-exact
+    against the plan that materialises the three upsampled tensors"""
+    img = torch.rand((2, 3, 256, 320), generator=torch.Generator().manual_seed(9))
+    det = build("yolov7-w6", 10, (256, 320), 2)
+    assert sum(int(o["up_C"]) > 0 for o in det.plan.ops) == 3 and not any(int(o["type"]) == 1 for o in det.plan.ops)
+    a = [t.clone() for t in det(img)[0].raw()]
+    monkeypatch.setenv("Y7T_UPSAMPLE_ON_READ", "0")
+    ref = build("yolov7-w6", 10, (256, 320), 2)
+    assert sum(int(o["type"]) == 1 for o in ref.plan.ops) == 3
+    b = ref(img)[0].raw()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_head_output_behaves_like_the_reference_tensor():
+    """`pred = model(img)[0]` is a (B, A, 5+nc) tensor in the reference (models/yolo.py:57); here it is a device handle that turns into
+    that tensor on request: indexing, numpy conversion, .cpu() -- all equal to the oracle's Detect decode of the raw heads"""
+    from oracle import detector_torch as dt
+    det = build("yolov7-tiny", 80, (128, 192), 2)
+    pred = det(torch.rand((2, 3, 128, 192), generator=torch.Generator().manual_seed(10)))[0]
+    want = dt.decode_heads([r.cpu() for r in pred.raw()], det.spec["anchors"], 128)
+    assert tuple(pred.shape) == tuple(want.shape) == (2, 3 * (16 * 24 + 8 * 12 + 4 * 6), 85)
+    assert torch.allclose(pred.cpu(), want, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(pred[1].cpu(), want[1], rtol=1e-5, atol=1e-4)
+    assert torch.allclose((pred[..., 4] > 0.5).cpu().float(), (want[..., 4] > 0.5).float())
+    np.testing.assert_allclose(np.asarray(pred), want.numpy(), rtol=1e-5, atol=1e-4)
+    assert len(pred) == 2
+
+
 def test_attempt_load_state_dict_checkpoint(tmp_path):
     """attempt_load (models/experimental.py:83-106 seam) on a state-dict checkpoint with reference-style parameter names
     ({'model': state_dict} as the reference's training code saves, plus a bare state dict): same network, bit for bit"""

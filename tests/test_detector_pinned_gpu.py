@@ -84,6 +84,7 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     assert fam["patch"] >= 10 and fam["patch_mt"] >= 4 and fam["patch_strip"] >= 8, fam
     assert any(n.startswith("igemm<256,") for n in names), hist         # 256-pixel tiles (stem, stride-2 layers on the big maps)
     assert any(n.startswith("igemm<128,128,32,2> 1x1") for n in names), hist
+    assert sum("upsample-on-read" in n for n in names) == 3 and "upsample2x" not in names, hist
     det(torch.from_numpy(bench_det[1]).cuda())       # launch_list re-ran the ops in place; leave the arena as a clean forward
     torch.cuda.synchronize()
 
@@ -105,10 +106,15 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
     det(torch.from_numpy(frames_host).cuda())
     torch.cuda.synchronize()
     worst = collections.defaultdict(float)
-    n_conv = n_other = 0
+    n_conv = n_other = n_up = 0
     for oi, op in enumerate(p.ops):
         H, W, Cin = int(op["H"]), int(op["W"]), int(op["Cin"])
         x = _slice(det, int(op["in_buf"]), int(op["in_ld"]), int(op["in_coff"]), Cin, H, W, fr).float().cpu().permute(0, 3, 1, 2).contiguous()
+        if int(op["up_C"]) > 0:      # upsample-on-read: these channels of the concat exist only at half resolution (nn.Upsample(None, 2, 'nearest'))
+            c0, cu = int(op["up_c0"]), int(op["up_C"])
+            lo = _slice(det, int(op["up_buf"]), int(op["up_ld"]), int(op["up_coff"]), cu, H // 2, W // 2, fr).float().cpu().permute(0, 3, 1, 2)
+            x[:, c0:c0 + cu] = F.interpolate(lo, scale_factor=2, mode="nearest")
+            n_up += 1
         if int(op["type"]) == 0:
             wl = p.wlayout[ci]
             ci += 1
@@ -140,7 +146,7 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             got = _slice(det, int(op["out_buf"]), int(op["out_ld"]), int(op["out_coff"]), Cin, ref.shape[2], ref.shape[3], fr).float().cpu()
             assert torch.equal(got, ref.permute(0, 2, 3, 1)), "op %d %s" % (oi, names[oi])
             n_other += 1
-    assert ci == len(p.wlayout) and n_conv >= 96 and n_other >= 6
+    assert ci == len(p.wlayout) and n_conv >= 96 and n_other + n_up >= 6 and n_up == 3      # w6: all three upsamples are read through
     print("per-op worst err / tol by kernel:", {k: "%.2e" % v for k, v in sorted(worst.items())})
 
 

@@ -27,7 +27,10 @@
 
 // KM = 1: 1x1 / stride 1 / pad 0 with Cin % 64 == 0 -- no taps, no padding, no K tail: every pixel DMA is `row offset (or out of range)
 // + scalar channel offset`, so the K loop carries no address arithmetic and no control flow besides its own counter.
-template <int BM, int BN, int BK, int NST, bool UT, int KM = 0>
+// EPI = 1 (Detect 1x1 convs in a fused forward): the epilogue decodes + filters (models/yolo.py:49-56, utils/general.py:629-662) instead
+// of storing the tile.  DUAL (KM = 1 only): upsample-on-read -- K-steps whose channels lie in [up_c0, up_c0 + up_C) fetch pixel (y, x)
+// from the half-resolution tensor `in2` at (y >> 1, x >> 1) (nn.Upsample(None, 2, 'nearest') folded into the consumer's loader).
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
 __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
@@ -39,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
     constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
     constexpr int STAGE = (BM + BN) * ROWB;      // bytes per LDS stage
-    constexpr int LDS_EPI_BYTES = BM * (BN * 2 + 16);
+    constexpr int LDS_EPI_BYTES = EPI == 1 ? BM * (BN + 1) * 4 : BM * (BN * 2 + 16);
     constexpr int BIAS_OFF = NST * STAGE > LDS_EPI_BYTES ? NST * STAGE : LDS_EPI_BYTES;   // BN biases behind everything else
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -72,12 +75,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
     // no zero page and no 64-bit address arithmetic in the K loop.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.in2 : p.in), 0, DUAL ? p.in2_bytes : p.in_bytes, 0x00020000);
 
     // ---- per-thread load geometry.  LDS slot of logical chunk c in row r:  c ^ sw(r),
     //      sw(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows (conflict-free ds_read_b128) ----
     const int lrow = wave * RPW + lane / CPR;      // row inside a load round
     const int gchunk = (lane % CPR) ^ (BK == 64 ? ((lrow >> 1) & 7) : ((lrow >> 2) & 3));
     int xoff[RM];          // byte offset of (b, hi0, wi0, cin_off [+ this lane's chunk]) -- may be negative before the tap is added
+    int xoff2[DUAL ? RM : 1];   // DUAL: the same pixel in the half-resolution source
     unsigned vmask[RM];    // bit t: tap t of this row is inside the image
     const int HoWo = p.Ho * p.Wo;
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
@@ -86,6 +91,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         const int m = m0 + r * RPR + lrow;
         vmask[r] = 0;
         xoff[r] = KM == 1 ? (int)0xFF000000u : 0;      // KM 1: an offset that stays out of range with the (< 16 MiB) scalar channel offset added
+        if (DUAL) xoff2[r] = (int)0xFF000000u;
         if (m < p.M) {
             // m -> (b, ho, wo) with a float reciprocal + one-step fix-up (M < 2^24), no integer division
             int b = (int)((float)m * inv_howo);
@@ -96,6 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
             const int wo = rem - ho * p.Wo;
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
             xoff[r] = ((((b * p.H + hi0) * p.W + wi0) * p.ldin + p.cin_off) + (UT ? gchunk * 8 : 0)) * 2;
+            if (DUAL) xoff2[r] = ((((b * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1)) * p.ldin2 + p.cin2_off) + gchunk * 8) * 2;
             if (KM == 1) continue;      // (m past M keeps the out-of-range sentinel set below)
             // taps inside the image: kh in [klo, khi], kw in [wlo, whi]
             const int klo = hi0 < 0 ? -hi0 : 0, khi = (p.H - 1 - hi0) < (p.KH - 1) ? (p.H - 1 - hi0) : (p.KH - 1);
@@ -128,7 +135,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         char* xs = smem + stage * STAGE;
         char* ws = xs + BM * ROWB;
         if (idx < RM && KM == 1) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (idx * RPR + wave * RPW) * ROWB), 16, xoff[idx], ci * 2, 0, 0);
+            if (DUAL && ci >= p.up_c0 && ci < p.up_c0 + p.up_C)      // wave-uniform: a K-step lies in one source (up_c0, up_C multiples of BK)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (LDS_AS void*)(xs + (idx * RPR + wave * RPW) * ROWB), 16, xoff2[DUAL ? idx : 0],
+                                                         (ci - p.up_c0) * 2, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(xs + (idx * RPR + wave * RPW) * ROWB), 16, xoff[idx], ci * 2, 0, 0);
         } else if (idx < RM) {
             const int r = idx;
             const int kh = (p.KW == 1) ? tap : (tap * 43) >> 7;   // tap / 3 for tap < 128
@@ -238,6 +249,86 @@ __global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
 
+    if (EPI == 1) {
+        // ---- Detect: stage the fp32 tile (bias added) in LDS, then one thread per (pixel, anchor): sigmoid, candidate filter, decode,
+        // atomic append.  Row stride Cout | 1 dwords: odd, so the per-pixel rows do not collide on banks. ----
+        const Y7TDecode& q = p.dec;
+        const int LD = p.Cout | 1;
+        float* tile = (float*)smem;
+        __syncthreads();          // every wave is done with the staging buffers
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int pix = wm * WTM + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int nl = wn * WTN + i * 32 + 8 * g + 4 * hi32 + e;
+                        if (nl < p.Cout) tile[pix * LD + nl] = acc[i][j][g * 4 + e] + lbias[nl];
+                    }
+        }
+        __syncthreads();
+        // Slots: a workgroup reserves ONE block per image with a single global atomic (every candidate bumping count[b] itself
+        // serialised ~200 same-address atomics per workgroup in L2: 470 us on the 40x40 level); ranks inside the block come from LDS atomics.
+        const int HoWo2 = q.ny * q.nx, nc = q.no - 5;
+        int* lcount = (int*)(smem + BM * LD * 4);        // [BM] candidates of image b0 + i found by this workgroup
+        int* lbase = lcount + BM;                        // [BM] first slot of that block
+        const int b0 = m0 / HoWo2;
+        for (int i = tid; i < BM; i += 256) lcount[i] = 0;
+        __syncthreads();
+        constexpr int MAXT = (BM * 3 + 255) / 256;       // tasks per thread (na <= 3)
+        int t_img[MAXT], t_rank[MAXT], t_cidx[MAXT];
+        float t_box[MAXT][4], t_score[MAXT], t_cls[MAXT];
+#pragma unroll
+        for (int it = 0; it < MAXT; ++it) {
+#pragma clang fp contract(off)      // the decode below must round like k_decode_filter (y7t_post.hip is built without contraction): bit-equal candidates
+            t_img[it] = -1;
+            const int t = tid + it * 256;
+            if (t >= BM * q.na) continue;
+            const int pix = t / q.na, an = t - pix * q.na;
+            const int m = m0 + pix;
+            if (m >= p.M) continue;
+            const float* v = tile + pix * LD + an * q.no;
+            const float obj = 1.0f / (1.0f + expf(-v[4]));
+            if (!(obj > q.conf_thres)) continue;                  // xc = prediction[..., 4] > conf_thres
+            float best = -1.f; int bj = 0;
+            for (int c = 0; c < nc; ++c) {                        // x[:, 5:] *= x[:, 4:5]; conf, j = x[:, 5:].max(1)
+                const float sc = (1.0f / (1.0f + expf(-v[5 + c]))) * obj;
+                if (sc > best) { best = sc; bj = c; }
+            }
+            if (!(best > q.conf_thres)) continue;
+            const int b = m / HoWo2, rem = m - b * HoWo2, y = rem / q.nx, x = rem - y * q.nx;
+            const float sx = 1.0f / (1.0f + expf(-v[0])), sy = 1.0f / (1.0f + expf(-v[1]));
+            const float sw = 1.0f / (1.0f + expf(-v[2])), sh = 1.0f / (1.0f + expf(-v[3]));
+            const float cx = (sx * 2.f - 0.5f + (float)x) * q.stride, cy = (sy * 2.f - 0.5f + (float)y) * q.stride;
+            const float w = (sw * 2.f) * (sw * 2.f) * q.aw[an], h = (sh * 2.f) * (sh * 2.f) * q.ah[an];
+            t_box[it][0] = cx - w / 2; t_box[it][1] = cy - h / 2; t_box[it][2] = cx + w / 2; t_box[it][3] = cy + h / 2;   // xywh2xyxy
+            t_score[it] = best; t_cls[it] = (float)bj;
+            t_cidx[it] = q.row0 + (an * q.ny + y) * q.nx + x;
+            t_img[it] = b - b0;
+            t_rank[it] = atomicAdd(lcount + (b - b0), 1);
+        }
+        __syncthreads();
+        for (int i = tid; i < BM; i += 256) {
+            const int c = lcount[i];
+            lbase[i] = c > 0 ? atomicAdd(q.count + b0 + i, c) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MAXT; ++it) {
+            if (t_img[it] < 0) continue;
+            const int b = b0 + t_img[it], slot = lbase[t_img[it]] + t_rank[it];
+            if (slot >= q.cap) continue;
+            float* bo = q.cbox + ((size_t)b * q.cap + slot) * 4;
+            bo[0] = t_box[it][0]; bo[1] = t_box[it][1]; bo[2] = t_box[it][2]; bo[3] = t_box[it][3];
+            q.cscore[(size_t)b * q.cap + slot] = t_score[it];
+            q.ccls[(size_t)b * q.cap + slot] = t_cls[it];
+            q.cidx[(size_t)b * q.cap + slot] = t_cidx[it];
+        }
+        return;
+    }
     if (p.splitk > 1) {   // raw fp32 partial sums of this K range: slab[split][m][Cout_pad]
         float* slab = p.partial + (size_t)split * p.M * p.Cout_pad;
 #pragma unroll
@@ -374,20 +465,20 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = 128ull << 20;
 
-template <int BM, int BN, int BK, int NST, bool UT, int KM = 0>
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
-    constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = BM * (BN * 2 + 16);
+    constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = EPI == 1 ? BM * (BN + 1) * 4 : BM * (BN * 2 + 16);
     constexpr unsigned lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + BN * 4;   // + the bias corner
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN, tiles = tiles_m * tiles_n;
     Y7TConvArgs b = a;
     const int nk = a.K_pad / BK;
     int S = 1;
-    if (a.allow_splitk && tiles < 256 && nk >= 8) {
+    if (a.allow_splitk && EPI == 0 && tiles < 256 && nk >= 8) {
         S = (512 + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;
@@ -399,9 +490,10 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
         b.partial = g_splitk_ws;
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "");
+    y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
+                    EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "");
     if (b.splitk > 1) {
         const long long tot = (long long)a.M * (a.Cout_pad / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -442,6 +534,7 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     Y7TConvArgs b = a;
     b.in_bytes = (unsigned)((long long)a.B * a.H * a.W * a.ldin * 2);
     b.w_bytes = (unsigned)((long long)a.Cout_pad * a.K_pad * 2);
+    b.in2_bytes = a.up_C > 0 ? (unsigned)((long long)a.B * (a.H / 2) * (a.W / 2) * a.ldin2 * 2) : 0u;
     { static int xs = -1; if (xs < 0) { const char* e = getenv("Y7T_CONV_XCD"); xs = e ? atoi(e) : 1; } b.xcd_swizzle = xs; }
     { static int sk = -1; if (sk < 0) { const char* e = getenv("Y7T_CONV_SPLITK"); sk = e ? atoi(e) : 1; } b.allow_splitk = sk; }
     b.splitk = 1; b.ksteps = b.K_pad; b.partial = nullptr;
@@ -454,6 +547,20 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+    if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
+        const bool fast = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24) &&
+                          (a.korder == 3 || a.korder == 0);
+        if (!fast) { y7t_set_error("conv: Detect-decode / upsample-on-read need a 1x1 stride-1 layer with Cin %% 64 == 0"); return Y7T_E_ARG; }
+        if (a.epi) {
+            if (a.Cout_pad != 64 || a.up_C > 0) { y7t_set_error("conv: fused Detect decode needs na * (5 + nc) <= 64 output channels (got %d)", a.Cout); return Y7T_E_ARG; }
+            return launch_conv_ut<128, 64, 32, 2, true, 1, 1, false>(a, s);
+        }
+        if (a.up_c0 % 32 || a.up_C % 32 || a.up_c0 + a.up_C > a.Cin || (a.H & 1) || (a.W & 1) || a.ldin2 % 8 || a.cin2_off % 8) {
+            y7t_set_error("conv: upsample-on-read channel range [%d, %d) / map %dx%d not supported", a.up_c0, a.up_c0 + a.up_C, a.H, a.W);
+            return Y7T_E_ARG;
+        }
+        return a.Cout_pad % 128 == 0 ? launch_conv_ut<128, 128, 32, 2, true, 1, 0, true>(a, s) : launch_conv_ut<128, 64, 32, 2, true, 1, 0, true>(a, s);
+    }
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);

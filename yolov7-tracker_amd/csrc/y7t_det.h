@@ -5,6 +5,16 @@
 
 enum { Y7T_ACT_NONE = 0, Y7T_ACT_SILU = 1, Y7T_ACT_LEAKY = 2 };
 
+// Detect decode fused into the 1x1 conv's epilogue (y7t_det_forward_fused): level parameters + where the candidates go
+struct Y7TDecode {
+    float stride, aw[3], ah[3];   // models/yolo.py:52-53: xy = (s*2 - 0.5 + grid) * stride; wh = (s*2)^2 * anchor_grid
+    int ny, nx, row0, na, no;     // row0: first row of this level in the reference's (B, A, no) ordering
+    float conf_thres;
+    int cap;                      // candidate capacity per image
+    float *cbox, *cscore, *ccls;  // [B][cap][4] xyxy, [B][cap], [B][cap]
+    int *cidx, *count;            // [B][cap] row index, [B] candidates found
+};
+
 struct Y7TConvArgs {
     const _Float16* in;  // NHWC fp16 buffer holding the input slice
     int ldin, cin_off;   // channels of that buffer, first channel of the slice
@@ -27,6 +37,12 @@ struct Y7TConvArgs {
     int dephase;       // patch kernel: start delay of workgroups 256..511 in units of 4096 clocks (0 = off)
     int force_patch;   // tests: run an eligible 3x3/s1 layer on k_conv3x3_patch whatever its tile efficiency
     int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)
+    int epi;      // 1: Detect decode + candidate filter instead of the output store (1x1 convs, dec below)
+    Y7TDecode dec;
+    // upsample-on-read (1x1 convs): channels [up_c0, up_c0 + up_C) of the input come from `in2` (H/2 x W/2, ldin2 channels, slice at cin2_off)
+    const _Float16* in2;
+    int ldin2, cin2_off, up_c0, up_C;
+    unsigned in2_bytes;
 };
 
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);
@@ -38,6 +54,7 @@ int y7t_maxpool_launch(const _Float16* in, int ldin, int cin_off, int B, int H, 
 // decode + NMS chain (y7t_post.hip)
 struct Y7TPostArgs {
     const float* head[4];   // per level NHWC fp32 [B][ny][nx][na*no]
+    int predecoded;         // 1: the candidate arrays of `ws` are already filled (fused Detect epilogue): skip the decode pass
     int ny[4], nx[4];
     float stride[4];
     float anchors[24];      // [nl][na][2] in pixels
@@ -52,4 +69,7 @@ struct Y7TPostArgs {
     void* ws; size_t ws_bytes;
 };
 size_t y7t_post_ws_bytes(int B, int cap, int max_nms);
+// the candidate arrays at the start of a postprocess workspace (shared with the fused Detect epilogue)
+struct Y7TCandWs { float *cbox, *cscore, *ccls; int *cidx, *count; };
+Y7TCandWs y7t_post_cand_ws(void* ws, int B, int cap);
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s);

@@ -7,7 +7,7 @@
 #include <string.h>
 #include <vector>
 
-static_assert(sizeof(y7t_op) == 112, "y7t_op layout must match detector/graph.py OP_DTYPE");
+static_assert(sizeof(y7t_op) == 136, "y7t_op layout must match detector/graph.py OP_DTYPE");
 
 struct y7t_det {
     std::vector<y7t_op> ops;
@@ -16,7 +16,12 @@ struct y7t_det {
     const _Float16* w; const float* bias;
     _Float16* zeros;
     int max_batch;
+    // Detect levels (y7t_det_set_detect)
+    int nl = 0, na = 0, no = 0;
+    float stride[4] = {0, 0, 0, 0}, anchors[24] = {0};
 };
+
+struct Y7TFused { float conf_thres; int cap; Y7TCandWs ws; };
 
 extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs, int n_bufs, void* arena, size_t arena_bytes,
                               const void* w, const void* bias, int max_batch, y7t_det** out) {
@@ -52,11 +57,10 @@ extern "C" int y7t_det_num_ops(const y7t_det* d) { return d ? (int)d->ops.size()
 
 extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) { return y7t_det_forward_ops(d, B, 0, -1, stream); }
 
-extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_stream stream) {
+static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* fused, hipStream_t s) {
     Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
     if (last < 0) last = (int)d->ops.size();
     Y7T_ARG_CHECK(first >= 0 && first <= last && last <= (int)d->ops.size());
-    hipStream_t s = (hipStream_t)stream;
     for (int oi = first; oi < last; ++oi) {
         const y7t_op& op = d->ops[oi];
         const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);
@@ -64,12 +68,31 @@ extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_s
         int rc = 0;
         if (op.type == Y7T_OP_CONV) {
             Y7TConvArgs a;
+            memset(&a, 0, sizeof(a));
             a.in = in; a.ldin = op.in_ld; a.cin_off = op.in_coff; a.B = B; a.H = op.H; a.W = op.W; a.Cin = op.Cin;
             a.w = d->w + op.w_off; a.bias = d->bias + op.bias_off;
             a.out = outp; a.ldout = op.out_ld; a.cout_off = op.out_coff; a.out_f32 = op.out_f32;
             a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.Cout_pad = op.Cout_pad;
             a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
-            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.reserved0; a.force_patch = 0;
+            a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.korder; a.force_patch = 0;
+            if (op.up_C > 0) {
+                a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]);
+                a.ldin2 = op.up_ld; a.cin2_off = op.up_coff; a.up_c0 = op.up_c0; a.up_C = op.up_C;
+            }
+            if (fused && op.detect_level >= 0) {
+                const int l = op.detect_level;
+                if (l >= d->nl || op.Cout != d->na * d->no) { y7t_set_error("fused Detect: level %d not described by y7t_det_set_detect", l); return Y7T_E_STATE; }
+                a.epi = 1;
+                Y7TDecode& q = a.dec;
+                q.stride = d->stride[l]; q.ny = op.Ho; q.nx = op.Wo; q.na = d->na; q.no = d->no;
+                q.row0 = 0;
+                for (int k = 0; k < (int)d->ops.size(); ++k)    // rows of the finer levels come first (models/yolo.py:57 cat order)
+                    if (d->ops[k].type == Y7T_OP_CONV && d->ops[k].detect_level >= 0 && d->ops[k].detect_level < l)
+                        q.row0 += d->na * d->ops[k].Ho * d->ops[k].Wo;
+                for (int k = 0; k < d->na; ++k) { q.aw[k] = d->anchors[(l * d->na + k) * 2]; q.ah[k] = d->anchors[(l * d->na + k) * 2 + 1]; }
+                q.conf_thres = fused->conf_thres; q.cap = fused->cap;
+                q.cbox = fused->ws.cbox; q.cscore = fused->ws.cscore; q.ccls = fused->ws.ccls; q.cidx = fused->ws.cidx; q.count = fused->ws.count;
+            }
             rc = y7t_conv_launch(a, s);
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
             rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
@@ -82,6 +105,29 @@ extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_s
     return 0;
 }
 
+extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_stream stream) {
+    return forward_impl(d, B, first, last, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int y7t_det_set_detect(y7t_det* d, int nl, int na, int no, const float* strides, const float* anchors) {
+    Y7T_ARG_CHECK(d && nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && strides && anchors);
+    d->nl = nl; d->na = na; d->no = no;
+    for (int l = 0; l < nl; ++l) d->stride[l] = strides[l];
+    for (int i = 0; i < nl * na * 2; ++i) d->anchors[i] = anchors[i];
+    return 0;
+}
+
+extern "C" int y7t_det_forward_fused(y7t_det* d, int B, int first, int last, float conf_thres, int cap, int max_nms, void* ws, size_t ws_bytes,
+                                     y7t_stream stream) {
+    Y7T_ARG_CHECK(d && ws && cap >= 64 && max_nms >= 1 && B > 0 && B <= d->max_batch);
+    Y7T_ARG_CHECK(d->nl > 0);
+    Y7T_ARG_CHECK(ws_bytes >= y7t_post_ws_bytes(B, cap, max_nms));
+    Y7TFused f;
+    f.conf_thres = conf_thres; f.cap = cap; f.ws = y7t_post_cand_ws(ws, B, cap);
+    if (first == 0) Y7T_HIP_CHECK(hipMemsetAsync(f.ws.count, 0, sizeof(int) * B, (hipStream_t)stream));
+    return forward_impl(d, B, first, last, &f, (hipStream_t)stream);
+}
+
 extern "C" size_t y7t_det_postprocess_workspace_bytes(int B, int cap, int max_nms) {
     return (B > 0 && cap > 0 && max_nms > 0) ? y7t_post_ws_bytes(B, cap, max_nms) : 0;
 }
@@ -90,12 +136,14 @@ extern "C" int y7t_det_postprocess(const float* const* head, const int* ny, cons
                                    int na, int no, int B, float conf_thres, float iou_thres, int max_det, int max_nms, int cap,
                                    const float* letterbox, float* dets, int* ndets, int* keep_idx, int* cand_count, void* ws, size_t ws_bytes,
                                    y7t_stream stream) {
-    Y7T_ARG_CHECK(head && ny && nx && strides && anchors && letterbox && dets && ndets && keep_idx && ws);
+    Y7T_ARG_CHECK(letterbox && dets && ndets && keep_idx && ws);
+    Y7T_ARG_CHECK(head == nullptr || (ny && nx && strides && anchors));
     Y7T_ARG_CHECK(nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && B >= 1 && cap >= 64 && max_det >= 1 && max_nms >= 1);
     Y7TPostArgs a;
     memset(&a, 0, sizeof(a));
-    for (int l = 0; l < nl; ++l) { a.head[l] = head[l]; a.ny[l] = ny[l]; a.nx[l] = nx[l]; a.stride[l] = strides[l]; }
-    for (int i = 0; i < nl * na * 2; ++i) a.anchors[i] = anchors[i];
+    a.predecoded = head == nullptr;
+    for (int l = 0; l < nl && head; ++l) { a.head[l] = head[l]; a.ny[l] = ny[l]; a.nx[l] = nx[l]; a.stride[l] = strides[l]; }
+    for (int i = 0; i < nl * na * 2 && head; ++i) a.anchors[i] = anchors[i];
     a.nl = nl; a.na = na; a.no = no; a.B = B; a.conf_thres = conf_thres; a.iou_thres = iou_thres;
     a.max_det = max_det; a.max_nms = max_nms < cap ? max_nms : cap; a.cap = cap;
     a.letterbox_dev = letterbox; a.dets = dets; a.ndets = ndets; a.keep_idx = keep_idx; a.count_out = cand_count;
@@ -108,6 +156,7 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
                                    const void* zeros16, y7t_stream stream) {
     Y7T_ARG_CHECK(in && w && bias && out && zeros16 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && stride > 0);
     Y7TConvArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = (const _Float16*)in; a.ldin = in_ld; a.cin_off = in_coff; a.B = B; a.H = H; a.W = W; a.Cin = Cin;
     a.w = (const _Float16*)w; a.bias = bias; a.out = out; a.ldout = out_ld; a.cout_off = out_coff; a.out_f32 = out_f32;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;

@@ -423,6 +423,19 @@ size_t y7t_post_ws_bytes(int B, int cap, int max_nms) {
     return o + 256;
 }
 
+Y7TCandWs y7t_post_cand_ws(void* ws, int B, int cap) {
+    char* base = (char*)ws;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base + o; o = (o + bytes + 255) & ~(size_t)255; return p; };
+    Y7TCandWs c;
+    c.cbox = (float*)take((size_t)B * cap * 16);
+    c.cscore = (float*)take((size_t)B * cap * 4);
+    c.ccls = (float*)take((size_t)B * cap * 4);
+    c.cidx = (int*)take((size_t)B * cap * 4);
+    c.count = (int*)take((size_t)B * 4);
+    return c;
+}
+
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     const int B = a.B, cap = a.cap;
     const size_t mcap = (size_t)(cap < a.max_nms ? cap : a.max_nms);
@@ -441,7 +454,7 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     unsigned long long* mask = (unsigned long long*)take((size_t)B * mcap * words * 8);
     float* lb = (float*)take((size_t)B * 5 * 4);
     if (o + 256 > a.ws_bytes) { y7t_set_error("postprocess workspace too small (%zu < %zu)", a.ws_bytes, o + 256); return Y7T_E_ARG; }
-    Y7T_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int) * B, s));
+    if (!a.predecoded) Y7T_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int) * B, s));
     Y7T_HIP_CHECK(hipMemcpyAsync(lb, a.letterbox_dev, sizeof(float) * 5 * B, hipMemcpyDeviceToDevice, s));
     DecodeArgs d;
     memset(&d, 0, sizeof(d));
@@ -453,7 +466,7 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
         for (int k = 0; k < a.na; ++k) { d.lv[l].aw[k] = a.anchors[(l * a.na + k) * 2]; d.lv[l].ah[k] = a.anchors[(l * a.na + k) * 2 + 1]; }
         row0 += a.na * a.ny[l] * a.nx[l];
     }
-    for (int l = 0; l < a.nl; ++l) {
+    for (int l = 0; l < a.nl && !a.predecoded; ++l) {
         const long long tot = (long long)B * a.na * a.ny[l] * a.nx[l];
         int blocks = (int)((tot + 255) / 256); if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_decode_filter, dim3(blocks), dim3(256), 0, s, d, l);

@@ -22,13 +22,14 @@ def make_divisible(x, divisor):
 
 class Node:
     """one tensor-producing op after expansion. kind: input|reorg|conv|concat|up|pool|detect"""
-    __slots__ = ("idx", "kind", "src", "c", "k", "s", "p", "act", "wkey", "layer", "extra", "h", "w", "home", "coff", "ld")
+    __slots__ = ("idx", "kind", "src", "c", "k", "s", "p", "act", "wkey", "layer", "extra", "h", "w", "home", "coff", "ld", "virt_up", "virtual")
 
     def __init__(self, kind, src, c, k=1, s=1, p=0, act=0, wkey=None, layer=-1, extra=None):
         self.kind, self.src, self.c, self.k, self.s, self.p, self.act, self.wkey, self.layer, self.extra = kind, list(src), c, k, s, p, act, wkey, layer, extra
         self.idx = -1
         self.h = self.w = 0
         self.home, self.coff, self.ld = None, 0, 0
+        self.virt_up, self.virtual = None, False
 
 
 def _act_code(a):
@@ -121,8 +122,9 @@ def parse(spec, ch=3):
 OP_DTYPE = np.dtype([("type", "<i4"), ("in_buf", "<i4"), ("in_ld", "<i4"), ("in_coff", "<i4"), ("H", "<i4"), ("W", "<i4"), ("Cin", "<i4"),
                      ("out_buf", "<i4"), ("out_ld", "<i4"), ("out_coff", "<i4"), ("out_f32", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"),
                      ("Cout", "<i4"), ("Cout_pad", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("K", "<i4"),
-                     ("K_pad", "<i4"), ("act", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4"), ("w_off", "<i8"), ("bias_off", "<i8")], align=False)
-assert OP_DTYPE.itemsize == 112   # == sizeof(y7t_op) in include/y7t.h
+                     ("K_pad", "<i4"), ("act", "<i4"), ("korder", "<i4"), ("detect_level", "<i4"), ("w_off", "<i8"), ("bias_off", "<i8"),
+                     ("up_buf", "<i4"), ("up_ld", "<i4"), ("up_coff", "<i4"), ("up_c0", "<i4"), ("up_C", "<i4"), ("pad0", "<i4")], align=False)
+assert OP_DTYPE.itemsize == 136   # == sizeof(y7t_op) in include/y7t.h
 
 
 def _rup(x, m):
@@ -198,6 +200,7 @@ def lower(nodes, H, W, max_batch=1):
                 else:
                     extra_copies.append((j, n.idx, off))
                 off += t.c
+    pending_src = {j for j, _, _ in extra_copies}
     first = nodes[1] if len(nodes) > 1 and nodes[1].kind == "reorg" else None
     in_ld = 16 if first is not None else 8
     nodes[0].home, nodes[0].coff, nodes[0].ld = None, 0, 0
@@ -220,12 +223,35 @@ def lower(nodes, H, W, max_batch=1):
     img_node.home, img_node.coff, img_node.ld = 0, 0, in_ld
     if first is not None:
         nodes[0].home = None
+    # ---- upsample-on-read (cfg/deploy/yolov7-w6.yaml:75,89,103): an nn.Upsample whose only consumer is a Concat that only 1x1 / stride-1
+    # convs read is never materialised -- those convs fetch its channel range from the half-resolution tensor at (y >> 1, x >> 1) ----
+    if os.environ.get("Y7T_UPSAMPLE_ON_READ", "1") != "0":
+        users = {}
+        for m in nodes:
+            if m.idx in live or m.kind == "detect":
+                for j in m.src:
+                    users.setdefault(j, []).append(m)
+        for n in nodes:
+            if n.idx not in live or n.kind != "up":
+                continue
+            cons = users.get(n.idx, [])
+            if len(cons) != 1 or cons[0].kind != "concat" or cons[0].virt_up is not None:
+                continue
+            c = cons[0]
+            readers = users.get(c.idx, [])
+            off = sum(nodes[j].c for j in c.src[:c.src.index(n.idx)])
+            t = nodes[n.src[0]]
+            ok = readers and all(r.kind == "conv" and r.k == 1 and r.s == 1 and r.p == 0 for r in readers) and c.c % 64 == 0 and \
+                n.c % 32 == 0 and off % 32 == 0 and n.home == c.home and t.home is not None and t.ld % 8 == 0 and t.coff % 8 == 0 and \
+                n.h % 2 == 0 and n.w % 2 == 0 and n.idx not in pending_src
+            if ok:
+                c.virt_up, n.virtual = (n, off), True
     # ---- ops ----
     ops, wlayout = [], []   # wlayout: (wkey, cin_real, cin_pad, cout, cout_pad, k, K, K_pad, w_off, b_off, kind)
     w_off = b_off = 0
     heads = []
 
-    def emit_conv(n, src, out_buf, out_ld, out_coff, out_f32, cout, act, wkey, kind="conv"):
+    def emit_conv(n, src, out_buf, out_ld, out_coff, out_f32, cout, act, wkey, kind="conv", level=-1):
         nonlocal w_off, b_off
         cin_real = src.c
         cin = _rup(cin_real, 8) if src.kind not in ("input", "reorg") else in_ld
@@ -245,7 +271,11 @@ def lower(nodes, H, W, max_batch=1):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
-        op["w_off"], op["bias_off"], op["reserved0"] = w_off, b_off, korder
+        op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level
+        if getattr(src, "virt_up", None) is not None:      # upsample-on-read: part of this concat exists only at half resolution
+            un, uoff = src.virt_up
+            t = nodes[un.src[0]]
+            op["up_buf"], op["up_ld"], op["up_coff"], op["up_c0"], op["up_C"] = t.home, t.ld, t.coff, uoff, un.c
         ops.append(op)
         wlayout.append(dict(korder=korder, wkey=wkey, cin=cin_real, cin_pad=cin, cout=cout, cout_pad=cout_pad, k=n.k, K=K, K_pad=K_pad, w_off=w_off,
                             b_off=b_off, kind=kind, act=act, macs=n.h * n.w * cout * n.k * n.k * cin_real))
@@ -260,6 +290,7 @@ def lower(nodes, H, W, max_batch=1):
         op["out_buf"], op["out_ld"], op["out_coff"] = out_home, out_ld, out_coff
         op["Ho"], op["Wo"], op["Cout"] = (src.h + 2 * p - k) // s + 1 if typ == 2 else n.h, (src.w + 2 * p - k) // s + 1 if typ == 2 else n.w, src.c
         op["KH"], op["KW"], op["stride"], op["pad"] = k, k, s, p
+        op["detect_level"] = -1
         ops.append(op)
 
     # ---- twin 1x1 branches (every ELAN block starts with two 1x1 convs of the SAME tensor, cfg/deploy/yolov7-w6.yaml:20-21,
@@ -305,7 +336,8 @@ def lower(nodes, H, W, max_batch=1):
             else:
                 emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
         elif n.kind == "up":
-            emit_simple(1, n, nodes[n.src[0]])
+            if not n.virtual:
+                emit_simple(1, n, nodes[n.src[0]])
         elif n.kind == "pool":
             emit_simple(2, n, nodes[n.src[0]], n.k, n.s, n.p)
         elif n.kind == "detect":
@@ -316,7 +348,7 @@ def lower(nodes, H, W, max_batch=1):
                 hn.h, hn.w = src.h, src.w
                 hb = len(table)
                 table.append((src.h * src.w * ex["na"] * ex["no"], 4))
-                emit_conv(hn, src, hb, ex["na"] * ex["no"], 0, 1, ex["na"] * ex["no"], 0, "model.%d.m.%d" % (n.layer, l), kind=ex["kind"])
+                emit_conv(hn, src, hb, ex["na"] * ex["no"], 0, 1, ex["na"] * ex["no"], 0, "model.%d.m.%d" % (n.layer, l), kind=ex["kind"], level=l)
                 wlayout[-1]["level"] = l
                 heads.append(dict(buf=hb, ny=src.h, nx=src.w, stride=H // src.h))
         for cidx, off in pending_copies.get(n.idx, []):   # tensor that sits in a second concat: copy (1x1 max-pool)

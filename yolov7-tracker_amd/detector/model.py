@@ -31,11 +31,16 @@ def check_img_size(img_size, s=32):
 
 
 class HeadOutput:
-    """what `model(img)[0]` stands for: the raw Detect conv outputs of one forward, still on the device"""
+    """what `model(img)[0]` stands for: the Detect outputs of one forward, still on the device.  Either the four raw head tensors
+    (in the arena, or a staged private copy) or -- after a fused forward -- the candidate list the Detect epilogues wrote
+    (post-processing set `pset`); the reference's (B, A, 5+nc) tensor is only built on request (`decoded()` / indexing / numpy)."""
 
-    def __init__(self, det, B, img_shape, staged=None):
+    def __init__(self, det, B, img_shape, staged=None, fused=None, pset=0):
         self.det, self.B, self.img_shape = det, B, img_shape
         self.staged = staged        # (tensors, ctypes pointer array) of a private copy of the head buffers, or None = the arena
+        self.fused = fused          # conf_thres the fused Detect epilogues filtered with, or None
+        self.pset = pset
+        self._epoch = det._epoch
 
     @property
     def shape(self):
@@ -43,8 +48,11 @@ class HeadOutput:
         return (self.B, sum(p.det["na"] * h["ny"] * h["nx"] for h in p.heads), p.det["no"])
 
     def raw(self):
-        """list of (B, na, ny, nx, no) float32 tensors == the second element the reference's Detect returns"""
+        """list of (B, na, ny, nx, no) float32 tensors == the second element the reference's Detect returns.  After a fused forward
+        the head tensors do not exist yet: the four Detect 1x1 convs are re-run in plain mode on the activations still in the arena."""
         p, out = self.det.plan, []
+        if self.fused is not None and self.staged is None:
+            self.det._materialise_heads(self)
         for l, h in enumerate(p.heads):
             t = self.det.head_tensor(l, self.B).reshape(self.B, h["ny"], h["nx"], p.det["na"], p.det["no"])
             out.append(t.permute(0, 3, 1, 2, 4).contiguous())
@@ -64,10 +72,40 @@ class HeadOutput:
             z.append(y.view(self.B, -1, p.det["no"]))
         return torch.cat(z, 1)
 
-    def __getitem__(self, i):   # `out = model(img); out = out[0]`
-        if i == 0:
-            return self
-        raise IndexError(i)
+    # -- lazy tensor view: code written against the reference's `pred = model(img)[0]` tensor keeps working ------------------------
+    def __getitem__(self, i):   # (`model(img)` is the tuple `(HeadOutput,)`, so `model(img)[0]` is this handle; indexing IT indexes the tensor)
+        return self.decoded()[i]
+
+    def tensor(self):
+        return self.decoded()
+
+    def cpu(self):
+        return self.decoded().cpu()
+
+    def float(self):
+        return self.decoded()
+
+    def numpy(self):
+        return self.decoded().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.B
+
+    @property
+    def device(self):
+        return torch.device("cuda")
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+
+class Plan_PostSet:
+    """workspace + outputs of one decode/NMS chain (y7t_det_postprocess)"""
 
 
 class Detector:
@@ -85,6 +123,7 @@ class Detector:
         # seeded random weights only (state_dict None): see weights.random_state_dict / calibrate_bn
         self._bn_bias_mean, self._calib_image = float(bn_bias_mean), calib_image
         self._plans = {}
+        self._epoch = 0             # forwards run so far (a HeadOutput is only valid against the arena of its own forward)
         self.plan = None
         self._handle = None
         strides = None
@@ -124,11 +163,17 @@ class Detector:
             # candidate capacity: every anchor fits (no overflow, like the reference); NMS works on the top MAX_NMS of them
             plan.cap = int(self._max_cand_arg) if self._max_cand_arg else (n_anchors + 63) // 64 * 64
             B, cap = self.max_batch, plan.cap
-            plan.ws = torch.zeros(int(self._L.y7t_det_postprocess_workspace_bytes(B, cap, MAX_NMS)), dtype=torch.uint8, device="cuda")
-            plan.dets = torch.zeros((B, MAX_DET, 6), dtype=torch.float32, device="cuda")
-            plan.ndets = torch.zeros(B, dtype=torch.int32, device="cuda")
-            plan.keep = torch.zeros((B, MAX_DET), dtype=torch.int32, device="cuda")
-            plan.cand = torch.zeros(B, dtype=torch.int32, device="cuda")
+            ws_bytes = int(self._L.y7t_det_postprocess_workspace_bytes(B, cap, MAX_NMS))
+            plan.post = []          # two post-processing sets: decode+NMS of batch n can run beside the forward of batch n+1
+            for _ in range(2):
+                ps = Plan_PostSet()
+                ps.ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+                ps.dets = torch.zeros((B, MAX_DET, 6), dtype=torch.float32, device="cuda")
+                ps.ndets = torch.zeros(B, dtype=torch.int32, device="cuda")
+                ps.keep = torch.zeros((B, MAX_DET), dtype=torch.int32, device="cuda")
+                ps.cand = torch.zeros(B, dtype=torch.int32, device="cuda")
+                plan.post.append(ps)
+            plan.ws, plan.dets, plan.ndets, plan.keep, plan.cand = (getattr(plan.post[0], k) for k in ("ws", "dets", "ndets", "keep", "cand"))
             plan.lb = torch.zeros((B, 5), dtype=torch.float32, device="cuda")
             plan.head_ptrs = (ctypes.c_void_p * 4)(*[plan.arena.data_ptr() + int(plan.buf_offsets[hd["buf"]]) for hd in plan.heads] +
                                                    [None] * (4 - len(plan.heads)))
@@ -137,6 +182,9 @@ class Detector:
             plan.strides = (ctypes.c_float * 4)(*[float(hd["stride"]) for hd in plan.heads] + [0.0] * (4 - len(plan.heads)))
             flat = [float(v) for lvl in self.spec["anchors"] for v in lvl]
             plan.anchors = (ctypes.c_float * 24)(*(flat + [0.0] * (24 - len(flat))))
+            _lib.check(self._L.y7t_det_set_detect(h, len(plan.heads), plan.det["na"], plan.det["no"], plan.strides, plan.anchors))
+            plan.detect_ops = [i for i, op in enumerate(plan.ops) if int(op["type"]) == 0 and int(op["detect_level"]) >= 0]
+            plan.fusable = plan.det["na"] * plan.det["no"] <= 64 and all(int(plan.ops[i]["Cin"]) % 64 == 0 for i in plan.detect_ops)
             self._plans[hw] = plan
         self.plan = self._plans[hw]
         self.max_cand = self.plan.cap
@@ -156,9 +204,21 @@ class Detector:
         return p.arena[off:off + 2 * elems * B].view(torch.float16).view(B, -1, C)
 
     # -- forward ---------------------------------------------------------------------------------------
-    def forward(self, img, mid_hook=None):
+    def _run_ops(self, B, first, last, fuse_decode, pset):
+        p, s = self.plan, _lib.stream_ptr()
+        if fuse_decode is None:
+            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, int(first), int(last), s))
+        else:
+            ps = p.post[pset]
+            _lib.check(self._L.y7t_det_forward_fused(p.handle, B, int(first), int(last), float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(ps.ws),
+                                                     ps.ws.numel(), s))
+
+    def forward(self, img, mid_hook=None, fuse_decode=None, pset=0):
         """img: (B,3,H,W) float32 RGB in [0,1] (the reference's input) or (B,H,W,3) uint8 BGR frames (fused
-        BGR->RGB, /255).  -> HeadOutput."""
+        BGR->RGB, /255).  -> HeadOutput.
+        fuse_decode = conf_thres: the Detect 1x1 convs decode + filter in their epilogue straight into the candidate arrays of
+        post-processing set `pset` (y7t_det_forward_fused); the head tensors are not written and `postprocess` skips its decode
+        pass.  The threshold is fixed at forward time -- the tracking path always uses 0.01 (tracker/track.py:239)."""
         if img.dim() == 3:
             img = img[None]
         if img.device.type != "cuda":
@@ -174,19 +234,22 @@ class Detector:
             raise ValueError("batch %d > max_batch %d" % (B, self.max_batch))
         self._select((H, W))
         p = self.plan
+        if fuse_decode is not None and not p.fusable:
+            fuse_decode = None          # e.g. nc = 80: 255 head channels do not fit one channel tile -> plain heads + decode pass
         s = _lib.stream_ptr()
         _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
         if mid_hook is None:
-            _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+            self._run_ops(B, 0, -1, fuse_decode, pset)
         else:   # (op index, callable): run the list up to that op, call the hook (e.g. record an event), run the rest
             k = min(int(mid_hook[0]), int(self._L.y7t_det_num_ops(p.handle)))
-            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, 0, k, s))
+            self._run_ops(B, 0, k, fuse_decode, pset)
             mid_hook[1]()
-            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, k, -1, s))
+            self._run_ops(B, k, -1, fuse_decode, pset)
         self._img_keep = img
-        return HeadOutput(self, B, (H, W))
+        self._epoch += 1
+        return HeadOutput(self, B, (H, W), fused=fuse_decode, pset=pset)
 
-    def forward_part(self, img, first, last):
+    def forward_part(self, img, first, last, fuse_decode=None, pset=0):
         """ops [first, last) of the current plan's launch list on the current stream (last < 0: to the end); with `img` (uint8
         NHWC or float32 NCHW device tensor of the plan's size) the input layout runs first.  For callers that capture the
         forward in pieces (bench.py --hipgraph 2); `forward` must have selected the plan before."""
@@ -197,7 +260,16 @@ class Detector:
             H, W = (img.shape[1], img.shape[2]) if is_u8 else (img.shape[2], img.shape[3])
             _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
             self._part_B = B
-        _lib.check(self._L.y7t_det_forward_ops(p.handle, self._part_B, int(first), int(last), s))
+        self._run_ops(self._part_B, first, last, fuse_decode if p.fusable else None, pset)
+
+    def _materialise_heads(self, out):
+        """re-run the Detect 1x1 convs of `out`'s forward in plain mode (fp32 head tensors into the arena)"""
+        if out._epoch != self._epoch:
+            raise _lib.Y7TError("the activations of this forward have been overwritten by a later one: the raw heads of a fused forward "
+                                "can only be materialised before the next forward")
+        p = self.plan
+        for i in p.detect_ops:
+            _lib.check(self._L.y7t_det_forward_ops(p.handle, out.B, i, i + 1, _lib.stream_ptr()))
 
     def plant_objectness_bias(self, frames, target=2000, level_offsets=None):
         """No trained checkpoint ships with the reference, and a randomly initialised Detect head fires on ~half of the 102 000
@@ -260,7 +332,7 @@ class Detector:
         left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
         return new_h + top + bottom, new_w + left + right, new_h, new_w, top, left
 
-    def forward_frames(self, frames, img_size=1280):
+    def forward_frames(self, frames, img_size=1280, fuse_decode=None, pset=0):
         """raw (B,H0,W0,3) uint8 BGR frames (device or host) -> letterbox + layout on the device + forward.
         -> (HeadOutput, letterboxed (H, W)).  What TrackerLoader.__getitem__ + model(img) do in the reference."""
         if frames.dim() == 3:
@@ -274,9 +346,12 @@ class Detector:
         s = _lib.stream_ptr()
         _lib.check(self._L.y7t_letterbox_layout_u8(_lib.ptr(frames), B, H0, W0, H, W, new_h, new_w, top, left, int(p.reorg), _lib.ptr(p.arena),
                                                    p.in_ld, s))
-        _lib.check(self._L.y7t_det_forward(p.handle, B, s))
+        if fuse_decode is not None and not p.fusable:
+            fuse_decode = None
+        self._run_ops(B, 0, -1, fuse_decode, pset)
         self._img_keep = frames
-        return HeadOutput(self, B, (H, W)), (H, W)
+        self._epoch += 1
+        return HeadOutput(self, B, (H, W), fused=fuse_decode, pset=pset), (H, W)
 
     def __call__(self, img, augment=False):
         return (self.forward(img),)
@@ -295,12 +370,19 @@ class Detector:
         if getattr(p, "_lb_key", None) != key:
             p.lb[:B].copy_(torch.from_numpy(lb))
             p._lb_key = key
-        head_ptrs = out.staged[1] if getattr(out, "staged", None) is not None else p.head_ptrs
+        ps = p.post[out.pset]
+        if out.fused is not None:
+            if abs(float(conf_thres) - float(out.fused)) > 1e-12:
+                raise ValueError("this forward fused the Detect decode with conf_thres=%g; post-processing it with %g needs a plain forward"
+                                 % (out.fused, conf_thres))
+            head_ptrs = None            # the candidates are already in ps.ws
+        else:
+            head_ptrs = out.staged[1] if getattr(out, "staged", None) is not None else p.head_ptrs
         _lib.check(self._L.y7t_det_postprocess(head_ptrs, p.ny, p.nx, p.strides, p.anchors, len(p.heads), p.det["na"], p.det["no"], B,
                                                float(conf_thres), float(iou_thres), MAX_DET, MAX_NMS, self.max_cand, _lib.ptr(p.lb),
-                                               _lib.ptr(p.dets), _lib.ptr(p.ndets), _lib.ptr(p.keep), _lib.ptr(p.cand), _lib.ptr(p.ws),
-                                               p.ws.numel(), _lib.stream_ptr()))
-        return p.dets, p.ndets
+                                               _lib.ptr(ps.dets), _lib.ptr(ps.ndets), _lib.ptr(ps.keep), _lib.ptr(ps.cand), _lib.ptr(ps.ws),
+                                               ps.ws.numel(), _lib.stream_ptr()))
+        return ps.dets, ps.ndets
 
     def stage_heads(self, out):
         """Copy the four raw head buffers of `out` (a few MB per frame, device to device, on the current stream) into a staging
@@ -313,24 +395,24 @@ class Detector:
             p._stage = (ts, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts] + [None] * (4 - len(ts))))
         for l, t in enumerate(p._stage[0]):
             t[:out.B].copy_(self.head_tensor(l, out.B), non_blocking=True)
-        return HeadOutput(self, out.B, out.img_shape, staged=p._stage)
+        return HeadOutput(self, out.B, out.img_shape, staged=p._stage, pset=out.pset)
 
     def capture(self, img, conf_thres=0.01, iou_thres=0.45, ori_shapes=None):
         """Capture input layout + the whole conv launch list + decode/NMS for the (fixed) device buffer `img` into a
         hipGraph (torch.cuda.CUDAGraph drives the capture; every launch of liby7t.so goes to the capturing stream, and
         nothing in the list allocates or synchronises).  Returns (graph, dets, ndets): `graph.replay()` re-runs the chain
         on whatever `img` holds, with no per-launch host cost."""
-        out = self.forward(img)                      # warm-up: plan selection, attribute setup, letterbox upload
+        out = self.forward(img, fuse_decode=conf_thres)   # warm-up: plan selection, attribute setup, letterbox upload
         self.postprocess(out, conf_thres, iou_thres, ori_shapes)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self.forward(img)
+            out = self.forward(img, fuse_decode=conf_thres)
             dets, nd = self.postprocess(out, conf_thres, iou_thres, ori_shapes)
         return g, dets, nd
 
     def check_overflow(self):
-        c = int(self.plan.cand.max().item())
+        c = max(int(ps.cand.max().item()) for ps in self.plan.post)
         if c > self.max_cand:
             raise _lib.Y7TError("%d NMS candidates exceed max_cand=%d" % (c, self.max_cand))
 
@@ -355,7 +437,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     """utils/general.py:607-695 for the arguments the tracking path uses (classes=None, agnostic=False, multi_label=False).
     prediction: the HeadOutput returned by Detector.  -> list of (n, 6) tensors [xyxy, conf, cls], score-descending."""
     if not isinstance(prediction, HeadOutput):
-        raise TypeError("non_max_suppression expects the detector's HeadOutput (the decoded tensor is never materialised)")
+        raise TypeError("non_max_suppression expects the detector's HeadOutput (the decoded tensor is only materialised on request: "
+                        "HeadOutput.decoded())")
     if classes is not None or agnostic or multi_label or labels:
         raise NotImplementedError("only the tracking path's NMS arguments are implemented")
     det = prediction.det
@@ -365,7 +448,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     out = []
     for b in range(prediction.B):
         d = dets[b, :nd[b]].clone()
-        d[:, :4] = det.plan_raw_boxes(b, int(nd[b]))   # un-rounded boxes: rounding is the caller's (track.py:240)
+        d[:, :4] = det.plan_raw_boxes(b, int(nd[b]), prediction.pset)   # un-rounded boxes: rounding is the caller's (track.py:240)
         out.append(d)
     return out
 
@@ -387,12 +470,12 @@ def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
     return coords
 
 
-def _plan_raw_boxes(self, b, n):
+def _plan_raw_boxes(self, b, n, pset=0):
     """xyxy of the kept detections before scale_coords/round (candidate boxes gathered by the kept slots)"""
-    p = self.plan
+    ps = self.plan.post[pset]
     cap = self.max_cand
-    cbox = p.ws[:self.max_batch * cap * 16].view(torch.float32).view(self.max_batch, cap, 4)
-    idx = p.keep[b, :n].long()
+    cbox = ps.ws[:self.max_batch * cap * 16].view(torch.float32).view(self.max_batch, cap, 4)
+    idx = ps.keep[b, :n].long()
     return cbox[b, idx]
 
 

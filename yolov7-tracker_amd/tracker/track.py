@@ -96,10 +96,11 @@ def main(opts, cfgs):
             detect = [not (i + 1 + k) % opts.detect_per_frame for k in range(nb)]
             outs = None
             if any(detect):
+                # conf_thres 0.01 (track.py:239) is known here, so the Detect convs decode + filter in their epilogue (fused forward)
                 if opts.device_preprocess:      # raw uint8 frames -> letterbox + layout on the GPU
-                    head, lb_size = model.forward_frames(imgs0, img_size=opts.img_size)
+                    head, lb_size = model.forward_frames(imgs0, img_size=opts.img_size, fuse_decode=0.01)
                 else:
-                    head, lb_size = model(imgs.cuda())[0], imgs.shape[2:]
+                    head, lb_size = model.forward(imgs.cuda(), fuse_decode=0.01), imgs.shape[2:]
                 outs = post_process_v7(head, img_size=lb_size, ori_img_size=imgs0.shape[1:], all_images=True)
             for k in range(nb):
                 if k:
