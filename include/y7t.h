@@ -30,7 +30,7 @@ enum { Y7T_OK = 0, Y7T_E_ARG = -1, Y7T_E_HIP = -2, Y7T_E_CAPACITY = -3, Y7T_E_ST
 /* Kalman filter kinds == KALMAN_DICT keys, tracker/basetrack.py:64-69 */
 enum { Y7T_KALMAN_DEFAULT = 0, Y7T_KALMAN_NAIVE = 1, Y7T_KALMAN_BOTSORT = 2, Y7T_KALMAN_STRONGSORT = 3 };
 /* tracker kinds == TRACKER_DICT keys implemented on the device, tracker/track.py:56-65 */
-enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1, Y7T_TRACKER_BOTSORT = 2 };
+enum { Y7T_TRACKER_SORT = 0, Y7T_TRACKER_BYTETRACK = 1, Y7T_TRACKER_BOTSORT = 2, Y7T_TRACKER_DEEPSORT = 3 };
 
 const char* y7t_last_error(void);
 int y7t_version(void);
@@ -116,6 +116,20 @@ int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, in
  * GMC.apply returns (botsort.py:13-248 -- OpenCV ORB/RANSAC estimation, out of scope); the step applies multi_gmc
  * (botsort.py:250-269) to the predicted pool and the unconfirmed tracks.  Same op on its own: */
 int y7t_kf_multi_gmc_f64(double* mean, double* cov, const double* warp, int N, y7t_stream stream);
+
+/* DeepSORT (tracker/deepsort.py:79-227, tracker kind Y7T_TRACKER_DEEPSORT): appearance + motion.  Next to the pool blob the tracker owns
+ * a FEATURE STATE (y7t_deepsort_feature_bytes, y7t_deepsort_init): per slot the last `budget` appearance vectors of the track
+ * (STrack.features, basetrack.py:97-103,324-332; budget = store_features_budget = 100) plus per-frame scratch.
+ * y7t_tracker_step_deepsort = DeepSORT.update for one frame:
+ *   det_feats   n x feat_dim float32, row j = what DeepSORT.get_feature (deepsort.py:19-41 -> the ReID network) returns for detection row j
+ *               (only rows with conf > conf_thresh are read)
+ *   launches: normalise the features, nearest_embedding_distance (tracker/matching.py:105-127) for every live slot (one workgroup per
+ *   slot), then ONE workgroup for matching_cascade with gate_cost_matrix (matching.py:216-277, deepsort.py:43-66), the two IoU
+ *   associations and the list bookkeeping.  update_without_detection: y7t_tracker_step(state, NULL, -1, ...) as for every tracker. */
+size_t y7t_deepsort_feature_bytes(int cap_tracks, int cap_dets, int feat_dim, int budget);
+int y7t_deepsort_init(void* feat_state, size_t bytes, int cap_tracks, int cap_dets, int feat_dim, int budget, y7t_stream stream);
+int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_tracks, const float* dets, int n, const float* det_feats, double* out_rows,
+                              int out_cap, int* out_count, int threads, y7t_stream stream);
 
 /* byte offsets of the arrays inside a state blob, for host-side views (tracked_stracks, lost_stracks, ...).
  * names/offsets: see y7t_tracker_field_name(i); returns the number of fields. */

@@ -14,7 +14,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "yolov7-tracker_am
 
 
 def build(force=False):
-    deps = [_SRC, os.path.join(_CSRC, "y7t_track_core.h"), os.path.join(_CSRC, "y7t_track_step.h")]
+    deps = [_SRC, os.path.join(_CSRC, "y7t_track_core.h"), os.path.join(_CSRC, "y7t_track_step.h"), os.path.join(_CSRC, "y7t_track_deepsort.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO, _SRC])
     return _SO
@@ -42,8 +42,24 @@ def lib():
         L.hs_kf_project.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_kf_gating.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.hs_kf_gating.restype = ctypes.c_double
+        L.hs_feat_bytes.restype = ctypes.c_size_t
+        L.hs_feat_bytes.argtypes = [ctypes.c_int] * 4
+        L.hs_feat_init.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+        L.hs_deepsort_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.hs_feat_status.argtypes = [ctypes.c_void_p]
+        L.hs_pyset_difference.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib = L
     return _lib
+
+
+def pyset_difference(n, matched):
+    """order of `list(set(range(n)) - set(matched))` as the device program emulates it"""
+    member = np.zeros(max(n, 1), np.int32)
+    member[list(matched)] = 1
+    out = np.zeros(max(n, 1), np.int32)
+    c = lib().hs_pyset_difference(n, member.ctypes.data, len(set(matched)), out.ctypes.data)
+    assert c >= 0
+    return out[:c].tolist()
 
 
 def lapjv(cost, limit, sap=False):
@@ -61,11 +77,11 @@ def lapjv(cost, limit, sap=False):
 
 
 class HostSimTracker:
-    TRACKERS = {"sort": 0, "bytetrack": 1, "botsort": 2}
+    TRACKERS = {"sort": 0, "bytetrack": 1, "botsort": 2, "deepsort": 3}
     KINDS = {"default": 0, "naive": 1, "botsort": 2, "strongsort": 3}
 
     def __init__(self, kind="bytetrack", conf_thresh=0.2, track_buffer=30, kalman_format="default", iou_thresh=0.5,
-                 frame_rate=30, cap_t=1024, cap_d=1024, ids=None, f32_quirk=1):
+                 frame_rate=30, cap_t=1024, cap_d=1024, ids=None, f32_quirk=1, feature_fn=None, feat_dim=128, feat_budget=100):
         self.ids = ids if ids is not None else np.zeros(1, np.int32)
         n = lib().hs_tracker_bytes(cap_t, cap_d)
         self.blob = np.zeros(n, np.uint8)
@@ -74,8 +90,22 @@ class HostSimTracker:
                               int(frame_rate / 30.0 * track_buffer), f32_quirk, conf_thresh, max(0.15, conf_thresh - 0.3),
                               iou_thresh, self.ids.ctypes.data)
         self.out = np.zeros((cap_t, 8), np.float64)
+        self.kind, self.feature_fn, self.feat_dim = kind, feature_fn, feat_dim
+        if kind == "deepsort":
+            self.fblob = np.zeros(lib().hs_feat_bytes(cap_t, cap_d, feat_dim, feat_budget), np.uint8)
+            lib().hs_feat_init(self.fblob.ctypes.data, cap_t, cap_d, feat_dim, feat_budget)
 
     def update(self, det, warp=None):
+        if self.kind == "deepsort" and det is not None:
+            det = np.ascontiguousarray(det, dtype=np.float32).reshape(-1, 6)
+            feats = np.zeros((max(len(det), 1), self.feat_dim), np.float32)
+            if len(det):
+                feats[:len(det)] = self.feature_fn(det[:, :4])     # (the reference extracts them for the rows above det_thresh only)
+            cnt = lib().hs_deepsort_step(self.blob.ctypes.data, self.fblob.ctypes.data, det.ctypes.data, det.shape[0], feats.ctypes.data,
+                                         self.out.ctypes.data, self.cap_t)
+            if lib().hs_tracker_status(self.blob.ctypes.data) or lib().hs_feat_status(self.fblob.ctypes.data):
+                raise RuntimeError("tracker capacity exceeded")
+            return [(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in self.out[:cnt]]
         wp = None
         if warp is not None:
             self._warp = np.ascontiguousarray(warp, dtype=np.float64).reshape(6)

@@ -4,6 +4,7 @@
 // `-m "not gpu"` suite where no GPU exists.  The product package never loads this library.
 #define Y7T_HOSTSIM 1
 #include "../../yolov7-tracker_amd/csrc/y7t_track_step.h"
+#include "../../yolov7-tracker_amd/csrc/y7t_track_deepsort.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -59,4 +60,28 @@ void hs_kf_predict(int kind, double* mean, double* cov) { y7t_kf_predict(kind, m
 void hs_kf_update(int kind, double* mean, double* cov, const double* z, double conf) { y7t_kf_update(kind, mean, cov, z, conf); }
 void hs_kf_project(int kind, const double* mean, const double* cov, double conf, double* pm, double* S) { y7t_kf_project(kind, mean, cov, conf, pm, S); }
 double hs_kf_gating(int kind, const double* mean, const double* cov, const double* z, int only_pos) { return y7t_kf_gating(kind, mean, cov, z, only_pos); }
+
+// ---- DeepSORT (y7t_track_deepsort.h) ----
+size_t hs_feat_bytes(int cap_t, int cap_d, int dim, int budget) { return y7t_feat_layout(cap_t, cap_d, dim, budget).total; }
+void hs_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budget) { y7t_feat_init(hs_ex(), fblob, cap_t, cap_d, dim, budget); }
+int hs_deepsort_step(void* blob, void* fblob, const float* dets, int n, const float* feats, double* out_rows, int out_cap) {
+    int cnt = 0;
+    const Y7TExec ex = hs_ex();
+    Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
+    const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
+    const Y7TFeat f = y7t_feat_bind(fblob);
+    y7t_feat_normalize_dets(ex, f, feats, n);
+    for (int k = 0; k < h->n_tracked; ++k) y7t_embed_slot(ex, f, s.tracked[k], n);
+    for (int k = 0; k < h->n_lost; ++k) y7t_embed_slot(ex, f, s.lost[k], n);
+    y7t_tracker_step_deepsort(ex, blob, fblob, dets, n, feats, out_rows, out_cap, &cnt);
+    return cnt;
+}
+int hs_feat_status(void* fblob) { return ((Y7TFeatHdr*)fblob)->status; }
+int hs_pyset_difference(int n, const int* member, int n_other, int* out) {
+    int* tab = (int*)malloc(sizeof(int) * 2 * Y7T_PYSET_CAP);
+    int st = 0;
+    const int c = y7t_pyset_difference(n, member, n_other, out, tab, &st);
+    free(tab);
+    return st ? -1 : c;
+}
 }

@@ -18,6 +18,27 @@ def test_hostsim_tracker_matches_reference_golden(name):
     util.assert_same_tracks(got, want, name)
 
 
+@pytest.mark.parametrize("name", util.DEEPSORT_CASES)
+def test_hostsim_deepsort_matches_reference_golden(name):
+    """DeepSORT's workgroup program (csrc/y7t_track_deepsort.h): matching cascade over the gated appearance cost, the IoU fallbacks, the
+    reference's two index quirks -- ids AND boxes equal to the sequences recorded from the reference's deepsort.py"""
+    from yolov7_tracker_amd import synth
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    got = hs.run(trk, dets, kalman_format=fmt, feature_fn=synth.make_features)
+    util.assert_same_tracks(got, want, name)
+
+
+def test_hostsim_cpython_set_order_emulation():
+    """matching_cascade returns list(set(range(n)) - set(matched)) (matching.py:275); its ORDER is CPython's set-table order and decides
+    which tracks deepsort.py:171-173 marks lost -- the emulation must agree with the real thing"""
+    import random
+    rnd = random.Random(0)
+    for trial in range(1500):
+        n = rnd.choice([1, 2, 5, 8, 19, 20, 33, 77, 78, 100, 150, 307, 308, 400, 700, 1000, 1200]) if trial % 3 else rnd.randint(0, 1228)
+        m = rnd.sample(range(n), rnd.randint(0, n)) if n else []
+        assert hs.pyset_difference(n, m) == list(set(range(n)) - set(k for k in m)), (n, len(m))
+
+
 def test_hostsim_lapjv_equals_oracle():
     rng = np.random.default_rng(0)
     for t in range(200):

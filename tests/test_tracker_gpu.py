@@ -174,6 +174,47 @@ def test_batched_step_with_one_shared_id_counter(L):
     assert int(idc.item()) == n_new >= len(seen) > nseq * 40
 
 
+@pytest.mark.parametrize("name", util.DEEPSORT_CASES)
+def test_device_deepsort_matches_reference_golden(name):
+    """DeepSORT on the device (tracker kind 3; features injected at the reference's get_feature seam): ids and boxes of every frame equal
+    to the sequences recorded from the reference's deepsort.py (matching cascade, gate_cost_matrix, nearest_embedding_distance)"""
+    import types
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    assert trk == "deepsort"
+    BaseTrack._count = 0
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format=fmt, img_size=1280, iou_thresh=0.5))
+    t.get_feature = lambda tlbrs, img: synth.make_features(tlbrs)
+    got = []
+    for d in dets:
+        cur = t.update_without_detection() if d is None else t.update(d, None)
+        got.append([(c.track_id, c.tlwh, float(c.cls), float(c.score)) for c in cur])
+    util.assert_same_tracks(got, want, name)
+    assert len(t.tracked_stracks) > 0 and t.frame_id == len(dets)
+
+
+def test_deepsort_crops_reach_the_reid_callable():
+    """the default get_feature crops ori_img like deepsort.py:28-34 and hands the crops to reid_model"""
+    import types
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    seen = []
+
+    def reid(crops):
+        seen.append([c.shape for c in crops])
+        return np.stack([np.full(16, float(c.shape[0] * 100 + c.shape[1]), np.float32) + np.arange(16, dtype=np.float32) for c in crops])
+    BaseTrack._count = 0
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=640, iou_thresh=0.5), reid_model=reid)
+    img = np.zeros((480, 640, 3), np.uint8)
+    det = np.array([[10, 20, 50, 100, 0.9, 0], [200, 100, 260, 220, 0.8, 1], [300, 300, 320, 340, 0.1, 0]], np.float32)
+    cur = t.update(det, img)
+    assert seen == [[(80, 40, 3), (120, 60, 3)]] and [c.track_id for c in cur] == [1, 2]
+    cur = t.update(det + np.float32([2, 1, 2, 1, 0, 0]), img)
+    assert [c.track_id for c in cur] == [1, 2]
+
+
 def test_empty_and_ragged_frames():
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack

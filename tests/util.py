@@ -6,7 +6,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRACKER_CASES = ["sort_default", "bytetrack_default", "bytetrack_default_gaps", "bytetrack_botsort", "sort_strongsort",
                  "bytetrack_crowd", "botsort_gmc", "botsort_crowd"]
-ORACLE_ONLY_CASES = ["deepsort_default", "deepsort_crowd"]      # next row of SURVEY 8f: pinned restatement, no device path yet
+DEEPSORT_CASES = ["deepsort_default", "deepsort_crowd"]      # appearance features from synth.make_features at the get_feature seam
+ORACLE_ONLY_CASES = DEEPSORT_CASES
 # stated tolerance: ids / cls identical, tlwh within 1e-6 relative (scale: image size ~1e3 px)
 TLWH_RTOL, TLWH_ATOL = 1e-6, 1e-5
 

@@ -30,6 +30,9 @@ SIGNATURES = {
                                  c_void_p]),
     "y7t_tracker_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y7t_tracker_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "y7t_deepsort_feature_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "y7t_deepsort_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "y7t_tracker_step_deepsort": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "y7t_kf_multi_gmc_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "y7t_tracker_layout": (c_int, [c_int, c_int, c_void_p, c_int]),
     "y7t_tracker_field_name": (ctypes.c_char_p, [c_int]),

@@ -7,6 +7,7 @@
 // the fused step keeps the LAP work arrays and (when it fits) the cost matrix in LDS.
 #include "y7t_common.h"
 #include "y7t_track_step.h"
+#include "y7t_track_deepsort.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -174,6 +175,40 @@ __global__ void k_tracker_step1(void* state, const float* dets, int n, double* o
     y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
 }
 
+// ---- DeepSORT (y7t_track_deepsort.h) ----
+__global__ void k_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budget) {
+    Y7TExec ex;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    y7t_feat_init(ex, fblob, cap_t, cap_d, dim, budget);
+}
+
+// detection features of the frame -> normalised rows (a lane per detection)
+__global__ void __launch_bounds__(64) k_ds_normalize(void* fblob, const float* __restrict__ det_feats, int n) {
+    const Y7TFeat f = y7t_feat_bind(fblob);
+    Y7TExec ex;
+    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    y7t_feat_normalize_dets(ex, f, det_feats, n);
+}
+
+// nearest-embedding distances: one workgroup per pool slot that holds a live track
+__global__ void __launch_bounds__(128) k_embed_dist(void* blob, void* fblob, int n) {
+    const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;
+    const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
+    const int slot = blockIdx.x;
+    const int st = s.state[slot];
+    if (st != Y7T_TRACKED && st != Y7T_LOST) return;
+    const Y7TFeat f = y7t_feat_bind(fblob);
+    Y7TExec ex;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    y7t_embed_slot(ex, f, slot, n);
+}
+
+__global__ void k_tracker_step_deepsort(void* state, void* fblob, const float* dets, int n, const float* det_feats, double* out_rows,
+                                        int out_cap, int* out_count, unsigned fast_bytes) {
+    const Y7TExec ex = make_exec(fast_bytes);
+    y7t_tracker_step_deepsort(ex, state, fblob, dets, n, det_feats, out_rows, out_cap, out_count);
+}
+
 __global__ void __launch_bounds__(64) k_kf_gmc(double* mean, double* cov, const double* __restrict__ warp, int N) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
@@ -304,7 +339,11 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
                                 double conf_thresh, double iou_thresh, int max_time_lost, int flags, int* id_counter,
                                 y7t_stream stream) {
     Y7T_ARG_CHECK(state && id_counter && cap_t > 0 && cap_d > 0);
-    Y7T_ARG_CHECK(tracker_kind == Y7T_SORT || tracker_kind == Y7T_BYTETRACK || tracker_kind == Y7T_BOTSORT);
+    Y7T_ARG_CHECK(tracker_kind == Y7T_SORT || tracker_kind == Y7T_BYTETRACK || tracker_kind == Y7T_BOTSORT || tracker_kind == Y7T_DEEPSORT);
+    if (tracker_kind == Y7T_DEEPSORT && kalman_kind == Y7T_KF_XYWH) {
+        y7t_set_error("DeepSORT gates on xyah measurements (deepsort.py:59): kalman_format default / strongsort only");
+        return Y7T_E_ARG;
+    }
     if (!kind_ok(kalman_kind)) { y7t_set_error("kalman kind %d is not implemented on the device", kalman_kind); return Y7T_E_ARG; }
     Y7T_ARG_CHECK(state_bytes >= y7t_trk_layout(cap_t, cap_d).total);
     Y7TTrkCfg c;
@@ -362,6 +401,39 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
                        out_count, kFastBytes, gmc_warp);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t y7t_deepsort_feature_bytes(int cap_t, int cap_d, int feat_dim, int budget) {
+    if (cap_t <= 0 || cap_d <= 0 || feat_dim <= 0 || budget <= 0) return 0;
+    return y7t_feat_layout(cap_t, cap_d, feat_dim, budget).total;
+}
+
+extern "C" int y7t_deepsort_init(void* feat_state, size_t bytes, int cap_t, int cap_d, int feat_dim, int budget, y7t_stream stream) {
+    Y7T_ARG_CHECK(feat_state && cap_t > 0 && cap_d > 0 && feat_dim > 0 && budget > 0);
+    Y7T_ARG_CHECK(bytes >= y7t_feat_layout(cap_t, cap_d, feat_dim, budget).total);
+    hipLaunchKernelGGL(k_feat_init, dim3(1), dim3(256), 0, S(stream), feat_state, cap_t, cap_d, feat_dim, budget);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_tracks, const float* dets, int n, const float* det_feats,
+                                         double* out_rows, int out_cap, int* out_count, int threads, y7t_stream stream) {
+    Y7T_ARG_CHECK(state && feat_state && out_rows && out_count && out_cap >= 0 && cap_tracks > 0 && n >= 0);
+    Y7T_ARG_CHECK(n == 0 || (dets && det_feats));
+    const int nt = step_threads(threads, n);
+    Y7T_ARG_CHECK(nt > 0);
+    static bool attr_done = false;
+    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_deepsort, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_ds_normalize, dim3((n + 63) / 64), dim3(64), 0, S(stream), feat_state, det_feats, n);
+        Y7T_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_embed_dist, dim3(cap_tracks), dim3(128), 0, S(stream), state, feat_state, n);
+        Y7T_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_tracker_step_deepsort, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats,
+                       out_rows, out_cap, out_count, kFastBytes);
     Y7T_LAUNCH_CHECK();
     return 0;
 }

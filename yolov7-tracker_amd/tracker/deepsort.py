@@ -1,0 +1,89 @@
+"""DeepSORT (/root/reference/tracker/deepsort.py:10-227) on the device track pool: the matching cascade over the gated appearance
+cost (nearest cosine distance to a track's last 100 appearance vectors, Mahalanobis gate on the predicted Kalman state), the IoU
+fallbacks and the list bookkeeping run in liby7t.so (y7t_tracker_step_deepsort; csrc/y7t_track_deepsort.h).
+
+Appearance features enter at the reference's own seam, `get_feature(tlbrs, ori_img) -> (N, D)` (deepsort.py:19-41): by default it
+crops `ori_img` like the reference and calls `self.reid_model(crops)`; `reid_model` is any callable returning (N, D) features -- the
+device ReID extractor of this package (`tracker/reid.py`), or a stand-in.  The reference hard-wires `Extractor(opts.reid_model_path)`
+with weights/ckpt.t7, which does not ship with it."""
+import numpy as np
+import torch
+
+from .. import _lib
+from .basetrack import BaseTracker
+
+STORE_FEATURES_BUDGET = 100     # STrack.__init__ store_features_budget (basetrack.py:76)
+
+
+class DeepSORT(BaseTracker):
+    _KIND = 3  # Y7T_TRACKER_DEEPSORT
+
+    def __init__(self, opts, frame_rate=30, gamma=0.02, reid_model=None, *args, **kwargs):
+        if getattr(opts, "kalman_format", "default") not in ("default", "strongsort"):
+            raise NotImplementedError("DeepSORT gates on xyah measurements (deepsort.py:59): kalman_format default / strongsort")
+        super().__init__(opts, frame_rate=frame_rate)
+        self.reid_model = reid_model if reid_model is not None else getattr(opts, "reid_model", None)
+        self.gamma = gamma
+        self.filter_small_area = False
+        self._feat = None           # feature state, allocated when the feature dimension is known
+        self._feat_dim = 0
+
+    def get_feature(self, tlbrs, ori_img):
+        """deepsort.py:19-41: crops of the boxes -> self.reid_model(crops) -> (N, D) features"""
+        if self.reid_model is None:
+            raise _lib.Y7TError("DeepSORT needs appearance features: pass reid_model=<callable(list of crops) -> (N, D)> (e.g. "
+                                "yolov7_tracker_amd.tracker.reid.ReIDExtractor) or override get_feature")
+        if hasattr(self.reid_model, "features_for_boxes"):      # device extractor: crop + resize + normalise on the GPU
+            return self.reid_model.features_for_boxes(ori_img, tlbrs)
+        if isinstance(ori_img, torch.Tensor):
+            ori_img = ori_img.cpu().numpy()
+        crops = []
+        for tlbr in tlbrs:
+            x1, y1, x2, y2 = (int(v) for v in tlbr)
+            crops.append(ori_img[y1:y2, x1:x2])
+        return self.reid_model(crops) if crops else np.zeros((0, max(self._feat_dim, 1)), np.float32)
+
+    def _ensure_feature_state(self, dim):
+        if self._feat is None:
+            self._feat_dim = int(dim)
+            nb = int(self._L.y7t_deepsort_feature_bytes(self.cap_t, self.cap_d, self._feat_dim, STORE_FEATURES_BUDGET))
+            self._feat = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            _lib.check(self._L.y7t_deepsort_init(_lib.ptr(self._feat), nb, self.cap_t, self.cap_d, self._feat_dim, STORE_FEATURES_BUDGET,
+                                                 _lib.stream_ptr()))
+        elif int(dim) != self._feat_dim:
+            raise ValueError("feature dimension changed from %d to %d" % (self._feat_dim, int(dim)))
+
+    def update(self, det_results, ori_img=None):
+        """(N,6) [x1,y1,x2,y2,conf,cls] + the frame -> list of tracks (deepsort.py:79-227)"""
+        if isinstance(det_results, torch.Tensor):
+            det_host = det_results.detach().cpu().numpy()
+        else:
+            det_host = np.asarray(det_results)
+        det_host = np.ascontiguousarray(det_host, dtype=np.float32).reshape(-1, 6)
+        n = det_host.shape[0]
+        if n > self.cap_d:
+            raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (n, self.cap_d))
+        keep = det_host[:, 4] > np.float32(self.det_thresh)            # deepsort.py:98: only these get features
+        feats = None
+        if keep.any():
+            feats = self.get_feature(det_host[keep, :4], ori_img)
+            if not isinstance(feats, torch.Tensor):
+                feats = torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
+            feats = feats.to(device="cuda", dtype=torch.float32)
+            self._ensure_feature_state(feats.shape[1])
+        elif self._feat is None:
+            self._ensure_feature_state(self._feat_dim or 128)
+        d = torch.from_numpy(det_host).cuda()
+        allf = torch.zeros((max(n, 1), self._feat_dim), dtype=torch.float32, device="cuda")
+        if feats is not None:
+            allf[torch.from_numpy(np.nonzero(keep)[0]).cuda()] = feats
+        self._det_keep = (d, allf)
+        _lib.check(self._L.y7t_tracker_step_deepsort(_lib.ptr(self._state), _lib.ptr(self._feat), self.cap_t, _lib.ptr(d), n, _lib.ptr(allf),
+                                                     _lib.ptr(self._out), self.cap_t, self._count_ptr, self.threads, _lib.stream_ptr()))
+        self.frame_id += 1
+        self._snap_cache = None
+        rows = self._collect()
+        st = int(self._feat[20:24].view(torch.int32).item())            # Y7TFeatHdr.status
+        if st:
+            raise _lib.Y7TError("DeepSORT feature state overflow (status %d)" % st)
+        return rows

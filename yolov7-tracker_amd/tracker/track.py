@@ -20,10 +20,11 @@ from . import tracker_dataloader
 from .basetrack import BaseTracker
 from .bytetrack import ByteTrack
 from .botsort import BoTSORT
+from .deepsort import DeepSORT
 from .timer import Timer
 from ..detector import attempt_load, check_img_size, non_max_suppression, scale_coords
 
-TRACKER_DICT = {'sort': BaseTracker, 'bytetrack': ByteTrack, 'botsort': BoTSORT}   # track.py:56-65; the other trackers are out of scope
+TRACKER_DICT = {'sort': BaseTracker, 'bytetrack': ByteTrack, 'botsort': BoTSORT, 'deepsort': DeepSORT}   # track.py:56-65; the other trackers are out of scope
 
 timer = Timer()
 seq_fps = []
