@@ -217,6 +217,33 @@ int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const i
                         int max_nms, int cap, const float* letterbox, float* dets, int* ndets, int* keep_idx, int* cand_count,
                         void* workspace, size_t workspace_bytes, y7t_stream stream);
 
+/* ---------------------------------------------------------------- ReID embedding (DeepSORT's appearance branch) ---- */
+/* DeepSORT.get_feature -> Extractor (tracker/deepsort.py:19-41, tracker/reid_models/deepsort_reid.py:112-153) with OSNet
+ * (tracker/reid_models/OSNet.py:282-438) as the network: crops of the frame -> /255, bilinear resize to in_h x in_w (cv2.INTER_LINEAR
+ * geometry on the float image), Normalize(mean, std) in the frame's channel order -> the network in eval mode -> (N, feat_dim) float32.
+ * Like the detector, the network is a host-lowered op list (BatchNorm folded, fp32 weights in one blob) over a caller-owned arena. */
+enum { Y7T_REID_CONV = 0, Y7T_REID_DWCONV3 = 1, Y7T_REID_MAXPOOL3S2 = 2, Y7T_REID_AVGPOOL2 = 3, Y7T_REID_GATE_ACC = 4, Y7T_REID_ADD_RELU = 5,
+       Y7T_REID_GAP = 6, Y7T_REID_FC = 7 };
+typedef struct y7t_reid_op {
+    int32_t type;
+    int32_t in_buf, out_buf, aux_buf;   /* arena buffers; aux: second addend (ADD_RELU), pooled + gate scratch (GATE_ACC), -1 otherwise */
+    int32_t H, W, C;                    /* input map and channels */
+    int32_t Ho, Wo, Co;                 /* output map and channels (CONV, pools, FC) */
+    int32_t k, s, p;                    /* CONV window */
+    int32_t relu;                       /* CONV / DWCONV3 / FC: ReLU after the bias; GATE_ACC: 1 = first branch (overwrite the accumulator) */
+    int32_t R, pad0;                    /* GATE_ACC: hidden width of the gate MLP (C / 16) */
+    int64_t w_off, b_off;               /* float offsets into the weight blob (b_off < 0: no bias); GATE_ACC: fc1 weight / bias */
+    int64_t w2_off, b2_off;             /* GATE_ACC: fc2 weight / bias */
+} y7t_reid_op;                          /* sizeof == 96 */
+typedef struct y7t_reid y7t_reid;
+int y7t_reid_create(const y7t_reid_op* ops_host, int n_ops, const int64_t* buf_offsets_host /* in floats */, int n_bufs, void* arena, size_t arena_bytes,
+                    const void* weights_f32, int max_crops, int in_h, int in_w, int feat_dim, y7t_reid** out);
+int y7t_reid_destroy(y7t_reid* reid);
+/* frame_u8: (H, W, 3) uint8 frame in DEVICE memory, boxes: N x 4 float32 tlbr (device) -- or crops_f32 != NULL: N x in_h x in_w x 3 float32
+ * crops that are already resized and normalised (device; frame_u8 / boxes ignored).  feats: N x feat_dim float32 (device). */
+int y7t_reid_forward(y7t_reid* reid, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats,
+                     y7t_stream stream);
+
 /* single fused Conv+bias+act launch (layer-level parity tests, rocprof attribution); same fields as y7t_op but
  * with raw device pointers. */
 int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B, int H, int W, int Cin, const void* w_packed, const float* bias,

@@ -1,0 +1,79 @@
+"""GPU: the device ReID path (csrc/y7t_reid.hip, tracker/reid.py) against oracle/reid_torch.py (pinned to the reference's OSNet class in
+tests/test_reid_oracle.py), and DeepSORT end to end with it (BASELINE config 4: appearance features from OSNet x0_25 crops)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def extractor():
+    from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+    return ReIDExtractor(None, seed=3, max_crops=256)
+
+
+def test_osnet_forward_matches_oracle(extractor):
+    from oracle import reid_torch
+    x = torch.randn((37, 3, 128, 64), generator=torch.Generator().manual_seed(1))
+    got = extractor.forward_crops(x.permute(0, 2, 3, 1).contiguous()).cpu()
+    want = reid_torch.osnet_forward(extractor.sd, x)
+    assert got.shape == want.shape == (37, 512) and float(want.abs().mean()) > 0.05
+    # fp32 on both sides; only the summation order differs (BatchNorm folded into the weights on the device side)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+
+
+def test_crop_resize_normalise_matches_oracle(extractor):
+    from oracle import reid_torch
+    from yolov7_tracker_amd import synth
+    frame = synth.make_frames(1, 80, 640, seq_idx=3)[0]
+    boxes = np.array([[10, 20, 60, 150], [100.7, 0.2, 130.9, 64.5], [300, 300, 364, 428], [600, 500, 640, 640], [5, 5, 13, 21], [200, 100, 520, 600]], np.float32)
+    want_x = reid_torch.preprocess(frame, boxes)
+    want = reid_torch.osnet_forward(extractor.sd, want_x)
+    got = extractor.features_for_boxes(frame, boxes).cpu()
+    # the device crop (first arena buffer) against the oracle's preprocessing
+    crop = extractor._arena[:6 * 128 * 64 * 3].view(6, 128, 64, 3).cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(crop.numpy(), want_x.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+    # host-crop entry point (Extractor.__call__ semantics) gives the same features
+    crops = [frame[int(b[1]):int(b[3]), int(b[0]):int(b[2])] for b in boxes]
+    np.testing.assert_allclose(extractor(crops), got.numpy(), rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+
+
+def test_deepsort_with_device_reid_tracks_the_scene(extractor):
+    """BASELINE config 4 in miniature: frames of the synthetic scene, its detections, appearance features from the device OSNet over the
+    device crops.  With real (non-degenerate) embeddings the cascade keeps identities: almost every object holds one id over the clip."""
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    n_frames, n_obj, size = 25, 30, 640
+    frames = synth.make_frames(n_frames, n_obj, size, seq_idx=5)
+    gt = []
+    dets = synth.make_detections(n_frames, n_obj, size, seq_idx=1005, miss=0.0, fp=0.0, ground_truth=gt)     # same objects as make_frames(seq 5)
+    BaseTrack._count = 0
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.05, track_buffer=30, kalman_format="default", img_size=size, iou_thresh=0.5), reid_model=extractor)
+    ids_per_frame = []
+    for f in range(n_frames):
+        cur = t.update(dets[f], torch.from_numpy(frames[f]))
+        ids_per_frame.append(sorted(c.track_id for c in cur))
+    assert len(ids_per_frame[-1]) >= 0.8 * len(dets[-1])
+    assert BaseTrack._count <= 1.3 * n_obj                     # few identity switches / re-births
+    assert len(set(ids_per_frame[5]) & set(ids_per_frame[-1])) >= 0.7 * len(ids_per_frame[5])
+
+
+def test_extractor_from_torchreid_checkpoint(tmp_path, extractor):
+    """a checkpoint in the form the reference loads (reid_models/load_model_tools.py: {'state_dict': ...} with 'module.' prefixes and a
+    classifier head) gives the same network; DeepSORT picks it up from opts.reid_model_path like deepsort.py:14"""
+    from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    sd = {"module." + k: v for k, v in extractor.sd.items()}
+    sd["module.classifier.weight"], sd["module.classifier.bias"] = torch.zeros(1, 512), torch.zeros(1)
+    path = str(tmp_path / "osnet_x0_25.pth")
+    torch.save({"state_dict": sd, "epoch": 3}, path)
+    e2 = ReIDExtractor.from_checkpoint(path, max_crops=8)
+    x = torch.randn((4, 128, 64, 3), generator=torch.Generator().manual_seed(2))
+    assert torch.equal(e2.forward_crops(x), extractor.forward_crops(x))
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=640, iou_thresh=0.5, reid_model_path=path))
+    assert isinstance(t.reid_model, ReIDExtractor)

@@ -48,6 +48,9 @@ SIGNATURES = {
     "y7t_det_postprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "y7t_det_postprocess": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "y7t_reid_create": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "y7t_reid_destroy": (c_int, [c_void_p]),
+    "y7t_reid_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "y7t_conv2d_nhwc_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

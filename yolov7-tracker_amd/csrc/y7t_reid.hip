@@ -1,0 +1,266 @@
+// y7t_reid.hip -- the appearance branch of DeepSORT (BASELINE config 4) on the device: crops of the detections taken straight from the
+// uint8 frame in HBM, resized and normalised, through OSNet x0_25 to one embedding per detection.
+//
+// Restates /root/reference/tracker/deepsort.py:19-41 (get_feature: crop ori_img[y1:y2, x1:x2]),
+// tracker/reid_models/deepsort_reid.py:112-153 (Extractor: /255, cv2.resize to 64 x 128 INTER_LINEAR on the float image, ToTensor,
+// Normalize(mean, std) in the frame's channel order) and tracker/reid_models/OSNet.py:28-438 (ConvLayer, Conv1x1, Conv1x1Linear,
+// LightConv3x3 = 1x1 linear + depthwise 3x3 + BN + ReLU, ChannelGate, OSBlock, OSNet.forward in eval mode -> fc output).
+//
+// The network is tiny (x0_25: 16/64/96/128 channels, ~60 MMAC per crop) and latency-bound at ~80 crops per frame, so it runs as a
+// data-driven list of plain fp32 NHWC kernels (one thread per output value, weights through L1) -- BatchNorm folded on the host.
+// Nothing here is worth MFMA: the whole forward is a few hundred microseconds next to an 18 ms detector forward.
+#include "y7t_common.h"
+#include <string.h>
+#include <vector>
+
+static_assert(sizeof(y7t_reid_op) == 96, "y7t_reid_op layout must match tracker/reid.py OP_DTYPE");
+
+enum { R_CONV = 0, R_DWCONV3 = 1, R_MAXPOOL3S2 = 2, R_AVGPOOL2 = 3, R_GATE_ACC = 4, R_ADD_RELU = 5, R_GAP = 6, R_FC = 7 };
+
+struct y7t_reid {
+    std::vector<y7t_reid_op> ops;
+    std::vector<int64_t> bufs;      // float offsets of the activation buffers (laid out for max_n crops)
+    float* arena; size_t arena_floats;
+    const float* w;
+    int max_n, in_h, in_w, feat_dim;
+};
+
+// crop + resize + normalise: out[n][y][x][c], c in the frame's channel order (BGR), cv2.INTER_LINEAR geometry on the float image
+__global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ frame, int H, int W, const float* __restrict__ boxes, int N, int oh, int ow,
+                                                   float* __restrict__ out) {
+    const long long tot = (long long)N * oh * ow;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(t % ow), y = (int)((t / ow) % oh), n = (int)(t / ((long long)ow * oh));
+        const float* b = boxes + 4 * (size_t)n;
+        int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];       // list(map(int, tlbr))
+        x1 = min(max(x1, 0), W); x2 = min(max(x2, 0), W); y1 = min(max(y1, 0), H); y2 = min(max(y2, 0), H);
+        const int cw = x2 - x1, ch = y2 - y1;
+        float* o = out + (size_t)t * 3;
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+        if (cw <= 0 || ch <= 0) { o[0] = o[1] = o[2] = 0.f; continue; }
+        const float fy = ((float)y + 0.5f) * ((float)ch / (float)oh) - 0.5f, fx = ((float)x + 0.5f) * ((float)cw / (float)ow) - 0.5f;
+        int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const int yb = min(max(y0 + 1, 0), ch - 1), xb = min(max(x0 + 1, 0), cw - 1);
+        y0 = min(max(y0, 0), ch - 1); x0 = min(max(x0, 0), cw - 1);
+        const uint8_t* r0 = frame + ((size_t)(y1 + y0) * W + x1) * 3;
+        const uint8_t* r1 = frame + ((size_t)(y1 + yb) * W + x1) * 3;
+        for (int c = 0; c < 3; ++c) {
+            const float p00 = r0[x0 * 3 + c] / 255.0f, p01 = r0[xb * 3 + c] / 255.0f, p10 = r1[x0 * 3 + c] / 255.0f, p11 = r1[xb * 3 + c] / 255.0f;
+            const float v = (1.f - wy) * ((1.f - wx) * p00 + wx * p01) + wy * ((1.f - wx) * p10 + wx * p11);
+            o[c] = (v - mean[c]) / sd[c];
+        }
+    }
+}
+
+// dense conv k x k, stride s, padding p, + bias (folded BN) + optional ReLU; weights [co][kh][kw][ci]; NHWC fp32
+__global__ void __launch_bounds__(256) k_reid_conv(const float* __restrict__ in, int N, int H, int W, int Ci, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, int k, int s, int p, int Ho, int Wo, int Co, int relu,
+                                                   float* __restrict__ out) {
+    const long long tot = (long long)N * Ho * Wo * Co;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(t % Co);
+        const long long px = t / Co;
+        const int xo = (int)(px % Wo), yo = (int)((px / Wo) % Ho), n = (int)(px / ((long long)Wo * Ho));
+        float acc = bias ? bias[co] : 0.f;
+        const float* wc = w + (size_t)co * k * k * Ci;
+        for (int kh = 0; kh < k; ++kh) {
+            const int y = yo * s - p + kh;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int x = xo * s - p + kw;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const float* ip = in + (((size_t)n * H + y) * W + x) * Ci;
+                const float* wp = wc + (kh * k + kw) * Ci;
+                for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[ci];
+            }
+        }
+        out[t] = relu ? fmaxf(acc, 0.f) : acc;
+    }
+}
+
+// depthwise 3x3, padding 1, + bias + ReLU; weights [c][3][3]
+__global__ void __launch_bounds__(256) k_reid_dwconv3(const float* __restrict__ in, int N, int H, int W, int C, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    const long long tot = (long long)N * H * W * C;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long px = t / C;
+        const int x = (int)(px % W), y = (int)((px / W) % H), n = (int)(px / ((long long)W * H));
+        float acc = bias[c];
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y - 1 + kh;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = x - 1 + kw;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                acc += in[(((size_t)n * H + yy) * W + xx) * C + c] * w[c * 9 + kh * 3 + kw];
+            }
+        }
+        out[t] = relu ? fmaxf(acc, 0.f) : acc;
+    }
+}
+
+// mode 0: max 3x3 / stride 2 / pad 1 (-inf padding); mode 1: average 2x2 / stride 2
+__global__ void __launch_bounds__(256) k_reid_pool(const float* __restrict__ in, int N, int H, int W, int C, int mode, int Ho, int Wo, float* __restrict__ out) {
+    const long long tot = (long long)N * Ho * Wo * C;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long px = t / C;
+        const int xo = (int)(px % Wo), yo = (int)((px / Wo) % Ho), n = (int)(px / ((long long)Wo * Ho));
+        float r;
+        if (mode == 0) {
+            r = -3.0e38f;
+            for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+                const int y = yo * 2 - 1 + kh, x = xo * 2 - 1 + kw;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) r = fmaxf(r, in[(((size_t)n * H + y) * W + x) * C + c]);
+            }
+        } else {
+            r = 0.f;
+            for (int kh = 0; kh < 2; ++kh) for (int kw = 0; kw < 2; ++kw) r += in[(((size_t)n * H + yo * 2 + kh) * W + xo * 2 + kw) * C + c];
+            r *= 0.25f;
+        }
+        out[t] = r;
+    }
+}
+
+// global average pool: out[n][c] = mean over H*W; one workgroup per crop
+__global__ void __launch_bounds__(256) k_reid_gap(const float* __restrict__ in, int HW, int C, float* __restrict__ out) {
+    __shared__ float part[256];
+    const int n = blockIdx.x;
+    const float* base = in + (size_t)n * HW * C;
+    const int groups = 256 / C > 0 ? 256 / C : 1;        // C <= 256: `groups` row-partitions per channel
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    float acc = 0.f;
+    if (g < groups) for (int i = g; i < HW; i += groups) acc += base[(size_t)i * C + c];
+    part[threadIdx.x] = (g < groups) ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float s = 0.f;
+        for (int k = 0; k < groups; ++k) s += part[k * C + threadIdx.x];
+        out[(size_t)n * C + threadIdx.x] = s / (float)HW;
+    }
+}
+
+// ChannelGate (OSNet.py:162-220) on the pooled vector: gate[n][c] = sigmoid(fc2(relu(fc1(pooled[n]))));  one workgroup per crop
+__global__ void __launch_bounds__(128) k_reid_gate(const float* __restrict__ pooled, int C, int R, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate) {
+    __shared__ float hid[64];
+    const int n = blockIdx.x;
+    const float* p = pooled + (size_t)n * C;
+    if ((int)threadIdx.x < R) {
+        float a = b1[threadIdx.x];
+        for (int c = 0; c < C; ++c) a += w1[threadIdx.x * C + c] * p[c];
+        hid[threadIdx.x] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = b2[c];
+        for (int r = 0; r < R; ++r) a += w2[c * R + r] * hid[r];
+        gate[(size_t)n * C + c] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
+// acc = (first ? 0 : acc) + x * gate[n][c]
+__global__ void __launch_bounds__(256) k_reid_scale_acc(const float* __restrict__ x, const float* __restrict__ gate, int HW, int C, long long tot, int first,
+                                                        float* __restrict__ acc) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int n = (int)(t / ((long long)HW * C));
+        const float v = x[t] * gate[(size_t)n * C + c];
+        acc[t] = first ? v : acc[t] + v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reid_add_relu(const float* __restrict__ a, const float* __restrict__ b, long long tot, float* __restrict__ out) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) out[t] = fmaxf(a[t] + b[t], 0.f);
+}
+
+// fc: out[n][o] = relu(bias[o] + sum_c w[o][c] * in[n][c])   (Linear + folded BatchNorm1d + ReLU, OSNet.py:367-386)
+__global__ void __launch_bounds__(256) k_reid_fc(const float* __restrict__ in, int N, int C, const float* __restrict__ w, const float* __restrict__ bias, int O,
+                                                 int relu, float* __restrict__ out) {
+    const long long tot = (long long)N * O;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(t % O), n = (int)(t / O);
+        float a = bias[o];
+        for (int c = 0; c < C; ++c) a += w[(size_t)o * C + c] * in[(size_t)n * C + c];
+        out[t] = relu ? fmaxf(a, 0.f) : a;
+    }
+}
+
+static int blocks_for(long long tot) { long long b = (tot + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
+extern "C" int y7t_reid_create(const y7t_reid_op* ops, int n_ops, const int64_t* buf_offsets, int n_bufs, void* arena, size_t arena_bytes, const void* weights_f32,
+                               int max_crops, int in_h, int in_w, int feat_dim, y7t_reid** out) {
+    Y7T_ARG_CHECK(ops && n_ops > 0 && buf_offsets && n_bufs > 0 && arena && weights_f32 && out && max_crops > 0 && in_h > 0 && in_w > 0 && feat_dim > 0);
+    for (int i = 0; i < n_ops; ++i) {
+        Y7T_ARG_CHECK(ops[i].type >= R_CONV && ops[i].type <= R_FC);
+        Y7T_ARG_CHECK(ops[i].in_buf >= 0 && ops[i].in_buf < n_bufs && ops[i].out_buf >= 0 && ops[i].out_buf < n_bufs && ops[i].aux_buf < n_bufs);
+        if (ops[i].type == R_GATE_ACC) Y7T_ARG_CHECK(ops[i].C <= 256 && ops[i].R <= 64 && ops[i].R >= 1);
+    }
+    y7t_reid* r = new y7t_reid();
+    r->ops.assign(ops, ops + n_ops);
+    r->bufs.assign(buf_offsets, buf_offsets + n_bufs);
+    r->arena = (float*)arena; r->arena_floats = arena_bytes / 4; r->w = (const float*)weights_f32;
+    r->max_n = max_crops; r->in_h = in_h; r->in_w = in_w; r->feat_dim = feat_dim;
+    *out = r;
+    return 0;
+}
+
+extern "C" int y7t_reid_destroy(y7t_reid* r) { delete r; return 0; }
+
+extern "C" int y7t_reid_forward(y7t_reid* r, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats, y7t_stream stream) {
+    Y7T_ARG_CHECK(r && feats && N >= 0 && N <= r->max_n);
+    Y7T_ARG_CHECK((frame_u8 && boxes && H > 0 && W > 0) || crops_f32);
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float* b0 = r->arena + r->bufs[0];
+    if (crops_f32) Y7T_HIP_CHECK(hipMemcpyAsync(b0, crops_f32, sizeof(float) * (size_t)N * r->in_h * r->in_w * 3, hipMemcpyDeviceToDevice, s));
+    else {
+        hipLaunchKernelGGL(k_reid_crop, dim3(blocks_for((long long)N * r->in_h * r->in_w)), dim3(256), 0, s, (const uint8_t*)frame_u8, H, W, boxes, N, r->in_h, r->in_w, b0);
+        Y7T_LAUNCH_CHECK();
+    }
+    for (const y7t_reid_op& op : r->ops) {
+        const float* in = r->arena + r->bufs[op.in_buf];
+        float* out = r->arena + r->bufs[op.out_buf];
+        float* aux = op.aux_buf >= 0 ? r->arena + r->bufs[op.aux_buf] : nullptr;
+        const float* w = r->w + op.w_off;
+        const float* bias = op.b_off >= 0 ? r->w + op.b_off : nullptr;
+        switch (op.type) {
+        case R_CONV:
+            hipLaunchKernelGGL(k_reid_conv, dim3(blocks_for((long long)N * op.Ho * op.Wo * op.Co)), dim3(256), 0, s, in, N, op.H, op.W, op.C, w, bias, op.k, op.s, op.p,
+                               op.Ho, op.Wo, op.Co, op.relu, out);
+            break;
+        case R_DWCONV3:
+            hipLaunchKernelGGL(k_reid_dwconv3, dim3(blocks_for((long long)N * op.H * op.W * op.C)), dim3(256), 0, s, in, N, op.H, op.W, op.C, w, bias, op.relu, out);
+            break;
+        case R_MAXPOOL3S2: case R_AVGPOOL2:
+            hipLaunchKernelGGL(k_reid_pool, dim3(blocks_for((long long)N * op.Ho * op.Wo * op.C)), dim3(256), 0, s, in, N, op.H, op.W, op.C, op.type == R_AVGPOOL2, op.Ho, op.Wo, out);
+            break;
+        case R_GATE_ACC: {   // aux: [N][C] pooled | [N][C] gates; out: accumulator
+            float* pooled = aux;
+            float* gate = aux + (size_t)r->max_n * op.C;
+            hipLaunchKernelGGL(k_reid_gap, dim3(N), dim3(256), 0, s, in, op.H * op.W, op.C, pooled);
+            hipLaunchKernelGGL(k_reid_gate, dim3(N), dim3(128), 0, s, (const float*)pooled, op.C, op.R, w, r->w + op.b_off, r->w + op.w2_off, r->w + op.b2_off, gate);
+            const long long tot = (long long)N * op.H * op.W * op.C;
+            hipLaunchKernelGGL(k_reid_scale_acc, dim3(blocks_for(tot)), dim3(256), 0, s, in, (const float*)gate, op.H * op.W, op.C, tot, op.relu /* first */, out);
+            break;
+        }
+        case R_ADD_RELU: {
+            const long long tot = (long long)N * op.H * op.W * op.C;
+            hipLaunchKernelGGL(k_reid_add_relu, dim3(blocks_for(tot)), dim3(256), 0, s, in, (const float*)aux, tot, out);
+            break;
+        }
+        case R_GAP:
+            hipLaunchKernelGGL(k_reid_gap, dim3(N), dim3(256), 0, s, in, op.H * op.W, op.C, out);
+            break;
+        case R_FC:
+            hipLaunchKernelGGL(k_reid_fc, dim3(blocks_for((long long)N * op.Co)), dim3(256), 0, s, in, N, op.C, w, bias, op.Co, op.relu, out);
+            break;
+        }
+        Y7T_LAUNCH_CHECK();
+    }
+    const y7t_reid_op& last = r->ops.back();
+    Y7T_HIP_CHECK(hipMemcpyAsync(feats, r->arena + r->bufs[last.out_buf], sizeof(float) * (size_t)N * r->feat_dim, hipMemcpyDeviceToDevice, s));
+    return 0;
+}

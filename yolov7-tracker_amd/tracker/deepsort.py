@@ -6,6 +6,8 @@ Appearance features enter at the reference's own seam, `get_feature(tlbrs, ori_i
 crops `ori_img` like the reference and calls `self.reid_model(crops)`; `reid_model` is any callable returning (N, D) features -- the
 device ReID extractor of this package (`tracker/reid.py`), or a stand-in.  The reference hard-wires `Extractor(opts.reid_model_path)`
 with weights/ckpt.t7, which does not ship with it."""
+import os
+
 import numpy as np
 import torch
 
@@ -23,6 +25,10 @@ class DeepSORT(BaseTracker):
             raise NotImplementedError("DeepSORT gates on xyah measurements (deepsort.py:59): kalman_format default / strongsort")
         super().__init__(opts, frame_rate=frame_rate)
         self.reid_model = reid_model if reid_model is not None else getattr(opts, "reid_model", None)
+        path = getattr(opts, "reid_model_path", None)
+        if self.reid_model is None and path and os.path.isfile(str(path)):      # deepsort.py:14: Extractor(opts.reid_model_path)
+            from .reid import ReIDExtractor
+            self.reid_model = ReIDExtractor.from_checkpoint(path)
         self.gamma = gamma
         self.filter_small_area = False
         self._feat = None           # feature state, allocated when the feature dimension is known

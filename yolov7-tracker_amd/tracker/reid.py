@@ -1,0 +1,275 @@
+"""ReID embedding for DeepSORT on the device: OSNet (x0_25 by default) over crops taken from the frame in HBM.
+
+Host half (this file): lower the OSNet graph of /root/reference/tracker/reid_models/OSNet.py:282-438 (osnet_x0_25 :567-579:
+channels [16, 64, 96, 128], two OSBlocks per stage, fc 512) into the op list of include/y7t.h (`y7t_reid_op`), fold every BatchNorm
+into its convolution / linear layer, pack the fp32 weights into one blob.  Device half: csrc/y7t_reid.hip.  `ReIDExtractor` is what
+DeepSORT's `get_feature` seam (deepsort.py:19-41) calls: `features_for_boxes(frame, tlbrs)` does crop + /255 + resize to 128 x 64 +
+Normalize on the GPU like the reference's Extractor (reid_models/deepsort_reid.py:112-153) and returns (N, 512) device features.
+
+Weights: a state dict with torchreid's OSNet parameter names (what weights/osnet_x0_25.pth holds) or seeded random ones."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+OP_DTYPE = np.dtype([("type", "<i4"), ("in_buf", "<i4"), ("out_buf", "<i4"), ("aux_buf", "<i4"), ("H", "<i4"), ("W", "<i4"), ("C", "<i4"),
+                     ("Ho", "<i4"), ("Wo", "<i4"), ("Co", "<i4"), ("k", "<i4"), ("s", "<i4"), ("p", "<i4"), ("relu", "<i4"), ("R", "<i4"),
+                     ("pad0", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("w2_off", "<i8"), ("b2_off", "<i8")], align=False)
+assert OP_DTYPE.itemsize == 96      # == sizeof(y7t_reid_op)
+CONV, DWCONV3, MAXPOOL3S2, AVGPOOL2, GATE_ACC, ADD_RELU, GAP, FC = range(8)
+BN_EPS = 1e-5
+
+
+def osnet_spec(width=0.25, feature_dim=512):
+    """channels of osnet_x1_0 .. osnet_x0_25 (OSNet.py:522-579)"""
+    ch = {1.0: [64, 256, 384, 512], 0.75: [48, 192, 288, 384], 0.5: [32, 128, 192, 256], 0.25: [16, 64, 96, 128]}[width]
+    return {"channels": ch, "layers": [2, 2, 2], "feature_dim": feature_dim}
+
+
+def random_state_dict(spec, seed=0):
+    """seeded OSNet state dict with torchreid's names (Kaiming-style scales, non-trivial BatchNorm statistics)"""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, co, ci, k, groups=1, bias=False):
+        fan = ci // groups * k * k
+        sd[name + ".weight"] = torch.from_numpy(rng.normal(0, (1.0 / fan) ** 0.5, (co, ci // groups, k, k)).astype(np.float32))
+        if bias:
+            sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, co).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.7, 1.3, c).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_mean"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.6, 1.4, c).astype(np.float32))
+
+    def light(name, c):
+        conv(name + ".conv1", c, c, 1)
+        conv(name + ".conv2", c, c, 3, groups=c)
+        bn(name + ".bn", c)
+    ch = spec["channels"]
+    conv("conv1.conv", ch[0], 3, 7)
+    bn("conv1.bn", ch[0])
+    for si, (cin, cout, nblk) in enumerate(zip(ch[:-1], ch[1:], spec["layers"])):
+        stage = "conv%d" % (si + 2)
+        for bi in range(nblk):
+            b = "%s.%d" % (stage, bi)
+            i_c = cin if bi == 0 else cout
+            mid = cout // 4
+            conv(b + ".conv1.conv", mid, i_c, 1)
+            bn(b + ".conv1.bn", mid)
+            light(b + ".conv2a", mid)
+            for tag, n in (("conv2b", 2), ("conv2c", 3), ("conv2d", 4)):
+                for j in range(n):
+                    light("%s.%s.%d" % (b, tag, j), mid)
+            conv(b + ".gate.fc1", mid // 16, mid, 1, bias=True)
+            conv(b + ".gate.fc2", mid, mid // 16, 1, bias=True)
+            conv(b + ".conv3.conv", cout, mid, 1)
+            bn(b + ".conv3.bn", cout)
+            if i_c != cout:
+                conv(b + ".downsample.conv", cout, i_c, 1)
+                bn(b + ".downsample.bn", cout)
+        if si < 2:      # reduce_spatial_size: Conv1x1 + AvgPool2d(2)
+            conv("%s.%d.0.conv" % (stage, nblk), cout, cout, 1)
+            bn("%s.%d.0.bn" % (stage, nblk), cout)
+    conv("conv5.conv", ch[3], ch[3], 1)
+    bn("conv5.bn", ch[3])
+    fd = spec["feature_dim"]
+    sd["fc.0.weight"] = torch.from_numpy(rng.normal(0, (1.0 / ch[3]) ** 0.5, (fd, ch[3])).astype(np.float32))
+    sd["fc.0.bias"] = torch.from_numpy(rng.normal(0, 0.1, fd).astype(np.float32))
+    bn("fc.1", fd)
+    return sd
+
+
+class _Lowering:
+    def __init__(self, sd, in_h, in_w):
+        self.sd, self.ops, self.bufs, self.w = sd, [], [], []
+        self.w_floats = 0
+        self.in_buf = self.buf(in_h * in_w * 3)
+
+    def buf(self, floats_per_crop):
+        self.bufs.append(int(floats_per_crop))
+        return len(self.bufs) - 1
+
+    def put(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.w_floats
+        self.w.append(arr)
+        self.w_floats += arr.size
+        return off
+
+    def _bn(self, name):
+        g, b = self.sd[name + ".weight"].double().numpy(), self.sd[name + ".bias"].double().numpy()
+        mu, var = self.sd[name + ".running_mean"].double().numpy(), self.sd[name + ".running_var"].double().numpy()
+        scale = g / np.sqrt(var + BN_EPS)
+        return scale, b - mu * scale
+
+    def op(self, **kw):
+        o = np.zeros((), OP_DTYPE)
+        o["aux_buf"], o["b_off"] = -1, -1
+        for k, v in kw.items():
+            o[k] = v
+        self.ops.append(o)
+
+    def conv(self, x, H, W, ci, co, k, s, p, wname, bnname=None, relu=0):
+        Wt = self.sd[wname + ".weight"].double().numpy()                       # (co, ci, k, k)
+        bias = np.zeros(co)
+        if bnname is not None:
+            scale, bias = self._bn(bnname)
+            Wt = Wt * scale[:, None, None, None]
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = self.buf(Ho * Wo * co)
+        self.op(type=CONV, in_buf=x, out_buf=y, H=H, W=W, C=ci, Ho=Ho, Wo=Wo, Co=co, k=k, s=s, p=p, relu=relu,
+                w_off=self.put(Wt.transpose(0, 2, 3, 1)), b_off=self.put(bias) if bnname is not None else -1)
+        return y, Ho, Wo
+
+    def light(self, x, H, W, c, name):
+        """LightConv3x3 (OSNet.py:128-157): 1x1 linear, depthwise 3x3, BN, ReLU"""
+        y, _, _ = self.conv(x, H, W, c, c, 1, 1, 0, name + ".conv1")
+        scale, bias = self._bn(name + ".bn")
+        Wd = self.sd[name + ".conv2.weight"].double().numpy().reshape(c, 9) * scale[:, None]
+        z = self.buf(H * W * c)
+        self.op(type=DWCONV3, in_buf=y, out_buf=z, H=H, W=W, C=c, Ho=H, Wo=W, Co=c, k=3, s=1, p=1, relu=1, w_off=self.put(Wd), b_off=self.put(bias))
+        return z
+
+    def osblock(self, x, H, W, cin, cout, name):
+        mid = cout // 4
+        x1, _, _ = self.conv(x, H, W, cin, mid, 1, 1, 0, name + ".conv1.conv", name + ".conv1.bn", relu=1)
+        acc = self.buf(H * W * mid)
+        scratch = self.buf(2 * mid)                                            # per crop: pooled vector + gates
+        g = name + ".gate"
+        R = mid // 16
+        w1, b1 = self.put(self.sd[g + ".fc1.weight"].numpy().reshape(R, mid)), self.put(self.sd[g + ".fc1.bias"].numpy())
+        w2, b2 = self.put(self.sd[g + ".fc2.weight"].numpy().reshape(mid, R)), self.put(self.sd[g + ".fc2.bias"].numpy())
+        for bi, (tag, n) in enumerate((("conv2a", 1), ("conv2b", 2), ("conv2c", 3), ("conv2d", 4))):
+            t = x1
+            for j in range(n):
+                t = self.light(t, H, W, mid, "%s.%s" % (name, tag) if tag == "conv2a" else "%s.%s.%d" % (name, tag, j))
+            self.op(type=GATE_ACC, in_buf=t, out_buf=acc, aux_buf=scratch, H=H, W=W, C=mid, R=R, relu=int(bi == 0), w_off=w1, b_off=b1, w2_off=w2, b2_off=b2)
+        x3, _, _ = self.conv(acc, H, W, mid, cout, 1, 1, 0, name + ".conv3.conv", name + ".conv3.bn")
+        idn = x
+        if cin != cout:
+            idn, _, _ = self.conv(x, H, W, cin, cout, 1, 1, 0, name + ".downsample.conv", name + ".downsample.bn")
+        y = self.buf(H * W * cout)
+        self.op(type=ADD_RELU, in_buf=x3, aux_buf=idn, out_buf=y, H=H, W=W, C=cout)
+        return y
+
+
+def lower(sd, spec, in_h=128, in_w=64):
+    """-> (ops structured array, buffer sizes in floats per crop, weight blob float32)"""
+    L = _Lowering(sd, in_h, in_w)
+    ch = spec["channels"]
+    x, H, W = L.conv(L.in_buf, in_h, in_w, 3, ch[0], 7, 2, 3, "conv1.conv", "conv1.bn", relu=1)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = L.buf(Ho * Wo * ch[0])
+    L.op(type=MAXPOOL3S2, in_buf=x, out_buf=y, H=H, W=W, C=ch[0], Ho=Ho, Wo=Wo, Co=ch[0])
+    x, H, W = y, Ho, Wo
+    for si, (cin, cout, nblk) in enumerate(zip(ch[:-1], ch[1:], spec["layers"])):
+        stage = "conv%d" % (si + 2)
+        for bi in range(nblk):
+            x = L.osblock(x, H, W, cin if bi == 0 else cout, cout, "%s.%d" % (stage, bi))
+        if si < 2:
+            x, _, _ = L.conv(x, H, W, cout, cout, 1, 1, 0, "%s.%d.0.conv" % (stage, nblk), "%s.%d.0.bn" % (stage, nblk), relu=1)
+            y = L.buf((H // 2) * (W // 2) * cout)
+            L.op(type=AVGPOOL2, in_buf=x, out_buf=y, H=H, W=W, C=cout, Ho=H // 2, Wo=W // 2, Co=cout)
+            x, H, W = y, H // 2, W // 2
+    x, _, _ = L.conv(x, H, W, ch[3], ch[3], 1, 1, 0, "conv5.conv", "conv5.bn", relu=1)
+    v = L.buf(ch[3])
+    L.op(type=GAP, in_buf=x, out_buf=v, H=H, W=W, C=ch[3])
+    fd = spec["feature_dim"]
+    scale, bias = L._bn("fc.1")
+    Wf = sd["fc.0.weight"].double().numpy() * scale[:, None]
+    bf = sd["fc.0.bias"].double().numpy() * scale + bias
+    out = L.buf(fd)
+    L.op(type=FC, in_buf=v, out_buf=out, H=1, W=1, C=ch[3], Co=fd, relu=1, w_off=L.put(Wf), b_off=L.put(bf))
+    return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
+
+
+class ReIDExtractor:
+    """callable at DeepSORT's reid_model seam.  state_dict: torchreid OSNet names (e.g. torch.load('weights/osnet_x0_25.pth')), or None
+    for seeded random weights.  size = (W, H) of the network input like Extractor.size (deepsort_reid.py:122)."""
+
+    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0):
+        _lib.require_gpu()
+        self._L = _lib.load()
+        self.spec = osnet_spec(width)
+        self.in_w, self.in_h = int(size[0]), int(size[1])
+        if state_dict is None:
+            state_dict = random_state_dict(self.spec, seed)
+        self.sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v.detach().float().cpu() for k, v in state_dict.items()}
+        self.max_crops = int(max_crops)
+        ops, bufs, w = lower(self.sd, self.spec, self.in_h, self.in_w)
+        self.ops, self.feat_dim = ops, self.spec["feature_dim"]
+        offs, o = [], 0
+        for b in bufs:
+            offs.append(o)
+            o += (b * self.max_crops + 63) // 64 * 64
+        self._offs = np.array(offs, dtype=np.int64)
+        self._arena = torch.zeros(o + 64, dtype=torch.float32, device="cuda")
+        self._w = torch.from_numpy(w).cuda()
+        h = ctypes.c_void_p()
+        _lib.check(self._L.y7t_reid_create(ops.ctypes.data_as(ctypes.c_void_p), len(ops), self._offs.ctypes.data_as(ctypes.c_void_p), len(offs),
+                                           _lib.ptr(self._arena), self._arena.numel() * 4, _lib.ptr(self._w), self.max_crops, self.in_h, self.in_w,
+                                           self.feat_dim, ctypes.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_checkpoint(cls, path, **kw):
+        """torchreid-style OSNet checkpoint (what the reference's load_pretrained_weights reads, reid_models/load_model_tools.py): a state
+        dict, or {'state_dict': ...}, with or without the DataParallel 'module.' prefix; classifier.* is ignored.  The width is read off
+        conv1's channel count."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck.state_dict()
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items() if not k.startswith(("classifier", "module.classifier"))}
+        if "conv1.conv.weight" not in sd:
+            raise _lib.Y7TError("%s is not an OSNet checkpoint (no conv1.conv.weight): the reference's own DeepSORT Extractor expects "
+                                "weights/ckpt.t7, which does not ship with it; OSNet (weights/osnet_x0_25.pth) is what this package runs" % path)
+        width = {64: 1.0, 48: 0.75, 32: 0.5, 16: 0.25}[int(sd["conv1.conv.weight"].shape[0])]
+        return cls(sd, width=width, **kw)
+
+    def features_for_boxes(self, frame, tlbrs):
+        """frame: (H, W, 3) uint8 BGR (host or device); tlbrs: (N, 4) -> (N, feat_dim) float32 DEVICE tensor"""
+        if not isinstance(frame, torch.Tensor):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        frame = frame.to(device="cuda", dtype=torch.uint8).contiguous()
+        boxes = torch.as_tensor(np.ascontiguousarray(np.asarray(tlbrs, dtype=np.float32).reshape(-1, 4))).cuda()
+        n = boxes.shape[0]
+        if n > self.max_crops:
+            raise _lib.Y7TError("%d crops exceed max_crops=%d" % (n, self.max_crops))
+        out = torch.empty((n, self.feat_dim), dtype=torch.float32, device="cuda")
+        _lib.check(self._L.y7t_reid_forward(self._h, _lib.ptr(frame), frame.shape[0], frame.shape[1], _lib.ptr(boxes), n, None, _lib.ptr(out),
+                                            _lib.stream_ptr()))
+        self._keep = (frame, boxes)
+        return out
+
+    def forward_crops(self, crops_nhwc):
+        """(N, in_h, in_w, 3) float32 crops already resized + normalised (tests) -> (N, feat_dim) device tensor"""
+        x = crops_nhwc.to(device="cuda", dtype=torch.float32).contiguous()
+        n = x.shape[0]
+        out = torch.empty((n, self.feat_dim), dtype=torch.float32, device="cuda")
+        _lib.check(self._L.y7t_reid_forward(self._h, None, 0, 0, None, n, _lib.ptr(x), _lib.ptr(out), _lib.stream_ptr()))
+        self._keep = x
+        return out
+
+    def __call__(self, im_crops):
+        """Extractor.__call__ (deepsort_reid.py:148-153) for host crops: list of (h, w, 3) uint8 BGR arrays -> (N, feat_dim) numpy.
+        The crops are packed side by side into one frame so that the device crop kernel does the resize."""
+        if not im_crops:
+            return np.zeros((0, self.feat_dim), np.float32)
+        hmax, wsum = max(c.shape[0] for c in im_crops), sum(c.shape[1] for c in im_crops)
+        canvas = np.zeros((hmax, wsum, 3), np.uint8)
+        boxes, x = [], 0
+        for c in im_crops:
+            canvas[:c.shape[0], x:x + c.shape[1]] = c
+            boxes.append((x, 0, x + c.shape[1], c.shape[0]))
+            x += c.shape[1]
+        return self.features_for_boxes(canvas, np.asarray(boxes, np.float32)).cpu().numpy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.y7t_reid_destroy(self._h)
+        except Exception:
+            pass
