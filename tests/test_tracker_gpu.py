@@ -215,6 +215,83 @@ def test_deepsort_crops_reach_the_reid_callable():
     assert [c.track_id for c in cur] == [1, 2]
 
 
+def test_plugin_tracker_written_against_the_strack_contract():
+    """a tracker plugin written like the reference's own trackers -- per-object STrack.activate / update / re_activate /
+    multi_predict, matching.iou_distance / linear_assignment, joint / sub / remove_duplicate_stracks -- runs on this package's classes (the
+    arithmetic in liby7t.so's per-op kernels) and reproduces the reference's SORT golden sequence id for id."""
+    from yolov7_tracker_amd.tracker import matching
+    from yolov7_tracker_amd.tracker.basetrack import (BaseTrack, STrack, TrackState, KALMAN_DICT, joint_stracks, sub_stracks,
+                                                      remove_duplicate_stracks)
+    trk, fmt, dets, want = util.load_tracker_case("sort_default")
+    n_frames = 25
+
+    class PluginSORT:                      # the control flow of basetrack.py:368-487, restated against the public surface only
+        def __init__(self):
+            self.tracked, self.lost, self.removed, self.frame_id = [], [], [], 0
+            self.kalman = KALMAN_DICT[fmt]()
+
+        def update(self, det):
+            self.frame_id += 1
+            act, refind, lost, removed = [], [], [], []
+            det = det[det[:, 4] > 0.2]
+            D = [STrack(c, STrack.tlbr2tlwh(b), s_, kalman_format=fmt) for c, b, s_ in zip(det[:, 5], det[:, :4], det[:, 4])]
+            unconf = [t for t in self.tracked if not t.is_activated]
+            pool = joint_stracks([t for t in self.tracked if t.is_activated], self.lost)
+            STrack.multi_predict(pool, self.kalman)
+            m, ut, ud = matching.linear_assignment(matching.iou_distance(pool, D), thresh=0.5)
+            for it, idt in m:
+                t = pool[it]
+                if t.state == TrackState.Tracked:
+                    t.update(D[idt], self.frame_id); act.append(t)
+                else:
+                    t.re_activate(D[idt], self.frame_id, new_id=False); refind.append(t)
+            for it in ut:
+                if pool[it].state == TrackState.Tracked:
+                    pool[it].mark_lost(); lost.append(pool[it])
+            left = [D[i] for i in ud]
+            m, ut, ud = matching.linear_assignment(matching.iou_distance(unconf, left), thresh=0.6)
+            for it, idt in m:
+                t = unconf[it]
+                if t.state == TrackState.Tracked:
+                    t.update(left[idt], self.frame_id); act.append(t)
+                else:
+                    t.re_activate(left[idt], self.frame_id, new_id=False); refind.append(t)
+            for it in ut:
+                unconf[it].mark_removed(); removed.append(unconf[it])
+            for i in ud:
+                if left[i].score > 0.2 + 0.1:
+                    left[i].activate(self.frame_id); act.append(left[i])
+            for t in self.lost:
+                if self.frame_id - t.end_frame > 30:
+                    t.mark_removed(); removed.append(t)
+            self.tracked = [t for t in self.tracked if t.state == TrackState.Tracked]
+            self.tracked = joint_stracks(joint_stracks(self.tracked, act), refind)
+            self.lost = sub_stracks(self.lost, self.tracked)
+            self.lost.extend(lost)
+            self.lost = sub_stracks(self.lost, self.removed)
+            self.removed.extend(removed)
+            self.tracked, self.lost = remove_duplicate_stracks(self.tracked, self.lost)
+            return [t for t in self.tracked if t.is_activated]
+
+    BaseTrack._count = 0
+    p = PluginSORT()
+    for f in range(n_frames):
+        cur = p.update(np.asarray(dets[f], dtype=np.float32))
+        assert [t.track_id for t in cur] == [r[0] for r in want[f]], f
+        for t, r in zip(cur, want[f]):
+            np.testing.assert_allclose(np.asarray(t.tlwh, dtype=np.float64), r[1], rtol=util.TLWH_RTOL, atol=util.TLWH_ATOL)
+    assert BaseTrack._count == max(r[0] for fr in want[:n_frames] for r in fr)
+    # tracks returned by the fused device trackers are views: their state only changes inside the tracker's step
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    from yolov7_tracker_amd import _lib
+    BaseTrack._count = 0
+    bt = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5))
+    view = bt.update(dets[0], None)[0]
+    with pytest.raises(_lib.Y7TError):
+        view.predict()
+    assert bt.removed_stracks == [] and view.state == TrackState.Tracked
+
+
 def test_empty_and_ragged_frames():
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack

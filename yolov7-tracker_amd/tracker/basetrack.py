@@ -114,10 +114,98 @@ class STrack(BaseTrack):
         self.frame_id = None
         self.time_since_update = None
         self.features = [] if feature is None else [feature]
+        self.store_features_budget = store_features_budget
         self.has_feature = feature is not None
+        self.use_avg_of_feature = use_avg_of_feature
         self.kalman_format = kalman_format
+        self._kalman = None          # KALMAN_DICT[kalman_format](), created on first use (device-backed)
         self.mean, self.cov = None, None
         self._pool = None
+
+    # -- the per-track plugin methods of the reference (basetrack.py:222-339): the same state transitions on host-side objects, the
+    # Kalman arithmetic in liby7t.so's per-op kernels (tracker/kalman_filter.py).  The fused device trackers of this package do not go
+    # through them (one kernel launch per frame); they exist so that a tracker written against the reference's STrack contract runs. ----
+    @property
+    def kalman(self):
+        if self._kalman is None:
+            self._kalman = KALMAN_DICT[self.kalman_format]()
+        return self._kalman
+
+    def _measurement(self, tlwh):
+        if self.kalman_format in ('default', 'strongsort'):
+            return self.tlwh2xyah(tlwh)
+        if self.kalman_format == 'naive':
+            return self.tlwh2xyar(tlwh)
+        if self.kalman_format == 'botsort':
+            return self.tlwh2xywh(tlwh)
+        raise ValueError(self.kalman_format)
+
+    def activate(self, frame_id):
+        """basetrack.py:222-245"""
+        self.track_id = BaseTrack.next_id()
+        self.mean, self.cov = self.kalman.initiate(self._measurement(self._tlwh))
+        self.state = TrackState.Tracked
+        if frame_id == 1:
+            self.is_activated = True
+        self.frame_id = frame_id
+        self.start_frame = frame_id
+        self.time_since_update = 0
+
+    def predict(self):
+        """basetrack.py:247-251"""
+        self.mean, self.cov = self.kalman.predict(self.mean, self.cov)
+
+    @staticmethod
+    def multi_predict(stracks, kalman):
+        """basetrack.py:253-271: zero the last state component of non-Tracked tracks, one batched predict"""
+        if len(stracks) > 0:
+            multi_mean = np.asarray([st.mean.copy() for st in stracks])
+            multi_covariance = np.asarray([st.cov for st in stracks])
+            for i, st in enumerate(stracks):
+                if st.state != TrackState.Tracked:
+                    multi_mean[i][-1] = 0
+            multi_mean, multi_covariance = kalman.multi_predict(multi_mean, multi_covariance)
+            for i, (mean, cov) in enumerate(zip(multi_mean, multi_covariance)):
+                stracks[i].mean = mean
+                stracks[i].cov = cov
+        for strack in stracks:
+            strack.time_since_update += 1
+
+    def re_activate(self, new_track, frame_id, new_id=False):
+        """basetrack.py:273-294"""
+        self.mean, self.cov = self.kalman.update(self.mean, self.cov, self._measurement(new_track.tlwh))
+        self.tracklet_len = 0
+        self.state = TrackState.Tracked
+        self.is_activated = True
+        self.frame_id = frame_id
+        if new_id:
+            self.track_id = self.next_id()
+        self.score = new_track.score
+        self.time_since_update = 0
+
+    def update(self, new_track, frame_id):
+        """basetrack.py:296-339"""
+        self.frame_id = frame_id
+        self.tracklet_len += 1
+        new_tlwh = new_track.tlwh
+        self.score = new_track.score
+        measurement = self._measurement(new_tlwh)
+        if self.kalman_format == 'strongsort':
+            self.mean, self.cov = self.kalman.update(self.mean, self.cov, measurement, self.score)
+        else:
+            self.mean, self.cov = self.kalman.update(self.mean, self.cov, measurement)
+        if new_track.has_feature:
+            feature = new_track.features[0] / np.linalg.norm(new_track.features[0])
+            if self.use_avg_of_feature:
+                smooth_feat = 0.9 * self.features[-1] + (1 - 0.9) * feature
+                smooth_feat /= np.linalg.norm(smooth_feat)
+                self.features = [smooth_feat]
+            else:
+                self.features.append(feature)
+                self.features = self.features[-self.store_features_budget:]
+        self.state = TrackState.Tracked
+        self.is_activated = True
+        self.time_since_update = 0
 
     # -- converters (basetrack.py:110-181) -----------------------------------------------------
     @staticmethod
@@ -198,6 +286,11 @@ class _PoolTrack(STrack):
         if self._epoch == self._pool.frame_id:
             return self._tlwh_now.copy()
         return STrack.tlwh.fget(self)
+
+    def _view_only(self, *a, **k):
+        raise _lib.Y7TError("this track is a view of a device track pool: its state changes only inside the tracker's fused step "
+                            "(y7t_tracker_step); detached STrack objects support activate / predict / update / re_activate")
+    activate = predict = update = re_activate = mark_lost = mark_removed = _view_only
 
 
 class BaseTracker(object):
@@ -340,9 +433,17 @@ class BaseTracker(object):
 
     @property
     def removed_stracks(self):
-        """The reference keeps every removed track forever; the device pool recycles them and only
-        keeps the count."""
-        return [None] * self._snapshot()["hdr_n_removed_total"]
+        """The reference keeps every removed track forever (an ever-growing list it only uses for id-membership tests); the device pool
+        recycles their slots and keeps the count.  -> one placeholder per removed track (state Removed, no geometry)."""
+        return [_RemovedTrack() for _ in range(self._snapshot()["hdr_n_removed_total"])]
+
+
+class _RemovedTrack(BaseTrack):
+    state = TrackState.Removed
+    track_id = -1
+
+    def __repr__(self):
+        return 'OT_removed'
 
 
 def joint_stracks(tlista, tlistb):
@@ -363,3 +464,20 @@ def sub_stracks(tlista, tlistb):
         if stracks.get(t.track_id, 0):
             del stracks[t.track_id]
     return list(stracks.values())
+
+
+def remove_duplicate_stracks(stracksa, stracksb):
+    """basetrack.py:562-576: of every (a, b) pair closer than IoU distance 0.15 drop the younger track (ties: drop a)"""
+    pdist = matching.iou_distance(stracksa, stracksb)
+    pairs = np.where(pdist < 0.15)
+    dupa, dupb = list(), list()
+    for p, q in zip(*pairs):
+        timep = stracksa[p].frame_id - stracksa[p].start_frame
+        timeq = stracksb[q].frame_id - stracksb[q].start_frame
+        if timep > timeq:
+            dupb.append(q)
+        else:
+            dupa.append(p)
+    resa = [t for i, t in enumerate(stracksa) if i not in dupa]
+    resb = [t for i, t in enumerate(stracksb) if i not in dupb]
+    return resa, resb
