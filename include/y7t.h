@@ -196,6 +196,14 @@ int y7t_det_forward_fused(y7t_det* det, int B, int first, int last, float conf_t
  * out: NHWC fp16 with ldout channels (16 with reorg: 12 + 4 zero; 8 without: 3 + 5 zero). */
 int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg, void* out_f16, int ldout, y7t_stream stream);
 
+/* The whole front of the forward as one kernel, for plans that start with ReOrg + Conv 3x3 -> 64 (YOLOv7-w6, cfg/deploy/yolov7-w6.yaml:16-17;
+ * y7t_det_stem_fusable): raw (B, H0, W0, 3) uint8 BGR frames -> TrackerLoader._letterbox (resize INTER_LINEAR to new_w x new_h at (top, left)
+ * of the H x W network input, pad 114; new == source: no resampling) -> BGR->RGB, /255 -> ReOrg -> stem Conv + bias + activation, i.e. what
+ * y7t_letterbox_layout_u8 / y7t_input_layout followed by op 0 compute, without the fp16 layout tensor in between.  Continue with
+ * y7t_det_forward_ops / y7t_det_forward_fused from op 1. */
+int y7t_det_stem_fusable(const y7t_det* det);
+int y7t_det_forward_stem_u8(y7t_det* det, const void* frames_u8, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream);
+
 /* TrackerLoader._letterbox (tracker/tracker_dataloader.py:100-130) fused with the layout above, for raw (B,H0,W0,3) uint8 BGR
  * frames: bilinear resize (cv2.INTER_LINEAR geometry: half-pixel centres; float arithmetic, rounded to uint8) to new_w x new_h,
  * placed at (top, left) of the H x W letterboxed image, pad colour 114.  The host computes new_h/new_w/top/left exactly like

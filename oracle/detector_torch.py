@@ -21,6 +21,12 @@ from . import cnative
 BN_EPS = 1e-3
 
 
+def _to_f16(w64):
+    """float64 -> the nearest fp16 value (ONE rounding, numpy's conversion), as float32.  torch's double.half() goes through float32 and
+    double-rounds: about one folded weight in 10^4 lands on the other neighbour, a 1e-3 relative change of that weight."""
+    return torch.from_numpy(w64.numpy().astype(np.float16).astype(np.float32))
+
+
 def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False, round_out=True):
     if fp16:
         # storage-precision emulation of the HIP path: BN folded into the weights (utils/torch_utils.py:181-201), folded
@@ -31,7 +37,7 @@ def _conv_bn_act(x, sd, key, k, s, p, act, fp16=False, round_out=True):
             scale = sd[key + ".bn.weight"].double() / torch.sqrt(sd[key + ".bn.running_var"].double() + BN_EPS)
             w = w * scale[:, None, None, None]
             b = (b - sd[key + ".bn.running_mean"].double()) * scale + sd[key + ".bn.bias"].double()
-        y = F.conv2d(x, w.half().float(), b.float(), stride=s, padding=p)
+        y = F.conv2d(x, _to_f16(w), b.float(), stride=s, padding=p)
         y = F.silu(y) if act == 1 else (F.leaky_relu(y, 0.1) if act == 2 else y)
         return y.half().float() if round_out else y      # round_out=False: the exact fp32 value the fp16 store of the HIP path rounds
     w = sd[key + ".conv.weight"].float()
@@ -56,7 +62,7 @@ def conv_abs_sum(x, sd, key, s, p):
         scale = sd[key + ".bn.weight"].double() / torch.sqrt(sd[key + ".bn.running_var"].double() + BN_EPS)
         w = w * scale[:, None, None, None]
         b = (b - sd[key + ".bn.running_mean"].double()) * scale + sd[key + ".bn.bias"].double()
-    return F.conv2d(x.abs(), w.half().float().abs(), b.float().abs(), stride=s, padding=p)
+    return F.conv2d(x.abs(), _to_f16(w).abs(), b.float().abs(), stride=s, padding=p)
 
 
 @torch.no_grad()

@@ -171,7 +171,13 @@ def test_letterbox_layout_matches_oracle(shape):
     # smooth-ish image so that bilinear taps are not pure noise
     small = rng.integers(0, 256, (shape[0] // 8 + 2, shape[1] // 8 + 2, 3)).astype(np.float32)
     frame = np.kron(small, np.ones((8, 8, 1), np.float32))[:shape[0], :shape[1]].astype(np.uint8)
-    out, (H, W) = det.forward_frames(torch.from_numpy(frame), img_size=256)
+    from yolov7_tracker_amd import _lib
+    out, (H, W) = det.forward_frames(torch.from_numpy(frame), img_size=256)      # selects the plan of the letterboxed size
+    _, _, new_h, new_w, top, left = det.letterbox_params(shape, 256, 64)
+    fd = torch.from_numpy(frame).cuda()[None].contiguous()
+    # the stand-alone kernel (plans whose stem is fused with it never write this tensor: test_fused_stem_equals_layout_plus_conv)
+    _lib.check(_lib.load().y7t_letterbox_layout_u8(_lib.ptr(fd), 1, shape[0], shape[1], H, W, new_h, new_w, top, left, 1, _lib.ptr(det.plan.arena), 16,
+                                                   _lib.stream_ptr()))
     torch.cuda.synchronize()
     ref = lb.letterbox(frame, new_shape=(256, 256), stride=64)
     assert ref.shape[:2] == (H, W)
@@ -299,6 +305,31 @@ def test_upsample_on_read_equals_materialised_upsample(monkeypatch):
     assert sum(int(o["type"]) == 1 for o in ref.plan.ops) == 3
     b = ref(img)[0].raw()
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_fused_stem_equals_layout_plus_conv(monkeypatch):
+    """uint8 frame -> [letterbox] -> BGR->RGB, /255, ReOrg -> stem conv as ONE kernel (y7t_det_forward_stem_u8) against the three-step
+    path (y7t_letterbox_layout_u8 / y7t_input_layout, then op 0): the same MFMA K order, so the heads must be equal bit for bit --
+    native-size frames, padded frames (360 x 640 -> 384 x 640) and resampled frames (540 x 960 -> 384 x 640)"""
+    g = torch.Generator().manual_seed(12)
+    det = build("yolov7-w6", 10, (256, 320), 2)
+    assert det.plan.stem_fused and det.launch_list is not None
+    frames = torch.randint(0, 256, (2, 256, 320, 3), dtype=torch.uint8, generator=g)
+    small = torch.randint(0, 256, (2, 360, 640, 3), dtype=torch.uint8, generator=g)
+    big = torch.randint(0, 256, (2, 540, 960, 3), dtype=torch.uint8, generator=g)
+    a0 = [t.clone() for t in det(frames.cuda())[0].raw()]
+    assert det.launch_list(2)[0].startswith("stem_u8")
+    a0b = [t.clone() for t in det(frames.cuda())[0].raw()]
+    assert all(torch.equal(x, y) for x, y in zip(a0, a0b))
+    a1 = [t.clone() for t in det.forward_frames(small, img_size=640)[0].raw()]
+    a2 = [t.clone() for t in det.forward_frames(big, img_size=640)[0].raw()]
+    monkeypatch.setenv("Y7T_STEM_FUSED", "0")
+    ref = build("yolov7-w6", 10, (256, 320), 2)
+    assert not ref.plan.stem_fused
+    assert all(torch.equal(x, y) for x, y in zip(a0, ref(frames.cuda())[0].raw()))
+    assert all(torch.equal(x, y) for x, y in zip(a1, ref.forward_frames(small, img_size=640)[0].raw()))
+    assert all(torch.equal(x, y) for x, y in zip(a2, ref.forward_frames(big, img_size=640)[0].raw()))
+    assert float(a0[0].abs().max()) > 0 and float(a2[0].abs().max()) > 0
 
 
 def test_head_output_behaves_like_the_reference_tensor():

@@ -43,6 +43,8 @@ SIGNATURES = {
     "y7t_det_forward_ops": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "y7t_det_set_detect": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y7t_det_forward_fused": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "y7t_det_stem_fusable": (c_int, [c_void_p]),
+    "y7t_det_forward_stem_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y7t_input_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y7t_letterbox_layout_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "y7t_det_postprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -47,6 +47,10 @@ struct Y7TConvArgs {
 
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);
 
+// fused uint8 frame -> (letterbox) -> layout -> stem conv (y7t_stem.hip)
+int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int W, int new_h, int new_w, int top, int left, const _Float16* w, int K_pad,
+                       const float* bias, _Float16* out, int ldout, int cout_off, int act, hipStream_t s);
+
 int y7t_upsample_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, _Float16* out, int ldout, int cout_off, hipStream_t s);
 int y7t_maxpool_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, int k, int st, int pd, _Float16* out, int ldout,
                        int cout_off, hipStream_t s);

@@ -109,6 +109,26 @@ extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_s
     return forward_impl(d, B, first, last, nullptr, (hipStream_t)stream);
 }
 
+static bool stem_fusable(const y7t_det* d) {
+    if (d->ops.empty()) return false;
+    const y7t_op& op = d->ops[0];
+    return op.type == Y7T_OP_CONV && op.in_buf == 0 && op.in_ld == 16 && op.in_coff == 0 && op.Cin == 16 && op.KH == 3 && op.KW == 3 && op.stride == 1 &&
+           op.pad == 1 && op.Cout == 64 && op.Cout_pad == 64 && !op.out_f32 && op.korder == 0 && op.up_C == 0 && op.detect_level < 0 &&
+           op.out_ld % 8 == 0 && op.out_coff % 8 == 0 && op.H % 16 == 0 && op.W % 16 == 0;
+}
+
+extern "C" int y7t_det_stem_fusable(const y7t_det* d) { return d && stem_fusable(d) ? 1 : 0; }
+
+extern "C" int y7t_det_forward_stem_u8(y7t_det* d, const void* frames_u8, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream) {
+    Y7T_ARG_CHECK(d && frames_u8 && B > 0 && B <= d->max_batch && H0 > 0 && W0 > 0 && new_h > 0 && new_w > 0 && top >= 0 && left >= 0);
+    if (!stem_fusable(d)) { y7t_set_error("the plan's first op is not a ReOrg + 3x3 -> 64 stem: use y7t_input_layout + y7t_det_forward"); return Y7T_E_STATE; }
+    const y7t_op& op = d->ops[0];
+    const int H = op.H * 2, W = op.W * 2;
+    Y7T_ARG_CHECK(top + new_h <= H && left + new_w <= W);
+    return y7t_stem_u8_launch(frames_u8, B, H0, W0, H, W, new_h, new_w, top, left, d->w + op.w_off, op.K_pad, d->bias + op.bias_off,
+                              (_Float16*)(d->arena + d->bufs[op.out_buf]), op.out_ld, op.out_coff, op.act, (hipStream_t)stream);
+}
+
 extern "C" int y7t_det_set_detect(y7t_det* d, int nl, int na, int no, const float* strides, const float* anchors) {
     Y7T_ARG_CHECK(d && nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && strides && anchors);
     d->nl = nl; d->na = na; d->no = no;

@@ -184,6 +184,7 @@ class Detector:
             plan.anchors = (ctypes.c_float * 24)(*(flat + [0.0] * (24 - len(flat))))
             _lib.check(self._L.y7t_det_set_detect(h, len(plan.heads), plan.det["na"], plan.det["no"], plan.strides, plan.anchors))
             plan.detect_ops = [i for i, op in enumerate(plan.ops) if int(op["type"]) == 0 and int(op["detect_level"]) >= 0]
+            plan.stem_fused = bool(self._L.y7t_det_stem_fusable(h)) and os.environ.get("Y7T_STEM_FUSED", "1") != "0"
             plan.fusable = plan.det["na"] * plan.det["no"] <= 64 and all(int(plan.ops[i]["Cin"]) % 64 == 0 for i in plan.detect_ops)
             self._plans[hw] = plan
         self.plan = self._plans[hw]
@@ -236,31 +237,44 @@ class Detector:
         p = self.plan
         if fuse_decode is not None and not p.fusable:
             fuse_decode = None          # e.g. nc = 80: 255 head channels do not fit one channel tile -> plain heads + decode pass
-        s = _lib.stream_ptr()
-        _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
+        first = self._front(img, is_u8, B, H, W, fuse_decode, pset)
         if mid_hook is None:
-            self._run_ops(B, 0, -1, fuse_decode, pset)
+            self._run_ops(B, first, -1, fuse_decode, pset)
         else:   # (op index, callable): run the list up to that op, call the hook (e.g. record an event), run the rest
-            k = min(int(mid_hook[0]), int(self._L.y7t_det_num_ops(p.handle)))
-            self._run_ops(B, 0, k, fuse_decode, pset)
+            k = max(first, min(int(mid_hook[0]), int(self._L.y7t_det_num_ops(p.handle))))
+            self._run_ops(B, first, k, fuse_decode, pset)
             mid_hook[1]()
             self._run_ops(B, k, -1, fuse_decode, pset)
         self._img_keep = img
         self._epoch += 1
         return HeadOutput(self, B, (H, W), fused=fuse_decode, pset=pset)
 
+    def _front(self, img, is_u8, B, H, W, fuse_decode, pset):
+        """input side of the forward for frames of the plan's size: uint8 frames of a ReOrg + stem plan go through the fused
+        frame -> stem kernel (no layout tensor), everything else through y7t_input_layout.  -> index of the first op still to run"""
+        p, s = self.plan, _lib.stream_ptr()
+        if is_u8 and p.stem_fused:
+            if fuse_decode is not None:     # the fused Detect epilogues append to counters that op 0 would have zeroed
+                _lib.check(self._L.y7t_det_forward_fused(p.handle, B, 0, 0, float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(p.post[pset].ws),
+                                                         p.post[pset].ws.numel(), s))
+            _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(img), B, H, W, H, W, 0, 0, s))
+            return 1
+        _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
+        return 0
+
     def forward_part(self, img, first, last, fuse_decode=None, pset=0):
         """ops [first, last) of the current plan's launch list on the current stream (last < 0: to the end); with `img` (uint8
         NHWC or float32 NCHW device tensor of the plan's size) the input layout runs first.  For callers that capture the
         forward in pieces (bench.py --hipgraph 2); `forward` must have selected the plan before."""
         p, s = self.plan, _lib.stream_ptr()
+        fd = fuse_decode if p.fusable else None
         if img is not None:
             is_u8 = img.dtype == torch.uint8
             B = img.shape[0]
             H, W = (img.shape[1], img.shape[2]) if is_u8 else (img.shape[2], img.shape[3])
-            _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
+            first = max(int(first), self._front(img, is_u8, B, H, W, fd, pset))
             self._part_B = B
-        self._run_ops(self._part_B, first, last, fuse_decode if p.fusable else None, pset)
+        self._run_ops(self._part_B, first, last, fd, pset)
 
     def _materialise_heads(self, out):
         """re-run the Detect 1x1 convs of `out`'s forward in plain mode (fp32 head tensors into the arena)"""
@@ -309,7 +323,11 @@ class Detector:
         B = self.max_batch if B is None else int(B)
         names = []
         for i in range(int(self._L.y7t_det_num_ops(p.handle))):
-            _lib.check(self._L.y7t_det_forward_ops(p.handle, B, i, i + 1, s))
+            img = getattr(self, "_img_keep", None)
+            if i == 0 and p.stem_fused and img is not None and img.dtype == torch.uint8 and tuple(img.shape[1:3]) == (p.H, p.W) and img.shape[0] >= B:
+                _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(img), B, p.H, p.W, p.H, p.W, 0, 0, s))   # how uint8 frames enter
+            else:
+                _lib.check(self._L.y7t_det_forward_ops(p.handle, B, i, i + 1, s))
             names.append(self._L.y7t_last_kernel().decode())
         torch.cuda.synchronize()
         return names
@@ -344,11 +362,19 @@ class Detector:
         self._select((H, W))
         p = self.plan
         s = _lib.stream_ptr()
-        _lib.check(self._L.y7t_letterbox_layout_u8(_lib.ptr(frames), B, H0, W0, H, W, new_h, new_w, top, left, int(p.reorg), _lib.ptr(p.arena),
-                                                   p.in_ld, s))
         if fuse_decode is not None and not p.fusable:
             fuse_decode = None
-        self._run_ops(B, 0, -1, fuse_decode, pset)
+        first = 0
+        if p.stem_fused:                # letterbox + layout + stem conv in one kernel
+            if fuse_decode is not None:
+                _lib.check(self._L.y7t_det_forward_fused(p.handle, B, 0, 0, float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(p.post[pset].ws),
+                                                         p.post[pset].ws.numel(), s))
+            _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(frames), B, H0, W0, new_h, new_w, top, left, s))
+            first = 1
+        else:
+            _lib.check(self._L.y7t_letterbox_layout_u8(_lib.ptr(frames), B, H0, W0, H, W, new_h, new_w, top, left, int(p.reorg), _lib.ptr(p.arena),
+                                                       p.in_ld, s))
+        self._run_ops(B, first, -1, fuse_decode, pset)
         self._img_keep = frames
         self._epoch += 1
         return HeadOutput(self, B, (H, W), fused=fuse_decode, pset=pset), (H, W)
