@@ -166,23 +166,24 @@ def frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, re
     sA, sB, sC, sD = (torch.cuda.Stream() for _ in range(4))
     ev = {}
     fwd_ms_ev = []
-    last_own = [None]
+
+    own = []              # steps this rank detected (candidate set k % 2 is reused every second own batch)
 
     def detect(s, timed):
+        k = len(own)
         with torch.cuda.stream(sA):
             e0, e1, est = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+            if k >= 2:
+                sA.wait_event(ev[own[k - 2]])            # the NMS that last read candidate set k % 2 is through
             e0.record(sA)
-            out = det.forward(frames)
+            out = det.forward(frames, fuse_decode=0.01, pset=k % 2)     # Detect epilogues decode + filter into candidate set k % 2
             e1.record(sA)
             if timed:
                 fwd_ms_ev.append((e0, e1))
-            if last_own[0] is not None:
-                sA.wait_event(ev[last_own[0]])           # staging set free again
-            staged = det.stage_heads(out)
             est.record(sA)
         with torch.cuda.stream(sC):
             sC.wait_event(est)
-            dets, nd = det.postprocess(staged, 0.01, 0.45, None)
+            dets, nd = det.postprocess(out, 0.01, 0.45, None)
             if rank != 0:
                 if on_gpu:
                     relay.send(dets, nd)                  # RCCL send, ordered behind the NMS on this stream
@@ -190,7 +191,7 @@ def frames_mode(args, dist, world, rank, backend, det, frames, dets_dev, trk, re
                     relay.send(dets.cpu(), nd.cpu())      # gloo smoke path
             ev[s] = torch.cuda.Event()
             ev[s].record(sC)
-        last_own[0] = s
+        own.append(s)
 
     def run(lo, hi, timed):
         for s in range(lo, hi):

@@ -1,0 +1,67 @@
+"""GPU, the N > 1 code path of bench.py on a ONE-GPU box: two ranks (torch.distributed.run) sharing the device, the gloo backend for the
+collective (RCCL refuses two ranks on one device).  Sequence-sharded mode: each rank tracks its own synthetic sequence with the DEVICE
+ByteTrack; the gathered rows / id bases must equal a single-process run over the same two sequences with the reference's global id
+counter (basetrack.py:22,43-46).  Frame-sharded single-stream mode: runs and produces tracks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, steps, warmup, batch, img, n_obj):
+    env = dict(os.environ, Y7T_BENCH_SHARE_GPU="1", Y7T_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch),
+           "--img", str(img), "--n_obj", str(n_obj), "--mode", mode, "--no_cpu_baseline", "--no_latency_mode"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_sequence_sharded_equals_single_process():
+    import torch
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    steps, warmup, batch, img, n_obj = 2, 1, 4, 640, 40
+    d = _run("sequences", steps, warmup, batch, img, n_obj)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["collective_backend"] == "gloo" and d["value"] > 0
+    g = d["config"]["result_gather"]
+    # single process, one global counter, sequence 0 then sequence 1 (the reference's serial loop over sequences, track.py:123)
+    n_frames = (steps + warmup) * batch
+    BaseTrack._count = 0
+    rows, bases = [], []
+    for seq in range(2):
+        bases.append(BaseTrack._count)
+        t = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5, max_tracks=512, max_dets=512))
+        n = 0
+        for det in synth.make_detections(n_frames, n_obj, img, seq_idx=seq, bounce=True):
+            n += len(t.update(det, None))
+        rows.append(n)
+    assert g["rows_per_rank"] == rows, (g, rows)
+    assert g["id_base_per_rank"] == bases, (g, bases)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu_sequences.json"), "w"), indent=1)
+
+
+def test_two_ranks_frame_sharded_single_stream_runs():
+    d = _run("frames", 2, 1, 4, 640, 40)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["tracks_alive_last_frame"] > 10
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu_frames.json"), "w"), indent=1)
