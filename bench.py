@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per step (consecutive frames of the sequence)")
-    ap.add_argument("--n_obj", type=int, default=80)
+    ap.add_argument("--n_obj", type=int, default=None, help="objects in the synthetic scene (default: 80 for cfg2, 500 for cfg3)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2 (default, BASELINE's metric): w6@1280 + ByteTrack, ~80 objects.  cfg3: BASELINE configs[2], w6@1280 + BoT-SORT "
+                         "(xywh Kalman, per-frame camera-motion warp), 500 objects -- stresses the IoU matrices / linear assignment")
     ap.add_argument("--img", type=int, default=1280)
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -109,12 +112,12 @@ def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=No
     t_nms = time.perf_counter() - t0
     n = min(100, len(dets_seq))
     t0 = time.perf_counter()
-    tracker_np.run("bytetrack", dets_seq[:n])
+    tracker_np.run("botsort" if args.workload == "cfg3" else "bytetrack", dets_seq[:n], **({"kalman_format": "botsort"} if args.workload == "cfg3" else {}))
     t_trk = (time.perf_counter() - t0) / n
     fps = 1.0 / (t_det + t_nms + t_trk)
     return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "%d frames 1280x1280 through the torch-fp32 detector oracle (%.2f s/frame, %d threads) + 1 NMS call on 2000 "
-                      "candidates (%.1f ms) + %d frames through the numpy ByteTrack oracle (%.2f ms/frame, 1 thread)"
+                      "candidates (%.1f ms) + %d frames through the numpy tracker oracle (%.2f ms/frame, 1 thread)"
                       % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}, parity
 
 
@@ -294,6 +297,9 @@ def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
 
 def main():
     args = parse()
+    cfg3 = args.workload == "cfg3"
+    if args.n_obj is None:
+        args.n_obj = 500 if cfg3 else 80
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -331,8 +337,23 @@ def main():
     plant_objectness_bias(det, frames)
 
     BaseTrack._count = 0
-    trk = ByteTrack(make_opts(), frame_rate=30)
+    if cfg3:
+        from yolov7_tracker_amd.tracker.botsort import BoTSORT
+        o3 = make_opts()
+        o3.kalman_format, o3.max_tracks, o3.max_dets = "botsort", 2048, 1024
+        trk = BoTSORT(o3, frame_rate=30)
+        warps_dev = torch.from_numpy(synth.make_warps(n_frames, seq_idx=seq).reshape(n_frames, 6)).cuda()     # what GMC.apply would estimate (botsort.py:13-248)
+    else:
+        trk = ByteTrack(make_opts(), frame_rate=30)
     results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    def launch_frame(t):
+        """one tracker frame step for frame t of the sequence (BoT-SORT: with that frame's camera-motion warp)"""
+        if cfg3:
+            trk._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
+        else:
+            trk._launch(dets_dev[t], out=results[t])
+    tracker_name = "botsort" if cfg3 else "bytetrack"
+    metric_name = "end-to-end fps (detect+track) YOLOv7-w6@1280 " + ("BoT-SORT, 500-object stress" if cfg3 else "ByteTrack")
     if args.halves == 2 and world == 1:
         dt_s, fwd_ms_step, d0 = halves_mode(args, lambda b: model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=b, seed=0),
                                            frames, dets_dev, trk, results, plant_objectness_bias)
@@ -381,6 +402,8 @@ def main():
     ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev_nms = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev_h2d = [torch.cuda.Event() for _ in range(NS)]
+    ev_trk0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+    ev_trk1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
 
     CONF = 0.01                 # tracker/track.py:239
     graph = None
@@ -419,9 +442,10 @@ def main():
             ev_nms[ps].record(sC)
         with torch.cuda.stream(sB):
             sB.wait_event(ev_nms[ps])      # a frame's detections exist before its tracker step runs
+            ev_trk0[ps].record(sB)
             for i in range(B):
-                t = ps * B + i
-                trk._launch(dets_dev[t], out=results[t])
+                launch_frame(ps * B + i)
+            ev_trk1[ps].record(sB)
 
     def step(s):
         if graph is not None:
@@ -432,8 +456,10 @@ def main():
                 ev_nms[s].record(sA)
             with torch.cuda.stream(sB):
                 sB.wait_event(ev_nms[s])
+                ev_trk0[s].record(sB)
                 for i in range(B):
-                    trk._launch(dets_dev[s * B + i], out=results[s * B + i])
+                    launch_frame(s * B + i)
+                ev_trk1[s].record(sB)
             return
         src = frames
         if host_feed is not None:              # this batch comes over PCIe: copy on its own stream into the buffer the forward two steps back used
@@ -517,8 +543,8 @@ def main():
     gflop_frame = det.gflop_per_frame
     conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
-    if os.path.exists(tpath):      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_conv_hbm_traffic.json", "r01_conv_hbm_traffic.json")) if os.path.exists(q)), "")
+    if tpath:      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed
         traffic = json.load(open(tpath))["hbm_bytes_per_frame"] * B
     if rank == 0:
         # sanity: the tracker produced tracks
@@ -526,11 +552,13 @@ def main():
         n_tracks_last = int(last[trk.cap_t].view(np.int32)[0])
         fps = world * K * B / dt_s
         line = {
-            "metric": "end-to-end fps (detect+track) YOLOv7-w6@1280 ByteTrack", "value": round(fps, 2), "unit": "frames/s",
+            "metric": metric_name, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack, 1 synthetic VisDrone-shape sequence per GPU, %d objects per frame "
-                                   "(10 %% missed, 5 %% false positives, reflected at the border)" % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc, "tracker": "bytetrack",
+            "config": {"workload": ("configs[2]: YOLOv7-w6 1280x1280 + BoT-SORT (xywh Kalman, multi_gmc with a synthetic 2x3 warp per frame)" if cfg3 else
+                                    "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack") + ", 1 synthetic VisDrone-shape sequence per GPU, %d objects per frame "
+                                   "(10 %% missed, 5 %% false positives, reflected at the border)" % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc,
+                       "tracker": tracker_name,
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
                        "parallelism": "sequence-sharded x%d" % world, "collective_backend": backend if world > 1 else None,
                        "result_gather": gathered_info if world > 1 else None},
@@ -539,13 +567,14 @@ def main():
                          "sustained_peak": 1550.0,
                          "sustained_peak_note": "register-only v_mfma_f32_32x32x16_f16 loop with random operands (power-limited clock; "
                                                 "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
-                         "traffic_note": "HBM bytes per launch list from profiles/r01_conv_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
-                                         "algorithmic = 1.217 GB/frame",
+                         "traffic_note": "HBM bytes per launch list from profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); "
+                                         "algorithmic = 1.217 GB/frame" % os.path.basename(tpath),
                          "kernel": "k_conv_igemm<BM,BN,BK,NST> + k_conv3x3_patch<TW,TH,BN> (the conv launch list of one forward: 107 convs in 96 launches; "
                                    "nearest-x2 upsamples folded into their consumers' loaders, Detect decode + candidate filter in the Detect convs' epilogues)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3),
+                                   "tracker_chain": round(float(np.mean([ev_trk0[s].elapsed_time(ev_trk1[s]) for s in range(Wm, Wm + K)])), 3),
                                    "note": "decode_nms = end of this batch's forward (its Detect epilogues have already decoded + filtered) -> end of its rank sort + "
                                            "NMS on stream C: held back until the NEXT forward has left the memory-bound 640^2/320^2 layers, then overlaps the "
                                            "rest of that forward (latency, not cost)"},
@@ -568,7 +597,7 @@ def main():
             torch.cuda.synchronize()
             heads0 = [r[:1].cpu() for r in out0.raw()]
             dets0 = d0[0, :int(n0[0])].cpu()
-            if not args.no_latency_mode:
+            if not args.no_latency_mode and not cfg3:
                 line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq)
             if not args.no_cpu_baseline:                         # the CPU baseline is timed on rank 0 at N=1 only
                 line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0)

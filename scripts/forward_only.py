@@ -1,0 +1,37 @@
+"""N forwards of the benchmarked detector configuration and nothing else (for rocprofv3 passes whose per-dispatch rows must be attributed
+to ops): YOLOv7-w6 @ 1280, 32 uint8 frames resident in HBM, fused stem + fused Detect decode -- the launch list bench.py times.
+Prints the launch list (op index -> kernel variant, shape, algorithmic GFLOP / bytes) as JSON on the last line."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolov7_tracker_amd import synth
+from yolov7_tracker_amd.detector import arch, model
+
+B = int(os.environ.get("B", "32"))
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+det = model.Detector(arch.yolov7_w6(10), None, img_size=(1280, 1280), max_batch=B, seed=0)
+frames = torch.from_numpy(synth.make_frames(B, 80, 1280, seq_idx=0)).cuda()
+det.plant_objectness_bias(frames)
+det.forward(frames)
+names = det.launch_list(B)
+torch.cuda.synchronize()
+print("MARK forwards begin")
+for i in range(N):
+    det.forward(frames, fuse_decode=0.01, pset=i % 2)
+    torch.cuda.synchronize()
+p = det.plan
+ops, ci = [], 0
+for oi, op in enumerate(p.ops):
+    if int(op["type"]) == 0 and int(op["detect_level"]) >= 0 and p.fusable:
+        names[oi] = "igemm<128,64,32,2> 1x1 detect-decode"      # (launch_list probes the ops in plain mode; the fused forward never splits K here)
+    d = {"op": oi, "kernel": names[oi], "H": int(op["H"]), "W": int(op["W"]), "Cin": int(op["Cin"]), "Cout": int(op["Cout"]), "k": int(op["KH"]), "s": int(op["stride"])}
+    if int(op["type"]) == 0:
+        wl = p.wlayout[ci]; ci += 1
+        d["gflop"] = 2 * wl["macs"] * B / 1e9
+        cin_bytes = (int(op["Cin"]) - int(op["up_C"])) * int(op["H"]) * int(op["W"]) + int(op["up_C"]) * int(op["H"]) * int(op["W"]) // 4
+        if oi == 0 and p.stem_fused:
+            cin_bytes = 3 * 1280 * 1280 // 2          # uint8 frame (bytes), expressed in fp16 elements
+        out_elems = int(op["Ho"]) * int(op["Wo"]) * int(op["Cout"]) if int(op["detect_level"]) < 0 else 0
+        d["bytes"] = (cin_bytes + out_elems) * 2 * B + int(op["Cout_pad"]) * int(op["K_pad"]) * 2
+    ops.append(d)
+print(json.dumps({"B": B, "forwards": N, "ops": ops}))

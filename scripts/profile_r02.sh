@@ -1,0 +1,93 @@
+#!/bin/bash
+# Round-2 profile of the default bench workload (run on the GPU box from the repo root).  Every rocprofv3 run is wrapped in `timeout`; PMC passes
+# carry --kernel-trace only.  Outputs under gpurun_out/prof2/ (copied into profiles/r02_* by hand).
+set -u
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/prof2; mkdir -p $out
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/ks /tmp/kt /tmp/pf /tmp/pw /tmp/mb
+# 1. kernel stats of the bench command itself
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no_cpu_baseline --no_latency_mode > $out/bench_under_rocprof.log 2>&1
+f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/bench_kernel_stats.csv
+# 2. per-op kernel trace of the launch list alone
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $root/scripts/forward_only.py 4 > $out/forward_only.log 2>&1
+f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $out/forward_kernel_trace.csv
+# 3. HBM traffic: two separate PMC passes
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python $root/scripts/forward_only.py 3 > /tmp/pf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python $root/scripts/forward_only.py 3 > /tmp/pw.log 2>&1
+# 4. MFMA busy
+CTRS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/mb -- python $root/scripts/forward_only.py 3 > /tmp/mb.log 2>&1
+python3 - $out "$CTRS" <<'PY'
+import csv, glob, json, sys, collections, re
+out, ctrs = sys.argv[1], sys.argv[2].split()
+FWD = ("k_conv", "k_stem", "k_splitk", "k_maxpool", "k_upsample")
+def last_forward(d, n_fwd):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not f: return None
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(f[0])):
+        if any(k in r["Kernel_Name"] for k in FWD):
+            disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(disp)
+    per = None
+    # the forwards are the trailing n_fwd identical runs: find the period
+    names = [disp[i]["name"] for i in ids]
+    for L in range(60, 200):
+        if len(names) >= 2 * L and names[-L:] == names[-2 * L:-L]:
+            per = L; break
+    if per is None: return None
+    return [disp[i] for i in ids[-per:]]
+res = {}
+pf, pw = last_forward("/tmp/pf", 3), last_forward("/tmp/pw", 3)
+if pf and pw:
+    fetch_kb, write_kb = sum(d.get("FETCH_SIZE", 0) for d in pf), sum(d.get("WRITE_SIZE", 0) for d in pw)
+    frames = 32
+    hbm = (2 * fetch_kb + write_kb) * 1024 / frames
+    json.dump({"source": "scripts/profile_r02.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python scripts/forward_only.py 3",
+               "kernels": "every launch of one forward of the benchmarked launch list (fused stem, convs, split-K reduces, pools; %d launches), 32 frames" % len(pf),
+               "frames_per_launch_list": frames, "FETCH_SIZE_KB_per_launch_list": fetch_kb, "WRITE_SIZE_KB_per_launch_list": write_kb,
+               "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as reported (uncalibrated)",
+               "hbm_bytes_per_frame": hbm, "algorithmic_bytes_per_frame": 1217000000.0, "ratio_to_algorithmic": hbm / 1217000000.0},
+              open(out + "/conv_hbm_traffic.json", "w"), indent=1)
+    print(open(out + "/conv_hbm_traffic.json").read())
+mb = last_forward("/tmp/mb", 3)
+if mb:
+    s = {c: sum(d.get(c, 0.0) for d in mb) for c in ctrs}
+    frames, gflop = 32, 354.9
+    exp = frames * gflop * 1e9 / (2.0 * 32 * 32 * 16)
+    cyc = s["GRBM_GUI_ACTIVE"] / 8.0
+    r = {"source": "scripts/profile_r02.sh: rocprofv3 --kernel-trace --pmc " + " ".join(ctrs) + " -- python scripts/forward_only.py 3",
+         "scope": "the %d launches of the last forward (32 frames)" % len(mb), "sum": s, "gpu_cycles_per_xcd": cyc,
+         "mfma_busy_fraction": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), "mfma_insts": s["SQ_INSTS_MFMA"], "expected_mfma_insts": exp,
+         "valu_per_mfma": s["SQ_INSTS_VALU"] / max(1.0, s["SQ_INSTS_MFMA"]),
+         "wave_cycle_split": {"wait_any": s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"], "wait_inst_any": s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]}}
+    json.dump(r, open(out + "/conv_mfma_busy.json", "w"), indent=1)
+    print(json.dumps({k: r[k] for k in ("mfma_busy_fraction", "mfma_insts", "expected_mfma_insts", "valu_per_mfma", "wave_cycle_split")}))
+# per-op table from the kernel trace
+try:
+    meta = json.loads([l for l in open(out + "/forward_only.log") if l.startswith("{")][-1])
+    rows = [r for r in csv.DictReader(open(out + "/forward_kernel_trace.csv")) if any(k in r["Kernel_Name"] for k in FWD)]
+    names = [r["Kernel_Name"] for r in rows]
+    per = next(L for L in range(60, 200) if names[-L:] == names[-2 * L:-L])
+    last = rows[-per:]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
+    # map dispatches to ops: a split-K conv is followed by its reduce
+    it = iter(zip(last, dur))
+    lines, tot_us, tot_gf = [], 0.0, 0.0
+    for op in meta["ops"]:
+        r, d = next(it)
+        if "splitK" in op["kernel"]:
+            r2, d2 = next(it); d += d2
+        gf, by = op.get("gflop", 0.0), op.get("bytes", 0)
+        lines.append("%3d %-44s %4dx%-4d %4d->%-4d %d/%d %9.1f us %8.1f TF/s %7.0f GB/s" % (op["op"], op["kernel"], op["H"], op["W"], op["Cin"], op["Cout"], op["k"], op["s"],
+                                                                                    d, gf / d * 1e3 if d else 0, by / d * 1e-3 if d else 0))
+        tot_us += d; tot_gf += gf
+    open(out + "/conv_per_layer_b32.txt", "w").write("op kernel shape(HxW Cin->Cout k/s)  time  TFLOP/s  algorithmic GB/s   (one forward of 32 frames, kernels timed back to back by rocprofv3 --kernel-trace)\n" +
+                                                   "\n".join(lines) + "\nTOTAL %.3f ms per 32 frames -> %.1f TFLOP/s\n" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
+    print("per-layer table: TOTAL %.3f ms -> %.1f TFLOP/s" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
+except Exception as e:
+    print("per-layer table failed:", repr(e))
+PY
+head -14 $out/bench_kernel_stats.csv 2>/dev/null | cut -c1-160
+grep -o '"value": [0-9.]*, "unit": "frames/s"\|"launch_list_ms": [0-9.]*' $out/bench_under_rocprof.log | head -2

@@ -280,7 +280,7 @@ def test_plugin_tracker_written_against_the_strack_contract():
         assert [t.track_id for t in cur] == [r[0] for r in want[f]], f
         for t, r in zip(cur, want[f]):
             np.testing.assert_allclose(np.asarray(t.tlwh, dtype=np.float64), r[1], rtol=util.TLWH_RTOL, atol=util.TLWH_ATOL)
-    assert BaseTrack._count == max(r[0] for fr in want[:n_frames] for r in fr)
+    assert BaseTrack._count >= max(r[0] for fr in want[:n_frames] for r in fr)      # (ids of never-confirmed tracks are not in the output)
     # tracks returned by the fused device trackers are views: their state only changes inside the tracker's step
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
     from yolov7_tracker_amd import _lib
