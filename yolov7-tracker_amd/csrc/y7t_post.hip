@@ -304,99 +304,77 @@ __global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbo
     if (i == 0) nsorted[b] = n < max_nms ? n : max_nms;
 }
 
-// ------------------------------------------------------------------------------------------------ NMS mask
-// mask[b][i][tj] bit jj: sorted box (tj*64+jj) has IoU > thr with sorted box i (only j > i matter)
-__global__ void __launch_bounds__(64) k_nms_mask(const float* __restrict__ sbox, const int* __restrict__ nsorted, int cap, float thr,
-                                                 unsigned long long* __restrict__ mask, int words) {
-    __shared__ float bx[64][4];
-    const int b = blockIdx.y;
-    const int n = nsorted[b];
-    const int nt = (n + 63) / 64;
-    const long long pairs = (long long)nt * (nt + 1) / 2;
-    const float* sb = sbox + (size_t)b * cap * 4;
-    for (long long pr = blockIdx.x; pr < pairs; pr += gridDim.x) {
-        // unrank (ti <= tj) from the linear pair index, row-major over the upper triangle
-        int ti = (int)((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)pr)) * 0.5);
-        while ((long long)ti * nt - (long long)ti * (ti - 1) / 2 > pr) --ti;
-        while ((long long)(ti + 1) * nt - (long long)(ti + 1) * ti / 2 <= pr) ++ti;
-        const int tj = ti + (int)(pr - ((long long)ti * nt - (long long)ti * (ti - 1) / 2));
-        __syncthreads();
-        const int j = tj * 64 + threadIdx.x;
-        if (j < n) { bx[threadIdx.x][0] = sb[4 * (size_t)j]; bx[threadIdx.x][1] = sb[4 * (size_t)j + 1]; bx[threadIdx.x][2] = sb[4 * (size_t)j + 2]; bx[threadIdx.x][3] = sb[4 * (size_t)j + 3]; }
-        __syncthreads();
-        const int i = ti * 64 + threadIdx.x;
-        if (i >= n) continue;
-        const float x1 = sb[4 * (size_t)i], y1 = sb[4 * (size_t)i + 1], x2 = sb[4 * (size_t)i + 2], y2 = sb[4 * (size_t)i + 3];
-        const float ai = (x2 - x1) * (y2 - y1);
-        unsigned long long bits = 0;
-        const int lim = (n - tj * 64) < 64 ? (n - tj * 64) : 64;
-        for (int t = 0; t < lim; ++t) {
-            if (tj * 64 + t <= i) continue;
-            const float xx1 = fmaxf(x1, bx[t][0]), yy1 = fmaxf(y1, bx[t][1]), xx2 = fminf(x2, bx[t][2]), yy2 = fminf(y2, bx[t][3]);
-            const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-            const float inter = w * h;
-            const float aj = (bx[t][2] - bx[t][0]) * (bx[t][3] - bx[t][1]);
-            const float ovr = inter / (ai + aj - inter);
-            if (ovr > thr) bits |= 1ull << t;
-        }
-        mask[((size_t)b * cap + i) * words + tj] = bits;
-    }
+// ------------------------------------------------------------------------------------------------ greedy NMS, kept-list form
+// torchvision.ops.nms semantics (general.py:676-682): walk the candidates in score order; keep one unless an EARLIER KEPT box of its class
+// (class-offset boxes) overlaps it with IoU > thr; stop after max_det keeps.  One workgroup per image walks the sorted list in chunks of 256:
+//   (a) every lane tests its candidate against the kept list so far (<= max_det boxes in LDS, broadcast reads);
+//   (b) the four waves take turns: a wave first tests against what the earlier waves of this chunk kept, then resolves its own 64 candidates
+//       with ballots (the first alive lane is kept, the later lanes test against it, repeat).
+// Work = (candidates walked) x (boxes kept), and the walk ends at max_det keeps -- typically a few hundred candidates of a few thousand --
+// where the previous form computed the full upper-triangular IoU bit-matrix (n^2 / 2 pairs, n * n / 8 bytes) before a serial scan.
+// The IoU arithmetic is the same expression as before (raw coordinates, no +1), so keep lists stay bit-identical.
+__device__ __forceinline__ bool nms_overlaps(const float* a, float aa, float x1, float y1, float x2, float y2, float ab, float thr) {
+    const float xx1 = fmaxf(a[0], x1), yy1 = fmaxf(a[1], y1), xx2 = fminf(a[2], x2), yy2 = fminf(a[3], y2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    return inter / (aa + ab - inter) > thr;
 }
 
-// ------------------------------------------------------------------------------------------------ NMS scan + finalize
-// one wave per image: greedy scan in score order, stops after max_det keeps; then writes the (n,6) rows
-// [x1,y1,x2,y2 (scale_coords, clip, round), conf, cls] in score order (== x[i] of the reference).
-__global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* __restrict__ mask, int words, const int* __restrict__ nsorted,
-                                                 const int* __restrict__ sorder, const float* __restrict__ cbox, const float* __restrict__ cscore,
-                                                 const float* __restrict__ ccls, int cap, int max_det, const float* __restrict__ lb /*[B][5] gain,padw,padh,H0,W0*/,
-                                                 float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/,
-                                                 int mcap) {
-    extern __shared__ unsigned long long removed[];   // words
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox, const int* __restrict__ nsorted, const int* __restrict__ sorder,
+                                                  const float* __restrict__ cbox, const float* __restrict__ cscore, const float* __restrict__ ccls, int cap,
+                                                  int mcap, float thr, int max_det, const float* __restrict__ lb /*[B][5] gain,padw,padh,H0,W0*/,
+                                                  float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/) {
+    extern __shared__ float ksm[];                 // kept boxes [max_det][4] | areas [max_det]
+    __shared__ int s_nkeep;
+    float* kbox = ksm;
+    float* karea = ksm + 4 * max_det;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = nsorted[b];
-    const int nw = (n + 63) / 64;
-    for (int w = lane; w < nw; w += 64) removed[w] = 0ull;
+    const float* sb = sbox + (size_t)b * mcap * 4;
+    if (tid == 0) s_nkeep = 0;
     __syncthreads();
-    const unsigned long long* mk = mask + (size_t)b * mcap * words;
-    const int* so = sorder + (size_t)b * mcap;
-    int nkeep = 0;
-    for (int c = 0; c < nw && nkeep < max_det; ++c) {
-        const int i = c * 64 + lane;
-        const unsigned long long diag = (i < n) ? mk[(size_t)i * words + c] : 0ull;
-        unsigned long long rem = removed[c];
-        unsigned long long kept = 0ull;
-        const int lim = (n - c * 64) < 64 ? (n - c * 64) : 64;
-        for (int t = 0; t < lim; ++t) {           // uniform across the wave
-            if (!((rem >> t) & 1ull)) {
-                if (nkeep < max_det) {
-                    kept |= 1ull << t;
-                    ++nkeep;
-                    rem |= __shfl(diag, t);
-                } else break;
+    for (int base = 0; base < n; base += 256) {
+        const int nk0 = s_nkeep;                   // kept before this chunk (uniform)
+        if (nk0 >= max_det) break;
+        const int i = base + tid;
+        const bool valid = i < n;
+        float bx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) { bx[0] = sb[4 * (size_t)i]; bx[1] = sb[4 * (size_t)i + 1]; bx[2] = sb[4 * (size_t)i + 2]; bx[3] = sb[4 * (size_t)i + 3]; }
+        const float area = (bx[2] - bx[0]) * (bx[3] - bx[1]);
+        bool alive = valid;
+        for (int k = 0; k < nk0; ++k)              // (a) against everything kept in earlier chunks: kept box k is the EARLIER (higher-score) box
+            if (alive && nms_overlaps(kbox + 4 * k, karea[k], bx[0], bx[1], bx[2], bx[3], area, thr)) alive = false;
+        for (int w = 0; w < 4; ++w) {              // (b) the waves of this chunk in score order
+            if (wave == w) {
+                int nk = s_nkeep;
+                for (int k = nk0; k < nk; ++k)     // kept by the earlier waves of this chunk
+                    if (alive && nms_overlaps(kbox + 4 * k, karea[k], bx[0], bx[1], bx[2], bx[3], area, thr)) alive = false;
+                unsigned long long m = __ballot(alive);
+                while (m && nk < max_det) {
+                    const int t = __ffsll((long long)m) - 1;
+                    const float tx1 = __shfl(bx[0], t), ty1 = __shfl(bx[1], t), tx2 = __shfl(bx[2], t), ty2 = __shfl(bx[3], t), ta = __shfl(area, t);
+                    if (lane == t) {
+                        kbox[4 * nk] = bx[0]; kbox[4 * nk + 1] = bx[1]; kbox[4 * nk + 2] = bx[2]; kbox[4 * nk + 3] = bx[3];
+                        karea[nk] = area;
+                        keep_idx[(size_t)b * max_det + nk] = i;
+                        alive = false;
+                    }
+                    ++nk;
+                    const float kb[4] = {tx1, ty1, tx2, ty2};
+                    if (alive && lane > t && nms_overlaps(kb, ta, bx[0], bx[1], bx[2], bx[3], area, thr)) alive = false;
+                    m = __ballot(alive) & ~((2ull << t) - 1ull);
+                }
+                if (lane == 0) s_nkeep = nk;
             }
+            __syncthreads();
         }
-        // record kept candidates of this chunk (lane t writes its own)
-        if ((kept >> lane) & 1ull) {
-            const int pos = (nkeep - __popcll(kept)) + __popcll(kept & ((1ull << lane) - 1ull));
-            keep_idx[(size_t)b * max_det + pos] = i;
-        }
-        // OR the kept rows into the removed words of later chunks
-        for (int w = c + 1 + lane; w < nw; w += 64) {
-            unsigned long long acc = removed[w];
-            unsigned long long kk = kept;
-            while (kk) {
-                const int t = __ffsll((long long)kk) - 1;
-                kk &= kk - 1;
-                acc |= mk[(size_t)(c * 64 + t) * words + w];
-            }
-            removed[w] = acc;
-        }
-        __syncthreads();
     }
     __syncthreads();
-    if (lane == 0) ndets[b] = nkeep;
+    const int nkeep = s_nkeep;
+    if (tid == 0) ndets[b] = nkeep;
+    const int* so = sorder + (size_t)b * mcap;
     const float gain = lb[b * 5 + 0], padw = lb[b * 5 + 1], padh = lb[b * 5 + 2], H0 = lb[b * 5 + 3], W0 = lb[b * 5 + 4];
-    for (int k = lane; k < nkeep; k += 64) {
+    for (int k = tid; k < nkeep; k += 256) {
         const int i = so[keep_idx[(size_t)b * max_det + k]];
         const float* bo = cbox + ((size_t)b * cap + i) * 4;
         float x1 = (bo[0] - padw) / gain, y1 = (bo[1] - padh) / gain, x2 = (bo[2] - padw) / gain, y2 = (bo[3] - padh) / gain;
@@ -405,20 +383,19 @@ __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* __res
         float* o = dets + ((size_t)b * max_det + k) * 6;
         o[0] = rintf(x1); o[1] = rintf(y1); o[2] = rintf(x2); o[3] = rintf(y2);
         o[4] = cscore[(size_t)b * cap + i]; o[5] = ccls[(size_t)b * cap + i];
-        keep_idx[(size_t)b * max_det + k] = i;   // leave the candidate index for callers that want raw boxes
     }
+    __syncthreads();
+    for (int k = tid; k < nkeep; k += 256) keep_idx[(size_t)b * max_det + k] = so[keep_idx[(size_t)b * max_det + k]];   // candidate slots, for callers that want raw boxes
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 size_t y7t_post_ws_bytes(int B, int cap, int max_nms) {
     const size_t mcap = (size_t)(cap < max_nms ? cap : max_nms);    // NMS runs on the top max_nms candidates only (general.py:664-665)
-    const size_t words = (mcap + 63) / 64;
     size_t o = 0;
     auto take = [&](size_t bytes) { o = (o + bytes + 255) & ~(size_t)255; };
     take((size_t)B * cap * 16); take((size_t)B * cap * 4); take((size_t)B * cap * 4); take((size_t)B * cap * 4);  // cbox cscore ccls cidx
     take((size_t)B * 4); take((size_t)B * 4);                                                                    // count nsorted
     take((size_t)B * mcap * 16); take((size_t)B * mcap * 4);                                                     // sbox sorder
-    take((size_t)B * mcap * words * 8);                                                                          // mask
     take((size_t)B * 5 * 4);                                                                                     // letterbox params
     return o + 256;
 }
@@ -439,7 +416,6 @@ Y7TCandWs y7t_post_cand_ws(void* ws, int B, int cap) {
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     const int B = a.B, cap = a.cap;
     const size_t mcap = (size_t)(cap < a.max_nms ? cap : a.max_nms);
-    const size_t words = (mcap + 63) / 64;
     char* base = (char*)a.ws;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base + o; o = (o + bytes + 255) & ~(size_t)255; return p; };
@@ -451,7 +427,6 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     int* nsorted = (int*)take((size_t)B * 4);
     float* sbox = (float*)take((size_t)B * mcap * 16);
     int* sorder = (int*)take((size_t)B * mcap * 4);
-    unsigned long long* mask = (unsigned long long*)take((size_t)B * mcap * words * 8);
     float* lb = (float*)take((size_t)B * 5 * 4);
     if (o + 256 > a.ws_bytes) { y7t_set_error("postprocess workspace too small (%zu < %zu)", a.ws_bytes, o + 256); return Y7T_E_ARG; }
     if (!a.predecoded) Y7T_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int) * B, s));
@@ -474,10 +449,8 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_rank_sort, dim3((cap + 255) / 256, B), dim3(256), 0, s, cbox, cscore, ccls, cidx, count, cap, a.max_nms, sbox, sorder, nsorted, (int)mcap);
     Y7T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_mask, dim3(1024, B), dim3(64), 0, s, sbox, nsorted, (int)mcap, a.iou_thres, mask, (int)words);
-    Y7T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(64), words * 8, s, mask, (int)words, nsorted, sorder, cbox, cscore, ccls, cap, a.max_det, lb, a.dets,
-                       a.ndets, a.keep_idx, (int)mcap);
+    hipLaunchKernelGGL(k_nms_keep, dim3(B), dim3(256), (size_t)a.max_det * 5 * sizeof(float), s, sbox, nsorted, sorder, cbox, cscore, ccls, cap, (int)mcap,
+                       a.iou_thres, a.max_det, lb, a.dets, a.ndets, a.keep_idx);
     Y7T_LAUNCH_CHECK();
     if (a.count_out) Y7T_HIP_CHECK(hipMemcpyAsync(a.count_out, count, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
     return 0;
