@@ -2,7 +2,7 @@
 device-side kernel time with detections resident in HBM (no host sync inside the loop)."""
 import sys, time, types
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov7_tracker_amd import synth, _lib
 from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
 from yolov7_tracker_amd.tracker.basetrack import BaseTrack

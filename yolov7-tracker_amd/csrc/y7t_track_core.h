@@ -60,7 +60,9 @@ Y7T_FN void y7t_sync(const Y7TExec&) {
 #define Y7T_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define Y7T_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define Y7T_FETCH_ADD(p, v) atomicAdd((p), (v))
+#define Y7T_ATOMIC_MIN_I(p, v) atomicMin((p), (v))
 #else
+#define Y7T_ATOMIC_MIN_I(p, v) (*(p) = (*(p) < (v)) ? *(p) : (v))
 #define Y7T_FETCH_ADD(p, v) y7t_fetch_add_host((p), (v))
 #define Y7T_ATOMIC_MAX(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
 #define Y7T_ATOMIC_ADD(p, v) (*(p) += (v))

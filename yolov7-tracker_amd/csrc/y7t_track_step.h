@@ -160,6 +160,170 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
     y7t_sync(ex);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse form of y7t_assoc for crowded frames (hundreds of tracks x hundreds of detections).  An IoU cost matrix is sparse: a track
+// overlaps a handful of detections, and only edges with cost <= thresh ("candidates") can be part of the optimum of
+// lap.lapjv(extend_cost=True, cost_limit=thresh) -- a dearer pair is beaten by leaving both unmatched, and in the shortest-augmenting-path
+// search the null column is always reached before a non-candidate column (its distance through any row is smaller), so such columns
+// are never scanned and never get a price.  Therefore:
+//   1. the cost pass appends candidate edges to per-row lists instead of storing na x nb doubles (rows sorted by column afterwards: the
+//      atomics make the append order arbitrary);
+//   2. rows without candidates are unmatched, isolated pairs are matched (as in the dense census);
+//   3. the rest splits into the connected components of the candidate graph (label propagation over the edge lists), and the assignment
+//      problem separates over components: ONE LANE solves one component with a serial sparse Dijkstra / augment loop, all components
+//      in parallel.  (The dense solver made ~10 block-wide passes over all columns per unsettled row: 65 % of a 500-object frame.)
+// Same optimum as the dense solver; identical assignment whenever it is unique.  Falls back (returns false) when a row has more than
+// Y7T_MAXC candidates or the scratch does not fit.
+// ---------------------------------------------------------------------------------------------
+#define Y7T_MAXC 24
+#ifndef Y7T_SPARSE_MIN
+#define Y7T_SPARSE_MIN 4096      // na * nb from which the sparse path is taken (64 x 64)
+#endif
+Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+    const int tid = ex.tid, nt = ex.nt;
+    // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
+    // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
+    const size_t list_bytes = (size_t)na * Y7T_MAXC * (sizeof(int) + sizeof(double));
+    const size_t T = (size_t)s.h->cfg.cap_t, D = (size_t)s.h->cfg.cap_d, blob_bytes = T * (T > D ? T : D) * sizeof(double);
+    char* wbase = (char*)s.cost;
+    char* lbase = (char*)s.cost + ((work_bytes + 63) & ~(size_t)63);
+    if (ex.fast && work_bytes + 64 <= ex.fast_bytes) {
+        wbase = ex.fast;
+        lbase = (work_bytes + 64 + list_bytes <= ex.fast_bytes) ? ex.fast + ((work_bytes + 63) & ~(size_t)63) : (char*)s.cost;
+    }
+    if (((work_bytes + 63) & ~(size_t)63) + list_bytes > blob_bytes) return false;
+    double* v = (double*)wbase;                               // [nb] column prices
+    double* dd = v + nb;                                      // [nb] tentative distances
+    int* rowcnt = (int*)(dd + nb + 2);                        // [na]
+    int* rowlab = rowcnt + na;                                // [na]
+    int* x = rowlab + na;                                     // [na]
+    int* nextrow = x + na;                                    // [na] (reserved)
+    int* colcnt = nextrow + na;                               // [nb]
+    int* collab = colcnt + nb;                                // [nb]
+    int* y = collab + nb;                                     // [nb]
+    int* pred = y + nb;                                       // [nb]
+    int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
+    int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
+    int* flag = nextcol + nb;                                 // [2] overflow, changed
+    double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
+    int* ccol = (int*)(ccost + (size_t)na * Y7T_MAXC);        // [na][MAXC] candidate columns
+    for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
+    for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    y7t_sync(ex);
+    // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix) ----
+    {
+        const int lanes = nt < 64 ? nt : 64, nw = nt / lanes, wave = tid / lanes, lane = tid - wave * lanes;
+        for (int j = lane; j < nb; j += lanes) {
+            const double q[4] = {s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]};
+            for (int i = wave; i < na; i += nw) {
+                const double c = y7t_iou_dist(s.ttlbr + 4 * i, q);
+                if (c <= thresh) {
+                    const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
+                    if (k < Y7T_MAXC) { ccol[(size_t)i * Y7T_MAXC + k] = j; ccost[(size_t)i * Y7T_MAXC + k] = c; }
+                    else flag[0] = 1;
+                    Y7T_FETCH_ADD(colcnt + j, 1);
+                }
+            }
+        }
+    }
+    y7t_sync(ex);
+    if (flag[0]) return false;
+    for (int i = tid; i < na; i += nt) {                      // sort each row's candidates by column (insertion sort, <= MAXC entries)
+        int* cc = ccol + (size_t)i * Y7T_MAXC;
+        double* cw = ccost + (size_t)i * Y7T_MAXC;
+        const int n = rowcnt[i];
+        for (int a = 1; a < n; ++a) {
+            const int cj = cc[a]; const double cv = cw[a];
+            int b = a - 1;
+            while (b >= 0 && cc[b] > cj) { cc[b + 1] = cc[b]; cw[b + 1] = cw[b]; --b; }
+            cc[b + 1] = cj; cw[b + 1] = cv;
+        }
+    }
+    y7t_sync(ex);
+    // ---- 2. forced decisions ----
+    for (int i = tid; i < na; i += nt) {
+        if (rowcnt[i] == 0) x[i] = nb;                        // null column
+        else if (rowcnt[i] == 1 && colcnt[ccol[(size_t)i * Y7T_MAXC]] == 1) {
+            const int j = ccol[(size_t)i * Y7T_MAXC];
+            const double red = ccost[(size_t)i * Y7T_MAXC] - thresh;
+            if (red < 0.0) { x[i] = j; y[j] = i; v[j] = red; }
+        }
+    }
+    y7t_sync(ex);
+    // ---- 3. components of the candidate graph among the unsettled rows: label = smallest row index ----
+    for (int it = 0; it < na + 2; ++it) {
+        for (int i = tid; i < na; i += nt)
+            if (x[i] == -1)
+                for (int k = 0; k < rowcnt[i]; ++k) Y7T_ATOMIC_MIN_I(collab + ccol[(size_t)i * Y7T_MAXC + k], rowlab[i]);
+        if (tid == 0) flag[1] = 0;
+        y7t_sync(ex);
+        for (int i = tid; i < na; i += nt)
+            if (x[i] == -1) {
+                int m = rowlab[i];
+                for (int k = 0; k < rowcnt[i]; ++k) { const int l = collab[ccol[(size_t)i * Y7T_MAXC + k]]; m = l < m ? l : m; }
+                if (m != rowlab[i]) { rowlab[i] = m; flag[1] = 1; }
+            }
+        y7t_sync(ex);
+        if (!flag[1]) break;
+        y7t_sync(ex);
+    }
+    // ---- 4. one lane per component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
+    for (int lead = tid; lead < na; lead += nt) {
+        if (x[lead] != -1 || rowlab[lead] != lead) continue;
+        for (int start = lead; start < na; ++start) {
+            if (rowlab[start] != lead || x[start] != -1) continue;
+            // Dijkstra from `start`; the null column lives in registers (every component has its own)
+            double d_null = 0.0; int pred_null = start;
+            int touched = -1;
+            for (int k = 0; k < rowcnt[start]; ++k) {
+                const int j = ccol[(size_t)start * Y7T_MAXC + k];
+                dd[j] = ccost[(size_t)start * Y7T_MAXC + k] - thresh - v[j]; pred[j] = start; st[j] = 1; nextcol[j] = touched; touched = j;
+            }
+            int final_j = -2; double mind = 0.0;
+            for (;;) {
+                double mv = d_null; int mj = nb;               // frontier minimum, ties to the lowest column index (the null column is index nb)
+                for (int j = touched; j >= 0; j = nextcol[j])
+                    if (st[j] == 1 && (dd[j] < mv || (dd[j] == mv && j < mj))) { mv = dd[j]; mj = j; }
+                mind = mv;
+                if (mj == nb || y[mj] < 0) { final_j = mj; break; }
+                st[mj] = 2;
+                const int i = y[mj];
+                double cij = 0.0;
+                for (int k = 0; k < rowcnt[i]; ++k) if (ccol[(size_t)i * Y7T_MAXC + k] == mj) cij = ccost[(size_t)i * Y7T_MAXC + k];
+                const double hh = cij - thresh - v[mj] - mind;
+                for (int k = 0; k < rowcnt[i]; ++k) {
+                    const int j = ccol[(size_t)i * Y7T_MAXC + k];
+                    if (st[j] == 2) continue;
+                    const double cred = ccost[(size_t)i * Y7T_MAXC + k] - thresh - v[j] - hh;
+                    if (st[j] == 0) { dd[j] = cred; pred[j] = i; st[j] = 1; nextcol[j] = touched; touched = j; }
+                    else if (cred < dd[j]) { dd[j] = cred; pred[j] = i; }
+                }
+                if (-hh < d_null) { d_null = -hh; pred_null = i; }
+            }
+            for (int j = touched; j >= 0; j = nextcol[j]) { if (st[j] == 2) v[j] += dd[j] - mind; }
+            // augment
+            {
+                int i = -1, j = final_j;
+                while (i != start) {
+                    i = (j == nb) ? pred_null : pred[j];
+                    if (j != nb) y[j] = i;
+                    const int t = j;
+                    j = x[i];
+                    x[i] = t;
+                }
+            }
+            for (int j = touched; j >= 0; ) { const int nx = nextcol[j]; st[j] = 0; j = nx; }
+        }
+    }
+    y7t_sync(ex);
+    for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
+    for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
+    y7t_sync(ex);
+    return true;
+}
+
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
 // dtlbr[0..nb)  ->  xrow[na] (det index or -1), ycol[nb] (track index or -1).
 // The LAP work arrays and, when it fits, the cost matrix are placed in the workgroup's fast
@@ -171,6 +335,7 @@ Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double
         y7t_sync(ex);
         return;
     }
+    if ((long long)na * nb >= Y7T_SPARSE_MIN && y7t_assoc_sparse(ex, s, na, nb, thresh)) return;
     Y7TLap L;
     L.nr = na; L.nc = nb; L.ld = nb; L.n = na + nb; L.half = thresh / 2.0;
     L.prof = (thresh == 0.9) ? s.h->prof + 16 : nullptr;   // stamp the first association
