@@ -72,6 +72,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise Y7TError("liby7t.so is missing (%s): build it with `python -m yolov7_tracker_amd.build` -- "
                        "this package has no CPU fallback" % LIB_PATH)
+    # torch's bundled HIP runtime must be the one in the process (the library works on torch-owned device memory and
+    # streams): loading liby7t.so first would bind /opt/rocm's libamdhip64 and leave torch without a visible device
+    import torch  # noqa: F401
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
