@@ -251,6 +251,17 @@ int y7t_reid_destroy(y7t_reid* reid);
  * crops that are already resized and normalised (device; frame_u8 / boxes ignored).  feats: N x feat_dim float32 (device). */
 int y7t_reid_forward(y7t_reid* reid, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats,
                      y7t_stream stream);
+/* Crops taken from several frames in one pass (a batch of frames and all their detections -- the throughput mode of BASELINE config 4):
+ * frames_u8 = n_frames x (H, W, 3) uint8 contiguous (device), frame_idx[i] = frame of box i (device int32). */
+int y7t_reid_forward_batch(y7t_reid* reid, const void* frames_u8, int n_frames, int H, int W, const float* boxes, const int* frame_idx, int N,
+                           float* feats, y7t_stream stream);
+/* The MFMA path of config 4 ("ReID conv as MFMA kernel"): OSNet x0_25 on 128 x 64 crops as ONE kernel, one workgroup per crop, every
+ * intermediate in LDS, fp16 storage / fp32 accumulate (tracker/reid_models/OSNet.py:223-279,282-438,567-579 with BatchNorm folded).  `blob`
+ * (device memory, y7t_reid_fused_blob_size() bytes) holds the parameters in the kernel's consumption order with the 1x1 weights already in
+ * MFMA fragment order (host: tracker/reid.py::pack_fused).  Once set, y7t_reid_forward / _batch on frame crops run the fused kernel; the
+ * op list above stays the fp32 path (crops_f32 input, other widths / crop sizes).  blob == NULL switches back. */
+size_t y7t_reid_fused_blob_size(void);
+int y7t_reid_set_fused(y7t_reid* reid, const void* blob, size_t blob_bytes);
 
 /* single fused Conv+bias+act launch (layer-level parity tests, rocprof attribution); same fields as y7t_op but
  * with raw device pointers. */

@@ -12,7 +12,15 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def extractor():
     from yolov7_tracker_amd.tracker.reid import ReIDExtractor
-    return ReIDExtractor(None, seed=3, max_crops=256)
+    return ReIDExtractor(None, seed=3, max_crops=256, fused=False)      # the fp32 op list: the exact path
+
+
+@pytest.fixture(scope="module")
+def fused_extractor():
+    from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+    e = ReIDExtractor(None, seed=3, max_crops=1024)                      # default for x0_25 / 128 x 64: the one-kernel MFMA path
+    assert e.fused
+    return e
 
 
 def test_osnet_forward_matches_oracle(extractor):
@@ -42,7 +50,55 @@ def test_crop_resize_normalise_matches_oracle(extractor):
     np.testing.assert_allclose(extractor(crops), got.numpy(), rtol=1e-4, atol=1e-4 * float(want.abs().max()))
 
 
-def test_deepsort_with_device_reid_tracks_the_scene(extractor):
+def test_fused_osnet_kernel_matches_oracle(fused_extractor, extractor):
+    """csrc/y7t_reid_fused.hip (one workgroup per crop, fp16 storage / fp32 accumulate on the MFMA units) against the fp32 oracle from the FRAME:
+    crop + resize + normalise + ~70 layers.  Tolerance: every stored activation is rounded to fp16 (rel. 2^-11 = 4.9e-4) and the errors add
+    incoherently over the ~35 layers of the longest path -> a few 1e-3 of the feature scale; measured 5e-4 of max|feature|, cosine 1 - 1e-7."""
+    from oracle import reid_torch
+    from yolov7_tracker_amd import synth
+    frame = synth.make_frames(1, 80, 640, seq_idx=3)[0]
+    rng = np.random.default_rng(5)
+    xy, wh = rng.uniform(0, 560, (60, 2)), rng.uniform(8, 200, (60, 2))
+    boxes = np.concatenate([xy, np.minimum(xy + wh, 700)], 1).astype(np.float32)      # some reach past the right / bottom edge (numpy clips the slice)
+    boxes[:6] = [[10, 20, 60, 150], [100.7, 0.2, 130.9, 64.5], [300, 300, 364, 428], [600, 500, 640, 640], [5, 5, 13, 21], [200, 100, 520, 600]]
+    want = reid_torch.osnet_forward(fused_extractor.sd, reid_torch.preprocess(frame, boxes)).numpy()
+    got = fused_extractor.features_for_boxes(frame, boxes).cpu().numpy()
+    assert np.isfinite(got).all() and float(np.abs(want).mean()) > 0.05
+    scale = float(np.abs(want).max())
+    assert np.abs(got - want).max() <= 3e-3 * scale, np.abs(got - want).max() / scale
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos.min() >= 1 - 1e-5, cos.min()
+    # and against the device fp32 path on the same crops, including an empty box (zero crop on both)
+    boxes[7] = [50, 50, 50, 90]
+    a, b = extractor.features_for_boxes(frame, boxes).cpu().numpy(), fused_extractor.features_for_boxes(frame, boxes).cpu().numpy()
+    assert np.abs(a - b).max() <= 3e-3 * scale
+
+
+def test_fused_batch_over_frames_equals_per_frame(fused_extractor):
+    """y7t_reid_forward_batch: crops of several frames in one launch == the same crops frame by frame (same kernel, bit-equal)"""
+    from yolov7_tracker_amd import synth
+    frames = torch.from_numpy(synth.make_frames(3, 40, 640, seq_idx=4)).cuda()
+    rng = np.random.default_rng(6)
+    xy, wh = rng.uniform(0, 500, (90, 2)), rng.uniform(10, 130, (90, 2))
+    boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    idx = rng.integers(0, 3, 90).astype(np.int32)
+    got = fused_extractor.features_for_frames(frames, boxes, idx).cpu()
+    for f in range(3):
+        sel = np.nonzero(idx == f)[0]
+        assert torch.equal(got[sel], fused_extractor.features_for_boxes(frames[f], boxes[sel]).cpu())
+    with pytest.raises(Exception):
+        fused_extractor.features_for_frames(frames, boxes, idx[:5])
+
+
+def test_fused_kernel_only_for_its_configuration():
+    from yolov7_tracker_amd import _lib
+    from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+    assert not ReIDExtractor(None, width=0.5, max_crops=4).fused            # other widths: the op list
+    with pytest.raises(_lib.Y7TError):
+        ReIDExtractor(None, size=(128, 256), max_crops=4, fused=True)
+
+
+def test_deepsort_with_device_reid_tracks_the_scene(fused_extractor):
     """BASELINE config 4 in miniature: frames of the synthetic scene, its detections, appearance features from the device OSNet over the
     device crops.  With real (non-degenerate) embeddings the cascade keeps identities: almost every object holds one id over the clip."""
     from yolov7_tracker_amd import synth
@@ -53,7 +109,7 @@ def test_deepsort_with_device_reid_tracks_the_scene(extractor):
     gt = []
     dets = synth.make_detections(n_frames, n_obj, size, seq_idx=1005, miss=0.0, fp=0.0, ground_truth=gt)     # same objects as make_frames(seq 5)
     BaseTrack._count = 0
-    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.05, track_buffer=30, kalman_format="default", img_size=size, iou_thresh=0.5), reid_model=extractor)
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.05, track_buffer=30, kalman_format="default", img_size=size, iou_thresh=0.5), reid_model=fused_extractor)
     ids_per_frame = []
     for f in range(n_frames):
         cur = t.update(dets[f], torch.from_numpy(frames[f]))

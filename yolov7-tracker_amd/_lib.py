@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liby7t.so")
+LIB_PATH = os.environ.get("Y7T_LIB") or os.path.join(_HERE, "lib", "liby7t.so")   # Y7T_LIB: kernel experiments (scripts/ablate)
 
 c_void_p, c_int, c_double, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_float
 
@@ -53,6 +53,9 @@ SIGNATURES = {
     "y7t_reid_create": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y7t_reid_destroy": (c_int, [c_void_p]),
     "y7t_reid_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "y7t_reid_forward_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "y7t_reid_fused_blob_size": (ctypes.c_size_t, []),
+    "y7t_reid_set_fused": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "y7t_conv2d_nhwc_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -31,7 +31,7 @@
 // of storing the tile.  DUAL (KM = 1 only): upsample-on-read -- K-steps whose channels lie in [up_c0, up_c0 + up_C) fetch pixel (y, x)
 // from the half-resolution tensor `in2` at (y >> 1, x >> 1) (nn.Upsample(None, 2, 'nearest') folded into the consumer's loader).
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
-__global__ void __launch_bounds__(256, 2) k_conv_igemm(const Y7TConvArgs p) {
+__global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
     constexpr int CPR = BK / 8;                  // 16-byte chunks per row (8 or 4)
@@ -571,13 +571,14 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const bool wide = a.Cout_pad % 128 == 0;
     const int var = conv_variant();
-    switch (var > 7 ? 0 : var) {
+    switch (var > 8 ? 0 : var) {
     case 1: return wide ? launch_conv<128, 128, 64, 3>(a, s) : launch_conv<128, 64, 64, 3>(a, s);
     case 2: return wide ? launch_conv<128, 128, 32, 3>(a, s) : launch_conv<128, 64, 32, 3>(a, s);
     case 3: return wide ? launch_conv<128, 128, 32, 4>(a, s) : launch_conv<128, 64, 32, 4>(a, s);
     case 4: return wide ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
     case 5: return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
     case 6: return wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
+    case 8: return a.Cout_pad % 256 == 0 ? launch_conv<256, 256, 64, 2>(a, s) : wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
     case 7: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     default: {
         const bool big256 = (long long)(a.M / 256) * (a.Cout_pad / (wide ? 128 : 64)) >= 2048;   // enough 256-pixel tiles to fill the chip 4x

@@ -10,6 +10,7 @@
 // data-driven list of plain fp32 NHWC kernels (one thread per output value, weights through L1) -- BatchNorm folded on the host.
 // Nothing here is worth MFMA: the whole forward is a few hundred microseconds next to an 18 ms detector forward.
 #include "y7t_common.h"
+#include "y7t_reid_fused.h"
 #include <string.h>
 #include <vector>
 
@@ -23,15 +24,17 @@ struct y7t_reid {
     float* arena; size_t arena_floats;
     const float* w;
     int max_n, in_h, in_w, feat_dim;
+    const char* fused_blob = nullptr;   // set: frame crops of a 128 x 64 x0_25 network go through k_osnet_x025 (y7t_reid_fused.hip)
 };
 
 // crop + resize + normalise: out[n][y][x][c], c in the frame's channel order (BGR), cv2.INTER_LINEAR geometry on the float image
-__global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ frame, int H, int W, const float* __restrict__ boxes, int N, int oh, int ow,
-                                                   float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ frames, long long frame_stride, const int* __restrict__ frame_idx, int H, int W,
+                                                   const float* __restrict__ boxes, int N, int oh, int ow, float* __restrict__ out) {
     const long long tot = (long long)N * oh * ow;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(t % ow), y = (int)((t / ow) % oh), n = (int)(t / ((long long)ow * oh));
         const float* b = boxes + 4 * (size_t)n;
+        const uint8_t* frame = frames + (frame_idx ? (size_t)frame_idx[n] * frame_stride : 0);
         int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];       // list(map(int, tlbr))
         x1 = min(max(x1, 0), W); x2 = min(max(x2, 0), W); y1 = min(max(y1, 0), H); y2 = min(max(y2, 0), H);
         const int cw = x2 - x1, ch = y2 - y1;
@@ -209,15 +212,38 @@ extern "C" int y7t_reid_create(const y7t_reid_op* ops, int n_ops, const int64_t*
 
 extern "C" int y7t_reid_destroy(y7t_reid* r) { delete r; return 0; }
 
-extern "C" int y7t_reid_forward(y7t_reid* r, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats, y7t_stream stream) {
+extern "C" size_t y7t_reid_fused_blob_size(void) { return y7t_reid_fused_blob_bytes(); }
+
+extern "C" int y7t_reid_set_fused(y7t_reid* r, const void* blob, size_t blob_bytes) {
+    Y7T_ARG_CHECK(r);
+    if (!blob) { r->fused_blob = nullptr; return 0; }
+    if (r->in_h != 128 || r->in_w != 64 || r->feat_dim != 512) { y7t_set_error("reid: the fused kernel is OSNet x0_25 on 128 x 64 crops with 512 features"); return Y7T_E_ARG; }
+    if (blob_bytes != y7t_reid_fused_blob_bytes()) {
+        y7t_set_error("reid: fused parameter blob has %zu bytes, the kernel consumes %zu", blob_bytes, y7t_reid_fused_blob_bytes());
+        return Y7T_E_ARG;
+    }
+    r->fused_blob = (const char*)blob;
+    return 0;
+}
+
+static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, int H, int W, const float* boxes, const int* frame_idx, int N, const float* crops_f32,
+                             float* feats, y7t_stream stream) {
     Y7T_ARG_CHECK(r && feats && N >= 0 && N <= r->max_n);
-    Y7T_ARG_CHECK((frame_u8 && boxes && H > 0 && W > 0) || crops_f32);
+    Y7T_ARG_CHECK((frames_u8 && boxes && H > 0 && W > 0 && n_frames >= 1) || crops_f32);
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    const long long fstride = (long long)H * W * 3;
+    if (r->fused_blob && !crops_f32) {
+        Y7TReidFusedArgs a;
+        a.frames = (const uint8_t*)frames_u8; a.frame_stride = fstride; a.H = H; a.W = W; a.boxes = boxes; a.frame_idx = frame_idx; a.N = N;
+        a.blob = r->fused_blob; a.feats = feats;
+        return y7t_reid_fused_launch(a, s);
+    }
     float* b0 = r->arena + r->bufs[0];
     if (crops_f32) Y7T_HIP_CHECK(hipMemcpyAsync(b0, crops_f32, sizeof(float) * (size_t)N * r->in_h * r->in_w * 3, hipMemcpyDeviceToDevice, s));
     else {
-        hipLaunchKernelGGL(k_reid_crop, dim3(blocks_for((long long)N * r->in_h * r->in_w)), dim3(256), 0, s, (const uint8_t*)frame_u8, H, W, boxes, N, r->in_h, r->in_w, b0);
+        hipLaunchKernelGGL(k_reid_crop, dim3(blocks_for((long long)N * r->in_h * r->in_w)), dim3(256), 0, s, (const uint8_t*)frames_u8, fstride, frame_idx, H, W, boxes, N,
+                           r->in_h, r->in_w, b0);
         Y7T_LAUNCH_CHECK();
     }
     for (const y7t_reid_op& op : r->ops) {
@@ -263,4 +289,14 @@ extern "C" int y7t_reid_forward(y7t_reid* r, const void* frame_u8, int H, int W,
     const y7t_reid_op& last = r->ops.back();
     Y7T_HIP_CHECK(hipMemcpyAsync(feats, r->arena + r->bufs[last.out_buf], sizeof(float) * (size_t)N * r->feat_dim, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+extern "C" int y7t_reid_forward(y7t_reid* r, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats, y7t_stream stream) {
+    return reid_forward_impl(r, frame_u8, 1, H, W, boxes, nullptr, N, crops_f32, feats, stream);
+}
+
+extern "C" int y7t_reid_forward_batch(y7t_reid* r, const void* frames_u8, int n_frames, int H, int W, const float* boxes, const int* frame_idx, int N, float* feats,
+                                      y7t_stream stream) {
+    Y7T_ARG_CHECK(frames_u8 && frame_idx);
+    return reid_forward_impl(r, frames_u8, n_frames, H, W, boxes, frame_idx, N, nullptr, feats, stream);
 }

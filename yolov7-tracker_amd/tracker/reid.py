@@ -187,11 +187,103 @@ def lower(sd, spec, in_h=128, in_w=64):
     return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
 
 
+def _frags(Wm, cout_p, cin_p):
+    """(cout, cin) matrix -> A operands of v_mfma_f32_16x16x16_f16, [cout_p/16][cin_p/16][lane][4] fp16: lane holds row lane % 16,
+    k = 4 * (lane // 16) + e of its 16 x 16 tile (zero padded)"""
+    M = np.zeros((cout_p, cin_p))
+    M[:Wm.shape[0], :Wm.shape[1]] = Wm
+    lane = np.arange(64)
+    out = np.empty((cout_p // 16, cin_p // 16, 64, 4), np.float16)
+    for g in range(cout_p // 16):
+        for k in range(cin_p // 16):
+            for e in range(4):
+                out[g, k, :, e] = M[g * 16 + lane % 16, k * 16 + 4 * (lane // 16) + e]
+    return out.tobytes()
+
+
+def _f32(a, n=None):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    if n is not None:
+        a = np.concatenate([a, np.zeros(n - a.size)])
+    return a.astype(np.float32).tobytes()
+
+
+def pack_fused(sd, spec):
+    """parameters of osnet_x0_25 in the consumption order of csrc/y7t_reid_fused.hip::k_osnet_x025 (BatchNorm folded; 1x1 weights as MFMA fragments;
+    the 24-channel bottleneck of stage 3 zero-padded to 32)"""
+    assert spec["channels"] == [16, 64, 96, 128] and spec["layers"] == [2, 2, 2] and spec["feature_dim"] == 512
+    L = _Lowering(sd, 128, 64)          # only for its BatchNorm folding helper
+    out = []
+
+    def conv_bn(name, bnname):
+        Wt = sd[name + ".weight"].double().numpy()
+        scale, bias = L._bn(bnname)
+        return Wt * scale[:, None, None, None], bias
+
+    # conv1 7x7: K-step (kh, half) covers input pixels kw = 4 * half + q (q = lane // 16) x 4 channels (the 4th channel and kw = 7 are zero)
+    W1, b1 = conv_bn("conv1.conv", "conv1.bn")
+    lane = np.arange(64)
+    fr = np.zeros((14, 64, 4), np.float16)
+    for kh in range(7):
+        for h in range(2):
+            kw = 4 * h + lane // 16
+            for c in range(3):
+                ok = kw < 7
+                fr[kh * 2 + h, ok, c] = W1[(lane % 16)[ok], c, kh, kw[ok]]
+    out += [fr.tobytes(), _f32(b1)]
+
+    def light(name, mid, midp):
+        scale, bias = L._bn(name + ".bn")
+        Wd = sd[name + ".conv2.weight"].double().numpy().reshape(mid, 9) * scale[:, None]
+        dw = np.zeros((midp // 8, 9, 8))
+        for c in range(mid):
+            dw[c // 8, :, c % 8] = Wd[c]
+        return [_frags(sd[name + ".conv1.weight"].double().numpy().reshape(mid, mid), midp, midp), _f32(dw), _f32(bias, midp)]
+
+    def block(name, cin, cout):
+        mid = cout // 4
+        midp, R = (16 if mid <= 16 else 32), mid // 16
+        Wc1, bc1 = conv_bn(name + ".conv1.conv", name + ".conv1.bn")
+        o = [_frags(Wc1.reshape(mid, cin), midp, cin), _f32(bc1, midp)]
+        g = name + ".gate"
+        w1 = np.zeros((R, midp)); w1[:, :mid] = sd[g + ".fc1.weight"].double().numpy().reshape(R, mid)
+        w2 = np.zeros((R, midp)); w2[:, :mid] = sd[g + ".fc2.weight"].double().numpy().reshape(mid, R).T
+        o += [_f32(w1), _f32(sd[g + ".fc1.bias"].double().numpy(), 4), _f32(w2), _f32(sd[g + ".fc2.bias"].double().numpy(), midp)]
+        Wc3, bc3 = conv_bn(name + ".conv3.conv", name + ".conv3.bn")
+        down = cin != cout
+        if down:
+            Wd, bd = conv_bn(name + ".downsample.conv", name + ".downsample.bn")
+            bc3 = bc3 + bd
+        o += [_frags(Wc3.reshape(cout, mid), cout, midp), _f32(bc3)]
+        if down:
+            o.append(_frags(Wd.reshape(cout, cin), cout, cin))
+        o += light(name + ".conv2a", mid, midp)
+        for tag, n in (("conv2b", 2), ("conv2c", 3), ("conv2d", 4)):
+            for j in range(n):
+                o += light("%s.%s.%d" % (name, tag, j), mid, midp)
+        return o
+
+    def conv1x1(name, c):
+        Wc, bc = conv_bn(name + ".conv", name + ".bn")
+        return [_frags(Wc.reshape(c, c), c, c), _f32(bc)]
+    out += block("conv2.0", 16, 64) + block("conv2.1", 64, 64) + conv1x1("conv2.2.0", 64)
+    out += block("conv3.0", 64, 96) + block("conv3.1", 96, 96) + conv1x1("conv3.2.0", 96)
+    out += block("conv4.0", 96, 128) + block("conv4.1", 128, 128)
+    out += conv1x1("conv5", 128)
+    scale, bias = L._bn("fc.1")
+    Wf = sd["fc.0.weight"].double().numpy() * scale[:, None]               # (512, 128)
+    bf = sd["fc.0.bias"].double().numpy() * scale + bias
+    out += [np.ascontiguousarray(Wf.T.reshape(64, 2, 512).transpose(0, 2, 1)).astype(np.float16).tobytes(), _f32(bf)]
+    return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+
 class ReIDExtractor:
     """callable at DeepSORT's reid_model seam.  state_dict: torchreid OSNet names (e.g. torch.load('weights/osnet_x0_25.pth')), or None
     for seeded random weights.  size = (W, H) of the network input like Extractor.size (deepsort_reid.py:122)."""
 
-    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0):
+    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0, fused=None):
+        """fused: run frame crops through the one-workgroup-per-crop MFMA kernel (fp16 storage, fp32 accumulate).  Default: on for the
+        configuration it exists for (x0_25, 128 x 64 crops); off = the fp32 op list (also what forward_crops always uses)."""
         _lib.require_gpu()
         self._L = _lib.load()
         self.spec = osnet_spec(width)
@@ -214,6 +306,15 @@ class ReIDExtractor:
                                            _lib.ptr(self._arena), self._arena.numel() * 4, _lib.ptr(self._w), self.max_crops, self.in_h, self.in_w,
                                            self.feat_dim, ctypes.byref(h)))
         self._h = h
+        can_fuse = width == 0.25 and (self.in_w, self.in_h) == (64, 128)
+        if fused and not can_fuse:
+            raise _lib.Y7TError("the fused ReID kernel is OSNet x0_25 on 128 x 64 crops (got width %s, size %s)" % (width, size))
+        self.fused = can_fuse if fused is None else bool(fused)
+        if self.fused:
+            blob = pack_fused(self.sd, self.spec)
+            assert blob.size == self._L.y7t_reid_fused_blob_size(), (blob.size, self._L.y7t_reid_fused_blob_size())
+            self._blob = torch.from_numpy(blob.copy()).cuda()
+            _lib.check(self._L.y7t_reid_set_fused(self._h, _lib.ptr(self._blob), self._blob.numel()))
 
     @classmethod
     def from_checkpoint(cls, path, **kw):
@@ -242,6 +343,21 @@ class ReIDExtractor:
         _lib.check(self._L.y7t_reid_forward(self._h, _lib.ptr(frame), frame.shape[0], frame.shape[1], _lib.ptr(boxes), n, None, _lib.ptr(out),
                                             _lib.stream_ptr()))
         self._keep = (frame, boxes)
+        return out
+
+    def features_for_frames(self, frames, tlbrs, frame_idx):
+        """crops from a batch of frames in one pass: frames (B, H, W, 3) uint8 device tensor, tlbrs (N, 4) float32 and frame_idx (N) int32
+        device tensors (or arrays) -> (N, feat_dim) float32 device tensor"""
+        frames = frames.to(device="cuda", dtype=torch.uint8).contiguous()
+        boxes = torch.as_tensor(tlbrs, dtype=torch.float32).reshape(-1, 4).cuda().contiguous()
+        idx = torch.as_tensor(frame_idx, dtype=torch.int32).reshape(-1).cuda().contiguous()
+        n = boxes.shape[0]
+        if n > self.max_crops or idx.shape[0] != n:
+            raise _lib.Y7TError("%d crops (max_crops=%d), %d frame indices" % (n, self.max_crops, idx.shape[0]))
+        out = torch.empty((n, self.feat_dim), dtype=torch.float32, device="cuda")
+        _lib.check(self._L.y7t_reid_forward_batch(self._h, _lib.ptr(frames), frames.shape[0], frames.shape[1], frames.shape[2], _lib.ptr(boxes), _lib.ptr(idx), n,
+                                                  _lib.ptr(out), _lib.stream_ptr()))
+        self._keep = (frames, boxes, idx)
         return out
 
     def forward_crops(self, crops_nhwc):
