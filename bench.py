@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per step (consecutive frames of the sequence)")
     ap.add_argument("--n_obj", type=int, default=None, help="objects in the synthetic scene (default: 80 for cfg2, 500 for cfg3)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
                     help="cfg2 (default, BASELINE's metric): w6@1280 + ByteTrack, ~80 objects.  cfg3: BASELINE configs[2], w6@1280 + BoT-SORT "
                          "(xywh Kalman, per-frame camera-motion warp), 500 objects -- stresses the IoU matrices / linear assignment")
     ap.add_argument("--img", type=int, default=1280)
@@ -336,7 +336,7 @@ def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
 
 def main():
     args = parse()
-    cfg3 = args.workload == "cfg3"
+    cfg3, cfg4 = args.workload == "cfg3", args.workload == "cfg4"
     if args.n_obj is None:
         args.n_obj = 500 if cfg3 else 80
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -382,17 +382,43 @@ def main():
         o3.kalman_format, o3.max_tracks, o3.max_dets = "botsort", 2048, 1024
         trk = BoTSORT(o3, frame_rate=30)
         warps_dev = torch.from_numpy(synth.make_warps(n_frames, seq_idx=seq).reshape(n_frames, 6)).cuda()     # what GMC.apply would estimate (botsort.py:13-248)
+    elif cfg4:
+        # BASELINE configs[3]: DeepSORT, appearance features from OSNet x0_25 over 128 x 64 crops of every detection, taken from the frames in HBM
+        from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+        from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+        reid = ReIDExtractor(None, max_crops=B * 2 * args.n_obj + 64, seed=0)
+        trk = DeepSORT(make_opts(), frame_rate=30, reid_model=reid)
+        step_boxes, step_idx, step_off = [], [], []       # per step: the boxes of its B frames' detections, their frame index, row ranges
+        for s0 in range(0, n_frames, B):
+            ns = [len(dets_seq[t]) for t in range(s0, s0 + B)]
+            step_boxes.append(torch.cat([dets_dev[t][:, :4] for t in range(s0, s0 + B)]).contiguous())
+            step_idx.append(torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), ns)).cuda())
+            step_off.append(np.concatenate([[0], np.cumsum(ns)]).astype(np.int64))
     else:
         trk = ByteTrack(make_opts(), frame_rate=30)
     results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
-    def launch_frame(t):
-        """one tracker frame step for frame t of the sequence (BoT-SORT: with that frame's camera-motion warp)"""
-        if cfg3:
-            trk._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
-        else:
-            trk._launch(dets_dev[t], out=results[t])
-    tracker_name = "botsort" if cfg3 else "bytetrack"
-    metric_name = "end-to-end fps (detect+track) YOLOv7-w6@1280 " + ("BoT-SORT, 500-object stress" if cfg3 else "ByteTrack")
+    ev_reid = {}
+    def launch_step(s):
+        """the tracker frame steps of batch s, in frame order (BoT-SORT: with each frame's camera-motion warp; DeepSORT: after ONE ReID pass
+        over all detections of the batch's frames)"""
+        if cfg4:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            feats = reid.features_for_frames(frames, step_boxes[s], step_idx[s])
+            e1.record()
+            ev_reid[s] = (e0, e1)
+            off = step_off[s]
+        for i in range(B):
+            t = s * B + i
+            if cfg3:
+                trk._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
+            elif cfg4:
+                trk._launch(dets_dev[t], feats[int(off[i]):int(off[i + 1])], out=results[t])
+            else:
+                trk._launch(dets_dev[t], out=results[t])
+    tracker_name = "botsort" if cfg3 else "deepsort" if cfg4 else "bytetrack"
+    metric_name = "end-to-end fps (detect+track) YOLOv7-w6@1280 " + ("BoT-SORT, 500-object stress" if cfg3 else
+                                                                     "DeepSORT + OSNet x0_25 ReID (128x64 crops)" if cfg4 else "ByteTrack")
     if args.halves == 2 and world == 1:
         dt_s, fwd_ms_step, d0 = halves_mode(args, lambda b: model.Detector(arch.ARCHS[args.arch](nc), None, img_size=(H, W), max_batch=b, seed=0),
                                            frames, dets_dev, trk, results, plant_objectness_bias)
@@ -482,8 +508,7 @@ def main():
         with torch.cuda.stream(sB):
             sB.wait_event(ev_nms[ps])      # a frame's detections exist before its tracker step runs
             ev_trk0[ps].record(sB)
-            for i in range(B):
-                launch_frame(ps * B + i)
+            launch_step(ps)
             ev_trk1[ps].record(sB)
 
     def step(s):
@@ -496,8 +521,7 @@ def main():
             with torch.cuda.stream(sB):
                 sB.wait_event(ev_nms[s])
                 ev_trk0[s].record(sB)
-                for i in range(B):
-                    launch_frame(s * B + i)
+                launch_step(s)
                 ev_trk1[s].record(sB)
             return
         src = frames
@@ -595,6 +619,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt_s / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("configs[2]: YOLOv7-w6 1280x1280 + BoT-SORT (xywh Kalman, multi_gmc with a synthetic 2x3 warp per frame)" if cfg3 else
+                                    "configs[3]: YOLOv7-w6 1280x1280 + DeepSORT, OSNet x0_25 embeddings of 128x64 crops of every detection (one fused "
+                                    "MFMA kernel, one workgroup per crop), cascade + gated cosine/Mahalanobis cost on the device" if cfg4 else
                                     "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack") + ", 1 synthetic VisDrone-shape sequence per GPU, %d objects per frame "
                                    "(10 %% missed, 5 %% false positives, reflected at the border)" % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc,
                        "tracker": tracker_name,
@@ -636,9 +662,13 @@ def main():
             torch.cuda.synchronize()
             heads0 = [r[:1].cpu() for r in out0.raw()]
             dets0 = d0[0, :int(n0[0])].cpu()
-            if not args.no_latency_mode and not cfg3:
+            if cfg4:
+                rs = [ev_reid[s][0].elapsed_time(ev_reid[s][1]) for s in range(Wm, Wm + K)]
+                line["phases_ms_per_step"]["reid"] = round(float(np.mean(rs)), 3)
+                line["config"]["reid_crops_per_step_mean"] = round(float(np.mean([len(step_boxes[s]) for s in range(Wm, Wm + K)])), 1)
+            if not args.no_latency_mode and not cfg3 and not cfg4:
                 line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq)
-            if not args.no_cpu_baseline:                         # the CPU baseline is timed on rank 0 at N=1 only
+            if not args.no_cpu_baseline and not cfg4:            # the CPU baseline is timed on rank 0 at N=1 only (configs[1] / [2])
                 line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0)
                 line["parity"]["note"] = ("the benchmarked weights are iid random (chaotic: rounding noise x ~300 over the depth); the same kernels "
                                           "on well-conditioned seeded weights:")

@@ -74,13 +74,16 @@ int hs_deepsort_step(void* blob, void* fblob, const float* dets, int n, const fl
     for (int k = 0; k < h->n_tracked; ++k) y7t_embed_slot(ex, f, s.tracked[k], n);
     for (int k = 0; k < h->n_lost; ++k) y7t_embed_slot(ex, f, s.lost[k], n);
     y7t_tracker_step_deepsort(ex, blob, fblob, dets, n, feats, out_rows, out_cap, &cnt);
+    y7t_feat_store_pending(ex, f, feats);
     return cnt;
 }
 int hs_feat_status(void* fblob) { return ((Y7TFeatHdr*)fblob)->status; }
 int hs_pyset_difference(int n, const int* member, int n_other, int* out) {
-    int* tab = (int*)malloc(sizeof(int) * 2 * Y7T_PYSET_CAP);
-    int st = 0;
-    const int c = y7t_pyset_difference(n, member, n_other, out, tab, &st);
+    int* tab = (int*)malloc(sizeof(int) * (2 * Y7T_PYSET_CAP + (size_t)n + 1));
+    int* unm = tab + 2 * Y7T_PYSET_CAP;          // the keys of range(n) outside `other`, ascending (the step builds this list by compaction)
+    int st = 0, n_unm = 0;
+    for (int v = 0; v < n; ++v) if (!member[v]) unm[n_unm++] = v;
+    const int c = y7t_pyset_difference_list(n, unm, n_unm, n_other, out, tab, &st);
     free(tab);
     return st ? -1 : c;
 }

@@ -18,15 +18,17 @@ enum { Y7T_DEEPSORT = 3 };
 #define Y7T_PYSET_CAP 8192      // table entries of the emulated CPython set (enough for 1228 unmatched tracks)
 
 // feature state of one DeepSORT tracker: caller-owned device memory next to the track-pool blob
-struct Y7TFeatHdr { int magic, dim, budget, cap_t, cap_d, status, pad0, pad1; };
-struct Y7TFeatLayout { size_t ring, nfeat, fpos, app, detn, anrm, casc_tr, casc_det, u0, tomatch, tmpd, pyset, total; };
+struct Y7TFeatHdr { int magic, dim, budget, cap_t, cap_d, status, n_pend, pad1; };
+struct Y7TFeatLayout { size_t ring, nfeat, fpos, app, detn, pend, casc_tr, casc_det, u0, tomatch, tmpd, pyset, total; };
 struct Y7TFeat {
     Y7TFeatHdr* h;
-    float* ring;        // [cap_t][budget][dim]   STrack.features (raw first feature, normalised later ones), a ring of the last `budget`
+    float* ring;        // [cap_t][budget][dim]   STrack.features, a ring of the last `budget` -- each stored as the row of cal_cosine_distance's mat1 it
+                        //                        becomes: (raw first feature | f / |f| later ones) divided by its np.linalg.norm (y7t_feat_store)
     int *nfeat, *fpos;  // [cap_t] stored features, next write position
     float* app;         // [cap_t][cap_d]         nearest_embedding_distance(slot, detection row) of this frame
     float* detn;        // [cap_d][dim]           this frame's detection features, normalised (cal_cosine_distance's mat2)
-    float* anrm;        // [cap_t][dim]           scratch: one stored feature of the slot, normalised (mat1 row)
+    int* pend;          // [cap_d][3]             appearance vectors this frame's step decided to store: (slot, detection row, 1 = update / 0 = new track);
+                        //                        written out after the step by y7t_feat_store_pending (grid-wide: a wave per vector)
     int *casc_tr, *casc_det, *u0;   // [cap_t]    cascade matches in match order (pool index, position in the detection list); unmatched pool indices
     int *tomatch, *tmpd;            // [cap_d]    detections_to_match of the current cascade level (+ scratch)
     int* pyset;         // [2][Y7T_PYSET_CAP]
@@ -38,7 +40,7 @@ Y7T_HD Y7TFeatLayout y7t_feat_layout(int cap_t, int cap_d, int dim, int budget) 
     const size_t T = (size_t)cap_t, D = (size_t)cap_d;
 #define Y7T_TAKE(f, bytes) L.f = o; o = y7t_al(o + (bytes));
     Y7T_TAKE(ring, T * budget * dim * 4) Y7T_TAKE(nfeat, T * 4) Y7T_TAKE(fpos, T * 4) Y7T_TAKE(app, T * D * 4)
-    Y7T_TAKE(detn, D * dim * 4) Y7T_TAKE(anrm, T * dim * 4)
+    Y7T_TAKE(detn, D * dim * 4) Y7T_TAKE(pend, D * 3 * 4)
     Y7T_TAKE(casc_tr, T * 4) Y7T_TAKE(casc_det, T * 4) Y7T_TAKE(u0, T * 4) Y7T_TAKE(tomatch, D * 4) Y7T_TAKE(tmpd, D * 4)
     Y7T_TAKE(pyset, (size_t)2 * Y7T_PYSET_CAP * 4)
 #undef Y7T_TAKE
@@ -53,7 +55,7 @@ Y7T_FN Y7TFeat y7t_feat_bind(void* blob) {
     Y7TFeat f;
     f.h = h;
     f.ring = (float*)(b + L.ring); f.nfeat = (int*)(b + L.nfeat); f.fpos = (int*)(b + L.fpos); f.app = (float*)(b + L.app);
-    f.detn = (float*)(b + L.detn); f.anrm = (float*)(b + L.anrm);
+    f.detn = (float*)(b + L.detn); f.pend = (int*)(b + L.pend);
     f.casc_tr = (int*)(b + L.casc_tr); f.casc_det = (int*)(b + L.casc_det); f.u0 = (int*)(b + L.u0);
     f.tomatch = (int*)(b + L.tomatch); f.tmpd = (int*)(b + L.tmpd); f.pyset = (int*)(b + L.pyset);
     return f;
@@ -61,7 +63,7 @@ Y7T_FN Y7TFeat y7t_feat_bind(void* blob) {
 
 Y7T_FN void y7t_feat_init(const Y7TExec& ex, void* blob, int cap_t, int cap_d, int dim, int budget) {
     Y7TFeatHdr* h = (Y7TFeatHdr*)blob;
-    if (ex.tid == 0) { h->magic = 0x59374631; h->dim = dim; h->budget = budget; h->cap_t = cap_t; h->cap_d = cap_d; h->status = 0; }
+    if (ex.tid == 0) { h->magic = 0x59374631; h->dim = dim; h->budget = budget; h->cap_t = cap_t; h->cap_d = cap_d; h->status = 0; h->n_pend = 0; }
     y7t_sync(ex);
     const Y7TFeat f = y7t_feat_bind(blob);
     for (int k = ex.tid; k < cap_t; k += ex.nt) { f.nfeat[k] = 0; f.fpos[k] = 0; }
@@ -92,18 +94,19 @@ Y7T_FN void y7t_pyset_insert_clean(int* t, int mask, int v) {
     }
 }
 
-Y7T_FN int y7t_pyset_difference(int n, const int* member, int n_other, int* out, int* tab, int* status) {
+// `unm`: the keys of range(n) that are NOT in `other`, ascending (what walking `so` in table order and skipping members visits)
+Y7T_FN int y7t_pyset_difference_list(int n, const int* unm, int n_unm, int n_other, int* out, int* tab, int* status, int cap = Y7T_PYSET_CAP) {
     int cnt = 0;
     if ((n >> 2) > n_other) {                     // set_copy_and_difference
-        for (int v = 0; v < n; ++v) if (!member[v]) out[cnt++] = v;
+        for (int k = 0; k < n_unm; ++k) out[cnt++] = unm[k];
         return cnt;
     }
     int* cur = tab;
-    int* nxt = tab + Y7T_PYSET_CAP;
+    int* nxt = tab + cap;                         // two tables of `cap` entries (cap >= the power of two above 4 * n_unm)
     int mask = 7, fill = 0;
     for (int i = 0; i <= mask; ++i) cur[i] = -1;
-    for (int v = 0; v < n; ++v) {
-        if (member[v]) continue;
+    for (int q = 0; q < n_unm; ++q) {
+        const int v = unm[q];
         // set_add_entry
         unsigned perturb = (unsigned)v;
         int i = v & mask, e = -1;
@@ -120,7 +123,7 @@ Y7T_FN int y7t_pyset_difference(int n, const int* member, int n_other, int* out,
         if (fill * 5 >= mask * 3) {               // set_table_resize(so, used * 4)   (used <= 50000)
             int newsize = 8;
             while (newsize <= fill * 4) newsize <<= 1;
-            if (newsize > Y7T_PYSET_CAP) { if (status) *status |= 8; break; }
+            if (newsize > cap) { if (status) *status |= 8; break; }
             for (int k = 0; k < newsize; ++k) nxt[k] = -1;
             for (int k = 0; k <= mask; ++k) if (cur[k] >= 0) y7t_pyset_insert_clean(nxt, newsize - 1, cur[k]);
             int* sw = cur; cur = nxt; nxt = sw;
@@ -188,9 +191,116 @@ Y7T_FN float y7t_blas_sdot_self(const float* x, int n) {
     return d;
 }
 
-// mat2 of cal_cosine_distance: every detection feature of the frame divided by its norm (one lane per detection)
+#if Y7T_DEVICE
+// The same sums with the 64 lanes of a wave sharing one vector (every lane calls; every lane gets the result) -- bit-identical to the serial forms:
+// each partial sum is built from the same operands in the same order, only by different lanes.
+Y7T_FN bool y7t_dim_wave_ok(int dim) { return dim == 128 || dim == 256 || dim == 512 || dim == 1024; }
+
+// y7t_np_pairwise_sumsq of the vector x[i] / div (div = 1: x itself): lane (block, j) owns running sum j of its 128-element block
+Y7T_FN float y7t_wave_pairwise_sumsq(const float* x, int dim, float div, int lane) {
+    const int nblk = dim >> 7, blk = lane >> 3, j = lane & 7;
+    float r = 0.f;
+    if (blk < nblk) {
+        const float* xb = x + blk * 128;
+        const float t0 = xb[j] / div;
+        r = t0 * t0;
+        for (int i = 8; i < 128; i += 8) { const float t = xb[i + j] / div; r = r + t * t; }
+    }
+    r = r + __shfl_xor(r, 1, 64); r = r + __shfl_xor(r, 2, 64); r = r + __shfl_xor(r, 4, 64);      // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+    for (int m = 1; m < nblk; m <<= 1) r = r + __shfl_xor(r, 8 * m, 64);                          // the recursive halving over blocks
+    return __shfl(r, 0, 64);
+}
+
+// y7t_blas_sdot_self: lane 16 v + l owns accumulator (v, l)
+Y7T_FN float y7t_wave_sdot_self(const float* x, int n, int lane) {
+    const int n1 = n & -32, n64 = n1 & ~63;
+    const int v = lane >> 4, l = lane & 15;
+    float a5 = 0.f;
+    for (int i = 0; i < n64; i += 64) { const float t = x[i + lane]; a5 = y7t_fmaf(t, t, a5); }
+    float a = a5 + __shfl(a5, (lane + 8) & 63, 64);                                             // meaningful on l < 8
+    if (n1 > n64 && l < 8) { const float t = x[n64 + 8 * v + l]; a = y7t_fmaf(t, t, a); }
+    const float a0 = __shfl(a, l & 7, 64), a1 = __shfl(a, 16 + (l & 7), 64), a2 = __shfl(a, 32 + (l & 7), 64), a3 = __shfl(a, 48 + (l & 7), 64);
+    const float sv = ((a0 + a1) + a2) + a3;                                                     // sv[l & 7] on every lane
+    const float hv = sv + __shfl(sv, (lane & 48) + (((l & 7) + 4) & 7), 64);                    // l & 7 < 4: sv[l] + sv[l + 4]
+    const float h0 = __shfl(hv, 0, 64), h1 = __shfl(hv, 1, 64), h2 = __shfl(hv, 2, 64), h3 = __shfl(hv, 3, 64);
+    float d = (h0 + h1) + (h2 + h3);
+    for (int k = n1; k < n; ++k) d = d + x[k] * x[k];
+    return d;
+}
+#endif
+
+// What STrack keeps of an appearance vector, in the form the distance uses it.  STrack stores the raw vector at creation (basetrack.py:97-103) and
+// f / np.linalg.norm(f) on every update (basetrack.py:324-332, 1-D norm = sqrt(sdot)); nearest_embedding_distance then divides every stored row by
+// its np.linalg.norm(axis=1) (pairwise sum) again.  Both divisions happen here, once, when the vector is stored.  Serial (one thread).
+Y7T_FN void y7t_feat_store(float* dst, const float* src, int dim, int update) {
+    const float nb = update ? sqrtf(y7t_blas_sdot_self(src, dim)) : 1.0f;
+    for (int d = 0; d < dim; ++d) dst[d] = src[d] / nb;
+    const float na = sqrtf(y7t_np_pairwise_sumsq(dst, dim));
+    for (int d = 0; d < dim; ++d) dst[d] = dst[d] / na;
+}
+
+// Queue the vectors a step decides to store; y7t_feat_store_pending writes them after the step (nothing in the step reads the ring: this frame's
+// distances were taken before it).  A detection row is stored at most once per frame and a slot receives at most one vector.
+template <class PairFn>
+Y7T_FN void y7t_feat_store_many(const Y7TExec& ex, const Y7TFeat& f, int count, int update, PairFn pair /* (i, slot&, detection row&) -> bool */) {
+    for (int i = ex.tid; i < count; i += ex.nt) {
+        int sl, row;
+        if (!pair(i, sl, row)) continue;
+        const int k = Y7T_FETCH_ADD(&f.h->n_pend, 1);
+        if (k < f.h->cap_d) { f.pend[3 * k] = sl; f.pend[3 * k + 1] = row; f.pend[3 * k + 2] = update; }
+        else f.h->status |= 16;
+    }
+    y7t_sync(ex);
+}
+
+// write the queued vectors (ex may span a whole grid: on the device a wave per vector); resets the queue
+Y7T_FN void y7t_feat_store_pending(const Y7TExec& ex, const Y7TFeat& f, const float* det_feats) {
+    const int dim = f.h->dim, budget = f.h->budget;
+    const int count = f.h->n_pend < f.h->cap_d ? f.h->n_pend : f.h->cap_d;
+#if Y7T_DEVICE
+    if (y7t_dim_wave_ok(dim) && (ex.nt & 63) == 0) {
+        const int lane = ex.tid & 63;
+        for (int i = ex.tid >> 6; i < count; i += ex.nt >> 6) {          // wave-uniform
+            const int sl = f.pend[3 * i], update = f.pend[3 * i + 2];
+            const float* b = det_feats + (size_t)f.pend[3 * i + 1] * dim;
+            const int pos = update ? f.fpos[sl] : 0;
+            float* dst = f.ring + ((size_t)sl * budget + pos) * dim;
+            const float nb = update ? sqrtf(y7t_wave_sdot_self(b, dim, lane)) : 1.0f;
+            const float na = sqrtf(y7t_wave_pairwise_sumsq(b, dim, nb, lane));
+            for (int d = lane; d < dim; d += 64) dst[d] = (b[d] / nb) / na;
+            if (lane == 0) {
+                if (update) { f.fpos[sl] = (pos + 1 == budget) ? 0 : pos + 1; if (f.nfeat[sl] < budget) f.nfeat[sl] += 1; }
+                else { f.nfeat[sl] = 1; f.fpos[sl] = 1 % budget; }
+            }
+        }
+        return;
+    }
+#endif
+    for (int i = ex.tid; i < count; i += ex.nt) {
+        const int sl = f.pend[3 * i], update = f.pend[3 * i + 2];
+        const int pos = update ? f.fpos[sl] : 0;
+        y7t_feat_store(f.ring + ((size_t)sl * budget + pos) * dim, det_feats + (size_t)f.pend[3 * i + 1] * dim, dim, update);
+        if (update) { f.fpos[sl] = (pos + 1 == budget) ? 0 : pos + 1; if (f.nfeat[sl] < budget) f.nfeat[sl] += 1; }
+        else { f.nfeat[sl] = 1; f.fpos[sl] = 1 % budget; }
+    }
+}
+
+// mat2 of cal_cosine_distance: every detection feature of the frame divided by its norm (device: a wave per detection; else a lane each)
 Y7T_FN void y7t_feat_normalize_dets(const Y7TExec& ex, const Y7TFeat& f, const float* det_feats, int n) {
     const int dim = f.h->dim;
+#if Y7T_DEVICE
+    if (y7t_dim_wave_ok(dim) && (ex.nt & 63) == 0) {
+        const int lane = ex.tid & 63;
+        for (int j = ex.tid >> 6; j < n; j += ex.nt >> 6) {
+            const float* b = det_feats + (size_t)j * dim;
+            const float nb = sqrtf(y7t_wave_pairwise_sumsq(b, dim, 1.0f, lane));
+            float* o = f.detn + (size_t)j * dim;
+            for (int d = lane; d < dim; d += 64) o[d] = b[d] / nb;
+        }
+        y7t_sync(ex);
+        return;
+    }
+#endif
     for (int j = ex.tid; j < n; j += ex.nt) {
         const float* b = det_feats + (size_t)j * dim;
         const float nb = sqrtf(y7t_np_pairwise_sumsq(b, dim));
@@ -201,28 +311,24 @@ Y7T_FN void y7t_feat_normalize_dets(const Y7TExec& ex, const Y7TFeat& f, const f
 }
 
 // nearest_embedding_distance (matching.py:105-127) for ONE pool slot against every detection feature of the frame:
-//   app[slot][j] = min over the slot's stored features a of  1 - (a / |a|) . (b_j / |b_j|)        (float32, see above)
-// One workgroup per slot on the device (k_embed_dist), a lane per detection; the normalised stored feature is a wave-uniform read.
+//   app[slot][j] = min over the slot's stored rows a' of  1 - a' . (b_j / |b_j|)        (float32: one sequential FMA chain over k per product)
+// Plain form (a lane per detection); the device runs the tiled k_embed_dist (y7t_tracker.hip) with the same chains instead.
 Y7T_FN void y7t_embed_slot(const Y7TExec& ex, const Y7TFeat& f, int slot, int n) {
     const int nf = f.nfeat[slot], dim = f.h->dim;
     if (nf <= 0) return;
     const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
-    float* an = f.anrm + (size_t)slot * dim;
     float* row = f.app + (size_t)slot * f.h->cap_d;
-    for (int j = ex.tid; j < n; j += ex.nt) row[j] = 3.0e38f;
-    for (int hI = 0; hI < nf; ++hI) {
-        const float* a = hist + (size_t)hI * dim;
-        y7t_sync(ex);                                  // the lanes are done with the previous `an`
-        const float na = sqrtf(y7t_np_pairwise_sumsq(a, dim));      // (every lane computes the same value: cheaper than a broadcast round trip)
-        for (int d = ex.tid; d < dim; d += ex.nt) an[d] = a[d] / na;
-        y7t_sync(ex);
-        for (int j = ex.tid; j < n; j += ex.nt) {
-            const float* b = f.detn + (size_t)j * dim;
+    for (int j = ex.tid; j < n; j += ex.nt) {
+        const float* b = f.detn + (size_t)j * dim;
+        float best = 3.0e38f;
+        for (int hI = 0; hI < nf; ++hI) {
+            const float* a = hist + (size_t)hI * dim;
             float acc = 0.f;
-            for (int k = 0; k < dim; ++k) acc = y7t_fmaf(an[k], b[k], acc);
+            for (int k = 0; k < dim; ++k) acc = y7t_fmaf(a[k], b[k], acc);
             const float c = 1.0f - acc;
-            row[j] = c < row[j] ? c : row[j];
+            best = c < best ? c : best;
         }
+        row[j] = best;
     }
     y7t_sync(ex);
 }
@@ -231,18 +337,12 @@ Y7T_FN void y7t_embed_slot(const Y7TExec& ex, const Y7TFeat& f, int slot, int n)
 // UPDATED (tmpa[i] == 1): features.append(f / np.linalg.norm(f)); features = features[-budget:]
 Y7T_FN void y7t_ds_append_features(const Y7TExec& ex, const Y7TTrk& s, const Y7TFeat& f, const int* tracks, int na, const int* dets,
                                    const float* det_feats) {
-    const int dim = f.h->dim, budget = f.h->budget;
-    for (int i = ex.tid; i < na; i += ex.nt) {
-        if (s.xrow[i] < 0 || s.tmpa[i] != 1) continue;
-        const int sl = tracks[i], dj = dets[s.xrow[i]];
-        const float* b = det_feats + (size_t)dj * dim;
-        const float nb = sqrtf(y7t_blas_sdot_self(b, dim));
-        float* dst = f.ring + ((size_t)sl * budget + f.fpos[sl]) * dim;
-        for (int d = 0; d < dim; ++d) dst[d] = b[d] / nb;
-        f.fpos[sl] = (f.fpos[sl] + 1 == budget) ? 0 : f.fpos[sl] + 1;
-        if (f.nfeat[sl] < budget) f.nfeat[sl] += 1;
-    }
-    y7t_sync(ex);
+    y7t_feat_store_many(ex, f, na, 1, [&](int i, int& sl, int& row) {
+        if (s.xrow[i] < 0 || s.tmpa[i] != 1) return false;
+        sl = tracks[i];
+        row = dets[s.xrow[i]];
+        return true;
+    });
 }
 
 // linear_assignment(cost, thresh) on a cost matrix already in s.cost (na x nb, row stride nb) -> s.xrow / s.ycol
@@ -273,6 +373,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_sync(ex);
     if (ex.tid == 0) {
         h->frame_id += 1;
+        f.h->n_pend = 0;
         h->n_act_last = h->n_refind_last = h->n_lostn_last = h->n_removed_last = 0;
         if (n > cfg.cap_d) h->status |= Y7T_ERR_CAP_D;
     }
@@ -280,6 +381,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     if (n > cfg.cap_d) n = cfg.cap_d;
     const int frame_id = h->frame_id;
     const int nt0 = h->n_tracked, nl0 = h->n_lost;
+    Y7T_PROF(h, 0);
     const int n_unc = y7t_compact(ex, nt0, [&](int i) { return !s.act[s.tracked[i]]; }, s.tmpa, 0);
     for (int k = ex.tid; k < n_unc; k += ex.nt) s.unconf[k] = s.tracked[s.tmpa[k]];
     const int n_conf = y7t_compact(ex, nt0, [&](int i) { return s.act[s.tracked[i]] != 0; }, s.tmpb, 0);
@@ -297,27 +399,59 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_sync(ex);
     const float det_t = (float)cfg.det_thresh;
     const int n_hi = y7t_compact(ex, n, [&](int j) { return dets[6 * (size_t)j + 4] > det_t; }, s.dhi, 0);
+    Y7T_PROF(h, 1);
     // ---- matching_cascade(gated_metric, 0.9, max_time_lost, strack_pool, detections) ----
     int n_to = n_hi, nm = 0;
     for (int k = ex.tid; k < n_hi; k += ex.nt) f.tomatch[k] = k;      // positions in the detection list (s.dhi)
     y7t_sync(ex);
+#if Y7T_DEVICE
+#define Y7T_CPROF(i) do { if (ex.tid == 0) { const long long t_ = clock64(); h->prof[i] += t_ - cprof_t; cprof_t = t_; } } while (0)
+    long long cprof_t = clock64();
+    if (ex.tid == 0) h->prof[16] = h->prof[17] = h->prof[18] = h->prof[19] = 0;
+#else
+#define Y7T_CPROF(i) do { } while (0)
+#endif
+    // which ages occur at all: one pass instead of a compaction per level (time_since_update of a pool track is 1 .. max_time_lost)
+    int* lvl = s.ycol;                         // [max_time_lost] flags (ycol is free until the first assignment)
+    for (int k = ex.tid; k < cfg.max_time_lost; k += ex.nt) lvl[k] = 0;
+    y7t_sync(ex);
+    for (int i = ex.tid; i < n_pool; i += ex.nt) { const int a = s.tsu[s.pool[i]] - 1; if (a >= 0 && a < cfg.max_time_lost) lvl[a] = 1; }
+    y7t_sync(ex);
+    unsigned long long lvl_mask = 0;           // max_time_lost <= 64 levels in the mask, anything above is scanned the slow way
+    for (int k = 0; k < cfg.max_time_lost && k < 64; ++k) if (lvl[k]) lvl_mask |= 1ull << k;
+    y7t_sync(ex);
     for (int level = 0; level < cfg.max_time_lost && n_to > 0; ++level) {
+        if (level < 64 && !((lvl_mask >> level) & 1ull)) continue;
         const int n_tl = y7t_compact(ex, n_pool, [&](int i) { return s.tsu[s.pool[i]] == 1 + level; }, s.rem, 0);   // pool indices of this age
+        Y7T_CPROF(16);
         if (n_tl == 0) continue;
-        // gated_metric: appearance cost, > 0.15 -> 1e5; squared Mahalanobis distance to the predicted state > chi2inv95[4] -> 1e5
-        const int tot = n_tl * n_to;
-        for (int k = ex.tid; k < tot; k += ex.nt) {
-            const int r = k / n_to, c = k - r * n_to;
-            const int sl = s.pool[s.rem[r]], dj = s.dhi[f.tomatch[c]];
+        // gated_metric: appearance cost, > 0.15 -> 1e5; squared Mahalanobis distance to the predicted state > chi2inv95[4] -> 1e5.  The gate is only
+        // evaluated where the appearance test leaves a finite cost (the result is 1e5 either way otherwise).
+        for (int r = ex.tid; r < n_tl; r += ex.nt) s.tmpb[r] = s.pool[s.rem[r]];             // pool slot of every row
+        for (int c = ex.tid; c < n_to; c += ex.nt) s.left[c] = s.dhi[f.tomatch[c]];           // detection row of every column
+        y7t_sync(ex);
+        auto gated_at = [&](int sl, int dj) {
             double cost = (double)f.app[(size_t)sl * cfg.cap_d + dj];
-            if (cost > 0.15) cost = 1e5;
+            if (cost > 0.15) return 1e5;
             double z[4];
             y7t_meas(kf, s.dbox + 4 * (size_t)dj, z);
             if (y7t_kf_gating(kf, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl, z, 0) > 9.4877) cost = 1e5;
-            s.cost[(size_t)r * n_to + c] = cost;
+            return cost;
+        };
+        // linear_assignment(cost, 0.9): entries above the limit can never be matched, so the candidate-list solver sees the same problem
+        if (y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); })) {      // (also for the small levels: a handful of candidates, no dense matrix to fill)
+            Y7T_CPROF(17);
+        } else {
+        const int tot = n_tl * n_to;
+        for (int k = ex.tid; k < tot; k += ex.nt) {
+            const int r = k / n_to, c = k - r * n_to;
+            s.cost[(size_t)r * n_to + c] = gated_at(s.tmpb[r], s.left[c]);
         }
         y7t_sync(ex);
+        Y7T_CPROF(17);
         y7t_assign_on_cost(ex, s, n_tl, n_to, 0.9);
+        }
+        Y7T_CPROF(18);
         const int nmatch = y7t_compact(ex, n_tl, [&](int r) { return s.xrow[r] >= 0; }, s.tmpa, 0);
         for (int k = ex.tid; k < nmatch; k += ex.nt) {
             const int r = s.tmpa[k];
@@ -331,22 +465,33 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         for (int k = ex.tid; k < n_left; k += ex.nt) f.tomatch[k] = f.tmpd[k];
         y7t_sync(ex);
         n_to = n_left;
+        Y7T_CPROF(19);
     }
     // unmatched_tracks = list(set(track_indices) - set(k for k, _ in matches)): CPython set order
+    Y7T_PROF(h, 2);
     for (int i = ex.tid; i < n_pool; i += ex.nt) s.mark[i] = 0;
     y7t_sync(ex);
     for (int k = ex.tid; k < nm; k += ex.nt) s.mark[f.casc_tr[k]] = 1;
     y7t_sync(ex);
-    if (ex.tid == 0) s.ycol[0] = y7t_pyset_difference(n_pool, s.mark, nm, f.u0, f.pyset, &f.h->status);
+    {
+        const int n_unm = y7t_compact(ex, n_pool, [&](int i) { return !s.mark[i]; }, s.tmpa, 0);      // ascending, built by everyone
+        int need = 8;                              // table entries this call can reach: the power of two above 4 * n_unm
+        while (need <= 4 * n_unm) need <<= 1;
+        const bool in_lds = ex.fast && need <= Y7T_PYSET_CAP && ex.fast_bytes >= (size_t)2 * need * sizeof(int);       // the serial part walks LDS
+        if (ex.tid == 0) s.ycol[0] = in_lds ? y7t_pyset_difference_list(n_pool, s.tmpa, n_unm, nm, f.u0, (int*)ex.fast, &f.h->status, need)
+                                            : y7t_pyset_difference_list(n_pool, s.tmpa, n_unm, nm, f.u0, f.pyset, &f.h->status);
+    }
     y7t_sync(ex);
     const int n_u0 = s.ycol[0];
     y7t_sync(ex);
+    Y7T_PROF(h, 3);
     // apply the cascade's matches in match order (Tracked -> update, Lost -> re_activate)
     for (int k = ex.tid; k < nm; k += ex.nt) { s.rem[k] = s.pool[f.casc_tr[k]]; s.xrow[k] = f.casc_det[k]; }
     y7t_sync(ex);
     int na, nr;
     y7t_apply_matches(ex, s, s.rem, nm, s.dhi, dets, 0, na, nr);
     y7t_ds_append_features(ex, s, f, s.rem, nm, s.dhi, det_feats);
+    Y7T_PROF(h, 4);
     // ---- Step 3: IoU association of the still-Tracked leftovers (in u0 order) with the leftover detections, thresh 0.5 ----
     const int n_t0 = y7t_compact(ex, n_u0, [&](int k) { return s.state[s.pool[f.u0[k]]] == Y7T_TRACKED; }, s.tmpa, 0);
     for (int k = ex.tid; k < n_t0; k += ex.nt) s.rem[k] = s.pool[f.u0[s.tmpa[k]]];
@@ -358,6 +503,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_assoc(ex, s, n_t0, n_to, 0.5);
     y7t_apply_matches(ex, s, s.rem, n_t0, s.left, dets, 0, na, nr);
     y7t_ds_append_features(ex, s, f, s.rem, n_t0, s.left, det_feats);
+    Y7T_PROF(h, 5);
     // u_det1 (detection rows), in column order
     const int n_d1 = y7t_compact(ex, n_to, [&](int c) { return s.ycol[c] < 0; }, s.tmpb, 0);
     for (int k = ex.tid; k < n_d1; k += ex.nt) s.dlo[k] = s.left[s.tmpb[k]];
@@ -378,6 +524,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_assoc(ex, s, n_unc, n_d1, 0.9);
     y7t_apply_matches(ex, s, s.unconf, n_unc, s.dlo, dets, 2, na, nr);
     y7t_ds_append_features(ex, s, f, s.unconf, n_unc, s.dlo, det_feats);
+    Y7T_PROF(h, 6);
     {
         const int n_rm = y7t_compact(ex, n_unc, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
         for (int k = ex.tid; k < n_rm; k += ex.nt) { const int sl = s.unconf[s.tmpa[k]]; s.removedl[k] = sl; s.state[sl] = Y7T_REMOVED; }
@@ -405,7 +552,6 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         }
         y7t_sync(ex);
         const int made = s.xrow[0];
-        const int dim = f.h->dim, budget = f.h->budget;
         for (int k = ex.tid; k < made; k += ex.nt) {
             const int sl = s.tmpb[k], dj = s.dlo[s.tmpa[k]];
             double z[4];
@@ -419,15 +565,17 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
             s.act[sl] = (frame_id == 1) ? 1 : 0;
             s.frame[sl] = frame_id; s.start[sl] = frame_id;
             s.tsu[sl] = 0; s.len[sl] = 0; s.inrem[sl] = 0;
-            // STrack(..., feature=f): features = [f] (the raw vector, basetrack.py:97-103)
-            float* dst = f.ring + (size_t)sl * budget * dim;
-            const float* b = det_feats + (size_t)dj * dim;
-            for (int d = 0; d < dim; ++d) dst[d] = b[d];
-            f.nfeat[sl] = 1; f.fpos[sl] = 1 % budget;
         }
         y7t_sync(ex);
+        // STrack(..., feature=f): features = [f] (the raw vector, basetrack.py:97-103)
+        y7t_feat_store_many(ex, f, made, 0, [&](int k, int& sl, int& row) {
+            sl = s.tmpb[k];
+            row = s.dlo[s.tmpa[k]];
+            return true;
+        });
     }
     // age out long-lost tracks
+    Y7T_PROF(h, 7);
     {
         const int n_old = y7t_compact(ex, nl0, [&](int i) { return frame_id - s.frame[s.lost[i]] > cfg.max_time_lost; }, s.tmpa, 0);
         const int base = h->n_removed_last;
@@ -436,5 +584,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         if (ex.tid == 0) h->n_removed_last = base + n_old;
         y7t_sync(ex);
     }
+    Y7T_PROF(h, 8);
     y7t_finish(ex, s, out_rows, out_cap, out_count);
+    Y7T_PROF(h, 9);
 }

@@ -179,7 +179,11 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #ifndef Y7T_SPARSE_MIN
 #define Y7T_SPARSE_MIN 4096      // na * nb from which the sparse path is taken (64 x 64)
 #endif
-Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+struct Y7TBox4 { double v[4]; };
+
+// colctx(j): whatever of column j the cost needs (loaded once per lane, outside the row loop); cost(i, j, ctx) -> double
+template <class ColFn, class CostFn>
+Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
     const int tid = ex.tid, nt = ex.nt;
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
     // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
@@ -216,9 +220,9 @@ Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb,
     {
         const int lanes = nt < 64 ? nt : 64, nw = nt / lanes, wave = tid / lanes, lane = tid - wave * lanes;
         for (int j = lane; j < nb; j += lanes) {
-            const double q[4] = {s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]};
+            const auto cj = colctx(j);
             for (int i = wave; i < na; i += nw) {
-                const double c = y7t_iou_dist(s.ttlbr + 4 * i, q);
+                const double c = cost(i, j, cj);
                 if (c <= thresh) {
                     const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
                     if (k < Y7T_MAXC) { ccol[(size_t)i * Y7T_MAXC + k] = j; ccost[(size_t)i * Y7T_MAXC + k] = c; }
@@ -322,6 +326,13 @@ Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb,
     for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
     y7t_sync(ex);
     return true;
+}
+
+// the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
+Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+    return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
+                               [&](int j) { return Y7TBox4{{s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]}}; },
+                               [&](int i, int, const Y7TBox4& q) { return y7t_iou_dist(s.ttlbr + 4 * i, q.v); });
 }
 
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /

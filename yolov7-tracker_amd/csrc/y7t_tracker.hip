@@ -182,25 +182,83 @@ __global__ void k_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budg
     y7t_feat_init(ex, fblob, cap_t, cap_d, dim, budget);
 }
 
-// detection features of the frame -> normalised rows (a lane per detection)
-__global__ void __launch_bounds__(64) k_ds_normalize(void* fblob, const float* __restrict__ det_feats, int n) {
+// detection features of the frame -> normalised rows (a wave per detection)
+__global__ void __launch_bounds__(256) k_ds_normalize(void* fblob, const float* __restrict__ det_feats, int n) {
     const Y7TFeat f = y7t_feat_bind(fblob);
     Y7TExec ex;
     ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
     y7t_feat_normalize_dets(ex, f, det_feats, n);
 }
 
-// nearest-embedding distances: one workgroup per pool slot that holds a live track
-__global__ void __launch_bounds__(128) k_embed_dist(void* blob, void* fblob, int n) {
+// nearest-embedding distances, tiled: workgroup (slot, 64 detections), the slot's stored rows 32 at a time, 32-deep k chunks of both operands in LDS,
+// 2 x 4 products per thread.  Every product is the sequential FMA chain over k = 0 .. dim-1 of y7t_embed_slot (= numpy's sgemm), so the costs -- and
+// the assignment that follows them -- are bit-identical; only the order in which DIFFERENT products advance changes.
+__global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int n) {
     const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;
     const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
-    const int slot = blockIdx.x;
+    const int slot = blockIdx.x, j0 = blockIdx.y * 64;
     const int st = s.state[slot];
     if (st != Y7T_TRACKED && st != Y7T_LOST) return;
     const Y7TFeat f = y7t_feat_bind(fblob);
+    const int nf = f.nfeat[slot], dim = f.h->dim;
+    if (dim & 31) {      // feature dimensions that are not a multiple of the k chunk: the plain form, one workgroup per slot
+        if (blockIdx.y == 0) {
+            Y7TExec ex;
+            ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+            y7t_embed_slot(ex, f, slot, n);
+        }
+        return;
+    }
+    if (nf <= 0 || j0 >= n) return;
+    __shared__ float sA[32][33], sB[64][33], smin[16][64];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lrow = tid >> 3, kq = (tid & 7) * 4;
+    const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
+    float best[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+    for (int h0 = 0; h0 < nf; h0 += 32) {
+        float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int k0 = 0; k0 < dim; k0 += 32) {
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb0 = va, vb1 = va;
+            if (h0 + lrow < nf) va = *(const float4*)(hist + (size_t)(h0 + lrow) * dim + k0 + kq);
+            if (j0 + lrow < n) vb0 = *(const float4*)(f.detn + (size_t)(j0 + lrow) * dim + k0 + kq);
+            if (j0 + 32 + lrow < n) vb1 = *(const float4*)(f.detn + (size_t)(j0 + 32 + lrow) * dim + k0 + kq);
+            __syncthreads();
+            sA[lrow][kq] = va.x; sA[lrow][kq + 1] = va.y; sA[lrow][kq + 2] = va.z; sA[lrow][kq + 3] = va.w;
+            sB[lrow][kq] = vb0.x; sB[lrow][kq + 1] = vb0.y; sB[lrow][kq + 2] = vb0.z; sB[lrow][kq + 3] = vb0.w;
+            sB[32 + lrow][kq] = vb1.x; sB[32 + lrow][kq + 1] = vb1.y; sB[32 + lrow][kq + 2] = vb1.z; sB[32 + lrow][kq + 3] = vb1.w;
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const float a0 = sA[2 * ty][k], a1 = sA[2 * ty + 1][k];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float b = sB[tx + 16 * c][k];
+                    acc[0][c] = __builtin_fmaf(a0, b, acc[0][c]);
+                    acc[1][c] = __builtin_fmaf(a1, b, acc[1][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (h0 + 2 * ty + r < nf)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float d = 1.0f - acc[r][c]; best[c] = d < best[c] ? d : best[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) smin[ty][tx + 16 * c] = best[c];
+    __syncthreads();
+    if (tid < 64 && j0 + tid < n) {
+        float m = smin[0][tid];
+        for (int q = 1; q < 16; ++q) m = smin[q][tid] < m ? smin[q][tid] : m;
+        f.app[(size_t)slot * f.h->cap_d + j0 + tid] = m;
+    }
+}
+
+// the appearance vectors the step queued -> the rings (a wave per vector, across the grid)
+__global__ void __launch_bounds__(256) k_ds_store(void* fblob, const float* __restrict__ det_feats) {
+    const Y7TFeat f = y7t_feat_bind(fblob);
     Y7TExec ex;
-    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
-    y7t_embed_slot(ex, f, slot, n);
+    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    y7t_feat_store_pending(ex, f, det_feats);
 }
 
 __global__ void k_tracker_step_deepsort(void* state, void* fblob, const float* dets, int n, const float* det_feats, double* out_rows,
@@ -226,6 +284,18 @@ __global__ void __launch_bounds__(64) k_kf_gmc(double* mean, double* cov, const 
 // ---------------------------------------------------------------------------------------------
 static inline hipStream_t S(y7t_stream s) { return (hipStream_t)s; }
 static const unsigned kFastBytes = 128 * 1024;  // fast scratch per workgroup (of the CU's 160 KiB LDS)
+// A frame step asks for what its frame can use: the candidate lists + work arrays of an n-detection frame (~0.35 KiB per detection) rather than the
+// maximum.  A 128 KiB request only fits a CU that has fully drained, and in a pipeline the CUs are kept full by the detector's workgroups (35-150 KiB
+// each): the step then waits for one to empty.  Whatever does not fit the fast scratch lives in the state blob (every user checks the size).
+static unsigned step_fast_bytes(int n_dets) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("Y7T_TRACKER_FAST_KB"); forced = e ? atoi(e) * 1024 : 0; }
+    if (forced > 0) return (unsigned)(forced < (int)kFastBytes ? forced : (int)kFastBytes);
+    if (n_dets < 0) return kFastBytes;
+    if (n_dets <= 128) return 48 * 1024;
+    if (n_dets <= 256) return 96 * 1024;
+    return kFastBytes;
+}
 
 template <class K>
 static int ensure_lds(K kernel, unsigned bytes) {
@@ -400,8 +470,9 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
     Y7T_ARG_CHECK(nt > 0);
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
-    hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
-                       out_count, kFastBytes, gmc_warp);
+    const unsigned fb = step_fast_bytes(n);
+    hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
+                       out_count, fb, gmc_warp);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
@@ -428,14 +499,19 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step_deepsort, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     if (n > 0) {
-        hipLaunchKernelGGL(k_ds_normalize, dim3((n + 63) / 64), dim3(64), 0, S(stream), feat_state, det_feats, n);
+        hipLaunchKernelGGL(k_ds_normalize, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats, n);      // a wave per detection
         Y7T_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_embed_dist, dim3(cap_tracks), dim3(128), 0, S(stream), state, feat_state, n);
+        hipLaunchKernelGGL(k_embed_dist, dim3(cap_tracks, (n + 63) / 64), dim3(256), 0, S(stream), state, feat_state, n);
         Y7T_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tracker_step_deepsort, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats,
-                       out_rows, out_cap, out_count, kFastBytes);
+    const unsigned fb = step_fast_bytes(n);
+    hipLaunchKernelGGL(k_tracker_step_deepsort, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats,
+                       out_rows, out_cap, out_count, fb);
     Y7T_LAUNCH_CHECK();
+    if (n > 0) {
+        hipLaunchKernelGGL(k_ds_store, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats);
+        Y7T_LAUNCH_CHECK();
+    }
     return 0;
 }
 

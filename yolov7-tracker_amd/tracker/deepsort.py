@@ -59,6 +59,25 @@ class DeepSORT(BaseTracker):
         elif int(dim) != self._feat_dim:
             raise ValueError("feature dimension changed from %d to %d" % (self._feat_dim, int(dim)))
 
+    def _launch(self, det_dev, feats_dev, out=None):
+        """enqueue one frame step without a host round trip (pipelines / bench.py): det_dev (n, 6) float32 and feats_dev (n, D) float32
+        DEVICE tensors (rows at or below det_thresh are ignored by the step), out like BaseTracker._launch"""
+        d = det_dev.reshape(-1, 6)
+        n = d.shape[0]
+        if n > self.cap_d:
+            raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (n, self.cap_d))
+        self._ensure_feature_state(feats_dev.shape[1])
+        self._det_keep = (d, feats_dev)
+        if out is None:
+            optr, cptr = _lib.ptr(self._out), self._count_ptr
+        else:
+            import ctypes
+            optr, cptr = _lib.ptr(out), ctypes.c_void_p(out.data_ptr() + self.cap_t * 8 * 8)
+        _lib.check(self._L.y7t_tracker_step_deepsort(_lib.ptr(self._state), _lib.ptr(self._feat), self.cap_t, _lib.ptr(d), n, _lib.ptr(feats_dev),
+                                                     optr, self.cap_t, cptr, self.threads, _lib.stream_ptr()))
+        self.frame_id += 1
+        self._snap_cache = None
+
     def update(self, det_results, ori_img=None):
         """(N,6) [x1,y1,x2,y2,conf,cls] + the frame -> list of tracks (deepsort.py:79-227)"""
         if isinstance(det_results, torch.Tensor):
