@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_latency_mode", action="store_true")
-    ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain)")
+    ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain); 2: the tracker chain's stream does")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
@@ -276,7 +276,7 @@ def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
     for d in dets:
         plant(d, frames[:Bh])
     sAs = [torch.cuda.Stream(), torch.cuda.Stream()]
-    sB, sC = torch.cuda.Stream(), torch.cuda.Stream()
+    sB, sC = (torch.cuda.Stream(priority=-1) if args.prio == 2 else torch.cuda.Stream()), torch.cuda.Stream()
     n = (K + Wm) * 2
     ev_mid = [torch.cuda.Event() for _ in range(n)]
     ev_staged = [torch.cuda.Event() for _ in range(n)]
@@ -459,7 +459,7 @@ def main():
             dist.destroy_process_group()
         return
     # the forward's stream gets the high hardware priority: its workgroups are dispatched ahead of the NMS / tracker kernels that run beside it
-    sA = torch.cuda.Stream(priority=-1) if args.prio else torch.cuda.Stream()
+    sA = torch.cuda.Stream(priority=-1) if args.prio == 1 else torch.cuda.Stream()
     sB, sC, sH = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     NS = 2 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory
     ev_staged = [torch.cuda.Event() for _ in range(NS)]

@@ -96,6 +96,10 @@ TRACKER_CASES = [
     # The ReID network is replaced at DeepSORT.get_feature by synth.make_features on both sides.
     ("deepsort_default", "deepsort", "default", 80, 60, 8, 0),
     ("deepsort_crowd", "deepsort", "default", 30, 250, 9, 0),
+    # other embedding widths: 512 (what OSNet produces; the wave-parallel norms and the tiled distance kernel) and 100 (not a multiple of the
+    # kernels' 32-deep chunks: the plain forms)
+    ("deepsort_dim512", "deepsort", "default", 60, 70, 10, 0, 512),
+    ("deepsort_dim100", "deepsort", "default", 40, 50, 11, 9, 100),
 ]
 
 
@@ -109,21 +113,25 @@ def pack_tracks(frames):
             np.array(score, np.float32))
 
 
-def golden_tracker():
-    for name, trk, fmt, nf, nobj, seq, drop in TRACKER_CASES:
+def golden_tracker(only=None):
+    for case in TRACKER_CASES:
+        name, trk, fmt, nf, nobj, seq, drop = case[:7]
+        feat_dim = case[7] if len(case) > 7 else 128
+        if only and name not in only:
+            continue
         dets = synth.make_detections(nf, nobj, seq_idx=seq)
         if drop:
             dets = [None if (i % drop == drop - 1) else d for i, d in enumerate(dets)]
         warps = synth.make_warps(nf, seq_idx=seq) if trk == "botsort" else None
         ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps,
-                                                feature_fn=synth.make_features if trk == "deepsort" else None)
+                                                feature_fn=(lambda b, _d=feat_dim: synth.make_features(b, dim=_d)) if trk == "deepsort" else None)
         fr, ids, tlwh, cls, score = pack_tracks(ref)
         counts = np.array([-1 if d is None else len(d) for d in dets], np.int32)
         flat = np.concatenate([d for d in dets if d is not None], 0).astype(np.float32)
         np.savez_compressed(os.path.join(HERE, "tracker_%s.npz" % name), tracker=np.array(trk), kalman_format=np.array(fmt),
                             det_counts=counts, dets=flat, frame=fr, track_id=ids, tlwh=tlwh, cls=cls, score=score,
                             warps=np.zeros((0, 2, 3)) if warps is None else warps,
-                            numpy_version=np.array(np.__version__))
+                            numpy_version=np.array(np.__version__), feat_dim=np.array(feat_dim))
         print(name, "rows", len(ids), "max id", ids.max())
 
 
@@ -215,6 +223,9 @@ def golden_trackeval():
 
 if __name__ == "__main__":
     assert ref_harness.available(), "needs /root/reference"
+    if len(sys.argv) > 2 and sys.argv[1] == "--tracker":      # python make_golden.py --tracker name[,name...]: (re)record only these sequences
+        golden_tracker(only=sys.argv[2].split(","))
+        sys.exit(0)
     golden_kalman()
     golden_tracker()
     golden_lap_iou()

@@ -24,7 +24,7 @@ def test_hostsim_deepsort_matches_reference_golden(name):
     reference's two index quirks -- ids AND boxes equal to the sequences recorded from the reference's deepsort.py"""
     from yolov7_tracker_amd import synth
     trk, fmt, dets, want = util.load_tracker_case(name)
-    got = hs.run(trk, dets, kalman_format=fmt, feature_fn=synth.make_features)
+    got = hs.run(trk, dets, kalman_format=fmt, feature_fn=util.feature_fn_for(name), feat_dim=util.tracker_feat_dim(name))
     util.assert_same_tracks(got, want, name)
 
 

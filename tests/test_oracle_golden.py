@@ -45,7 +45,7 @@ def test_tracker_np_matches_reference_golden(name):
     trk, fmt, dets, want = util.load_tracker_case(name)
     from yolov7_tracker_amd import synth
     got = tracker_np.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name),
-                         feature_fn=synth.make_features if trk == "deepsort" else None)
+                         feature_fn=util.feature_fn_for(name) if trk == "deepsort" else None)
     util.assert_same_tracks(got, want, name)
 
 

@@ -186,13 +186,40 @@ def test_device_deepsort_matches_reference_golden(name):
     assert trk == "deepsort"
     BaseTrack._count = 0
     t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format=fmt, img_size=1280, iou_thresh=0.5))
-    t.get_feature = lambda tlbrs, img: synth.make_features(tlbrs)
+    feat = util.feature_fn_for(name)          # 128 wide, 512 (OSNet's width: wave-parallel norms, tiled distance kernel), 100 (the plain forms)
+    t.get_feature = lambda tlbrs, img: feat(tlbrs)
     got = []
     for d in dets:
         cur = t.update_without_detection() if d is None else t.update(d, None)
         got.append([(c.track_id, c.tlwh, float(c.cls), float(c.score)) for c in cur])
     util.assert_same_tracks(got, want, name)
     assert len(t.tracked_stracks) > 0 and t.frame_id == len(dets)
+
+
+def test_device_deepsort_chain_without_host_round_trips():
+    """DeepSORT._launch (what bench.py --workload cfg4 enqueues: detections and features already on the device, results left on the device, no
+    host sync between frames) reproduces the reference-recorded sequence row for row"""
+    import types
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    name = "deepsort_dim512"
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    assert all(d is not None for d in dets)
+    feat = util.feature_fn_for(name)
+    BaseTrack._count = 0
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format=fmt, img_size=1280, iou_thresh=0.5))
+    ddev = [torch.from_numpy(d).cuda() for d in dets]
+    fdev = [torch.from_numpy(feat(d[:, :4])).cuda() for d in dets]
+    res = torch.zeros((len(dets), t.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    for i in range(len(dets)):
+        t._launch(ddev[i], fdev[i], out=res[i])
+    torch.cuda.synchronize()
+    res = res.cpu().numpy()
+    got = []
+    for i in range(len(dets)):
+        cnt = int(res[i, t.cap_t].view(np.int32)[0])
+        got.append([(int(r[0]), r[1:5], float(np.float32(r[5])), float(np.float32(r[6]))) for r in res[i, :cnt]])
+    util.assert_same_tracks(got, want, name)
 
 
 def test_deepsort_crops_reach_the_reid_callable():

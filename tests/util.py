@@ -6,7 +6,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRACKER_CASES = ["sort_default", "bytetrack_default", "bytetrack_default_gaps", "bytetrack_botsort", "sort_strongsort",
                  "bytetrack_crowd", "botsort_gmc", "botsort_crowd"]
-DEEPSORT_CASES = ["deepsort_default", "deepsort_crowd"]      # appearance features from synth.make_features at the get_feature seam
+DEEPSORT_CASES = ["deepsort_default", "deepsort_crowd", "deepsort_dim512", "deepsort_dim100"]      # appearance features from synth.make_features at the get_feature seam
 ORACLE_ONLY_CASES = DEEPSORT_CASES
 # stated tolerance: ids / cls identical, tlwh within 1e-6 relative (scale: image size ~1e3 px)
 TLWH_RTOL, TLWH_ATOL = 1e-6, 1e-5
@@ -26,6 +26,18 @@ def load_tracker_case(name):
     for f, i, b, c, s in zip(g["frame"], g["track_id"], g["tlwh"], g["cls"], g["score"]):
         frames[f].append((int(i), b, float(c), float(s)))
     return str(g["tracker"]), str(g["kalman_format"]), dets, frames
+
+
+def tracker_feat_dim(name):
+    """embedding width a DeepSORT case was recorded with (synth.make_features(boxes, dim=...))"""
+    g = np.load(os.path.join(GOLDEN, "tracker_%s.npz" % name))
+    return int(g["feat_dim"]) if "feat_dim" in g.files else 128
+
+
+def feature_fn_for(name):
+    from yolov7_tracker_amd import synth
+    dim = tracker_feat_dim(name)
+    return lambda boxes: synth.make_features(boxes, dim=dim)
 
 
 def load_tracker_warps(name):

@@ -26,6 +26,9 @@ def _tracks(rng, n_obj, size):
     return cx, cy, w, h, vx, vy, cls, conf0
 
 
+_FEAT_DIM = 128
+
+
 def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=0.05, conf_jitter=0.05, ground_truth=None, bounce=False):
     """-> list of float32 (N_t, 6) arrays, one per frame.  `ground_truth`: a list that receives, per frame, the float64
     (n, 7) rows `[id (1-based), x, y, w, h, cls, detected]` of the true rectangles (clipped to the image; objects that left it
@@ -82,17 +85,15 @@ def make_detections(n_frames=100, n_obj=80, size=1280, seq_idx=0, miss=0.10, fp=
     return out
 
 
-_FEAT_DIM = 128
 
-
-def make_features(boxes, seed=0):
+def make_features(boxes, seed=0, dim=_FEAT_DIM):
     """Deterministic stand-in for a ReID embedding at DeepSORT's `get_feature(tlbrs, ori_img)` seam (tracker/deepsort.py:19-41; no
     ReID checkpoint ships with the reference, weights/ckpt.t7): a fixed random projection of what stays constant for an object in
-    these scenes -- its box width and height -- through a few non-linear terms to a unit vector of dimension 128, float32.
+    these scenes -- its box width and height -- through a few non-linear terms to a unit vector of dimension `dim` (128), float32.
     boxes: (N, >=4) [x1, y1, x2, y2, ...]."""
     boxes = np.asarray(boxes, dtype=np.float32).reshape(len(boxes), -1)
     rng = np.random.default_rng(BASE_SEED + 1000 + seed)
-    proj = rng.normal(0, 1, (6, _FEAT_DIM)).astype(np.float32)
+    proj = rng.normal(0, 1, (6, dim)).astype(np.float32)
     w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
     code = np.stack([w / 32.0, h / 32.0, np.sqrt(np.maximum(w * h, 0)) / 32.0, w / np.maximum(h, 1.0), np.sin(w / 7.0), np.cos(h / 9.0)], 1).astype(np.float32)
     f = code @ proj

@@ -59,9 +59,14 @@ class DeepSORT(BaseTracker):
         elif int(dim) != self._feat_dim:
             raise ValueError("feature dimension changed from %d to %d" % (self._feat_dim, int(dim)))
 
-    def _launch(self, det_dev, feats_dev, out=None):
+    def _launch(self, det_dev, feats_dev=None, out=None, **kw):
         """enqueue one frame step without a host round trip (pipelines / bench.py): det_dev (n, 6) float32 and feats_dev (n, D) float32
-        DEVICE tensors (rows at or below det_thresh are ignored by the step), out like BaseTracker._launch"""
+        DEVICE tensors (rows at or below det_thresh are ignored by the step), out like BaseTracker._launch.  det_dev None: the predict-only
+        step of update_without_detection (basetrack.py:489-537), the same for every tracker."""
+        if det_dev is None:
+            return super()._launch(None, out=out, **kw)
+        if feats_dev is None:
+            raise _lib.Y7TError("DeepSORT._launch needs the detections' appearance features (use update() for the get_feature seam)")
         d = det_dev.reshape(-1, 6)
         n = d.shape[0]
         if n > self.cap_d:
