@@ -25,7 +25,7 @@ def variant(n):
     return s
 tmp = os.path.join(b.OBJ, "ablate"); os.makedirs(tmp, exist_ok=True)
 objs = [os.path.join(b.OBJ, f[:-4] + ".o") for f in b._sources() if f != "y7t_conv.hip"]
-for n in (1, 2, 3, 4):
+for n in [int(a) for a in sys.argv[1:]] or (1, 2, 3, 4):
     p = os.path.join(tmp, "y7t_conv_%d.hip" % n); open(p, "w").write(variant(n))
     o = p[:-4] + ".o"
     subprocess.check_call([b.HIPCC] + b.FLAGS + ["-ffp-contract=fast", "-I", b.CSRC, "-c", p, "-o", o])
