@@ -236,7 +236,7 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
     if (r->fused_blob && !crops_f32) {
         Y7TReidFusedArgs a;
         a.frames = (const uint8_t*)frames_u8; a.frame_stride = fstride; a.H = H; a.W = W; a.boxes = boxes; a.frame_idx = frame_idx; a.N = N;
-        a.blob = r->fused_blob; a.feats = feats;
+        a.blob = r->fused_blob; a.feats = feats; a.prof = nullptr;
         return y7t_reid_fused_launch(a, s);
     }
     float* b0 = r->arena + r->bufs[0];

@@ -13,6 +13,7 @@ struct Y7TReidFusedArgs {
     int N;
     const char* blob;           // parameters in the kernel's consumption order (tracker/reid.py::pack_fused)
     float* feats;               // (N, 512)
+    long long* prof;            // diagnostics (Y7T_REID_PROF=1): shader-clock stamps of workgroup 0's phases, or null
 };
 
 size_t y7t_reid_fused_blob_bytes();

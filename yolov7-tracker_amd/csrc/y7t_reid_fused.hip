@@ -19,6 +19,8 @@
 #include "y7t_common.h"
 #include "y7t_conv_common.h"
 #include "y7t_reid_fused.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float floatx4;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
@@ -210,25 +212,48 @@ __device__ __forceinline__ void dwconv3(const char* U, char* T, const float* dww
 
 // one OSBlock (OSNet.py:223-279).  Param stream: conv1 frags + bias | gate fc1 w, b (4 floats), fc2 w, b | conv3 frags + bias (b3 + downsample bias) |
 // downsample frags | 10 x (light 1x1 frags, depthwise weights [MID/8][9][8], bias [MID])
-template <int H, int W, int CIN, int COUT, int MID, int R, int O_XIN, int O_XOUT, int O_X1, int O_T, int O_U, int O_S>
+// O_WH / O_WL: where the block's parameters are staged in LDS (header = conv1, gate, conv3, downsample; lights = the ten LightConv3x3), O_WH < 0: the
+// header is read from global memory.  A phase that fetches its own weights pays an L2 round trip (~1.4 us) before it can start, and a block is ~25 phases
+// of a few hundred cycles of work each; one cooperative copy per block replaces them.
+template <int H, int W, int CIN, int COUT, int MID, int R, int O_XIN, int O_XOUT, int O_X1, int O_T, int O_U, int O_S, int O_WH, int O_WL>
 __device__ __forceinline__ const char* osblock(char* lds, const char* wp, int tid) {
     constexpr int NPX = H * W, PIN = Pitch<CIN>::v, POUT = Pitch<COUT>::v, PM = Pitch<MID>::v;
     constexpr bool DOWN = CIN != COUT;
     constexpr int U_BYTES = (H + 2) * (W + 2) * PM;
+    constexpr int HDR_BYTES = (MID / 16) * (CIN / 16) * 512 + MID * 4 + R * MID * 4 + 16 + R * MID * 4 + MID * 4 + (COUT / 16) * (MID / 16) * 512 + COUT * 4 +
+                              (DOWN ? (COUT / 16) * (CIN / 16) * 512 : 0);
+    constexpr int LIGHTS_BYTES = 10 * ((MID / 16) * (MID / 16) * 512 + MID * 9 * 4 + MID * 4);
     const int wave = tid >> 6, lane = tid & 63;
-    const char* c1f = wp; wp += (MID / 16) * (CIN / 16) * 512;
-    const float* c1b = (const float*)wp; wp += MID * 4;
-    const float* g_w1 = (const float*)wp; wp += R * MID * 4;
-    const float* g_b1 = (const float*)wp; wp += 16;
-    const float* g_w2 = (const float*)wp; wp += R * MID * 4;
-    const float* g_b2 = (const float*)wp; wp += MID * 4;
-    const char* c3f = wp; wp += (COUT / 16) * (MID / 16) * 512;
-    const float* c3b = (const float*)wp; wp += COUT * 4;
-    const char* dnf = wp; if (DOWN) wp += (COUT / 16) * (CIN / 16) * 512;
+    {
+        auto stage = [&](char* dst, const char* src, int bytes) {
+            for (int i = tid; i < bytes / 16; i += 4 * NT) {       // four loads in flight per thread before the first store
+                floatx4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (i + q * NT < bytes / 16) v[q] = ((const floatx4*)src)[i + q * NT];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (i + q * NT < bytes / 16) ((floatx4*)dst)[i + q * NT] = v[q];
+            }
+        };
+        stage(lds + O_WL, wp + HDR_BYTES, LIGHTS_BYTES);
+        if (O_WH >= 0) stage(lds + (O_WH >= 0 ? O_WH : 0), wp, HDR_BYTES);
+        for (int i = tid; i < U_BYTES / 16; i += NT) ((floatx4*)(lds + O_U))[i] = floatx4{0.f, 0.f, 0.f, 0.f};      // the haloed image's border stays zero
+    }
+    const char* hp = O_WH >= 0 ? (const char*)(lds + (O_WH >= 0 ? O_WH : 0)) : wp;
+    const char* lp = lds + O_WL;
+    wp += HDR_BYTES + LIGHTS_BYTES;
+    if (O_WH >= 0) __syncthreads();
+    const char* c1f = hp; hp += (MID / 16) * (CIN / 16) * 512;
+    const float* c1b = (const float*)hp; hp += MID * 4;
+    const float* g_w1 = (const float*)hp; hp += R * MID * 4;
+    const float* g_b1 = (const float*)hp; hp += 16;
+    const float* g_w2 = (const float*)hp; hp += R * MID * 4;
+    const float* g_b2 = (const float*)hp; hp += MID * 4;
+    const char* c3f = hp; hp += (COUT / 16) * (MID / 16) * 512;
+    const float* c3b = (const float*)hp; hp += COUT * 4;
+    const char* dnf = hp;
     float* S = (float*)(lds + O_S);          // S[NW][MID]: per-wave pooled sums of the stream being finished | gate[MID]
 
-    // conv1 (1x1 + BN + ReLU) -> x1; zero the haloed image and the pooled sums meanwhile
-    for (int i = tid; i < U_BYTES / 16; i += NT) ((floatx4*)(lds + O_U))[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // conv1 (1x1 + BN + ReLU) -> x1
     conv1x1<NPX, W, CIN, MID, PIN, PM, false, true, true>(lds + O_XIN, lds + O_X1, c1f, c1b, wave, lane);
     floatx4 acc[AccShape<NPX, COUT>::N];
 #pragma unroll
@@ -240,9 +265,9 @@ __device__ __forceinline__ const char* osblock(char* lds, const char* wp, int ti
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j <= s; ++j) {
-            const char* lf = wp; wp += (MID / 16) * (MID / 16) * 512;
-            const float* dww = (const float*)wp; wp += MID * 9 * 4;
-            const float* dwb = (const float*)wp; wp += MID * 4;
+            const char* lf = lp; lp += (MID / 16) * (MID / 16) * 512;
+            const float* dww = (const float*)lp; lp += MID * 9 * 4;
+            const float* dwb = (const float*)lp; lp += MID * 4;
             conv1x1<NPX, W, MID, MID, PM, PM, true, false, false>(lds + (j == 0 ? O_X1 : O_T), lds + O_U, lf, nullptr, wave, lane);
             __syncthreads();
             if (j == s) dwconv3<H, W, MID, true>(lds + O_U, lds + O_T, dww, dwb, S, tid);
@@ -299,17 +324,20 @@ __device__ __forceinline__ const char* transition(char* lds, const char* wp, int
 // LDS map (bytes).  conv1 phase: CR (the normalised crop, 4-channel pixels, 3-pixel zero halo: 134 x 72 x 8) | C1 (64 x 32 x 16ch)
 constexpr int O_CR = 0, CR_W = 72, CR_H = 134, O_C1 = 77824;
 // stage 2 (32 x 16): X0 16ch | x1 | T | U (34 x 18 x 32) | S | X 64ch (pitch 144);  transition: Y at 0, pooled output over X
-constexpr int S2_X0 = 0, S2_X1 = 16384, S2_T = 32768, S2_U = 49152, S2_S = 68736, S2_X = 77824, S2_Y = 0;
+constexpr int S2_X0 = 0, S2_X1 = 16384, S2_T = 32768, S2_U = 49152, S2_S = 68736, S2_X = 77824, S2_Y = 0, S2_WL = 151552;      // + the lights' weights (11.25 KiB)
 // stage 3 (16 x 8): input 64ch at 77824 (pitch 144) | X 96ch (pitch 208) | x1 / T (pitch 80) | U (18 x 10 x 80) | S
-constexpr int S3_XIN = 77824, S3_X = 96256, S3_X1 = 0, S3_T = 10240, S3_U = 20480, S3_S = 34880, S3_Y = 0;
+constexpr int S3_XIN = 77824, S3_X = 96256, S3_X1 = 0, S3_T = 10240, S3_U = 20480, S3_S = 34880, S3_Y = 0, S3_WL = 36864, S3_WH = 122880;
 // stage 4 (8 x 4): input 96ch (pitch 208) | X 128ch (pitch 272) | x1 / T | U (10 x 6 x 80) | S;  conv5 output, pooled vector
-constexpr int S4_XIN = 40960, S4_X = 49152, S4_X1 = 0, S4_T = 2560, S4_U = 5120, S4_S = 9984, S4_Y5 = 61440, S4_V = 71680;
-constexpr int LDS_BYTES = 151552;
+constexpr int S4_XIN = 40960, S4_X = 49152, S4_X1 = 0, S4_T = 2560, S4_U = 5120, S4_S = 9984, S4_Y5 = 61440, S4_V = 71680, S4_WL = 73728, S4_WH = 108544;
+constexpr int LDS_BYTES = 163840;
 
 __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = blockIdx.x;
     const char* wp = p.blob;
+    int stamp = 0;
+#define REID_PROF() do { if (p.prof && n == 0 && tid == 0) p.prof[stamp] = clock64(); ++stamp; } while (0)
+    REID_PROF();
 
     // ---- crop + /255 + bilinear resize to 128 x 64 + Normalize -> CR (fp16, channel order of the frame, 4th channel 0) ----
     for (int i = tid; i < CR_H * CR_W * 8 / 16; i += NT) ((floatx4*)(lds + O_CR))[i] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -346,6 +374,7 @@ __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
     }
     __syncthreads();
 
+    REID_PROF();
     // ---- conv1: 7x7 / stride 2 / pad 3, 3 -> 16, BN, ReLU as an implicit GEMM: K-step (kh, half) = 4 pixels x 4 channels of input row 2*yo - 3 + kh ----
     {
         half4 a[14];
@@ -367,6 +396,7 @@ __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
         }
     }
     __syncthreads();
+    REID_PROF();
     // ---- maxpool 3x3 / stride 2 / pad 1 -> X0 (32 x 16 x 16ch); inputs are >= 0, so skipping the padding == -inf padding ----
     for (int task = tid; task < 32 * 16 * 2; task += NT) {
         const int cg = task & 1, px = task >> 1, yo = px >> 4, xo = px & 15;
@@ -388,14 +418,23 @@ __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
     }
     __syncthreads();
 
-    wp = osblock<32, 16, 16, 64, 16, 1, S2_X0, S2_X, S2_X1, S2_T, S2_U, S2_S>(lds, wp, tid);
-    wp = osblock<32, 16, 64, 64, 16, 1, S2_X, S2_X, S2_X1, S2_T, S2_U, S2_S>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<32, 16, 16, 64, 16, 1, S2_X0, S2_X, S2_X1, S2_T, S2_U, S2_S, -1, S2_WL>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<32, 16, 64, 64, 16, 1, S2_X, S2_X, S2_X1, S2_T, S2_U, S2_S, -1, S2_WL>(lds, wp, tid);
+    REID_PROF();
     wp = transition<32, 16, 64, S2_X, S2_Y, S3_XIN>(lds, wp, tid);
-    wp = osblock<16, 8, 64, 96, 32, 1, S3_XIN, S3_X, S3_X1, S3_T, S3_U, S3_S>(lds, wp, tid);
-    wp = osblock<16, 8, 96, 96, 32, 1, S3_X, S3_X, S3_X1, S3_T, S3_U, S3_S>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<16, 8, 64, 96, 32, 1, S3_XIN, S3_X, S3_X1, S3_T, S3_U, S3_S, S3_WH, S3_WL>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<16, 8, 96, 96, 32, 1, S3_X, S3_X, S3_X1, S3_T, S3_U, S3_S, S3_WH, S3_WL>(lds, wp, tid);
+    REID_PROF();
     wp = transition<16, 8, 96, S3_X, S3_Y, S4_XIN>(lds, wp, tid);
-    wp = osblock<8, 4, 96, 128, 32, 2, S4_XIN, S4_X, S4_X1, S4_T, S4_U, S4_S>(lds, wp, tid);
-    wp = osblock<8, 4, 128, 128, 32, 2, S4_X, S4_X, S4_X1, S4_T, S4_U, S4_S>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<8, 4, 96, 128, 32, 2, S4_XIN, S4_X, S4_X1, S4_T, S4_U, S4_S, S4_WH, S4_WL>(lds, wp, tid);
+    REID_PROF();
+    wp = osblock<8, 4, 128, 128, 32, 2, S4_X, S4_X, S4_X1, S4_T, S4_U, S4_S, S4_WH, S4_WL>(lds, wp, tid);
+    REID_PROF();
 
     // ---- conv5 (1x1 + BN + ReLU), global average pool, fc + BatchNorm1d + ReLU ----
     {
@@ -422,6 +461,7 @@ __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
         }
         p.feats[(size_t)n * 512 + tid] = fmaxf(a, 0.f);
     }
+    REID_PROF();
 }
 
 }  // namespace
@@ -447,8 +487,23 @@ int y7t_reid_fused_launch(const Y7TReidFusedArgs& a, hipStream_t s) {
         attr = true;
     }
     if (a.N <= 0) return 0;
-    hipLaunchKernelGGL(k_osnet_x025, dim3(a.N), dim3(NT), LDS_BYTES, s, a);
+    static int prof = -1;
+    static long long* prof_dev = nullptr;
+    if (prof < 0) { const char* e = getenv("Y7T_REID_PROF"); prof = e ? atoi(e) : 0; if (prof) Y7T_HIP_CHECK(hipMalloc((void**)&prof_dev, 32 * sizeof(long long))); }
+    Y7TReidFusedArgs b = a;
+    b.prof = prof ? prof_dev : nullptr;
+    hipLaunchKernelGGL(k_osnet_x025, dim3(a.N), dim3(NT), LDS_BYTES, s, b);
     Y7T_LAUNCH_CHECK();
+    if (prof) {      // diagnostics only: synchronous
+        long long h[32];
+        Y7T_HIP_CHECK(hipStreamSynchronize(s));
+        Y7T_HIP_CHECK(hipMemcpy(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost));
+        static const char* names[] = {"crop", "conv1 7x7", "maxpool", "block 2.0", "block 2.1", "transition 2", "block 3.0", "block 3.1", "transition 3", "block 4.0", "block 4.1",
+                                      "conv5+gap+fc"};
+        fprintf(stderr, "osnet_x025 workgroup 0 (kcycles):");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.1f,", names[i], (h[i + 1] - h[i]) / 1e3);
+        fprintf(stderr, " total %.1f\n", (h[12] - h[0]) / 1e3);
+    }
     y7t_note_kernel("osnet_x025_fused");
     return 0;
 }
