@@ -475,11 +475,25 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_sync(ex);
     {
         const int n_unm = y7t_compact(ex, n_pool, [&](int i) { return !s.mark[i]; }, s.tmpa, 0);      // ascending, built by everyone
-        int need = 8;                              // table entries this call can reach: the power of two above 4 * n_unm
-        while (need <= 4 * n_unm) need <<= 1;
-        const bool in_lds = ex.fast && need <= Y7T_PYSET_CAP && ex.fast_bytes >= (size_t)2 * need * sizeof(int);       // the serial part walks LDS
-        if (ex.tid == 0) s.ycol[0] = in_lds ? y7t_pyset_difference_list(n_pool, s.tmpa, n_unm, nm, f.u0, (int*)ex.fast, &f.h->status, need)
-                                            : y7t_pyset_difference_list(n_pool, s.tmpa, n_unm, nm, f.u0, f.pyset, &f.h->status);
+        if ((n_pool >> 2) > nm) {                  // set_copy_and_difference: ascending order, nothing serial about it
+            for (int k = ex.tid; k < n_unm; k += ex.nt) f.u0[k] = s.tmpa[k];
+            if (ex.tid == 0) s.ycol[0] = n_unm;
+        } else {
+            int need = 8;                          // table entries this call can reach: the power of two above 4 * n_unm
+            while (need <= 4 * n_unm) need <<= 1;
+            // the serial walk runs out of LDS when it fits: two tables + the list itself
+            const bool in_lds = ex.fast && need <= Y7T_PYSET_CAP && ex.fast_bytes >= (size_t)(2 * need + n_unm) * sizeof(int);
+            int* tab = in_lds ? (int*)ex.fast : f.pyset;
+            const int* unm = s.tmpa;
+            if (in_lds) {
+                int* l = tab + 2 * need;
+                for (int k = ex.tid; k < n_unm; k += ex.nt) l[k] = s.tmpa[k];
+                unm = l;
+                y7t_sync(ex);
+            }
+            if (ex.tid == 0) s.ycol[0] = in_lds ? y7t_pyset_difference_list(n_pool, unm, n_unm, nm, f.u0, tab, &f.h->status, need)
+                                                : y7t_pyset_difference_list(n_pool, unm, n_unm, nm, f.u0, tab, &f.h->status);
+        }
     }
     y7t_sync(ex);
     const int n_u0 = s.ycol[0];

@@ -284,16 +284,14 @@ __global__ void __launch_bounds__(64) k_kf_gmc(double* mean, double* cov, const 
 // ---------------------------------------------------------------------------------------------
 static inline hipStream_t S(y7t_stream s) { return (hipStream_t)s; }
 static const unsigned kFastBytes = 128 * 1024;  // fast scratch per workgroup (of the CU's 160 KiB LDS)
-// A frame step asks for what its frame can use: the candidate lists + work arrays of an n-detection frame (~0.35 KiB per detection) rather than the
-// maximum.  A 128 KiB request only fits a CU that has fully drained, and in a pipeline the CUs are kept full by the detector's workgroups (35-150 KiB
-// each): the step then waits for one to empty.  Whatever does not fit the fast scratch lives in the state blob (every user checks the size).
+// Fast scratch of a frame step.  Asking for less than the maximum on small frames (so that the step's workgroup can share a CU with the detector's
+// workgroups instead of waiting for one to drain) was measured: no gain in the step's start latency, and the association's cost matrix / candidate
+// lists falling back to the state blob made the in-pipeline chain 12 % slower (14.1 -> 15.8 ms per 32 frames).  Y7T_TRACKER_FAST_KB overrides.
 static unsigned step_fast_bytes(int n_dets) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("Y7T_TRACKER_FAST_KB"); forced = e ? atoi(e) * 1024 : 0; }
     if (forced > 0) return (unsigned)(forced < (int)kFastBytes ? forced : (int)kFastBytes);
-    if (n_dets < 0) return kFastBytes;
-    if (n_dets <= 128) return 48 * 1024;
-    if (n_dets <= 256) return 96 * 1024;
+    (void)n_dets;
     return kFastBytes;
 }
 
