@@ -3,6 +3,10 @@
 // CPU (one "thread", nt = 1) so the control flow of the device tracker can be exercised by the
 // `-m "not gpu"` suite where no GPU exists.  The product package never loads this library.
 #define Y7T_HOSTSIM 1
+static int g_literal_calls = 0;      // how many assignments met a tie and were re-solved by the literal lapjv
+#define Y7T_COUNT_LITERAL() (++g_literal_calls)
+static int g_tie_reason[8] = {0};
+#define Y7T_TIE_REASON(k) (++g_tie_reason[k])
 #include "../../yolov7-tracker_amd/csrc/y7t_track_step.h"
 #include "../../yolov7-tracker_amd/csrc/y7t_track_deepsort.h"
 #include <stdlib.h>
@@ -29,6 +33,8 @@ int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int 
 void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(H, mean, cov); }
 
 int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
+int hs_literal_calls() { return g_literal_calls; }
+int hs_tie_reason(int k) { return g_tie_reason[k]; }
 
 void hs_lapjv(const double* cost, int nr, int nc, double limit, int* x, int* y) {
     Y7TLap L;
@@ -46,7 +52,7 @@ void hs_lapsap(const double* cost, int nr, int nc, double limit, int* x, int* y)
     L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0; L.prof = nullptr;
     void* ws = malloc(y7t_lap_ws_bytes(L.n + 1) + 64);
     y7t_lap_bind(L, ws, L.n + 1);
-    y7t_lap_solve_sap(hs_ex(), L);
+    if (y7t_lap_solve_sap(hs_ex(), L)) y7t_lap_solve_literal(hs_ex(), L);
     for (int i = 0; i < nr; ++i) x[i] = L.x[i] >= nc ? -1 : L.x[i];
     for (int j = 0; j < nc; ++j) y[j] = L.y[j] >= nr ? -1 : L.y[j];
     free(ws);

@@ -79,3 +79,41 @@ def unique_optimum(cost, limit, x):
             if e2[r2, c2].sum() <= best + 1e-12:
                 return False
     return True
+
+
+def tie_prone_iou_costs(rng, n_cases=300):
+    """IoU cost matrices of INTEGER boxes on a coarse lattice: IoUs are small rationals, so pairs exactly at the limit (1 - IoU == 0.5 / 0.6) and
+    equal-cost alternatives are common -- the optimum of linear_assignment is then not unique and the answer is whatever lapjv's algorithm returns"""
+    from oracle import cnative
+    out = []
+    for t in range(n_cases):
+        nr, nc = (int(v) for v in rng.integers(1, 14, 2))
+        def boxes(n):
+            xy = rng.integers(0, 8, (n, 2)) * 10.0
+            wh = rng.choice([19.0, 29.0, 39.0], (n, 2))
+            return np.concatenate([xy, xy + wh], 1)
+        a, b = boxes(nr), boxes(nc)
+        out.append((1.0 - cnative.bbox_overlaps(a, b), [0.5, 0.6, 0.9, 0.7][t % 4]))
+    return out
+
+
+def sort_tie_scenes():
+    """two random SORT scenes in which a frame's assignment has a tie (found by sweeping the seeds of the random-scene tests): (seed, scene index)"""
+    return [(5, 6), (58, 7)]
+
+
+def random_scene(seed, scene_index, kind="sort"):
+    """scene number `scene_index` of the random-scene generator seeded with `seed` (tests/test_hostsim.py)"""
+    from yolov7_tracker_amd import synth
+    rng = np.random.default_rng(seed)
+    for scene in range(scene_index + 1):
+        n_obj = int(rng.integers(5, 120))
+        n_frames = int(rng.integers(15, 40))
+        miss, fp = float(rng.uniform(0.0, 0.3)), float(rng.uniform(0.0, 0.2))
+        gap = int(rng.integers(0, 9))
+    dets = synth.make_detections(n_frames, n_obj, 640, seq_idx=100 + scene_index, miss=miss, fp=fp)
+    if gap > 2:
+        dets = [None if (i % gap == gap - 1) else d for i, d in enumerate(dets)]
+    if scene_index % 4 == 3:
+        dets[n_frames // 2] = np.zeros((0, 6), np.float32)
+    return dets

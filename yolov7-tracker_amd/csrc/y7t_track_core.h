@@ -636,6 +636,149 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// lapjv.cpp LITERALLY (lap 0.4.0: _ccrrt_dense, _carr_dense x 2, _ca_dense with its `cols` permutation, find / scan order and "last free column of
+// the frontier" rule) on the implicit extended matrix.  Which optimum lapjv returns when there are several is a property of exactly these orders, so the
+// re-solve of a problem with ties runs them as written: the column minima in parallel, everything order-dependent by thread 0.  Rare (about one frame in
+// two thousand of the random-scene tests) and O(n^2) per free row at worst, so speed is not a concern here.
+// Work arrays as y7t_lap_solve (n = nr + nc each): cnt = `unique`, st = `cols`.
+// ---------------------------------------------------------------------------------------------
+#ifndef Y7T_COUNT_LITERAL
+#if Y7T_DEVICE
+static __device__ int y7t_g_literal_calls = 0;      // how many assignments met a tie and were re-solved literally (y7t_lap_literal_calls())
+#define Y7T_COUNT_LITERAL() do { if (ex.tid == 0) atomicAdd(&y7t_g_literal_calls, 1); } while (0)
+#else
+#define Y7T_COUNT_LITERAL() do { } while (0)      // (the CPU test build counts how often ties are met)
+#endif
+#endif
+Y7T_NOINL void y7t_lap_solve_literal(const Y7TExec& ex, Y7TLap& L) {
+    const int n = L.n, tid = ex.tid, nt = ex.nt;
+    if (n <= 0) return;
+    Y7T_COUNT_LITERAL();
+    for (int j = tid; j < n; j += nt) {              // v[j] = min_i c[i][j], y[j] = the first row that attains it
+        double best = Y7T_LARGE;
+        int bi = 0;
+        for (int i = 0; i < n; ++i) {
+            const double c = y7t_lap_cost(L, i, j);
+            if (c < best) { best = c; bi = i; }
+        }
+        L.v[j] = best; L.y[j] = bi; L.x[j] = -1; L.cnt[j] = 1;
+    }
+    y7t_sync(ex);
+    if (tid == 0) {
+        int* x = L.x; int* y = L.y; int* fr = L.fr; int* pred = L.pred; int* cols = L.st; int* unique = L.cnt;
+        double* v = L.v; double* d = L.d;
+        for (int j = n - 1; j >= 0; --j) {
+            const int i = y[j];
+            if (x[i] < 0) x[i] = j;
+            else { unique[i] = 0; y[j] = -1; }
+        }
+        int n_free = 0;
+        for (int i = 0; i < n; ++i) {
+            if (x[i] < 0) fr[n_free++] = i;
+            else if (unique[i]) {
+                const int j = x[i];
+                double mn = Y7T_LARGE;
+                for (int j2 = 0; j2 < n; ++j2) {
+                    if (j2 == j) continue;
+                    const double c = y7t_lap_cost(L, i, j2) - v[j2];
+                    if (c < mn) mn = c;
+                }
+                v[j] -= mn;
+            }
+        }
+        for (int pass = 0; pass < 2 && n_free > 0; ++pass) {      // _carr_dense
+            unsigned current = 0, rr_cnt = 0;
+            int new_free = 0;
+            while (current < (unsigned)n_free) {
+                rr_cnt++;
+                const int free_i = fr[current++];
+                int j1 = 0, j2 = -1;
+                double v1 = y7t_lap_cost(L, free_i, 0) - v[0], v2 = Y7T_LARGE;
+                for (int j = 1; j < n; ++j) {
+                    const double c = y7t_lap_cost(L, free_i, j) - v[j];
+                    if (c < v2) {
+                        if (c >= v1) { v2 = c; j2 = j; }
+                        else { v2 = v1; v1 = c; j2 = j1; j1 = j; }
+                    }
+                }
+                int i0 = y[j1];
+                const double v1_new = v[j1] - (v2 - v1);
+                const bool lowers = v1_new < v[j1];
+                if (rr_cnt < current * (unsigned)n) {
+                    if (lowers) v[j1] = v1_new;
+                    else if (i0 >= 0 && j2 >= 0) { j1 = j2; i0 = y[j2]; }
+                    if (i0 >= 0) {
+                        if (lowers) fr[--current] = i0;
+                        else fr[new_free++] = i0;
+                    }
+                } else if (i0 >= 0) fr[new_free++] = i0;
+                x[free_i] = j1;
+                y[j1] = free_i;
+            }
+            n_free = new_free;
+        }
+        for (int f = 0; f < n_free; ++f) {                         // _ca_dense / _find_path_dense
+            const int start = fr[f];
+            unsigned lo = 0, hi = 0, n_ready = 0;
+            int final_j = -1;
+            for (int j = 0; j < n; ++j) { cols[j] = j; pred[j] = start; d[j] = y7t_lap_cost(L, start, j) - v[j]; }
+            while (final_j == -1) {
+                if (lo == hi) {
+                    n_ready = lo;
+                    {                                              // _find_dense
+                        hi = lo + 1;
+                        double mind = d[cols[lo]];
+                        for (unsigned k = hi; k < (unsigned)n; ++k) {
+                            const int j = cols[k];
+                            if (d[j] <= mind) {
+                                if (d[j] < mind) { hi = lo; mind = d[j]; }
+                                cols[k] = cols[hi];
+                                cols[hi++] = j;
+                            }
+                        }
+                    }
+                    for (unsigned k = lo; k < hi; ++k) { const int j = cols[k]; if (y[j] < 0) final_j = j; }
+                }
+                if (final_j == -1) {                               // _scan_dense (on its own copies of lo / hi: it returns without writing them back when it ends the search)
+                    unsigned lo2 = lo, hi2 = hi;
+                    while (lo2 != hi2 && final_j == -1) {
+                        int j = cols[lo2++];
+                        const int i = y[j];
+                        const double mind = d[j];
+                        const double h = y7t_lap_cost(L, i, j) - v[j] - mind;
+                        for (unsigned k = hi2; k < (unsigned)n; ++k) {
+                            j = cols[k];
+                            const double cred = y7t_lap_cost(L, i, j) - v[j] - h;
+                            if (cred < d[j]) {
+                                d[j] = cred;
+                                pred[j] = i;
+                                if (cred == mind) {
+                                    if (y[j] < 0) { final_j = j; break; }
+                                    cols[k] = cols[hi2];
+                                    cols[hi2++] = j;
+                                }
+                            }
+                        }
+                    }
+                    if (final_j == -1) { lo = lo2; hi = hi2; }
+                }
+            }
+            {
+                const double mind = d[cols[lo]];
+                for (unsigned k = 0; k < n_ready; ++k) { const int j = cols[k]; v[j] += d[j] - mind; }
+            }
+            int i = -1, j = final_j;
+            while (i != start) {
+                i = pred[j];
+                y[j] = i;
+                const int t = j; j = x[i]; x[i] = t;
+            }
+        }
+    }
+    y7t_sync(ex);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same optimisation problem without the dummy rows/columns.  lap's extended matrix prices every unmatched row and
 // column at limit/2, so its objective is  const + sum over matched pairs of (c_ij - limit):  a rectangular assignment
 // where a row may also take a "null" column of cost 0 that never fills up.  Shortest augmenting paths (the augmentation
@@ -647,11 +790,33 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
 // ---------------------------------------------------------------------------------------------
 Y7T_FN double y7t_sap_cost(const Y7TLap& L, int i, int j) { return j < L.nc ? L.c[(size_t)i * L.ld + j] - 2.0 * L.half : 0.0; }
 
-Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
+// Returns true when the optimum may not be unique, because which optimum lapjv returns is then a property of ITS algorithm (column reduction /
+// augmenting row reduction / scan order): the caller re-solves with y7t_lap_solve_literal.  Two signs are watched:
+//   * a pair costs EXACTLY cost_limit (matching it and leaving both sides unmatched cost the same) -- always;
+//   * equal distances inside the search (two columns at the same shortest distance, a second path of the same length) -- for problems of up to
+//     Y7T_TIE_FULL_N rows + columns: the association of the unconfirmed tracks, whose boxes are still the integer boxes they were created from (a
+//     Kalman-filtered box meets an integer detection at an exactly equal cost practically never).  The primal-dual search produces such equalities by
+//     construction too (tight edges), so this over-reports (one association in ~900 at 80 objects, one in four at 500), and the literal re-solve is
+//     serial: ~5 ms at 160 rows + columns -- fine for a 20-column problem, not for the frame's main association.  Beyond the limit, equal-cost
+//     alternatives are resolved to the lowest column index.
+// IoU costs of integer boxes are small rationals (1 - 368/920 == 0.6; two detections at the same IoU from a fresh track; 5/6 + 1/3 == 2/3 + 1/2):
+// about one frame in 2000 of the random-scene tests has such a tie.
+#ifndef Y7T_TIE_REASON
+#define Y7T_TIE_REASON(k) do { } while (0)
+#endif
+#define Y7T_TIE_FULL_N 64      // problems up to this many rows + columns are also checked for equal-distance ties inside the search
+#define Y7T_TIE_EPS 1e-11      // two costs / path lengths closer than this are treated as tied (IoU rationals differ by >= ~1e-8; rounding noise is ~1e-16)
+Y7T_FN bool y7t_near(double a, double b) { const double d = a - b; return d <= Y7T_TIE_EPS && d >= -Y7T_TIE_EPS; }
+
+template <bool small>      // small: also watch for equal distances inside the search (problems of up to Y7T_TIE_FULL_N rows + columns)
+Y7T_NOINL bool y7t_lap_solve_sap_t(const Y7TExec& ex, Y7TLap& L) {
     const int nr = L.nr, nc = L.nc, ncol = nc + 1, tid = ex.tid, nt = ex.nt;
     Y7T_LPROF(0);
+    int* tie = L.fr + nr;         // (fr holds nr row candidates; the work arrays are nr + nc long)
+    if (tid == 0) *tie = 0;
     for (int j = tid; j < ncol; j += nt) { L.v[j] = 0.0; L.y[j] = -1; }
     for (int i = tid; i < nr; i += nt) L.x[i] = -1;
+    y7t_sync(ex);
     // ---- census of the CANDIDATE edges (c <= cost_limit, i.e. reduced cost <= 0): IoU cost matrices are sparse -- a track
     // overlaps a handful of detections -- so most rows can be settled without a search:
     //   * a row without candidates takes the null column;
@@ -659,7 +824,7 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
     //     the column price v = c - cost_limit that makes the edge tight.
     // Both are forced in every optimal solution (the objective separates over connected components of the candidate graph) and
     // leave a feasible dual with complementary slackness, so the shortest-augmenting-path loop below simply skips those rows.
-    const double lim = 2.0 * L.half;
+    const double lim = 2.0 * L.half, lim_hi = lim + Y7T_TIE_EPS;
     int* rowcnt = L.cnt;          // [nr]
     int* colcnt = L.cnt + nr;     // [nc]
     int* rowcand = L.fr;          // [nr]
@@ -670,12 +835,18 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
     }
     for (int i = tid; i < nr; i += nt) {
         int k = 0, cand = -1;
-        for (int j = 0; j < nc; ++j)
-            if (L.c[(size_t)i * L.ld + j] <= lim) { ++k; cand = j; }
+        for (int j = 0; j < nc; ++j) {
+            const double c = L.c[(size_t)i * L.ld + j];
+            if (c <= lim_hi) {
+                if (c <= lim) { ++k; cand = j; }
+                if (c >= lim - Y7T_TIE_EPS) { *tie = 1; Y7T_TIE_REASON(0); }
+            }
+        }
         rowcnt[i] = k;
         rowcand[i] = cand;
     }
     y7t_sync(ex);
+    if (*tie) return true;
     for (int i = tid; i < nr; i += nt) {
         if (rowcnt[i] == 0) L.x[i] = nc;
         else if (rowcnt[i] == 1 && colcnt[rowcand[i]] == 1) {
@@ -706,6 +877,7 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
             mind = mv;
             int fin = 0x7fffffff, nxt = 0x7fffffff;
             for (int j = tid; j < ncol; j += nt) {
+                if (small && L.st[j] == 0 && j != mj && y7t_near(L.d[j], mind)) { *tie = 1; Y7T_TIE_REASON(1); }      // two columns at the same shortest distance: equal-cost alternatives
                 if (L.st[j] == 0 && L.d[j] == mind) {
                     L.st[j] = 1;
                     if (j == nc || L.y[j] < 0) { if (j < fin) fin = j; }
@@ -724,9 +896,11 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
                     if (j == jc) { L.st[j] = 3; continue; }
                     if (sj == 0) {
                         const double cred = y7t_sap_cost(L, i, j) - L.v[j] - h;
+                        if (small && y7t_near(cred, L.d[j]) && cred <= L.d[nc] + Y7T_TIE_EPS) { *tie = 1; Y7T_TIE_REASON(2); }      // a second path of the same length to a column that can still matter
                         if (cred < L.d[j]) {
                             L.d[j] = cred;
                             L.pred[j] = i;
+                            if (small && y7t_near(cred, mind)) { *tie = 1; Y7T_TIE_REASON(3); }       // a further column at the distance being settled
                             if (cred == mind) {
                                 if (j == nc || L.y[j] < 0) { if (j < fin) fin = j; }
                                 else { L.st[j] = 1; sj = 1; }
@@ -758,5 +932,11 @@ Y7T_NOINL void y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
     for (int i = tid; i < nr; i += nt) if (L.x[i] >= nc) L.x[i] = nc + nr;   // >= nc reads as unmatched for the callers
     y7t_sync(ex);
     Y7T_LPROF(4);
+    y7t_sync(ex);
+    return *tie != 0;
+}
+
+Y7T_FN bool y7t_lap_solve_sap(const Y7TExec& ex, Y7TLap& L) {
+    return (L.nr + L.nc <= Y7T_TIE_FULL_N) ? y7t_lap_solve_sap_t<true>(ex, L) : y7t_lap_solve_sap_t<false>(ex, L);
 }
 

@@ -354,7 +354,7 @@ Y7T_FN void y7t_assign_on_cost(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     if (ex.fast && ws <= ex.fast_bytes) lapws = ex.fast;
     L.c = s.cost;
     y7t_lap_bind(L, lapws, L.n);
-    y7t_lap_solve_sap(ex, L);
+    if (y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
     for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
     for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];
     y7t_sync(ex);

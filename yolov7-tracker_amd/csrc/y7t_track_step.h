@@ -185,6 +185,8 @@ struct Y7TBox4 { double v[4]; };
 template <class ColFn, class CostFn>
 Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
     const int tid = ex.tid, nt = ex.nt;
+    const double thresh_hi = thresh + Y7T_TIE_EPS;      // (a pair exactly at the limit: see y7t_lap_solve_sap; the in-search watch is for <= Y7T_TIE_FULL_N
+                                                        //  rows + columns, which never come here: na * nb >= Y7T_SPARSE_MIN)
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
     // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
     const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
@@ -223,11 +225,14 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             const auto cj = colctx(j);
             for (int i = wave; i < na; i += nw) {
                 const double c = cost(i, j, cj);
+                if (c <= thresh_hi) {                         // (one compare on the common path: most pairs do not overlap at all)
+                if (c >= thresh - Y7T_TIE_EPS) { flag[0] = 1; Y7T_TIE_REASON(4); }      // exactly at the limit: the optimum is not unique -> dense path, lapjv's own order
                 if (c <= thresh) {
                     const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
                     if (k < Y7T_MAXC) { ccol[(size_t)i * Y7T_MAXC + k] = j; ccost[(size_t)i * Y7T_MAXC + k] = c; }
                     else flag[0] = 1;
                     Y7T_FETCH_ADD(colcnt + j, 1);
+                }
                 }
             }
         }
@@ -361,7 +366,11 @@ Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double
     if (L.prof && ex.tid == 0) L.prof[9] = clock64();
     L.c = cost;
     y7t_lap_bind(L, lapws, L.n);
-    y7t_lap_solve_sap(ex, L);
+#ifdef Y7T_ASSOC_JV       // experiments: lapjv's own algorithm on the implicit extended matrix (also what the SAP solver is checked against)
+    y7t_lap_solve(ex, L);
+#else
+    if (y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
+#endif
     if (L.prof && ex.tid == 0) L.prof[10] = clock64();
     for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
     for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];

@@ -146,7 +146,8 @@ __global__ void k_lapjv(const double* __restrict__ cost, int nr, int nc, double 
     __syncthreads();
     L.c = c;
     y7t_lap_bind(L, lapws, L.n);
-    if (jv_extended) y7t_lap_solve(ex, L); else y7t_lap_solve_sap(ex, L);
+    if (jv_extended) y7t_lap_solve(ex, L);
+    else if (y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
     for (int i = ex.tid; i < nr; i += ex.nt) x[i] = (L.x[i] >= nc) ? -1 : L.x[i];
     for (int j = ex.tid; j < nc; j += ex.nt) y[j] = (L.y[j] >= nr) ? -1 : L.y[j];
     if (opt && ex.tid == 0) {
@@ -368,6 +369,12 @@ extern "C" int y7t_kf_gating_f64(int kind, const double* mean, const double* cov
                        only_position, out);
     Y7T_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int y7t_lap_literal_calls(void) {
+    int v = -1;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(y7t_g_literal_calls), sizeof(int)) != hipSuccess) return -1;
+    return v;
 }
 
 extern "C" size_t y7t_lapjv_workspace_bytes(int n, int m) {
