@@ -77,12 +77,16 @@ int y7t_kf_gating_f64(int kind, const double* mean, const double* cov, const dou
  * tracker/matching.py:30-41.  cost: n x m row-major.  x[n]: column of row i or -1; y[m]: row of
  * column j or -1; opt (may be NULL): sum of the kept costs.  One workgroup on the device;
  * workspace: y7t_lapjv_workspace_bytes(n, m) bytes of device memory. */
-/* Diagnostics: how many assignments of this process met a tie (a pair exactly at cost_limit, equal-cost alternatives in a small problem) and were
- * re-solved with lap's lapjv.cpp run literally, because the optimum lapjv returns is then a property of its own scan order (matching.py:30-44). */
-int y7t_lap_literal_calls(void);
 size_t y7t_lapjv_workspace_bytes(int n, int m);
 int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit, int* x, int* y, double* opt, void* workspace,
                   y7t_stream stream);
+/* The same with HOST pointers (SURVEY 8b "+ _host variant": matching.linear_assignment is called with numpy arrays): cost / x / y / opt live in host
+ * memory; the library stages them through device buffers it owns (grown on demand), solves on the device and returns when x / y / opt are written.
+ * No CPU solver behind it: without a GPU it fails like every other entry point. */
+int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double cost_limit, int* x_host, int* y_host, double* opt_host, y7t_stream stream);
+/* Diagnostics: how many assignments of this process met a tie (a pair exactly at cost_limit, equal-cost alternatives in a small problem) and were
+ * re-solved with lap's lapjv.cpp run literally, because the optimum lapjv returns is then a property of its own scan order (matching.py:30-44). */
+int y7t_lap_literal_calls(void);
 
 /* ---------------------------------------------------------------- device-resident tracker ---- */
 /* BaseTrack._count (tracker/basetrack.py:22,43-46): one int in device memory, shared by every

@@ -381,6 +381,10 @@ def test_lapjv_device_bit_exact_vs_oracle_and_golden():
         np.testing.assert_array_equal(x0, x1)
         np.testing.assert_array_equal(y0, y1)
         assert abs(opt0 - opt1) < 1e-12
+        opt2, x2, y2 = matching.lapjv_host(c, lim)              # host-pointer entry: same kernel behind library-owned staging buffers
+        np.testing.assert_array_equal(x0, x2)
+        np.testing.assert_array_equal(y0, y2)
+        assert abs(opt0 - opt2) < 1e-12
     m, ua, ub = matching.linear_assignment(np.zeros((0, 5)), 0.9)
     assert m.shape == (0, 2) and ua == () and ub == (0, 1, 2, 3, 4)
 

@@ -405,6 +405,35 @@ extern "C" int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit
     return 0;
 }
 
+extern "C" int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double cost_limit, int* x_host, int* y_host, double* opt_host, y7t_stream stream) {
+    Y7T_ARG_CHECK(n >= 0 && m >= 0 && (n == 0 || x_host) && (m == 0 || y_host));
+    if (n == 0 || m == 0) {
+        for (int i = 0; i < n; ++i) x_host[i] = -1;
+        for (int j = 0; j < m; ++j) y_host[j] = -1;
+        if (opt_host) *opt_host = 0.0;
+        return 0;
+    }
+    Y7T_ARG_CHECK(cost_host);
+    static char* buf = nullptr;            // one staging allocation per process, grown on demand: cost | x | y | opt | solver workspace
+    static size_t cap = 0;
+    const size_t cb = y7t_al(sizeof(double) * (size_t)n * m), xb = y7t_al(sizeof(int) * (size_t)n), yb = y7t_al(sizeof(int) * (size_t)m), ob = y7t_al(sizeof(double));
+    const size_t need = cb + xb + yb + ob + y7t_lapjv_workspace_bytes(n, m);
+    if (need > cap) {
+        if (buf) Y7T_HIP_CHECK(hipFree(buf));
+        buf = nullptr; cap = 0;
+        Y7T_HIP_CHECK(hipMalloc((void**)&buf, need));
+        cap = need;
+    }
+    double* dc = (double*)buf; int* dx = (int*)(buf + cb); int* dy = (int*)(buf + cb + xb); double* dopt = (double*)(buf + cb + xb + yb);
+    Y7T_HIP_CHECK(hipMemcpyAsync(dc, cost_host, sizeof(double) * (size_t)n * m, hipMemcpyHostToDevice, S(stream)));
+    if (int e = y7t_lapjv_f64(dc, n, m, cost_limit, dx, dy, dopt, buf + cb + xb + yb + ob, stream)) return e;
+    Y7T_HIP_CHECK(hipMemcpyAsync(x_host, dx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, S(stream)));
+    Y7T_HIP_CHECK(hipMemcpyAsync(y_host, dy, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, S(stream)));
+    if (opt_host) Y7T_HIP_CHECK(hipMemcpyAsync(opt_host, dopt, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    Y7T_HIP_CHECK(hipStreamSynchronize(S(stream)));
+    return 0;
+}
+
 extern "C" size_t y7t_tracker_state_bytes(int cap_t, int cap_d) {
     if (cap_t <= 0 || cap_d <= 0) return 0;
     return y7t_trk_layout(cap_t, cap_d).total;

@@ -53,11 +53,26 @@ def lapjv_device(cost, cost_limit):
     return float(opt.item()), x[:n].cpu().numpy().astype(np.int64), y[:m].cpu().numpy().astype(np.int64)
 
 
+def lapjv_host(cost, cost_limit):
+    """the same for a numpy cost matrix through the library's host-pointer entry (y7t_lapjv_f64_host: staging buffers owned by the library, one call,
+    one synchronisation) -- what matching.linear_assignment uses, since the reference calls it with numpy arrays"""
+    _lib.require_gpu()
+    L = _lib.load()
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    n, m = c.shape
+    x, y, opt = np.empty(max(n, 1), np.int32), np.empty(max(m, 1), np.int32), np.zeros(1, np.float64)
+    _lib.check(L.y7t_lapjv_f64_host(c.ctypes.data, n, m, float(cost_limit), x.ctypes.data, y.ctypes.data, opt.ctypes.data, _lib.stream_ptr()))
+    return float(opt[0]), x[:n].astype(np.int64), y[:m].astype(np.int64)
+
+
 def linear_assignment(cost_matrix, thresh):
     """matching.py:30-41 -> (matches (K,2) int, unmatched_a, unmatched_b)."""
     cost_matrix = np.asarray(cost_matrix)
     if cost_matrix.size == 0:
         return np.empty((0, 2), dtype=int), tuple(range(cost_matrix.shape[0])), tuple(range(cost_matrix.shape[1]))
-    _, x, y = lapjv_device(cost_matrix, thresh)
+    if isinstance(cost_matrix, np.ndarray):
+        _, x, y = lapjv_host(cost_matrix, thresh)
+    else:
+        _, x, y = lapjv_device(cost_matrix, thresh)
     matches = np.asarray([[ix, mx] for ix, mx in enumerate(x) if mx >= 0])
     return matches, np.where(x < 0)[0], np.where(y < 0)[0]
