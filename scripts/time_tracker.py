@@ -41,9 +41,7 @@ for nobj in (80, 500):
         p = t._state[off:off + 32 * 8].view(torch.int64).cpu().numpy()
         if i >= 10:
             acc += np.diff(p[:12])
-            lap = lap + np.r_[np.diff(p[16:21]), p[22]] if i > 10 else np.r_[np.diff(p[16:21]), p[22]].astype(float)
     acc /= (len(dets) - 10)
     print("n_obj=%d  total %.0f kcycles: " % (nobj, acc.sum() / 1e3) + ", ".join("%s %.0f" % (n, v / 1e3) for n, v in zip(names, acc)))
-    lap /= (len(dets) - 10)
-    print("   assoc1 raw stamps (kcycles rel. to PROF3): cost-start %.0f cost-end %.0f solve-start %.0f solve-end %.0f post %.0f | assoc end %.0f" % tuple((pp - p[3]) / 1e3 for pp in (p[24], p[25], p[16], p[20], p[26], p[4])))
-    print("   (LAP#1 = solve-end - solve-start of the reduced shortest-augmenting-path solver)")
+    sp = np.diff(p[16:22]) / 1e3
+    print("   sparse association #1 (kcycles, last frame): cost pass %.0f, candidate sort %.0f, forced decisions %.0f, components %.0f, per-component solves %.0f" % tuple(sp))

@@ -185,6 +185,12 @@ struct Y7TBox4 { double v[4]; };
 template <class ColFn, class CostFn>
 Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
     const int tid = ex.tid, nt = ex.nt;
+#if Y7T_DEVICE
+#define Y7T_SPROF(i) do { if (thresh == 0.9 && tid == 0) s.h->prof[16 + (i)] = clock64(); } while (0)
+#else
+#define Y7T_SPROF(i) do { } while (0)
+#endif
+    Y7T_SPROF(0);
     const double thresh_hi = thresh + Y7T_TIE_EPS;      // (a pair exactly at the limit: see y7t_lap_solve_sap; the in-search watch is for <= Y7T_TIE_FULL_N
                                                         //  rows + columns, which never come here: na * nb >= Y7T_SPARSE_MIN)
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
@@ -238,6 +244,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         }
     }
     y7t_sync(ex);
+    Y7T_SPROF(1);
     if (flag[0]) return false;
     for (int i = tid; i < na; i += nt) {                      // sort each row's candidates by column (insertion sort, <= MAXC entries)
         int* cc = ccol + (size_t)i * Y7T_MAXC;
@@ -251,6 +258,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         }
     }
     y7t_sync(ex);
+    Y7T_SPROF(2);
     // ---- 2. forced decisions ----
     for (int i = tid; i < na; i += nt) {
         if (rowcnt[i] == 0) x[i] = nb;                        // null column
@@ -261,6 +269,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         }
     }
     y7t_sync(ex);
+    Y7T_SPROF(3);
     // ---- 3. components of the candidate graph among the unsettled rows: label = smallest row index ----
     for (int it = 0; it < na + 2; ++it) {
         for (int i = tid; i < na; i += nt)
@@ -278,6 +287,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         if (!flag[1]) break;
         y7t_sync(ex);
     }
+    Y7T_SPROF(4);
     // ---- 4. one lane per component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
     for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
@@ -327,6 +337,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         }
     }
     y7t_sync(ex);
+    Y7T_SPROF(5);
     for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
     for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
     y7t_sync(ex);
