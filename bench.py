@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--arch", default="yolov7-w6")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_latency_mode", action="store_true")
+    ap.add_argument("--seqs", type=int, default=1, help="sequences per GPU: the frames of a step are split over S independent sequences, each with its own "
+                    "tracker and stream (their frame-step chains run side by side); default 1 = one sequence per GPU (the metric's configuration)")
     ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain); 2: the tracker chain's stream does")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
@@ -371,7 +373,13 @@ def main():
     frames_host = synth.make_frames(B, args.n_obj, H, seq_idx=seq)           # B distinct frames, reused every step
     frames = torch.from_numpy(frames_host).cuda()
     n_frames *= 2 if (world == 1 and args.mode == "sequences" and args.halves == 1) else 1   # second pass: the same pipeline fed from host memory
-    dets_seq = synth.make_detections(n_frames, args.n_obj, H, seq_idx=seq, bounce=True)   # the scene's detections, frame by frame
+    S = max(1, args.seqs)
+    if B % S:
+        raise SystemExit("--seqs must divide --batch")
+    Bq = B // S                                                               # frames of one sequence per step
+    per_seq = [synth.make_detections(n_frames // S, args.n_obj, H, seq_idx=seq * S + q, bounce=True) for q in range(S)]   # each scene's detections, frame by frame
+    # frame slot i of step s belongs to sequence i // Bq, at its local time s * Bq + i % Bq; everything below is indexed by t = s * B + i
+    dets_seq = [per_seq[(t % B) // Bq][(t // B) * Bq + (t % B) % Bq] for t in range(n_frames)]
     dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
     plant_objectness_bias(det, frames)
 
@@ -380,14 +388,15 @@ def main():
         from yolov7_tracker_amd.tracker.botsort import BoTSORT
         o3 = make_opts()
         o3.kalman_format, o3.max_tracks, o3.max_dets = "botsort", 2048, 1024
-        trk = BoTSORT(o3, frame_rate=30)
-        warps_dev = torch.from_numpy(synth.make_warps(n_frames, seq_idx=seq).reshape(n_frames, 6)).cuda()     # what GMC.apply would estimate (botsort.py:13-248)
+        trks = [BoTSORT(o3, frame_rate=30) for _ in range(S)]
+        wq = [synth.make_warps(n_frames // S, seq_idx=seq * S + q).reshape(-1, 6) for q in range(S)]            # what GMC.apply would estimate (botsort.py:13-248)
+        warps_dev = torch.from_numpy(np.stack([wq[(t % B) // Bq][(t // B) * Bq + (t % B) % Bq] for t in range(n_frames)])).cuda()
     elif cfg4:
         # BASELINE configs[3]: DeepSORT, appearance features from OSNet x0_25 over 128 x 64 crops of every detection, taken from the frames in HBM
         from yolov7_tracker_amd.tracker.deepsort import DeepSORT
         from yolov7_tracker_amd.tracker.reid import ReIDExtractor
         reid = ReIDExtractor(None, max_crops=B * 2 * args.n_obj + 64, seed=0)
-        trk = DeepSORT(make_opts(), frame_rate=30, reid_model=reid)
+        trks = [DeepSORT(make_opts(), frame_rate=30, reid_model=reid) for _ in range(S)]
         step_boxes, step_idx, step_off = [], [], []       # per step: the boxes of its B frames' detections, their frame index, row ranges
         for s0 in range(0, n_frames, B):
             ns = [len(dets_seq[t]) for t in range(s0, s0 + B)]
@@ -395,12 +404,15 @@ def main():
             step_idx.append(torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), ns)).cuda())
             step_off.append(np.concatenate([[0], np.cumsum(ns)]).astype(np.int64))
     else:
-        trk = ByteTrack(make_opts(), frame_rate=30)
+        trks = [ByteTrack(make_opts(), frame_rate=30) for _ in range(S)]
+    trk = trks[0]
     results = torch.zeros((n_frames, trk.cap_t + 1, 8), dtype=torch.float64, device="cuda")
     ev_reid = {}
+    seq_streams = [torch.cuda.Stream() for _ in range(S - 1)]      # sequence 0 steps on the caller's stream, the others beside it
     def launch_step(s):
-        """the tracker frame steps of batch s, in frame order (BoT-SORT: with each frame's camera-motion warp; DeepSORT: after ONE ReID pass
-        over all detections of the batch's frames)"""
+        """the tracker frame steps of batch s: every sequence's frames in order on that sequence's stream (BoT-SORT: with each frame's
+        camera-motion warp; DeepSORT: after ONE ReID pass over all detections of the batch's frames)"""
+        cur = torch.cuda.current_stream()
         if cfg4:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -408,14 +420,25 @@ def main():
             e1.record()
             ev_reid[s] = (e0, e1)
             off = step_off[s]
-        for i in range(B):
-            t = s * B + i
-            if cfg3:
-                trk._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
-            elif cfg4:
-                trk._launch(dets_dev[t], feats[int(off[i]):int(off[i + 1])], out=results[t])
-            else:
-                trk._launch(dets_dev[t], out=results[t])
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        for q in range(S):
+            st = cur if q == 0 else seq_streams[q - 1]
+            with torch.cuda.stream(st):
+                if q:
+                    st.wait_event(fork)
+                for i in range(q * Bq, (q + 1) * Bq):
+                    t = s * B + i
+                    if cfg3:
+                        trks[q]._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
+                    elif cfg4:
+                        trks[q]._launch(dets_dev[t], feats[int(off[i]):int(off[i + 1])], out=results[t])
+                    else:
+                        trks[q]._launch(dets_dev[t], out=results[t])
+                if q:
+                    j = torch.cuda.Event()
+                    j.record(st)
+                    cur.wait_event(j)          # join: the step's chain is complete on the caller's stream
     tracker_name = "botsort" if cfg3 else "deepsort" if cfg4 else "bytetrack"
     metric_name = "end-to-end fps (detect+track) YOLOv7-w6@1280 " + ("BoT-SORT, 500-object stress" if cfg3 else
                                                                      "DeepSORT + OSNet x0_25 ReID (128x64 crops)" if cfg4 else "ByteTrack")
@@ -621,9 +644,9 @@ def main():
             "config": {"workload": ("configs[2]: YOLOv7-w6 1280x1280 + BoT-SORT (xywh Kalman, multi_gmc with a synthetic 2x3 warp per frame)" if cfg3 else
                                     "configs[3]: YOLOv7-w6 1280x1280 + DeepSORT, OSNet x0_25 embeddings of 128x64 crops of every detection (one fused "
                                     "MFMA kernel, one workgroup per crop), cascade + gated cosine/Mahalanobis cost on the device" if cfg4 else
-                                    "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack") + ", 1 synthetic VisDrone-shape sequence per GPU, %d objects per frame "
-                                   "(10 %% missed, 5 %% false positives, reflected at the border)" % args.n_obj, "frames_per_step": B, "arch": args.arch, "nc": nc,
-                       "tracker": tracker_name,
+                                    "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack") + ", %d synthetic VisDrone-shape sequence%s per GPU, %d objects per frame "
+                                   "(10 %% missed, 5 %% false positives, reflected at the border)" % (S, "" if S == 1 else "s (their tracker chains side by side)", args.n_obj), "frames_per_step": B, "arch": args.arch, "nc": nc,
+                       "tracker": tracker_name, "sequences_per_gpu": S,
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
                        "parallelism": "sequence-sharded x%d" % world, "collective_backend": backend if world > 1 else None,
                        "result_gather": gathered_info if world > 1 else None},
