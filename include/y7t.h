@@ -82,7 +82,7 @@ int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit, int* x, i
                   y7t_stream stream);
 /* The same with HOST pointers (SURVEY 8b "+ _host variant": matching.linear_assignment is called with numpy arrays): cost / x / y / opt live in host
  * memory; the library stages them through device buffers it owns (grown on demand), solves on the device and returns when x / y / opt are written.
- * No CPU solver behind it: without a GPU it fails like every other entry point. */
+ * No CPU solver behind it: without a GPU it fails like every other entry point.  Not re-entrant (one staging allocation per process). */
 int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double cost_limit, int* x_host, int* y_host, double* opt_host, y7t_stream stream);
 /* Diagnostics: how many assignments of this process met a tie (a pair exactly at cost_limit, equal-cost alternatives in a small problem) and were
  * re-solved with lap's lapjv.cpp run literally, because the optimum lapjv returns is then a property of its own scan order (matching.py:30-44). */
@@ -259,7 +259,7 @@ int y7t_reid_destroy(y7t_reid* reid);
 int y7t_reid_forward(y7t_reid* reid, const void* frame_u8, int H, int W, const float* boxes, int N, const float* crops_f32, float* feats,
                      y7t_stream stream);
 /* Crops taken from several frames in one pass (a batch of frames and all their detections -- the throughput mode of BASELINE config 4):
- * frames_u8 = n_frames x (H, W, 3) uint8 contiguous (device), frame_idx[i] = frame of box i (device int32). */
+ * frames_u8 = n_frames x (H, W, 3) uint8 contiguous (device), frame_idx[i] = frame of box i (device int32; clamped to [0, n_frames)). */
 int y7t_reid_forward_batch(y7t_reid* reid, const void* frames_u8, int n_frames, int H, int W, const float* boxes, const int* frame_idx, int N,
                            float* feats, y7t_stream stream);
 /* The MFMA path of config 4 ("ReID conv as MFMA kernel"): OSNet x0_25 on 128 x 64 crops as ONE kernel, one workgroup per crop, every

@@ -28,13 +28,13 @@ struct y7t_reid {
 };
 
 // crop + resize + normalise: out[n][y][x][c], c in the frame's channel order (BGR), cv2.INTER_LINEAR geometry on the float image
-__global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ frames, long long frame_stride, const int* __restrict__ frame_idx, int H, int W,
+__global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ frames, long long frame_stride, const int* __restrict__ frame_idx, int n_frames, int H, int W,
                                                    const float* __restrict__ boxes, int N, int oh, int ow, float* __restrict__ out) {
     const long long tot = (long long)N * oh * ow;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(t % ow), y = (int)((t / ow) % oh), n = (int)(t / ((long long)ow * oh));
         const float* b = boxes + 4 * (size_t)n;
-        const uint8_t* frame = frames + (frame_idx ? (size_t)frame_idx[n] * frame_stride : 0);
+        const uint8_t* frame = frames + (frame_idx ? (size_t)min(max(frame_idx[n], 0), n_frames - 1) * frame_stride : 0);
         int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];       // list(map(int, tlbr))
         x1 = min(max(x1, 0), W); x2 = min(max(x2, 0), W); y1 = min(max(y1, 0), H); y2 = min(max(y2, 0), H);
         const int cw = x2 - x1, ch = y2 - y1;
@@ -235,14 +235,14 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
     const long long fstride = (long long)H * W * 3;
     if (r->fused_blob && !crops_f32) {
         Y7TReidFusedArgs a;
-        a.frames = (const uint8_t*)frames_u8; a.frame_stride = fstride; a.H = H; a.W = W; a.boxes = boxes; a.frame_idx = frame_idx; a.N = N;
+        a.frames = (const uint8_t*)frames_u8; a.frame_stride = fstride; a.H = H; a.W = W; a.boxes = boxes; a.frame_idx = frame_idx; a.n_frames = n_frames; a.N = N;
         a.blob = r->fused_blob; a.feats = feats; a.prof = nullptr;
         return y7t_reid_fused_launch(a, s);
     }
     float* b0 = r->arena + r->bufs[0];
     if (crops_f32) Y7T_HIP_CHECK(hipMemcpyAsync(b0, crops_f32, sizeof(float) * (size_t)N * r->in_h * r->in_w * 3, hipMemcpyDeviceToDevice, s));
     else {
-        hipLaunchKernelGGL(k_reid_crop, dim3(blocks_for((long long)N * r->in_h * r->in_w)), dim3(256), 0, s, (const uint8_t*)frames_u8, fstride, frame_idx, H, W, boxes, N,
+        hipLaunchKernelGGL(k_reid_crop, dim3(blocks_for((long long)N * r->in_h * r->in_w)), dim3(256), 0, s, (const uint8_t*)frames_u8, fstride, frame_idx, n_frames, H, W, boxes, N,
                            r->in_h, r->in_w, b0);
         Y7T_LAUNCH_CHECK();
     }

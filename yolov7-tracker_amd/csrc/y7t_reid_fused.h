@@ -10,6 +10,7 @@ struct Y7TReidFusedArgs {
     int H, W;
     const float* boxes;         // (N, 4) tlbr in frame pixels
     const int* frame_idx;       // (N) frame of every box, or null: all boxes on frame 0
+    int n_frames;               // frame indices are clamped to [0, n_frames)
     int N;
     const char* blob;           // parameters in the kernel's consumption order (tracker/reid.py::pack_fused)
     float* feats;               // (N, 512)

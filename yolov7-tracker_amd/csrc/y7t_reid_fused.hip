@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(NT) k_osnet_x025(const Y7TReidFusedArgs p) {
     __syncthreads();
     {
         const float* b = p.boxes + 4 * (size_t)n;
-        const uint8_t* frame = p.frames + (p.frame_idx ? (size_t)p.frame_idx[n] * p.frame_stride : 0);
+        const uint8_t* frame = p.frames + (p.frame_idx ? (size_t)min(max(p.frame_idx[n], 0), p.n_frames - 1) * p.frame_stride : 0);
         int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];       // list(map(int, tlbr)), clipped like a numpy slice
         x1 = min(max(x1, 0), p.W); x2 = min(max(x2, 0), p.W); y1 = min(max(y1, 0), p.H); y2 = min(max(y2, 0), p.H);
         const int cw = x2 - x1, ch = y2 - y1;
