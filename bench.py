@@ -686,6 +686,9 @@ def main():
             heads0 = [r[:1].cpu() for r in out0.raw()]
             dets0 = d0[0, :int(n0[0])].cpu()
             if cfg4:
+                pr = trk._state[trk._layout["hdr_prof"]:trk._layout["hdr_prof"] + 256].view(torch.int64).cpu().numpy()
+                line["config"]["cascade"] = {"frames_with_several_ages": int(pr[27]), "of_them_with_a_contested_detection": int(pr[28]),
+                                             "solved_as_one_assignment": int(pr[29])}
                 rs = [ev_reid[s][0].elapsed_time(ev_reid[s][1]) for s in range(Wm, Wm + K)]
                 line["phases_ms_per_step"]["reid"] = round(float(np.mean(rs)), 3)
                 line["config"]["reid_crops_per_step_mean"] = round(float(np.mean([len(step_boxes[s]) for s in range(Wm, Wm + K)])), 1)

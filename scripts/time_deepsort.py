@@ -41,4 +41,4 @@ for threads in (64, 256):
     p = t._state[off:off + 32 * 8].view(torch.int64).cpu().numpy()
     ph = np.diff(p[:10]) / 1e3
     print("threads=%d  %.1f us/frame (4 kernels), ids so far %d | last frame kcycles: " % (threads, e0.elapsed_time(e1) * 1e3 / (nf - 20), BaseTrack._count)
-          + ", ".join("%s %.0f" % (n, v) for n, v in zip(names, ph)) + " | cascade: candidate-list assignments %.0f, dense assignments %.0f, bookkeeping %.0f" % tuple(p[17:20] / 1e3))
+          + ", ".join("%s %.0f" % (n, v) for n, v in zip(names, ph)) + " | frames with several ages %d, of them contested %d, solved jointly %d" % tuple(p[27:30]))

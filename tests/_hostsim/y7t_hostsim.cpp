@@ -77,8 +77,8 @@ int hs_deepsort_step(void* blob, void* fblob, const float* dets, int n, const fl
     const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
     const Y7TFeat f = y7t_feat_bind(fblob);
     y7t_feat_normalize_dets(ex, f, feats, n);
-    for (int k = 0; k < h->n_tracked; ++k) y7t_embed_slot(ex, f, s.tracked[k], n);
-    for (int k = 0; k < h->n_lost; ++k) y7t_embed_slot(ex, f, s.lost[k], n);
+    for (int k = 0; k < h->n_tracked; ++k) y7t_embed_slot(ex, f, s.tracked[k], n, s.tsu[s.tracked[k]]);
+    for (int k = 0; k < h->n_lost; ++k) y7t_embed_slot(ex, f, s.lost[k], n, s.tsu[s.lost[k]]);
     y7t_tracker_step_deepsort(ex, blob, fblob, dets, n, feats, out_rows, out_cap, &cnt);
     y7t_feat_store_pending(ex, f, feats);
     return cnt;

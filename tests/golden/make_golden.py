@@ -100,6 +100,10 @@ TRACKER_CASES = [
     # kernels' 32-deep chunks: the plain forms)
     ("deepsort_dim512", "deepsort", "default", 60, 70, 10, 0, 512),
     ("deepsort_dim100", "deepsort", "default", 40, 50, 11, 9, 100),
+    # appearance features that identify the object (synth.make_identity_features: what a ReID network delivers): a detection is wanted by one
+    # track only, the case in which the device solves all cascade levels in one assignment; 20-30 % missed detections keep several ages alive
+    ("deepsort_identity", "deepsort", "default", 60, 60, 20, 0, 128, "identity", 0.2),
+    ("deepsort_identity512", "deepsort", "default", 50, 80, 21, 0, 512, "identity", 0.3),
 ]
 
 
@@ -119,19 +123,26 @@ def golden_tracker(only=None):
         feat_dim = case[7] if len(case) > 7 else 128
         if only and name not in only:
             continue
-        dets = synth.make_detections(nf, nobj, seq_idx=seq)
+        identity = len(case) > 8 and case[8] == "identity"
+        feat_fn = (lambda b, _d=feat_dim: synth.make_features(b, dim=_d))
+        if identity:
+            dets, feat_fn = synth.make_identity_features(nf, nobj, 1280, seq_idx=seq, dim=feat_dim, miss=case[9])
+        else:
+            dets = synth.make_detections(nf, nobj, seq_idx=seq)
         if drop:
             dets = [None if (i % drop == drop - 1) else d for i, d in enumerate(dets)]
         warps = synth.make_warps(nf, seq_idx=seq) if trk == "botsort" else None
         ref = ref_harness.run_reference_tracker(trk, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps,
-                                                feature_fn=(lambda b, _d=feat_dim: synth.make_features(b, dim=_d)) if trk == "deepsort" else None)
+                                                feature_fn=feat_fn if trk == "deepsort" else None)
         fr, ids, tlwh, cls, score = pack_tracks(ref)
         counts = np.array([-1 if d is None else len(d) for d in dets], np.int32)
         flat = np.concatenate([d for d in dets if d is not None], 0).astype(np.float32)
         np.savez_compressed(os.path.join(HERE, "tracker_%s.npz" % name), tracker=np.array(trk), kalman_format=np.array(fmt),
                             det_counts=counts, dets=flat, frame=fr, track_id=ids, tlwh=tlwh, cls=cls, score=score,
                             warps=np.zeros((0, 2, 3)) if warps is None else warps,
-                            numpy_version=np.array(np.__version__), feat_dim=np.array(feat_dim))
+                            numpy_version=np.array(np.__version__), feat_dim=np.array(feat_dim),
+                            feat_kind=np.array("identity" if identity else "size"), scene=np.array([nf, nobj, seq], np.int64),
+                            feat_miss=np.array(case[9] if identity else 0.0))
         print(name, "rows", len(ids), "max id", ids.max())
 
 

@@ -28,6 +28,19 @@ def test_hostsim_deepsort_matches_reference_golden(name):
     util.assert_same_tracks(got, want, name)
 
 
+def test_hostsim_deepsort_joint_cascade_is_exercised():
+    """with features that identify the object no detection is wanted by tracks of two ages, and the step solves all cascade levels in one
+    assignment -- the identity goldens must actually take that path (and the size-feature goldens the level-by-level one)"""
+    L = hs.lib()
+    for name, joint in (("deepsort_identity", True), ("deepsort_default", False)):
+        trk, fmt, dets, want = util.load_tracker_case(name)
+        c0 = L.hs_tie_reason(7)
+        got = hs.run(trk, dets, kalman_format=fmt, feature_fn=util.feature_fn_for(name), feat_dim=util.tracker_feat_dim(name))
+        util.assert_same_tracks(got, want, name)
+        n = L.hs_tie_reason(7) - c0
+        assert (n > len(dets) // 2) if joint else (n == 0), (name, n)
+
+
 def test_hostsim_cpython_set_order_emulation():
     """matching_cascade returns list(set(range(n)) - set(matched)) (matching.py:275); its ORDER is CPython's set-table order and decides
     which tracks deepsort.py:171-173 marks lost -- the emulation must agree with the real thing"""

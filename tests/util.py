@@ -6,7 +6,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRACKER_CASES = ["sort_default", "bytetrack_default", "bytetrack_default_gaps", "bytetrack_botsort", "sort_strongsort",
                  "bytetrack_crowd", "botsort_gmc", "botsort_crowd"]
-DEEPSORT_CASES = ["deepsort_default", "deepsort_crowd", "deepsort_dim512", "deepsort_dim100"]      # appearance features from synth.make_features at the get_feature seam
+DEEPSORT_CASES = ["deepsort_default", "deepsort_crowd", "deepsort_dim512", "deepsort_dim100", "deepsort_identity", "deepsort_identity512"]      # appearance features from synth.make_features at the get_feature seam
 ORACLE_ONLY_CASES = DEEPSORT_CASES
 # stated tolerance: ids / cls identical, tlwh within 1e-6 relative (scale: image size ~1e3 px)
 TLWH_RTOL, TLWH_ATOL = 1e-6, 1e-5
@@ -35,8 +35,15 @@ def tracker_feat_dim(name):
 
 
 def feature_fn_for(name):
+    """the appearance features a DeepSORT case was recorded with, as a function of the boxes (the get_feature seam)"""
     from yolov7_tracker_amd import synth
+    g = np.load(os.path.join(GOLDEN, "tracker_%s.npz" % name))
     dim = tracker_feat_dim(name)
+    if "feat_kind" in g.files and str(g["feat_kind"]) == "identity":
+        nf, nobj, seq = (int(v) for v in g["scene"])
+        dets, fn = synth.make_identity_features(nf, nobj, 1280, seq_idx=seq, dim=dim, miss=float(g["feat_miss"]))
+        assert np.array_equal(np.concatenate(dets, 0), g["dets"]), "the regenerated scene is not the recorded one"
+        return fn
     return lambda boxes: synth.make_features(boxes, dim=dim)
 
 

@@ -19,7 +19,7 @@ enum { Y7T_DEEPSORT = 3 };
 
 // feature state of one DeepSORT tracker: caller-owned device memory next to the track-pool blob
 struct Y7TFeatHdr { int magic, dim, budget, cap_t, cap_d, status, n_pend, pad1; };
-struct Y7TFeatLayout { size_t ring, nfeat, fpos, app, detn, pend, casc_tr, casc_det, u0, tomatch, tmpd, pyset, total; };
+struct Y7TFeatLayout { size_t ring, nfeat, fpos, app, detn, pend, cmin, cmax, casc_tr, casc_det, u0, tomatch, tmpd, pyset, total; };
 struct Y7TFeat {
     Y7TFeatHdr* h;
     float* ring;        // [cap_t][budget][dim]   STrack.features, a ring of the last `budget` -- each stored as the row of cal_cosine_distance's mat1 it
@@ -29,6 +29,8 @@ struct Y7TFeat {
     float* detn;        // [cap_d][dim]           this frame's detection features, normalised (cal_cosine_distance's mat2)
     int* pend;          // [cap_d][3]             appearance vectors this frame's step decided to store: (slot, detection row, 1 = update / 0 = new track);
                         //                        written out after the step by y7t_feat_store_pending (grid-wide: a wave per vector)
+    int *cmin, *cmax;   // [cap_d]                youngest / oldest time_since_update among the live slots whose nearest-embedding distance to the detection
+                        //                        passes the appearance test (<= 0.15): reset by y7t_feat_normalize_dets, filled with the distances
     int *casc_tr, *casc_det, *u0;   // [cap_t]    cascade matches in match order (pool index, position in the detection list); unmatched pool indices
     int *tomatch, *tmpd;            // [cap_d]    detections_to_match of the current cascade level (+ scratch)
     int* pyset;         // [2][Y7T_PYSET_CAP]
@@ -40,7 +42,7 @@ Y7T_HD Y7TFeatLayout y7t_feat_layout(int cap_t, int cap_d, int dim, int budget) 
     const size_t T = (size_t)cap_t, D = (size_t)cap_d;
 #define Y7T_TAKE(f, bytes) L.f = o; o = y7t_al(o + (bytes));
     Y7T_TAKE(ring, T * budget * dim * 4) Y7T_TAKE(nfeat, T * 4) Y7T_TAKE(fpos, T * 4) Y7T_TAKE(app, T * D * 4)
-    Y7T_TAKE(detn, D * dim * 4) Y7T_TAKE(pend, D * 3 * 4)
+    Y7T_TAKE(detn, D * dim * 4) Y7T_TAKE(pend, D * 3 * 4) Y7T_TAKE(cmin, D * 4) Y7T_TAKE(cmax, D * 4)
     Y7T_TAKE(casc_tr, T * 4) Y7T_TAKE(casc_det, T * 4) Y7T_TAKE(u0, T * 4) Y7T_TAKE(tomatch, D * 4) Y7T_TAKE(tmpd, D * 4)
     Y7T_TAKE(pyset, (size_t)2 * Y7T_PYSET_CAP * 4)
 #undef Y7T_TAKE
@@ -55,7 +57,7 @@ Y7T_FN Y7TFeat y7t_feat_bind(void* blob) {
     Y7TFeat f;
     f.h = h;
     f.ring = (float*)(b + L.ring); f.nfeat = (int*)(b + L.nfeat); f.fpos = (int*)(b + L.fpos); f.app = (float*)(b + L.app);
-    f.detn = (float*)(b + L.detn); f.pend = (int*)(b + L.pend);
+    f.detn = (float*)(b + L.detn); f.pend = (int*)(b + L.pend); f.cmin = (int*)(b + L.cmin); f.cmax = (int*)(b + L.cmax);
     f.casc_tr = (int*)(b + L.casc_tr); f.casc_det = (int*)(b + L.casc_det); f.u0 = (int*)(b + L.u0);
     f.tomatch = (int*)(b + L.tomatch); f.tmpd = (int*)(b + L.tmpd); f.pyset = (int*)(b + L.pyset);
     return f;
@@ -288,6 +290,7 @@ Y7T_FN void y7t_feat_store_pending(const Y7TExec& ex, const Y7TFeat& f, const fl
 // mat2 of cal_cosine_distance: every detection feature of the frame divided by its norm (device: a wave per detection; else a lane each)
 Y7T_FN void y7t_feat_normalize_dets(const Y7TExec& ex, const Y7TFeat& f, const float* det_feats, int n) {
     const int dim = f.h->dim;
+    for (int j = ex.tid; j < n; j += ex.nt) { f.cmin[j] = 0x7fffffff; f.cmax[j] = -1; }
 #if Y7T_DEVICE
     if (y7t_dim_wave_ok(dim) && (ex.nt & 63) == 0) {
         const int lane = ex.tid & 63;
@@ -313,7 +316,7 @@ Y7T_FN void y7t_feat_normalize_dets(const Y7TExec& ex, const Y7TFeat& f, const f
 // nearest_embedding_distance (matching.py:105-127) for ONE pool slot against every detection feature of the frame:
 //   app[slot][j] = min over the slot's stored rows a' of  1 - a' . (b_j / |b_j|)        (float32: one sequential FMA chain over k per product)
 // Plain form (a lane per detection); the device runs the tiled k_embed_dist (y7t_tracker.hip) with the same chains instead.
-Y7T_FN void y7t_embed_slot(const Y7TExec& ex, const Y7TFeat& f, int slot, int n) {
+Y7T_FN void y7t_embed_slot(const Y7TExec& ex, const Y7TFeat& f, int slot, int n, int tsu /* the slot's time_since_update: ages of a detection's appearance candidates */) {
     const int nf = f.nfeat[slot], dim = f.h->dim;
     if (nf <= 0) return;
     const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
@@ -329,6 +332,7 @@ Y7T_FN void y7t_embed_slot(const Y7TExec& ex, const Y7TFeat& f, int slot, int n)
             best = c < best ? c : best;
         }
         row[j] = best;
+        if ((double)best <= 0.15) { Y7T_ATOMIC_MIN_I(f.cmin + j, tsu); Y7T_ATOMIC_MAX(f.cmax + j, tsu); }
     }
     y7t_sync(ex);
 }
@@ -420,24 +424,68 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     unsigned long long lvl_mask = 0;           // max_time_lost <= 64 levels in the mask, anything above is scanned the slow way
     for (int k = 0; k < cfg.max_time_lost && k < 64; ++k) if (lvl[k]) lvl_mask |= 1ull << k;
     y7t_sync(ex);
-    for (int level = 0; level < cfg.max_time_lost && n_to > 0; ++level) {
+    auto gated_at = [&](int sl, int dj) {
+        // gated_metric: appearance cost, > 0.15 -> 1e5; squared Mahalanobis distance to the predicted state > chi2inv95[4] -> 1e5.  The gate is only
+        // evaluated where the appearance test leaves a finite cost (the result is 1e5 either way otherwise).
+        double cost = (double)f.app[(size_t)sl * cfg.cap_d + dj];
+        if (cost > 0.15) return 1e5;
+        double z[4];
+        y7t_meas(kf, s.dbox + 4 * (size_t)dj, z);
+        if (y7t_kf_gating(kf, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl, z, 0) > 9.4877) cost = 1e5;
+        return cost;
+    };
+    // ---- all levels in ONE assignment when no detection is wanted by tracks of two different ages.  The cascade hands level L only the detections the
+    // younger levels left over; if every detection's appearance candidates (a superset of its candidates) share one age, those left-overs are exactly the
+    // columns level L could use anyway: the candidate graph of the joint problem is the disjoint union of the levels' graphs, the solver works per
+    // connected component, and rows / columns keep their relative order -- same matches, one set of passes instead of one per age. ----
+    bool joint_done = false;
+    if (cfg.max_time_lost <= 64 && (lvl_mask & (lvl_mask - 1)) != 0 && n_to > 0) {
+        const int n_rows = y7t_compact(ex, n_pool, [&](int i) { const int a = s.tsu[s.pool[i]] - 1; return a >= 0 && a < cfg.max_time_lost; }, s.rem, 0);
+        for (int r = ex.tid; r < n_rows; r += ex.nt) s.tmpb[r] = s.pool[s.rem[r]];
+        for (int c = ex.tid; c < n_hi; c += ex.nt) s.left[c] = s.dhi[c];
+        if (ex.tid == 0) s.xrow[0] = 0;
+        y7t_sync(ex);
+        // (f.cmin / f.cmax: ages of every detection's appearance candidates among ALL live slots, recorded with the distances -- a superset of the pool's)
+        for (int c = ex.tid; c < n_hi; c += ex.nt) if (f.cmax[s.left[c]] > f.cmin[s.left[c]]) s.xrow[0] = 1;
+        y7t_sync(ex);
+        const bool mixed = s.xrow[0] != 0;
+        y7t_sync(ex);
+#if Y7T_DEVICE
+        if (ex.tid == 0) { h->prof[27] += 1; if (mixed) h->prof[28] += 1; }      // diagnostics: frames with several ages / with a contested detection
+#endif
+        if (!mixed && y7t_assoc_sparse_fn(ex, s, n_rows, n_hi, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); })) {
+            // the cascade's match order: by age, inside an age by row
+            const int nm2 = y7t_compact(ex, n_rows, [&](int r) { return s.xrow[r] >= 0; }, s.tmpa, 0);
+            int* age = f.tmpd;
+            for (int k = ex.tid; k < nm2; k += ex.nt) age[k] = s.tsu[s.tmpb[s.tmpa[k]]];
+            y7t_sync(ex);
+            for (int k = ex.tid; k < nm2; k += ex.nt) {
+                const int r = s.tmpa[k], a = age[k];
+                int rank = 0;
+                for (int k2 = 0; k2 < nm2; ++k2) rank += (age[k2] < a) || (age[k2] == a && s.tmpa[k2] < r);
+                f.casc_tr[rank] = s.rem[r];
+                f.casc_det[rank] = s.xrow[r];              // (detections_to_match was the whole list: position == column)
+            }
+            nm = nm2;
+            const int n_left = y7t_compact(ex, n_hi, [&](int c) { return s.ycol[c] < 0; }, f.tomatch, 0);
+            y7t_sync(ex);
+            n_to = n_left;
+            joint_done = true;
+#if Y7T_DEVICE
+            if (ex.tid == 0) h->prof[29] += 1;
+#endif
+            Y7T_TIE_REASON(7);                         // (counted by the CPU test build: how often the joint form applies)
+        }
+        y7t_sync(ex);
+    }
+    for (int level = 0; !joint_done && level < cfg.max_time_lost && n_to > 0; ++level) {
         if (level < 64 && !((lvl_mask >> level) & 1ull)) continue;
         const int n_tl = y7t_compact(ex, n_pool, [&](int i) { return s.tsu[s.pool[i]] == 1 + level; }, s.rem, 0);   // pool indices of this age
         Y7T_CPROF(16);
         if (n_tl == 0) continue;
-        // gated_metric: appearance cost, > 0.15 -> 1e5; squared Mahalanobis distance to the predicted state > chi2inv95[4] -> 1e5.  The gate is only
-        // evaluated where the appearance test leaves a finite cost (the result is 1e5 either way otherwise).
         for (int r = ex.tid; r < n_tl; r += ex.nt) s.tmpb[r] = s.pool[s.rem[r]];             // pool slot of every row
         for (int c = ex.tid; c < n_to; c += ex.nt) s.left[c] = s.dhi[f.tomatch[c]];           // detection row of every column
         y7t_sync(ex);
-        auto gated_at = [&](int sl, int dj) {
-            double cost = (double)f.app[(size_t)sl * cfg.cap_d + dj];
-            if (cost > 0.15) return 1e5;
-            double z[4];
-            y7t_meas(kf, s.dbox + 4 * (size_t)dj, z);
-            if (y7t_kf_gating(kf, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl, z, 0) > 9.4877) cost = 1e5;
-            return cost;
-        };
         // linear_assignment(cost, 0.9): entries above the limit can never be matched, so the candidate-list solver sees the same problem
         if (y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); })) {      // (also for the small levels: a handful of candidates, no dense matrix to fill)
             Y7T_CPROF(17);

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
         if (blockIdx.y == 0) {
             Y7TExec ex;
             ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
-            y7t_embed_slot(ex, f, slot, n);
+            y7t_embed_slot(ex, f, slot, n, s.tsu[slot]);
         }
         return;
     }
@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
         float m = smin[0][tid];
         for (int q = 1; q < 16; ++q) m = smin[q][tid] < m ? smin[q][tid] : m;
         f.app[(size_t)slot * f.h->cap_d + j0 + tid] = m;
+        if ((double)m <= 0.15) { const int a = s.tsu[slot]; atomicMin(f.cmin + j0 + tid, a); atomicMax(f.cmax + j0 + tid, a); }
     }
 }
 

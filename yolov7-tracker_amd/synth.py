@@ -100,6 +100,35 @@ def make_features(boxes, seed=0, dim=_FEAT_DIM):
     return (f / np.maximum(np.linalg.norm(f, axis=1, keepdims=True), 1e-12)).astype(np.float32)
 
 
+def make_identity_features(n_frames=60, n_obj=60, size=1280, seq_idx=0, dim=128, noise=0.15, **kw):
+    """A scene whose appearance features IDENTIFY the object (what a ReID network delivers): -> (dets, feature_fn).  Every detection of object k
+    gets unit(base_k + noise * N(0, 1)), false positives a random unit vector; feature_fn(boxes) looks the vectors up by the box (the seam
+    DeepSORT.get_feature(tlbrs, ori_img) only sees boxes).  With such features a detection is an appearance candidate of ONE track, which is
+    when the matching cascade's levels do not compete for detections."""
+    gt = []
+    dets = make_detections(n_frames, n_obj, size, seq_idx, ground_truth=gt, **kw)
+    rng = np.random.default_rng(BASE_SEED + 2000 + seq_idx)
+    base = rng.normal(0, 1, (n_obj + 1, dim)).astype(np.float32)
+    table = {}
+    for d, g in zip(dets, gt):
+        f = rng.normal(0, 1, (len(d), dim)).astype(np.float32)
+        if len(g) and len(d):
+            gc = np.stack([g[:, 1] + g[:, 3] / 2, g[:, 2] + g[:, 4] / 2], 1)
+            dc = np.stack([(d[:, 0] + d[:, 2]) / 2, (d[:, 1] + d[:, 3]) / 2], 1)
+            dist = np.abs(dc[:, None, :] - gc[None, :, :]).max(2)
+            j = dist.argmin(1)
+            hit = dist[np.arange(len(d)), j] < 4.0
+            f[hit] = base[g[j[hit], 0].astype(int)] + np.float32(noise) * f[hit]
+        f = (f / np.maximum(np.linalg.norm(f, axis=1, keepdims=True), 1e-12)).astype(np.float32)
+        for row, v in zip(d, f):
+            table[tuple(float(x) for x in row[:4])] = v
+
+    def feature_fn(boxes):
+        boxes = np.asarray(boxes, dtype=np.float32).reshape(len(boxes), -1)
+        return np.stack([table[tuple(float(x) for x in b[:4])] for b in boxes]) if len(boxes) else np.zeros((0, dim), np.float32)
+    return dets, feature_fn
+
+
 def make_ground_truth(n_frames=100, n_obj=80, size=1280, seq_idx=0, **kw):
     """ground truth of the sequence make_detections(...) observes: per frame float64 (n, 7) `[id, x, y, w, h, cls, detected]`"""
     gt = []
