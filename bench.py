@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no_latency_mode", action="store_true")
     ap.add_argument("--seqs", type=int, default=1, help="sequences per GPU: the frames of a step are split over S independent sequences, each with its own "
                     "tracker and stream (their frame-step chains run side by side); default 1 = one sequence per GPU (the metric's configuration)")
+    ap.add_argument("--tracker_threads", type=int, default=0, help="threads of the tracker step workgroup (64 / 256 / 1024; 0 = the library's rule)")
     ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain); 2: the tracker chain's stream does")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
@@ -63,9 +64,12 @@ def parse():
     return ap.parse_args()
 
 
+TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (one wave up to 192 detections, 4 up to 384, 16 beyond)
+
+
 def make_opts():
     return types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5,
-                                 max_tracks=512, max_dets=512)
+                                 max_tracks=512, max_dets=512, tracker_threads=TRACKER_THREADS)
 
 
 def plant_objectness_bias(det, frames, target=2000):
@@ -337,7 +341,9 @@ def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
 
 
 def main():
+    global TRACKER_THREADS
     args = parse()
+    TRACKER_THREADS = args.tracker_threads
     cfg3, cfg4 = args.workload == "cfg3", args.workload == "cfg4"
     if args.n_obj is None:
         args.n_obj = 500 if cfg3 else 80

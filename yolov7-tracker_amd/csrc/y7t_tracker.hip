@@ -464,10 +464,11 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
 }
 
 static int step_threads(int threads, int n_hint = -1) {
-    // measured on MI355X (scripts/time_tracker.py): one wave wins for ~100-object scenes (no cross-wave barriers in the
-    // LAP reductions), four waves for crowded ones
-    // (round 2, sparse association: 500-object frames 971 us with four waves, 808 us with sixteen -- the cost pass is what is left)
-    if (threads == 0) return (n_hint >= 0 && n_hint <= 192) ? 64 : (n_hint > 384 ? 1024 : 256);
+    // measured on MI355X: four waves up to ~384 detections, sixteen beyond (500-object frames 971 us with four waves, 808 us with sixteen).  Round 1
+    // chose ONE wave for ~100-object scenes from stand-alone timings (no cross-wave barriers in the LAP reductions); inside the pipeline, where the step
+    // runs beside the detector's kernels, four waves hide the longer memory round trips: tracker chain 14.1 -> 12.1 ms per 32 frames on the same box
+    // (bench.py --tracker_threads 0 / 256, profiles/r02_bench_variants.txt), and stand-alone they are no slower any more (179 vs 186 us).
+    if (threads == 0) return (n_hint > 384) ? 1024 : 256;
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) return -1;
     return threads;
 }
