@@ -65,3 +65,109 @@ def test_preprocess_oracle_shapes():
     y = reid_torch.preprocess(frame, [[5, 7, 69, 135]])[0]
     want = ((frame[7:135, 5:69].astype(np.float32) / 255 - np.float32([0.485, 0.456, 0.406])) / np.float32([0.229, 0.224, 0.225])).transpose(2, 0, 1)
     np.testing.assert_allclose(y.numpy(), want, rtol=1e-6, atol=1e-6)
+
+
+def _interpret_fused_blob(blob, x):
+    """run OSNet x0_25 FROM the parameter blob of the fused kernel (tracker/reid.py::pack_fused), reading it in the kernel's consumption order
+    (csrc/y7t_reid_fused.hip) -- in float32 torch ops, so what is checked is the blob's content and layout, not the kernel's fp16 storage.
+    x: (N, 3, 128, 64) -> (N, 512)"""
+    import torch.nn.functional as F
+    buf = memoryview(blob.tobytes())
+    pos = [0]
+
+    def take(nbytes, dtype):
+        a = np.frombuffer(buf[pos[0]:pos[0] + nbytes], dtype=dtype)
+        pos[0] += nbytes
+        return a
+
+    def unfrag(ng, nk):
+        fr = take(ng * nk * 512, np.float16).reshape(ng, nk, 64, 4).astype(np.float32)
+        M = np.zeros((ng * 16, nk * 16), np.float32)
+        lane = np.arange(64)
+        for g in range(ng):
+            for k in range(nk):
+                for e in range(4):
+                    M[g * 16 + lane % 16, k * 16 + 4 * (lane // 16) + e] = fr[g, k, :, e]
+        return torch.from_numpy(M)
+
+    def f32(n):
+        return torch.from_numpy(take(4 * n, np.float32).copy())
+
+    def conv1x1(t, cout_p, cin_p, bias=True, relu=False):
+        W = unfrag(cout_p // 16, cin_p // 16)
+        b = f32(cout_p) if bias else None
+        y = F.conv2d(t, W[:, :, None, None], b)
+        return F.relu(y) if relu else y
+
+    # conv1 7x7: fragments [kh*2 + half][lane][e]: row lane % 16, input pixel kw = 4 * half + lane // 16, channel e
+    fr = take(14 * 512, np.float16).reshape(14, 64, 4).astype(np.float32)
+    W1 = np.zeros((16, 3, 7, 7), np.float32)
+    lane = np.arange(64)
+    for kh in range(7):
+        for h in range(2):
+            kw = 4 * h + lane // 16
+            for c in range(3):
+                ok = kw < 7
+                W1[(lane % 16)[ok], c, kh, kw[ok]] = fr[kh * 2 + h, ok, c]
+    t = F.relu(F.conv2d(x, torch.from_numpy(W1), f32(16), stride=2, padding=3))
+    t = F.max_pool2d(t, 3, 2, 1)
+
+    def block(t, cin, cout, midp, R):
+        x1_W = unfrag(midp // 16, cin // 16); x1_b = f32(midp)
+        w1 = f32(R * midp).reshape(R, midp); b1 = f32(4)[:R]; w2 = f32(R * midp).reshape(R, midp); b2 = f32(midp)
+        W3 = unfrag(cout // 16, midp // 16); b3 = f32(cout)
+        Wd = unfrag(cout // 16, cin // 16) if cin != cout else None
+        x1 = F.relu(F.conv2d(t, x1_W[:, :, None, None], x1_b))
+        x2 = 0
+        for n in (1, 2, 3, 4):
+            u = x1
+            for _ in range(n):
+                Wl = unfrag(midp // 16, midp // 16)
+                dw = f32(midp * 9).reshape(midp // 8, 9, 8).permute(0, 2, 1).reshape(midp, 1, 3, 3)
+                db = f32(midp)
+                u = F.relu(F.conv2d(F.conv2d(u, Wl[:, :, None, None]), dw, db, padding=1, groups=midp))
+            g = u.mean((2, 3))
+            g = torch.sigmoid(F.relu(g @ w1.T + b1) @ w2 + b2)
+            x2 = x2 + u * g[:, :, None, None]
+        y = F.conv2d(x2, W3[:, :, None, None], b3)
+        return F.relu(y + (F.conv2d(t, Wd[:, :, None, None]) if Wd is not None else t))
+
+    t = block(t, 16, 64, 16, 1); t = block(t, 64, 64, 16, 1)
+    t = F.avg_pool2d(conv1x1(t, 64, 64, relu=True), 2)
+    t = block(t, 64, 96, 32, 1); t = block(t, 96, 96, 32, 1)
+    t = F.avg_pool2d(conv1x1(t, 96, 96, relu=True), 2)
+    t = block(t, 96, 128, 32, 2); t = block(t, 128, 128, 32, 2)
+    t = conv1x1(t, 128, 128, relu=True)
+    v = t.mean((2, 3))
+    wt = torch.from_numpy(take(64 * 512 * 4, np.float16).reshape(64, 512, 2).astype(np.float32))      # [channel pair][output][2]
+    Wf = wt.permute(1, 0, 2).reshape(512, 128)
+    out = F.relu(v @ Wf.T + f32(512))
+    assert pos[0] == len(buf), "the kernel's walk and the blob's length disagree"
+    return out
+
+
+def test_fused_blob_encodes_the_network():
+    """tracker/reid.py::pack_fused (BatchNorm folded, MFMA fragment order, 24 -> 32 channel padding of stage 3, downsample bias merged into conv3's)
+    read back in the order csrc/y7t_reid_fused.hip consumes it == the oracle network, up to the fp16 rounding of the stored weights"""
+    spec = reid.osnet_spec(0.25)
+    sd = reid.random_state_dict(spec, 5)
+    blob = reid.pack_fused(sd, spec)
+    x = torch.randn((3, 3, 128, 64), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        got = _interpret_fused_blob(blob, x)
+        want = reid_torch.osnet_forward(sd, x)
+    assert got.shape == want.shape == (3, 512) and float(want.abs().mean()) > 0.05
+    assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
+def test_identity_feature_scene_is_deterministic():
+    """synth.make_identity_features (the scenes of the deepsort_identity* goldens): same arguments -> same detections and the same feature per box"""
+    from yolov7_tracker_amd import synth
+    d1, f1 = synth.make_identity_features(12, 30, 640, seq_idx=3, dim=64, miss=0.2)
+    d2, f2 = synth.make_identity_features(12, 30, 640, seq_idx=3, dim=64, miss=0.2)
+    assert all(np.array_equal(a, b) for a, b in zip(d1, d2))
+    for d in d1:
+        a, b = f1(d[:, :4]), f2(d[:, :4])
+        assert a.shape == (len(d), 64) and np.array_equal(a, b)
+        if len(d):
+            np.testing.assert_allclose(np.linalg.norm(a, axis=1), 1.0, rtol=1e-5)
