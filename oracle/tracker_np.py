@@ -139,6 +139,7 @@ class TrackerNP:
                  frame_rate=30, ids=None):
         assert kind in ("sort", "bytetrack", "botsort", "deepsort")
         self.feature_fn = None            # deepsort: (N, 4) tlbr -> (N, D) appearance features (stands in for the ReID network)
+        self.dot = np.dot                 # cal_cosine_distance's product (matching.py:178)
         self.kind, self.fmt = kind, kalman_format
         self.det_thresh = conf_thresh
         self.iou_thresh = iou_thresh
@@ -233,12 +234,12 @@ class TrackerNP:
             tr.mean, tr.cov = m, R8.dot(tr.cov).dot(R8.transpose())
 
     # --- DeepSORT (deepsort.py:43-224) ---------------------------------------------
-    @staticmethod
-    def _cos(a, b):
-        """matching.py:165-178"""
+    def _cos(self, a, b):
+        """matching.py:165-178.  `self.dot` is np.dot like the reference; a test may set it to `dot_sequential` to pin the summation order
+        (numpy's BLAS picks one by operand shape and CPU -- see that function)"""
         a = a / np.linalg.norm(a, axis=1, keepdims=True)
         b = b / np.linalg.norm(b, axis=1, keepdims=True)
-        return np.dot(a, b.T)
+        return self.dot(a, b.T)
 
     def _gated_metric(self, tracks, dets):
         """nearest_embedding_distance (matching.py:105-127) + gate_cost_matrix (deepsort.py:43-66)"""
@@ -371,10 +372,24 @@ class TrackerNP:
         return self._finish([], [], [], [])
 
 
-def run(kind, dets_per_frame, ids=None, warps=None, feature_fn=None, **kw):
+def dot_sequential(a, bt):
+    """float32 a @ bt with every product ONE fused-multiply-add chain over k = 0 .. K-1 -- the order OpenBLAS's blocked sgemm kernel uses for
+    operands of more than a few rows with K <= one panel, and the order the device kernels use for every shape.  np.dot itself switches order with
+    the operand shapes (gemv / sdot for one-row operands, a small-matrix kernel, K panels beyond 384) and with the CPU the wheel dispatches on, so
+    the last bit of a cosine distance is not a property of the reference; tests that need the cascade's near-ties (costs one ulp apart) decided
+    the same way on both sides pin the order with this function.  (float64 product of two float32 is exact; the one rounding is the fma's)"""
+    acc = np.zeros((a.shape[0], bt.shape[1]), np.float32)
+    for k in range(a.shape[1]):
+        acc = (a[:, k:k + 1].astype(np.float64) * bt[k][None, :].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+    return acc
+
+
+def run(kind, dets_per_frame, ids=None, warps=None, feature_fn=None, dot=None, **kw):
     """-> per-frame list of (track_id, tlwh float64[4], cls, score), like ref_harness.run_reference_tracker."""
     trk = TrackerNP(kind, ids=ids if ids is not None else IdCounter(), **kw)
     trk.feature_fn = feature_fn
+    if dot is not None:
+        trk.dot = dot
     out = []
     for fi, det in enumerate(dets_per_frame):
         cur = trk.update_without_detection() if det is None else trk.update(det, None if warps is None else warps[fi])

@@ -35,6 +35,7 @@ def lib():
         L.hs_tracker_status.argtypes = [ctypes.c_void_p]
         L.hs_lapjv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_lapsap.argtypes = L.hs_lapjv.argtypes
+        L.hs_laplit.argtypes = L.hs_lapjv.argtypes
         L.hs_iou_cost.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.hs_kf_initiate.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_kf_predict.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -62,14 +63,15 @@ def pyset_difference(n, matched):
     return out[:c].tolist()
 
 
-def lapjv(cost, limit, sap=False):
-    """JV on lap's implicit extended matrix (sap=False) or the reduced shortest-augmenting-path solver (sap=True)"""
+def lapjv(cost, limit, sap=False, literal=False):
+    """JV on lap's implicit extended matrix (sap=False), the reduced shortest-augmenting-path solver with its tie fallback (sap=True), or
+    lapjv.cpp run literally (literal=True)"""
     cost = np.ascontiguousarray(cost, dtype=np.float64)
     nr, nc = cost.shape
     x = np.empty(max(nr, 1), np.int32)
     y = np.empty(max(nc, 1), np.int32)
     if nr and nc:
-        (lib().hs_lapsap if sap else lib().hs_lapjv)(cost.ctypes.data, nr, nc, float(limit), x.ctypes.data, y.ctypes.data)
+        (lib().hs_laplit if literal else lib().hs_lapsap if sap else lib().hs_lapjv)(cost.ctypes.data, nr, nc, float(limit), x.ctypes.data, y.ctypes.data)
     else:
         x[:] = -1
         y[:] = -1

@@ -58,6 +58,17 @@ void hs_lapsap(const double* cost, int nr, int nc, double limit, int* x, int* y)
     free(ws);
 }
 
+void hs_laplit(const double* cost, int nr, int nc, double limit, int* x, int* y) {      // lapjv.cpp run literally (the re-solve of problems with ties)
+    Y7TLap L;
+    L.c = cost; L.nr = nr; L.nc = nc; L.ld = nc; L.n = nr + nc; L.half = limit / 2.0; L.prof = nullptr;
+    void* ws = malloc(y7t_lap_ws_bytes(L.n + 1) + 64);
+    y7t_lap_bind(L, ws, L.n + 1);
+    y7t_lap_solve_literal(hs_ex(), L);
+    for (int i = 0; i < nr; ++i) x[i] = L.x[i] >= nc ? -1 : L.x[i];
+    for (int j = 0; j < nc; ++j) y[j] = L.y[j] >= nr ? -1 : L.y[j];
+    free(ws);
+}
+
 void hs_iou_cost(const double* a, int n, const double* b, int m, double* cost) {
     for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) cost[(size_t)i * m + j] = y7t_iou_dist(a + 4 * i, b + 4 * j);
 }

@@ -109,6 +109,36 @@ def test_hostsim_sort_scenes_with_assignment_ties(seed, scene):
     util.assert_same_tracks(hs.run("sort", dets, kalman_format="default"), tracker_np.run("sort", dets, kalman_format="default"), "seed %d scene %d" % (seed, scene))
 
 
+@pytest.mark.parametrize("seeds", [(20, 50, 62, 76), tuple(range(0, 6)), tuple(range(6, 12))])
+def test_hostsim_deepsort_equals_oracle_on_random_scenes(seeds):
+    """random scenes through DeepSORT (util.random_deepsort_scene): device program == oracle on every id and box.  Box-size features make many
+    appearance vectors equal or nearly so, and then the cascade is decided by (a) which of several optimal assignments lapjv returns -- the step
+    notices duplicate candidate costs and runs lapjv.cpp literally (seeds 20, 62) -- and (b) the last bit of a cosine distance, which in numpy
+    depends on the summation order the BLAS picks for the operands' shape; the oracle is run with the order pinned (tracker_np.dot_sequential, the
+    order the kernels use; seeds 20, 50, 62, 76 differ from np.dot's own answer on this machine by exactly such one-ulp near-ties).  The goldens
+    above, recorded from the live reference, hold with np.dot as it is."""
+    from oracle import tracker_np
+    for seed in seeds:
+        dets, fn, dim = util.random_deepsort_scene(seed)
+        want = tracker_np.run("deepsort", dets, feature_fn=fn, dot=tracker_np.dot_sequential)
+        util.assert_same_tracks(hs.run("deepsort", dets, feature_fn=fn, feat_dim=dim), want, "seed %d (dim %d)" % (seed, dim))
+
+
+def test_oracle_dot_sequential_is_the_blocked_sgemm_order():
+    """for the shapes where OpenBLAS runs its blocked kernel on one K panel (tens of stored rows x tens of detections, K <= 128) np.dot IS the
+    sequential chain -- which is why the reference-recorded goldens agree bit for bit; elsewhere the two differ by an ulp or two, never more"""
+    from oracle import tracker_np
+    rng = np.random.default_rng(0)
+    for k, n, dim, same in ((100, 60, 128, True), (64, 40, 32, True), (1, 40, 128, False), (100, 60, 512, False)):
+        a, b = rng.standard_normal((k, dim)).astype(np.float32), rng.standard_normal((n, dim)).astype(np.float32)
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        x, y = np.dot(a, b.T), tracker_np.dot_sequential(a, b.T)
+        assert np.abs(x - y).max() <= 4 * np.finfo(np.float32).eps, (k, n, dim)
+        if same and not np.array_equal(x, y):
+            pytest.skip("this machine's BLAS uses another order for (%d, %d, %d)" % (k, n, dim))
+
+
 def test_hostsim_kalman_matches_reference_golden():
     kal = np.load(util.GOLDEN + "/kalman.npz")
     L = hs.lib()

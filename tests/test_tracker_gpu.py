@@ -421,6 +421,26 @@ def test_device_sort_scenes_with_assignment_ties(seed, scene):
     util.assert_same_tracks(got, tracker_np.run("sort", dets, kalman_format="default"), "seed %d scene %d" % (seed, scene))
 
 
+@pytest.mark.parametrize("seed", [20, 62, 76, 3, 4])
+def test_device_deepsort_equals_oracle_on_random_scenes(seed):
+    """random DeepSORT scenes on the device against the oracle with the product's summation order pinned (see tests/test_hostsim.py,
+    test_hostsim_deepsort_equals_oracle_on_random_scenes): seeds 20 and 62 hold rows with two candidate detections of exactly equal appearance cost
+    (the step re-solves those with lapjv.cpp run literally), 76 is 512 wide, 3 and 4 are ordinary"""
+    import types
+    from oracle import tracker_np
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    dets, fn, dim = util.random_deepsort_scene(seed)
+    BaseTrack._count = 0
+    t = DeepSORT(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=640, iou_thresh=0.5))
+    t.get_feature = lambda tlbrs, img: fn(tlbrs)
+    got = []
+    for d in dets:
+        cur = t.update_without_detection() if d is None else t.update(d, None)
+        got.append([(c.track_id, c.tlwh, float(c.cls), float(c.score)) for c in cur])
+    util.assert_same_tracks(got, tracker_np.run("deepsort", dets, feature_fn=fn, dot=tracker_np.dot_sequential), "seed %d (dim %d)" % (seed, dim))
+
+
 def test_lapjv_device_500x500_optimal():
     """BASELINE config 3 size: properties instead of the O(n^3) oracle -- valid partial matching, every kept cost
     below the limit, total cost equal to scipy's optimum of the explicit extended problem."""

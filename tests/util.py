@@ -124,3 +124,21 @@ def random_scene(seed, scene_index, kind="sort"):
     if scene_index % 4 == 3:
         dets[n_frames // 2] = np.zeros((0, 6), np.float32)
     return dets
+
+
+def random_deepsort_scene(seed):
+    """-> (dets per frame, feature_fn, dim): 5..90 objects, 15..45 frames, random miss / clutter rates, feature dimension and frame gaps; even seeds
+    use box-size features (many near-identical vectors: appearance ties and near-ties), odd seeds identity features with noise"""
+    from yolov7_tracker_amd import synth
+    rng = np.random.default_rng(seed)
+    n_obj, n_frames = int(rng.integers(5, 90)), int(rng.integers(15, 45))
+    miss, fp, dim = float(rng.uniform(0.0, 0.35)), float(rng.uniform(0.0, 0.2)), int(rng.choice([32, 100, 128, 512]))
+    if seed % 2:
+        dets, fn = synth.make_identity_features(n_frames, n_obj, 640, seq_idx=300 + seed, dim=dim, miss=miss, fp=fp, noise=float(rng.uniform(0.05, 0.5)))
+    else:
+        dets = synth.make_detections(n_frames, n_obj, 640, seq_idx=300 + seed, miss=miss, fp=fp)
+        fn = lambda b, _d=dim: synth.make_features(b, dim=_d)
+    gap = int(rng.integers(0, 9))
+    if gap > 2:
+        dets = [None if (i % gap == gap - 1) else d for i, d in enumerate(dets)]
+    return dets, fn, dim

@@ -350,7 +350,7 @@ Y7T_FN void y7t_ds_append_features(const Y7TExec& ex, const Y7TTrk& s, const Y7T
 }
 
 // linear_assignment(cost, thresh) on a cost matrix already in s.cost (na x nb, row stride nb) -> s.xrow / s.ycol
-Y7T_FN void y7t_assign_on_cost(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+Y7T_FN void y7t_assign_on_cost(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, bool literal = false) {
     Y7TLap L;
     L.nr = na; L.nc = nb; L.ld = nb; L.n = na + nb; L.half = thresh / 2.0; L.prof = nullptr;
     const size_t ws = y7t_al(y7t_lap_ws_bytes(L.n));
@@ -358,7 +358,7 @@ Y7T_FN void y7t_assign_on_cost(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     if (ex.fast && ws <= ex.fast_bytes) lapws = ex.fast;
     L.c = s.cost;
     y7t_lap_bind(L, lapws, L.n);
-    if (y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
+    if (literal || y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
     for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
     for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];
     y7t_sync(ex);
@@ -439,7 +439,11 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     // columns level L could use anyway: the candidate graph of the joint problem is the disjoint union of the levels' graphs, the solver works per
     // connected component, and rows / columns keep their relative order -- same matches, one set of passes instead of one per age. ----
     bool joint_done = false;
+#ifdef Y7T_NO_JOINT      // (experiments: the level-by-level cascade only)
+    if (false) {
+#else
     if (cfg.max_time_lost <= 64 && (lvl_mask & (lvl_mask - 1)) != 0 && n_to > 0) {
+#endif
         const int n_rows = y7t_compact(ex, n_pool, [&](int i) { const int a = s.tsu[s.pool[i]] - 1; return a >= 0 && a < cfg.max_time_lost; }, s.rem, 0);
         for (int r = ex.tid; r < n_rows; r += ex.nt) s.tmpb[r] = s.pool[s.rem[r]];
         for (int c = ex.tid; c < n_hi; c += ex.nt) s.left[c] = s.dhi[c];
@@ -453,7 +457,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
 #if Y7T_DEVICE
         if (ex.tid == 0) { h->prof[27] += 1; if (mixed) h->prof[28] += 1; }      // diagnostics: frames with several ages / with a contested detection
 #endif
-        if (!mixed && y7t_assoc_sparse_fn(ex, s, n_rows, n_hi, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); })) {
+        if (!mixed && y7t_assoc_sparse_fn(ex, s, n_rows, n_hi, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); }) == 1) {
             // the cascade's match order: by age, inside an age by row
             const int nm2 = y7t_compact(ex, n_rows, [&](int r) { return s.xrow[r] >= 0; }, s.tmpa, 0);
             int* age = f.tmpd;
@@ -487,7 +491,8 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         for (int c = ex.tid; c < n_to; c += ex.nt) s.left[c] = s.dhi[f.tomatch[c]];           // detection row of every column
         y7t_sync(ex);
         // linear_assignment(cost, 0.9): entries above the limit can never be matched, so the candidate-list solver sees the same problem
-        if (y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); })) {      // (also for the small levels: a handful of candidates, no dense matrix to fill)
+        const int sp = y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r, int, int dj) { return gated_at(s.tmpb[r], dj); });
+        if (sp == 1) {      // (also for the small levels: a handful of candidates, no dense matrix to fill)
             Y7T_CPROF(17);
         } else {
         const int tot = n_tl * n_to;
@@ -497,7 +502,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         }
         y7t_sync(ex);
         Y7T_CPROF(17);
-        y7t_assign_on_cost(ex, s, n_tl, n_to, 0.9);
+        y7t_assign_on_cost(ex, s, n_tl, n_to, 0.9, sp == 2);
         }
         Y7T_CPROF(18);
         const int nmatch = y7t_compact(ex, n_tl, [&](int r) { return s.xrow[r] >= 0; }, s.tmpa, 0);

@@ -182,9 +182,15 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 struct Y7TBox4 { double v[4]; };
 
 // colctx(j): whatever of column j the cost needs (loaded once per lane, outside the row loop); cost(i, j, ctx) -> double
+// Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
+// connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
+// caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
 template <class ColFn, class CostFn>
-Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
+Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
     const int tid = ex.tid, nt = ex.nt;
+#ifdef Y7T_ALWAYS_LITERAL
+    return 2;
+#endif
 #if Y7T_DEVICE
 #define Y7T_SPROF(i) do { if (thresh == 0.9 && tid == 0) s.h->prof[16 + (i)] = clock64(); } while (0)
 #else
@@ -204,7 +210,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         wbase = ex.fast;
         lbase = (work_bytes + 64 + list_bytes <= ex.fast_bytes) ? ex.fast + ((work_bytes + 63) & ~(size_t)63) : (char*)s.cost;
     }
-    if (((work_bytes + 63) & ~(size_t)63) + list_bytes > blob_bytes) return false;
+    if (((work_bytes + 63) & ~(size_t)63) + list_bytes > blob_bytes) return 0;
     double* v = (double*)wbase;                               // [nb] column prices
     double* dd = v + nb;                                      // [nb] tentative distances
     int* rowcnt = (int*)(dd + nb + 2);                        // [na]
@@ -217,12 +223,12 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [2] overflow, changed
+    int* flag = nextcol + nb;                                 // [3] overflow / at-limit pair, changed, duplicate cost inside a component
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * Y7T_MAXC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; }
     y7t_sync(ex);
     // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix) ----
     {
@@ -245,7 +251,7 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     }
     y7t_sync(ex);
     Y7T_SPROF(1);
-    if (flag[0]) return false;
+    if (flag[0]) return 0;
     for (int i = tid; i < na; i += nt) {                      // sort each row's candidates by column (insertion sort, <= MAXC entries)
         int* cc = ccol + (size_t)i * Y7T_MAXC;
         double* cw = ccost + (size_t)i * Y7T_MAXC;
@@ -256,6 +262,8 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             while (b >= 0 && cc[b] > cj) { cc[b + 1] = cc[b]; cw[b + 1] = cw[b]; --b; }
             cc[b + 1] = cj; cw[b + 1] = cv;
         }
+        for (int a = 1; a < n; ++a)                           // tie watch: one row equally far from two columns (identical boxes / appearance vectors)
+            for (int b = 0; b < a; ++b) if (cw[a] == cw[b]) { flag[2] = 1; Y7T_TIE_REASON(6); }
     }
     y7t_sync(ex);
     Y7T_SPROF(2);
@@ -291,6 +299,21 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // ---- 4. one lane per component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
     for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
+        {   // tie watch: two candidate edges of this component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
+            int crow[8], ncr = 0;
+            for (int a = lead; a < na && ncr < 9; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
+            if (ncr <= 8) {
+                bool dup = false;
+                for (int ia = 0; ia < ncr && !dup; ++ia)
+                    for (int pq = 0; pq < rowcnt[crow[ia]] && !dup; ++pq) {
+                        const double ca = ccost[(size_t)crow[ia] * Y7T_MAXC + pq];
+                        for (int q = pq + 1; q < rowcnt[crow[ia]]; ++q) dup |= (ccost[(size_t)crow[ia] * Y7T_MAXC + q] == ca);
+                        for (int ib = ia + 1; ib < ncr; ++ib)
+                            for (int q = 0; q < rowcnt[crow[ib]]; ++q) dup |= (ccost[(size_t)crow[ib] * Y7T_MAXC + q] == ca);
+                    }
+                if (dup) { flag[2] = 1; Y7T_TIE_REASON(5); }
+            }
+        }
         for (int start = lead; start < na; ++start) {
             if (rowlab[start] != lead || x[start] != -1) continue;
             // Dijkstra from `start`; the null column lives in registers (every component has its own)
@@ -338,14 +361,15 @@ Y7T_FN bool y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     }
     y7t_sync(ex);
     Y7T_SPROF(5);
+    if (flag[2]) return 2;
     for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
     for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
     y7t_sync(ex);
-    return true;
+    return 1;
 }
 
 // the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
-Y7T_FN bool y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
                                [&](int j) { return Y7TBox4{{s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]}}; },
                                [&](int i, int, const Y7TBox4& q) { return y7t_iou_dist(s.ttlbr + 4 * i, q.v); });
@@ -362,7 +386,8 @@ Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double
         y7t_sync(ex);
         return;
     }
-    if ((long long)na * nb >= Y7T_SPARSE_MIN && y7t_assoc_sparse(ex, s, na, nb, thresh)) return;
+    int sp = 0;
+    if ((long long)na * nb >= Y7T_SPARSE_MIN && (sp = y7t_assoc_sparse(ex, s, na, nb, thresh)) == 1) return;
     Y7TLap L;
     L.nr = na; L.nc = nb; L.ld = nb; L.n = na + nb; L.half = thresh / 2.0;
     L.prof = (thresh == 0.9) ? s.h->prof + 16 : nullptr;   // stamp the first association
@@ -380,7 +405,7 @@ Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double
 #ifdef Y7T_ASSOC_JV       // experiments: lapjv's own algorithm on the implicit extended matrix (also what the SAP solver is checked against)
     y7t_lap_solve(ex, L);
 #else
-    if (y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
+    if (sp == 2 || y7t_lap_solve_sap(ex, L)) y7t_lap_solve_literal(ex, L);      // ties: lapjv's own order decides
 #endif
     if (L.prof && ex.tid == 0) L.prof[10] = clock64();
     for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = (L.x[i] >= nb) ? -1 : L.x[i];
