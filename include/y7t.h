@@ -238,7 +238,7 @@ int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const i
  * geometry on the float image), Normalize(mean, std) in the frame's channel order -> the network in eval mode -> (N, feat_dim) float32.
  * Like the detector, the network is a host-lowered op list (BatchNorm folded, fp32 weights in one blob) over a caller-owned arena. */
 enum { Y7T_REID_CONV = 0, Y7T_REID_DWCONV3 = 1, Y7T_REID_MAXPOOL3S2 = 2, Y7T_REID_AVGPOOL2 = 3, Y7T_REID_GATE_ACC = 4, Y7T_REID_ADD_RELU = 5,
-       Y7T_REID_GAP = 6, Y7T_REID_FC = 7 };
+       Y7T_REID_GAP = 6, Y7T_REID_FC = 7, Y7T_REID_L2NORM = 8 /* x / |x| per crop: Net.forward with reid=True, reid_models/deepsort_reid.py:104 */ };
 typedef struct y7t_reid_op {
     int32_t type;
     int32_t in_buf, out_buf, aux_buf;   /* arena buffers; aux: second addend (ADD_RELU), pooled + gate scratch (GATE_ACC), -1 otherwise */
@@ -246,7 +246,7 @@ typedef struct y7t_reid_op {
     int32_t Ho, Wo, Co;                 /* output map and channels (CONV, pools, FC) */
     int32_t k, s, p;                    /* CONV window */
     int32_t relu;                       /* CONV / DWCONV3 / FC: ReLU after the bias; GATE_ACC: 1 = first branch (overwrite the accumulator) */
-    int32_t R, pad0;                    /* GATE_ACC: hidden width of the gate MLP (C / 16) */
+    int32_t R, w_kmajor;                /* GATE_ACC: hidden width of the gate MLP (C / 16); CONV: 1 = weights stored (kh, kw, ci, co) instead of (co, kh, kw, ci) */
     int64_t w_off, b_off;               /* float offsets into the weight blob (b_off < 0: no bias); GATE_ACC: fc1 weight / bias */
     int64_t w2_off, b2_off;             /* GATE_ACC: fc2 weight / bias */
 } y7t_reid_op;                          /* sizeof == 96 */

@@ -8,6 +8,10 @@ Plain-PyTorch fp32 CPU restatement of the reference's ReID path, the oracle of c
                                     (/255, cv2.resize INTER_LINEAR on the float image -- PARITY UNPINNED for cv2 itself: geometry restated
                                     in float32 --, ToTensor, Normalize in the frame's channel order)
 
+  * DeepSORT's own embedding network  /root/reference/tracker/reid_models/deepsort_reid.py:14-110 (BasicBlock, make_layers, Net with reid=True:
+                                    conv 3x3 + BN + ReLU + MaxPool(3, 2, 1), four stages of two residual blocks 64/128/256/512, AvgPool (8, 4), x / |x|)
+                                    on the `net_dict` state dict of its checkpoint (weights/ckpt.t7, which the reference does not ship)
+
 It works on the same torchreid-style state dict as the product and is pinned against the reference's own OSNet class (random weights and
 weights/osnet_x0_25.pth) in tests/test_reid_oracle.py where /root/reference exists."""
 import numpy as np
@@ -71,6 +75,27 @@ def osnet_forward(sd, x, layers=(2, 2, 2)):
     v = F.linear(v, sd["fc.0.weight"], sd["fc.0.bias"])
     v = F.batch_norm(v, sd["fc.1.running_mean"], sd["fc.1.running_var"], sd["fc.1.weight"], sd["fc.1.bias"], False, 0.0, EPS)
     return F.relu(v)
+
+
+def _basic_block(x, sd, name, stride):
+    """deepsort_reid.py:14-49"""
+    y = F.relu(_bn(F.conv2d(x, sd[name + ".conv1.weight"], None, stride, 1), sd, name + ".bn1"))
+    y = _bn(F.conv2d(y, sd[name + ".conv2.weight"], None, 1, 1), sd, name + ".bn2")
+    if name + ".downsample.0.weight" in sd:
+        x = _bn(F.conv2d(x, sd[name + ".downsample.0.weight"], None, stride), sd, name + ".downsample.1")
+    return F.relu(x.add(y))
+
+
+def deepsort_net_forward(sd, x):
+    """Net.forward with reid=True in eval mode (deepsort_reid.py:62-110): (N, 3, 128, 64) -> (N, 512) unit vectors"""
+    x = F.relu(_bn(F.conv2d(x, sd["conv.0.weight"], sd["conv.0.bias"], 1, 1), sd, "conv.1"))
+    x = F.max_pool2d(x, 3, 2, padding=1)
+    for li, down in ((1, False), (2, True), (3, True), (4, True)):
+        for bi in range(2):
+            x = _basic_block(x, sd, "layer%d.%d" % (li, bi), 2 if (down and bi == 0) else 1)
+    x = F.avg_pool2d(x, (8, 4), 1)
+    x = x.view(x.size(0), -1)
+    return x.div(x.norm(p=2, dim=1, keepdim=True))
 
 
 def resize_linear_f32(img, new_h, new_w):

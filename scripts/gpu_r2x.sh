@@ -1,6 +1,17 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" || exit 1
-O=$PWD/gpurun_out/r2x; mkdir -p $O
-timeout 40 python scripts/dbg_botsort.py botsort_gmc 2>&1 | tail -3
-timeout 300 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -n 3 $O/tests.log
-timeout 200 python scripts/time_tracker.py 2>&1 | grep "threads=256"
+# round 2: the reference's DeepSORT embedding network on the device op list + the OSNet op-list tests that share its kernels
+mkdir -p gpurun_out/r2x
+timeout 200 python -m pytest tests/test_reid_gpu.py -x -q -m gpu > gpurun_out/r2x/tests.log 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r2x/tests.log
+tail -15 gpurun_out/r2x/tests.log
+timeout 100 python - > gpurun_out/r2x/time_deepsort_net.txt 2>&1 <<'PY'
+import time, torch
+from yolov7_tracker_amd.tracker import reid
+e = reid.ReIDExtractor(None, arch="deepsort", max_crops=80)
+x = torch.randn((80, 128, 64, 3), device="cuda")
+for _ in range(2): e.forward_crops(x)
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(3): e.forward_crops(x)
+torch.cuda.synchronize(); dt = (time.time() - t0) / 3
+print("deepsort_reid.Net, fp32 op list: 80 crops %.1f ms (%.2f TFLOP/s of 2.2 GFLOP per crop)" % (dt * 1e3, 80 * 2.2e9 / dt / 1e12))
+PY
+cat gpurun_out/r2x/time_deepsort_net.txt | tail -3

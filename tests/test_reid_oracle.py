@@ -38,6 +38,116 @@ def test_oracle_equals_reference_osnet(have_reference):
     assert torch.equal(reid_torch.osnet_forward(real, x), want) and float(want.abs().mean()) > 0.1
 
 
+def _reference_deepsort_net():
+    """the reference's Net class (reid_models/deepsort_reid.py); the module imports cv2 / torchvision for its Extractor, absent here: stubbed"""
+    import sys
+    import types
+    stubs = {}
+    for name in ("cv2", "torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            stubs[name] = sys.modules[name] = types.ModuleType(name)
+    if "torchvision" in stubs:
+        stubs["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    try:
+        spec = importlib.util.spec_from_file_location("ref_deepsort_reid", os.path.join(REF, "tracker/reid_models/deepsort_reid.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for name in stubs:
+            del sys.modules[name]
+    return m.Net(reid=True).eval()
+
+
+def test_oracle_equals_reference_deepsort_net(have_reference):
+    """oracle/reid_torch.py::deepsort_net_forward == the reference's own Net(reid=True) on the same `net_dict`, bit for bit"""
+    if not have_reference:
+        pytest.skip("/root/reference not present")
+    net = _reference_deepsort_net()
+    sd = reid.deepsort_net_random_state_dict(2)
+    r = net.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.startswith("classifier") or k.endswith("num_batches_tracked") for k in r.missing_keys)
+    x = torch.randn((3, 3, 128, 64), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = net(x)
+    got = reid_torch.deepsort_net_forward(sd, x)
+    assert tuple(want.shape) == (3, 512) and torch.equal(got, want)
+    np.testing.assert_allclose(got.norm(dim=1).numpy(), 1.0, rtol=1e-6)
+
+
+def _interpret_ops(ops, bufs, w, x):
+    """run an op list of tracker/reid.py (include/y7t.h: y7t_reid_op) in float32 torch ops with the semantics of csrc/y7t_reid.hip's kernels --
+    checks the host lowering (BatchNorm folding, weight layouts, buffer wiring) on the CPU.  x: (N, 3, H, W) -> (N, feat)"""
+    import torch.nn.functional as F
+    w = torch.from_numpy(np.asarray(w))
+    N = x.shape[0]
+    val = {0: x.permute(0, 2, 3, 1).contiguous()}            # NHWC like the arena
+    for o in ops:
+        t, H, W, C, Ho, Wo, Co, k = (int(o[f]) for f in ("type", "H", "W", "C", "Ho", "Wo", "Co", "k"))
+        xin = val[int(o["in_buf"])]
+        nchw = lambda a, h, ww, c: a.reshape(N, h, ww, c).permute(0, 3, 1, 2)
+        bias = w[int(o["b_off"]):int(o["b_off"]) + Co] if int(o["b_off"]) >= 0 else None
+        if t == reid.CONV:
+            wt = w[int(o["w_off"]):int(o["w_off"]) + Co * k * k * C]
+            wt = wt.reshape(k, k, C, Co).permute(3, 2, 0, 1) if int(o["w_kmajor"]) else wt.reshape(Co, k, k, C).permute(0, 3, 1, 2)
+            y = F.conv2d(nchw(xin, H, W, C), wt, bias, int(o["s"]), int(o["p"]))
+            y = F.relu(y) if int(o["relu"]) else y
+        elif t == reid.DWCONV3:
+            wt = w[int(o["w_off"]):int(o["w_off"]) + C * 9].reshape(C, 1, 3, 3)
+            y = F.conv2d(nchw(xin, H, W, C), wt, w[int(o["b_off"]):int(o["b_off"]) + C], 1, 1, groups=C)
+            y = F.relu(y) if int(o["relu"]) else y
+        elif t == reid.MAXPOOL3S2:
+            y = F.max_pool2d(nchw(xin, H, W, C), 3, 2, padding=1)
+        elif t == reid.AVGPOOL2:
+            y = F.avg_pool2d(nchw(xin, H, W, C), 2)
+        elif t == reid.GATE_ACC:
+            R = int(o["R"])
+            a = nchw(xin, H, W, C)
+            w1 = w[int(o["w_off"]):int(o["w_off"]) + R * C].reshape(R, C)
+            b1 = w[int(o["b_off"]):int(o["b_off"]) + R]
+            w2 = w[int(o["w2_off"]):int(o["w2_off"]) + C * R].reshape(C, R)
+            b2 = w[int(o["b2_off"]):int(o["b2_off"]) + C]
+            g = torch.sigmoid(F.relu(a.mean((2, 3)) @ w1.T + b1) @ w2.T + b2)
+            y = a * g[:, :, None, None]
+            if not int(o["relu"]):                               # relu == 1 marks the first branch (overwrite)
+                y = y + val[int(o["out_buf"])].permute(0, 3, 1, 2)
+        elif t == reid.ADD_RELU:
+            y = F.relu(nchw(xin, H, W, C) + nchw(val[int(o["aux_buf"])], H, W, C))
+        elif t == reid.GAP:
+            val[int(o["out_buf"])] = nchw(xin, H, W, C).mean((2, 3))
+            continue
+        elif t == reid.FC:
+            y = xin.reshape(N, C) @ w[int(o["w_off"]):int(o["w_off"]) + Co * C].reshape(Co, C).T + bias
+            val[int(o["out_buf"])] = F.relu(y) if int(o["relu"]) else y
+            continue
+        elif t == reid.L2NORM:
+            v = xin.reshape(N, C)
+            val[int(o["out_buf"])] = v / v.norm(dim=1, keepdim=True)
+            continue
+        else:
+            raise AssertionError(t)
+        assert int(bufs[int(o["out_buf"])]) == y.shape[1] * y.shape[2] * y.shape[3]
+        val[int(o["out_buf"])] = y.permute(0, 2, 3, 1).contiguous()
+    return val[int(ops[-1]["out_buf"])]
+
+
+def test_op_lists_encode_their_networks():
+    """both lowerings -- OSNet x0_25 and the reference's DeepSORT Net -- interpreted on the CPU equal the oracle networks (fp32, BatchNorm folded:
+    1e-4 of the output scale)"""
+    x = torch.randn((2, 3, 128, 64), generator=torch.Generator().manual_seed(4))
+    spec = reid.osnet_spec(0.25)
+    sd = reid.random_state_dict(spec, 5)
+    got, want = _interpret_ops(*reid.lower(sd, spec), x), reid_torch.osnet_forward(sd, x)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    sd = reid.deepsort_net_random_state_dict(6)
+    ops, bufs, w = reid.lower_deepsort_net(sd)
+    got, want = _interpret_ops(ops, bufs, w, x), reid_torch.deepsort_net_forward(sd, x)
+    assert tuple(got.shape) == (2, 512) and float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert w.size == sum(v.numel() for k, v in sd.items() if k.endswith(".weight") and v.dim() == 4) + sum(v.numel() for k, v in sd.items() if k.endswith("running_mean"))
+    assert int(ops[-1]["type"]) == reid.L2NORM and sum(int(o["type"]) == reid.ADD_RELU for o in ops) == 8
+    with pytest.raises(ValueError):
+        reid.lower_deepsort_net(sd, 256, 128)
+
+
 def test_lowering_covers_every_parameter():
     spec = reid.osnet_spec(0.25)
     sd = reid.random_state_dict(spec, 0)

@@ -16,7 +16,7 @@
 
 static_assert(sizeof(y7t_reid_op) == 96, "y7t_reid_op layout must match tracker/reid.py OP_DTYPE");
 
-enum { R_CONV = 0, R_DWCONV3 = 1, R_MAXPOOL3S2 = 2, R_AVGPOOL2 = 3, R_GATE_ACC = 4, R_ADD_RELU = 5, R_GAP = 6, R_FC = 7 };
+enum { R_CONV = 0, R_DWCONV3 = 1, R_MAXPOOL3S2 = 2, R_AVGPOOL2 = 3, R_GATE_ACC = 4, R_ADD_RELU = 5, R_GAP = 6, R_FC = 7, R_L2NORM = 8 };
 
 struct y7t_reid {
     std::vector<y7t_reid_op> ops;
@@ -59,14 +59,15 @@ __global__ void __launch_bounds__(256) k_reid_crop(const uint8_t* __restrict__ f
 // dense conv k x k, stride s, padding p, + bias (folded BN) + optional ReLU; weights [co][kh][kw][ci]; NHWC fp32
 __global__ void __launch_bounds__(256) k_reid_conv(const float* __restrict__ in, int N, int H, int W, int Ci, const float* __restrict__ w,
                                                    const float* __restrict__ bias, int k, int s, int p, int Ho, int Wo, int Co, int relu,
-                                                   float* __restrict__ out) {
+                                                   int kmajor, float* __restrict__ out) {
     const long long tot = (long long)N * Ho * Wo * Co;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
         const int co = (int)(t % Co);
         const long long px = t / Co;
         const int xo = (int)(px % Wo), yo = (int)((px / Wo) % Ho), n = (int)(px / ((long long)Wo * Ho));
         float acc = bias ? bias[co] : 0.f;
-        const float* wc = w + (size_t)co * k * k * Ci;
+        const float* wc = kmajor ? w + co : w + (size_t)co * k * k * Ci;     // kmajor: (kh, kw, ci, co) -- a wave reads one line per ci
+        const size_t wstep = kmajor ? (size_t)Co : 1;
         for (int kh = 0; kh < k; ++kh) {
             const int y = yo * s - p + kh;
             if ((unsigned)y >= (unsigned)H) continue;
@@ -74,8 +75,8 @@ __global__ void __launch_bounds__(256) k_reid_conv(const float* __restrict__ in,
                 const int x = xo * s - p + kw;
                 if ((unsigned)x >= (unsigned)W) continue;
                 const float* ip = in + (((size_t)n * H + y) * W + x) * Ci;
-                const float* wp = wc + (kh * k + kw) * Ci;
-                for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[ci];
+                const float* wp = wc + (size_t)(kh * k + kw) * Ci * wstep;
+                for (int ci = 0; ci < Ci; ++ci) acc += ip[ci] * wp[ci * wstep];
             }
         }
         out[t] = relu ? fmaxf(acc, 0.f) : acc;
@@ -130,18 +131,19 @@ __global__ void __launch_bounds__(256) k_reid_pool(const float* __restrict__ in,
 // global average pool: out[n][c] = mean over H*W; one workgroup per crop
 __global__ void __launch_bounds__(256) k_reid_gap(const float* __restrict__ in, int HW, int C, float* __restrict__ out) {
     __shared__ float part[256];
-    const int n = blockIdx.x;
-    const float* base = in + (size_t)n * HW * C;
-    const int groups = 256 / C > 0 ? 256 / C : 1;        // C <= 256: `groups` row-partitions per channel
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const int n = blockIdx.x, c0 = blockIdx.y * 256;     // grid.y: 256-channel slices (one for C <= 256)
+    const int Cc = C - c0 < 256 ? C - c0 : 256;
+    const float* base = in + (size_t)n * HW * C + c0;
+    const int groups = 256 / Cc > 0 ? 256 / Cc : 1;      // `groups` row-partitions per channel
+    const int c = threadIdx.x % Cc, g = threadIdx.x / Cc;
     float acc = 0.f;
     if (g < groups) for (int i = g; i < HW; i += groups) acc += base[(size_t)i * C + c];
     part[threadIdx.x] = (g < groups) ? acc : 0.f;
     __syncthreads();
-    if (threadIdx.x < C) {
+    if (threadIdx.x < Cc) {
         float s = 0.f;
-        for (int k = 0; k < groups; ++k) s += part[k * C + threadIdx.x];
-        out[(size_t)n * C + threadIdx.x] = s / (float)HW;
+        for (int k = 0; k < groups; ++k) s += part[k * Cc + threadIdx.x];
+        out[(size_t)n * C + c0 + threadIdx.x] = s / (float)HW;
     }
 }
 
@@ -191,13 +193,29 @@ __global__ void __launch_bounds__(256) k_reid_fc(const float* __restrict__ in, i
     }
 }
 
+// x / |x|_2 per crop (deepsort_reid.py:104: x.div(x.norm(p=2, dim=1, keepdim=True))); one workgroup per crop, fixed-shape tree sum
+__global__ void __launch_bounds__(256) k_reid_l2norm(const float* __restrict__ in, int C, float* __restrict__ out) {
+    __shared__ float part[256];
+    const float* x = in + (size_t)blockIdx.x * C;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) acc += x[c] * x[c];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float nrm = sqrtf(part[0]);
+    for (int c = threadIdx.x; c < C; c += 256) out[(size_t)blockIdx.x * C + c] = x[c] / nrm;
+}
+
 static int blocks_for(long long tot) { long long b = (tot + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 
 extern "C" int y7t_reid_create(const y7t_reid_op* ops, int n_ops, const int64_t* buf_offsets, int n_bufs, void* arena, size_t arena_bytes, const void* weights_f32,
                                int max_crops, int in_h, int in_w, int feat_dim, y7t_reid** out) {
     Y7T_ARG_CHECK(ops && n_ops > 0 && buf_offsets && n_bufs > 0 && arena && weights_f32 && out && max_crops > 0 && in_h > 0 && in_w > 0 && feat_dim > 0);
     for (int i = 0; i < n_ops; ++i) {
-        Y7T_ARG_CHECK(ops[i].type >= R_CONV && ops[i].type <= R_FC);
+        Y7T_ARG_CHECK(ops[i].type >= R_CONV && ops[i].type <= R_L2NORM);
         Y7T_ARG_CHECK(ops[i].in_buf >= 0 && ops[i].in_buf < n_bufs && ops[i].out_buf >= 0 && ops[i].out_buf < n_bufs && ops[i].aux_buf < n_bufs);
         if (ops[i].type == R_GATE_ACC) Y7T_ARG_CHECK(ops[i].C <= 256 && ops[i].R <= 64 && ops[i].R >= 1);
     }
@@ -255,7 +273,7 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
         switch (op.type) {
         case R_CONV:
             hipLaunchKernelGGL(k_reid_conv, dim3(blocks_for((long long)N * op.Ho * op.Wo * op.Co)), dim3(256), 0, s, in, N, op.H, op.W, op.C, w, bias, op.k, op.s, op.p,
-                               op.Ho, op.Wo, op.Co, op.relu, out);
+                               op.Ho, op.Wo, op.Co, op.relu, op.w_kmajor, out);
             break;
         case R_DWCONV3:
             hipLaunchKernelGGL(k_reid_dwconv3, dim3(blocks_for((long long)N * op.H * op.W * op.C)), dim3(256), 0, s, in, N, op.H, op.W, op.C, w, bias, op.relu, out);
@@ -278,7 +296,10 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
             break;
         }
         case R_GAP:
-            hipLaunchKernelGGL(k_reid_gap, dim3(N), dim3(256), 0, s, in, op.H * op.W, op.C, out);
+            hipLaunchKernelGGL(k_reid_gap, dim3(N, (op.C + 255) / 256), dim3(256), 0, s, in, op.H * op.W, op.C, out);
+            break;
+        case R_L2NORM:
+            hipLaunchKernelGGL(k_reid_l2norm, dim3(N), dim3(256), 0, s, in, op.C, out);
             break;
         case R_FC:
             hipLaunchKernelGGL(k_reid_fc, dim3(blocks_for((long long)N * op.Co)), dim3(256), 0, s, in, N, op.C, w, bias, op.Co, op.relu, out);

@@ -16,9 +16,9 @@ from .. import _lib
 
 OP_DTYPE = np.dtype([("type", "<i4"), ("in_buf", "<i4"), ("out_buf", "<i4"), ("aux_buf", "<i4"), ("H", "<i4"), ("W", "<i4"), ("C", "<i4"),
                      ("Ho", "<i4"), ("Wo", "<i4"), ("Co", "<i4"), ("k", "<i4"), ("s", "<i4"), ("p", "<i4"), ("relu", "<i4"), ("R", "<i4"),
-                     ("pad0", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("w2_off", "<i8"), ("b2_off", "<i8")], align=False)
+                     ("w_kmajor", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("w2_off", "<i8"), ("b2_off", "<i8")], align=False)
 assert OP_DTYPE.itemsize == 96      # == sizeof(y7t_reid_op)
-CONV, DWCONV3, MAXPOOL3S2, AVGPOOL2, GATE_ACC, ADD_RELU, GAP, FC = range(8)
+CONV, DWCONV3, MAXPOOL3S2, AVGPOOL2, GATE_ACC, ADD_RELU, GAP, FC, L2NORM = range(9)
 BN_EPS = 1e-5
 
 
@@ -113,16 +113,20 @@ class _Lowering:
             o[k] = v
         self.ops.append(o)
 
-    def conv(self, x, H, W, ci, co, k, s, p, wname, bnname=None, relu=0):
+    def conv(self, x, H, W, ci, co, k, s, p, wname, bnname=None, relu=0, kmajor=False):
         Wt = self.sd[wname + ".weight"].double().numpy()                       # (co, ci, k, k)
         bias = np.zeros(co)
         if bnname is not None:
             scale, bias = self._bn(bnname)
             Wt = Wt * scale[:, None, None, None]
+            if wname + ".bias" in self.sd:                                     # a biased conv in front of the BatchNorm
+                bias = bias + scale * self.sd[wname + ".bias"].double().numpy()
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         y = self.buf(Ho * Wo * co)
-        self.op(type=CONV, in_buf=x, out_buf=y, H=H, W=W, C=ci, Ho=Ho, Wo=Wo, Co=co, k=k, s=s, p=p, relu=relu,
-                w_off=self.put(Wt.transpose(0, 2, 3, 1)), b_off=self.put(bias) if bnname is not None else -1)
+        # (co, kh, kw, ci): a thread walks its own filter; kmajor (kh, kw, ci, co): neighbouring threads (output channels) read neighbouring
+        # weights -- the layout for wide layers.  Same products in the same order either way
+        self.op(type=CONV, in_buf=x, out_buf=y, H=H, W=W, C=ci, Ho=Ho, Wo=Wo, Co=co, k=k, s=s, p=p, relu=relu, w_kmajor=int(kmajor),
+                w_off=self.put(Wt.transpose(2, 3, 1, 0) if kmajor else Wt.transpose(0, 2, 3, 1)), b_off=self.put(bias) if bnname is not None else -1)
         return y, Ho, Wo
 
     def light(self, x, H, W, c, name):
@@ -184,6 +188,71 @@ def lower(sd, spec, in_h=128, in_w=64):
     bf = sd["fc.0.bias"].double().numpy() * scale + bias
     out = L.buf(fd)
     L.op(type=FC, in_buf=v, out_buf=out, H=1, W=1, C=ch[3], Co=fd, relu=1, w_off=L.put(Wf), b_off=L.put(bf))
+    return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
+
+
+def deepsort_net_random_state_dict(seed=0):
+    """seeded `net_dict` of the reference's DeepSORT embedding network (reid_models/deepsort_reid.py:62-110; the classifier is not part of the
+    reid=True forward and is left out)"""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, co, ci, k, bias=False):
+        sd[name + ".weight"] = torch.from_numpy(rng.normal(0, (2.0 / (ci * k * k)) ** 0.5, (co, ci, k, k)).astype(np.float32))
+        if bias:
+            sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, co).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.7, 1.3, c).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_mean"] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+        sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.6, 1.4, c).astype(np.float32))
+    conv("conv.0", 64, 3, 3, bias=True)
+    bn("conv.1", 64)
+    cin = 64
+    for li, cout in ((1, 64), (2, 128), (3, 256), (4, 512)):
+        for bi in range(2):
+            b = "layer%d.%d" % (li, bi)
+            conv(b + ".conv1", cout, cin, 3)
+            bn(b + ".bn1", cout)
+            conv(b + ".conv2", cout, cout, 3)
+            bn(b + ".bn2", cout)
+            if cin != cout:
+                conv(b + ".downsample.0", cout, cin, 1)
+                bn(b + ".downsample.1", cout)
+            cin = cout
+    return sd
+
+
+def lower_deepsort_net(sd, in_h=128, in_w=64):
+    """the reference's DeepSORT embedding network (reid_models/deepsort_reid.py:14-110, Net(reid=True)) as the same op list: conv 3x3 + BN + ReLU,
+    MaxPool(3, 2, 1), four stages of two BasicBlocks (64, 128, 256, 512; the first block of stages 2-4 strides by 2 and projects the shortcut with a
+    strided 1x1 + BN), AvgPool2d((8, 4)) -- the whole 8 x 4 map of a 128 x 64 crop --, x / |x|"""
+    if (in_h, in_w) != (128, 64):
+        raise ValueError("deepsort_reid.Net pools an 8 x 4 map: crops are 128 x 64 (H x W)")
+    L = _Lowering(sd, in_h, in_w)
+    x, H, W = L.conv(L.in_buf, in_h, in_w, 3, 64, 3, 1, 1, "conv.0", "conv.1", relu=1, kmajor=True)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = L.buf(Ho * Wo * 64)
+    L.op(type=MAXPOOL3S2, in_buf=x, out_buf=y, H=H, W=W, C=64, Ho=Ho, Wo=Wo, Co=64)
+    x, H, W, cin = y, Ho, Wo, 64
+    for li, cout in ((1, 64), (2, 128), (3, 256), (4, 512)):
+        for bi in range(2):
+            b = "layer%d.%d" % (li, bi)
+            s = 2 if (bi == 0 and li > 1) else 1
+            y1, H1, W1 = L.conv(x, H, W, cin, cout, 3, s, 1, b + ".conv1", b + ".bn1", relu=1, kmajor=True)
+            y2, _, _ = L.conv(y1, H1, W1, cout, cout, 3, 1, 1, b + ".conv2", b + ".bn2", kmajor=True)
+            idn = x
+            if b + ".downsample.0.weight" in sd:
+                idn, _, _ = L.conv(x, H, W, cin, cout, 1, s, 0, b + ".downsample.0", b + ".downsample.1", kmajor=True)
+            out = L.buf(H1 * W1 * cout)
+            L.op(type=ADD_RELU, in_buf=y2, aux_buf=idn, out_buf=out, H=H1, W=W1, C=cout)
+            x, H, W, cin = out, H1, W1, cout
+    assert (H, W) == (8, 4)
+    v = L.buf(512)
+    L.op(type=GAP, in_buf=x, out_buf=v, H=H, W=W, C=512)
+    out = L.buf(512)
+    L.op(type=L2NORM, in_buf=v, out_buf=out, H=1, W=1, C=512, Co=512)
     return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
 
 
@@ -278,21 +347,37 @@ def pack_fused(sd, spec):
 
 
 class ReIDExtractor:
-    """callable at DeepSORT's reid_model seam.  state_dict: torchreid OSNet names (e.g. torch.load('weights/osnet_x0_25.pth')), or None
-    for seeded random weights.  size = (W, H) of the network input like Extractor.size (deepsort_reid.py:122)."""
+    """callable at DeepSORT's reid_model seam.  state_dict: torchreid OSNet names (e.g. torch.load('weights/osnet_x0_25.pth')), or the
+    `net_dict` of the reference's own DeepSORT embedding network (arch="deepsort": reid_models/deepsort_reid.py Net, what Extractor loads from
+    weights/ckpt.t7), or None for seeded random weights.  size = (W, H) of the network input like Extractor.size (deepsort_reid.py:122)."""
 
-    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0, fused=None):
+    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0, fused=None, arch=None):
         """fused: run frame crops through the one-workgroup-per-crop MFMA kernel (fp16 storage, fp32 accumulate).  Default: on for the
-        configuration it exists for (x0_25, 128 x 64 crops); off = the fp32 op list (also what forward_crops always uses)."""
+        configuration it exists for (OSNet x0_25, 128 x 64 crops); off = the fp32 op list (also what forward_crops always uses).
+        arch: "osnet" | "deepsort"; default: read off the state dict's parameter names (OSNet without one).  The deepsort network runs as the fp32
+        op list (1.1 GMAC and 9.4 MB of per-crop buffers per crop: keep max_crops near the detections of a frame)."""
         _lib.require_gpu()
         self._L = _lib.load()
-        self.spec = osnet_spec(width)
+        if arch is None:
+            arch = "deepsort" if (state_dict is not None and any(k in ("conv.0.weight", "module.conv.0.weight") for k in state_dict)) else "osnet"
+        if arch not in ("osnet", "deepsort"):
+            raise ValueError("arch %r: osnet or deepsort" % (arch,))
+        self.arch = arch
         self.in_w, self.in_h = int(size[0]), int(size[1])
-        if state_dict is None:
-            state_dict = random_state_dict(self.spec, seed)
-        self.sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.max_crops = int(max_crops)
-        ops, bufs, w = lower(self.sd, self.spec, self.in_h, self.in_w)
+        if arch == "deepsort":
+            self.spec = {"feature_dim": 512}
+            if state_dict is None:
+                state_dict = deepsort_net_random_state_dict(seed)
+        else:
+            self.spec = osnet_spec(width)
+            if state_dict is None:
+                state_dict = random_state_dict(self.spec, seed)
+        self.sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v.detach().float().cpu() for k, v in state_dict.items()}
+        if arch == "deepsort":
+            ops, bufs, w = lower_deepsort_net(self.sd, self.in_h, self.in_w)
+        else:
+            ops, bufs, w = lower(self.sd, self.spec, self.in_h, self.in_w)
         self.ops, self.feat_dim = ops, self.spec["feature_dim"]
         offs, o = [], 0
         for b in bufs:
@@ -306,7 +391,7 @@ class ReIDExtractor:
                                            _lib.ptr(self._arena), self._arena.numel() * 4, _lib.ptr(self._w), self.max_crops, self.in_h, self.in_w,
                                            self.feat_dim, ctypes.byref(h)))
         self._h = h
-        can_fuse = width == 0.25 and (self.in_w, self.in_h) == (64, 128)
+        can_fuse = arch == "osnet" and width == 0.25 and (self.in_w, self.in_h) == (64, 128)
         if fused and not can_fuse:
             raise _lib.Y7TError("the fused ReID kernel is OSNet x0_25 on 128 x 64 crops (got width %s, size %s)" % (width, size))
         self.fused = can_fuse if fused is None else bool(fused)
@@ -322,11 +407,14 @@ class ReIDExtractor:
         dict, or {'state_dict': ...}, with or without the DataParallel 'module.' prefix; classifier.* is ignored.  The width is read off
         conv1's channel count."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
+        if isinstance(ck, dict) and "net_dict" in ck:       # Extractor.__init__ (deepsort_reid.py:115-117): weights/ckpt.t7 of the original DeepSORT
+            sd = {k: v for k, v in ck["net_dict"].items() if not k.startswith("classifier")}
+            kw.setdefault("max_crops", 128)
+            return cls(sd, arch="deepsort", **kw)
         sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck.state_dict()
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items() if not k.startswith(("classifier", "module.classifier"))}
         if "conv1.conv.weight" not in sd:
-            raise _lib.Y7TError("%s is not an OSNet checkpoint (no conv1.conv.weight): the reference's own DeepSORT Extractor expects "
-                                "weights/ckpt.t7, which does not ship with it; OSNet (weights/osnet_x0_25.pth) is what this package runs" % path)
+            raise _lib.Y7TError("%s is neither an OSNet checkpoint (conv1.conv.weight) nor a DeepSORT one ({'net_dict': ...})" % path)
         width = {64: 1.0, 48: 0.75, 32: 0.5, 16: 0.25}[int(sd["conv1.conv.weight"].shape[0])]
         return cls(sd, width=width, **kw)
 
