@@ -271,7 +271,8 @@ size_t y7t_reid_fused_blob_size(void);
 int y7t_reid_set_fused(y7t_reid* reid, const void* blob, size_t blob_bytes);
 
 /* single fused Conv+bias+act launch (layer-level parity tests, rocprof attribution); same fields as y7t_op but
- * with raw device pointers. */
+ * with raw device pointers.  Small launches split K and sum fp32 slabs from ONE process-wide workspace: call it from one stream at
+ * a time (a y7t_det owns its own workspace and has no such limit). */
 int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B, int H, int W, int Cin, const void* w_packed, const float* bias,
                         void* out, int out_ld, int out_coff, int out_f32, int Cout, int Cout_pad, int KH, int KW, int stride, int pad,
                         int act, const void* zeros16, y7t_stream stream);

@@ -1,9 +1,6 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2y; mkdir -p $O
-export TMPDIR=/tmp
-timeout 200 python scripts/bench_conv.py 32 10 > $O/base.txt 2>&1
-for v in a1 a2 w2 a2w2; do
-  Y7T_LIB=$PWD/yolov7-tracker_amd/lib/aux_$v.so timeout 200 python scripts/bench_conv.py 32 10 > $O/$v.txt 2>&1
-done
-tail -n 1 $O/*.txt
+# round 2: per-detector split-K workspace -- detector tests (layer level, whole network, two streams) + smoke
+mkdir -p gpurun_out/r2y
+timeout 240 python -m pytest tests/test_detector_gpu.py -x -q -m gpu > gpurun_out/r2y/tests.log 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r2y/tests.log
+tail -12 gpurun_out/r2y/tests.log
+timeout 100 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r2y/smoke.log

@@ -152,6 +152,27 @@ def test_whole_network_heads_match_oracle(name, nc, hw, B):
             eq.mean().item(), eq.max().item(), err.mean().item(), err.max().item(), scale))
 
 
+def test_two_detectors_on_two_streams_do_not_share_scratch():
+    """small-batch launches split K over several workgroups and sum fp32 slabs from a workspace: each detector owns one (y7t_det_create), so two
+    detectors enqueued on different streams at the same time give the heads each gives alone"""
+    d1, d2 = build("yolov7-w6", 10, (256, 320), 1, seed=0), build("yolov7-w6", 10, (256, 320), 1, seed=1)
+    x1 = torch.rand((1, 3, 256, 320), generator=torch.Generator().manual_seed(3)).cuda()
+    x2 = torch.rand((1, 3, 256, 320), generator=torch.Generator().manual_seed(4)).cuda()
+    alone1 = [r.clone() for r in d1(x1)[0].raw()]
+    alone2 = [r.clone() for r in d2(x2)[0].raw()]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            o1 = d1(x1)[0]
+            r1 = [r.clone() for r in o1.raw()]
+        with torch.cuda.stream(s2):
+            o2 = d2(x2)[0]
+            r2 = [r.clone() for r in o2.raw()]
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(r1, alone1)) and all(torch.equal(a, b) for a, b in zip(r2, alone2))
+
+
 def test_u8_bgr_input_equals_float_input():
     det = build("yolov7-tiny", 80, (128, 128), 1)
     frame = torch.randint(0, 256, (1, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))

@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 }
 
 static float* g_splitk_ws = nullptr;
-static const size_t kSplitKWsBytes = 128ull << 20;
+static const size_t kSplitKWsBytes = Y7T_SPLITK_WS_BYTES;
 
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
@@ -486,8 +486,8 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     }
     b.splitk = S; b.ksteps = (nk + S - 1) / S; b.partial = nullptr;
     if (S > 1) {
-        if (!g_splitk_ws) Y7T_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, kSplitKWsBytes));
-        b.partial = g_splitk_ws;
+        if (!a.splitk_ws && !g_splitk_ws) Y7T_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, kSplitKWsBytes));
+        b.partial = a.splitk_ws ? a.splitk_ws : g_splitk_ws;
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(256), lds, s, b);

@@ -33,6 +33,8 @@ struct Y7TConvArgs {
     int xcd_swizzle, tile_order;
     int splitk, ksteps, allow_splitk;   // split-K: workgroups per output tile, K-steps per split
     float* partial;                     // fp32 slabs [splitk][M][Cout_pad]
+    float* splitk_ws;                   // caller's split-K workspace of Y7T_SPLITK_WS_BYTES (a detector owns one, so detectors on different streams
+                                        // never share slabs), or null: one process-wide workspace (the single-layer entry point; one stream at a time)
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0)
     int dephase;       // patch kernel: start delay of workgroups 256..511 in units of 4096 clocks (0 = off)
     int force_patch;   // tests: run an eligible 3x3/s1 layer on k_conv3x3_patch whatever its tile efficiency
@@ -45,6 +47,7 @@ struct Y7TConvArgs {
     unsigned in2_bytes;
 };
 
+#define Y7T_SPLITK_WS_BYTES (128ull << 20)
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);
 
 // fused uint8 frame -> (letterbox) -> layout -> stem conv (y7t_stem.hip)

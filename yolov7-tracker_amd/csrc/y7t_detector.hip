@@ -15,6 +15,7 @@ struct y7t_det {
     char* arena; size_t arena_bytes;
     const _Float16* w; const float* bias;
     _Float16* zeros;
+    float* splitk_ws = nullptr;
     int max_batch;
     // Detect levels (y7t_det_set_detect)
     int nl = 0, na = 0, no = 0;
@@ -42,6 +43,12 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
         y7t_set_error("y7t_det_create: cannot allocate the zero page");
         return Y7T_E_HIP;
     }
+    if (hipMalloc((void**)&d->splitk_ws, Y7T_SPLITK_WS_BYTES) != hipSuccess) {     // this detector's split-K slabs (small-batch launches)
+        (void)hipFree(d->zeros);
+        delete d;
+        y7t_set_error("y7t_det_create: cannot allocate the split-K workspace");
+        return Y7T_E_HIP;
+    }
     *out = d;
     return 0;
 }
@@ -49,6 +56,7 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
 extern "C" int y7t_det_destroy(y7t_det* d) {
     if (!d) return 0;
     if (d->zeros) (void)hipFree(d->zeros);
+    if (d->splitk_ws) (void)hipFree(d->splitk_ws);
     delete d;
     return 0;
 }
@@ -75,6 +83,7 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
             a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.Cout_pad = op.Cout_pad;
             a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
             a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.korder; a.force_patch = 0;
+            a.splitk_ws = d->splitk_ws;
             if (op.up_C > 0) {
                 a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]);
                 a.ldin2 = op.up_ld; a.cin2_off = op.up_coff; a.up_c0 = op.up_c0; a.up_C = op.up_C;
