@@ -238,7 +238,13 @@ int y7t_det_postprocess(const float* const* head_host_array_of_dev_ptrs, const i
  * geometry on the float image), Normalize(mean, std) in the frame's channel order -> the network in eval mode -> (N, feat_dim) float32.
  * Like the detector, the network is a host-lowered op list (BatchNorm folded, fp32 weights in one blob) over a caller-owned arena. */
 enum { Y7T_REID_CONV = 0, Y7T_REID_DWCONV3 = 1, Y7T_REID_MAXPOOL3S2 = 2, Y7T_REID_AVGPOOL2 = 3, Y7T_REID_GATE_ACC = 4, Y7T_REID_ADD_RELU = 5,
-       Y7T_REID_GAP = 6, Y7T_REID_FC = 7, Y7T_REID_L2NORM = 8 /* x / |x| per crop: Net.forward with reid=True, reid_models/deepsort_reid.py:104 */ };
+       Y7T_REID_GAP = 6, Y7T_REID_FC = 7, Y7T_REID_L2NORM = 8 /* x / |x| per crop: Net.forward with reid=True, reid_models/deepsort_reid.py:104 */,
+       /* fp16 NHWC buffers (sized in floats like the others: halves / 2), convolutions on the detector's MFMA kernels -- the op list of the
+        * reference's DeepSORT embedding network (reid_models/deepsort_reid.py:14-110), tracker/reid.py::lower_deepsort_net_f16:
+        * H_PACK fp32 (H, W, 3) -> fp16 (H, W, 16); H_CONV k in {1, 3}, C % 8 == 0, Co % 64 == 0, weights fp16 [Co][round_up(k*k*C, 64)] with
+        * k index (kh * k + kw) * C + ci stored at float offset w_off of the blob, fp32 bias [Co] at b_off, no activation; H_MAXPOOL_RELU
+        * relu then 3x3 / 2 / pad 1; H_RELU; H_ADD_RELU relu(in + aux); H_GAP_L2NORM mean over the map then x / |x| -> fp32 (C) */
+       Y7T_REID_H_PACK = 9, Y7T_REID_H_CONV = 10, Y7T_REID_H_MAXPOOL_RELU = 11, Y7T_REID_H_RELU = 12, Y7T_REID_H_ADD_RELU = 13, Y7T_REID_H_GAP_L2NORM = 14 };
 typedef struct y7t_reid_op {
     int32_t type;
     int32_t in_buf, out_buf, aux_buf;   /* arena buffers; aux: second addend (ADD_RELU), pooled + gate scratch (GATE_ACC), -1 otherwise */

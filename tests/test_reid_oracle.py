@@ -123,9 +123,32 @@ def _interpret_ops(ops, bufs, w, x):
             v = xin.reshape(N, C)
             val[int(o["out_buf"])] = v / v.norm(dim=1, keepdim=True)
             continue
+        # the fp16 op types: values are kept as float32 tensors that hold fp16-representable numbers (one rounding per stored tensor)
+        elif t == reid.H_PACK:
+            y = torch.zeros((N, H, W, 16))
+            y[..., :3] = xin.reshape(N, H, W, 3)
+            val[int(o["out_buf"])] = y.half().float()
+            continue
+        elif t == reid.H_CONV:
+            K = k * k * C
+            Kp = (K + 63) // 64 * 64
+            blk = w[int(o["w_off"]):int(o["w_off"]) + Co * Kp // 2].numpy().view(np.float16).reshape(Co, Kp)
+            assert not blk[:, K:].any()
+            wt = torch.from_numpy(blk[:, :K].astype(np.float32)).reshape(Co, k, k, C).permute(0, 3, 1, 2)
+            y = F.conv2d(nchw(xin, H, W, C), wt, bias, int(o["s"]), int(o["p"])).half().float()
+        elif t == reid.H_MAXPOOL_RELU:
+            y = F.max_pool2d(F.relu(nchw(xin, H, W, C)), 3, 2, padding=1)
+        elif t == reid.H_RELU:
+            y = F.relu(nchw(xin, H, W, C))
+        elif t == reid.H_ADD_RELU:
+            y = F.relu(nchw(xin, H, W, C) + nchw(val[int(o["aux_buf"])], H, W, C)).half().float()
+        elif t == reid.H_GAP_L2NORM:
+            v = nchw(xin, H, W, C).mean((2, 3))
+            val[int(o["out_buf"])] = v / v.norm(dim=1, keepdim=True)
+            continue
         else:
             raise AssertionError(t)
-        assert int(bufs[int(o["out_buf"])]) == y.shape[1] * y.shape[2] * y.shape[3]
+        assert int(bufs[int(o["out_buf"])]) == y.shape[1] * y.shape[2] * y.shape[3] // (2 if t >= reid.H_PACK else 1)
         val[int(o["out_buf"])] = y.permute(0, 2, 3, 1).contiguous()
     return val[int(ops[-1]["out_buf"])]
 
@@ -146,6 +169,18 @@ def test_op_lists_encode_their_networks():
     assert int(ops[-1]["type"]) == reid.L2NORM and sum(int(o["type"]) == reid.ADD_RELU for o in ops) == 8
     with pytest.raises(ValueError):
         reid.lower_deepsort_net(sd, 256, 128)
+    # the MFMA op list of the same network: fp16 weights and stored activations (one rounding per tensor), fp32 accumulation -- what the
+    # detector's conv kernels compute; shortcut projections as centre-tap 3x3 filters
+    ops, bufs, w = reid.lower_deepsort_net_f16(sd)
+    got = _interpret_ops(ops, bufs, w, x)
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    cos = float(((got * want).sum(1) / (got.norm(dim=1) * want.norm(dim=1))).min())
+    assert err <= 5e-3 and cos >= 1 - 1e-5, (err, cos)
+    assert sum(int(o["type"]) == reid.H_CONV for o in ops) == 1 + 16 + 3 and all(int(o["k"]) == 3 for o in ops if int(o["type"]) == reid.H_CONV)
+    for o in ops:        # alignment the conv launcher needs: 16-byte aligned weights / bias, channel counts
+        if int(o["type"]) == reid.H_CONV:
+            assert int(o["w_off"]) % 4 == 0 and int(o["b_off"]) % 4 == 0 and int(o["C"]) % 8 == 0 and int(o["Co"]) % 64 == 0
+    print("fp16 op list vs fp32 oracle: max err %.2e of the feature scale, min cosine 1 - %.1e" % (err, 1 - cos))
 
 
 def test_lowering_covers_every_parameter():

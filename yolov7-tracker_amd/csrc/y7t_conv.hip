@@ -565,7 +565,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
     }
-    if (conv_variant() == 0 || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
+    if ((conv_variant() == 0 && !a.no_patch) || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;
     }

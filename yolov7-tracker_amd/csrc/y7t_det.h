@@ -38,6 +38,7 @@ struct Y7TConvArgs {
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0)
     int dephase;       // patch kernel: start delay of workgroups 256..511 in units of 4096 clocks (0 = off)
     int force_patch;   // tests: run an eligible 3x3/s1 layer on k_conv3x3_patch whatever its tile efficiency
+    int no_patch;      // host-side: keep this launch on the generic implicit-GEMM kernel
     int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)
     int epi;      // 1: Detect decode + candidate filter instead of the output store (1x1 convs, dec below)
     Y7TDecode dec;

@@ -10,13 +10,18 @@
 // data-driven list of plain fp32 NHWC kernels (one thread per output value, weights through L1) -- BatchNorm folded on the host.
 // Nothing here is worth MFMA: the whole forward is a few hundred microseconds next to an 18 ms detector forward.
 #include "y7t_common.h"
+#include "y7t_conv_common.h"
 #include "y7t_reid_fused.h"
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 static_assert(sizeof(y7t_reid_op) == 96, "y7t_reid_op layout must match tracker/reid.py OP_DTYPE");
 
-enum { R_CONV = 0, R_DWCONV3 = 1, R_MAXPOOL3S2 = 2, R_AVGPOOL2 = 3, R_GATE_ACC = 4, R_ADD_RELU = 5, R_GAP = 6, R_FC = 7, R_L2NORM = 8 };
+enum { R_CONV = 0, R_DWCONV3 = 1, R_MAXPOOL3S2 = 2, R_AVGPOOL2 = 3, R_GATE_ACC = 4, R_ADD_RELU = 5, R_GAP = 6, R_FC = 7, R_L2NORM = 8,
+       // fp16 NHWC activations, convolutions on the detector's MFMA kernels (y7t_conv_launch): the reference's DeepSORT embedding network
+       // (reid_models/deepsort_reid.py Net: 1.1 GMAC per crop -- GEMM-shaped, unlike OSNet's depthwise stacks)
+       R_H_PACK = 9, R_H_CONV = 10, R_H_MAXPOOL_RELU = 11, R_H_RELU = 12, R_H_ADD_RELU = 13, R_H_GAP_L2NORM = 14 };
 
 struct y7t_reid {
     std::vector<y7t_reid_op> ops;
@@ -25,6 +30,8 @@ struct y7t_reid {
     const float* w;
     int max_n, in_h, in_w, feat_dim;
     const char* fused_blob = nullptr;   // set: frame crops of a 128 x 64 x0_25 network go through k_osnet_x025 (y7t_reid_fused.hip)
+    float* splitk_ws = nullptr;         // R_H_CONV: this extractor's split-K slabs (small launches), Y7T_SPLITK_WS_BYTES
+    ~y7t_reid() { if (splitk_ws) (void)hipFree(splitk_ws); }
 };
 
 // crop + resize + normalise: out[n][y][x][c], c in the frame's channel order (BGR), cv2.INTER_LINEAR geometry on the float image
@@ -209,17 +216,107 @@ __global__ void __launch_bounds__(256) k_reid_l2norm(const float* __restrict__ i
     for (int c = threadIdx.x; c < C; c += 256) out[(size_t)blockIdx.x * C + c] = x[c] / nrm;
 }
 
+// ---- fp16 NHWC helpers of the MFMA op list --------------------------------------------------------------------------------
+// fp32 (N, H, W, 3) crops -> fp16 (N, H, W, 16), channels 3..15 zero (the conv kernels read 16-byte channel groups)
+__global__ void __launch_bounds__(256) k_h_pack(const float* __restrict__ in, long long npix, half_t* __restrict__ out) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < npix; t += (long long)gridDim.x * blockDim.x) {
+        half8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = (half_t)0.f; hi[e] = (half_t)0.f; }
+        lo[0] = (half_t)in[t * 3]; lo[1] = (half_t)in[t * 3 + 1]; lo[2] = (half_t)in[t * 3 + 2];
+        *(half8*)(out + t * 16) = lo;
+        *(half8*)(out + t * 16 + 8) = hi;
+    }
+}
+
+// ReLU then MaxPool2d(3, 2, padding=1) (max and ReLU commute), C % 8 == 0
+__global__ void __launch_bounds__(256) k_h_maxpool3s2_relu(const half_t* __restrict__ in, int N, int H, int W, int C, int Ho, int Wo, half_t* __restrict__ out) {
+    const int C8 = C / 8;
+    const long long tot = (long long)N * Ho * Wo * C8;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < tot; t += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        const long long px = t / C8;
+        const int xo = (int)(px % Wo), yo = (int)((px / Wo) % Ho), n = (int)(px / ((long long)Wo * Ho));
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)0.f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int y = yo * 2 - 1 + kh;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int x = xo * 2 - 1 + kw;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const half8 v = *(const half8*)(in + (((size_t)n * H + y) * W + x) * C + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *(half8*)(out + (size_t)px * C + c8 * 8) = m;
+    }
+}
+
+// out = relu(a + b) (b == nullptr: relu(a)); fp32 add of the two fp16 values, one rounding
+__global__ void __launch_bounds__(256) k_h_add_relu(const half_t* __restrict__ a, const half_t* __restrict__ b, long long n8, half_t* __restrict__ out) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+        const half8 x = *(const half8*)(a + t * 8);
+        half8 r;
+        if (b) {
+            const half8 y = *(const half8*)(b + t * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (half_t)fmaxf((float)x[e] + (float)y[e], 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = x[e] > (half_t)0.f ? x[e] : (half_t)0.f;
+        }
+        *(half8*)(out + t * 8) = r;
+    }
+}
+
+// AvgPool over the whole map + x / |x|_2 (deepsort_reid.py:96-105), one workgroup per crop: fp16 (HW, C) -> fp32 (C), C <= 1024
+__global__ void __launch_bounds__(256) k_h_gap_l2norm(const half_t* __restrict__ in, int HW, int C, float* __restrict__ out) {
+    __shared__ float mean[1024];
+    __shared__ float part[256];
+    const half_t* x = in + (size_t)blockIdx.x * HW * C;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int i = 0; i < HW; ++i) a += (float)x[(size_t)i * C + c];
+        a /= (float)HW;
+        mean[c] = a;
+        ss += a * a;
+    }
+    part[threadIdx.x] = ss;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float nrm = sqrtf(part[0]);
+    for (int c = threadIdx.x; c < C; c += 256) out[(size_t)blockIdx.x * C + c] = mean[c] / nrm;
+}
+
 static int blocks_for(long long tot) { long long b = (tot + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 
 extern "C" int y7t_reid_create(const y7t_reid_op* ops, int n_ops, const int64_t* buf_offsets, int n_bufs, void* arena, size_t arena_bytes, const void* weights_f32,
                                int max_crops, int in_h, int in_w, int feat_dim, y7t_reid** out) {
     Y7T_ARG_CHECK(ops && n_ops > 0 && buf_offsets && n_bufs > 0 && arena && weights_f32 && out && max_crops > 0 && in_h > 0 && in_w > 0 && feat_dim > 0);
+    bool need_ws = false;
     for (int i = 0; i < n_ops; ++i) {
-        Y7T_ARG_CHECK(ops[i].type >= R_CONV && ops[i].type <= R_L2NORM);
+        Y7T_ARG_CHECK(ops[i].type >= R_CONV && ops[i].type <= R_H_GAP_L2NORM);
         Y7T_ARG_CHECK(ops[i].in_buf >= 0 && ops[i].in_buf < n_bufs && ops[i].out_buf >= 0 && ops[i].out_buf < n_bufs && ops[i].aux_buf < n_bufs);
         if (ops[i].type == R_GATE_ACC) Y7T_ARG_CHECK(ops[i].C <= 256 && ops[i].R <= 64 && ops[i].R >= 1);
+        if (ops[i].type == R_H_CONV) Y7T_ARG_CHECK(ops[i].C % 8 == 0 && ops[i].Co % 64 == 0 && (ops[i].k == 1 || ops[i].k == 3) && ops[i].b_off >= 0);
+        if (ops[i].type == R_H_MAXPOOL_RELU || ops[i].type == R_H_RELU || ops[i].type == R_H_ADD_RELU) Y7T_ARG_CHECK(ops[i].C % 8 == 0);
+        if (ops[i].type == R_H_ADD_RELU) Y7T_ARG_CHECK(ops[i].aux_buf >= 0);
+        if (ops[i].type == R_H_GAP_L2NORM) Y7T_ARG_CHECK(ops[i].C <= 1024);
+        need_ws = need_ws || ops[i].type == R_H_CONV;
     }
     y7t_reid* r = new y7t_reid();
+    if (need_ws && hipMalloc((void**)&r->splitk_ws, Y7T_SPLITK_WS_BYTES) != hipSuccess) {
+        delete r;
+        y7t_set_error("y7t_reid_create: cannot allocate the split-K workspace");
+        return Y7T_E_HIP;
+    }
     r->ops.assign(ops, ops + n_ops);
     r->bufs.assign(buf_offsets, buf_offsets + n_bufs);
     r->arena = (float*)arena; r->arena_floats = arena_bytes / 4; r->w = (const float*)weights_f32;
@@ -300,6 +397,37 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
             break;
         case R_L2NORM:
             hipLaunchKernelGGL(k_reid_l2norm, dim3(N), dim3(256), 0, s, in, op.C, out);
+            break;
+        case R_H_PACK: {
+            const long long npix = (long long)N * op.H * op.W;
+            hipLaunchKernelGGL(k_h_pack, dim3(blocks_for(npix)), dim3(256), 0, s, in, npix, (half_t*)out);
+            break;
+        }
+        case R_H_CONV: {     // weights: fp16 [Co][K_pad] (k = (kh * 3 + kw) * C + ci) stored in the float blob at w_off; bias fp32 [Co] at b_off
+            Y7TConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = (const _Float16*)in; a.ldin = op.C; a.cin_off = 0; a.B = N; a.H = op.H; a.W = op.W; a.Cin = op.C;
+            a.w = (const _Float16*)w; a.bias = bias; a.out = out; a.ldout = op.Co; a.cout_off = 0; a.out_f32 = 0;
+            a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Co; a.Cout_pad = op.Co; a.KH = op.k; a.KW = op.k; a.stride = op.s; a.pad = op.p;
+            a.K = op.k * op.k * op.C; a.K_pad = (a.K + 63) / 64 * 64; a.M = N * op.Ho * op.Wo; a.act = Y7T_ACT_NONE; a.splitk_ws = r->splitk_ws;
+            // plain (kh, kw, ci) weights: the generic kernel is the one tested on this layout for every shape here; Y7T_REID_PATCH=1 lets the
+            // 64 / 128-channel stride-1 layers of large batches take the LDS-patch kernel (faster; enable by default once it is covered)
+            { static int rp = -1; if (rp < 0) { const char* e = getenv("Y7T_REID_PATCH"); rp = e ? atoi(e) : 0; } a.no_patch = !rp; }
+            if (int rc = y7t_conv_launch(a, s)) return rc;
+            break;
+        }
+        case R_H_MAXPOOL_RELU:
+            hipLaunchKernelGGL(k_h_maxpool3s2_relu, dim3(blocks_for((long long)N * op.Ho * op.Wo * (op.C / 8))), dim3(256), 0, s, (const half_t*)in, N, op.H, op.W, op.C,
+                               op.Ho, op.Wo, (half_t*)out);
+            break;
+        case R_H_RELU: case R_H_ADD_RELU: {
+            const long long n8 = (long long)N * op.H * op.W * (op.C / 8);
+            hipLaunchKernelGGL(k_h_add_relu, dim3(blocks_for(n8)), dim3(256), 0, s, (const half_t*)in, op.type == R_H_ADD_RELU ? (const half_t*)aux : (const half_t*)nullptr, n8,
+                               (half_t*)out);
+            break;
+        }
+        case R_H_GAP_L2NORM:
+            hipLaunchKernelGGL(k_h_gap_l2norm, dim3(N), dim3(256), 0, s, (const half_t*)in, op.H * op.W, op.C, out);
             break;
         case R_FC:
             hipLaunchKernelGGL(k_reid_fc, dim3(blocks_for((long long)N * op.Co)), dim3(256), 0, s, in, N, op.C, w, bias, op.Co, op.relu, out);

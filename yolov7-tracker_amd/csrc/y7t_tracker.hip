@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256) k_ds_normalize(void* fblob, const float* 
     const Y7TFeat f = y7t_feat_bind(fblob);
     Y7TExec ex;
     ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    if (n > f.h->cap_d) n = f.h->cap_d;      // (the step reports Y7T_ERR_CAP_D; nothing is written past the state)
     y7t_feat_normalize_dets(ex, f, det_feats, n);
 }
 
@@ -198,6 +199,8 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
     const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;
     const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
     const int slot = blockIdx.x, j0 = blockIdx.y * 64;
+    if (slot >= h->cfg.cap_t) return;
+    if (n > h->cfg.cap_d) n = h->cfg.cap_d;
     const int st = s.state[slot];
     if (st != Y7T_TRACKED && st != Y7T_LOST) return;
     const Y7TFeat f = y7t_feat_bind(fblob);

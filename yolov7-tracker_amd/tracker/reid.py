@@ -18,7 +18,7 @@ OP_DTYPE = np.dtype([("type", "<i4"), ("in_buf", "<i4"), ("out_buf", "<i4"), ("a
                      ("Ho", "<i4"), ("Wo", "<i4"), ("Co", "<i4"), ("k", "<i4"), ("s", "<i4"), ("p", "<i4"), ("relu", "<i4"), ("R", "<i4"),
                      ("w_kmajor", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("w2_off", "<i8"), ("b2_off", "<i8")], align=False)
 assert OP_DTYPE.itemsize == 96      # == sizeof(y7t_reid_op)
-CONV, DWCONV3, MAXPOOL3S2, AVGPOOL2, GATE_ACC, ADD_RELU, GAP, FC, L2NORM = range(9)
+CONV, DWCONV3, MAXPOOL3S2, AVGPOOL2, GATE_ACC, ADD_RELU, GAP, FC, L2NORM, H_PACK, H_CONV, H_MAXPOOL_RELU, H_RELU, H_ADD_RELU, H_GAP_L2NORM = range(15)
 BN_EPS = 1e-5
 
 
@@ -256,6 +256,64 @@ def lower_deepsort_net(sd, in_h=128, in_w=64):
     return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
 
 
+def lower_deepsort_net_f16(sd, in_h=128, in_w=64):
+    """the same network for the MFMA path: fp16 NHWC activations, every convolution one launch of the detector's implicit-GEMM kernels
+    (include/y7t.h: Y7T_REID_H_*).  BatchNorm folded; weights fp16 [Cout][round_up(9 Cin, 64)] in (kh, kw, ci) order; the 3-channel crop is
+    padded to 16 channels; the strided 1x1 shortcut projections are written as 3x3 / stride 2 / pad 1 filters whose only non-zero tap is the
+    centre (the same pixels: 2y - 1 + 1 = 2y), so every launch is a shape the conv kernels are tested on; ReLU is applied by the consumer
+    side kernels (pool, add) or an in-place pass"""
+    if (in_h, in_w) != (128, 64):
+        raise ValueError("deepsort_reid.Net pools an 8 x 4 map: crops are 128 x 64 (H x W)")
+    L = _Lowering(sd, in_h, in_w)
+    hbuf = lambda halves: L.buf((halves + 1) // 2)            # buffer sizes are in floats per crop
+
+    def hconv(x, H, W, cin, cin_pad, cout, k, s, p, wname, bnname, centre_tap_of_3x3=False):
+        Wt = sd[wname + ".weight"].double().numpy()
+        scale, bias = L._bn(bnname)
+        Wt = Wt * scale[:, None, None, None]
+        if wname + ".bias" in sd:
+            bias = bias + scale * sd[wname + ".bias"].double().numpy()
+        if centre_tap_of_3x3:                                  # 1x1 / stride s / pad 0 == 3x3 / stride s / pad 1 with the centre tap only
+            W3 = np.zeros((cout, cin, 3, 3))
+            W3[:, :, 1, 1] = Wt[:, :, 0, 0]
+            Wt, k, p = W3, 3, 1
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        K = k * k * cin_pad
+        Kp = (K + 63) // 64 * 64
+        Wp = np.zeros((cout, k, k, cin_pad))
+        Wp[..., :cin] = Wt.transpose(0, 2, 3, 1)
+        blk = np.zeros((cout, Kp), np.float16)
+        blk[:, :K] = Wp.reshape(cout, K).astype(np.float16)
+        y = hbuf(Ho * Wo * cout)
+        L.op(type=H_CONV, in_buf=x, out_buf=y, H=H, W=W, C=cin_pad, Ho=Ho, Wo=Wo, Co=cout, k=k, s=s, p=p,
+             w_off=L.put(blk.reshape(-1).view(np.float32)), b_off=L.put(bias))
+        return y, Ho, Wo
+    x = hbuf(in_h * in_w * 16)
+    L.op(type=H_PACK, in_buf=L.in_buf, out_buf=x, H=in_h, W=in_w, C=3, Co=16)
+    x, H, W = hconv(x, in_h, in_w, 3, 16, 64, 3, 1, 1, "conv.0", "conv.1")
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = hbuf(Ho * Wo * 64)
+    L.op(type=H_MAXPOOL_RELU, in_buf=x, out_buf=y, H=H, W=W, C=64, Ho=Ho, Wo=Wo, Co=64)
+    x, H, W, cin = y, Ho, Wo, 64
+    for li, cout in ((1, 64), (2, 128), (3, 256), (4, 512)):
+        for bi in range(2):
+            b = "layer%d.%d" % (li, bi)
+            s = 2 if (bi == 0 and li > 1) else 1
+            y1, H1, W1 = hconv(x, H, W, cin, cin, cout, 3, s, 1, b + ".conv1", b + ".bn1")
+            L.op(type=H_RELU, in_buf=y1, out_buf=y1, H=H1, W=W1, C=cout)
+            y2, _, _ = hconv(y1, H1, W1, cout, cout, cout, 3, 1, 1, b + ".conv2", b + ".bn2")
+            idn = x
+            if b + ".downsample.0.weight" in sd:
+                idn, _, _ = hconv(x, H, W, cin, cin, cout, 1, s, 0, b + ".downsample.0", b + ".downsample.1", centre_tap_of_3x3=True)
+            out = hbuf(H1 * W1 * cout)
+            L.op(type=H_ADD_RELU, in_buf=y2, aux_buf=idn, out_buf=out, H=H1, W=W1, C=cout)
+            x, H, W, cin = out, H1, W1, cout
+    assert (H, W) == (8, 4)
+    out = L.buf(512)
+    L.op(type=H_GAP_L2NORM, in_buf=x, out_buf=out, H=H, W=W, C=512, Co=512)
+    return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
+
+
 def _frags(Wm, cout_p, cin_p):
     """(cout, cin) matrix -> A operands of v_mfma_f32_16x16x16_f16, [cout_p/16][cin_p/16][lane][4] fp16: lane holds row lane % 16,
     k = 4 * (lane // 16) + e of its 16 x 16 tile (zero padded)"""
@@ -351,11 +409,12 @@ class ReIDExtractor:
     `net_dict` of the reference's own DeepSORT embedding network (arch="deepsort": reid_models/deepsort_reid.py Net, what Extractor loads from
     weights/ckpt.t7), or None for seeded random weights.  size = (W, H) of the network input like Extractor.size (deepsort_reid.py:122)."""
 
-    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0, fused=None, arch=None):
+    def __init__(self, state_dict=None, width=0.25, size=(64, 128), max_crops=512, seed=0, fused=None, arch=None, mfma=True):
         """fused: run frame crops through the one-workgroup-per-crop MFMA kernel (fp16 storage, fp32 accumulate).  Default: on for the
         configuration it exists for (OSNet x0_25, 128 x 64 crops); off = the fp32 op list (also what forward_crops always uses).
-        arch: "osnet" | "deepsort"; default: read off the state dict's parameter names (OSNet without one).  The deepsort network runs as the fp32
-        op list (1.1 GMAC and 9.4 MB of per-crop buffers per crop: keep max_crops near the detections of a frame)."""
+        arch: "osnet" | "deepsort"; default: read off the state dict's parameter names (OSNet without one).  The deepsort network (1.1 GMAC per
+        crop, all of it dense 3x3 convolutions) runs on the detector's MFMA conv kernels with fp16 activations (mfma=True, 4.9 MB of buffers per
+        crop) or as the exact fp32 op list (mfma=False, 9.4 MB per crop: keep max_crops near the detections of a frame)."""
         _lib.require_gpu()
         self._L = _lib.load()
         if arch is None:
@@ -374,8 +433,9 @@ class ReIDExtractor:
             if state_dict is None:
                 state_dict = random_state_dict(self.spec, seed)
         self.sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v.detach().float().cpu() for k, v in state_dict.items()}
+        self.mfma = bool(mfma) and arch == "deepsort"
         if arch == "deepsort":
-            ops, bufs, w = lower_deepsort_net(self.sd, self.in_h, self.in_w)
+            ops, bufs, w = (lower_deepsort_net_f16 if self.mfma else lower_deepsort_net)(self.sd, self.in_h, self.in_w)
         else:
             ops, bufs, w = lower(self.sd, self.spec, self.in_h, self.in_w)
         self.ops, self.feat_dim = ops, self.spec["feature_dim"]
