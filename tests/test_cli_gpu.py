@@ -50,6 +50,40 @@ def test_track_cli_synthetic(tmp_path, tracker, model, size, frames, objs, batch
     assert float(vals["MOTA"]) > 50 and float(vals["IDF1"]) > 50 and float(vals["HOTA"]) > 40
 
 
+def test_track_cli_deepsort_with_device_reid(tmp_path):
+    """BASELINE config 4 through the CLI: --tracker deepsort with the OSNet x0_25 embedding network on the device (seeded random weights:
+    --reid_model_path random:osnet), crops taken from the synthetic frames.  The oracle DeepSORT fed with the SAME embeddings (computed by the
+    same extractor from the same frames) must write the same file: ids and boxes of every row"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker import track
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.reid import ReIDExtractor
+    frames_n, objs, size = 30, 40, 640
+    BaseTrack._count = 0
+    folder = track.cli(["--dataset", "synthetic", "--tracker", "deepsort", "--reid_model_path", "random:osnet", "--model_path", "random:yolov7-tiny", "--nc", "10",
+                        "--img_size", str(size), "--synthetic_dets", "--synthetic_frames", str(frames_n), "--synthetic_objs", str(objs),
+                        "--results_root", str(tmp_path)])
+    got = open(os.path.join(folder, "synthetic-000.txt")).read().splitlines()
+    frames = synth.make_frames(frames_n, objs, size, 0)
+    dets = synth.make_detections(frames_n, objs, size, 0)
+    ext, state = ReIDExtractor(None, arch="osnet", max_crops=512), {"f": 0}
+
+    def feature_fn(tlbrs):          # called once per frame, in order, with the rows above the confidence threshold (deepsort.py:98)
+        f = state["f"]
+        state["f"] += 1
+        return ext.features_for_boxes(frames[f], tlbrs).cpu().numpy()
+    want = []
+    for f, rows in enumerate(tracker_np.run("deepsort", dets, feature_fn=feature_fn)):
+        for tid, tlwh, cls, score in rows:
+            if tlwh[2] * tlwh[3] > 150:
+                want.append(f'{f + 1},{tid},{tlwh[0]:.2f},{tlwh[1]:.2f},{tlwh[2]:.2f},{tlwh[3]:.2f},1.0,-1,-1,-1')
+    assert len(got) > 0.5 * sum(len(d) for d in dets) and len(got) == len(want)
+    same = sum(a == b for a, b in zip(got, want))
+    assert same >= 0.99 * len(want), (same, len(want))
+    assert [l.split(",")[:2] for l in got] == [l.split(",")[:2] for l in want]          # frame, id of every row
+
+
 def _rows(txt):
     return [tuple(l.split(",")[:2]) for l in txt.splitlines()]
 

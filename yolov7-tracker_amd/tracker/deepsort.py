@@ -26,7 +26,15 @@ class DeepSORT(BaseTracker):
         super().__init__(opts, frame_rate=frame_rate)
         self.reid_model = reid_model if reid_model is not None else getattr(opts, "reid_model", None)
         path = getattr(opts, "reid_model_path", None)
-        if self.reid_model is None and path and os.path.isfile(str(path)):      # deepsort.py:14: Extractor(opts.reid_model_path)
+        if self.reid_model is None and isinstance(path, str) and path.startswith("random"):
+            # "random[:osnet|:deepsort]" -- seeded random weights of the named embedding network, like the detector's "random:<arch>" model
+            # paths: for synthetic runs (track.py --dataset synthetic, bench.py); no checkpoint ships that the reference's DeepSORT can load
+            from .reid import ReIDExtractor
+            arch = path.partition(":")[2] or "osnet"
+            if arch not in ("osnet", "deepsort"):
+                raise ValueError("reid_model_path %r: random, random:osnet or random:deepsort" % (path,))
+            self.reid_model = ReIDExtractor(None, arch=arch, max_crops=512 if arch == "osnet" else 128)
+        elif self.reid_model is None and path and os.path.isfile(str(path)):      # deepsort.py:14: Extractor(opts.reid_model_path)
             from .reid import ReIDExtractor
             self.reid_model = ReIDExtractor.from_checkpoint(path)
         self.gamma = gamma

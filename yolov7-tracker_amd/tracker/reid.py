@@ -485,11 +485,11 @@ class ReIDExtractor:
         frame = frame.to(device="cuda", dtype=torch.uint8).contiguous()
         boxes = torch.as_tensor(np.ascontiguousarray(np.asarray(tlbrs, dtype=np.float32).reshape(-1, 4))).cuda()
         n = boxes.shape[0]
-        if n > self.max_crops:
-            raise _lib.Y7TError("%d crops exceed max_crops=%d" % (n, self.max_crops))
         out = torch.empty((n, self.feat_dim), dtype=torch.float32, device="cuda")
-        _lib.check(self._L.y7t_reid_forward(self._h, _lib.ptr(frame), frame.shape[0], frame.shape[1], _lib.ptr(boxes), n, None, _lib.ptr(out),
-                                            _lib.stream_ptr()))
+        for i in range(0, n, self.max_crops):       # more boxes than the arena holds: max_crops at a time (stream order keeps the buffers safe)
+            m = min(self.max_crops, n - i)
+            _lib.check(self._L.y7t_reid_forward(self._h, _lib.ptr(frame), frame.shape[0], frame.shape[1], _lib.ptr(boxes[i:]), m, None, _lib.ptr(out[i:]),
+                                                _lib.stream_ptr()))
         self._keep = (frame, boxes)
         return out
 

@@ -174,7 +174,8 @@ def build_parser():
     parser.add_argument('--model_path', type=str, default='./weights/best.pt', help='model path')
     parser.add_argument('--trace', type=bool, default=False, help='traced model of YOLO v7')
     parser.add_argument('--img_size', nargs='+', type=int, default=1280, help='[train, test] image sizes')
-    parser.add_argument('--reid_model_path', type=str, default='./weights/ckpt.t7', help='path for reid model path')
+    parser.add_argument('--reid_model_path', type=str, default='./weights/ckpt.t7',
+                        help='path for reid model path (an OSNet or a DeepSORT net_dict checkpoint; random[:osnet|:deepsort] = seeded random weights)')
     parser.add_argument('--dhn_path', type=str, default='./weights/DHN.pth', help='path of DHN path for DeepMOT')
     parser.add_argument('--conf_thresh', type=float, default=0.2, help='filter tracks')
     parser.add_argument('--nms_thresh', type=float, default=0.7, help='thresh for NMS')
