@@ -24,6 +24,8 @@
 #include <stdlib.h>
 
 #include "y7t_conv_common.h"
+#include <algorithm>
+#include <vector>
 
 // KM = 1: 1x1 / stride 1 / pad 0 with Cin % 64 == 0 -- no taps, no padding, no K tail: every pixel DMA is `row offset (or out of range)
 // + scalar channel offset`, so the K loop carries no address arithmetic and no control flow besides its own counter.
@@ -345,6 +347,37 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_ig
                     *(float4v*)(slab + (size_t)m * p.Cout_pad + n) = v;
                 }
         }
+#ifdef Y7T_SPLITK_FIXUP   // experiment for the batch-1 latency mode (next round; build with -DY7T_SPLITK_FIXUP and run with Y7T_CONV_SPLITK=2):
+        // no k_splitk_reduce launch -- the LAST workgroup of a tile to arrive sums the slabs in split order (the same arithmetic in the same order
+        // as k_splitk_reduce, so the result does not depend on who arrives last), adds the bias, activates and stores
+        if (p.allow_splitk != 2) return;
+        __threadfence();                                   // this workgroup's slab is visible device-wide before its ticket
+        __syncthreads();
+        int* ticket = (int*)smem;                          // (the stages are drained; the bias corner lies behind them)
+        if (tid == 0) *ticket = atomicAdd(p.splitk_done + bid, 1);
+        __syncthreads();
+        if (*ticket != p.splitk - 1) return;
+        __threadfence();                                   // the other workgroups' slabs, not this CU's / XCD's stale lines
+        if (tid == 0) p.splitk_done[bid] = 0;              // ready for the next launch on this stream
+        const float* lb = (const float*)(smem + BIAS_OFF);
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int m = m0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+            if (m >= p.M || n >= p.Cout) continue;
+            typedef __attribute__((ext_vector_type(4))) float float4v;
+            float4v a = *(const float4v*)(p.partial + (size_t)m * p.Cout_pad + n);
+            for (int sp = 1; sp < p.splitk; ++sp) {
+                const float4v b = *(const float4v*)(p.partial + ((size_t)sp * p.M + m) * p.Cout_pad + n);
+                a += b;
+            }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn(a[e] + lb[n - n0 + e], p.act);
+            const size_t o = (size_t)m * p.ldout + p.cout_off + n;
+            if (p.out_f32) { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) ((float*)p.out)[o + e] = v[e]; }
+            else if (n + 3 < p.Cout) { half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; *(half4*)((half_t*)p.out + o) = h; }
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) ((half_t*)p.out)[o + e] = (half_t)v[e]; }
+        }
+#endif
         return;
     }
     // ---- epilogue: bias + activation.  A lane holds channels n..n+3 of its pixel for each group g (n = 8g + 4*hi32);
@@ -464,6 +497,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = Y7T_SPLITK_WS_BYTES;
+static const size_t kSplitKDoneBytes = 64 << 10;      // (reserved at the end of the workspace for Y7T_SPLITK_FIXUP's tile counters)
 
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
@@ -482,18 +516,33 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
         S = (512 + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;
+#ifdef Y7T_SPLITK_FIXUP
+        while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes - kSplitKDoneBytes) --S;
+#else
         while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes) --S;
+#endif
     }
     b.splitk = S; b.ksteps = (nk + S - 1) / S; b.partial = nullptr;
     if (S > 1) {
         if (!a.splitk_ws && !g_splitk_ws) Y7T_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, kSplitKWsBytes));
         b.partial = a.splitk_ws ? a.splitk_ws : g_splitk_ws;
+#ifdef Y7T_SPLITK_FIXUP   // arrival counters of the tiles: the last 64 KiB of the workspace, zeroed once, left at zero by every launch
+        b.splitk_done = (int*)((char*)b.partial + kSplitKWsBytes - kSplitKDoneBytes);
+        static std::vector<void*> zeroed;
+        if (std::find(zeroed.begin(), zeroed.end(), (void*)b.partial) == zeroed.end()) {
+            Y7T_HIP_CHECK(hipMemsetAsync(b.splitk_done, 0, kSplitKDoneBytes, s));
+            zeroed.push_back((void*)b.partial);
+        }
+#endif
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
                     EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "");
+#ifdef Y7T_SPLITK_FIXUP
+    if (b.splitk > 1 && b.allow_splitk == 2) return 0;    // reduced by the last arriver of each tile
+#endif
     if (b.splitk > 1) {
         const long long tot = (long long)a.M * (a.Cout_pad / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 2048) blocks = 2048;
