@@ -104,3 +104,33 @@ def test_oracle_pinned_against_live_reference(have_reference):
         ref = ref_harness.run_reference_tracker(trk, dets)
         got = tracker_np.run(trk, dets)
         util.assert_same_tracks(got, ref, trk)
+
+
+@pytest.mark.parametrize("kind,fmt", [("sort", "default"), ("bytetrack", "default"), ("bytetrack", "strongsort"), ("botsort", "botsort"), ("deepsort", "default")])
+def test_oracle_equals_live_reference_on_random_scenes(have_reference, kind, fmt):
+    """the scenes of the random-scene tests (tests/test_hostsim.py: density, misses, clutter, gaps, empty frames, warps; DeepSORT: the seeds with
+    appearance ties and near-ties among them) through the reference's OWN tracker classes and through the oracle: every id and box equal.  This is
+    what lets the device tests use the oracle where /root/reference is absent"""
+    if not have_reference:
+        pytest.skip("/root/reference not present (GPU box)")
+    import zlib
+    from oracle import ref_harness
+    from yolov7_tracker_amd import synth
+    if kind == "deepsort":
+        for seed in (20, 50, 62, 76, 1, 2, 3):
+            dets, fn, dim = util.random_deepsort_scene(seed)
+            ref = ref_harness.run_reference_tracker("deepsort", dets, feature_fn=fn)
+            util.assert_same_tracks(tracker_np.run("deepsort", dets, feature_fn=fn), ref, "deepsort seed %d (dim %d)" % (seed, dim))
+        return
+    rng = np.random.default_rng(zlib.crc32(("%s/%s" % (kind, fmt)).encode()))
+    for scene in range(8):
+        n_obj, n_frames = int(rng.integers(5, 120)), int(rng.integers(15, 40))
+        dets = synth.make_detections(n_frames, n_obj, 640, seq_idx=100 + scene, miss=float(rng.uniform(0.0, 0.3)), fp=float(rng.uniform(0.0, 0.2)))
+        gap = int(rng.integers(0, 9))
+        if gap > 2:
+            dets = [None if (i % gap == gap - 1) else d for i, d in enumerate(dets)]
+        if scene % 4 == 3:
+            dets[n_frames // 2] = np.zeros((0, 6), np.float32)
+        warps = synth.make_warps(n_frames, seq_idx=scene) if kind == "botsort" else None
+        ref = ref_harness.run_reference_tracker(kind, dets, opts=ref_harness.make_opts(kalman_format=fmt), warps=warps)
+        util.assert_same_tracks(tracker_np.run(kind, dets, kalman_format=fmt, warps=warps), ref, "%s/%s scene %d" % (kind, fmt, scene))
