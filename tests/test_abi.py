@@ -57,3 +57,13 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
                 assert "_hostsim" not in txt or f.endswith((".h",)), os.path.join(dp, f)
+
+
+def test_integration_doc_shows_every_entry_point():
+    """INTEGRATION.md is where a maintainer of the reference finds the binding for each C entry point: none may be missing"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    syms = sorted(set(re.findall(r"\b(y7t_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "y7t.h")).read())))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(syms) >= 40 and not [s for s in syms if s not in doc]
