@@ -32,14 +32,22 @@
 // EPI = 1 (Detect 1x1 convs in a fused forward): the epilogue decodes + filters (models/yolo.py:49-56, utils/general.py:629-662) instead
 // of storing the tile.  DUAL (KM = 1 only): upsample-on-read -- K-steps whose channels lie in [up_c0, up_c0 + up_C) fetch pixel (y, x)
 // from the half-resolution tensor `in2` at (y >> 1, x >> 1) (nn.Upsample(None, 2, 'nearest') folded into the consumer's loader).
+// Experiment for the next round (build a second library with -DY7T_IGEMM_NW=8): 512-thread workgroups, 2 x 4 waves, so that a 256 x 256 tile (half the
+// operand bytes per flop through the vector-memory path, which is what bounds these kernels -- DESIGN 3b) runs with 2 waves per SIMD instead of the
+// one that the 256-thread instance of that tile leaves.  The default build (4 waves) is unchanged by it.
+#ifndef Y7T_IGEMM_NW
+#define Y7T_IGEMM_NW 4
+#endif
+constexpr int kNW = Y7T_IGEMM_NW, kNT = 64 * kNW, kNWM = kNW / 2;      // waves, threads, waves along the pixel dimension
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
-__global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
+__global__ void __launch_bounds__(kNT, (kNW == 8 || BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
     constexpr int CPR = BK / 8;                  // 16-byte chunks per row (8 or 4)
     constexpr int RPW = 64 / CPR;                // rows covered by one wave-wide 1 KiB DMA (8 or 16)
-    constexpr int RPR = RPW * 4;                 // rows per load round over the 4 waves (32 or 64)
-    constexpr int WTN = BN / 2, WTM = BM / 2;    // wave tile
+    constexpr int RPR = RPW * kNW;               // rows per load round over the 4 waves (32 or 64)
+    constexpr int WTN = BN / 2, WTM = BM / kNWM; // wave tile
+    static_assert(kNW == 4 || (EPI == 0 && !DUAL), "the 8-wave experiment covers the plain convolution only");
     constexpr int TN = WTN / 32, TM = WTM / 32;  // 32x32 MFMA tiles per wave
     constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
     constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
@@ -49,7 +57,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_ig
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = wave / kNWM, wm = wave % kNWM;
     const int n_tiles_m = (p.M + BM - 1) / BM;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order), so give every XCD a CONTIGUOUS range of
     // tiles -- neighbouring pixel tiles share halo rows and the same weight panel in that XCD's private 4 MiB L2
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_ig
         __threadfence();                                   // the other workgroups' slabs, not this CU's / XCD's stale lines
         if (tid == 0) p.splitk_done[bid] = 0;              // ready for the next launch on this stream
         const float* lb = (const float*)(smem + BIAS_OFF);
-        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+        for (int idx = tid; idx < BM * (BN / 4); idx += kNT) {
             const int m = m0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
             if (m >= p.M || n >= p.Cout) continue;
             typedef __attribute__((ext_vector_type(4))) float float4v;
@@ -459,7 +467,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : 2)) k_conv_ig
         constexpr int NCH = BM * CPP;
         half_t* outp = (half_t*)p.out;
 #pragma unroll 4
-        for (int c = tid; c < NCH; c += 256) {
+        for (int c = tid; c < NCH; c += kNT) {
             const int pix = c / CPP, ch = c - pix * CPP;
             const int m = m0 + pix, n = n0 + ch * 8;
             if (m < p.M && n < p.Cout) {
@@ -536,7 +544,7 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
 #endif
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(kNT), lds, s, b);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
                     EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "");
@@ -596,6 +604,16 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+#if Y7T_IGEMM_NW == 8      // experimental library: 512-thread workgroups, 64-deep stages, 256 x 256 / 256 x 128 / 128 x 128 tiles only (layer-level timing and tests)
+    if (a.epi || a.up_C > 0 || a.korder >= 2 || a.Cout_pad % 128 || a.Cin % 64) {
+        y7t_set_error("conv: this is the 8-wave experimental build (plain layers with Cin %% 64 == 0 and Cout %% 128 == 0 only)");
+        return Y7T_E_ARG;
+    }
+    const int v8 = conv_variant();
+    if (v8 == 7) return launch_conv<128, 128, 64, 2>(a, s);
+    if (v8 == 6 || a.Cout_pad % 256) return launch_conv<256, 128, 64, 2>(a, s);
+    return launch_conv<256, 256, 64, 2>(a, s);
+#else
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
         const bool fast = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24) &&
                           (a.korder == 3 || a.korder == 0);
@@ -642,4 +660,5 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     }
     }
+#endif
 }
