@@ -6,6 +6,10 @@
    fixup  -DY7T_SPLITK_FIXUP   the last workgroup of a tile to arrive reduces the split-K slabs (no k_splitk_reduce launch) when
                                Y7T_CONV_SPLITK=2; batch-1 latency mode (Y7T_LIB=.../exp_fixup.so Y7T_CONV_SPLITK=2 python scripts/latency_mode.py)
 
+   next   -DY7T_NEXT_TRACKER   tracker step: candidate lists on a run-time row stride so that they sit in LDS at 500 objects (the per-component solves are
+                               42 % of that frame step and every access of theirs is an L2 round trip today); parity of the macro build is tested on the CPU
+                               (tests/test_hostsim_next.py, scripts/parity_sweep.py); measure with Y7T_LIB=.../exp_next.so python scripts/time_tracker.py
+
 Unlike y7t_conv.hip itself these libraries have not run on a GPU yet; the default build's device code is unaffected by the macros
 (checked byte for byte against the tested build when they were added).
 (y7t_det.h changes layout under Y7T_SPLITK_FIXUP, so that variant recompiles every translation unit.)"""
@@ -16,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from yolov7_tracker_amd import build as b  # noqa: E402
 
-VARIANTS = {"nw8": (["-DY7T_IGEMM_NW=8"], ["y7t_conv.hip"]), "fixup": (["-DY7T_SPLITK_FIXUP=1"], None)}
+VARIANTS = {"nw8": (["-DY7T_IGEMM_NW=8"], ["y7t_conv.hip"]), "fixup": (["-DY7T_SPLITK_FIXUP=1"], None), "next": (["-DY7T_NEXT_TRACKER=1"], ["y7t_tracker.hip"])}
 b.build()
 tmp = os.path.join(b.OBJ, "exp")
 os.makedirs(tmp, exist_ok=True)

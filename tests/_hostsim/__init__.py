@@ -8,7 +8,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liby7t_hostsim.so")
+# Y7T_HOSTSIM_DEFS="-DY7T_NEXT_TRACKER=1": a second library with experimental macros of the headers switched on (the tests then run against it)
+_DEFS = os.environ.get("Y7T_HOSTSIM_DEFS", "").split()
+_SO = os.path.join(_HERE, "liby7t_hostsim%s.so" % ("_" + "".join(c for c in "".join(_DEFS) if c.isalnum()) if _DEFS else ""))
 _SRC = os.path.join(_HERE, "y7t_hostsim.cpp")
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "yolov7-tracker_amd", "csrc")
 
@@ -16,7 +18,11 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "yolov7-tracker_am
 def build(force=False):
     deps = [_SRC, os.path.join(_CSRC, "y7t_track_core.h"), os.path.join(_CSRC, "y7t_track_step.h"), os.path.join(_CSRC, "y7t_track_deepsort.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO, _SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + _DEFS + ["-o", _SO, _SRC])
+    fast = os.environ.get("Y7T_HOSTSIM_FAST_BYTES")
+    if fast:                                  # give the programs a fast scratch of this size (the device's is 131072)
+        L = ctypes.CDLL(_SO)
+        L.hs_set_fast_bytes(int(fast))
     return _SO
 
 

@@ -7,12 +7,18 @@ static int g_literal_calls = 0;      // how many assignments met a tie and were 
 #define Y7T_COUNT_LITERAL() (++g_literal_calls)
 static int g_tie_reason[8] = {0};
 #define Y7T_TIE_REASON(k) (++g_tie_reason[k])
+static int g_next_stat[4] = {0};
+#define Y7T_NEXT_STAT(k) (++g_next_stat[k])
 #include "../../yolov7-tracker_amd/csrc/y7t_track_step.h"
 #include "../../yolov7-tracker_amd/csrc/y7t_track_deepsort.h"
 #include <stdlib.h>
 #include <string.h>
 
-static Y7TExec hs_ex() { Y7TExec e; e.tid = 0; e.nt = 1; e.rv = 0; e.ri = 0; e.fast = 0; e.fast_bytes = 0; return e; }
+// the workgroup's fast scratch (LDS on the device): off by default (everything in the state blob); hs_set_fast_bytes(n) gives the programs n bytes of it,
+// so the placement logic (work arrays / cost matrix / candidate lists in fast scratch when they fit) runs on the host too
+static char g_fast[160 * 1024] __attribute__((aligned(64)));
+static unsigned g_fast_bytes = 0;
+static Y7TExec hs_ex() { Y7TExec e; e.tid = 0; e.nt = 1; e.rv = 0; e.ri = 0; e.fast = g_fast_bytes ? g_fast : 0; e.fast_bytes = g_fast_bytes; return e; }
 
 extern "C" {
 size_t hs_tracker_bytes(int cap_t, int cap_d) { return y7t_trk_layout(cap_t, cap_d).total; }
@@ -34,6 +40,15 @@ void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(H, mean,
 
 int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
 int hs_literal_calls() { return g_literal_calls; }
+void hs_set_fast_bytes(int n) { g_fast_bytes = n < 0 ? 0 : (n > (int)sizeof(g_fast) ? (unsigned)sizeof(g_fast) : (unsigned)n); }
+int hs_next_stat(int k) { return g_next_stat[k]; }
+int hs_next_tracker() {
+#ifdef Y7T_NEXT_TRACKER
+    return 1;
+#else
+    return 0;
+#endif
+}
 int hs_tie_reason(int k) { return g_tie_reason[k]; }
 
 void hs_lapjv(const double* cost, int nr, int nc, double limit, int* x, int* y) {

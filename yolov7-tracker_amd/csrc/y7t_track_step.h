@@ -185,8 +185,17 @@ struct Y7TBox4 { double v[4]; };
 // Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
 // connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
 // caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
+// Y7T_NEXT_TRACKER (experiment for the next round; the default build is unchanged by it): the row stride of the candidate lists is chosen at run time so that
+// the lists fit in the fast scratch next to the work arrays -- 24 entries per row keep a 500-object frame's lists (121 KB) in global memory, where every step
+// of the per-component solves is a dependent L2 round trip (964 of 2315 kcycles of the frame step); 16 per row (80 KB) fit in LDS and the largest row of that
+// scene has 9 candidates.  A row that overflows the shorter stride repeats the association with the full one.
 template <class ColFn, class CostFn>
+#ifdef Y7T_NEXT_TRACKER
+Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost, const int MC) {
+#else
 Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
+    constexpr int MC = Y7T_MAXC;
+#endif
     const int tid = ex.tid, nt = ex.nt;
 #ifdef Y7T_ALWAYS_LITERAL
     return 2;
@@ -202,7 +211,7 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
     // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
     const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
-    const size_t list_bytes = (size_t)na * Y7T_MAXC * (sizeof(int) + sizeof(double));
+    const size_t list_bytes = (size_t)na * MC * (sizeof(int) + sizeof(double));
     const size_t T = (size_t)s.h->cfg.cap_t, D = (size_t)s.h->cfg.cap_d, blob_bytes = T * (T > D ? T : D) * sizeof(double);
     char* wbase = (char*)s.cost;
     char* lbase = (char*)s.cost + ((work_bytes + 63) & ~(size_t)63);
@@ -225,7 +234,7 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
     int* flag = nextcol + nb;                                 // [3] overflow / at-limit pair, changed, duplicate cost inside a component
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
-    int* ccol = (int*)(ccost + (size_t)na * Y7T_MAXC);        // [na][MAXC] candidate columns
+    int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
     if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; }
@@ -241,7 +250,7 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
                 if (c >= thresh - Y7T_TIE_EPS) { flag[0] = 1; Y7T_TIE_REASON(4); }      // exactly at the limit: the optimum is not unique -> dense path, lapjv's own order
                 if (c <= thresh) {
                     const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
-                    if (k < Y7T_MAXC) { ccol[(size_t)i * Y7T_MAXC + k] = j; ccost[(size_t)i * Y7T_MAXC + k] = c; }
+                    if (k < MC) { ccol[(size_t)i * MC + k] = j; ccost[(size_t)i * MC + k] = c; }
                     else flag[0] = 1;
                     Y7T_FETCH_ADD(colcnt + j, 1);
                 }
@@ -253,8 +262,8 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     Y7T_SPROF(1);
     if (flag[0]) return 0;
     for (int i = tid; i < na; i += nt) {                      // sort each row's candidates by column (insertion sort, <= MAXC entries)
-        int* cc = ccol + (size_t)i * Y7T_MAXC;
-        double* cw = ccost + (size_t)i * Y7T_MAXC;
+        int* cc = ccol + (size_t)i * MC;
+        double* cw = ccost + (size_t)i * MC;
         const int n = rowcnt[i];
         for (int a = 1; a < n; ++a) {
             const int cj = cc[a]; const double cv = cw[a];
@@ -270,9 +279,9 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     // ---- 2. forced decisions ----
     for (int i = tid; i < na; i += nt) {
         if (rowcnt[i] == 0) x[i] = nb;                        // null column
-        else if (rowcnt[i] == 1 && colcnt[ccol[(size_t)i * Y7T_MAXC]] == 1) {
-            const int j = ccol[(size_t)i * Y7T_MAXC];
-            const double red = ccost[(size_t)i * Y7T_MAXC] - thresh;
+        else if (rowcnt[i] == 1 && colcnt[ccol[(size_t)i * MC]] == 1) {
+            const int j = ccol[(size_t)i * MC];
+            const double red = ccost[(size_t)i * MC] - thresh;
             if (red < 0.0) { x[i] = j; y[j] = i; v[j] = red; }
         }
     }
@@ -282,13 +291,13 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     for (int it = 0; it < na + 2; ++it) {
         for (int i = tid; i < na; i += nt)
             if (x[i] == -1)
-                for (int k = 0; k < rowcnt[i]; ++k) Y7T_ATOMIC_MIN_I(collab + ccol[(size_t)i * Y7T_MAXC + k], rowlab[i]);
+                for (int k = 0; k < rowcnt[i]; ++k) Y7T_ATOMIC_MIN_I(collab + ccol[(size_t)i * MC + k], rowlab[i]);
         if (tid == 0) flag[1] = 0;
         y7t_sync(ex);
         for (int i = tid; i < na; i += nt)
             if (x[i] == -1) {
                 int m = rowlab[i];
-                for (int k = 0; k < rowcnt[i]; ++k) { const int l = collab[ccol[(size_t)i * Y7T_MAXC + k]]; m = l < m ? l : m; }
+                for (int k = 0; k < rowcnt[i]; ++k) { const int l = collab[ccol[(size_t)i * MC + k]]; m = l < m ? l : m; }
                 if (m != rowlab[i]) { rowlab[i] = m; flag[1] = 1; }
             }
         y7t_sync(ex);
@@ -306,10 +315,10 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
                 bool dup = false;
                 for (int ia = 0; ia < ncr && !dup; ++ia)
                     for (int pq = 0; pq < rowcnt[crow[ia]] && !dup; ++pq) {
-                        const double ca = ccost[(size_t)crow[ia] * Y7T_MAXC + pq];
-                        for (int q = pq + 1; q < rowcnt[crow[ia]]; ++q) dup |= (ccost[(size_t)crow[ia] * Y7T_MAXC + q] == ca);
+                        const double ca = ccost[(size_t)crow[ia] * MC + pq];
+                        for (int q = pq + 1; q < rowcnt[crow[ia]]; ++q) dup |= (ccost[(size_t)crow[ia] * MC + q] == ca);
                         for (int ib = ia + 1; ib < ncr; ++ib)
-                            for (int q = 0; q < rowcnt[crow[ib]]; ++q) dup |= (ccost[(size_t)crow[ib] * Y7T_MAXC + q] == ca);
+                            for (int q = 0; q < rowcnt[crow[ib]]; ++q) dup |= (ccost[(size_t)crow[ib] * MC + q] == ca);
                     }
                 if (dup) { flag[2] = 1; Y7T_TIE_REASON(5); }
             }
@@ -320,8 +329,8 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
             double d_null = 0.0; int pred_null = start;
             int touched = -1;
             for (int k = 0; k < rowcnt[start]; ++k) {
-                const int j = ccol[(size_t)start * Y7T_MAXC + k];
-                dd[j] = ccost[(size_t)start * Y7T_MAXC + k] - thresh - v[j]; pred[j] = start; st[j] = 1; nextcol[j] = touched; touched = j;
+                const int j = ccol[(size_t)start * MC + k];
+                dd[j] = ccost[(size_t)start * MC + k] - thresh - v[j]; pred[j] = start; st[j] = 1; nextcol[j] = touched; touched = j;
             }
             int final_j = -2; double mind = 0.0;
             for (;;) {
@@ -333,12 +342,12 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
                 st[mj] = 2;
                 const int i = y[mj];
                 double cij = 0.0;
-                for (int k = 0; k < rowcnt[i]; ++k) if (ccol[(size_t)i * Y7T_MAXC + k] == mj) cij = ccost[(size_t)i * Y7T_MAXC + k];
+                for (int k = 0; k < rowcnt[i]; ++k) if (ccol[(size_t)i * MC + k] == mj) cij = ccost[(size_t)i * MC + k];
                 const double hh = cij - thresh - v[mj] - mind;
                 for (int k = 0; k < rowcnt[i]; ++k) {
-                    const int j = ccol[(size_t)i * Y7T_MAXC + k];
+                    const int j = ccol[(size_t)i * MC + k];
                     if (st[j] == 2) continue;
-                    const double cred = ccost[(size_t)i * Y7T_MAXC + k] - thresh - v[j] - hh;
+                    const double cred = ccost[(size_t)i * MC + k] - thresh - v[j] - hh;
                     if (st[j] == 0) { dd[j] = cred; pred[j] = i; st[j] = 1; nextcol[j] = touched; touched = j; }
                     else if (cred < dd[j]) { dd[j] = cred; pred[j] = i; }
                 }
@@ -367,6 +376,24 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     y7t_sync(ex);
     return 1;
 }
+
+#ifdef Y7T_NEXT_TRACKER
+template <class ColFn, class CostFn>
+Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
+    int mc = Y7T_MAXC;
+    if (ex.fast && work_bytes + 64 <= ex.fast_bytes)
+        while (mc > 8 && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc -= 4;      // 24, 20, 16, 12, 8
+    if (mc < Y7T_MAXC && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc = Y7T_MAXC;      // nothing fits: as before
+#ifndef Y7T_NEXT_STAT
+#define Y7T_NEXT_STAT(k) do { } while (0)
+#endif
+    if (mc < Y7T_MAXC) Y7T_NEXT_STAT(0);                    // (host build: how often the short stride is used / has to be repeated)
+    int r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, cost, mc);
+    if (r == 0 && mc < Y7T_MAXC) { Y7T_NEXT_STAT(1); y7t_sync(ex); r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, cost, Y7T_MAXC); }
+    return r;
+}
+#endif
 
 // the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
 Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
