@@ -19,10 +19,9 @@ def build(force=False):
     deps = [_SRC, os.path.join(_CSRC, "y7t_track_core.h"), os.path.join(_CSRC, "y7t_track_step.h"), os.path.join(_CSRC, "y7t_track_deepsort.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + _DEFS + ["-o", _SO, _SRC])
-    fast = os.environ.get("Y7T_HOSTSIM_FAST_BYTES")
-    if fast:                                  # give the programs a fast scratch of this size (the device's is 131072)
-        L = ctypes.CDLL(_SO)
-        L.hs_set_fast_bytes(int(fast))
+    # the workgroup's fast scratch: 131072 bytes like the device's LDS budget (csrc/y7t_tracker.hip: kFastBytes), so the placement branches taken here are
+    # the ones the GPU takes; Y7T_HOSTSIM_FAST_BYTES=0 runs everything out of the state blob (the other branches), any other value sizes it
+    ctypes.CDLL(_SO).hs_set_fast_bytes(int(os.environ.get("Y7T_HOSTSIM_FAST_BYTES", "131072")))
     return _SO
 
 
