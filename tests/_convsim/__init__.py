@@ -1,0 +1,49 @@
+"""tests/_convsim -- TEST INFRASTRUCTURE ONLY: the implicit-GEMM convolution kernel of csrc/y7t_conv.hip compiled for the CPU from its real source and run
+work-item by work-item (fake/hip/hip_runtime.h models the gfx950 builtins it uses; runtime.inc runs workgroups as OS threads).  Checks the kernel's index
+arithmetic against a plain convolution where no GPU exists, for the shipped 4-wave build and for experimental builds (macros).  Never imported by the product."""
+import ctypes
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_CSRC = os.path.join(_ROOT, "yolov7-tracker_amd", "csrc")
+_CLANG = os.environ.get("Y7T_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")      # ext_vector_type / _Float16: clang, compiling for the host
+_libs = {}
+
+
+def build(defs=()):
+    tag = "".join(c for c in "".join(defs) if c.isalnum()) or "default"
+    bdir = os.path.join(_HERE, "build_" + tag)
+    so = os.path.join(bdir, "libconvsim.so")
+    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h")]
+    deps = srcs + [os.path.join(_HERE, "runtime.inc"), os.path.join(_HERE, "fake", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
+    if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+        return so
+    os.makedirs(bdir, exist_ok=True)
+    text = open(srcs[0]).read()
+    text, n = re.subn(r"asm volatile\([^;]*\);", ";", text)          # the s_waitcnt statements: loads complete at once here
+    assert n == 3, n
+    common = open(srcs[1]).read()
+    common = common.replace("#define GLOBAL_AS __attribute__((address_space(1)))", "#define GLOBAL_AS").replace(
+        "#define LDS_AS __attribute__((address_space(3)))", "#define LDS_AS")
+    assert "address_space" not in common
+    open(os.path.join(bdir, "y7t_conv_common.h"), "w").write(common)
+    open(os.path.join(bdir, "convsim.cpp"), "w").write(text + "\n" + open(os.path.join(_HERE, "runtime.inc")).read())
+    cmd = [_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-I", os.path.join(_HERE, "fake"), "-I", _CSRC,
+           "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp")]
+    subprocess.check_call(cmd)
+    return so
+
+
+def lib(defs=()):
+    key = tuple(defs)
+    if key not in _libs:
+        L = ctypes.CDLL(build(defs))
+        L.cs_last_error.restype = ctypes.c_char_p
+        L.cs_last_kernel.restype = ctypes.c_char_p
+        L.cs_conv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_int] * 10
+        _libs[key] = L
+    return _libs[key]

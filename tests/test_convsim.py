@@ -1,0 +1,103 @@
+"""CPU: the implicit-GEMM convolution kernel of csrc/y7t_conv.hip, compiled for the host FROM ITS REAL SOURCE and run work-item by work-item
+(tests/_convsim: OS threads per work-item, pthread barriers, models of the gfx950 builtins -- buffer->LDS DMA with the hardware range check,
+v_mfma_f32_32x32x16_f16, v_permlane32_swap), against a plain convolution.  What this pins without a GPU: load geometry, LDS swizzle, MFMA fragment
+mapping, K orders, ragged K, slices, split-K, the epilogue's transposition, the tile order -- for the shipped 4-wave build and for the experimental
+builds that have not run on a GPU yet (8-wave workgroups, split-K reduced by the last arriver).  The `-m gpu` layer tests remain the check of the real thing."""
+import numpy as np
+import pytest
+import torch
+
+from tests import _convsim as cs
+
+pytestmark = pytest.mark.skipif(not __import__("os").path.exists(cs._CLANG), reason="needs the ROCm clang++ (host compile of the kernel source)")
+
+
+def pack_w(W, cin_pad, cout_pad, korder=0):
+    cout, cin, k, _ = W.shape
+    K = k * k * cin_pad
+    Kp = (K + 63) // 64 * 64
+    Wt = np.zeros((cout, k, k, cin_pad), np.float32)
+    Wt[..., :cin] = W.transpose(0, 2, 3, 1)
+    if korder == 1:      # (kh, 64-channel chunk, kw) K order
+        Wt = Wt.reshape(cout, k, k, cin_pad // 64, 64).transpose(0, 1, 3, 2, 4)
+    blk = np.zeros((cout_pad, Kp), np.float16)
+    blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
+    return blk
+
+
+def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_ld=None, out_coff=0, out_f32=0, korder=0, splitk=0, seed=0):
+    in_ld, out_ld = in_ld or Cin, out_ld or Cout
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
+    Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = rng.normal(0, 0.5, Cout).astype(np.float32)
+    cp = (Cout + 63) // 64 * 64
+    wp = pack_w(Wt, Cin, cp, korder)
+    bp = np.zeros(cp, np.float32)
+    bp[:Cout] = bias
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    out = np.full((B, Ho, Wo, out_ld), 7.0, np.float32 if out_f32 else np.float16)
+    rc = L.cs_conv(x.ctypes.data, in_ld, in_coff, B, H, W, Cin, wp.ctypes.data, bp.ctypes.data, out.ctypes.data, out_ld, out_coff, out_f32, Cout, cp, k, k, s, pad,
+                   act, korder, tile, splitk)
+    assert rc == 0, L.cs_last_error().decode()
+    xt = torch.from_numpy(x[..., in_coff:in_coff + Cin].astype(np.float32)).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xt, torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias), s, pad)
+    ref = ref * torch.sigmoid(ref) if act == 1 else torch.where(ref > 0, ref, 0.1 * ref) if act == 2 else ref
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    got = out[..., out_coff:out_coff + Cout].astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)       # fp16 output rounding (2^-11) + the summation order
+    other = np.ones(out_ld, bool)
+    other[out_coff:out_coff + Cout] = False
+    assert np.all(out[..., other] == 7.0)                            # nothing outside the slice is written
+    return L.cs_last_kernel().decode()
+
+
+# B, H, W, Cin, Cout, k, s, act, tile, extras -- shapes that exercise every branch of the generic kernel on a few workgroups
+CASES = [
+    (1, 12, 12, 64, 128, 3, 1, 1, 128128064, {}),
+    (1, 10, 14, 64, 64, 3, 2, 1, 128064064, {}),                                       # stride 2, 64-channel tile, ragged image edge
+    (2, 9, 9, 128, 128, 1, 1, 1, 128128032, {}),                                       # 1x1 fast path, 32-deep stages
+    (1, 16, 16, 16, 64, 3, 1, 1, 256064032, {}),                                       # stem-like: Cin = 16, K = 144 (ragged K)
+    (1, 8, 8, 96, 192, 1, 1, 2, 0, {"in_ld": 256, "in_coff": 64, "out_ld": 384, "out_coff": 192}),      # slices of wider buffers, LeakyReLU, dispatch rules
+    (1, 8, 8, 256, 45, 1, 1, 0, 0, {"out_ld": 45, "out_f32": 1}),                      # Detect head (plain): fp32 out, Cout not a multiple of 4
+    (1, 11, 9, 128, 128, 3, 1, 1, 128128064, {"korder": 1}),                          # (kh, chunk, kw) K order
+    (1, 13, 11, 192, 64, 3, 2, 1, 128064064, {"korder": 1, "in_ld": 256, "in_coff": 64}),
+    (1, 17, 17, 64, 256, 3, 1, 1, 256256064, {}),                                      # the 256 x 256 tile
+    (1, 10, 10, 128, 128, 3, 1, 1, 128128064, {"splitk": 1}),                          # split-K + k_splitk_reduce
+    (1, 12, 12, 64, 128, 3, 1, 1, 128128364, {}),                                      # three-stage ring
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_%d-%d_k%ds%d_t%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8]))
+def test_shipped_kernel_source_on_the_host(case):
+    B, H, W, Cin, Cout, k, s, act, tile, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, k, s, act, tile, **kw)
+    assert name.startswith("igemm<") and (tile == 0 or ("splitK" in name) == bool(kw.get("splitk")))      # (the dispatch rules split K of small problems themselves)
+
+
+def test_eight_wave_experiment_on_the_host():
+    """-DY7T_IGEMM_NW=8 (512-thread workgroups; scripts/ablate/build_experiments.py nw8), not yet run on a GPU: same results as the 4-wave build"""
+    L8 = cs.lib(("-DY7T_IGEMM_NW=8",))
+    assert L8.cs_waves() == 8
+    for B, H, W, Cin, Cout, k, s, tile, kw in [(1, 17, 17, 64, 256, 3, 1, 256256064, {}), (1, 23, 19, 128, 256, 1, 1, 256256064, {}),
+                                               (1, 20, 20, 64, 128, 3, 2, 256128064, {}), (2, 9, 9, 64, 128, 3, 1, 128128064, {"korder": 1}),
+                                               (1, 9, 9, 128, 128, 1, 1, 128128032, {}), (1, 10, 10, 128, 256, 3, 1, 256256064, {"splitk": 1}),
+                                               (1, 9, 13, 192, 128, 3, 1, 0, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64})]:
+        run_case(L8, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
+
+
+def test_split_k_reduced_by_the_last_arriver_on_the_host():
+    """-DY7T_SPLITK_FIXUP with allow_splitk = 2: no k_splitk_reduce launch, the tile's last workgroup sums the slabs in split order -> the same bits as the
+    reduce kernel; the arrival counters are left at zero (second launch).  (Workgroups run one after the other here: the memory-ordering side -- fences,
+    cross-XCD visibility -- is what the GPU run has to show.)"""
+    LF = cs.lib(("-DY7T_SPLITK_FIXUP=1",))
+    for rep in range(2):
+        n0 = LF.cs_workgroups_run()
+        name = run_case(LF, 1, 12, 12, 1024, 128, 1, 1, 2, 128128064, splitk=2)
+        n_fix = LF.cs_workgroups_run() - n0
+        assert "splitK" in name
+        n0 = LF.cs_workgroups_run()
+        run_case(LF, 1, 12, 12, 1024, 128, 1, 1, 2, 128128064, splitk=1)
+        assert LF.cs_workgroups_run() - n0 > n_fix          # the reduce kernel's workgroups are gone
+    run_case(LF, 1, 10, 10, 128, 128, 3, 1, 1, 128128064, splitk=2, out_ld=192, out_coff=64)
