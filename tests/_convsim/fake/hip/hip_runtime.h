@@ -46,6 +46,8 @@ void cs_launch(const std::function<void()>& kernel, dim3 grid, dim3 block);
 #define __syncthreads() cs_wg_barrier()
 #define __builtin_amdgcn_s_barrier() cs_wg_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)          /* (only applied to wave-uniform values) */
 #define __threadfence() ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)

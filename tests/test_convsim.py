@@ -22,10 +22,13 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
         Wt = Wt.reshape(cout, k, k, cin_pad // 64, 64).transpose(0, 1, 3, 2, 4)
     blk = np.zeros((cout_pad, Kp), np.float16)
     blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
+    if korder == 2:      # the patch kernel's panel order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack(blk, cin_pad)
     return blk
 
 
-def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_ld=None, out_coff=0, out_f32=0, korder=0, splitk=0, seed=0):
+def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_ld=None, out_coff=0, out_f32=0, korder=0, splitk=0, seed=0, force_patch=0):
     in_ld, out_ld = in_ld or Cin, out_ld or Cout
     rng = np.random.default_rng(seed)
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
@@ -39,7 +42,7 @@ def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     out = np.full((B, Ho, Wo, out_ld), 7.0, np.float32 if out_f32 else np.float16)
     rc = L.cs_conv(x.ctypes.data, in_ld, in_coff, B, H, W, Cin, wp.ctypes.data, bp.ctypes.data, out.ctypes.data, out_ld, out_coff, out_f32, Cout, cp, k, k, s, pad,
-                   act, korder, tile, splitk)
+                   act, korder, tile, splitk, force_patch)
     assert rc == 0, L.cs_last_error().decode()
     xt = torch.from_numpy(x[..., in_coff:in_coff + Cin].astype(np.float32)).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xt, torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias), s, pad)
@@ -101,3 +104,20 @@ def test_split_k_reduced_by_the_last_arriver_on_the_host():
         run_case(LF, 1, 12, 12, 1024, 128, 1, 1, 2, 128128064, splitk=1)
         assert LF.cs_workgroups_run() - n0 > n_fix          # the reduce kernel's workgroups are gone
     run_case(LF, 1, 10, 10, 128, 128, 3, 1, 1, 128128064, splitk=2, out_ld=192, out_coff=64)
+
+
+# the LDS-patch kernels (csrc/y7t_conv_patch.hip; 3x3 / stride 1): B, H, W, Cin, Cout, act, korder, extras -- forced onto the patch kernel like the GPU layer tests
+PATCH_CASES = [
+    (1, 24, 32, 64, 128, 1, 0, {}),                                                   # 16x16 tiles, 128-channel panels
+    (1, 16, 40, 128, 64, 2, 1, {"in_ld": 192, "in_coff": 64}),                        # 64-channel panels (multi-tile workgroups when forced), input slice
+    (1, 37, 53, 64, 128, 1, 2, {"out_ld": 192, "out_coff": 64}),                      # ragged edges, panel-packed weights, output slice
+    (2, 40, 40, 64, 128, 1, 2, {}),                                                   # strip tiling of the 40-wide map
+    (3, 20, 20, 128, 64, 1, 1, {}),                                                   # strip tiling, 20-wide, 64 channels
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "%dx%dx%d_%d-%d_o%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
+def test_patch_kernel_source_on_the_host(case):
+    B, H, W, Cin, Cout, act, korder, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=1, **kw)
+    assert name.startswith("patch"), name
