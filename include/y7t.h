@@ -159,7 +159,8 @@ typedef struct y7t_op {
     int32_t KH, KW, stride, pad;        /* conv / pool window */
     int32_t K, K_pad;
     int32_t act;                        /* 0 none, 1 SiLU, 2 LeakyReLU(0.1) */
-    int32_t korder;                     /* weight packing: 0 k = (kh*KW+kw)*Cin + ci; 1 (kh, 64-ch chunk, kw); 2 LDS-patch panels; 3 1x1 panels */
+    int32_t korder;                     /* weight packing: 0 k = (kh*KW+kw)*Cin + ci; 1 (kh, 64-ch chunk, kw); 2 LDS-patch panels; 3 1x1 panels;
+                                           4 stride-2 LDS-patch panels (opt-in experiment, detector/weights.py::panel_pack_s2) */
     int32_t detect_level;               /* -1: ordinary layer.  l >= 0: the 1x1 conv of Detect level l (models/yolo.py:46); in a fused forward
                                            (y7t_det_forward_fused) its epilogue decodes + filters instead of writing the head tensor */
     int64_t w_off;                      /* element offset into the fp16 weight blob */

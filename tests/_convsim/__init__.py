@@ -17,7 +17,7 @@ def build(defs=()):
     tag = "".join(c for c in "".join(defs) if c.isalnum()) or "default"
     bdir = os.path.join(_HERE, "build_" + tag)
     so = os.path.join(bdir, "libconvsim.so")
-    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip")]
+    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip")]
     deps = srcs + [os.path.join(_HERE, "runtime.inc"), os.path.join(_HERE, "fake", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
     if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
@@ -37,8 +37,14 @@ def build(defs=()):
     patch, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", patch)
     assert n >= 1
     open(os.path.join(bdir, "convsim_patch.cpp"), "w").write(patch)
+    s2 = re.sub(r"asm volatile\([^;]*\);", ";", open(srcs[5]).read())          # the stride-2 patch kernel (opt-in experiment): same treatment
+    assert "asm" not in s2
+    s2, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", s2)
+    assert n == 1
+    open(os.path.join(bdir, "convsim_patch_s2.cpp"), "w").write(s2)
     cmd = [_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-I", os.path.join(_HERE, "fake"), "-I", _CSRC,
-           "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp"), os.path.join(bdir, "convsim_patch.cpp")]
+           "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp"), os.path.join(bdir, "convsim_patch.cpp"),
+                                                                          os.path.join(bdir, "convsim_patch_s2.cpp")]
     subprocess.check_call(cmd)
     return so
 

@@ -25,6 +25,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder == 2:      # the patch kernel's panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack(blk, cin_pad)
+    if korder == 4:      # the stride-2 patch kernel's panel order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_s2(blk, cin_pad)
     return blk
 
 
@@ -34,7 +37,7 @@ def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    cp = (Cout + 63) // 64 * 64
+    cp = (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
     wp = pack_w(Wt, Cin, cp, korder)
     bp = np.zeros(cp, np.float32)
     bp[:Cout] = bias
@@ -121,3 +124,34 @@ def test_patch_kernel_source_on_the_host(case):
     B, H, W, Cin, Cout, act, korder, kw = case
     name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=1, **kw)
     assert name.startswith("patch"), name
+
+
+# the stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; opt-in experiment, korder 4): B, H, W, Cin, Cout, act, extras
+S2_CASES = [
+    (1, 16, 32, 64, 128, 1, {}),                                                      # one full 8 x 16 output tile, 128-channel panels (6-slot weight ring)
+    (1, 16, 32, 64, 256, 1, {}),                                                      # 256-channel panels (3-slot ring, four waves along the channels)
+    (2, 23, 45, 128, 128, 2, {"in_ld": 192, "in_coff": 64, "out_ld": 192, "out_coff": 64}),   # odd sizes: ragged tiles on both edges, slices, LeakyReLU
+    (1, 20, 20, 64, 384, 1, {}),                                                      # Cout_pad = 384: 128-channel panels, three channel tiles
+    (1, 18, 34, 192, 248, 0, {"out_ld": 256}),                                        # Cout not a multiple of the panel (padded rows), six chunk pairs, no activation
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "%dx%dx%d_%d-%d" % (c[0], c[1], c[2], c[3], c[4]))
+def test_stride2_patch_kernel_source_on_the_host(case):
+    """csrc/y7t_conv_patch_s2.hip (parity-split patch columns, 16-channel chunks, panel-packed weights) has not run on a GPU yet: its load geometry,
+    plane addressing, ring positions and epilogue against a plain stride-2 convolution"""
+    B, H, W, Cin, Cout, act, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, **kw)
+    cp = (Cout + 127) // 128 * 128
+    assert name == "patch_s2<%d>" % (256 if cp % 256 == 0 else 128), name
+
+
+def test_stride2_patch_kernel_rejects_what_it_cannot_run():
+    """korder 4 weights are readable by the stride-2 patch kernel only: a stride-1 layer carrying them is an error, not a silent fallback"""
+    L = cs.lib()
+    x = np.zeros((1, 8, 8, 64), np.float16)
+    w = np.zeros((128, 576), np.float16)
+    b = np.zeros(128, np.float32)
+    out = np.zeros((1, 8, 8, 128), np.float16)
+    rc = L.cs_conv(x.ctypes.data, 64, 0, 1, 8, 8, 64, w.ctypes.data, b.ctypes.data, out.ctypes.data, 128, 0, 0, 128, 128, 3, 3, 1, 1, 1, 4, 0, 0, 0)
+    assert rc != 0 and b"korder 4" in L.cs_last_error()

@@ -37,6 +37,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 3:   # 1x1 panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_linear(blk)
+    if korder == 4:   # stride-2 patch-kernel panel order (opt-in experiment)
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_s2(blk, cin_pad)
     return blk
 
 
@@ -91,8 +94,8 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    cout_pad = (Cout + 63) // 64 * 64
-    korder = 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    korder = 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    cout_pad = (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful
@@ -118,6 +121,27 @@ def test_conv_layer_matches_torch_fp32(L, case):
     # nothing outside the output slice may be touched
     mask = np.ones(out_ld, bool); mask[out_coff:out_coff + Cout] = False
     assert np.all(got[..., mask] == 7.0)
+
+
+# csrc/y7t_conv_patch_s2.hip (stride-2 LDS-patch kernel) is an opt-in experiment that had not run on a GPU when it was committed (end of round 2, no GPU
+# minutes left; tests/test_convsim.py runs its source on the host).  Its device tests run only on request, so that the default suite stays what was verified:
+#     Y7T_TEST_EXPERIMENTS=1 python -m pytest tests/test_detector_gpu.py -m gpu -k stride2
+#     Y7T_CONV_PATCH_S2=1 python -m pytest tests/test_detector_pinned_gpu.py -m gpu          (the whole launch list, teacher-forced against the oracle)
+S2_CASES = [
+    # B, H, W, Cin, Cout, k, s, act (bit 12: korder 4), in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 16, 32, 64, 128, 3, 2, 1 | 4096, 64, 0, 128, 0, 0),
+    (2, 46, 90, 128, 256, 3, 2, 1 | 4096, 192, 64, 320, 64, 0),
+    (4, 80, 80, 256, 384, 3, 2, 1 | 4096, 256, 0, 384, 0, 0),
+    (2, 41, 37, 192, 248, 3, 2, 2 | 4096, 192, 0, 256, 0, 0),
+    (8, 160, 160, 64, 128, 3, 2, 1 | 4096, 64, 0, 128, 0, 0),
+    (2, 40, 40, 768, 1024, 3, 2, 1 | 4096, 768, 0, 1024, 0, 0),
+]
+
+
+@pytest.mark.skipif(os.environ.get("Y7T_TEST_EXPERIMENTS") != "1", reason="opt-in experiment (Y7T_TEST_EXPERIMENTS=1): not part of the verified default suite")
+@pytest.mark.parametrize("case", S2_CASES)
+def test_stride2_patch_kernel_matches_torch_fp32(L, case):
+    test_conv_layer_matches_torch_fp32(L, case)
 
 
 def build(name, nc, hw, B, seed=0):

@@ -176,6 +176,38 @@ def test_weight_panel_packings_are_permutations_with_the_documented_layout():
             assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
 
 
+def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
+    """CPU: korder 4 (csrc/y7t_conv_patch_s2.hip, opt-in experiment): the packing is a permutation with slot s of row r = channel octet s ^ ((r >> 3) & 1) of the
+    K-step's 16 channels; the default lowering of yolov7-w6 contains no korder-4 op, with Y7T_CONV_PATCH_S2=1 exactly the eight stride-2 3x3 layers with
+    Cin % 64 == 0 carry it (the stem's successor 64 -> 128 included) and nothing else changes"""
+    import numpy as np
+    from yolov7_tracker_amd.detector import arch, graph, weights
+    rng = np.random.default_rng(0)
+    for cout_pad, cin in ((128, 64), (256, 128), (384, 64), (512, 192)):
+        blk = rng.permutation(cout_pad * 9 * cin).astype(np.float64).reshape(cout_pad, 9 * cin)
+        out = weights.panel_pack_s2(blk, cin)
+        assert out.shape == blk.shape and np.array_equal(np.sort(out.ravel()), np.sort(blk.ravel()))
+        BN, nc16 = (256 if cout_pad % 256 == 0 else 128), cin // 16
+        flat = out.ravel()
+        for tile, c, tap, r, s in ((0, 0, 0, 0, 0), (cout_pad // BN - 1, nc16 - 1, 8, BN - 1, 1), (0, 1, 4, 37, 1), (0, nc16 - 1, 7, 21, 0), (0, 2, 3, 8, 0)):
+            o = ((((tile * nc16 + c) * 9 + tap) * BN + r) * 2 + s) * 8
+            k = tap * cin + c * 16 + (s ^ ((r >> 3) & 1)) * 8
+            assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
+    base = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    assert not any(int(op["korder"]) == 4 for op in base.ops)
+    monkeypatch.setenv("Y7T_CONV_PATCH_S2", "1")
+    exp = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    assert len(exp.ops) == len(base.ops)
+    changed = [(a, b) for a, b in zip(base.ops, exp.ops) if int(a["korder"]) != int(b["korder"])]
+    assert len(changed) == 8 and all(int(b["korder"]) == 4 and int(b["stride"]) == 2 and int(b["KH"]) == 3 and int(b["Cin"]) % 64 == 0 for _, b in changed)
+    for a, b in zip(base.ops, exp.ops):
+        for f in a.dtype.names:
+            assert f == "korder" or a[f] == b[f]
+    monkeypatch.setenv("Y7T_CONV_PATCH_S2_MIN_COUT", "256")
+    wide = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    assert sum(int(op["korder"]) == 4 for op in wide.ops) == 7          # all but the 64 -> 128 layer at 640x640
+
+
 def test_patch_eligibility_rule():
     """the Python mirror of the dispatcher's rule for the LDS-patch kernel (detector/graph.py::patch_eligible)"""
     from yolov7_tracker_amd.detector import graph

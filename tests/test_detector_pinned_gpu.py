@@ -19,6 +19,7 @@ default), i.e. the launch list bench.py times: LDS-patch / multi-tile / strip ke
   trained one.  Same kernels, same launch list -- only the numbers in the weight blob differ.
 """
 import collections
+import os
 
 import numpy as np
 import pytest
@@ -82,7 +83,10 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     fam = collections.Counter(n.split("<")[0] for n in names)
     # the kernel families 45 % of the bench's conv time runs on (profiles/r01_bench_kernel_stats.csv) are all in this list
     assert fam["patch"] >= 10 and fam["patch_mt"] >= 4 and fam["patch_strip"] >= 8, fam
-    assert any(n.startswith("igemm<256,") for n in names), hist         # 256-pixel tiles (stride-2 layers on the big maps)
+    if os.environ.get("Y7T_CONV_PATCH_S2", "0") == "1":                  # opt-in experiment: the eight down-sampling layers on csrc/y7t_conv_patch_s2.hip
+        assert fam["patch_s2"] == (8 if os.environ.get("Y7T_CONV_PATCH_S2_MIN_COUT", "128") == "128" else 7), fam
+    else:
+        assert any(n.startswith("igemm<256,") for n in names), hist     # 256-pixel tiles (stride-2 layers on the big maps)
     assert names[0] == "stem_u8<direct>", names[0]                       # uint8 frame -> stem conv in one kernel
     assert any(n.startswith("igemm<128,128,32,2> 1x1") for n in names), hist
     assert sum("upsample-on-read" in n for n in names) == 3 and "upsample2x" not in names, hist

@@ -602,6 +602,7 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 }
 
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
+int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
 #if Y7T_IGEMM_NW == 8      // experimental library: 512-thread workgroups, 64-deep stages, 256 x 256 / 256 x 128 / 128 x 128 tiles only (layer-level timing and tests)
@@ -628,6 +629,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         }
         return a.Cout_pad % 128 == 0 ? launch_conv_ut<128, 128, 32, 2, true, 1, 0, true>(a, s) : launch_conv_ut<128, 64, 32, 2, true, 1, 0, true>(a, s);
     }
+    if (a.korder == 4) return y7t_conv_patch_s2_launch(a, s);   // stride-2 LDS-patch kernel's panels: only that kernel reads them
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);

@@ -151,6 +151,19 @@ def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 2
     return max(eff(16, 16), eff(32, 8), eflat) >= 0.8
 
 
+def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32):
+    """mirror of y7t_conv_patch_s2_launch (csrc/y7t_conv_patch_s2.hip), which is OPT-IN: only with Y7T_CONV_PATCH_S2=1 in the environment when the plan is
+    lowered (the kernel has not been measured on a GPU yet; the default launch list keeps the generic kernel for the down-sampling layers).
+    Y7T_CONV_PATCH_S2_MIN_COUT (default 128) restricts it to the wider layers (256: only those that get 256-channel panels)."""
+    if os.environ.get("Y7T_CONV_PATCH_S2", "0") != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+        return False
+    cout_pad = -(-cout // 64) * 64
+    if cout_pad < int(os.environ.get("Y7T_CONV_PATCH_S2_MIN_COUT", "128")):
+        return False
+    return (k == 3 and s == 2 and p == 1 and cin % 64 == 0 and cout_pad % 128 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0
+            and out_coff % 8 == 0)
+
+
 def lower(nodes, H, W, max_batch=1):
     det = next(n for n in nodes if n.kind == "detect")
     # ---- liveness: only what reaches the (main) Detect inputs ----
@@ -269,6 +282,8 @@ def lower(nodes, H, W, max_batch=1):
         korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
         if patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
+        elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32):
+            korder = 4                               # opt-in experiment: stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level

@@ -140,6 +140,28 @@ def panel_pack_linear(blk):
     return np.ascontiguousarray(a).reshape(cout_pad, K)
 
 
+def s2_panel_width(cout_pad):
+    """panel width of the stride-2 patch kernel for a layer (csrc/y7t_conv_patch_s2.hip::s2_bn, same rule)"""
+    import os
+    return 256 if cout_pad % 256 == 0 and os.environ.get("Y7T_CONV_PATCH_S2_BN", "") != "128" else 128
+
+
+def panel_pack_s2(blk, cin_pad):
+    """[Cout_pad][K_pad] block with k = (kh*3 + kw)*Cin + ci  ->  the STRIDE-2 patch kernel's panel order (csrc/y7t_conv_patch_s2.hip, korder 4):
+    [n-tile of BN rows][K-step = 16-channel chunk * 9 + tap][row][two 16-byte slots], slot s of row r holding channel octet s ^ ((r >> 3) & 1)
+    of the chunk -- the image the kernel's buffer->LDS DMA leaves in LDS.  BN = 256 when Cout_pad allows, else 128."""
+    cout_pad, K = blk.shape
+    assert K == 9 * cin_pad and cin_pad % 64 == 0 and cout_pad % 128 == 0
+    BN = s2_panel_width(cout_pad)
+    nc16 = cin_pad // 16
+    a = blk.reshape(cout_pad // BN, BN, 9, nc16, 2, 8)           # [tile][row][tap][chunk][octet][8]
+    a = a.transpose(0, 3, 2, 1, 4, 5)                            # [tile][chunk][tap][row][octet][8]
+    r = np.arange(BN)
+    src = np.arange(2)[None, :] ^ ((r[:, None] >> 3) & 1)        # slot s of row r <- octet s ^ ((r >> 3) & 1)
+    a = np.take_along_axis(a, src[None, None, None, :, :, None], axis=4)
+    return np.ascontiguousarray(a).reshape(cout_pad, K)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -159,6 +181,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = panel_pack(blk, w["cin_pad"])
         elif w.get("korder") == 3:
             blk = panel_pack_linear(blk)
+        elif w.get("korder") == 4:
+            blk = panel_pack_s2(blk, w["cin_pad"])
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
