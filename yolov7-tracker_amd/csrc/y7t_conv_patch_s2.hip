@@ -113,8 +113,12 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
     // ---- fragment read bases ----
     // weights: row = wn*64 + i*32 + l31; logical half hi32 sits in slot hi32 ^ ((row >> 3) & 1) = hi32 ^ ((l31 >> 3) & 1)
     const char* wlane = smem + C::W_OFF + (wn * 64 + l31) * C::WROWB + ((hi32 ^ ((l31 >> 3) & 1)) << 4);
-    // patch: MFMA tile j of this wave = output rows 2*(wm*TM + j) + (l31 >> 4), column l31 & 15 -> patch row 2*orow + kh, plane by kw
-    const char* plane = smem + C::P_OFF + ((wm * TM * 2 + (l31 >> 4)) * 2) * RP + (l31 & 15) * PIXB + hi32 * 16;
+    // patch: MFMA tile j of this wave = output rows 2*(wm*TM + j) + (l31 >> 4), column xl -> patch row 2*orow + kh, plane by kw.
+    // Lanes 16-31 (the tile's second output row) take their columns ROTATED by 14: ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} (+32), i.e. half a group from each row; the rows are 2 * RP = 198 sixteen-byte units apart (6 mod 16), and with
+    // 3 * 14 + 6 = 0 mod 16 the two halves of a group land on complementary bank groups (tests/test_convsim.py checks the address set).
+    const int xl = (l31 & 16) ? (((l31 & 15) + 14) & 15) : (l31 & 15);
+    const char* plane = smem + C::P_OFF + ((wm * TM * 2 + (l31 >> 4)) * 2) * RP + xl * PIXB + hi32 * 16;
 
     auto issue_w = [&](int slot, int so, bool real) {   // weight waves only
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
     constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int pix = (wm * TM + j) * 32 + l31;   // tile-local pixel id: row = pix >> 4, x = pix & 15
+        const int pix = (wm * TM + j) * 32 + (l31 & 16) + xl;   // tile-local pixel id of this lane's accumulator column: row = pix >> 4, x = pix & 15
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int nl = wn * 64 + i * 32;
