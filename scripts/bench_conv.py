@@ -27,9 +27,15 @@ for key, cnt in shapes.items():
     w = (torch.randn((Cout_pad, K_pad), device="cuda") / K ** 0.5).half()
     b = torch.randn(Cout_pad, device="cuda")
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
+    # `act` bits of y7t_conv2d_nhwc_f16 = the weight packing the plan would give this layer (the weights are random: only the kernel choice matters here)
+    if graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = 1 | 1024
+    elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32): code = 1 | 4096          # opt-in: Y7T_CONV_PATCH_S2=1
+    elif k == 3 and Cin % 64 == 0: code = 1 | (KORDER << 8)
+    elif k == 1 and Cin % 32 == 0 and KORDER and os.environ.get('Y7T_CONV_WPANEL', '1') != '0': code = 1 | 2048
+    else: code = 1
     def run():
         _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), in_ld, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), out_ld, 0, f32, Cout, Cout_pad,
-                                         k, k, s, pad, 1 | (1024 if graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER else (KORDER << 8 if (k == 3 and Cin % 64 == 0) else (2048 if (k == 1 and Cin % 32 == 0 and KORDER and os.environ.get('Y7T_CONV_WPANEL', '1') != '0') else 0))), _lib.ptr(zeros), _lib.stream_ptr()))
+                                         k, k, s, pad, code, _lib.ptr(zeros), _lib.stream_ptr()))
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

@@ -1,0 +1,77 @@
+#!/bin/bash
+# Round 3, FIRST GPU call: the four experiments that were written and host-validated at the end of round 2 without GPU minutes.
+#
+#   BEFORE calling gpurun (here, on the CPU):   python -m yolov7_tracker_amd.build && python scripts/ablate/build_experiments.py
+#   (the experimental libraries lib/exp_{nw8,fixup,next}.so travel with the snapshot; the stride-2 patch kernel is in liby7t.so, opt-in by environment)
+#   then:   gpurun --timeout 1500 -- 'bash scripts/gpu_r3a.sh'
+#
+# Every step is wrapped in its own timeout and writes to gpurun_out/r3a/; a failing experiment does not stop the others.
+# What to do with the answers: DESIGN.md section 7 ("what the first GPU call of round 3 decides").
+O=gpurun_out/r3a; mkdir -p $O
+LIBD=$GRAFT_REPO_ROOT/yolov7-tracker_amd/lib
+say() { echo "=== $*" | tee -a $O/summary.txt; }
+
+# ---- 0. the default build is what round 2 verified: layer tests + the pinned launch list (2 min) ----
+say "0. default suite (conv layers, pinned list)"
+timeout 200 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -x -q -m gpu > $O/t0_default.log 2>&1; echo "rc=$?" >> $O/t0_default.log
+tail -2 $O/t0_default.log | tee -a $O/summary.txt
+
+# ---- 1. stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; korder 4) ----
+say "1a. stride-2 patch kernel: layer parity vs torch fp32"
+Y7T_TEST_EXPERIMENTS=1 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t1a_s2_layers.log 2>&1; echo "rc=$?" >> $O/t1a_s2_layers.log
+tail -2 $O/t1a_s2_layers.log | tee -a $O/summary.txt
+say "1b. stride-2 patch kernel inside the benchmarked launch list, teacher-forced against the oracle"
+Y7T_CONV_PATCH_S2=1 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t1b_s2_pinned.log 2>&1; echo "rc=$?" >> $O/t1b_s2_pinned.log
+tail -2 $O/t1b_s2_pinned.log | tee -a $O/summary.txt
+say "1c. per-layer timing, 32 frames: generic vs patch_s2 (256-channel panels where Cout allows) vs patch_s2 with 128-channel panels only"
+timeout 200 python scripts/bench_conv.py 32 > $O/b1c_default.txt 2>&1
+Y7T_CONV_PATCH_S2=1 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2.txt 2>&1
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_BN=128 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_bn128.txt 2>&1
+for f in default s2 s2_bn128; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b1c_$f.txt; done | tee -a $O/summary.txt
+say "1d. bench line with the stride-2 kernel on (all eight layers / only the layers with 256-channel panels)"
+timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+Y7T_CONV_PATCH_S2=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2.json 2> $O/bench_s2.err
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_MIN_COUT=256 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2_wide.json 2> $O/bench_s2_wide.err
+python - <<'PY' | tee -a $O/summary.txt
+import json
+for n in ("default", "s2", "s2_wide"):
+    try:
+        l = json.loads(open("gpurun_out/r3a/bench_%s.json" % n).read().strip().splitlines()[-1])
+        wc = l.get("parity", {}).get("well_conditioned", {})
+        print("%-8s %.0f fps  list %.2f ms  frac %.4f  well-conditioned boxes matched %s / %s" % (n, l["value"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"],
+              wc.get("boxes_matched_same_class_1px_conf5e-3"), wc.get("boxes_oracle")))
+    except Exception as e:
+        print(n, "no bench line:", e)
+PY
+
+# ---- 2. nw8: 512-thread workgroups, 256x256x64 tile (layer-level: plain layers with Cin % 64 == 0 and Cout % 128 == 0) ----
+say "2. nw8 (Y7T_IGEMM_NW=8): layer parity, then per-layer timing at 256x256 (default), 256x128 (VARIANT=6), 128x128 (VARIANT=7)"
+if [ -f $LIBD/exp_nw8.so ]; then
+  Y7T_LIB=$LIBD/exp_nw8.so Y7T_CONV_PATCH=0 Y7T_CONV_WPANEL=0 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer" > $O/t2_nw8_layers.log 2>&1; echo "rc=$?" >> $O/t2_nw8_layers.log
+  tail -3 $O/t2_nw8_layers.log | tee -a $O/summary.txt      # (cases outside the build's envelope are reported as Y7T_E_ARG failures: read the log, not the count)
+  for v in 0 6 7; do
+    Y7T_LIB=$LIBD/exp_nw8.so Y7T_CONV_PATCH=0 Y7T_CONV_WPANEL=0 KORDER=1 Y7T_CONV_VARIANT=$v timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_v$v.txt 2>&1
+    echo "-- nw8 variant $v"; grep "TOTAL\| 1/1 .*ld\| 3/2 " $O/b2_nw8_v$v.txt | head -40
+  done | tee -a $O/summary.txt
+else say "exp_nw8.so missing: run scripts/ablate/build_experiments.py before gpurun"; fi
+
+# ---- 3. fixup: split-K reduced by the last arriving workgroup (batch-1 latency mode) ----
+say "3. fixup (Y7T_SPLITK_FIXUP, Y7T_CONV_SPLITK=2): layer parity incl. repeated launches, then latency mode against the default library"
+if [ -f $LIBD/exp_fixup.so ]; then
+  Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer or whole_network or batch" > $O/t3_fixup.log 2>&1; echo "rc=$?" >> $O/t3_fixup.log
+  tail -2 $O/t3_fixup.log | tee -a $O/summary.txt
+  timeout 200 python scripts/latency_mode.py 120 > $O/lat_default.txt 2>&1
+  Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python scripts/latency_mode.py 120 > $O/lat_fixup.txt 2>&1
+  for f in default fixup; do echo "-- $f"; grep -i "fps" $O/lat_$f.txt | tail -8; done | tee -a $O/summary.txt
+else say "exp_fixup.so missing"; fi
+
+# ---- 4. next: tracker candidate lists on a run-time row stride (LDS-resident at 500 objects) ----
+say "4. next (Y7T_NEXT_TRACKER): tracker parity on the device, then the 500-object frame step against the default library"
+if [ -f $LIBD/exp_next.so ]; then
+  Y7T_LIB=$LIBD/exp_next.so timeout 250 python -m pytest tests/test_tracker_gpu.py -q -m gpu > $O/t4_next.log 2>&1; echo "rc=$?" >> $O/t4_next.log
+  tail -2 $O/t4_next.log | tee -a $O/summary.txt
+  timeout 150 python scripts/time_tracker.py > $O/trk_default.txt 2>&1
+  Y7T_LIB=$LIBD/exp_next.so timeout 150 python scripts/time_tracker.py > $O/trk_next.txt 2>&1
+  for f in default next; do echo "-- $f"; grep -v amdgpu.ids $O/trk_$f.txt | tail -12; done | tee -a $O/summary.txt
+else say "exp_next.so missing"; fi
+say "done"
