@@ -20,21 +20,25 @@ tail -2 $O/t0_default.log | tee -a $O/summary.txt
 say "1a. stride-2 patch kernel: layer parity vs torch fp32"
 Y7T_TEST_EXPERIMENTS=1 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t1a_s2_layers.log 2>&1; echo "rc=$?" >> $O/t1a_s2_layers.log
 tail -2 $O/t1a_s2_layers.log | tee -a $O/summary.txt
+Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_NW=8 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t1a_s2_layers_nw8.log 2>&1; echo "rc=$?" >> $O/t1a_s2_layers_nw8.log
+echo "512-thread form:" | tee -a $O/summary.txt; tail -2 $O/t1a_s2_layers_nw8.log | tee -a $O/summary.txt
 say "1b. stride-2 patch kernel inside the benchmarked launch list, teacher-forced against the oracle"
 Y7T_CONV_PATCH_S2=1 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t1b_s2_pinned.log 2>&1; echo "rc=$?" >> $O/t1b_s2_pinned.log
 tail -2 $O/t1b_s2_pinned.log | tee -a $O/summary.txt
-say "1c. per-layer timing, 32 frames: generic vs patch_s2 (256-channel panels where Cout allows) vs patch_s2 with 128-channel panels only"
+say "1c. per-layer timing, 32 frames: generic vs patch_s2 (256-channel panels where Cout allows) vs 128-channel panels only vs the 512-thread form (16x16 pixels, one workgroup per CU)"
 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_default.txt 2>&1
 Y7T_CONV_PATCH_S2=1 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2.txt 2>&1
 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_BN=128 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_bn128.txt 2>&1
-for f in default s2 s2_bn128; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b1c_$f.txt; done | tee -a $O/summary.txt
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_nw8.txt 2>&1
+for f in default s2 s2_bn128 s2_nw8; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b1c_$f.txt; done | tee -a $O/summary.txt
 say "1d. bench line with the stride-2 kernel on (all eight layers / only the layers with 256-channel panels)"
 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 Y7T_CONV_PATCH_S2=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2.json 2> $O/bench_s2.err
 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_MIN_COUT=256 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2_wide.json 2> $O/bench_s2_wide.err
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2_nw8.json 2> $O/bench_s2_nw8.err
 python - <<'PY' | tee -a $O/summary.txt
 import json
-for n in ("default", "s2", "s2_wide"):
+for n in ("default", "s2", "s2_wide", "s2_nw8"):
     try:
         l = json.loads(open("gpurun_out/r3a/bench_%s.json" % n).read().strip().splitlines()[-1])
         wc = l.get("parity", {}).get("well_conditioned", {})

@@ -146,6 +146,16 @@ def test_stride2_patch_kernel_source_on_the_host(case):
     assert name == "patch_s2<%d>" % (256 if cp % 256 == 0 else 128), name
 
 
+@pytest.mark.parametrize("case", [S2_CASES[1], S2_CASES[2], (1, 34, 36, 64, 256, 1, {}), (2, 9, 70, 128, 384, 1, {"out_ld": 384})],
+                         ids=lambda c: "%dx%dx%d_%d-%d" % (c[0], c[1], c[2], c[3], c[4]))
+def test_stride2_patch_kernel_eight_wave_form_on_the_host(case):
+    """the 512-thread form (16 x 16 output pixels per workgroup, 33 x 33 patch, one workgroup per CU; Y7T_CONV_PATCH_S2_NW=8 on the device, force_patch = 8 here)"""
+    B, H, W, Cin, Cout, act, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, force_patch=8, **kw)
+    cp = (Cout + 127) // 128 * 128
+    assert name == "patch_s2<%d,8>" % (256 if cp % 256 == 0 else 128), name
+
+
 def test_stride2_patch_kernel_rejects_what_it_cannot_run():
     """korder 4 weights are readable by the stride-2 patch kernel only: a stride-1 layer carrying them is an error, not a silent fallback"""
     L = cs.lib()

@@ -30,44 +30,50 @@ namespace {
 
 constexpr unsigned kOOB = 0xFF000000u;   // voffset of a zero-filled lane: out of range with or without the (< 16 MiB) scalar offset
 
-template <int BN>
+// NW = 4: 256 threads, 8 x 16 output pixels, two workgroups per CU.  NW = 8: 512 threads, 16 x 16 output pixels, ONE workgroup per CU (two waves per SIMD
+// either way): twice the pixels per weight panel and a 33 x 33 patch (1.06 input pixels fetched per input pixel used instead of 1.10) -- the fewest
+// buffer->LDS pieces per MFMA of the forms that fit in LDS; selected at run time with Y7T_CONV_PATCH_S2_NW=8.
+template <int BN, int NW>
 struct S2Cfg {
-    static constexpr int TW = 16, TH = 8;                                 // output tile: 128 pixels
+    static constexpr int TW = 16, TH = NW == 8 ? 16 : 8;                  // output tile: 128 / 256 pixels
+    static constexpr int NT = 64 * NW, NLW = NW / 2;                      // threads; waves per DMA role (weights: waves 0 .. NLW-1, patch: the rest)
     static constexpr int PIXB = 48;                                       // bytes per patch pixel in LDS: 16 channels + 16 pad
     static constexpr int NE = TW + 1, NO = TW;                            // even / odd patch columns per row
     static constexpr int O_OFF = NE * PIXB;                               // the odd plane inside a row
     static constexpr int RP = (NE + NO) * PIXB;                           // patch row pitch (1584)
     static constexpr int ROWS = 2 * TH + 1;
-    static constexpr int PATCH_DMA = (ROWS * RP + 1023) / 1024;           // wave-wide 1 KiB DMAs per patch (27)
-    static constexpr int NPX = (PATCH_DMA + 1) / 2;                       // per PATCH wave (waves 2, 3)
+    static constexpr int PATCH_DMA = (ROWS * RP + 1023) / 1024;           // wave-wide 1 KiB DMAs per patch (27 / 52)
+    static constexpr int NPX = (PATCH_DMA + NLW - 1) / NLW;               // per PATCH wave
     static constexpr int PATCH_BYTES = PATCH_DMA * 1024;
     static constexpr int PPT = (NPX + 6) / 7;                             // pieces per patch wave per tap (taps 0..6)
     static constexpr int WROWB = 32;                                      // weight rows: 16 channels
     static constexpr int W_BYTES = BN * WROWB;                            // one K-step's panel: 4 / 8 KiB
-    static constexpr int W_DMA = W_BYTES / 1024, NWX = W_DMA / 2;         // DMAs per panel, per WEIGHT wave (waves 0, 1)
-    static constexpr int NWS = BN == 128 ? 6 : 3;                         // ring slots (24 KiB either way): K-step u+NWS goes out at step u
+    static constexpr int W_DMA = W_BYTES / 1024, NWX = W_DMA / NLW;       // DMAs per panel, per WEIGHT wave
+    static constexpr int NWS = (BN == 128 || NW == 8) ? 6 : 3;            // ring slots (NW = 4: 24 KiB either way): K-step u+NWS goes out at step u
     static constexpr int W_OFF = 0, P_OFF = NWS * W_BYTES;                // LDS map: W ring | patch A | patch B
     static constexpr int LDS_LOOP = P_OFF + 2 * PATCH_BYTES;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int LDS_EPI = TW * TH * OROW;
     static constexpr int BIAS_OFF = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
     static constexpr int LDS = BIAS_OFF + BN * 4;
-    static constexpr int WN = BN / 64, WM = 4 / WN;                       // waves along channels / pixels
-    static constexpr int TM = 4 / WM;                                     // 32-pixel MFMA tiles (2 output rows x 16) per wave
+    static constexpr int WN = BN / 64, WM = NW / WN;                      // waves along channels / pixels
+    static constexpr int TM = (TH / 2) / WM;                              // 32-pixel MFMA tiles (2 output rows x 16) per wave
+    static constexpr int LDS_MAX = NW == 8 ? 163840 : 81920;              // one / two workgroups per CU
     static constexpr int JOFF = 4 * RP;                                   // LDS distance between consecutive MFMA tiles of a wave (2 output rows = 4 patch rows)
 };
 
-template <int BN>
-__global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p) {
+template <int BN, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = S2Cfg<BN>;
-    constexpr int PIXB = C::PIXB, RP = C::RP, TM = C::TM, TW = C::TW, TH = C::TH, NWS = C::NWS;
-    static_assert(C::LDS <= 81920, "two workgroups per CU");
+    using C = S2Cfg<BN, NW>;
+    constexpr int PIXB = C::PIXB, RP = C::RP, TM = C::TM, TW = C::TW, TH = C::TH, NWS = C::NWS, NLW = C::NLW;
+    static_assert(C::LDS <= C::LDS_MAX, "LDS budget of the chosen occupancy");
+    static_assert(TM >= 1 && C::NWX >= 1 && C::WM * C::WN == NW, "wave layout");
     static_assert(C::PPT * 7 >= C::NPX, "patch pieces fit into taps 0..6");
     static_assert(18 % NWS == 0, "ring positions are compile-time in the 18-step unrolled loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = (C::WN == 2) ? (wave >> 1) : wave, wm = (C::WN == 2) ? (wave & 1) : 0;
+    const int wn = wave / C::WM, wm = wave % C::WM;
     const int l31 = lane & 31, hi32 = lane >> 5;
 
     // ---- tile decode: channel tiles fastest, XCD-contiguous ranges (as y7t_conv_patch.hip) ----
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
     const int nc16 = p.Cin >> 4;
 
     // ---- per-lane DMA sources (computed once): waves 0/1 the weight panels, waves 2/3 the patch ----
-    const bool wrole = wave < 2;
+    const bool wrole = wave < NLW;
     constexpr int NOFF = C::NPX > C::NWX ? C::NPX : C::NWX;
     unsigned off[NOFF];
 #pragma unroll
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
         if (wrole) {
             if (i < C::NWX) v = (unsigned)(tile_n * (nc16 * 9) * C::W_BYTES + (wave * C::NWX + i) * 1024 + lane * 16);   // memory image == LDS image
         } else if (i < C::NPX) {
-            int I = (wave - 2) + 2 * i;
+            int I = (wave - NLW) + NLW * i;
             if (I >= C::PATCH_DMA) I = C::PATCH_DMA - 1;
             const int byte = I * 1024 + lane * 16;
             const int r = byte / RP, rb = byte - r * RP;
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
                                                      real ? off[i] : kOOB, real ? so : 0, 0, 0);
     };
     auto issue_patch_piece = [&](int pb, int c, int i, bool real) {   // patch waves only
-        const int I = ((wave - 2) + 2 * i < C::PATCH_DMA) ? (wave - 2) + 2 * i : C::PATCH_DMA - 1;
+        const int I = ((wave - NLW) + NLW * i < C::PATCH_DMA) ? (wave - NLW) + NLW * i : C::PATCH_DMA - 1;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + C::P_OFF + pb * C::PATCH_BYTES + I * 1024), 16,
                                                  real ? off[i] : kOOB, c << 5, 0, 0);
     };
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
         constexpr int CPP = BN / 8;
         half_t* outp = (half_t*)p.out;
 #pragma unroll 4
-        for (int cidx = tid; cidx < TW * TH * CPP; cidx += 256) {
+        for (int cidx = tid; cidx < TW * TH * CPP; cidx += C::NT) {
             const int pix = cidx / CPP, ch = cidx - pix * CPP;
             const int n = n0 + ch * 8;
             const int gy = h0 + (pix >> 4), gx = w0 + (pix & 15);
@@ -261,18 +267,19 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3s2_patch(const Y7TConvArgs p)
 #endif
 }
 
-template <int BN>
+template <int BN, int NW>
 int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
-    using C = S2Cfg<BN>;
+    using C = S2Cfg<BN, NW>;
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_patch<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_patch<BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     const int ptiles = a.B * ((a.Ho + C::TH - 1) / C::TH) * ((a.Wo + C::TW - 1) / C::TW);
-    hipLaunchKernelGGL((k_conv3x3s2_patch<BN>), dim3(ptiles * (a.Cout_pad / BN)), dim3(256), C::LDS, s, a);
+    hipLaunchKernelGGL((k_conv3x3s2_patch<BN, NW>), dim3(ptiles * (a.Cout_pad / BN)), dim3(C::NT), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("patch_s2<%d>", BN);
+    if (NW == 4) y7t_note_kernel("patch_s2<%d>", BN);
+    else y7t_note_kernel("patch_s2<%d,%d>", BN, NW);
     return 0;
 }
 
@@ -293,5 +300,8 @@ int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_set_error("conv: weights are in the stride-2 patch kernel's panel order (korder 4) but the layer cannot run on it");
         return Y7T_E_ARG;
     }
-    return s2_bn(a.Cout_pad) == 256 ? launch_s2<256>(a, s) : launch_s2<128>(a, s);
+    static int nw = -1;      // (a.force_patch == 8 selects the 8-wave form per call: tests on the host simulator)
+    if (nw < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_NW"); nw = (e && atoi(e) == 8) ? 8 : 4; }
+    if (nw == 8 || a.force_patch == 8) return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 8>(a, s) : launch_s2<128, 8>(a, s);
+    return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 4>(a, s) : launch_s2<128, 4>(a, s);
 }
