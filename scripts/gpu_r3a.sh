@@ -30,7 +30,11 @@ timeout 200 python scripts/bench_conv.py 32 > $O/b1c_default.txt 2>&1
 Y7T_CONV_PATCH_S2=1 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2.txt 2>&1
 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_BN=128 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_bn128.txt 2>&1
 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_nw8.txt 2>&1
-for f in default s2 s2_bn128 s2_nw8; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b1c_$f.txt; done | tee -a $O/summary.txt
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_late.txt 2>&1                            # DMAs behind the step's MFMAs
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b1c_s2_nw8_late.txt 2>&1
+for f in default s2 s2_bn128 s2_nw8 s2_late s2_nw8_late; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b1c_$f.txt; done | tee -a $O/summary.txt
+Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t1c_s2_layers_late.log 2>&1; echo "rc=$?" >> $O/t1c_s2_layers_late.log
+echo "dma-late order, parity:" | tee -a $O/summary.txt; tail -2 $O/t1c_s2_layers_late.log | tee -a $O/summary.txt
 say "1d. bench line with the stride-2 kernel on (all eight layers / only the layers with 256-channel panels)"
 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 Y7T_CONV_PATCH_S2=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2.json 2> $O/bench_s2.err

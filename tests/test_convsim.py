@@ -146,7 +146,7 @@ def test_stride2_patch_kernel_source_on_the_host(case):
     assert name == "patch_s2<%d>" % (256 if cp % 256 == 0 else 128), name
 
 
-@pytest.mark.parametrize("case", [S2_CASES[1], S2_CASES[2], (1, 34, 36, 64, 256, 1, {}), (2, 9, 70, 128, 384, 1, {"out_ld": 384})],
+@pytest.mark.parametrize("case", [S2_CASES[1], S2_CASES[2], (1, 34, 36, 64, 256, 1, {}), (1, 9, 40, 64, 384, 1, {"out_ld": 384})],
                          ids=lambda c: "%dx%dx%d_%d-%d" % (c[0], c[1], c[2], c[3], c[4]))
 def test_stride2_patch_kernel_eight_wave_form_on_the_host(case):
     """the 512-thread form (16 x 16 output pixels per workgroup, 33 x 33 patch, one workgroup per CU; Y7T_CONV_PATCH_S2_NW=8 on the device, force_patch = 8 here)"""
@@ -154,6 +154,14 @@ def test_stride2_patch_kernel_eight_wave_form_on_the_host(case):
     name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, force_patch=8, **kw)
     cp = (Cout + 127) // 128 * 128
     assert name == "patch_s2<%d,8>" % (256 if cp % 256 == 0 else 128), name
+
+
+@pytest.mark.parametrize("force,case", [(16, S2_CASES[2]), (16, S2_CASES[1]), (24, S2_CASES[1]), (24, (1, 18, 36, 128, 128, 1, {}))], ids=["4w-128", "4w-256", "8w-256", "8w-128"])
+def test_stride2_patch_kernel_dma_late_order_on_the_host(force, case):
+    """ORD = 1 (Y7T_CONV_PATCH_S2_ORDER=1 on the device; force_patch bit 4 here): the step's DMAs issued behind its MFMAs instead of in front of the fragment reads"""
+    B, H, W, Cin, Cout, act, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, force_patch=force, **kw)
+    assert name.startswith("patch_s2<") and name.endswith("dma-late") and ((",8>" in name) == bool(force & 8)), name
 
 
 def test_stride2_patch_kernel_rejects_what_it_cannot_run():

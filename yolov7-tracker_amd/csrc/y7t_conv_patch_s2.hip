@@ -62,7 +62,10 @@ struct S2Cfg {
     static constexpr int JOFF = 4 * RP;                                   // LDS distance between consecutive MFMA tiles of a wave (2 output rows = 4 patch rows)
 };
 
-template <int BN, int NW>
+// ORD = 0: behind the barrier the DMAs go out first, then the next step's fragment reads, then the MFMAs (the order y7t_conv_patch.hip was tuned to).
+// ORD = 1: fragment reads, the MFMAs, THEN the DMAs -- a buffer->LDS piece costs its wave 60-185 clocks of issue, most when the phase also carries ds_reads
+// (MI355X_MICROARCH.md), and in this order the matrix pipe has the step's MFMAs queued while they go out.  Y7T_CONV_PATCH_S2_ORDER=1 at launch time.
+template <int BN, int NW, int ORD>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = S2Cfg<BN, NW>;
@@ -192,20 +195,24 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(co
             if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * C::NWX) : "memory");
             else if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (wrole) {
-                const int un = u + NWS;                            // K-step whose weights go out now (ccn = 2: first chunk of the next pair)
-                const int ccn = un / 9;
-                issue_w(u % NWS, cbase + un * C::W_BYTES, c0 + ccn < nc16);
-            } else if (t < 7) {
+            auto issue_dmas = [&]() {
+                if (wrole) {
+                    const int un = u + NWS;                            // K-step whose weights go out now (ccn = 2: first chunk of the next pair)
+                    const int ccn = un / 9;
+                    issue_w(u % NWS, cbase + un * C::W_BYTES, c0 + ccn < nc16);
+                } else if (t < 7) {
 #pragma unroll
-                for (int q = 0; q < C::PPT; ++q)
-                    if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc16);
-            }
+                    for (int q = 0; q < C::PPT; ++q)
+                        if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc16);
+                }
+            };
+            if (ORD == 0) issue_dmas();
             {
                 const int un = u + 1, tn = un % 9;
                 read_frags(cur ^ 1, un % NWS, (un / 9) & 1, tn / 3, tn % 3);
             }
             mfma_half(cur, 1);
+            if (ORD == 1) issue_dmas();
         }
         cbase += 18 * C::W_BYTES;
     }
@@ -267,20 +274,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(co
 #endif
 }
 
-template <int BN, int NW>
-int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
+template <int BN, int NW, int ORD>
+int launch_s2_ord(const Y7TConvArgs& a, hipStream_t s) {
     using C = S2Cfg<BN, NW>;
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_patch<BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_patch<BN, NW, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     const int ptiles = a.B * ((a.Ho + C::TH - 1) / C::TH) * ((a.Wo + C::TW - 1) / C::TW);
-    hipLaunchKernelGGL((k_conv3x3s2_patch<BN, NW>), dim3(ptiles * (a.Cout_pad / BN)), dim3(C::NT), C::LDS, s, a);
+    hipLaunchKernelGGL((k_conv3x3s2_patch<BN, NW, ORD>), dim3(ptiles * (a.Cout_pad / BN)), dim3(C::NT), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    if (NW == 4) y7t_note_kernel("patch_s2<%d>", BN);
-    else y7t_note_kernel("patch_s2<%d,%d>", BN, NW);
+    if (NW == 4) y7t_note_kernel("patch_s2<%d>%s", BN, ORD ? " dma-late" : "");
+    else y7t_note_kernel("patch_s2<%d,%d>%s", BN, NW, ORD ? " dma-late" : "");
     return 0;
+}
+
+template <int BN, int NW>
+int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
+    static int ord = -1;     // (force_patch bit 4 selects ORD = 1 per call: tests on the host simulator)
+    if (ord < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_ORDER"); ord = (e && atoi(e) == 1) ? 1 : 0; }
+    return (ord == 1 || (a.force_patch & 16)) ? launch_s2_ord<BN, NW, 1>(a, s) : launch_s2_ord<BN, NW, 0>(a, s);
 }
 
 }   // namespace
@@ -300,8 +314,8 @@ int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_set_error("conv: weights are in the stride-2 patch kernel's panel order (korder 4) but the layer cannot run on it");
         return Y7T_E_ARG;
     }
-    static int nw = -1;      // (a.force_patch == 8 selects the 8-wave form per call: tests on the host simulator)
+    static int nw = -1;      // (force_patch bit 3 selects the 8-wave form per call: tests on the host simulator)
     if (nw < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_NW"); nw = (e && atoi(e) == 8) ? 8 : 4; }
-    if (nw == 8 || a.force_patch == 8) return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 8>(a, s) : launch_s2<128, 8>(a, s);
+    if (nw == 8 || (a.force_patch & 8)) return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 8>(a, s) : launch_s2<128, 8>(a, s);
     return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 4>(a, s) : launch_s2<128, 4>(a, s);
 }
