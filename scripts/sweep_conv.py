@@ -1,5 +1,7 @@
 """time ONE conv shape over a list of batch sizes (tile-quantisation experiments):
-python scripts/sweep_conv.py H W Cin Cout k s B1,B2,... [reps]"""
+python scripts/sweep_conv.py H W Cin Cout k s B1,B2,... [reps]
+ACT_BITS=<n> in the environment: the weight-packing bits of y7t_conv2d_nhwc_f16's `act` (256 (kh, chunk, kw) order, 1024 LDS-patch panels, 2048 1x1 panels,
+4096 stride-2 patch panels) -- the values are random, only the kernel the dispatcher picks matters here."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from yolov7_tracker_amd import _lib
@@ -9,7 +11,8 @@ reps = int(sys.argv[8]) if len(sys.argv) > 8 else 20
 L = _lib.load()
 pad = k // 2
 Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-K = k * k * Cin; K_pad = (K + 63) // 64 * 64; Cout_pad = (Cout + 63) // 64 * 64
+BITS = int(os.environ.get("ACT_BITS", "0"))
+K = k * k * Cin; K_pad = (K + 63) // 64 * 64; Cout_pad = (Cout + 127) // 128 * 128 if BITS & 4096 else (Cout + 63) // 64 * 64
 zeros = torch.zeros(256, dtype=torch.float16, device="cuda")
 for B in Bs:
     # DATA=zeros|ones|small|randn: operand values (the MFMA power draw -- and with it the sustained clock -- depends on them)
@@ -21,7 +24,7 @@ for B in Bs:
     b = torch.randn(Cout_pad, device="cuda")
     out = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=torch.float16)
     def run():
-        _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), Cin, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), Cout, 0, 0, Cout, Cout_pad, k, k, s, pad, 1,
+        _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), Cin, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), Cout, 0, 0, Cout, Cout_pad, k, k, s, pad, 1 | BITS,
                                          _lib.ptr(zeros), _lib.stream_ptr()))
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
