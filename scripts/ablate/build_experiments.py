@@ -1,6 +1,7 @@
 """Experimental builds of liby7t.so for the next round's measurements -- macro variants of csrc/y7t_conv.hip linked with the product's other objects:
 
-   nw8    -DY7T_IGEMM_NW=8     512-thread workgroups (2 x 4 waves); tiles 256x256x64 (default), 256x128x64 (Y7T_CONV_VARIANT=6), 128x128x64 (=7);
+   nw8    -DY7T_IGEMM_NW=8     (superseded: the same 8-wave kernels are template instances inside liby7t.so now, Y7T_CONV_NW8=1 -- csrc/y7t_conv.hip)
+                               512-thread workgroups (2 x 4 waves); tiles 256x256x64 (default), 256x128x64 (Y7T_CONV_VARIANT=6), 128x128x64 (=7);
                                plain layers with Cin % 64 == 0 and Cout % 128 == 0 only: layer-level tests / timing
                                (Y7T_LIB=.../exp_nw8.so python scripts/bench_conv.py 32)
    fixup  -DY7T_SPLITK_FIXUP   the last workgroup of a tile to arrive reduces the split-K slabs (no k_splitk_reduce launch) when

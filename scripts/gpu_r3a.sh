@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round 3, FIRST GPU call: the four experiments that were written and host-validated at the end of round 2 without GPU minutes.
 #
-#   BEFORE calling gpurun (here, on the CPU):   python -m yolov7_tracker_amd.build && python scripts/ablate/build_experiments.py
-#   (the experimental libraries lib/exp_{nw8,fixup,next}.so travel with the snapshot; the stride-2 patch kernel is in liby7t.so, opt-in by environment)
+#   BEFORE calling gpurun (here, on the CPU):   python -m yolov7_tracker_amd.build && python scripts/ablate/build_experiments.py fixup next
+#   (the experimental libraries lib/exp_{fixup,next}.so travel with the snapshot; the stride-2 patch kernel and the 8-wave instances of the generic kernel
+#   are in liby7t.so, opt-in by environment)
 #   then:   gpurun --timeout 1500 -- 'bash scripts/gpu_r3a.sh'
 #
 # Every step is wrapped in its own timeout and writes to gpurun_out/r3a/; a failing experiment does not stop the others.
@@ -52,16 +53,29 @@ for n in ("default", "s2", "s2_wide", "s2_nw8"):
         print(n, "no bench line:", e)
 PY
 
-# ---- 2. nw8: 512-thread workgroups, 256x256x64 tile (layer-level: plain layers with Cin % 64 == 0 and Cout % 128 == 0) ----
-say "2. nw8 (Y7T_IGEMM_NW=8): layer parity, then per-layer timing at 256x256 (default), 256x128 (VARIANT=6), 128x128 (VARIANT=7)"
-if [ -f $LIBD/exp_nw8.so ]; then
-  Y7T_LIB=$LIBD/exp_nw8.so Y7T_CONV_PATCH=0 Y7T_CONV_WPANEL=0 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer" > $O/t2_nw8_layers.log 2>&1; echo "rc=$?" >> $O/t2_nw8_layers.log
-  tail -3 $O/t2_nw8_layers.log | tee -a $O/summary.txt      # (cases outside the build's envelope are reported as Y7T_E_ARG failures: read the log, not the count)
-  for v in 0 6 7; do
-    Y7T_LIB=$LIBD/exp_nw8.so Y7T_CONV_PATCH=0 Y7T_CONV_WPANEL=0 KORDER=1 Y7T_CONV_VARIANT=$v timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_v$v.txt 2>&1
-    echo "-- nw8 variant $v"; grep "TOTAL\| 1/1 .*ld\| 3/2 " $O/b2_nw8_v$v.txt | head -40
-  done | tee -a $O/summary.txt
-else say "exp_nw8.so missing: run scripts/ablate/build_experiments.py before gpurun"; fi
+# ---- 2. 8-wave instances of the generic kernel (512 threads, 256x256x64 / 256x128x64 tiles at two waves per SIMD), inside the default library ----
+# Y7T_CONV_NW8=1 at run time; the plan is lowered with Y7T_CONV_WPANEL=0 so that the 1x1 layers keep row-major weights (the panels are packed for 128x32 tiles)
+say "2a. 8-wave instances in the benchmarked launch list, teacher-forced against the oracle"
+Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t2a_nw8_pinned.log 2>&1; echo "rc=$?" >> $O/t2a_nw8_pinned.log
+tail -2 $O/t2a_nw8_pinned.log | tee -a $O/summary.txt
+say "2b. per-layer timing: row-major weights on 4 waves (the fair baseline), then 8 waves at 256x256 (1), 256x128 (6), 128x128 (7)"
+Y7T_CONV_WPANEL=0 timeout 200 python scripts/bench_conv.py 32 > $O/b2_rowmajor.txt 2>&1
+for v in 1 6 7; do Y7T_CONV_NW8=$v Y7T_CONV_WPANEL=0 timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_$v.txt 2>&1; done
+for f in rowmajor nw8_1 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \| 20x20 " $O/b2_$f.txt | head -60; done | tee -a $O/summary.txt
+say "2c. bench line with the 8-wave instances on (alone, and together with the 512-thread stride-2 patch kernel)"
+Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8.json 2> $O/bench_nw8.err
+Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8_s2.json 2> $O/bench_nw8_s2.err
+python - <<'PY' | tee -a $O/summary.txt
+import json
+for n in ("nw8", "nw8_s2"):
+    try:
+        l = json.loads(open("gpurun_out/r3a/bench_%s.json" % n).read().strip().splitlines()[-1])
+        wc = l.get("parity", {}).get("well_conditioned", {})
+        print("%-8s %.0f fps  list %.2f ms  frac %.4f  well-conditioned boxes matched %s / %s" % (n, l["value"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"],
+              wc.get("boxes_matched_same_class_1px_conf5e-3"), wc.get("boxes_oracle")))
+    except Exception as e:
+        print(n, "no bench line:", e)
+PY
 
 # ---- 3. fixup: split-K reduced by the last arriving workgroup (batch-1 latency mode) ----
 say "3. fixup (Y7T_SPLITK_FIXUP, Y7T_CONV_SPLITK=2): layer parity incl. repeated launches, then latency mode against the default library"

@@ -93,6 +93,23 @@ def test_eight_wave_experiment_on_the_host():
         run_case(L8, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
 
 
+def test_eight_wave_instances_of_the_default_build_on_the_host():
+    """the same 512-thread kernels as template instances INSIDE the default library (csrc/y7t_conv.hip: NW template parameter; Y7T_CONV_NW8=1 on the device,
+    force_patch bit 5 / explicit tile codes here) -- what round 3 measures without a second library.  The 4-wave instances' instruction streams were checked
+    identical before / after the wave count became a template parameter."""
+    L = cs.lib()
+    for B, H, W, Cin, Cout, k, s, tile, kw in [(1, 17, 17, 64, 256, 3, 1, 256256564, {}), (1, 23, 19, 128, 256, 1, 1, 256256564, {}),
+                                               (1, 20, 20, 64, 128, 3, 2, 256128564, {"korder": 1}), (1, 9, 9, 128, 128, 1, 1, 128128564, {}),
+                                               (1, 9, 13, 192, 128, 3, 1, 256128564, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64})]:
+        name = run_case(L, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
+        assert name.endswith("8-wave"), name
+    # through the dispatcher: the rule picks 256 x 256 when Cout % 256 == 0, else 256 x 128; layers outside the envelope keep their 4-wave kernel
+    assert run_case(L, 1, 12, 12, 128, 256, 1, 1, 1, 0, force_patch=32) == "igemm<256,256,64,2> 1x1 8-wave"
+    name = run_case(L, 1, 16, 16, 64, 384, 3, 2, 1, 0, korder=1, force_patch=32)          # (a problem this small also splits K: that path on 8 waves too)
+    assert name.startswith("igemm<256,128,64,2>") and name.endswith("8-wave"), name
+    assert "8-wave" not in run_case(L, 1, 8, 8, 96, 192, 1, 1, 2, 0, force_patch=32)           # Cin % 64, Cout % 128
+
+
 def test_split_k_reduced_by_the_last_arriver_on_the_host():
     """-DY7T_SPLITK_FIXUP with allow_splitk = 2: no k_splitk_reduce launch, the tile's last workgroup sums the slabs in split order -> the same bits as the
     reduce kernel; the arrival counters are left at zero (second launch).  (Workgroups run one after the other here: the memory-ordering side -- fences,

@@ -38,16 +38,18 @@
 #ifndef Y7T_IGEMM_NW
 #define Y7T_IGEMM_NW 4
 #endif
-constexpr int kNW = Y7T_IGEMM_NW, kNT = 64 * kNW, kNWM = kNW / 2;      // waves, threads, waves along the pixel dimension
-template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
-__global__ void __launch_bounds__(kNT, (kNW == 8 || BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
+constexpr int kNW = Y7T_IGEMM_NW;      // default number of waves per workgroup (the macro build switches every instance; NW below is per instance)
+// NW = 8 instances are also part of the DEFAULT build, opt-in per layer at run time (Y7T_CONV_NW8=1; conv_dispatch): the same experiment without a second library
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false, int NW = kNW>
+__global__ void __launch_bounds__(64 * NW, (NW == 8 || BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 or 64)
     constexpr int CPR = BK / 8;                  // 16-byte chunks per row (8 or 4)
     constexpr int RPW = 64 / CPR;                // rows covered by one wave-wide 1 KiB DMA (8 or 16)
-    constexpr int RPR = RPW * kNW;               // rows per load round over the 4 waves (32 or 64)
+    constexpr int kNT = 64 * NW, kNWM = NW / 2;  // threads, waves along the pixel dimension
+    constexpr int RPR = RPW * NW;                // rows per load round over the waves (32 or 64; twice that with 8 waves)
     constexpr int WTN = BN / 2, WTM = BM / kNWM; // wave tile
-    static_assert(kNW == 4 || (EPI == 0 && !DUAL), "the 8-wave experiment covers the plain convolution only");
+    static_assert(NW == 4 || (EPI == 0 && !DUAL), "the 8-wave experiment covers the plain convolution only");
     constexpr int TN = WTN / 32, TM = WTM / 32;  // 32x32 MFMA tiles per wave
     constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
     constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
@@ -507,13 +509,13 @@ static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = Y7T_SPLITK_WS_BYTES;
 static const size_t kSplitKDoneBytes = 64 << 10;      // (reserved at the end of the workspace for Y7T_SPLITK_FIXUP's tile counters)
 
-template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false>
+template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false, int NW = kNW>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = EPI == 1 ? BM * (BN + 1) * 4 : BM * (BN * 2 + 16);
     constexpr unsigned lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + BN * 4;   // + the bias corner
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN, tiles = tiles_m * tiles_n;
@@ -544,10 +546,10 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
 #endif
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL>), dim3(tiles * b.splitk), dim3(kNT), lds, s, b);
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL, NW>), dim3(tiles * b.splitk), dim3(64 * NW), lds, s, b);
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
-                    EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "");
+    y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
+                    EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "", NW != kNW ? " 8-wave" : "");
 #ifdef Y7T_SPLITK_FIXUP
     if (b.splitk > 1 && b.allow_splitk == 2) return 0;    // reduced by the last arriver of each tile
 #endif
@@ -561,11 +563,12 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int NST>
+template <int BM, int BN, int BK, int NST, int NW = kNW>
 static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
     // uniform-tap specialisation: every K-step of BK channels lies inside one filter tap; 1x1 fast path on top of it
     if (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24))
-        return launch_conv_ut<BM, BN, BK, NST, true, 1>(a, s);
+        return launch_conv_ut<BM, BN, BK, NST, true, 1, 0, false, NW>(a, s);
+    if (NW != kNW) return launch_conv_ut<BM, BN, BK, NST, true, 0, 0, false, NW>(a, s);      // (the opt-in 8-wave instances: uniform taps only, checked by the caller)
     return (a.Cin % BK == 0) ? launch_conv_ut<BM, BN, BK, NST, true>(a, s) : launch_conv_ut<BM, BN, BK, NST, false>(a, s);
 }
 
@@ -637,6 +640,21 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     if ((conv_variant() == 0 && !a.no_patch) || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;
+    }
+    // Opt-in experiment inside the default build (Y7T_CONV_NW8 = 1: 256 x 256 x 64 tiles where Cout allows, else 256 x 128; 6: 256 x 128; 7: 128 x 128 -- all on
+    // 512-thread workgroups at two waves per SIMD): the layers the generic kernel runs today whose DMA bytes per flop bound them.
+    // Weights must be in a row layout (korder 0 / 1: lower the plan with Y7T_CONV_WPANEL=0 so that the 1x1 layers are not panel-packed for the 128 x 32 tile).
+    {
+        static int nw8 = -1;
+        if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }
+        const int want = (a.force_patch & 32) ? 1 : nw8;      // (force_patch bit 5: tests on the host simulator)
+        const int bn8 = (a.Cout_pad % 256 == 0 && want == 1) ? 256 : 128;
+        if (want && a.korder < 2 && a.Cin % 64 == 0 && a.Cout_pad % 128 == 0 && (a.KH == 1 || a.KH == 3) &&
+            ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256)) {
+            if (want == 7) return launch_conv<128, 128, 64, 2, 8>(a, s);
+            if (bn8 == 128) return launch_conv<256, 128, 64, 2, 8>(a, s);
+            return launch_conv<256, 256, 64, 2, 8>(a, s);
+        }
     }
     const bool wide = a.Cout_pad % 128 == 0;
     const int var = conv_variant();
