@@ -680,6 +680,9 @@ def main():
             line["fps_incl_h2d"] = {"value": round(K * B / dt_h2d, 2), "ms_per_step": round(dt_h2d / K * 1e3, 3),
                                     "note": "same pipeline, every batch copied from pinned host memory (uint8 BGR, %.1f MB per frame) on a copy "
                                             "stream, double-buffered; never `value`" % (H * W * 3 / 1e6)}
+        exps = {k: v for k, v in os.environ.items() if k.startswith("Y7T_") and k != "Y7T_TEST_EXPERIMENTS"}
+        if exps:      # a run with experiment switches in the environment says so in its own line (none in the driver's run)
+            line["config"]["environment_switches"] = exps
         if world == 1:
             hist = {}
             for nme in det.launch_list(B):
