@@ -96,4 +96,10 @@ if [ -f $LIBD/exp_next.so ]; then
   Y7T_LIB=$LIBD/exp_next.so timeout 150 python scripts/time_tracker.py > $O/trk_next.txt 2>&1
   for f in default next; do echo "-- $f"; grep -v amdgpu.ids $O/trk_$f.txt | tail -12; done | tee -a $O/summary.txt
 else say "exp_next.so missing"; fi
+# ---- 5. stride-1 LDS-patch kernel with the step's DMAs behind its MFMAs (ABL bit 9: k_conv3x3_patch<..., 512>; correct results) ----
+say "5. patch kernel, DMA-late order (Y7T_CONV_ABLATE=512): parity in the benchmarked list, then the 3x3 / stride-1 rows against 1c's default table"
+Y7T_CONV_ABLATE=512 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t5_late_pinned.log 2>&1; echo "rc=$?" >> $O/t5_late_pinned.log
+tail -2 $O/t5_late_pinned.log | tee -a $O/summary.txt
+Y7T_CONV_ABLATE=512 timeout 200 python scripts/bench_conv.py 32 > $O/b5_late.txt 2>&1
+for f in b1c_default b5_late; do echo "-- $f (the 64-channel layers run single-tile under the switch: compare the 128-channel and 40x40 rows)"; grep " 3/1 \|TOTAL" $O/$f.txt; done | tee -a $O/summary.txt
 say "done"

@@ -143,6 +143,16 @@ def test_patch_kernel_source_on_the_host(case):
     assert name.startswith("patch"), name
 
 
+@pytest.mark.parametrize("case", [(1, 32, 32, 64, 128, 1, 0, {}), (1, 16, 48, 128, 64, 2, 1, {"in_ld": 192, "in_coff": 64}), PATCH_CASES[3]],
+                         ids=["16x16x128", "16x16x64", "strip40"])
+def test_patch_kernel_dma_late_order_on_the_host(case):
+    """ABL bit 9 of k_conv3x3_patch (Y7T_CONV_ABLATE=512 on the device, force_patch bit 6 here): the K-step's DMAs issued behind its second MFMA half -- an
+    order experiment with correct results, to be timed next round; the instruction streams of all other instances were checked unchanged when it was added"""
+    B, H, W, Cin, Cout, act, korder, kw = case
+    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=65, **kw)
+    assert name.startswith("patch") and name.endswith("dma-late"), name
+
+
 # the stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; opt-in experiment, korder 4): B, H, W, Cin, Cout, act, extras
 S2_CASES = [
     (1, 16, 32, 64, 128, 1, {}),                                                      # one full 8 x 16 output tile, 128-channel panels (6-slot weight ring)

@@ -56,6 +56,25 @@ struct PatchCfg {
     static constexpr int JOFF = FLAT ? 32 * PIXB : RPT * RP;              // LDS distance between a wave's consecutive 32-pixel MFMA tiles
 };
 
+// the DMAs of one K-step (a macro, not a lambda: the ABL = 0 instances must compile to exactly the code that was measured).
+// ABL bit 9 (512) is not an ablation but an ORDER experiment with correct results (Y7T_CONV_ABLATE=512; next round's measurement): the step's DMAs go out
+// behind its second MFMA half instead of in front of the fragment reads -- a buffer->LDS piece costs its wave most in a phase that also carries ds_reads
+// (MI355X_MICROARCH.md), and in that order the matrix pipe has the half queued while the pieces go out.
+#define Y7T_PATCH_ISSUE_DMAS() \
+            { \
+                constexpr bool live = !(ABL & 1); \
+                if (wrole) { \
+                    const int un = u + 3; \
+                    const int ccn = (un / 9), tn = un % 9; \
+                    const int cn = c0 + ccn; \
+                    if (ABL & 16) issue_w(u % 3, 0, 0, 0, true); \
+                    else issue_w(u % 3, ccn == 2 ? cbase + s_pair : cbase + ccn * s_odd, tn / 3, tn % 3, cn < nc32 && live); \
+                } else if (t < 7) { \
+                _Pragma("unroll") \
+                    for (int q = 0; q < C::PPT; ++q) \
+                        if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc32 && live && !(ABL & 32)); \
+                } \
+            }
 // ABL: compile-time ablation bits for scripts/sweep_conv.py (Y7T_CONV_ABLATE): 1 zero-filling DMAs only, 2 no MFMAs, 4 no fragment
 // reads, 8 no epilogue.  (Run-time switches inside the K loop change its schedule by tens of percent -- hence template instances.)
 template <int TW, int TH, int BN, int ABL>
@@ -259,25 +278,13 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
             if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NWX) : "memory");
             else if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            {
-                constexpr bool live = !(ABL & 1);
-                if (wrole) {
-                    const int un = u + 3;                              // K-step whose weights go out now
-                    const int ccn = (un / 9), tn = un % 9;             // ccn = 2: first chunk of the next pair
-                    const int cn = c0 + ccn;
-                    if (ABL & 16) issue_w(u % 3, 0, 0, 0, true);        // diagnostics: the same (L1-resident) panel every step
-                    else issue_w(u % 3, ccn == 2 ? cbase + s_pair : cbase + ccn * s_odd, tn / 3, tn % 3, cn < nc32 && live);
-                } else if (t < 7) {
-#pragma unroll
-                    for (int q = 0; q < C::PPT; ++q)
-                        if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc32 && live && !(ABL & 32));
-                }
-            }
+            if (!(ABL & 512)) Y7T_PATCH_ISSUE_DMAS()
             {
                 const int un = u + 1, tn = un % 9;
                 read_frags(cur ^ 1, un % 3, (un / 9) & 1, tn / 3, tn % 3);
             }
             mfma_half(cur, 1);
+            if (ABL & 512) Y7T_PATCH_ISSUE_DMAS()
         }
         cbase += s_pair;
     }
@@ -623,8 +630,8 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     const int tiles = ptiles * (a.Cout_pad / BN);
     hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    if (C::FLAT) y7t_note_kernel("patch_strip<%d,%d>", C::PW, BN);
-    else y7t_note_kernel("patch<%d,%d,%d>", TW, TH, BN);
+    if (C::FLAT) y7t_note_kernel("patch_strip<%d,%d>%s", C::PW, BN, ABL == 512 ? " dma-late" : "");
+    else y7t_note_kernel("patch<%d,%d,%d>%s", TW, TH, BN, ABL == 512 ? " dma-late" : "");
     return 0;
 }
 
@@ -652,16 +659,21 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
     // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
     if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;
-    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && !a.ablate) {
+    const int abl = (a.force_patch & 64) ? 512 : a.ablate;      // (force_patch bit 6: the DMA-late order per call -- tests on the host simulator)
+    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && (!abl || abl == 512)) {
         int rcf;
-        if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
+        if (abl == 512) {
+            if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128, 512>(a, s) : launch_patch<0, 42, 64, 512>(a, s);
+            else rcf = wide ? launch_patch<0, 22, 128, 512>(a, s) : launch_patch<0, 22, 64, 512>(a, s);
+        } else if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
         else rcf = wide ? launch_patch<0, 22, 128>(a, s) : launch_patch<0, 22, 64>(a, s);
         return rcf ? rcf : 1;
     }
     if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     int rc;
-    if (a.ablate && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
-        switch (a.ablate) {
+    if (abl && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
+        switch (abl) {
+        case 512: return launch_patch<16, 16, 64, 512>(a, s) ? -1 : 1;
         case 1: return launch_patch<16, 16, 64, 1>(a, s) ? -1 : 1;
         case 2: return launch_patch<16, 16, 64, 2>(a, s) ? -1 : 1;
         case 7: return launch_patch<16, 16, 64, 7>(a, s) ? -1 : 1;
@@ -670,8 +682,9 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
         default: break;
         }
     }
-    if (a.ablate && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
-        switch (a.ablate) {
+    if (abl && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
+        switch (abl) {
+        case 512: return launch_patch<16, 16, 128, 512>(a, s) ? -1 : 1;
         case 1: return launch_patch<16, 16, 128, 1>(a, s) ? -1 : 1;
         case 2: return launch_patch<16, 16, 128, 2>(a, s) ? -1 : 1;
         case 3: return launch_patch<16, 16, 128, 3>(a, s) ? -1 : 1;
@@ -695,7 +708,7 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     static int mt = -1;
     if (mt < 0) { const char* e = getenv("Y7T_CONV_PATCH_MT"); mt = e ? atoi(e) : 1; }
     const int ptiles = a.B * ((a.H + (use16 ? 15 : 7)) / (use16 ? 16 : 8)) * ((a.W + (use16 ? 15 : 31)) / (use16 ? 16 : 32));
-    if (!wide && mt && !a.ablate && (ptiles * (a.Cout_pad / 64) >= 4 * 2048 || a.force_patch)) {   // (force_patch: tests)   // 64-channel panels on big maps: multi-tile workgroups
+    if (!wide && mt && !abl && (ptiles * (a.Cout_pad / 64) >= 4 * 2048 || a.force_patch)) {   // (force_patch: tests)   // 64-channel panels on big maps: multi-tile workgroups
         rc = use16 ? launch_patch_mt<16, 16, 4>(a, s) : launch_patch_mt<32, 8, 4>(a, s);
         return rc ? rc : 1;
     }
