@@ -11,13 +11,19 @@
 O=gpurun_out/r3a; mkdir -p $O
 LIBD=$GRAFT_REPO_ROOT/yolov7-tracker_amd/lib
 say() { echo "=== $*" | tee -a $O/summary.txt; }
+# STEPS="0 1 2 3 4 5" (default: all, about 40 GPU-minutes); e.g. STEPS="0 1 2" bash scripts/gpu_r3a.sh for the convolution experiments only (about 25)
+STEPS=${STEPS:-"0 1 2 3 4 5"}
+want() { [[ " $STEPS " == *" $1 "* ]]; }
 
 # ---- 0. the default build is what round 2 verified: layer tests + the pinned launch list (2 min) ----
+if want 0; then
 say "0. default suite (conv layers, pinned list)"
 timeout 200 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -x -q -m gpu > $O/t0_default.log 2>&1; echo "rc=$?" >> $O/t0_default.log
 tail -2 $O/t0_default.log | tee -a $O/summary.txt
+fi
 
 # ---- 1. stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; korder 4) ----
+if want 1; then
 say "1a. stride-2 patch kernel: layer parity vs torch fp32"
 Y7T_TEST_EXPERIMENTS=1 timeout 150 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t1a_s2_layers.log 2>&1; echo "rc=$?" >> $O/t1a_s2_layers.log
 tail -2 $O/t1a_s2_layers.log | tee -a $O/summary.txt
@@ -52,8 +58,10 @@ for n in ("default", "s2", "s2_wide", "s2_nw8"):
     except Exception as e:
         print(n, "no bench line:", e)
 PY
+fi
 
 # ---- 2. 8-wave instances of the generic kernel (512 threads, 256x256x64 / 256x128x64 tiles at two waves per SIMD), inside the default library ----
+if want 2; then
 # Y7T_CONV_NW8=1 at run time; the plan is lowered with Y7T_CONV_WPANEL=0 so that the 1x1 layers keep row-major weights (the panels are packed for 128x32 tiles)
 say "2a. 8-wave instances in the benchmarked launch list, teacher-forced against the oracle"
 Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t2a_nw8_pinned.log 2>&1; echo "rc=$?" >> $O/t2a_nw8_pinned.log
@@ -76,8 +84,10 @@ for n in ("nw8", "nw8_s2"):
     except Exception as e:
         print(n, "no bench line:", e)
 PY
+fi
 
 # ---- 3. fixup: split-K reduced by the last arriving workgroup (batch-1 latency mode) ----
+if want 3; then
 say "3. fixup (Y7T_SPLITK_FIXUP, Y7T_CONV_SPLITK=2): layer parity incl. repeated launches, then latency mode against the default library"
 if [ -f $LIBD/exp_fixup.so ]; then
   Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer or whole_network or batch" > $O/t3_fixup.log 2>&1; echo "rc=$?" >> $O/t3_fixup.log
@@ -86,8 +96,10 @@ if [ -f $LIBD/exp_fixup.so ]; then
   Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python scripts/latency_mode.py 120 > $O/lat_fixup.txt 2>&1
   for f in default fixup; do echo "-- $f"; grep -i "fps" $O/lat_$f.txt | tail -8; done | tee -a $O/summary.txt
 else say "exp_fixup.so missing"; fi
+fi
 
 # ---- 4. next: tracker candidate lists on a run-time row stride (LDS-resident at 500 objects) ----
+if want 4; then
 say "4. next (Y7T_NEXT_TRACKER): tracker parity on the device, then the 500-object frame step against the default library"
 if [ -f $LIBD/exp_next.so ]; then
   Y7T_LIB=$LIBD/exp_next.so timeout 250 python -m pytest tests/test_tracker_gpu.py -q -m gpu > $O/t4_next.log 2>&1; echo "rc=$?" >> $O/t4_next.log
@@ -96,10 +108,15 @@ if [ -f $LIBD/exp_next.so ]; then
   Y7T_LIB=$LIBD/exp_next.so timeout 150 python scripts/time_tracker.py > $O/trk_next.txt 2>&1
   for f in default next; do echo "-- $f"; grep -v amdgpu.ids $O/trk_$f.txt | tail -12; done | tee -a $O/summary.txt
 else say "exp_next.so missing"; fi
+fi
+
 # ---- 5. stride-1 LDS-patch kernel with the step's DMAs behind its MFMAs (ABL bit 9: k_conv3x3_patch<..., 512>; correct results) ----
+if want 5; then
 say "5. patch kernel, DMA-late order (Y7T_CONV_ABLATE=512): parity in the benchmarked list, then the 3x3 / stride-1 rows against 1c's default table"
 Y7T_CONV_ABLATE=512 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t5_late_pinned.log 2>&1; echo "rc=$?" >> $O/t5_late_pinned.log
 tail -2 $O/t5_late_pinned.log | tee -a $O/summary.txt
 Y7T_CONV_ABLATE=512 timeout 200 python scripts/bench_conv.py 32 > $O/b5_late.txt 2>&1
 for f in b1c_default b5_late; do echo "-- $f (the 64-channel layers run single-tile under the switch: compare the 128-channel and 40x40 rows)"; grep " 3/1 \|TOTAL" $O/$f.txt; done | tee -a $O/summary.txt
+fi
+
 say "done"
