@@ -1,0 +1,77 @@
+"""CPU: the bench.py contract that can be checked without a GPU -- the command line the driver uses, the refusal to run without a device (no CPU
+fallback), and the shape of the bench lines committed under profiles/ (what `python bench.py` printed on the MI355X): every key the driver and the judge
+read, the arithmetic that ties them together, and the scope rules (value is whole-job throughput, roofline priced against the nominal peak,
+cpu_baseline a bounded port run on stated cores, vs_baseline null while BASELINE.json publishes nothing)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    txt = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
+    return json.loads(txt)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stdout + r.stderr)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())          # and prints no JSON line
+
+
+def test_bench_command_line_is_the_drivers():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert a.gpus == 1 and 1 <= a.steps <= 50 and 0 <= a.warmup <= 20          # no flags: one GPU, a run of minutes
+
+
+@pytest.mark.parametrize("name,workload", [("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"), ("r02_bench_line_cfg4.json", "configs[3]")])
+def test_committed_bench_lines_keep_the_contract(name, workload):
+    l = _line(name)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline"):
+        assert k in l, k
+    assert l["unit"] == "frames/s" and l["higher_is_better"] is True and l["scaling"] == "weak" and l["data"] == "synthetic" and l["dtype"] == "f16"
+    assert l["metric"].startswith("end-to-end fps (detect+track)") and base["metric"].startswith("end-to-end fps (detect+track)")
+    assert l["vs_baseline"] is None and base["published"] == {}                   # nothing published for this metric
+    c = l["config"]
+    assert workload in c["workload"] and "model" not in c
+    # value = frames of all ranks / wall time of the timed steps
+    fps = c["frames_per_step"] * c.get("sequences_per_gpu", 1) * l["n_gpus"] / (l["ms_per_step"] * 1e-3)
+    assert abs(fps - l["value"]) / l["value"] < 0.02 or abs(c["frames_per_step"] * l["n_gpus"] / (l["ms_per_step"] * 1e-3) - l["value"]) / l["value"] < 0.02
+    r = l["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0          # nominal dense fp16 peak, not the measured power-limited one
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    # achieved = algorithmic FLOP of one launch list / its HIP-event duration
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch_list"] / r["launch_list_ms"]) / r["achieved"] < 0.01
+    assert r["traffic"] is None or r["traffic"] > 0
+    if workload == "configs[1]":          # the driver's line (the other workloads are parity / stress cases run with --workload)
+        b = l["cpu_baseline"]
+        assert b["kind"] == "port" and b["unit"] == "frames/s" and b["cores"] >= 1 and b["value"] > 0 and b["sample"]
+        assert l["value"] > 10 * b["value"]
+
+
+def test_headline_line_carries_parity_and_reference_semantics_fps():
+    l = _line("r02_bench_line.json")
+    p = l["parity"]["well_conditioned"]
+    assert p["boxes_matched_same_class_1px_conf5e-3"] >= 0.95 * p["boxes_oracle"] and max(p["heads_mean_abs_err_over_logit_std"]) < 0.01
+    assert l["latency_mode"]["f32_chw_host"] and l["latency_mode"]["u8_hwc_host"] and l["fps_incl_h2d"]["value"] < l["value"] * 1.05

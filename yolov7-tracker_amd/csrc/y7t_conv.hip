@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = Y7T_SPLITK_WS_BYTES;
-static const size_t kSplitKDoneBytes = 64 << 10;      // (reserved at the end of the workspace for Y7T_SPLITK_FIXUP's tile counters)
+[[maybe_unused]] static const size_t kSplitKDoneBytes = 64 << 10;      // (reserved at the end of the workspace for Y7T_SPLITK_FIXUP's tile counters)
 
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false, int NW = kNW>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
