@@ -24,7 +24,7 @@ def build(defs=()):
     os.makedirs(bdir, exist_ok=True)
     text = open(srcs[0]).read()
     text, n = re.subn(r"asm volatile\([^;]*\);", ";", text)          # the s_waitcnt statements: loads complete at once here
-    assert n == 3, n
+    assert n == 4, n
     common = open(srcs[1]).read()
     common = common.replace("#define GLOBAL_AS __attribute__((address_space(1)))", "#define GLOBAL_AS").replace(
         "#define LDS_AS __attribute__((address_space(3)))", "#define LDS_AS")

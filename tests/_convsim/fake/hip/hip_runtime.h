@@ -49,6 +49,7 @@ void cs_launch(const std::function<void()>& kernel, dim3 grid, dim3 block);
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)          /* (only applied to wave-uniform values) */
 #define __threadfence() ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)   /* (workgroups run one after the other here) */
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -361,13 +361,24 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 || BM * BN >= 256 * 256 ? 1 
         // no k_splitk_reduce launch -- the LAST workgroup of a tile to arrive sums the slabs in split order (the same arithmetic in the same order
         // as k_splitk_reduce, so the result does not depend on who arrives last), adds the bias, activates and stores
         if (p.allow_splitk != 2) return;
-        __threadfence();                                   // this workgroup's slab is visible device-wide before its ticket
+        // Release / acquire with as few cache-wide operations as the memory model allows (__threadfence() is a seq_cst agent fence = an L2 write-back AND
+        // an L2 + L1 invalidate, per wave: eight of each per workgroup would cost more than the reduce launches this experiment removes):
+        //   every wave: its slab stores have completed (workgroup-scope release: they are in this XCD's L2)      -> barrier
+        //   ONE lane:   agent-scope release (one L2 write-back per workgroup) -> ticket -> if last: agent-scope acquire (one invalidate per TILE)
+        //   barrier -> the last arriver's waves read the slabs with plain loads (MI355X_MICROARCH.md, inter-workgroup visibility recipe)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         int* ticket = (int*)smem;                          // (the stages are drained; the bias corner lies behind them)
-        if (tid == 0) *ticket = atomicAdd(p.splitk_done + bid, 1);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-back has COMPLETED before the ticket (in this kernel the compiler's own wait after
+                                                               // buffer_wbl2 did not survive the wave-aggregation of the atomic: checked in the ISA)
+            const int tk = atomicAdd(p.splitk_done + bid, 1);
+            if (tk == p.splitk - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *ticket = tk;
+        }
         __syncthreads();
         if (*ticket != p.splitk - 1) return;
-        __threadfence();                                   // the other workgroups' slabs, not this CU's / XCD's stale lines
         if (tid == 0) p.splitk_done[bid] = 0;              // ready for the next launch on this stream
         const float* lb = (const float*)(smem + BIAS_OFF);
         for (int idx = tid; idx < BM * (BN / 4); idx += kNT) {
