@@ -100,7 +100,8 @@ def test_eight_wave_instances_of_the_default_build_on_the_host():
     L = cs.lib()
     for B, H, W, Cin, Cout, k, s, tile, kw in [(1, 17, 17, 64, 256, 3, 1, 256256564, {}), (1, 23, 19, 128, 256, 1, 1, 256256564, {}),
                                                (1, 20, 20, 64, 128, 3, 2, 256128564, {"korder": 1}), (1, 9, 9, 128, 128, 1, 1, 128128564, {}),
-                                               (1, 9, 13, 192, 128, 3, 1, 256128564, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64})]:
+                                               (1, 9, 13, 192, 128, 3, 1, 256128564, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64}),
+                                               (1, 19, 17, 192, 256, 1, 1, 256256532, {}), (1, 18, 18, 128, 256, 3, 2, 256256532, {"korder": 1})]:   # four-stage ring
         name = run_case(L, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
         assert name.endswith("8-wave"), name
     # through the dispatcher: the rule picks 256 x 256 when Cout % 256 == 0, else 256 x 128; layers outside the envelope keep their 4-wave kernel

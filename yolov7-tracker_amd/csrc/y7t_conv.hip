@@ -652,18 +652,21 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;
     }
-    // Opt-in experiment inside the default build (Y7T_CONV_NW8 = 1: 256 x 256 x 64 tiles where Cout allows, else 256 x 128; 6: 256 x 128; 7: 128 x 128 -- all on
+    // Opt-in experiment inside the default build (Y7T_CONV_NW8 = 1: 256 x 256 x 64 tiles where Cout allows, else 256 x 128; 2: 256 x 256 x 32 with a four-stage ring; 6: 256 x 128; 7: 128 x 128 -- all on
     // 512-thread workgroups at two waves per SIMD): the layers the generic kernel runs today whose DMA bytes per flop bound them.
     // Weights must be in a row layout (korder 0 / 1: lower the plan with Y7T_CONV_WPANEL=0 so that the 1x1 layers are not panel-packed for the 128 x 32 tile).
     {
         static int nw8 = -1;
         if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }
         const int want = (a.force_patch & 32) ? 1 : nw8;      // (force_patch bit 5: tests on the host simulator)
-        const int bn8 = (a.Cout_pad % 256 == 0 && want == 1) ? 256 : 128;
+        const int bn8 = (a.Cout_pad % 256 == 0 && (want == 1 || want == 2)) ? 256 : 128;
         if (want && a.korder < 2 && a.Cin % 64 == 0 && a.Cout_pad % 128 == 0 && (a.KH == 1 || a.KH == 3) &&
             ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256)) {
             if (want == 7) return launch_conv<128, 128, 64, 2, 8>(a, s);
             if (bn8 == 128) return launch_conv<256, 128, 64, 2, 8>(a, s);
+            // (the epilogue's transposition of a 256 x 256 tile needs 135 KB of LDS anyway: a FOUR-stage ring of 32-deep stages fits into the same
+            //  allocation and keeps three stages = 96 KB in flight instead of one = 64 KB -- Y7T_CONV_NW8=2)
+            if (want == 2 && a.Cout_pad % 256 == 0) return launch_conv<256, 256, 32, 4, 8>(a, s);
             return launch_conv<256, 256, 64, 2, 8>(a, s);
         }
     }
