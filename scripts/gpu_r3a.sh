@@ -62,17 +62,19 @@ fi
 
 # ---- 2. 8-wave instances of the generic kernel (512 threads, 256x256x64 / 256x128x64 tiles at two waves per SIMD), inside the default library ----
 if want 2; then
-# Y7T_CONV_NW8=1 at run time; the plan is lowered with Y7T_CONV_WPANEL=0 so that the 1x1 layers keep row-major weights (the panels are packed for 128x32 tiles)
+# Y7T_CONV_NW8=<form> in the environment: the C dispatcher takes the eligible layers to the 8-wave tiles, and detector/graph.py::nw8_eligible lowers exactly
+# those 1x1 layers with row-major weights (the weight panels are packed for the 128x32 tile); every other layer keeps its packing
 say "2a. 8-wave instances in the benchmarked launch list, teacher-forced against the oracle"
-Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t2a_nw8_pinned.log 2>&1; echo "rc=$?" >> $O/t2a_nw8_pinned.log
+Y7T_CONV_NW8=1 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t2a_nw8_pinned.log 2>&1; echo "rc=$?" >> $O/t2a_nw8_pinned.log
 tail -2 $O/t2a_nw8_pinned.log | tee -a $O/summary.txt
-say "2b. per-layer timing: row-major weights on 4 waves (the fair baseline), then 8 waves at 256x256x64 (1), 256x256x32 with a four-stage ring (2), 256x128 (6), 128x128 (7)"
-Y7T_CONV_WPANEL=0 timeout 200 python scripts/bench_conv.py 32 > $O/b2_rowmajor.txt 2>&1
-for v in 1 2 6 7; do Y7T_CONV_NW8=$v Y7T_CONV_WPANEL=0 timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_$v.txt 2>&1; done
-for f in rowmajor nw8_1 nw8_2 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \| 20x20 " $O/b2_$f.txt | head -60; done | tee -a $O/summary.txt
+say "2b. per-layer timing (baseline: 1c's default table): 8 waves at 256x256x64 (1), 256x256x32 with a four-stage ring (2), 256x128 (6), 128x128 (7)"
+[ -f $O/b1c_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b1c_default.txt 2>&1
+cp $O/b1c_default.txt $O/b2_default.txt
+for v in 1 2 6 7; do Y7T_CONV_NW8=$v timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_$v.txt 2>&1; done
+for f in default nw8_1 nw8_2 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \| 20x20 " $O/b2_$f.txt | head -60; done | tee -a $O/summary.txt
 say "2c. bench line with the 8-wave instances on (alone, and together with the 512-thread stride-2 patch kernel)"
-Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8.json 2> $O/bench_nw8.err
-Y7T_CONV_NW8=1 Y7T_CONV_WPANEL=0 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8_s2.json 2> $O/bench_nw8_s2.err
+Y7T_CONV_NW8=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8.json 2> $O/bench_nw8.err
+Y7T_CONV_NW8=1 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8_s2.json 2> $O/bench_nw8_s2.err
 python - <<'PY' | tee -a $O/summary.txt
 import json
 for n in ("nw8", "nw8_s2"):

@@ -654,7 +654,8 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     }
     // Opt-in experiment inside the default build (Y7T_CONV_NW8 = 1: 256 x 256 x 64 tiles where Cout allows, else 256 x 128; 2: 256 x 256 x 32 with a four-stage ring; 6: 256 x 128; 7: 128 x 128 -- all on
     // 512-thread workgroups at two waves per SIMD): the layers the generic kernel runs today whose DMA bytes per flop bound them.
-    // Weights must be in a row layout (korder 0 / 1: lower the plan with Y7T_CONV_WPANEL=0 so that the 1x1 layers are not panel-packed for the 128 x 32 tile).
+    // Weights must be in a row layout (korder 0 / 1): detector/graph.py::nw8_eligible mirrors this rule and lowers exactly these 1x1 layers row-major when the
+    // same switch is in the environment (their weight panels are packed for the 128 x 32 tile); a layer that arrives panel-packed never gets here.
     {
         static int nw8 = -1;
         if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }

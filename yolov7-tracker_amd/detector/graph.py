@@ -151,6 +151,18 @@ def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 2
     return max(eff(16, 16), eff(32, 8), eflat) >= 0.8
 
 
+def nw8_eligible(M, cin, cout, k):
+    """mirror of the 8-wave rule in conv_dispatch (csrc/y7t_conv.hip), OPT-IN with Y7T_CONV_NW8 = 1 / 2 / 6 / 7 in the environment: a layer of the generic kernel
+    with Cin % 64 == 0, Cout_pad % 128 == 0 and at least 256 tiles of 256 pixels x (256 | 128) channels.  (A disagreement with the C rule is harmless: a layer
+    lowered row-major that stays on four waves merely loses its weight panels.)"""
+    want = os.environ.get("Y7T_CONV_NW8", "0")
+    if want not in ("1", "2", "6", "7") or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+        return False
+    cout_pad = -(-cout // 64) * 64
+    bn8 = 256 if (cout_pad % 256 == 0 and want in ("1", "2")) else 128
+    return k in (1, 3) and cin % 64 == 0 and cout_pad % 128 == 0 and (M // 256) * (cout_pad // bn8) >= 256
+
+
 def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32):
     """mirror of y7t_conv_patch_s2_launch (csrc/y7t_conv_patch_s2.hip), which is OPT-IN: only with Y7T_CONV_PATCH_S2=1 in the environment when the plan is
     lowered (the kernel has not been measured on a GPU yet; the default launch list keeps the generic kernel for the down-sampling layers).
@@ -284,6 +296,8 @@ def lower(nodes, H, W, max_batch=1):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32):
             korder = 4                               # opt-in experiment: stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
+        elif n.k == 1 and nw8_eligible(max_batch * n.h * n.w, cin, cout, n.k) and level < 0 and getattr(src, "virt_up", None) is None:
+            korder = 0                               # opt-in experiment: this 1x1 layer runs on the 8-wave 256-pixel tiles, which read row-major weights
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level
