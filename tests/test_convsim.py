@@ -82,6 +82,41 @@ def test_shipped_kernel_source_on_the_host(case):
     assert name.startswith("igemm<") and (tile == 0 or ("splitK" in name) == bool(kw.get("splitk")))      # (the dispatch rules split K of small problems themselves)
 
 
+@pytest.mark.parametrize("korder,Cout,lat_first,force", [(0, 128, True, 0), (3, 192, False, 0), (3, 256, True, 0), (0, 256, True, 32), (0, 384, False, 32)],
+                         ids=["rows-128", "panels-64", "panels-128", "8-wave-256", "8-wave-128"])
+def test_upsample_on_read_loader_on_the_host(korder, Cout, lat_first, force):
+    """the DUAL instance of the 1x1 fast path (default launch list: the three convs behind Concat[lateral, Upsample(x)], /root/reference/cfg/deploy/yolov7-w6.yaml:75,89,103):
+    K-steps whose channels lie in the upsampled range DMA pixel (y >> 1, x >> 1) of the half-resolution tensor -- against a conv over the materialised concat"""
+    L = cs.lib()
+    rng = np.random.default_rng(5)
+    B, H, W, C_lat, C_up = 2, 10, 14, 64, 128
+    Cin = C_lat + C_up
+    up_c0 = C_lat if lat_first else 0                                    # nn.Upsample output after or before the lateral tensor in the concat
+    lat = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)            # the concat buffer: the upsampled channel range is never written (garbage) ...
+    lat[..., up_c0:up_c0 + C_up] = 77.0                                  # ... and must never be read
+    half = rng.normal(0, 1, (B, H // 2, W // 2, 192)).astype(np.float16)  # a wider half-resolution buffer, slice at channel 32
+    Wt = (rng.normal(0, 1, (Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.normal(0, 0.5, Cout).astype(np.float32)
+    cp = (Cout + 63) // 64 * 64
+    wp = pack_w(Wt, Cin, cp, 0)
+    if korder == 3:
+        from yolov7_tracker_amd.detector import weights
+        wp = weights.panel_pack_linear(wp)
+    bp = np.zeros(cp, np.float32)
+    bp[:Cout] = bias
+    out = np.full((B, H, W, Cout), 7.0, np.float16)
+    rc = L.cs_conv_dual(lat.ctypes.data, Cin, 0, half.ctypes.data, 192, 32, up_c0, C_up, B, H, W, Cin, wp.ctypes.data, bp.ctypes.data, out.ctypes.data, Cout, 0, Cout, cp, 1,
+                        korder, force)
+    assert rc == 0, L.cs_last_error().decode()
+    name = L.cs_last_kernel().decode()
+    assert "upsample-on-read" in name and (("8-wave" in name) == bool(force)), name          # (force: the opt-in 8-wave instances of the same loader)
+    x = lat.astype(np.float32)
+    x[..., up_c0:up_c0 + C_up] = np.repeat(np.repeat(half[..., 32:32 + C_up].astype(np.float32), 2, axis=1), 2, axis=2)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(out.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_eight_wave_experiment_on_the_host():
     """-DY7T_IGEMM_NW=8 (512-thread workgroups; scripts/ablate/build_experiments.py nw8), not yet run on a GPU: same results as the 4-wave build"""
     L8 = cs.lib(("-DY7T_IGEMM_NW=8",))

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 || BM * BN >= 256 * 256 ? 1 
     constexpr int kNT = 64 * NW, kNWM = NW / 2;  // threads, waves along the pixel dimension
     constexpr int RPR = RPW * NW;                // rows per load round over the waves (32 or 64; twice that with 8 waves)
     constexpr int WTN = BN / 2, WTM = BM / kNWM; // wave tile
-    static_assert(NW == 4 || (EPI == 0 && !DUAL), "the 8-wave experiment covers the plain convolution only");
+    static_assert(NW == 4 || EPI == 0, "the 8-wave instances cover the plain convolution and the upsample-on-read loader, not the Detect epilogue");
     constexpr int TN = WTN / 32, TM = WTM / 32;  // 32x32 MFMA tiles per wave
     constexpr int RM = BM / RPR, RN = BN / RPR;  // load rounds per operand
     constexpr int NLD = RM + RN;                 // DMA instructions per thread per stage
@@ -618,6 +618,13 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
 
+// Y7T_CONV_NW8 (opt-in experiment: 8-wave instances of this kernel inside the default build), or force_patch bit 5 from the host simulator's tests
+static int nw8_want(const Y7TConvArgs& a) {
+    static int nw8 = -1;
+    if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }
+    return (a.force_patch & 32) ? 1 : nw8;
+}
+
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
 #if Y7T_IGEMM_NW == 8      // experimental library: 512-thread workgroups, 64-deep stages, 256 x 256 / 256 x 128 / 128 x 128 tiles only (layer-level timing and tests)
     if (a.epi || a.up_C > 0 || a.korder >= 2 || a.Cout_pad % 128 || a.Cin % 64) {
@@ -641,6 +648,13 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
             y7t_set_error("conv: upsample-on-read channel range [%d, %d) / map %dx%d not supported", a.up_c0, a.up_c0 + a.up_C, a.H, a.W);
             return Y7T_E_ARG;
         }
+        {   // the same loader on the 8-wave 256-pixel tiles (64-deep stages: the upsampled range must be a multiple of 64 channels; row-major weights)
+            const int want = nw8_want(a);
+            const int bn8 = (a.Cout_pad % 256 == 0 && want == 1) ? 256 : 128;
+            if (want && a.korder == 0 && a.Cout_pad % 128 == 0 && a.up_c0 % 64 == 0 && a.up_C % 64 == 0 &&
+                ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256))
+                return bn8 == 256 ? launch_conv_ut<256, 256, 64, 2, true, 1, 0, true, 8>(a, s) : launch_conv_ut<256, 128, 64, 2, true, 1, 0, true, 8>(a, s);
+        }
         return a.Cout_pad % 128 == 0 ? launch_conv_ut<128, 128, 32, 2, true, 1, 0, true>(a, s) : launch_conv_ut<128, 64, 32, 2, true, 1, 0, true>(a, s);
     }
     if (a.korder == 4) return y7t_conv_patch_s2_launch(a, s);   // stride-2 LDS-patch kernel's panels: only that kernel reads them
@@ -657,9 +671,7 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     // Weights must be in a row layout (korder 0 / 1): detector/graph.py::nw8_eligible mirrors this rule and lowers exactly these 1x1 layers row-major when the
     // same switch is in the environment (their weight panels are packed for the 128 x 32 tile); a layer that arrives panel-packed never gets here.
     {
-        static int nw8 = -1;
-        if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }
-        const int want = (a.force_patch & 32) ? 1 : nw8;      // (force_patch bit 5: tests on the host simulator)
+        const int want = nw8_want(a);
         const int bn8 = (a.Cout_pad % 256 == 0 && (want == 1 || want == 2)) ? 256 : 128;
         if (want && a.korder < 2 && a.Cin % 64 == 0 && a.Cout_pad % 128 == 0 && (a.KH == 1 || a.KH == 3) &&
             ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256)) {

@@ -296,7 +296,8 @@ def lower(nodes, H, W, max_batch=1):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32):
             korder = 4                               # opt-in experiment: stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
-        elif n.k == 1 and nw8_eligible(max_batch * n.h * n.w, cin, cout, n.k) and level < 0 and getattr(src, "virt_up", None) is None:
+        elif (n.k == 1 and nw8_eligible(max_batch * n.h * n.w, cin, cout, n.k) and level < 0 and
+              (getattr(src, "virt_up", None) is None or (src.virt_up[1] % 64 == 0 and src.virt_up[0].c % 64 == 0))):      # (upsample-on-read: 64-deep stages)
             korder = 0                               # opt-in experiment: this 1x1 layer runs on the 8-wave 256-pixel tiles, which read row-major weights
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
