@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 3, FIRST GPU call: the four experiments that were written and host-validated at the end of round 2 without GPU minutes.
+# Round 3, FIRST GPU call: the experiments that were written and host-validated at the end of round 2 without GPU minutes (stride-2 patch kernel, 8-wave
+# instances of the generic kernel, split-K fix-up, tracker candidate lists in LDS, DMA-late order of the stride-1 patch kernel).
 #
 #   BEFORE calling gpurun (here, on the CPU):   python -m yolov7_tracker_amd.build && python scripts/ablate/build_experiments.py fixup next
 #   (the experimental libraries lib/exp_{fixup,next}.so travel with the snapshot; the stride-2 patch kernel and the 8-wave instances of the generic kernel
@@ -44,9 +45,9 @@ Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 150 python -m pytest te
 echo "dma-late order, parity:" | tee -a $O/summary.txt; tail -2 $O/t1c_s2_layers_late.log | tee -a $O/summary.txt
 say "1d. bench line with the stride-2 kernel on (all eight layers / only the layers with 256-channel panels)"
 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
-Y7T_CONV_PATCH_S2=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2.json 2> $O/bench_s2.err
-Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_MIN_COUT=256 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2_wide.json 2> $O/bench_s2_wide.err
-Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_s2_nw8.json 2> $O/bench_s2_nw8.err
+Y7T_CONV_PATCH_S2=1 timeout 240 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_s2.json 2> $O/bench_s2.err
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_MIN_COUT=256 timeout 240 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_s2_wide.json 2> $O/bench_s2_wide.err
+Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_s2_nw8.json 2> $O/bench_s2_nw8.err
 python - <<'PY' | tee -a $O/summary.txt
 import json
 for n in ("default", "s2", "s2_wide", "s2_nw8"):
@@ -73,8 +74,8 @@ cp $O/b1c_default.txt $O/b2_default.txt
 for v in 1 2 6 7; do Y7T_CONV_NW8=$v timeout 200 python scripts/bench_conv.py 32 > $O/b2_nw8_$v.txt 2>&1; done
 for f in default nw8_1 nw8_2 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \| 20x20 " $O/b2_$f.txt | head -60; done | tee -a $O/summary.txt
 say "2c. bench line with the 8-wave instances on (alone, and together with the 512-thread stride-2 patch kernel)"
-Y7T_CONV_NW8=1 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8.json 2> $O/bench_nw8.err
-Y7T_CONV_NW8=1 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 > $O/bench_nw8_s2.json 2> $O/bench_nw8_s2.err
+Y7T_CONV_NW8=1 timeout 240 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nw8.json 2> $O/bench_nw8.err
+Y7T_CONV_NW8=1 Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 240 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nw8_s2.json 2> $O/bench_nw8_s2.err
 python - <<'PY' | tee -a $O/summary.txt
 import json
 for n in ("nw8", "nw8_s2"):
@@ -117,6 +118,7 @@ if want 5; then
 say "5. patch kernel, DMA-late order (Y7T_CONV_ABLATE=512): parity in the benchmarked list, then the 3x3 / stride-1 rows against 1c's default table"
 Y7T_CONV_ABLATE=512 timeout 250 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t5_late_pinned.log 2>&1; echo "rc=$?" >> $O/t5_late_pinned.log
 tail -2 $O/t5_late_pinned.log | tee -a $O/summary.txt
+[ -f $O/b1c_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b1c_default.txt 2>&1
 Y7T_CONV_ABLATE=512 timeout 200 python scripts/bench_conv.py 32 > $O/b5_late.txt 2>&1
 for f in b1c_default b5_late; do echo "-- $f (the 64-channel layers run single-tile under the switch: compare the 128-channel and 40x40 rows)"; grep " 3/1 \|TOTAL" $O/$f.txt; done | tee -a $O/summary.txt
 fi
