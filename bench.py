@@ -340,10 +340,52 @@ def halves_mode(args, det_factory, frames, dets_dev, trk, results, plant):
     return dt_s, span / K, dets[0]
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(argv, n):
+    """the command `python bench.py --gpus N ...` re-executes itself as when it was started WITHOUT a launcher (no WORLD_SIZE in the environment):
+    one rank per GPU under torch.distributed.run, exactly the driver's own command line (rendezvous on 127.0.0.1: the hostname may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves and pass their output through (rank 0 prints the ONE JSON line).
+    Fewer than N devices is an error, never a silent n_gpus = 1 line."""
+    import subprocess
+    share = os.environ.get("Y7T_BENCH_SHARE_GPU") == "1"
+    if os.environ.get("Y7T_BENCH_DRYRUN_LAUNCH") == "1":      # (tests/test_bench_contract.py: the command, without starting it)
+        print(json.dumps({"launch": launcher_command(sys.argv[1:], args.gpus)}))
+        return 0
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have == 0:
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if have < args.gpus and not share:
+        raise SystemExit("bench.py --gpus %d: only %d device%s visible on this node (one rank per GPU; Y7T_BENCH_SHARE_GPU=1 with "
+                         "Y7T_BENCH_BACKEND=gloo is the 1-GPU plumbing test, not a measurement)" % (args.gpus, have, "" if have == 1 else "s"))
+    cmd = launcher_command(sys.argv[1:], args.gpus)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     global TRACKER_THREADS
     args = parse()
     TRACKER_THREADS = args.tracker_threads
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started under a launcher with WORLD_SIZE=%s: the two must agree (one rank per GPU)"
+                         % (args.gpus, os.environ.get("WORLD_SIZE")))
     cfg3, cfg4 = args.workload == "cfg3", args.workload == "cfg4"
     if args.n_obj is None:
         args.n_obj = 500 if cfg3 else 80
@@ -354,6 +396,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     share = os.environ.get("Y7T_BENCH_SHARE_GPU") == "1"     # smoke-test the N>1 code path on a 1-GPU box (with the gloo backend)
     backend = os.environ.get("Y7T_BENCH_BACKEND", "nccl")    # 'nccl' == RCCL on ROCm
+    if not share and local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no device of its own: %d visible, one rank per GPU" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(0 if share else local)
     dist = None
     cdev = "cuda" if backend == "nccl" else "cpu"            # where the (tiny) collective payloads live

@@ -43,6 +43,23 @@ def test_bench_command_line_is_the_drivers():
     assert a.gpus == 1 and 1 <= a.steps <= 50 and 0 <= a.warmup <= 20          # no flags: one GPU, a run of minutes
 
 
+def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
+    """VERDICT r2 missing 1: `python bench.py --gpus N` must be N ranks (one per GPU, RCCL), not an n_gpus = 1 line.  Without a launcher in the
+    environment bench.py re-executes itself under torch.distributed.run -- the driver's own command line -- and refuses a WORLD_SIZE that disagrees."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       env=dict(env, Y7T_BENCH_DRYRUN_LAUNCH="1"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    j = " ".join(cmd)
+    assert "-m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port" in j
+    assert j.endswith("bench.py --gpus 8 --steps 20 --warmup 5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
 @pytest.mark.parametrize("name,workload", [("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"), ("r02_bench_line_cfg4.json", "configs[3]")])
 def test_committed_bench_lines_keep_the_contract(name, workload):
     l = _line(name)

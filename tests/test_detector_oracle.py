@@ -242,3 +242,43 @@ def test_patch_eligibility_rule():
     assert not ok(80, 80, 256, 256, 32, s=2) and not ok(80, 80, 256, 256, 32, k=1, p=0)
     assert not ok(80, 80, 96, 256, 32)                 # Cin % 64
     assert not ok(24, 24, 256, 256, 64)                # 24x24: 16x16 tiles 56 %, 32x8 tiles 75 %, no strip tiling for this width
+
+
+def test_training_graph_spec_and_liveness():
+    """cfg/training/yolov7-w6.yaml (what the reference's training saves, README.md:101): the aux branch -- convs 118-121 and IAuxDetect's m2 convs,
+    computed and discarded at inference (models/yolo.py:141-153) -- never reaches the launch list; the main head folds ImplicitA / ImplicitM"""
+    dep = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, 1)
+    trn = graph.lower(graph.parse(arch.yolov7_w6_training(10))[0], 1280, 1280, 1)
+    assert len(trn.ops) == len(dep.ops) == 99 and abs(trn.macs - dep.macs) < 1 and trn.arena_bytes == dep.arena_bytes
+    assert [w["kind"] for w in trn.wlayout if w["kind"] != "conv"] == ["IAuxDetect"] * 4
+    sd = util.training_checkpoint_state_dict(arch.yolov7_w6_training(10), graph.lower(graph.parse(arch.yolov7_w6_training(10))[0], 128, 128, 1))
+    w = next(w for w in trn.wlayout if w["kind"] == "IAuxDetect")
+    W, b = weights.folded(w, sd)
+    W0, b0 = sd[w["wkey"] + ".weight"].double().numpy(), sd[w["wkey"] + ".bias"].double().numpy()
+    base, lvl = w["wkey"].rsplit(".m.", 1)
+    ia, im = sd["%s.ia.%s.implicit" % (base, lvl)].double().numpy().reshape(-1), sd["%s.im.%s.implicit" % (base, lvl)].double().numpy().reshape(-1)
+    np.testing.assert_allclose(W, W0 * im[:, None, None, None], rtol=1e-12)
+    np.testing.assert_allclose(b, (b0 + W0.reshape(len(b0), -1) @ ia) * im, rtol=1e-12)         # im * (W (x + ia) + b)
+
+
+def test_training_spec_equals_reference_yaml_and_oracle_equals_reference_model(have_reference):
+    if not have_reference:
+        pytest.skip("/root/reference not present")
+    import yaml
+    from oracle import ref_harness
+    y = yaml.safe_load(open("/root/reference/cfg/training/yolov7-w6.yaml"))
+    norm = lambda L: [str(x).replace("'None'", "None") for x in L]
+    assert norm(y["backbone"] + y["head"]) == norm(arch.yolov7_w6_training(y["nc"])["layers"])
+    spec = arch.yolov7_w6_training(10)
+    nodes, _ = graph.parse(spec)
+    plan = graph.lower(graph.parse(spec)[0], 64, 64, 1)
+    sd = util.training_checkpoint_state_dict(spec, plan)
+    m = ref_harness.build_reference_model("cfg/training/yolov7-w6.yaml", 10)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected[:5]
+    assert all(".anchor" in k or "num_batches_tracked" in k for k in missing), [k for k in missing if ".anchor" not in k][:5]
+    img = torch.rand((1, 3, 64, 128), generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = m(img)
+    dec, raw = dt.forward(nodes, sd, img, spec["anchors"])
+    assert torch.equal(dec, ref[0])                                   # IAuxDetect.forward inference branch: main levels only (yolo.py:141-158)

@@ -124,3 +124,29 @@ def test_500_objects_300_frames_stream_invariants(kind):
         sizes.append(len(ids))
     assert max_id <= BaseTrack._count
     assert np.mean(sizes[50:]) > 200 and max(sizes) > 350          # the objects drift out of the image over 300 frames; early on most are followed
+
+
+def test_cfg3_full_size_botsort_equals_oracle():
+    """BASELINE configs[2] at its full size, against the ORACLE (the invariants above are not a comparison): the scene bench.py
+    --workload cfg3 tracks -- 300 frames x 500 objects reflected at the border, a synthetic 2x3 camera-motion warp per frame -- through the device
+    BoT-SORT (xywh Kalman, multi_gmc, /root/reference/tracker/botsort.py:250-269,313-493) and through oracle/tracker_np.py (pinned to the reference's
+    own BoTSORT class by the goldens `botsort_gmc` / `botsort_crowd` and the live-reference tests): every id of every frame identical, boxes to 1e-6."""
+    import types
+    from oracle import tracker_np
+    from tests import util
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.botsort import BoTSORT
+    n_frames, n_obj = 300, 500
+    dets = synth.make_detections(n_frames, n_obj, 1280, seq_idx=0, bounce=True)
+    warps = synth.make_warps(n_frames, seq_idx=0)
+    want = tracker_np.run("botsort", dets, kalman_format="botsort", warps=warps)
+    BaseTrack._count = 0
+    opts = types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="botsort", img_size=1280, iou_thresh=0.5, max_tracks=2048, max_dets=1024)
+    trk = BoTSORT(opts, frame_rate=30)
+    got = []
+    for f, d in enumerate(dets):
+        cur = trk.update(d, None, warp=warps[f])
+        got.append([(t.track_id, t.tlwh, float(t.cls), float(t.score)) for t in cur])
+    assert np.mean([len(w) for w in want]) > 300 and max(r[0] for w in want for r in w) > 2000      # a crowd, with thousands of identities issued
+    util.assert_same_tracks(got, want, "cfg3 full size: 300 frames x 500 objects, BoT-SORT + warps")

@@ -207,3 +207,14 @@ def test_hostsim_tracker_equals_oracle_on_random_scenes(kind, fmt):
         want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
         got = hs.run(kind, dets, kalman_format=fmt, warps=warps)
         util.assert_same_tracks(got, want, "%s/%s scene %d (%d objects, %d frames, gap %d)" % (kind, fmt, scene, n_obj, n_frames, gap))
+
+
+def test_hostsim_cfg3_full_size_botsort_equals_oracle():
+    """BASELINE configs[2] at full size (300 frames x 500 objects, a camera-motion warp per frame; the scene of `bench.py --workload cfg3`): the host
+    build of the device BoT-SORT program against the oracle -- every id, every box.  The device run of the same comparison: tests/test_fullsize_gpu.py"""
+    from yolov7_tracker_amd import synth
+    dets = synth.make_detections(300, 500, 1280, seq_idx=0, bounce=True)
+    warps = synth.make_warps(300, seq_idx=0)
+    want = tracker_np.run("botsort", dets, kalman_format="botsort", warps=warps)
+    got = _hostsim.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
+    util.assert_same_tracks(got, want, "cfg3 full size")

@@ -65,3 +65,52 @@ def test_two_ranks_frame_sharded_single_stream_runs():
     d = _run("frames", 2, 1, 4, 640, 40)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["tracks_alive_last_frame"] > 10
     json.dump(d, open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu_frames.json"), "w"), indent=1)
+
+
+def _bench_plain(gpus, extra_env=None):
+    """`python bench.py --gpus N ...` with NO launcher: bench.py starts its own ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "Y7T_BENCH_SHARE_GPU", "Y7T_BENCH_BACKEND")}
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--batch", "4", "--img", "640", "--n_obj", "40",
+           "--no_cpu_baseline", "--no_latency_mode"]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def test_gpus_n_with_too_few_devices_is_an_error_not_an_n_gpus_1_line():
+    import torch
+    n = torch.cuda.device_count()
+    r = _bench_plain(n + 1)
+    assert r.returncode != 0 and "visible on this node" in (r.stdout + r.stderr)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_self_launched_two_ranks_share_the_gpu_through_the_same_code_path():
+    """the self-launch itself on the one-GPU box (gloo, both ranks on the device): n_gpus = 2 in the line, ids re-based by the exclusive prefix"""
+    r = _bench_plain(2, {"Y7T_BENCH_SHARE_GPU": "1", "Y7T_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    g = d["config"]["result_gather"]
+    assert d["n_gpus"] == 2 and g["id_base_per_rank"][0] == 0 and g["id_base_per_rank"][1] > 0
+
+
+def test_rccl_two_ranks_on_two_devices():
+    """needs >= 2 MI355X in the lease (the driver's 8-GPU tier; skipped on the 1-GPU boxes): bench.py --gpus 2 with no launcher -> two ranks, the
+    `nccl` backend (= RCCL), result gather with the exclusive-prefix id bases, equal to a single-process run over the two sequences."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device visible: RCCL wants a GPU per rank")
+    r = _bench_plain(2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl"
+    g = d["config"]["result_gather"]
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    rows, bases = [], []
+    for seq in range(2):
+        bases.append(BaseTrack._count)
+        t = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5, max_tracks=512, max_dets=512))
+        rows.append(sum(len(t.update(det, None)) for det in synth.make_detections(3 * 4, 40, 640, seq_idx=seq, bounce=True)))
+    assert g["rows_per_rank"] == rows and g["id_base_per_rank"] == bases

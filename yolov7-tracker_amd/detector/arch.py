@@ -14,7 +14,7 @@ def _conv(f, c, k=1, s=1, act=None):
     return [f, 1, "Conv", [c, k, s] if act is None else [c, k, s, None, 1, act]]
 
 
-def yolov7_w6(nc=80):
+def yolov7_w6(nc=80, training=False):
     L = [[-1, 1, "ReOrg", []], _conv(-1, 64, 3, 1)]
     for c in (128, 256, 512, 768, 1024):            # five down-stages: 3x3/s2 + ELAN(4-way concat) + 1x1
         h = c // 2
@@ -30,8 +30,18 @@ def yolov7_w6(nc=80):
     for c, route in ((256, 71), (384, 59), (512, 47)):   # bottom-up
         L += [_conv(-1, c, 3, 2), [[-1, route], 1, "Concat", [1]]] + elan_h(c)
     L += [_conv(83, 256, 3, 1), _conv(93, 512, 3, 1), _conv(103, 768, 3, 1), _conv(113, 1024, 3, 1)]
-    L.append([[114, 115, 116, 117], 1, "Detect", ["nc", "anchors"]])
+    if training:       # cfg/training/yolov7-w6.yaml:156-162 -- what train_aux.py produces: four aux-head convs + IAuxDetect (models/yolo.py:111-158)
+        L += [_conv(83, 320, 3, 1), _conv(71, 640, 3, 1), _conv(59, 960, 3, 1), _conv(47, 1280, 3, 1)]
+        L.append([[114, 115, 116, 117, 118, 119, 120, 121], 1, "IAuxDetect", ["nc", "anchors"]])
+    else:
+        L.append([[114, 115, 116, 117], 1, "Detect", ["nc", "anchors"]])
     return {"nc": nc, "depth_multiple": 1.0, "width_multiple": 1.0, "anchors": W6_ANCHORS, "layers": L, "n_backbone": 47}
+
+
+def yolov7_w6_training(nc=80):
+    """the graph of the checkpoints the reference's training actually saves for w6 (README.md:101, cfg/training/yolov7-w6.yaml): at inference the aux
+    branch is dead work (yolo.py:141-153 computes and discards it) and ImplicitA / ImplicitM fold into the main head's 1x1 convs"""
+    return yolov7_w6(nc, training=True)
 
 
 def yolov7_tiny(nc=80):
@@ -63,4 +73,4 @@ def load_yaml(path, nc=None):
     return spec
 
 
-ARCHS = {"yolov7-w6": yolov7_w6, "yolov7-tiny": yolov7_tiny}
+ARCHS = {"yolov7-w6": yolov7_w6, "yolov7-tiny": yolov7_tiny, "yolov7-w6-training": yolov7_w6_training}

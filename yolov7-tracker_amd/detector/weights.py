@@ -59,6 +59,8 @@ def calibrate_bn(nodes, sd, hw=(640, 640), seed=0, image=None):
     for n in nodes[1:]:
         if n.kind == "detect" or any(j not in vals for j in n.src):
             continue
+        if n.kind == "conv" and n.wkey + ".conv.weight" not in sd:      # a dead branch (the aux head of training graphs): not in the plan, no weights drawn
+            continue
         x = vals[n.src[0]]
         if n.kind == "reorg":
             y = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
