@@ -64,7 +64,7 @@ def parse():
     return ap.parse_args()
 
 
-TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (one wave up to 192 detections, 4 up to 384, 16 beyond)
+TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (four waves up to 384 detections, sixteen beyond: csrc/y7t_tracker.hip::step_threads)
 
 
 def make_opts():

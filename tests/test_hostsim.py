@@ -215,6 +215,7 @@ def test_hostsim_cfg3_full_size_botsort_equals_oracle():
     from yolov7_tracker_amd import synth
     dets = synth.make_detections(300, 500, 1280, seq_idx=0, bounce=True)
     warps = synth.make_warps(300, seq_idx=0)
+    from oracle import tracker_np
     want = tracker_np.run("botsort", dets, kalman_format="botsort", warps=warps)
-    got = _hostsim.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
+    got = hs.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
     util.assert_same_tracks(got, want, "cfg3 full size")

@@ -545,3 +545,57 @@ def test_fused_tracker_equals_oracle_on_random_scenes(kind, fmt):
         want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
         got, _ = run_device_tracker(kind, fmt, dets, warps=warps)
         util.assert_same_tracks(got, want, "%s scene %d (%d objects, %d frames, gap %d)" % (kind, scene, n_obj, n_frames, gap))
+
+
+def test_deepsort_empty_and_low_confidence_first_frames_then_real_embeddings():
+    """frames without a detection above det_thresh before the first real one must not pin the feature width to a guess --
+    real footage opens like this, and OSNet / the DeepSORT net are 512 wide.  Tracks only exist after a kept detection, so the feature state is
+    re-made for the real width; once vectors are stored a change of width is an error."""
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    BaseTrack._count = 0
+    rng = np.random.default_rng(5)
+    dim = [512]
+    t = DeepSORT(make_opts(), frame_rate=30, reid_model=lambda crops: rng.normal(size=(len(crops), dim[0])).astype(np.float32))
+    img = np.zeros((200, 300, 3), np.uint8)
+    assert t.update(np.zeros((0, 6), np.float32), img) == []
+    assert t.update(np.array([[10, 10, 50, 90, 0.1, 0]], np.float32), img) == []          # below det_thresh = 0.2: no features asked for
+    one = np.array([[10, 10, 50, 90, 0.9, 3]], np.float32)
+    t.update(one, img)
+    assert t._feat_dim == 512
+    t.update(one, img)
+    cur = t.update(one, img)
+    assert [c.track_id for c in cur] == [1] and cur[0].cls == 3
+    dim[0] = 128
+    with pytest.raises(ValueError):
+        t.update(one, img)
+
+
+def test_plain_step_refuses_a_deepsort_pool():
+    """y7t_tracker_step on a pool initialised as DeepSORT would create / update tracks without the appearance rings (a reused
+    slot keeps its previous occupant's vectors): frames with detections are refused with Y7T_E_STATE; the predict-only step is shared"""
+    from yolov7_tracker_amd import _lib
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack, BaseTracker
+    from yolov7_tracker_amd.tracker.deepsort import DeepSORT
+    BaseTrack._count = 0
+    t = DeepSORT(make_opts(), frame_rate=30, reid_model=lambda crops: np.ones((len(crops), 64), np.float32))
+    with pytest.raises(_lib.Y7TError):
+        BaseTracker._launch(t, np.array([[10, 10, 50, 90, 0.9, 3]], np.float32))
+    assert t.update_without_detection(None, None) == []
+    # the feature tensor of the device chain is validated too (a short / half tensor would be read out of bounds)
+    with pytest.raises(_lib.Y7TError):
+        t._launch(torch.zeros((2, 6), device="cuda"), torch.zeros((1, 64), device="cuda"))
+
+
+def test_nms_max_det_beyond_the_lds_budget_is_an_argument_error():
+    """k_nms_keep keeps max_det boxes in LDS; a huge max_det is refused as an argument error, not a bare launch failure"""
+    import ctypes
+    from yolov7_tracker_amd import _lib
+    L = _lib.load()
+    B, cap = 1, 256
+    ws = torch.zeros(int(L.y7t_det_postprocess_workspace_bytes(B, cap, 30000)), dtype=torch.uint8, device="cuda")
+    lb = torch.tensor([[1.0, 0, 0, 64, 64]], device="cuda")
+    dets, nd, keep = torch.zeros((B, 4000, 6), device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros((B, 4000), dtype=torch.int32, device="cuda")
+    rc = L.y7t_det_postprocess(None, None, None, None, None, 4, 3, 15, B, ctypes.c_float(0.01), ctypes.c_float(0.45), 4000, 30000, cap, _lib.ptr(lb),
+                               _lib.ptr(dets), _lib.ptr(nd), _lib.ptr(keep), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    assert rc == -1 and b"max_det" in L.y7t_last_error()

@@ -415,6 +415,11 @@ Y7TCandWs y7t_post_cand_ws(void* ws, int B, int cap) {
 
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     const int B = a.B, cap = a.cap;
+    if (a.max_det <= 0 || (size_t)a.max_det * 5 * sizeof(float) > 60u * 1024u) {      // k_nms_keep holds the kept boxes in LDS: 20 bytes each
+        y7t_set_error("postprocess: max_det = %d outside (0, %d] (the kept-list NMS keeps max_det boxes in LDS; the reference uses 300, general.py:619)",
+                      a.max_det, (int)(60u * 1024u / (5 * sizeof(float))));
+        return Y7T_E_ARG;
+    }
     const size_t mcap = (size_t)(cap < a.max_nms ? cap : a.max_nms);
     char* base = (char*)a.ws;
     size_t o = 0;

@@ -37,7 +37,7 @@
 
 enum { Y7T_KF_XYAH = 0, Y7T_KF_NAIVE = 1, Y7T_KF_XYWH = 2, Y7T_KF_NSA = 3 };
 enum { Y7T_NEW = 0, Y7T_TRACKED = 1, Y7T_LOST = 2, Y7T_REMOVED = 3 };
-enum { Y7T_SORT = 0, Y7T_BYTETRACK = 1, Y7T_BOTSORT = 2 };
+enum { Y7T_SORT = 0, Y7T_BYTETRACK = 1, Y7T_BOTSORT = 2, Y7T_DEEPSORT = 3 };
 
 // ---------------------------------------------------------------------------------------------
 // execution context: one workgroup; rv/ri are >=32-entry cross-wave scratch arrays (LDS on device)

@@ -14,7 +14,7 @@
 #pragma once
 #include "y7t_track_step.h"
 
-enum { Y7T_DEEPSORT = 3 };
+// (Y7T_DEEPSORT = 3: y7t_track_core.h)
 #define Y7T_PYSET_CAP 8192      // table entries of the emulated CPython set (enough for 1228 unmatched tracks)
 
 // feature state of one DeepSORT tracker: caller-owned device memory next to the track-pool blob

@@ -103,7 +103,7 @@ Y7T_FN Y7TTrk y7t_trk_bind(void* blob, int cap_t, int cap_d) {
     return s;
 }
 
-enum { Y7T_ERR_CAP_T = 1, Y7T_ERR_CAP_D = 2, Y7T_ERR_OUT = 4 };
+enum { Y7T_ERR_CAP_T = 1, Y7T_ERR_CAP_D = 2, Y7T_ERR_OUT = 4, Y7T_ERR_KIND = 8 /* a DeepSORT pool stepped with detections by the plain step */ };
 
 #if !Y7T_DEVICE
 static inline long long clock64() { return 0; }
@@ -648,6 +648,10 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     const Y7TTrkCfg cfg = h->cfg;
     const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
     const int kf = cfg.kf;
+    if (cfg.tracker == Y7T_DEEPSORT && n >= 0) {      // frames with detections of a DeepSORT pool belong to y7t_tracker_step_deepsort (appearance rings); refuse, loudly
+        if (ex.tid == 0) { h->status |= Y7T_ERR_KIND; if (out_count) *out_count = 0; }
+        return;
+    }
     y7t_sync(ex);
     Y7T_PROF(h, 0);
     if (ex.tid == 0) {

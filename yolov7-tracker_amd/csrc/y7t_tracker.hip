@@ -10,6 +10,8 @@
 #include "y7t_track_deepsort.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
 void y7t_set_error(const char* fmt, ...) {
@@ -420,6 +422,8 @@ extern "C" int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double 
     Y7T_ARG_CHECK(cost_host);
     static char* buf = nullptr;            // one staging allocation per process, grown on demand: cost | x | y | opt | solver workspace
     static size_t cap = 0;
+    static std::mutex mu;                  // matching.linear_assignment routes every numpy call through here: one caller at a time owns the buffer
+    std::lock_guard<std::mutex> lock(mu);  // (the call synchronises its stream before returning, so nothing of it is in flight when the lock drops)
     const size_t cb = y7t_al(sizeof(double) * (size_t)n * m), xb = y7t_al(sizeof(int) * (size_t)n), yb = y7t_al(sizeof(int) * (size_t)m), ob = y7t_al(sizeof(double));
     const size_t need = cb + xb + yb + ob + y7t_lapjv_workspace_bytes(n, m);
     if (need > cap) {
@@ -436,6 +440,18 @@ extern "C" int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double 
     if (opt_host) Y7T_HIP_CHECK(hipMemcpyAsync(opt_host, dopt, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
     Y7T_HIP_CHECK(hipStreamSynchronize(S(stream)));
     return 0;
+}
+
+// tracker kind of every initialised state blob (host side; the header itself lives in device memory): the plain frame step refuses a DeepSORT pool
+// with detections -- it would create / update tracks without the appearance-ring bookkeeping, and a reused slot would keep its previous
+// occupant's vectors.  Only the predict-only form (n < 0) is shared between the trackers.
+static std::mutex g_kind_mu;
+static std::unordered_map<const void*, int> g_state_kind;
+static void note_state_kind(const void* state, int kind) { std::lock_guard<std::mutex> l(g_kind_mu); g_state_kind[state] = kind; }
+static int state_kind(const void* state) {
+    std::lock_guard<std::mutex> l(g_kind_mu);
+    auto it = g_state_kind.find(state);
+    return it == g_state_kind.end() ? -1 : it->second;
 }
 
 extern "C" size_t y7t_tracker_state_bytes(int cap_t, int cap_d) {
@@ -463,6 +479,7 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
     c.iou_thresh = iou_thresh;
     hipLaunchKernelGGL(k_tracker_init, dim3(1), dim3(256), 0, S(stream), state, c, (unsigned long long)(uintptr_t)id_counter);
     Y7T_LAUNCH_CHECK();
+    note_state_kind(state, tracker_kind);
     return 0;
 }
 
@@ -507,6 +524,11 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
     Y7T_ARG_CHECK(n <= 0 || dets);
     const int nt = step_threads(threads, n);
     Y7T_ARG_CHECK(nt > 0);
+    if (n >= 0 && state_kind(state) == Y7T_DEEPSORT) {
+        y7t_set_error("y7t_tracker_step: this pool was initialised as DeepSORT -- frames with detections go through y7t_tracker_step_deepsort "
+                      "(appearance rings); only the predict-only step (n < 0) is shared");
+        return Y7T_E_STATE;
+    }
     static bool attr_done = false;
     if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
     const unsigned fb = step_fast_bytes(n);

@@ -41,6 +41,7 @@ class DeepSORT(BaseTracker):
         self.filter_small_area = False
         self._feat = None           # feature state, allocated when the feature dimension is known
         self._feat_dim = 0
+        self._feat_used = False     # a frame with appearance vectors has been stepped (from then on the width is fixed)
 
     def get_feature(self, tlbrs, ori_img):
         """deepsort.py:19-41: crops of the boxes -> self.reid_model(crops) -> (N, D) features"""
@@ -58,7 +59,10 @@ class DeepSORT(BaseTracker):
         return self.reid_model(crops) if crops else np.zeros((0, max(self._feat_dim, 1)), np.float32)
 
     def _ensure_feature_state(self, dim):
-        if self._feat is None:
+        """the per-slot appearance rings + per-frame scratch, sized for `dim`-wide embeddings.  Until a frame has carried a detection above det_thresh
+        no track exists (a new track needs score > det_thresh + 0.1, deepsort.py:207) and no slot holds a vector, so a state that was sized on a
+        guess for such frames (empty / low-confidence first frames are common in real footage) is simply re-made when the real width shows up."""
+        if self._feat is None or (int(dim) != self._feat_dim and not self._feat_used):
             self._feat_dim = int(dim)
             nb = int(self._L.y7t_deepsort_feature_bytes(self.cap_t, self.cap_d, self._feat_dim, STORE_FEATURES_BUDGET))
             self._feat = torch.zeros(nb, dtype=torch.uint8, device="cuda")
@@ -66,6 +70,15 @@ class DeepSORT(BaseTracker):
                                                  _lib.stream_ptr()))
         elif int(dim) != self._feat_dim:
             raise ValueError("feature dimension changed from %d to %d" % (self._feat_dim, int(dim)))
+
+    def _check_feats(self, feats_dev, n):
+        """what the device step dereferences: n rows of `_feat_dim` contiguous float32 on the GPU (a short, fp16 or strided tensor would be read out
+        of bounds / misinterpreted by k_ds_normalize, k_embed_dist and k_ds_store)"""
+        if not isinstance(feats_dev, torch.Tensor) or feats_dev.dim() != 2:
+            raise _lib.Y7TError("DeepSORT: features must be an (n, D) tensor")
+        if feats_dev.shape[0] < n:
+            raise _lib.Y7TError("DeepSORT: %d feature rows for %d detections" % (feats_dev.shape[0], n))
+        return feats_dev.to(device="cuda", dtype=torch.float32).contiguous()
 
     def _launch(self, det_dev, feats_dev=None, out=None, **kw):
         """enqueue one frame step without a host round trip (pipelines / bench.py): det_dev (n, 6) float32 and feats_dev (n, D) float32
@@ -79,7 +92,10 @@ class DeepSORT(BaseTracker):
         n = d.shape[0]
         if n > self.cap_d:
             raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (n, self.cap_d))
+        d = d.to(device="cuda", dtype=torch.float32).contiguous()
+        feats_dev = self._check_feats(feats_dev, n)
         self._ensure_feature_state(feats_dev.shape[1])
+        self._feat_used = self._feat_used or n > 0
         self._det_keep = (d, feats_dev)
         if out is None:
             optr, cptr = _lib.ptr(self._out), self._count_ptr
@@ -107,10 +123,11 @@ class DeepSORT(BaseTracker):
             feats = self.get_feature(det_host[keep, :4], ori_img)
             if not isinstance(feats, torch.Tensor):
                 feats = torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
-            feats = feats.to(device="cuda", dtype=torch.float32)
+            feats = self._check_feats(feats, int(keep.sum()))
             self._ensure_feature_state(feats.shape[1])
-        elif self._feat is None:
-            self._ensure_feature_state(self._feat_dim or 128)
+            self._feat_used = True
+        elif self._feat is None:        # nothing above det_thresh yet: the extractor's width if it states one, else a placeholder that the first real frame replaces
+            self._ensure_feature_state(getattr(self.reid_model, "feat_dim", None) or self._feat_dim or 128)
         d = torch.from_numpy(det_host).cuda()
         allf = torch.zeros((max(n, 1), self._feat_dim), dtype=torch.float32, device="cuda")
         if feats is not None:

@@ -67,12 +67,14 @@ def lapjv_host(cost, cost_limit):
 
 def linear_assignment(cost_matrix, thresh):
     """matching.py:30-41 -> (matches (K,2) int, unmatched_a, unmatched_b)."""
-    cost_matrix = np.asarray(cost_matrix)
-    if cost_matrix.size == 0:
+    on_device = torch.is_tensor(cost_matrix) and cost_matrix.device.type == "cuda"      # (the reference only ever passes numpy; a device cost stays there)
+    if not on_device:
+        cost_matrix = np.asarray(cost_matrix.cpu() if torch.is_tensor(cost_matrix) else cost_matrix)
+    if (cost_matrix.numel() if on_device else cost_matrix.size) == 0:
         return np.empty((0, 2), dtype=int), tuple(range(cost_matrix.shape[0])), tuple(range(cost_matrix.shape[1]))
-    if isinstance(cost_matrix, np.ndarray):
-        _, x, y = lapjv_host(cost_matrix, thresh)
-    else:
+    if on_device:
         _, x, y = lapjv_device(cost_matrix, thresh)
+    else:
+        _, x, y = lapjv_host(cost_matrix, thresh)
     matches = np.asarray([[ix, mx] for ix, mx in enumerate(x) if mx >= 0])
     return matches, np.where(x < 0)[0], np.where(y < 0)[0]
