@@ -40,6 +40,12 @@ int y7t_version(void);
 const char* y7t_last_kernel(void);
 /* number of HIP devices visible (0 when there is none); host-synchronous */
 int y7t_device_count(void);
+/* A HIP stream restricted to a set of compute units (bit i of mask_words_host = CU i; hipExtStreamCreateWithCUMask).  The reference runs the detector
+ * and `tracker.update` one after the other on one stream (tracker/track.py:144-151); the pipelined form of that loop (bench.py, track.py --batch)
+ * runs the tracker's single-workgroup frame steps beside the next batch's convolutions, and gives them compute units of their own so that they do
+ * not queue behind / share issue slots with 256-thread convolution workgroups.  The stream is an ordinary hipStream_t for every other call here. */
+int y7t_stream_create_cu_mask(const uint32_t* mask_words_host, int n_words, y7t_stream* out_stream_host);
+int y7t_stream_destroy(y7t_stream stream);
 
 /* ---------------------------------------------------------------- tracker math (float64) ---- */
 

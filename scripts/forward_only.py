@@ -9,11 +9,17 @@ from yolov7_tracker_amd.detector import arch, model
 
 B = int(os.environ.get("B", "32"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-det = model.Detector(arch.yolov7_w6(10), None, img_size=(1280, 1280), max_batch=B, seed=0)
-frames = torch.from_numpy(synth.make_frames(B, 80, 1280, seq_idx=0)).cuda()
-det.plant_objectness_bias(frames)
+import hashlib, types
+import bench       # the timed run's weights (bench.py --weights conditioned, its default)
+WEIGHTS = os.environ.get("WEIGHTS", "conditioned")
+frames_host = synth.make_frames(B, 80, 1280, seq_idx=0)
+sd = bench.conditioned_state_dict(types.SimpleNamespace(arch="yolov7-w6", img=1280), 10, frames_host) if WEIGHTS == "conditioned" else None
+det = model.Detector(arch.yolov7_w6(10), sd, img_size=(1280, 1280), max_batch=B, seed=0)
+frames = torch.from_numpy(frames_host).cuda()
+det.plant_objectness_bias(frames, level_offsets=(0, 0, -3, -6) if sd is not None else None)
 det.forward(frames)
 names = det.launch_list(B)
+LL_SHA = hashlib.sha1(json.dumps(names).encode()).hexdigest()[:16]      # == bench.py's config.launch_list_sha for the same list
 torch.cuda.synchronize()
 print("MARK forwards begin")
 for i in range(N):
@@ -34,4 +40,4 @@ for oi, op in enumerate(p.ops):
         out_elems = int(op["Ho"]) * int(op["Wo"]) * int(op["Cout"]) if int(op["detect_level"]) < 0 else 0
         d["bytes"] = (cin_bytes + out_elems) * 2 * B + int(op["Cout_pad"]) * int(op["K_pad"]) * 2
     ops.append(d)
-print(json.dumps({"B": B, "forwards": N, "ops": ops}))
+print(json.dumps({"B": B, "forwards": N, "weights": WEIGHTS, "launch_list_sha": LL_SHA, "ops": ops}))

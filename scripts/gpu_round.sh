@@ -1,0 +1,160 @@
+#!/bin/bash
+# ONE parametrised GPU script (replaces the per-call scripts of rounds 1-2).  Run on the GPU box from the repo root:
+#
+#   gpurun --timeout 2400 -- 'TAG=r3a bash scripts/gpu_round.sh tests exp_s2 exp_nw8 exp_late exp_fixup exp_next bench_variants pmc_queues'
+#   gpurun --timeout 1500 -- 'TAG=r03 bash scripts/gpu_round.sh suite bench profile'
+#
+# Every step runs under its own `timeout`, writes to gpurun_out/$TAG/ and appends its verdict to gpurun_out/$TAG/summary.txt; a failing step does not
+# stop the others.  BEFORE calling (CPU): python -m yolov7_tracker_amd.build  (+ python scripts/ablate/build_experiments.py fixup next  for exp_fixup / exp_next).
+# Steps:
+#   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
+#   suite           the whole `-m gpu` suite, as the driver runs it
+#   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
+#   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
+#   profile         rocprofv3 kernel stats of the bench command, per-op table of the launch list, HBM traffic (2 PMC passes), MFMA busy -> stamped JSONs
+#   exp_s2          stride-2 LDS-patch kernel (opt-in Y7T_CONV_PATCH_S2): layer parity, per-layer timing of its forms against the generic kernel
+#   exp_nw8         8-wave instances of the generic kernel (opt-in Y7T_CONV_NW8): parity in the pinned list, per-layer timing
+#   exp_late        stride-1 patch kernel with the step's DMAs behind its MFMAs (Y7T_CONV_ABLATE=512)
+#   exp_fixup       split-K reduced by the last arriver (lib/exp_fixup.so): parity, batch-1 latency
+#   exp_next        tracker candidate lists on a run-time row stride (lib/exp_next.so): parity, 500-object step time
+#   pmc_queues      which queue of the buffer->LDS path the generic kernel waits in (TA / TCP / TCC / SQ counters on three layers)
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${TAG:-r03}
+O=$ROOT/gpurun_out/$TAG; mkdir -p $O
+LIBD=$ROOT/yolov7-tracker_amd/lib
+cd $ROOT
+say() { echo "=== $*" | tee -a $O/summary.txt; }
+tailsum() { tail -${2:-2} $1 | tee -a $O/summary.txt; }
+benchsum() {   # name ...: one line per bench JSON
+python3 - "$O" "$@" <<'PY' | tee -a $O/summary.txt
+import json, sys
+o = sys.argv[1]
+for n in sys.argv[2:]:
+    try:
+        l = json.loads([x for x in open("%s/bench_%s.json" % (o, n)).read().splitlines() if x.startswith("{")][-1])
+        p, ph = l.get("parity") or {}, l.get("phases_ms_per_step", {})
+        c = p.get("candidates_before_nms", {})
+        print("%-14s %7.0f fps  step %.2f ms  list %.2f ms  frac %.4f  tracker chain %.2f ms  nms %.2f ms | latency %s | cands within bar %s of %s, boxes %s/%s"
+              % (n, l["value"], l["ms_per_step"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"], ph.get("tracker_chain", float("nan")),
+                 ph.get("decode_nms", float("nan")), (l.get("latency_mode") or {}).get("u8_hwc_host", {}).get("fps"), c.get("frac_within_bar"), c.get("n_both"),
+                 p.get("boxes_matched_same_class_1px_conf5e-3"), p.get("boxes_oracle")))
+    except Exception as e:
+        print("%-14s no bench line: %r" % (n, e))
+PY
+}
+
+for step in "$@"; do case $step in
+
+tests)
+  say "tests: new GPU tests of the round"
+  timeout 900 python -m pytest -x -q -m gpu -s tests/test_detector_pinned_gpu.py -k "candidates or training" > $O/t_new_detector.log 2>&1; echo "rc=$?" >> $O/t_new_detector.log
+  grep -h "candidates:\|training graph, level" $O/t_new_detector.log | cut -c1-400 | tee -a $O/summary.txt; tailsum $O/t_new_detector.log
+  timeout 600 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py -k cfg3 > $O/t_new_cfg3.log 2>&1; echo "rc=$?" >> $O/t_new_cfg3.log; tailsum $O/t_new_cfg3.log
+  timeout 600 python -m pytest -q -m gpu tests/test_tracker_gpu.py -k "deepsort_empty or refuses or max_det" > $O/t_new_advice.log 2>&1; echo "rc=$?" >> $O/t_new_advice.log; tailsum $O/t_new_advice.log
+  timeout 900 python -m pytest -q -m gpu tests/test_multirank_gpu.py > $O/t_new_multirank.log 2>&1; echo "rc=$?" >> $O/t_new_multirank.log; tailsum $O/t_new_multirank.log
+  ;;
+
+suite)
+  say "suite: python -m pytest tests/ -x -q -m gpu"
+  timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3
+  ;;
+
+bench)
+  say "bench: the driver's line"
+  timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err; echo "rc=$?" | tee -a $O/summary.txt
+  cp $O/bench_line.json $O/bench_default.json; benchsum default
+  ;;
+
+bench_variants)
+  say "bench_variants (one session): default, chaotic weights, tracker chain on reserved CUs"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+  timeout 300 python bench.py $X --weights chaotic > $O/bench_chaotic.json 2> $O/bench_chaotic.err
+  timeout 300 python bench.py $X --cu_reserve 8 > $O/bench_cu8.json 2> $O/bench_cu8.err
+  timeout 300 python bench.py $X --cu_reserve 16 > $O/bench_cu16.json 2> $O/bench_cu16.err
+  timeout 300 python bench.py $X --cu_reserve 8 --cu_reserve_nms 1 > $O/bench_cu8nms.json 2> $O/bench_cu8nms.err
+  timeout 300 python bench.py $X > $O/bench_default2.json 2> $O/bench_default2.err
+  benchsum default chaotic cu8 cu16 cu8nms default2
+  for n in default chaotic cu8 cu16 cu8nms default2; do [ -s $O/bench_$n.err ] && { echo "-- stderr of $n"; grep -v amdgpu.ids $O/bench_$n.err | tail -4; }; done | tee -a $O/summary.txt
+  ;;
+
+profile)
+  say "profile: rocprofv3 of the bench command + the launch list alone (kernel stats, per-op table, HBM traffic, MFMA busy)"
+  P=$O/prof; mkdir -p $P
+  COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown)
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ks /tmp/kt /tmp/pf /tmp/pw /tmp/mb
+    timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $P/bench_under_rocprof.log 2>&1
+    f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/bench_kernel_stats.csv
+    timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $ROOT/scripts/forward_only.py 4 > $P/forward_only.log 2>&1
+    f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $P/forward_kernel_trace.csv
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python $ROOT/scripts/forward_only.py 3 > /tmp/pf.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python $ROOT/scripts/forward_only.py 3 > /tmp/pw.log 2>&1
+    CTRS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+    timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/mb -- python $ROOT/scripts/forward_only.py 3 > /tmp/mb.log 2>&1
+    python3 $ROOT/scripts/profile_reduce.py $P "$CTRS" "$COMMIT" 2>&1 | tee -a $O/summary.txt )
+  head -14 $P/bench_kernel_stats.csv 2>/dev/null | cut -c1-160 | tee -a $O/summary.txt
+  grep -o '"value": [0-9.]*, "unit": "frames/s"\|"launch_list_ms": [0-9.]*' $P/bench_under_rocprof.log | head -2 | tee -a $O/summary.txt
+  ;;
+
+exp_s2)
+  say "exp_s2 a: stride-2 patch kernel, layer parity vs torch fp32 (4-wave, 8-wave, DMA-late order)"
+  Y7T_TEST_EXPERIMENTS=1 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2.log 2>&1; echo "rc=$?" >> $O/t_s2.log; tailsum $O/t_s2.log
+  Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2_nw8.log 2>&1; echo "rc=$?" >> $O/t_s2_nw8.log; tailsum $O/t_s2_nw8.log
+  Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2_late.log 2>&1; echo "rc=$?" >> $O/t_s2_late.log; tailsum $O/t_s2_late.log
+  say "exp_s2 b: per-layer timing at 32 frames (3/2 rows): generic | patch_s2 (256-ch panels where Cout allows) | 128-ch panels | 512 threads | DMA-late | 512 threads + DMA-late"
+  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
+  Y7T_CONV_PATCH_S2=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2.txt 2>&1
+  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_BN=128 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_bn128.txt 2>&1
+  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_nw8.txt 2>&1
+  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_late.txt 2>&1
+  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_nw8_late.txt 2>&1
+  for f in default s2 s2_bn128 s2_nw8 s2_late s2_nw8_late; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
+  ;;
+
+exp_nw8)
+  say "exp_nw8 a: 8-wave instances inside the benchmarked list, teacher-forced against the oracle"
+  Y7T_CONV_NW8=1 timeout 300 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_nw8.log 2>&1; echo "rc=$?" >> $O/t_nw8.log; tailsum $O/t_nw8.log
+  say "exp_nw8 b: per-layer timing: 256x256x64 (1), 256x256x32 four-stage ring (2), 256x128 (6), 128x128 (7), all at two waves per SIMD"
+  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
+  for v in 1 2 6 7; do Y7T_CONV_NW8=$v timeout 200 python scripts/bench_conv.py 32 > $O/b_nw8_$v.txt 2>&1; done
+  for f in default nw8_1 nw8_2 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \|  20x20 " $O/b_$f.txt | head -70; done | tee -a $O/summary.txt
+  ;;
+
+exp_late)
+  say "exp_late: stride-1 patch kernel, DMA-late order (Y7T_CONV_ABLATE=512): parity in the pinned list, 3/1 rows"
+  Y7T_CONV_ABLATE=512 timeout 300 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_late.log 2>&1; echo "rc=$?" >> $O/t_late.log; tailsum $O/t_late.log
+  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
+  Y7T_CONV_ABLATE=512 timeout 200 python scripts/bench_conv.py 32 > $O/b_late.txt 2>&1
+  for f in default late; do echo "-- $f"; grep " 3/1 \|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
+  ;;
+
+exp_fixup)
+  say "exp_fixup: split-K reduced by the last arriver: parity incl. repeated launches, then batch-1 latency against the default library"
+  if [ -f $LIBD/exp_fixup.so ]; then
+    Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer or whole_network or batch" > $O/t_fixup.log 2>&1; echo "rc=$?" >> $O/t_fixup.log; tailsum $O/t_fixup.log
+    timeout 200 python scripts/latency_mode.py 120 > $O/lat_default.txt 2>&1
+    Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python scripts/latency_mode.py 120 > $O/lat_fixup.txt 2>&1
+    for f in default fixup; do echo "-- $f"; grep -i "fps" $O/lat_$f.txt | tail -8; done | tee -a $O/summary.txt
+  else say "exp_fixup.so missing"; fi
+  ;;
+
+exp_next)
+  say "exp_next: tracker candidate lists on a run-time row stride: parity on the device, then the frame step against the default library"
+  if [ -f $LIBD/exp_next.so ]; then
+    Y7T_LIB=$LIBD/exp_next.so timeout 400 python -m pytest tests/test_tracker_gpu.py -q -m gpu > $O/t_next.log 2>&1; echo "rc=$?" >> $O/t_next.log; tailsum $O/t_next.log
+    timeout 200 python scripts/time_tracker.py > $O/trk_default.txt 2>&1
+    Y7T_LIB=$LIBD/exp_next.so timeout 200 python scripts/time_tracker.py > $O/trk_next.txt 2>&1
+    for f in default next; do echo "-- $f"; grep -v amdgpu.ids $O/trk_$f.txt | tail -12; done | tee -a $O/summary.txt
+  else say "exp_next.so missing"; fi
+  ;;
+
+pmc_queues)
+  say "pmc_queues: TA / TCP / TCC / SQ counters of the 1x1 (80x80 1024->512), stride-2 (160x160 256->512) generic layers and the patch kernel (80x80 256->256)"
+  OUT=$O/pmc_raw SHAPES="${SHAPES:-1x1 s2 patch}" bash scripts/pmc_queues.sh > $O/pmc_queues.txt 2>&1
+  grep -v "^  TCP_\|^  TA_\|^  TCC_\|^  SQ_\|^  GRBM" $O/pmc_queues.txt | tail -60 | tee -a $O/summary.txt
+  ;;
+
+*) say "unknown step $step";;
+esac; done
+say "done: $*"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, diagnosis call: WHAT bounds the buffer->LDS path of the generic implicit-GEMM kernel?  Round 2 established that its 1x1 and stride-2 layers take
+# Diagnosis (step `pmc_queues` of scripts/gpu_round.sh): WHAT bounds the buffer->LDS path of the generic implicit-GEMM kernel?  Round 2 established that its 1x1 and stride-2 layers take
 # ~1 us per K-step and workgroup whatever the K-step carries (ring depth, BK, tile and weight layout do not move it) but not which queue that
 # microsecond is spent in.  The counters below separate the candidates:
 #   issue side      SQ_INST_CYCLES_VMEM_RD / SQ_INSTS_VMEM_RD (cycles to send one wave's addresses), SQ_VMEM_TA_{ADDR,CMD}_FIFO_FULL, SQ_ACTIVE_INST_VMEM
@@ -9,8 +9,8 @@
 #   LDS side        SQ_LDS_{DATA,CMD}_FIFO_FULL, SQ_LDS_BANK_CONFLICT
 # on three layers at 32 frames: the 1x1 80x80 1024->512 (generic, 1x1 weight panels), the stride-2 3x3 160x160 256->512 (generic), and for contrast the
 # stride-1 3x3 80x80 256->256 on the LDS-patch kernel (1000+ TFLOP/s).  Each counter group is its own rocprofv3 run (--pmc with --kernel-trace only).
-#   gpurun --timeout 1500 -- 'bash scripts/gpu_r3b.sh'                      (about 36 short runs; SHAPES="1x1" or "s2" or "patch" restricts)
-O=$GRAFT_REPO_ROOT/gpurun_out/r3b
+#   OUT=<dir> bash scripts/pmc_queues.sh                      (about 36 short runs; SHAPES="1x1" or "s2" or "patch" restricts)
+O=${OUT:-$GRAFT_REPO_ROOT/gpurun_out/pmc_queues}
 GROUPS_=(
  "TA_BUSY_avr TA_BUFFER_TOTAL_CYCLES_sum GRBM_GUI_ACTIVE"
  "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
@@ -41,7 +41,7 @@ done
 # one table: counter -> value per kernel, normalised per wave-DMA where that makes sense
 python3 - <<'PY'
 import collections, os, re
-root = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r3b")
+root = os.environ.get("OUT") or os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "pmc_queues")
 for d in sorted(os.listdir(root)):
     f = os.path.join(root, d, "summary.txt")
     if not os.path.isfile(f):

@@ -1,26 +1,13 @@
-#!/bin/bash
-# Round-2 profile of the default bench workload (run on the GPU box from the repo root).  Every rocprofv3 run is wrapped in `timeout`; PMC passes
-# carry --kernel-trace only.  Outputs under gpurun_out/prof2/ (copied into profiles/r02_* by hand).
-set -u
-root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/prof2; mkdir -p $out
-cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/ks /tmp/kt /tmp/pf /tmp/pw /tmp/mb
-# 1. kernel stats of the bench command itself
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no_cpu_baseline --no_latency_mode > $out/bench_under_rocprof.log 2>&1
-f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/bench_kernel_stats.csv
-# 2. per-op kernel trace of the launch list alone
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $root/scripts/forward_only.py 4 > $out/forward_only.log 2>&1
-f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $out/forward_kernel_trace.csv
-# 3. HBM traffic: two separate PMC passes
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python $root/scripts/forward_only.py 3 > /tmp/pf.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python $root/scripts/forward_only.py 3 > /tmp/pw.log 2>&1
-# 4. MFMA busy
-CTRS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d /tmp/mb -- python $root/scripts/forward_only.py 3 > /tmp/mb.log 2>&1
-python3 - $out "$CTRS" <<'PY'
+
+"""reduce the rocprofv3 passes of `scripts/gpu_round.sh profile` (kernel trace of the launch list, FETCH_SIZE / WRITE_SIZE passes, MFMA-busy pass) into the
+files the documents cite: conv_hbm_traffic.json (stamped with the commit and the launch list it was measured on -- bench.py prints roofline.traffic only
+for that list), conv_mfma_busy.json, conv_per_layer_b32.txt.   python scripts/profile_reduce.py OUTDIR "CTR1 CTR2 ..." COMMIT"""
 import csv, glob, json, sys, collections, re
-out, ctrs = sys.argv[1], sys.argv[2].split()
+out, ctrs, commit = sys.argv[1], sys.argv[2].split(), (sys.argv[3] if len(sys.argv) > 3 else "unknown")
+try:
+    META = json.loads([l for l in open(out + "/forward_only.log") if l.startswith("{")][-1])
+except Exception:
+    META = {}
 FWD = ("k_conv", "k_stem", "k_splitk", "k_maxpool", "k_upsample")
 def last_forward(d, n_fwd):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -44,7 +31,8 @@ if pf and pw:
     fetch_kb, write_kb = sum(d.get("FETCH_SIZE", 0) for d in pf), sum(d.get("WRITE_SIZE", 0) for d in pw)
     frames = 32
     hbm = (2 * fetch_kb + write_kb) * 1024 / frames
-    json.dump({"source": "scripts/profile_r02.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python scripts/forward_only.py 3",
+    json.dump({"commit": commit, "launch_list_sha": META.get("launch_list_sha"), "weights": META.get("weights"),
+               "source": "scripts/gpu_round.sh profile: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python scripts/forward_only.py 3",
                "kernels": "every launch of one forward of the benchmarked launch list (fused stem, convs, split-K reduces, pools; %d launches), 32 frames" % len(pf),
                "frames_per_launch_list": frames, "FETCH_SIZE_KB_per_launch_list": fetch_kb, "WRITE_SIZE_KB_per_launch_list": write_kb,
                "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as reported (uncalibrated)",
@@ -57,7 +45,7 @@ if mb:
     frames, gflop = 32, 354.9
     exp = frames * gflop * 1e9 / (2.0 * 32 * 32 * 16)
     cyc = s["GRBM_GUI_ACTIVE"] / 8.0
-    r = {"source": "scripts/profile_r02.sh: rocprofv3 --kernel-trace --pmc " + " ".join(ctrs) + " -- python scripts/forward_only.py 3",
+    r = {"commit": commit, "launch_list_sha": META.get("launch_list_sha"), "source": "scripts/gpu_round.sh profile: rocprofv3 --kernel-trace --pmc " + " ".join(ctrs) + " -- python scripts/forward_only.py 3",
          "scope": "the %d launches of the last forward (32 frames)" % len(mb), "sum": s, "gpu_cycles_per_xcd": cyc,
          "mfma_busy_fraction": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), "mfma_insts": s["SQ_INSTS_MFMA"], "expected_mfma_insts": exp,
          "valu_per_mfma": s["SQ_INSTS_VALU"] / max(1.0, s["SQ_INSTS_MFMA"]),
@@ -88,6 +76,3 @@ try:
     print("per-layer table: TOTAL %.3f ms -> %.1f TFLOP/s" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
 except Exception as e:
     print("per-layer table failed:", repr(e))
-PY
-head -14 $out/bench_kernel_stats.csv 2>/dev/null | cut -c1-160
-grep -o '"value": [0-9.]*, "unit": "frames/s"\|"launch_list_ms": [0-9.]*' $out/bench_under_rocprof.log | head -2

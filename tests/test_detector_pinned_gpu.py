@@ -232,19 +232,13 @@ def test_boxes_end_to_end_against_fp32_oracle(smooth_det):
         assert matched >= 0.97 * len(r)
 
 
-def _device_candidates(det, ps, b):
-    """candidate arrays of image b in post-processing set `ps` (layout of y7t_det_postprocess' workspace: cbox, cscore, ccls, cidx, each 256-byte
-    aligned) -> dict anchor row -> (xyxy, conf, cls)"""
-    B, cap, ws = det.max_batch, det.max_cand, ps.ws
-    rup = lambda n: (n + 255) // 256 * 256
-    o1 = rup(B * cap * 16); o2 = o1 + rup(B * cap * 4); o3 = o2 + rup(B * cap * 4)
-    n = int(ps.cand[b])
-    cbox = ws[:B * cap * 16].view(torch.float32).view(B, cap, 4)[b, :n].cpu().numpy()
-    cscore = ws[o1:o1 + B * cap * 4].view(torch.float32).view(B, cap)[b, :n].cpu().numpy()
-    ccls = ws[o2:o2 + B * cap * 4].view(torch.float32).view(B, cap)[b, :n].cpu().numpy()
-    cidx = ws[o3:o3 + B * cap * 4].view(torch.int32).view(B, cap)[b, :n].cpu().numpy()
-    assert len(set(cidx.tolist())) == n                    # an anchor row is a candidate at most once
-    return {int(r): (bx, float(s), int(c)) for r, bx, s, c in zip(cidx, cbox, cscore, ccls)}
+def _device_candidates(det, pset, b):
+    """candidates of image b in post-processing set `pset` -> dict anchor row -> (xyxy, conf, cls)"""
+    cbox, cscore, ccls, cidx, count = det.candidate_arrays(pset)
+    n = int(count[b])
+    rows = cidx[b, :n].cpu().numpy()
+    assert len(set(rows.tolist())) == n                    # an anchor row is a candidate at most once
+    return {int(r): (bx, float(s), int(c)) for r, bx, s, c in zip(rows, cbox[b, :n].cpu().numpy(), cscore[b, :n].cpu().numpy(), ccls[b, :n].cpu().numpy())}
 
 
 def test_candidates_before_nms_against_fp32_oracle(smooth_det):
@@ -268,7 +262,7 @@ def test_candidates_before_nms_against_fp32_oracle(smooth_det):
     dec, _ = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
     keep = ps.keep.cpu().numpy()
     for i, b in enumerate(fr):
-        got = _device_candidates(det, ps, b)
+        got = _device_candidates(det, out.pset, b)
         want = util.oracle_candidates(dec[i], 0.01)
         st = util.compare_candidate_sets(got, want, 0.01, px=1.0, dconf=5e-3)
         print("frame %d candidates:" % b, st)
@@ -280,11 +274,7 @@ def test_candidates_before_nms_against_fp32_oracle(smooth_det):
         cbox = np.stack([got[r][0] for r in rows]); cs = np.array([got[r][1] for r in rows], np.float32); cc = np.array([got[r][2] for r in rows], np.float32)
         order = np.lexsort((rows, -cs.astype(np.float64)))[:30000]
         k = cnative.nms((cbox + cc[:, None] * np.float32(4096)).astype(np.float32)[order], cs[order], 0.45)[:300]
-        B, cap = det.max_batch, det.max_cand
-        o3 = 0
-        for bytes_ in (B * cap * 16, B * cap * 4, B * cap * 4):
-            o3 += (bytes_ + 255) // 256 * 256
-        cidx = ps.ws[o3:o3 + B * cap * 4].view(torch.int32).view(B, cap)[b].cpu().numpy()
+        cidx = det.candidate_arrays(out.pset)[3][b].cpu().numpy()
         assert int(nd[b]) == len(k)
         np.testing.assert_array_equal(rows[order[k]], cidx[keep[b, :int(nd[b])]])
 

@@ -170,39 +170,4 @@ def training_checkpoint_state_dict(spec, plan, seed=0, bn_bias_mean=0.0, calib_i
     return sd
 
 
-def oracle_candidates(dec, conf_thres=0.01):
-    """the candidate filter of non_max_suppression (utils/general.py:629-662) on ONE image's decoded tensor (A, 5+nc), without the NMS:
-    -> dict anchor row -> (xyxy float32[4], conf, cls, per-class conf vector) for rows with obj > conf_thres and best-class conf > conf_thres"""
-    import torch
-    x = dec.clone()
-    rows = torch.nonzero(x[:, 4] > conf_thres).flatten()
-    x = x[rows]
-    x[:, 5:] *= x[:, 4:5]
-    box = x[:, :4].clone()
-    box[:, 0], box[:, 1] = x[:, 0] - x[:, 2] / 2, x[:, 1] - x[:, 3] / 2
-    box[:, 2], box[:, 3] = x[:, 0] + x[:, 2] / 2, x[:, 1] + x[:, 3] / 2
-    conf, j = x[:, 5:].max(1)
-    ok = conf > conf_thres
-    return {int(r): (b.numpy(), float(c), int(k), sc.numpy()) for r, b, c, k, sc in zip(rows[ok], box[ok], conf[ok], j[ok], x[:, 5:][ok])}
-
-
-def compare_candidate_sets(got, want, conf_thres=0.01, px=1.0, dconf=5e-3):
-    """got / want: dicts anchor row -> (xyxy, conf, cls) of ONE image (device / oracle).  SURVEY 8a's bar applied BEFORE the NMS, where no greedy
-    order can amplify a rounding difference: every candidate both sides have must agree in class (or pick a class the oracle scores within dconf of its best), |dcoord| <= px, |dconf| <= dconf; a candidate
-    only one side has must sit within dconf of the threshold (it crossed conf_thres by rounding noise).  -> statistics dict"""
-    import numpy as np
-    both = sorted(set(got) & set(want))
-    only = sorted(set(got) ^ set(want))
-    dc = np.array([np.abs(got[r][0] - want[r][0]).max() for r in both]) if both else np.zeros(0)
-    ds = np.array([abs(got[r][1] - want[r][1]) for r in both]) if both else np.zeros(0)
-    side = np.array([max(want[r][0][2] - want[r][0][0], want[r][0][3] - want[r][0][1]) for r in both]) if both else np.zeros(0)
-    # a different class is a difference only if the oracle does not score the device's class within dconf of its own best (two classes tied within the
-    # conf tolerance: `conf, j = x[:, 5:].max(1)` picks by rounding noise)
-    cls_diff = [r for r in both if got[r][2] != want[r][2] and (len(want[r]) < 4 or want[r][3][got[r][2]] < want[r][1] - dconf)]
-    only_margin = np.array([abs((got.get(r) or want.get(r))[1] - conf_thres) for r in only]) if only else np.zeros(0)
-    return {"n_got": len(got), "n_want": len(want), "n_both": len(both), "n_only_one_side": len(only),
-            "max_dcoord": float(dc.max()) if len(dc) else 0.0, "max_dconf": float(ds.max()) if len(ds) else 0.0,
-            "max_dcoord_rel_side": float((dc / np.maximum(side, 1.0)).max()) if len(dc) else 0.0,
-            "frac_within_bar": float(((dc <= px) & (ds <= dconf)).mean()) if len(dc) else 1.0,
-            "n_class_differs": len(cls_diff), "max_margin_only_one_side": float(only_margin.max()) if len(only) else 0.0,
-            "worst_rows": [both[i] for i in np.argsort(-dc)[:3]] if len(dc) else []}
+from oracle.detector_torch import candidates as oracle_candidates, compare_candidate_sets  # noqa: E402,F401  (test-side names)

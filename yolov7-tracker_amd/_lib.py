@@ -58,6 +58,8 @@ SIGNATURES = {
     "y7t_reid_forward_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "y7t_reid_fused_blob_size": (ctypes.c_size_t, []),
     "y7t_reid_set_fused": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "y7t_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
+    "y7t_stream_destroy": (c_int, [c_void_p]),
     "y7t_conv2d_nhwc_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
@@ -115,3 +117,26 @@ def stream_ptr():
 def ptr(t):
     """device/host pointer of a torch tensor (or None)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def cu_masked_streams(reserved, total=None):
+    """-> (stream_rest, stream_reserved): two torch streams (torch.cuda.ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run on
+    disjoint sets of compute units: `reserved` CUs (mask bits 0 .. reserved-1; consecutive bits land on different XCDs) for the second, all others
+    for the first.  For pipelines that keep single-workgroup latency-bound kernels (the tracker frame steps) off the CUs the convolutions fill."""
+    import torch
+    require_gpu()
+    L = load()
+    total = int(total or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    reserved = int(reserved)
+    if not 0 < reserved < total:
+        raise Y7TError("cu_masked_streams: reserved=%d of %d compute units" % (reserved, total))
+    words = (total + 31) // 32
+    out = []
+    for bits in (range(reserved, total), range(0, reserved)):
+        m = (ctypes.c_uint32 * words)()
+        for b in bits:
+            m[b // 32] |= 1 << (b % 32)
+        h = ctypes.c_void_p()
+        check(L.y7t_stream_create_cu_mask(m, words, ctypes.byref(h)))
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out[0], out[1]

@@ -195,3 +195,21 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
     a.force_patch = (act >> 9) & 1;   // bit 9: force the LDS-patch kernel for an eligible 3x3/s1 layer (tests)
     return y7t_conv_launch(a, (hipStream_t)stream);
 }
+
+// ---- streams with a compute-unit mask (include/y7t.h) ----
+extern "C" int y7t_stream_create_cu_mask(const uint32_t* mask_words_host, int n_words, y7t_stream* out_stream_host) {
+    Y7T_ARG_CHECK(mask_words_host && n_words > 0 && n_words <= 64 && out_stream_host);
+    bool any = false;
+    for (int i = 0; i < n_words; ++i) any = any || mask_words_host[i] != 0;
+    if (!any) { y7t_set_error("y7t_stream_create_cu_mask: empty mask"); return Y7T_E_ARG; }
+    hipStream_t s = nullptr;
+    Y7T_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words_host));
+    *out_stream_host = (y7t_stream)s;
+    return 0;
+}
+
+extern "C" int y7t_stream_destroy(y7t_stream stream) {
+    Y7T_ARG_CHECK(stream);
+    Y7T_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}

@@ -410,6 +410,18 @@ class Detector:
                                                ps.ws.numel(), _lib.stream_ptr()))
         return ps.dets, ps.ndets
 
+    def candidate_arrays(self, pset=0):
+        """device views of post-processing set `pset`'s candidate arrays (the head of y7t_det_postprocess' workspace, each 256-byte aligned):
+        -> (cbox (B, cap, 4) f32 xyxy, cscore (B, cap) f32, ccls (B, cap) f32, cidx (B, cap) i32 anchor row, count (B,) i32).  What the fused Detect
+        epilogues / the decode pass wrote = `x` of utils/general.py:662 before the NMS; for parity checks and callers that want raw candidates."""
+        p = self.plan
+        B, cap, ws = self.max_batch, self.max_cand, p.post[pset].ws
+        rup = lambda n: (n + 255) // 256 * 256
+        o1 = rup(B * cap * 16); o2 = o1 + rup(B * cap * 4); o3 = o2 + rup(B * cap * 4); o4 = o3 + rup(B * cap * 4)
+        return (ws[:B * cap * 16].view(torch.float32).view(B, cap, 4), ws[o1:o1 + B * cap * 4].view(torch.float32).view(B, cap),
+                ws[o2:o2 + B * cap * 4].view(torch.float32).view(B, cap), ws[o3:o3 + B * cap * 4].view(torch.int32).view(B, cap),
+                ws[o4:o4 + B * 4].view(torch.int32))
+
     def stage_heads(self, out):
         """Copy the four raw head buffers of `out` (a few MB per frame, device to device, on the current stream) into a staging
         set owned by the plan and return a HeadOutput that reads from it.  With it decode+NMS of batch n can run on another
