@@ -1,22 +1,20 @@
 #!/bin/bash
 # ONE parametrised GPU script (replaces the per-call scripts of rounds 1-2).  Run on the GPU box from the repo root:
 #
-#   gpurun --timeout 2400 -- 'TAG=r3a bash scripts/gpu_round.sh tests exp_s2 exp_nw8 exp_late exp_fixup exp_next bench_variants pmc_queues'
+#   gpurun --timeout 1500 -- 'TAG=r3b bash scripts/gpu_round.sh tests exp_ws bench_variants'
 #   gpurun --timeout 1500 -- 'TAG=r03 bash scripts/gpu_round.sh suite bench profile'
 #
 # Every step runs under its own `timeout`, writes to gpurun_out/$TAG/ and appends its verdict to gpurun_out/$TAG/summary.txt; a failing step does not
-# stop the others.  BEFORE calling (CPU): python -m yolov7_tracker_amd.build  (+ python scripts/ablate/build_experiments.py fixup next  for exp_fixup / exp_next).
+# stop the others.  BEFORE calling (CPU): python -m yolov7_tracker_amd.build && git rev-parse HEAD > .commit_stamp
 # Steps:
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
 #   profile         rocprofv3 kernel stats of the bench command, per-op table of the launch list, HBM traffic (2 PMC passes), MFMA busy -> stamped JSONs
-#   exp_s2          stride-2 LDS-patch kernel (opt-in Y7T_CONV_PATCH_S2): layer parity, per-layer timing of its forms against the generic kernel
-#   exp_nw8         8-wave instances of the generic kernel (opt-in Y7T_CONV_NW8): parity in the pinned list, per-layer timing
-#   exp_late        stride-1 patch kernel with the step's DMAs behind its MFMAs (Y7T_CONV_ABLATE=512)
-#   exp_fixup       split-K reduced by the last arriver (lib/exp_fixup.so): parity, batch-1 latency
-#   exp_next        tracker candidate lists on a run-time row stride (lib/exp_next.so): parity, 500-object step time
+#   exp_ws          weights-stationary 64 -> 64 kernel (opt-in Y7T_CONV_WS=1): layer parity, parity inside the pinned list, per-layer timing, bench line
+#   (round 3's first call also had exp_s2 / exp_nw8 / exp_late / exp_fixup / exp_next -- the kernels prepared at the end of round 2; their results are in
+#    profiles/r03_conv_variants.txt and the losing variants are no longer in the source)
 #   pmc_queues      which queue of the buffer->LDS path the generic kernel waits in (TA / TCP / TCC / SQ counters on three layers)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -97,56 +95,19 @@ profile)
   grep -o '"value": [0-9.]*, "unit": "frames/s"\|"launch_list_ms": [0-9.]*' $P/bench_under_rocprof.log | head -2 | tee -a $O/summary.txt
   ;;
 
-exp_s2)
-  say "exp_s2 a: stride-2 patch kernel, layer parity vs torch fp32 (4-wave, 8-wave, DMA-late order)"
-  Y7T_TEST_EXPERIMENTS=1 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2.log 2>&1; echo "rc=$?" >> $O/t_s2.log; tailsum $O/t_s2.log
-  Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2_nw8.log 2>&1; echo "rc=$?" >> $O/t_s2_nw8.log; tailsum $O/t_s2_nw8.log
-  Y7T_TEST_EXPERIMENTS=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stride2 > $O/t_s2_late.log 2>&1; echo "rc=$?" >> $O/t_s2_late.log; tailsum $O/t_s2_late.log
-  say "exp_s2 b: per-layer timing at 32 frames (3/2 rows): generic | patch_s2 (256-ch panels where Cout allows) | 128-ch panels | 512 threads | DMA-late | 512 threads + DMA-late"
-  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
-  Y7T_CONV_PATCH_S2=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2.txt 2>&1
-  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_BN=128 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_bn128.txt 2>&1
-  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_nw8.txt 2>&1
-  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_late.txt 2>&1
-  Y7T_CONV_PATCH_S2=1 Y7T_CONV_PATCH_S2_NW=8 Y7T_CONV_PATCH_S2_ORDER=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_s2_nw8_late.txt 2>&1
-  for f in default s2 s2_bn128 s2_nw8 s2_late s2_nw8_late; do echo "-- $f"; grep " 3/2 \|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
-  ;;
-
-exp_nw8)
-  say "exp_nw8 a: 8-wave instances inside the benchmarked list, teacher-forced against the oracle"
-  Y7T_CONV_NW8=1 timeout 300 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_nw8.log 2>&1; echo "rc=$?" >> $O/t_nw8.log; tailsum $O/t_nw8.log
-  say "exp_nw8 b: per-layer timing: 256x256x64 (1), 256x256x32 four-stage ring (2), 256x128 (6), 128x128 (7), all at two waves per SIMD"
-  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
-  for v in 1 2 6 7; do Y7T_CONV_NW8=$v timeout 200 python scripts/bench_conv.py 32 > $O/b_nw8_$v.txt 2>&1; done
-  for f in default nw8_1 nw8_2 nw8_6 nw8_7; do echo "-- $f"; grep "TOTAL\| 1/1 \| 3/2 \|  20x20 " $O/b_$f.txt | head -70; done | tee -a $O/summary.txt
-  ;;
-
-exp_late)
-  say "exp_late: stride-1 patch kernel, DMA-late order (Y7T_CONV_ABLATE=512): parity in the pinned list, 3/1 rows"
-  Y7T_CONV_ABLATE=512 timeout 300 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_late.log 2>&1; echo "rc=$?" >> $O/t_late.log; tailsum $O/t_late.log
-  [ -f $O/b_default.txt ] || timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
-  Y7T_CONV_ABLATE=512 timeout 200 python scripts/bench_conv.py 32 > $O/b_late.txt 2>&1
-  for f in default late; do echo "-- $f"; grep " 3/1 \|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
-  ;;
-
-exp_fixup)
-  say "exp_fixup: split-K reduced by the last arriver: parity incl. repeated launches, then batch-1 latency against the default library"
-  if [ -f $LIBD/exp_fixup.so ]; then
-    Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer or whole_network or batch" > $O/t_fixup.log 2>&1; echo "rc=$?" >> $O/t_fixup.log; tailsum $O/t_fixup.log
-    timeout 200 python scripts/latency_mode.py 120 > $O/lat_default.txt 2>&1
-    Y7T_LIB=$LIBD/exp_fixup.so Y7T_CONV_SPLITK=2 timeout 200 python scripts/latency_mode.py 120 > $O/lat_fixup.txt 2>&1
-    for f in default fixup; do echo "-- $f"; grep -i "fps" $O/lat_$f.txt | tail -8; done | tee -a $O/summary.txt
-  else say "exp_fixup.so missing"; fi
-  ;;
-
-exp_next)
-  say "exp_next: tracker candidate lists on a run-time row stride: parity on the device, then the frame step against the default library"
-  if [ -f $LIBD/exp_next.so ]; then
-    Y7T_LIB=$LIBD/exp_next.so timeout 400 python -m pytest tests/test_tracker_gpu.py -q -m gpu > $O/t_next.log 2>&1; echo "rc=$?" >> $O/t_next.log; tailsum $O/t_next.log
-    timeout 200 python scripts/time_tracker.py > $O/trk_default.txt 2>&1
-    Y7T_LIB=$LIBD/exp_next.so timeout 200 python scripts/time_tracker.py > $O/trk_next.txt 2>&1
-    for f in default next; do echo "-- $f"; grep -v amdgpu.ids $O/trk_$f.txt | tail -12; done | tee -a $O/summary.txt
-  else say "exp_next.so missing"; fi
+exp_ws)
+  say "exp_ws a: weights-stationary 64 -> 64 kernel (csrc/y7t_conv_ws.hip): layer parity vs torch fp32, then inside the benchmarked list (teacher-forced)"
+  timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k weights_stationary > $O/t_ws.log 2>&1; echo "rc=$?" >> $O/t_ws.log; tailsum $O/t_ws.log
+  Y7T_CONV_WS=1 timeout 400 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_ws_pinned.log 2>&1; echo "rc=$?" >> $O/t_ws_pinned.log; tailsum $O/t_ws_pinned.log
+  say "exp_ws b: per-layer timing at 32 frames (64->64 3/1 rows): default (patch_mt / patch) vs ws64; ws64 with fewer / more workgroups than compute units"
+  timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
+  Y7T_CONV_WS=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_ws.txt 2>&1
+  Y7T_CONV_WS=1 Y7T_CONV_WS_WGS=512 timeout 200 python scripts/bench_conv.py 32 > $O/b_ws_512.txt 2>&1
+  for f in default ws ws_512; do echo "-- $f"; grep "  64->64 \|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
+  say "exp_ws c: bench line with it on"
+  Y7T_CONV_WS=1 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_ws.json 2> $O/bench_ws.err
+  timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nows.json 2> $O/bench_nows.err
+  benchsum ws nows
   ;;
 
 pmc_queues)

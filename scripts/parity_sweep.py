@@ -50,4 +50,4 @@ for seed in range(lo, hi):
 print(kind, fmt, "big" if big else "", "seeds %d..%d: %d mismatches %s, %.0f s, assignments re-solved literally: %d" % (lo, hi, len(bad), bad, time.time() - t0,
                                                                                                          hs.lib().hs_literal_calls()))
 if hs.lib().hs_next_tracker():
-    print("Y7T_NEXT_TRACKER build: associations on a short candidate stride %d, repeated with the full one %d" % (hs.lib().hs_next_stat(0), hs.lib().hs_next_stat(1)))
+    print("associations on a short candidate stride %d, repeated with the full one %d" % (hs.lib().hs_next_stat(0), hs.lib().hs_next_stat(1)))

@@ -17,14 +17,14 @@ def build(defs=()):
     tag = "".join(c for c in "".join(defs) if c.isalnum()) or "default"
     bdir = os.path.join(_HERE, "build_" + tag)
     so = os.path.join(bdir, "libconvsim.so")
-    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip")]
+    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip", "y7t_conv_ws.hip")]
     deps = srcs + [os.path.join(_HERE, "runtime.inc"), os.path.join(_HERE, "fake", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
     if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
     os.makedirs(bdir, exist_ok=True)
     text = open(srcs[0]).read()
     text, n = re.subn(r"asm volatile\([^;]*\);", ";", text)          # the s_waitcnt statements: loads complete at once here
-    assert n == 4, n
+    assert n == 3, n
     common = open(srcs[1]).read()
     common = common.replace("#define GLOBAL_AS __attribute__((address_space(1)))", "#define GLOBAL_AS").replace(
         "#define LDS_AS __attribute__((address_space(3)))", "#define LDS_AS")
@@ -42,9 +42,14 @@ def build(defs=()):
     s2, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", s2)
     assert n == 1
     open(os.path.join(bdir, "convsim_patch_s2.cpp"), "w").write(s2)
+    ws = re.sub(r"asm volatile\([^;]*\);", ";", open(srcs[6]).read())          # the weights-stationary 64 -> 64 kernel: same treatment
+    assert "asm" not in ws
+    ws, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", ws)
+    assert n == 1
+    open(os.path.join(bdir, "convsim_ws.cpp"), "w").write(ws)
     cmd = [_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-I", os.path.join(_HERE, "fake"), "-I", _CSRC,
            "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp"), os.path.join(bdir, "convsim_patch.cpp"),
-                                                                          os.path.join(bdir, "convsim_patch_s2.cpp")]
+                                                                          os.path.join(bdir, "convsim_patch_s2.cpp"), os.path.join(bdir, "convsim_ws.cpp")]
     subprocess.check_call(cmd)
     return so
 

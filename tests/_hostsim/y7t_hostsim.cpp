@@ -42,13 +42,7 @@ int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
 int hs_literal_calls() { return g_literal_calls; }
 void hs_set_fast_bytes(int n) { g_fast_bytes = n < 0 ? 0 : (n > (int)sizeof(g_fast) ? (unsigned)sizeof(g_fast) : (unsigned)n); }
 int hs_next_stat(int k) { return g_next_stat[k]; }
-int hs_next_tracker() {
-#ifdef Y7T_NEXT_TRACKER
-    return 1;
-#else
-    return 0;
-#endif
-}
+int hs_next_tracker() { return 1; }      // (the run-time candidate stride is the shipped path since round 3)
 int hs_tie_reason(int k) { return g_tie_reason[k]; }
 
 void hs_lapjv(const double* cost, int nr, int nc, double limit, int* x, int* y) {

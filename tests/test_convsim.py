@@ -1,8 +1,8 @@
 """CPU: the implicit-GEMM convolution kernel of csrc/y7t_conv.hip, compiled for the host FROM ITS REAL SOURCE and run work-item by work-item
 (tests/_convsim: OS threads per work-item, pthread barriers, models of the gfx950 builtins -- buffer->LDS DMA with the hardware range check,
 v_mfma_f32_32x32x16_f16, v_permlane32_swap), against a plain convolution.  What this pins without a GPU: load geometry, LDS swizzle, MFMA fragment
-mapping, K orders, ragged K, slices, split-K, the epilogue's transposition, the tile order -- for the shipped 4-wave build and for the experimental
-builds that have not run on a GPU yet (8-wave workgroups, split-K reduced by the last arriver).  The `-m gpu` layer tests remain the check of the real thing."""
+mapping, K orders, ragged K, slices, split-K, the epilogue's transposition, the tile order -- and it is where a new kernel (the stride-2 patch kernel, the
+weights-stationary 64 -> 64 kernel) is developed before GPU minutes are spent on it.  The `-m gpu` layer tests remain the check of the real thing."""
 import numpy as np
 import pytest
 import torch
@@ -25,6 +25,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder == 2:      # the patch kernel's panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack(blk, cin_pad)
+    if korder == 5:      # the weights-stationary kernel's register-fragment order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws(blk)
     if korder == 4:      # the stride-2 patch kernel's panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_s2(blk, cin_pad)
@@ -82,8 +85,7 @@ def test_shipped_kernel_source_on_the_host(case):
     assert name.startswith("igemm<") and (tile == 0 or ("splitK" in name) == bool(kw.get("splitk")))      # (the dispatch rules split K of small problems themselves)
 
 
-@pytest.mark.parametrize("korder,Cout,lat_first,force", [(0, 128, True, 0), (3, 192, False, 0), (3, 256, True, 0), (0, 256, True, 32), (0, 384, False, 32)],
-                         ids=["rows-128", "panels-64", "panels-128", "8-wave-256", "8-wave-128"])
+@pytest.mark.parametrize("korder,Cout,lat_first,force", [(0, 128, True, 0), (3, 192, False, 0), (3, 256, True, 0)], ids=["rows-128", "panels-64", "panels-128"])
 def test_upsample_on_read_loader_on_the_host(korder, Cout, lat_first, force):
     """the DUAL instance of the 1x1 fast path (default launch list: the three convs behind Concat[lateral, Upsample(x)], /root/reference/cfg/deploy/yolov7-w6.yaml:75,89,103):
     K-steps whose channels lie in the upsampled range DMA pixel (y >> 1, x >> 1) of the half-resolution tensor -- against a conv over the materialised concat"""
@@ -109,57 +111,12 @@ def test_upsample_on_read_loader_on_the_host(korder, Cout, lat_first, force):
                         korder, force)
     assert rc == 0, L.cs_last_error().decode()
     name = L.cs_last_kernel().decode()
-    assert "upsample-on-read" in name and (("8-wave" in name) == bool(force)), name          # (force: the opt-in 8-wave instances of the same loader)
+    assert "upsample-on-read" in name, name
     x = lat.astype(np.float32)
     x[..., up_c0:up_c0 + C_up] = np.repeat(np.repeat(half[..., 32:32 + C_up].astype(np.float32), 2, axis=1), 2, axis=2)
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))
     ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(out.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
-
-
-def test_eight_wave_experiment_on_the_host():
-    """-DY7T_IGEMM_NW=8 (512-thread workgroups; scripts/ablate/build_experiments.py nw8), not yet run on a GPU: same results as the 4-wave build"""
-    L8 = cs.lib(("-DY7T_IGEMM_NW=8",))
-    assert L8.cs_waves() == 8
-    for B, H, W, Cin, Cout, k, s, tile, kw in [(1, 17, 17, 64, 256, 3, 1, 256256064, {}), (1, 23, 19, 128, 256, 1, 1, 256256064, {}),
-                                               (1, 20, 20, 64, 128, 3, 2, 256128064, {}), (2, 9, 9, 64, 128, 3, 1, 128128064, {"korder": 1}),
-                                               (1, 9, 9, 128, 128, 1, 1, 128128032, {}), (1, 10, 10, 128, 256, 3, 1, 256256064, {"splitk": 1}),
-                                               (1, 9, 13, 192, 128, 3, 1, 0, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64})]:
-        run_case(L8, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
-
-
-def test_eight_wave_instances_of_the_default_build_on_the_host():
-    """the same 512-thread kernels as template instances INSIDE the default library (csrc/y7t_conv.hip: NW template parameter; Y7T_CONV_NW8=1 on the device,
-    force_patch bit 5 / explicit tile codes here) -- what round 3 measures without a second library.  The 4-wave instances' instruction streams were checked
-    identical before / after the wave count became a template parameter."""
-    L = cs.lib()
-    for B, H, W, Cin, Cout, k, s, tile, kw in [(1, 17, 17, 64, 256, 3, 1, 256256564, {}), (1, 23, 19, 128, 256, 1, 1, 256256564, {}),
-                                               (1, 20, 20, 64, 128, 3, 2, 256128564, {"korder": 1}), (1, 9, 9, 128, 128, 1, 1, 128128564, {}),
-                                               (1, 9, 13, 192, 128, 3, 1, 256128564, {"in_ld": 256, "in_coff": 64, "out_ld": 192, "out_coff": 64}),
-                                               (1, 19, 17, 192, 256, 1, 1, 256256532, {}), (1, 18, 18, 128, 256, 3, 2, 256256532, {"korder": 1})]:   # four-stage ring
-        name = run_case(L, B, H, W, Cin, Cout, k, s, 1, tile, **kw)
-        assert name.endswith("8-wave"), name
-    # through the dispatcher: the rule picks 256 x 256 when Cout % 256 == 0, else 256 x 128; layers outside the envelope keep their 4-wave kernel
-    assert run_case(L, 1, 12, 12, 128, 256, 1, 1, 1, 0, force_patch=32) == "igemm<256,256,64,2> 1x1 8-wave"
-    name = run_case(L, 1, 16, 16, 64, 384, 3, 2, 1, 0, korder=1, force_patch=32)          # (a problem this small also splits K: that path on 8 waves too)
-    assert name.startswith("igemm<256,128,64,2>") and name.endswith("8-wave"), name
-    assert "8-wave" not in run_case(L, 1, 8, 8, 96, 192, 1, 1, 2, 0, force_patch=32)           # Cin % 64, Cout % 128
-
-
-def test_split_k_reduced_by_the_last_arriver_on_the_host():
-    """-DY7T_SPLITK_FIXUP with allow_splitk = 2: no k_splitk_reduce launch, the tile's last workgroup sums the slabs in split order -> the same bits as the
-    reduce kernel; the arrival counters are left at zero (second launch).  (Workgroups run one after the other here: the memory-ordering side -- fences,
-    cross-XCD visibility -- is what the GPU run has to show.)"""
-    LF = cs.lib(("-DY7T_SPLITK_FIXUP=1",))
-    for rep in range(2):
-        n0 = LF.cs_workgroups_run()
-        name = run_case(LF, 1, 12, 12, 1024, 128, 1, 1, 2, 128128064, splitk=2)
-        n_fix = LF.cs_workgroups_run() - n0
-        assert "splitK" in name
-        n0 = LF.cs_workgroups_run()
-        run_case(LF, 1, 12, 12, 1024, 128, 1, 1, 2, 128128064, splitk=1)
-        assert LF.cs_workgroups_run() - n0 > n_fix          # the reduce kernel's workgroups are gone
-    run_case(LF, 1, 10, 10, 128, 128, 3, 1, 1, 128128064, splitk=2, out_ld=192, out_coff=64)
 
 
 # the LDS-patch kernels (csrc/y7t_conv_patch.hip; 3x3 / stride 1): B, H, W, Cin, Cout, act, korder, extras -- forced onto the patch kernel like the GPU layer tests
@@ -179,17 +136,7 @@ def test_patch_kernel_source_on_the_host(case):
     assert name.startswith("patch"), name
 
 
-@pytest.mark.parametrize("case", [(1, 32, 32, 64, 128, 1, 0, {}), (1, 16, 48, 128, 64, 2, 1, {"in_ld": 192, "in_coff": 64}), PATCH_CASES[3]],
-                         ids=["16x16x128", "16x16x64", "strip40"])
-def test_patch_kernel_dma_late_order_on_the_host(case):
-    """ABL bit 9 of k_conv3x3_patch (Y7T_CONV_ABLATE=512 on the device, force_patch bit 6 here): the K-step's DMAs issued behind its second MFMA half -- an
-    order experiment with correct results, to be timed next round; the instruction streams of all other instances were checked unchanged when it was added"""
-    B, H, W, Cin, Cout, act, korder, kw = case
-    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=65, **kw)
-    assert name.startswith("patch") and name.endswith("dma-late"), name
-
-
-# the stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; opt-in experiment, korder 4): B, H, W, Cin, Cout, act, extras
+# the stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; korder 4): B, H, W, Cin, Cout, act, extras
 S2_CASES = [
     (1, 16, 32, 64, 128, 1, {}),                                                      # one full 8 x 16 output tile, 128-channel panels (6-slot weight ring)
     (1, 16, 32, 64, 256, 1, {}),                                                      # 256-channel panels (3-slot ring, four waves along the channels)
@@ -201,30 +148,12 @@ S2_CASES = [
 
 @pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "%dx%dx%d_%d-%d" % (c[0], c[1], c[2], c[3], c[4]))
 def test_stride2_patch_kernel_source_on_the_host(case):
-    """csrc/y7t_conv_patch_s2.hip (parity-split patch columns, 16-channel chunks, panel-packed weights) has not run on a GPU yet: its load geometry,
-    plane addressing, ring positions and epilogue against a plain stride-2 convolution"""
+    """csrc/y7t_conv_patch_s2.hip (parity-split patch columns, 16-channel chunks, panel-packed weights): its load geometry, plane addressing, ring
+    positions and epilogue against a plain stride-2 convolution"""
     B, H, W, Cin, Cout, act, kw = case
     name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, **kw)
     cp = (Cout + 127) // 128 * 128
     assert name == "patch_s2<%d>" % (256 if cp % 256 == 0 else 128), name
-
-
-@pytest.mark.parametrize("case", [S2_CASES[1], S2_CASES[2], (1, 34, 36, 64, 256, 1, {}), (1, 9, 40, 64, 384, 1, {"out_ld": 384})],
-                         ids=lambda c: "%dx%dx%d_%d-%d" % (c[0], c[1], c[2], c[3], c[4]))
-def test_stride2_patch_kernel_eight_wave_form_on_the_host(case):
-    """the 512-thread form (16 x 16 output pixels per workgroup, 33 x 33 patch, one workgroup per CU; Y7T_CONV_PATCH_S2_NW=8 on the device, force_patch = 8 here)"""
-    B, H, W, Cin, Cout, act, kw = case
-    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, force_patch=8, **kw)
-    cp = (Cout + 127) // 128 * 128
-    assert name == "patch_s2<%d,8>" % (256 if cp % 256 == 0 else 128), name
-
-
-@pytest.mark.parametrize("force,case", [(16, S2_CASES[2]), (16, S2_CASES[1]), (24, S2_CASES[1]), (24, (1, 18, 36, 128, 128, 1, {}))], ids=["4w-128", "4w-256", "8w-256", "8w-128"])
-def test_stride2_patch_kernel_dma_late_order_on_the_host(force, case):
-    """ORD = 1 (Y7T_CONV_PATCH_S2_ORDER=1 on the device; force_patch bit 4 here): the step's DMAs issued behind its MFMAs instead of in front of the fragment reads"""
-    B, H, W, Cin, Cout, act, kw = case
-    name = run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, force_patch=force, **kw)
-    assert name.startswith("patch_s2<") and name.endswith("dma-late") and ((",8>" in name) == bool(force & 8)), name
 
 
 def test_stride2_patch_kernel_rejects_what_it_cannot_run():
@@ -268,3 +197,42 @@ def test_stride2_patch_kernel_fragment_reads_are_bank_conflict_free():
     # every immediate the kernel adds (tap row kh * RP, plane offsets 0 / 17 * 48 / 48, tile j * 4 * RP, buffers, ring slots) is a multiple of 16 bytes and
     # shifts all lanes alike, so it cannot create a conflict
     assert RP % 16 == 0 and (17 * PIXB) % 16 == 0 and PIXB % 16 == 0
+
+
+# B, H, W, act, slices -- the weights-stationary 64 -> 64 kernel (csrc/y7t_conv_ws.hip; the fake device has 3 compute units, so a workgroup walks
+# several tiles: the three-buffer patch ring wraps, tile ranges end unevenly, the last workgroups run out of tiles early)
+WS_CASES = [
+    (1, 16, 16, 1, {}),                                                                # one tile, one workgroup
+    (1, 32, 48, 1, {}),                                                                # 6 tiles on 3 workgroups
+    (2, 48, 32, 2, {"in_ld": 128, "in_coff": 64, "out_ld": 256, "out_coff": 128}),     # 12 tiles, two images, slices of concat buffers, LeakyReLU
+    (1, 64, 80, 0, {"out_ld": 64}),                                                    # 20 tiles: 7 per workgroup (the ring wraps twice), the last one gets 6
+    (5, 16, 16, 1, {}),                                                                # 5 tiles over 3 workgroups: 2, 2, 1
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
+def test_weights_stationary_kernel_source_on_the_host(case):
+    B, H, W, act, kw = case
+    name = run_case(cs.lib(), B, H, W, 64, 64, 3, 1, act, 0, korder=5, seed=B * 1000 + H + W, **kw)
+    assert name == "ws64<16,16>", name
+
+
+def test_weights_stationary_kernel_rejects_what_it_cannot_run():
+    """korder 5 weights are readable by that kernel only: a ragged map (its store count must be exact), other channel counts, a stride -> argument error"""
+    L = cs.lib()
+    x, w, b, out = np.zeros((1, 20, 16, 64), np.float16), np.zeros((64, 576), np.float16), np.zeros(64, np.float32), np.zeros((1, 20, 16, 64), np.float16)
+    rc = L.cs_conv(x.ctypes.data, 64, 0, 1, 20, 16, 64, w.ctypes.data, b.ctypes.data, out.ctypes.data, 64, 0, 0, 64, 64, 3, 3, 1, 1, 1, 5, 0, 0, 0)
+    assert rc != 0 and b"whole 16 x 16 tiles" in L.cs_last_error()
+
+
+def test_weights_stationary_fragment_reads_are_bank_conflict_free():
+    """ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32); with 144-byte pixels and a row pitch that is a
+    multiple of 256 bytes the 16 addresses of a group fall on 16 different 16-byte bank quads (MI355X_MICROARCH.md, LDS)"""
+    PIXB, RP = 144, 2816
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for hi in (0, 1):
+        for g in groups:
+            for kw in range(3):
+                for ks in range(4):
+                    addr = [((l >> 4) * RP + (l & 15) * PIXB + hi * 16 + kw * PIXB + ks * 32) for l in g]
+                    assert len({(a // 16) % 16 for a in addr}) == 16

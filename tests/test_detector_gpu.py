@@ -40,6 +40,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 4:   # stride-2 patch-kernel panel order (opt-in experiment)
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_s2(blk, cin_pad)
+    if korder == 5:   # register-fragment order of the weights-stationary 64 -> 64 kernel
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws(blk)
     return blk
 
 
@@ -94,7 +97,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    korder = 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
     cout_pad = (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
@@ -123,10 +126,27 @@ def test_conv_layer_matches_torch_fp32(L, case):
     assert np.all(got[..., mask] == 7.0)
 
 
-# csrc/y7t_conv_patch_s2.hip (stride-2 LDS-patch kernel) is an opt-in experiment that had not run on a GPU when it was committed (end of round 2, no GPU
-# minutes left; tests/test_convsim.py runs its source on the host).  Its device tests run only on request, so that the default suite stays what was verified:
-#     Y7T_TEST_EXPERIMENTS=1 python -m pytest tests/test_detector_gpu.py -m gpu -k stride2
-#     Y7T_CONV_PATCH_S2=1 python -m pytest tests/test_detector_pinned_gpu.py -m gpu          (the whole launch list, teacher-forced against the oracle)
+# csrc/y7t_conv_ws.hip: the 64 -> 64 3x3 layers with the filter bank resident in registers, one persistent workgroup per compute unit walking a range of
+# 16 x 16 tiles through a three-buffer patch ring (act bit 13: korder 5).  Shapes: fewer tiles than compute units; thousands of tiles (every workgroup
+# walks many, the ring wraps, uneven ranges); slices of concat buffers; both activations; the benchmarked layer itself (320 x 320, 8 frames).
+WS_CASES = [
+    # B, H, W, Cin, Cout, k, s, act (bit 13), in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 16, 16, 64, 64, 3, 1, 1 | 8192, 64, 0, 64, 0, 0),
+    (1, 48, 80, 64, 64, 3, 1, 1 | 8192, 64, 0, 64, 0, 0),
+    (3, 160, 160, 64, 64, 3, 1, 2 | 8192, 128, 64, 256, 128, 0),
+    (7, 96, 112, 64, 64, 3, 1, 0 | 8192, 64, 0, 64, 0, 0),
+    (8, 320, 320, 64, 64, 3, 1, 1 | 8192, 128, 0, 256, 192, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_weights_stationary_kernel_matches_torch_fp32(L, case):
+    from yolov7_tracker_amd import _lib
+    test_conv_layer_matches_torch_fp32(L, case)
+    assert L.y7t_last_kernel().decode() == "ws64<16,16>"
+
+
+# csrc/y7t_conv_patch_s2.hip: the stride-2 LDS-patch kernel (parity-split patch columns, 16-channel chunks; korder 4 = act bit 12), 128- and 256-channel panels
 S2_CASES = [
     # B, H, W, Cin, Cout, k, s, act (bit 12: korder 4), in_ld, in_coff, out_ld, out_coff, out_f32
     (1, 16, 32, 64, 128, 3, 2, 1 | 4096, 64, 0, 128, 0, 0),
@@ -138,7 +158,6 @@ S2_CASES = [
 ]
 
 
-@pytest.mark.skipif(os.environ.get("Y7T_TEST_EXPERIMENTS") != "1", reason="opt-in experiment (Y7T_TEST_EXPERIMENTS=1): not part of the verified default suite")
 @pytest.mark.parametrize("case", S2_CASES)
 def test_stride2_patch_kernel_matches_torch_fp32(L, case):
     test_conv_layer_matches_torch_fp32(L, case)

@@ -193,8 +193,15 @@ def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
             o = ((((tile * nc16 + c) * 9 + tap) * BN + r) * 2 + s) * 8
             k = tap * cin + c * 16 + (s ^ ((r >> 3) & 1)) * 8
             assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
+    monkeypatch.setenv("Y7T_CONV_PATCH_S2", "0")
     base = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
     assert not any(int(op["korder"]) == 4 for op in base.ops)
+    monkeypatch.delenv("Y7T_CONV_PATCH_S2")
+    # the default rule = where the kernel measured faster (round 3): 256-channel panels, Cin >= 128, >= 50 000 output pixels per launch
+    auto = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    took = sorted((int(op["H"]), int(op["Cin"]), int(op["Cout"])) for op in auto.ops if int(op["korder"]) == 4)
+    assert took == [(80, 512, 768), (160, 128, 256), (160, 256, 512), (320, 128, 256)], took
+    assert not any(int(op["korder"]) == 4 for op in graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=1).ops)      # batch 1: generic + split-K
     monkeypatch.setenv("Y7T_CONV_PATCH_S2", "1")
     exp = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
     assert len(exp.ops) == len(base.ops)
@@ -208,28 +215,27 @@ def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
     assert sum(int(op["korder"]) == 4 for op in wide.ops) == 7          # all but the 64 -> 128 layer at 640x640
 
 
-def test_eight_wave_opt_in_lowers_only_the_layers_it_takes_row_major(monkeypatch):
-    """CPU: Y7T_CONV_NW8=1 (8-wave instances of the generic kernel, opt-in experiment): exactly the 1x1 layers the C rule will take lose their 128 x 32 weight
-    panels (korder 3 -> 0); Detect convs, small maps and everything else keep their packing; the default lowering is untouched"""
-    from yolov7_tracker_amd.detector import arch, graph
+def test_weights_stationary_packing_and_opt_in_lowering(monkeypatch):
+    """CPU: korder 5 = the 64 x 576 filter bank of a 64 -> 64 3x3 layer as MFMA A-fragments (csrc/y7t_conv_ws.hip): a permutation with the documented
+    index map; Y7T_CONV_WS=1 lowers exactly the seven 64 -> 64 layers on the 320^2 / 160^2 maps to it and nothing else changes"""
+    from yolov7_tracker_amd.detector import arch, graph, weights
+    blk = np.random.default_rng(0).permutation(64 * 576).astype(np.float64).reshape(64, 576)
+    out = weights.pack_ws(blk).ravel()
+    assert np.array_equal(np.sort(out), np.sort(blk.ravel()))
+    for tap, ks, i, lane in ((0, 0, 0, 0), (8, 3, 1, 63), (4, 2, 0, 37), (7, 1, 1, 5)):
+        f = (tap * 4 + ks) * 2 + i
+        assert np.array_equal(out[(f * 64 + lane) * 8:(f * 64 + lane) * 8 + 8], blk[i * 32 + lane % 32, tap * 64 + ks * 16 + 8 * (lane // 32):][:8])
     low = lambda: graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
     base = low()
-    monkeypatch.setenv("Y7T_CONV_NW8", "1")
+    assert not any(int(op["korder"]) == 5 for op in base.ops)
+    monkeypatch.setenv("Y7T_CONV_WS", "1")
     exp = low()
-    changed = [(a, b) for a, b in zip(base.ops, exp.ops) if int(a["korder"]) != int(b["korder"])]
-    assert len(changed) >= 10
-    for a, b in changed:
-        assert int(a["korder"]) == 3 and int(b["korder"]) == 0 and int(b["KH"]) == 1 and int(b["detect_level"]) < 0
-        assert int(b["up_C"]) % 64 == 0 and int(b["up_c0"]) % 64 == 0          # (upsample-on-read layers too, when the upsampled range fits 64-deep stages)
-        assert int(b["Cin"]) % 64 == 0 and int(b["Cout_pad"]) % 128 == 0
-        bn = 256 if int(b["Cout_pad"]) % 256 == 0 else 128
-        assert (32 * int(b["Ho"]) * int(b["Wo"]) // 256) * (int(b["Cout_pad"]) // bn) >= 256
-    kept = [b for a, b in zip(base.ops, exp.ops) if int(b["korder"]) == 3]
-    assert any(int(b["up_C"]) > 0 for _, b in changed)
-    assert kept and all(32 * int(b["Ho"]) * int(b["Wo"]) // 256 * (int(b["Cout_pad"]) // 128) < 512 or int(b["Cout_pad"]) % 128 for b in kept)
+    took = [(int(op["H"]), int(op["Cin"]), int(op["Cout"])) for op in exp.ops if int(op["korder"]) == 5]
+    assert took == [(320, 64, 64)] * 4 + [(160, 64, 64)] * 3
     for a, b in zip(base.ops, exp.ops):
         for f in a.dtype.names:
             assert f == "korder" or a[f] == b[f]
+    assert not any(int(op["korder"]) == 5 for op in graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=1).ops)      # 400 tiles: too few
 
 
 def test_patch_eligibility_rule():

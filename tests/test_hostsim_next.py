@@ -1,6 +1,5 @@
-"""CPU: the experimental builds of the tracker headers (macros that are off in the shipped library) keep parity -- the host build with the macro on,
-with a fast scratch of the device's size, against the oracle on crowded random scenes.  Y7T_NEXT_TRACKER: candidate lists on a run-time row stride so that
-they fit in LDS at 500 objects (csrc/y7t_track_step.h)."""
+"""CPU: placement branches of the tracker programs -- the host build with a fast scratch of the device's size against the oracle on crowded random scenes
+(candidate lists on a run-time row stride so that they fit in LDS at 500 objects, csrc/y7t_track_step.h::y7t_assoc_sparse_fn), and with no fast scratch at all."""
 import os
 import subprocess
 import sys
@@ -8,8 +7,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_next_tracker_build_keeps_parity_on_crowded_scenes():
-    env = dict(os.environ, Y7T_HOSTSIM_DEFS="-DY7T_NEXT_TRACKER=1", Y7T_HOSTSIM_FAST_BYTES="131072")
+def test_short_candidate_stride_keeps_parity_on_crowded_scenes():
+    env = dict(os.environ, Y7T_HOSTSIM_FAST_BYTES="131072")
+    env.pop("Y7T_HOSTSIM_DEFS", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_sweep.py"), "bytetrack", "default", "0", "8", "--big"], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

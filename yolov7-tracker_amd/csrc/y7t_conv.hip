@@ -32,14 +32,9 @@
 // EPI = 1 (Detect 1x1 convs in a fused forward): the epilogue decodes + filters (models/yolo.py:49-56, utils/general.py:629-662) instead
 // of storing the tile.  DUAL (KM = 1 only): upsample-on-read -- K-steps whose channels lie in [up_c0, up_c0 + up_C) fetch pixel (y, x)
 // from the half-resolution tensor `in2` at (y >> 1, x >> 1) (nn.Upsample(None, 2, 'nearest') folded into the consumer's loader).
-// Experiment for the next round (build a second library with -DY7T_IGEMM_NW=8): 512-thread workgroups, 2 x 4 waves, so that a 256 x 256 tile (half the
-// operand bytes per flop through the vector-memory path, which is what bounds these kernels -- DESIGN 3b) runs with 2 waves per SIMD instead of the
-// one that the 256-thread instance of that tile leaves.  The default build (4 waves) is unchanged by it.
-#ifndef Y7T_IGEMM_NW
-#define Y7T_IGEMM_NW 4
-#endif
-constexpr int kNW = Y7T_IGEMM_NW;      // default number of waves per workgroup (the macro build switches every instance; NW below is per instance)
-// NW = 8 instances are also part of the DEFAULT build, opt-in per layer at run time (Y7T_CONV_NW8=1; conv_dispatch): the same experiment without a second library
+constexpr int kNW = 4;      // waves per workgroup (NW below stays a template parameter: 8-wave instances with 256 x 256 x 64 / 256 x 128 x 64 tiles at two waves per
+                            // SIMD were built and measured in round 3 -- 1x1 layers 5-15 % SLOWER, stride-2 3x3 layers on a par with the stride-2 patch kernel,
+                            // profiles/r03_conv_variants.txt -- and are no longer instantiated)
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false, int NW = kNW>
 __global__ void __launch_bounds__(64 * NW, (NW == 8 || BM * BN >= 256 * 256 ? 1 : 2)) k_conv_igemm(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (it only needs the stub)
@@ -357,48 +352,6 @@ __global__ void __launch_bounds__(64 * NW, (NW == 8 || BM * BN >= 256 * 256 ? 1 
                     *(float4v*)(slab + (size_t)m * p.Cout_pad + n) = v;
                 }
         }
-#ifdef Y7T_SPLITK_FIXUP   // experiment for the batch-1 latency mode (next round; build with -DY7T_SPLITK_FIXUP and run with Y7T_CONV_SPLITK=2):
-        // no k_splitk_reduce launch -- the LAST workgroup of a tile to arrive sums the slabs in split order (the same arithmetic in the same order
-        // as k_splitk_reduce, so the result does not depend on who arrives last), adds the bias, activates and stores
-        if (p.allow_splitk != 2) return;
-        // Release / acquire with as few cache-wide operations as the memory model allows (__threadfence() is a seq_cst agent fence = an L2 write-back AND
-        // an L2 + L1 invalidate, per wave: eight of each per workgroup would cost more than the reduce launches this experiment removes):
-        //   every wave: its slab stores have completed (workgroup-scope release: they are in this XCD's L2)      -> barrier
-        //   ONE lane:   agent-scope release (one L2 write-back per workgroup) -> ticket -> if last: agent-scope acquire (one invalidate per TILE)
-        //   barrier -> the last arriver's waves read the slabs with plain loads (MI355X_MICROARCH.md, inter-workgroup visibility recipe)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        int* ticket = (int*)smem;                          // (the stages are drained; the bias corner lies behind them)
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-back has COMPLETED before the ticket (in this kernel the compiler's own wait after
-                                                               // buffer_wbl2 did not survive the wave-aggregation of the atomic: checked in the ISA)
-            const int tk = atomicAdd(p.splitk_done + bid, 1);
-            if (tk == p.splitk - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            *ticket = tk;
-        }
-        __syncthreads();
-        if (*ticket != p.splitk - 1) return;
-        if (tid == 0) p.splitk_done[bid] = 0;              // ready for the next launch on this stream
-        const float* lb = (const float*)(smem + BIAS_OFF);
-        for (int idx = tid; idx < BM * (BN / 4); idx += kNT) {
-            const int m = m0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-            if (m >= p.M || n >= p.Cout) continue;
-            typedef __attribute__((ext_vector_type(4))) float float4v;
-            float4v a = *(const float4v*)(p.partial + (size_t)m * p.Cout_pad + n);
-            for (int sp = 1; sp < p.splitk; ++sp) {
-                const float4v b = *(const float4v*)(p.partial + ((size_t)sp * p.M + m) * p.Cout_pad + n);
-                a += b;
-            }
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fn(a[e] + lb[n - n0 + e], p.act);
-            const size_t o = (size_t)m * p.ldout + p.cout_off + n;
-            if (p.out_f32) { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) ((float*)p.out)[o + e] = v[e]; }
-            else if (n + 3 < p.Cout) { half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; *(half4*)((half_t*)p.out + o) = h; }
-            else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) ((half_t*)p.out)[o + e] = (half_t)v[e]; }
-        }
-#endif
         return;
     }
     // ---- epilogue: bias + activation.  A lane holds channels n..n+3 of its pixel for each group g (n = 8g + 4*hi32);
@@ -518,7 +471,6 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 static float* g_splitk_ws = nullptr;
 static const size_t kSplitKWsBytes = Y7T_SPLITK_WS_BYTES;
-[[maybe_unused]] static const size_t kSplitKDoneBytes = 64 << 10;      // (reserved at the end of the workspace for Y7T_SPLITK_FIXUP's tile counters)
 
 template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, bool DUAL = false, int NW = kNW>
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
@@ -537,33 +489,18 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
         S = (512 + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;
-#ifdef Y7T_SPLITK_FIXUP
-        while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes - kSplitKDoneBytes) --S;
-#else
         while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes) --S;
-#endif
     }
     b.splitk = S; b.ksteps = (nk + S - 1) / S; b.partial = nullptr;
     if (S > 1) {
         if (!a.splitk_ws && !g_splitk_ws) Y7T_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, kSplitKWsBytes));
         b.partial = a.splitk_ws ? a.splitk_ws : g_splitk_ws;
-#ifdef Y7T_SPLITK_FIXUP   // arrival counters of the tiles: the last 64 KiB of the workspace, zeroed once, left at zero by every launch
-        b.splitk_done = (int*)((char*)b.partial + kSplitKWsBytes - kSplitKDoneBytes);
-        static std::vector<void*> zeroed;
-        if (std::find(zeroed.begin(), zeroed.end(), (void*)b.partial) == zeroed.end()) {
-            Y7T_HIP_CHECK(hipMemsetAsync(b.splitk_done, 0, kSplitKDoneBytes, s));
-            zeroed.push_back((void*)b.partial);
-        }
-#endif
         b.splitk = (nk + b.ksteps - 1) / b.ksteps;      // no empty splits
     }
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL, NW>), dim3(tiles * b.splitk), dim3(64 * NW), lds, s, b);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("igemm<%d,%d,%d,%d>%s%s%s%s%s", BM, BN, BK, NST, KM == 1 ? " 1x1" : UT ? "" : " ragged-K", b.splitk > 1 ? " splitK" : "",
                     EPI == 1 ? " detect-decode" : "", DUAL ? " upsample-on-read" : "", NW != kNW ? " 8-wave" : "");
-#ifdef Y7T_SPLITK_FIXUP
-    if (b.splitk > 1 && b.allow_splitk == 2) return 0;    // reduced by the last arriver of each tile
-#endif
     if (b.splitk > 1) {
         const long long tot = (long long)a.M * (a.Cout_pad / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -579,7 +516,6 @@ static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
     // uniform-tap specialisation: every K-step of BK channels lies inside one filter tap; 1x1 fast path on top of it
     if (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24))
         return launch_conv_ut<BM, BN, BK, NST, true, 1, 0, false, NW>(a, s);
-    if (NW != kNW) return launch_conv_ut<BM, BN, BK, NST, true, 0, 0, false, NW>(a, s);      // (the opt-in 8-wave instances: uniform taps only, checked by the caller)
     return (a.Cin % BK == 0) ? launch_conv_ut<BM, BN, BK, NST, true>(a, s) : launch_conv_ut<BM, BN, BK, NST, false>(a, s);
 }
 
@@ -617,25 +553,9 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
-
-// Y7T_CONV_NW8 (opt-in experiment: 8-wave instances of this kernel inside the default build), or force_patch bit 5 from the host simulator's tests
-static int nw8_want(const Y7TConvArgs& a) {
-    static int nw8 = -1;
-    if (nw8 < 0) { const char* e = getenv("Y7T_CONV_NW8"); nw8 = e ? atoi(e) : 0; }
-    return (a.force_patch & 32) ? 1 : nw8;
-}
+int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_ws.hip (korder 5: 64 -> 64 3x3 layers, weights stationary in registers)
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
-#if Y7T_IGEMM_NW == 8      // experimental library: 512-thread workgroups, 64-deep stages, 256 x 256 / 256 x 128 / 128 x 128 tiles only (layer-level timing and tests)
-    if (a.epi || a.up_C > 0 || a.korder >= 2 || a.Cout_pad % 128 || a.Cin % 64) {
-        y7t_set_error("conv: this is the 8-wave experimental build (plain layers with Cin %% 64 == 0 and Cout %% 128 == 0 only)");
-        return Y7T_E_ARG;
-    }
-    const int v8 = conv_variant();
-    if (v8 == 7) return launch_conv<128, 128, 64, 2>(a, s);
-    if (v8 == 6 || a.Cout_pad % 256) return launch_conv<256, 128, 64, 2>(a, s);
-    return launch_conv<256, 256, 64, 2>(a, s);
-#else
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
         const bool fast = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24) &&
                           (a.korder == 3 || a.korder == 0);
@@ -648,16 +568,10 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
             y7t_set_error("conv: upsample-on-read channel range [%d, %d) / map %dx%d not supported", a.up_c0, a.up_c0 + a.up_C, a.H, a.W);
             return Y7T_E_ARG;
         }
-        {   // the same loader on the 8-wave 256-pixel tiles (64-deep stages: the upsampled range must be a multiple of 64 channels; row-major weights)
-            const int want = nw8_want(a);
-            const int bn8 = (a.Cout_pad % 256 == 0 && want == 1) ? 256 : 128;
-            if (want && a.korder == 0 && a.Cout_pad % 128 == 0 && a.up_c0 % 64 == 0 && a.up_C % 64 == 0 &&
-                ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256))
-                return bn8 == 256 ? launch_conv_ut<256, 256, 64, 2, true, 1, 0, true, 8>(a, s) : launch_conv_ut<256, 128, 64, 2, true, 1, 0, true, 8>(a, s);
-        }
         return a.Cout_pad % 128 == 0 ? launch_conv_ut<128, 128, 32, 2, true, 1, 0, true>(a, s) : launch_conv_ut<128, 64, 32, 2, true, 1, 0, true>(a, s);
     }
     if (a.korder == 4) return y7t_conv_patch_s2_launch(a, s);   // stride-2 LDS-patch kernel's panels: only that kernel reads them
+    if (a.korder == 5) return y7t_conv_ws_launch(a, s);         // register-fragment order: only the weights-stationary kernel reads it
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
@@ -665,23 +579,6 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     if ((conv_variant() == 0 && !a.no_patch) || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);
         if (rc) return rc < 0 ? rc : 0;
-    }
-    // Opt-in experiment inside the default build (Y7T_CONV_NW8 = 1: 256 x 256 x 64 tiles where Cout allows, else 256 x 128; 2: 256 x 256 x 32 with a four-stage ring; 6: 256 x 128; 7: 128 x 128 -- all on
-    // 512-thread workgroups at two waves per SIMD): the layers the generic kernel runs today whose DMA bytes per flop bound them.
-    // Weights must be in a row layout (korder 0 / 1): detector/graph.py::nw8_eligible mirrors this rule and lowers exactly these 1x1 layers row-major when the
-    // same switch is in the environment (their weight panels are packed for the 128 x 32 tile); a layer that arrives panel-packed never gets here.
-    {
-        const int want = nw8_want(a);
-        const int bn8 = (a.Cout_pad % 256 == 0 && (want == 1 || want == 2)) ? 256 : 128;
-        if (want && a.korder < 2 && a.Cin % 64 == 0 && a.Cout_pad % 128 == 0 && (a.KH == 1 || a.KH == 3) &&
-            ((a.force_patch & 32) || (long long)(a.M / 256) * (a.Cout_pad / bn8) >= 256)) {
-            if (want == 7) return launch_conv<128, 128, 64, 2, 8>(a, s);
-            if (bn8 == 128) return launch_conv<256, 128, 64, 2, 8>(a, s);
-            // (the epilogue's transposition of a 256 x 256 tile needs 135 KB of LDS anyway: a FOUR-stage ring of 32-deep stages fits into the same
-            //  allocation and keeps three stages = 96 KB in flight instead of one = 64 KB -- Y7T_CONV_NW8=2)
-            if (want == 2 && a.Cout_pad % 256 == 0) return launch_conv<256, 256, 32, 4, 8>(a, s);
-            return launch_conv<256, 256, 64, 2, 8>(a, s);
-        }
     }
     const bool wide = a.Cout_pad % 128 == 0;
     const int var = conv_variant();
@@ -707,5 +604,4 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
     }
     }
-#endif
 }

@@ -659,13 +659,10 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
     // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
     if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;
-    const int abl = (a.force_patch & 64) ? 512 : a.ablate;      // (force_patch bit 6: the DMA-late order per call -- tests on the host simulator)
-    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && (!abl || abl == 512)) {
+    const int abl = a.ablate;      // (ABL = 512, the step's DMAs behind its MFMAs, was measured in round 3: 15.98 vs 16.02 ms for the list -- not instantiated any more)
+    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && !abl) {
         int rcf;
-        if (abl == 512) {
-            if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128, 512>(a, s) : launch_patch<0, 42, 64, 512>(a, s);
-            else rcf = wide ? launch_patch<0, 22, 128, 512>(a, s) : launch_patch<0, 22, 64, 512>(a, s);
-        } else if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
+        if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
         else rcf = wide ? launch_patch<0, 22, 128>(a, s) : launch_patch<0, 22, 64>(a, s);
         return rcf ? rcf : 1;
     }
@@ -673,7 +670,6 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     int rc;
     if (abl && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
         switch (abl) {
-        case 512: return launch_patch<16, 16, 64, 512>(a, s) ? -1 : 1;
         case 1: return launch_patch<16, 16, 64, 1>(a, s) ? -1 : 1;
         case 2: return launch_patch<16, 16, 64, 2>(a, s) ? -1 : 1;
         case 7: return launch_patch<16, 16, 64, 7>(a, s) ? -1 : 1;
@@ -684,7 +680,6 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     }
     if (abl && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
         switch (abl) {
-        case 512: return launch_patch<16, 16, 128, 512>(a, s) ? -1 : 1;
         case 1: return launch_patch<16, 16, 128, 1>(a, s) ? -1 : 1;
         case 2: return launch_patch<16, 16, 128, 2>(a, s) ? -1 : 1;
         case 3: return launch_patch<16, 16, 128, 3>(a, s) ? -1 : 1;

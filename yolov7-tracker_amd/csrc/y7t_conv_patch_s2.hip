@@ -292,9 +292,9 @@ int launch_s2_ord(const Y7TConvArgs& a, hipStream_t s) {
 
 template <int BN, int NW>
 int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
-    static int ord = -1;     // (force_patch bit 4 selects ORD = 1 per call: tests on the host simulator)
-    if (ord < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_ORDER"); ord = (e && atoi(e) == 1) ? 1 : 0; }
-    return (ord == 1 || (a.force_patch & 16)) ? launch_s2_ord<BN, NW, 1>(a, s) : launch_s2_ord<BN, NW, 0>(a, s);
+    // (ORD = 1 -- the step's DMAs behind its MFMAs -- and NW = 8 -- 512 threads, 16 x 16 output pixels, one workgroup per CU -- were measured in round 3:
+    //  within +-1 % resp. 3-20 % slower than this form, profiles/r03_conv_variants.txt; they are no longer instantiated)
+    return launch_s2_ord<BN, NW, 0>(a, s);
 }
 
 }   // namespace
@@ -314,8 +314,5 @@ int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_set_error("conv: weights are in the stride-2 patch kernel's panel order (korder 4) but the layer cannot run on it");
         return Y7T_E_ARG;
     }
-    static int nw = -1;      // (force_patch bit 3 selects the 8-wave form per call: tests on the host simulator)
-    if (nw < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_NW"); nw = (e && atoi(e) == 8) ? 8 : 4; }
-    if (nw == 8 || (a.force_patch & 8)) return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 8>(a, s) : launch_s2<128, 8>(a, s);
     return s2_bn(a.Cout_pad) == 256 ? launch_s2<256, 4>(a, s) : launch_s2<128, 4>(a, s);
 }

@@ -33,9 +33,6 @@ struct Y7TConvArgs {
     int xcd_swizzle, tile_order;
     int splitk, ksteps, allow_splitk;   // split-K: workgroups per output tile, K-steps per split
     float* partial;                     // fp32 slabs [splitk][M][Cout_pad]
-#ifdef Y7T_SPLITK_FIXUP
-    int* splitk_done;                   // per-tile arrival counters (inside the workspace)
-#endif
     float* splitk_ws;                   // caller's split-K workspace of Y7T_SPLITK_WS_BYTES (a detector owns one, so detectors on different streams
                                         // never share slabs), or null: one process-wide workspace (the single-layer entry point; one stream at a time)
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0); 2: LDS-patch panels; 3: 1x1 panels; 4: stride-2 LDS-patch panels

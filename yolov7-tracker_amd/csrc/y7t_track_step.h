@@ -185,17 +185,12 @@ struct Y7TBox4 { double v[4]; };
 // Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
 // connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
 // caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
-// Y7T_NEXT_TRACKER (experiment for the next round; the default build is unchanged by it): the row stride of the candidate lists is chosen at run time so that
-// the lists fit in the fast scratch next to the work arrays -- 24 entries per row keep a 500-object frame's lists (121 KB) in global memory, where every step
-// of the per-component solves is a dependent L2 round trip (964 of 2315 kcycles of the frame step); 16 per row (80 KB) fit in LDS and the largest row of that
-// scene has 9 candidates.  A row that overflows the shorter stride repeats the association with the full one.
+// The row stride MC of the candidate lists is chosen at run time (y7t_assoc_sparse_fn below) so that the lists fit in the fast scratch next to the work
+// arrays -- 24 entries per row keep a 500-object frame's lists (121 KB) in global memory, where every step of the per-component solves is a dependent L2
+// round trip; 16 per row (80 KB) fit in LDS and the largest row of that scene has 9 candidates.  A row that overflows the shorter stride repeats the
+// association with the full one.  (Round 3, measured: the 500-object frame step 932 -> 902 us, 80 objects unchanged; profiles/r03_tracker_phases.txt)
 template <class ColFn, class CostFn>
-#ifdef Y7T_NEXT_TRACKER
 Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost, const int MC) {
-#else
-Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
-    constexpr int MC = Y7T_MAXC;
-#endif
     const int tid = ex.tid, nt = ex.nt;
 #ifdef Y7T_ALWAYS_LITERAL
     return 2;
@@ -377,7 +372,6 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     return 1;
 }
 
-#ifdef Y7T_NEXT_TRACKER
 template <class ColFn, class CostFn>
 Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
     const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
@@ -393,7 +387,6 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     if (r == 0 && mc < Y7T_MAXC) { Y7T_NEXT_STAT(1); y7t_sync(ex); r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, cost, Y7T_MAXC); }
     return r;
 }
-#endif
 
 // the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
 Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {

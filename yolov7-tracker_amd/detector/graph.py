@@ -151,29 +151,32 @@ def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 2
     return max(eff(16, 16), eff(32, 8), eflat) >= 0.8
 
 
-def nw8_eligible(M, cin, cout, k):
-    """mirror of the 8-wave rule in conv_dispatch (csrc/y7t_conv.hip), OPT-IN with Y7T_CONV_NW8 = 1 / 2 / 6 / 7 in the environment: a layer of the generic kernel
-    with Cin % 64 == 0, Cout_pad % 128 == 0 and at least 256 tiles of 256 pixels x (256 | 128) channels.  (A disagreement with the C rule is harmless: a layer
-    lowered row-major that stays on four waves merely loses its weight panels.)"""
-    want = os.environ.get("Y7T_CONV_NW8", "0")
-    if want not in ("1", "2", "6", "7") or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32, M_out=1 << 30):
+    """mirror of y7t_conv_patch_s2_launch (csrc/y7t_conv_patch_s2.hip): the 3x3 / stride-2 down-sampling layers on the parity-split LDS-patch kernel.
+    Measured per layer at 32 frames (round 3, profiles/r03_conv_variants.txt): with 256-channel panels and Cin >= 128 it beats the generic kernel on the
+    320^2 / 160^2 / 80^2 inputs (672 -> 587, 598 -> 491, 415 -> 395, 188 -> 164 us); with 128-channel panels (Cout = 128, 384) and on the small maps
+    (fewer than ~50 000 output pixels per launch: 40^2 inputs, batch-1 latency mode) it loses -- those keep the generic kernel.
+    Y7T_CONV_PATCH_S2=0 switches it off; =1 takes every layer the kernel can run (the experiment's rule; Y7T_CONV_PATCH_S2_MIN_COUT, _BN as before)."""
+    mode = os.environ.get("Y7T_CONV_PATCH_S2", "auto")
+    if mode == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
     cout_pad = -(-cout // 64) * 64
-    bn8 = 256 if (cout_pad % 256 == 0 and want in ("1", "2")) else 128
-    return k in (1, 3) and cin % 64 == 0 and cout_pad % 128 == 0 and (M // 256) * (cout_pad // bn8) >= 256
+    can = (k == 3 and s == 2 and p == 1 and cin % 64 == 0 and cout_pad % 128 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0
+           and out_coff % 8 == 0)
+    if mode == "1":
+        return can and cout_pad >= int(os.environ.get("Y7T_CONV_PATCH_S2_MIN_COUT", "128"))
+    return can and cout_pad % 256 == 0 and cin >= 128 and M_out >= 50000 and os.environ.get("Y7T_CONV_PATCH_S2_BN", "") != "128"
 
 
-def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32):
-    """mirror of y7t_conv_patch_s2_launch (csrc/y7t_conv_patch_s2.hip), which is OPT-IN: only with Y7T_CONV_PATCH_S2=1 in the environment when the plan is
-    lowered (the kernel has not been measured on a GPU yet; the default launch list keeps the generic kernel for the down-sampling layers).
-    Y7T_CONV_PATCH_S2_MIN_COUT (default 128) restricts it to the wider layers (256: only those that get 256-channel panels)."""
-    if os.environ.get("Y7T_CONV_PATCH_S2", "0") != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
+    """mirror of y7t_conv_ws_launch (csrc/y7t_conv_ws.hip): the 64 -> 64 3x3 / stride 1 layers with the whole filter bank resident in registers and a
+    persistent workgroup per compute unit.  OPT-IN with Y7T_CONV_WS=1 in the environment when the plan is lowered until it has been measured; needs
+    enough 16 x 16 tiles to give every compute unit a few (below that -- batch-1 latency mode -- the launch keeps its current kernel)."""
+    if os.environ.get("Y7T_CONV_WS", "0") != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
-    cout_pad = -(-cout // 64) * 64
-    if cout_pad < int(os.environ.get("Y7T_CONV_PATCH_S2_MIN_COUT", "128")):
-        return False
-    return (k == 3 and s == 2 and p == 1 and cin % 64 == 0 and cout_pad % 128 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0
-            and out_coff % 8 == 0)
+    tiles = B * -(-H // 16) * -(-W // 16)
+    return (k == 3 and s == 1 and p == 1 and cin == 64 and cout == 64 and H % 16 == 0 and W % 16 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0
+            and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
 def lower(nodes, H, W, max_batch=1):
@@ -292,13 +295,12 @@ def lower(nodes, H, W, max_batch=1):
         op["Ho"], op["Wo"], op["Cout"], op["Cout_pad"] = n.h, n.w, cout, cout_pad
         op["KH"], op["KW"], op["stride"], op["pad"], op["K"], op["K_pad"], op["act"] = n.k, n.k, n.s, n.p, K, K_pad, act
         korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
-        if patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
+        if ws_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
+            korder = 5                               # weights-stationary kernel: the filter bank as MFMA A-fragments (weights.pack_ws)
+        elif patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
-        elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32):
-            korder = 4                               # opt-in experiment: stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
-        elif (n.k == 1 and nw8_eligible(max_batch * n.h * n.w, cin, cout, n.k) and level < 0 and
-              (getattr(src, "virt_up", None) is None or (src.virt_up[1] % 64 == 0 and src.virt_up[0].c % 64 == 0))):      # (upsample-on-read: 64-deep stages)
-            korder = 0                               # opt-in experiment: this 1x1 layer runs on the 8-wave 256-pixel tiles, which read row-major weights
+        elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch * n.h * n.w):
+            korder = 4                               # stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level

@@ -164,6 +164,16 @@ def panel_pack_s2(blk, cin_pad):
     return np.ascontiguousarray(a).reshape(cout_pad, K)
 
 
+def pack_ws(blk):
+    """[64][576] block of a 64 -> 64 3x3 layer with k = (kh*3 + kw)*64 + ci  ->  the register-fragment order of csrc/y7t_conv_ws.hip (korder 5): fragment
+    f = (tap * 4 + ks) * 2 + i is 1 KiB = 64 lanes x 8 halves, lane l holding W[i*32 + l % 32][tap][ks*16 + 8*(l // 32) .. +7] -- the A operand of
+    v_mfma_f32_32x32x16_f16 exactly as a lane keeps it, so that a wave loads a fragment with ONE 16-byte load per lane from consecutive addresses."""
+    assert blk.shape == (64, 576)
+    a = blk.reshape(2, 32, 9, 4, 2, 8)          # [i][l31][tap][ks][hi][8]
+    a = a.transpose(2, 3, 0, 4, 1, 5)           # [tap][ks][i][hi][l31][8]   (lane = hi * 32 + l31)
+    return np.ascontiguousarray(a).reshape(64, 576)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -185,6 +195,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = panel_pack_linear(blk)
         elif w.get("korder") == 4:
             blk = panel_pack_s2(blk, w["cin_pad"])
+        elif w.get("korder") == 5:
+            blk = pack_ws(blk)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
