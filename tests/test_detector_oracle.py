@@ -215,9 +215,9 @@ def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
     assert sum(int(op["korder"]) == 4 for op in wide.ops) == 7          # all but the 64 -> 128 layer at 640x640
 
 
-def test_weights_stationary_packing_and_opt_in_lowering(monkeypatch):
+def test_weights_stationary_packing_and_lowering(monkeypatch):
     """CPU: korder 5 = the 64 x 576 filter bank of a 64 -> 64 3x3 layer as MFMA A-fragments (csrc/y7t_conv_ws.hip): a permutation with the documented
-    index map; Y7T_CONV_WS=1 lowers exactly the seven 64 -> 64 layers on the 320^2 / 160^2 maps to it and nothing else changes"""
+    index map; the lowering sends exactly the seven 64 -> 64 layers on the 320^2 / 160^2 maps to it and nothing else changes"""
     from yolov7_tracker_amd.detector import arch, graph, weights
     blk = np.random.default_rng(0).permutation(64 * 576).astype(np.float64).reshape(64, 576)
     out = weights.pack_ws(blk).ravel()
@@ -226,9 +226,10 @@ def test_weights_stationary_packing_and_opt_in_lowering(monkeypatch):
         f = (tap * 4 + ks) * 2 + i
         assert np.array_equal(out[(f * 64 + lane) * 8:(f * 64 + lane) * 8 + 8], blk[i * 32 + lane % 32, tap * 64 + ks * 16 + 8 * (lane // 32):][:8])
     low = lambda: graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    monkeypatch.setenv("Y7T_CONV_WS", "0")
     base = low()
     assert not any(int(op["korder"]) == 5 for op in base.ops)
-    monkeypatch.setenv("Y7T_CONV_WS", "1")
+    monkeypatch.delenv("Y7T_CONV_WS")
     exp = low()
     took = [(int(op["H"]), int(op["Cin"]), int(op["Cout"])) for op in exp.ops if int(op["korder"]) == 5]
     assert took == [(320, 64, 64)] * 4 + [(160, 64, 64)] * 3

@@ -170,9 +170,10 @@ def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32, M_out=1 << 
 
 def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
     """mirror of y7t_conv_ws_launch (csrc/y7t_conv_ws.hip): the 64 -> 64 3x3 / stride 1 layers with the whole filter bank resident in registers and a
-    persistent workgroup per compute unit.  OPT-IN with Y7T_CONV_WS=1 in the environment when the plan is lowered until it has been measured; needs
-    enough 16 x 16 tiles to give every compute unit a few (below that -- batch-1 latency mode -- the launch keeps its current kernel)."""
-    if os.environ.get("Y7T_CONV_WS", "0") != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    persistent workgroup per compute unit.  Measured at 32 frames (round 3): 320^2 358 -> 312 us, 160^2 91 -> 78 us per layer against the multi-tile patch
+    kernel (Y7T_CONV_WS=0 switches back); needs enough 16 x 16 tiles to give every compute unit a few (below that -- batch-1 latency mode -- the launch
+    keeps its current kernel)."""
+    if os.environ.get("Y7T_CONV_WS", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
     tiles = B * -(-H // 16) * -(-W // 16)
     return (k == 3 and s == 1 and p == 1 and cin == 64 and cout == 64 and H % 16 == 0 and W % 16 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0
