@@ -218,13 +218,6 @@ int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg,
 int y7t_det_stem_fusable(const y7t_det* det);
 int y7t_det_forward_stem_u8(y7t_det* det, const void* frames_u8, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream);
 
-/* The first THREE convolutions of YOLOv7-w6 as one kernel (cfg/deploy/yolov7-w6.yaml:16-21: ReOrg, Conv 12->64 3x3, Conv 64->128 3x3/2, and the two 1x1
- * branches of the first ELAN block as one 128->128 conv; y7t_det_stem_block_fusable): uint8 BGR frames of the network's geometry in, the twin's output
- * slice out; the 64-channel 640^2 and 128-channel 320^2 tensors in between are never written.  wfrag: the two inner filter banks as MFMA A-fragments
- * (detector/weights.py::pack_stem_block; device pointer).  Continue with y7t_det_forward_ops / y7t_det_forward_fused from op 3. */
-int y7t_det_stem_block_fusable(const y7t_det* det);
-int y7t_det_forward_stem_block_u8(y7t_det* det, const void* frames_u8, int B, int H0, int W0, const void* wfrag_f16, y7t_stream stream);
-
 /* TrackerLoader._letterbox (tracker/tracker_dataloader.py:100-130) fused with the layout above, for raw (B,H0,W0,3) uint8 BGR
  * frames: bilinear resize (cv2.INTER_LINEAR geometry: half-pixel centres; float arithmetic, rounded to uint8) to new_w x new_h,
  * placed at (top, left) of the H x W letterboxed image, pad colour 114.  The host computes new_h/new_w/top/left exactly like

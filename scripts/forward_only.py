@@ -40,10 +40,4 @@ for oi, op in enumerate(p.ops):
         out_elems = int(op["Ho"]) * int(op["Wo"]) * int(op["Cout"]) if int(op["detect_level"]) < 0 else 0
         d["bytes"] = (cin_bytes + out_elems) * 2 * B + int(op["Cout_pad"]) * int(op["K_pad"]) * 2
     ops.append(d)
-if names[0].startswith("stem_block"):      # ops 0..2 are one dispatch: its algorithmic work = the three convs', its bytes = the frame in + the twin's output out + the filters
-    ops[0]["gflop"] = sum(o["gflop"] for o in ops[:3])
-    ops[0]["bytes"] = 3 * 1280 * 1280 * B + int(p.ops[2]["Ho"]) * int(p.ops[2]["Wo"]) * int(p.ops[2]["Cout"]) * 2 * B + sum(int(o["Cout_pad"]) * int(o["K_pad"]) * 2 for o in p.ops[:3])
-    ops[0]["Cout"], ops[0]["s"] = int(p.ops[2]["Cout"]), 4
-    for o in ops[1:3]:
-        o["skip"] = True
 print(json.dumps({"B": B, "forwards": N, "weights": WEIGHTS, "launch_list_sha": LL_SHA, "ops": ops}))

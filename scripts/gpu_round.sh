@@ -12,7 +12,6 @@
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
 #   profile         rocprofv3 kernel stats of the bench command, per-op table of the launch list, HBM traffic (2 PMC passes), MFMA busy -> stamped JSONs
-#   exp_sb          fused stem block (opt-in Y7T_STEM_BLOCK=1): parity vs the three launches, pinned list, bench A/B, kernel time
 #   exp_ws          weights-stationary 64 -> 64 kernel (default; Y7T_CONV_WS=0 = the patch kernels): layer parity, parity inside the pinned list, per-layer timing, bench line
 #   (round 3's first call also had exp_s2 / exp_nw8 / exp_late / exp_fixup / exp_next -- the kernels prepared at the end of round 2; their results are in
 #    profiles/r03_conv_variants.txt and the losing variants are no longer in the source)
@@ -109,22 +108,6 @@ exp_ws)
   timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_ws.json 2> $O/bench_ws.err
   Y7T_CONV_WS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nows.json 2> $O/bench_nows.err
   benchsum ws nows
-  ;;
-
-exp_sb)
-  say "exp_sb a: fused stem block (csrc/y7t_stem_block.hip): vs the three launches, then inside the benchmarked list (teacher-forced, chain check on op 2)"
-  timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k stem_block > $O/t_sb.log 2>&1; echo "rc=$?" >> $O/t_sb.log; tailsum $O/t_sb.log
-  Y7T_STEM_BLOCK=1 timeout 400 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list or candidates" > $O/t_sb_pinned.log 2>&1; echo "rc=$?" >> $O/t_sb_pinned.log; tailsum $O/t_sb_pinned.log
-  say "exp_sb b: bench line with it on / off (one session)"
-  Y7T_STEM_BLOCK=1 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_sb.json 2> $O/bench_sb.err
-  timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nosb.json 2> $O/bench_nosb.err
-  benchsum sb nosb
-  grep -v amdgpu.ids $O/bench_sb.err | tail -3
-  say "exp_sb c: kernel times (rocprofv3 --kernel-trace --stats of 3 forwards)"
-  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/sbk
-    Y7T_STEM_BLOCK=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sbk -- python $ROOT/scripts/forward_only.py 3 > $O/sb_forward.log 2>&1
-    f=$(find /tmp/sbk -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/sb_kernel_stats.csv )
-  head -8 $O/sb_kernel_stats.csv | cut -c1-150 | tee -a $O/summary.txt
   ;;
 
 pmc_queues)

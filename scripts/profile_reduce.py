@@ -64,8 +64,6 @@ try:
     it = iter(zip(last, dur))
     lines, tot_us, tot_gf = [], 0.0, 0.0
     for op in meta["ops"]:
-        if op.get("skip"):      # fused into the previous dispatch
-            continue
         r, d = next(it)
         if "splitK" in op["kernel"]:
             r2, d2 = next(it); d += d2

@@ -17,7 +17,7 @@ def build(defs=()):
     tag = "".join(c for c in "".join(defs) if c.isalnum()) or "default"
     bdir = os.path.join(_HERE, "build_" + tag)
     so = os.path.join(bdir, "libconvsim.so")
-    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip", "y7t_conv_ws.hip", "y7t_stem_block.hip")]
+    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip", "y7t_conv_ws.hip")]
     deps = srcs + [os.path.join(_HERE, "runtime.inc"), os.path.join(_HERE, "fake", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
     if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
@@ -47,14 +47,9 @@ def build(defs=()):
     ws, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", ws)
     assert n == 1
     open(os.path.join(bdir, "convsim_ws.cpp"), "w").write(ws)
-    sb = open(srcs[7]).read()                                                   # the fused stem block (no inline asm)
-    assert "asm" not in sb
-    sb, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", sb)
-    assert n == 1
-    open(os.path.join(bdir, "convsim_stem_block.cpp"), "w").write(sb)
     cmd = [_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-I", os.path.join(_HERE, "fake"), "-I", _CSRC,
            "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp"), os.path.join(bdir, "convsim_patch.cpp"),
-                                                                          os.path.join(bdir, "convsim_patch_s2.cpp"), os.path.join(bdir, "convsim_ws.cpp"), os.path.join(bdir, "convsim_stem_block.cpp")]
+                                                                          os.path.join(bdir, "convsim_patch_s2.cpp"), os.path.join(bdir, "convsim_ws.cpp")]
     subprocess.check_call(cmd)
     return so
 
@@ -68,6 +63,5 @@ def lib(defs=()):
         L.cs_conv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_int] * 11
         L.cs_conv_dual.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
-        L.cs_stem_block.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5
         _libs[key] = L
     return _libs[key]

@@ -236,45 +236,3 @@ def test_weights_stationary_fragment_reads_are_bank_conflict_free():
                 for ks in range(4):
                     addr = [((l >> 4) * RP + (l & 15) * PIXB + hi * 16 + kw * PIXB + ks * 32) for l in g]
                     assert len({(a // 16) % 16 for a in addr}) == 16
-
-
-# the fused stem block (csrc/y7t_stem_block.hip): uint8 frame -> stem 12->64 3x3 -> 64->128 3x3/2 -> twin 1x1 128->128, one kernel.  B, H0, W0, acts, output slice.
-# (the fake device has 3 compute units: a workgroup walks several 8 x 16 tiles; 48 x 80 -> 12 x 20 map = 2 x 2 ragged tiles; 64 x 128 -> whole tiles)
-SB_CASES = [(1, 32, 64, (1, 1, 1), {}), (1, 48, 80, (1, 1, 1), {"out_ld": 256, "out_coff": 64}), (2, 64, 128, (2, 1, 0), {}), (5, 36, 68, (1, 1, 1), {})]
-
-
-@pytest.mark.parametrize("case", SB_CASES, ids=lambda c: "%dx%dx%d" % c[:3])
-def test_stem_block_kernel_source_on_the_host(case):
-    """against the three layers one after the other in torch, every intermediate rounded to fp16 like the kernel's LDS tiles: BGR -> RGB, /255, ReOrg
-    (models/common.py:48-53), Conv + bias + act three times.  Zero padding of BOTH 3x3 convs at the image border, ragged tiles, batch, output slices."""
-    from yolov7_tracker_amd.detector import weights
-    B, H0, W0, acts, kw = case
-    out_ld, out_coff = kw.get("out_ld", 128), kw.get("out_coff", 0)
-    rng = np.random.default_rng(B * 100 + H0 + W0)
-    frames = rng.integers(0, 256, (B, H0, W0, 3), dtype=np.uint8)
-    Wt0 = (rng.normal(0, 1, (64, 12, 3, 3)) / np.sqrt(108)).astype(np.float16)
-    Wt1 = (rng.normal(0, 1, (128, 64, 3, 3)) / np.sqrt(576)).astype(np.float16)
-    Wt2 = (rng.normal(0, 1, (128, 128, 1, 1)) / np.sqrt(128)).astype(np.float16)
-    b0, b1, b2 = (rng.normal(0, 0.3, n).astype(np.float32) for n in (64, 128, 128))
-    w0p = pack_w(Wt0.astype(np.float32), 16, 64, 0)                                   # the plan's op-0 layout: [64][K_pad], k = tap * 16 + ci
-    wfrag = weights.pack_stem_block(Wt1.astype(np.float64), Wt2.astype(np.float64))
-    Ho, Wo = H0 // 4, W0 // 4
-    out = np.full((B, Ho, Wo, out_ld), 7.0, np.float16)
-    L = cs.lib()
-    rc = L.cs_stem_block(frames.ctypes.data, B, H0, W0, w0p.ctypes.data, w0p.shape[1], wfrag.ctypes.data, b0.ctypes.data, b1.ctypes.data, b2.ctypes.data, out.ctypes.data,
-                         out_ld, out_coff, *acts)
-    assert rc == 0, L.cs_last_error().decode()
-    assert L.cs_last_kernel().decode() == "stem_block_u8<8,16>"
-    F = torch.nn.functional
-    act = lambda y, a: y * torch.sigmoid(y) if a == 1 else torch.where(y > 0, y, 0.1 * y) if a == 2 else y
-    img = (torch.from_numpy(frames[..., ::-1].copy()).permute(0, 3, 1, 2).float() * np.float32(0.00392156862745098)).half().float()
-    x = torch.cat([img[..., ::2, ::2], img[..., 1::2, ::2], img[..., ::2, 1::2], img[..., 1::2, 1::2]], 1)
-    y0 = act(F.conv2d(x, torch.from_numpy(Wt0.astype(np.float32)), torch.from_numpy(b0), 1, 1), acts[0]).half().float()
-    y1 = act(F.conv2d(y0, torch.from_numpy(Wt1.astype(np.float32)), torch.from_numpy(b1), 2, 1), acts[1]).half().float()
-    ref = act(F.conv2d(y1, torch.from_numpy(Wt2.astype(np.float32)), torch.from_numpy(b2)), acts[2]).permute(0, 2, 3, 1).numpy()
-    got = out[..., out_coff:out_coff + 128].astype(np.float32)
-    # (an intermediate that lands on the other fp16 neighbour -- summation order -- moves an output by ~1e-3 of one of its 128 / 576 terms)
-    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3)
-    other = np.ones(out_ld, bool)
-    other[out_coff:out_coff + 128] = False
-    assert np.all(out[..., other] == 7.0)

@@ -428,32 +428,3 @@ def test_attempt_load_state_dict_checkpoint(tmp_path):
         attempt_load(str(tmp_path / "bare.pt"), img_size=128)          # a bare state dict needs the architecture
     with pytest.raises(FileNotFoundError):
         attempt_load(str(tmp_path / "missing.pt"), cfg="yolov7-tiny")
-
-
-def test_stem_block_equals_the_three_launches(monkeypatch):
-    """csrc/y7t_stem_block.hip: uint8 frame -> stem -> 3x3/2 64->128 -> twin 1x1 as ONE kernel (the 64-channel and 128-channel tensors in between stay in LDS)
-    against the same three ops as three launches, on the tensor both write (the twin's output slice of the ELAN concat buffer) and on the heads.  Both keep
-    fp16 intermediates; the accumulation order differs, so single values land on the other fp16 neighbour."""
-    g = torch.Generator().manual_seed(31)
-    frames = torch.randint(0, 256, (4, 256, 384, 3), dtype=torch.uint8, generator=g)
-    ref = build("yolov7-w6", 10, (256, 384), 4)
-    assert not ref.plan.stem_block
-    h_ref = [t.clone() for t in ref(frames.cuda())[0].raw()]
-    op2 = ref.plan.ops[2]
-    view = lambda d: d.buffer_view(int(op2["out_buf"]), 4, int(op2["out_ld"])).view(4, int(op2["Ho"]), int(op2["Wo"]), -1)[..., int(op2["out_coff"]):int(op2["out_coff"]) + 128].float().clone()
-    t_ref = view(ref)
-    monkeypatch.setenv("Y7T_STEM_BLOCK", "1")
-    monkeypatch.setenv("Y7T_STEM_BLOCK_MIN_TILES", "1")
-    det = build("yolov7-w6", 10, (256, 384), 4)
-    assert det.plan.stem_block
-    h = det(frames.cuda())[0].raw()
-    assert det.launch_list(4)[:3] == ["stem_block_u8<8,16>", "fused:stem_block", "fused:stem_block"]
-    h = [t.clone() for t in det(frames.cuda())[0].raw()]
-    t = view(det)
-    err = (t - t_ref).abs()
-    assert float(t_ref.abs().max()) > 0.5 and float(err.max()) <= 4e-3 + 4e-3 * float(t_ref.abs().max()) and float((err > 1e-3 + 1e-3 * t_ref.abs()).float().mean()) < 0.02
-    for a, b in zip(h, h_ref):
-        assert (a - b).abs().mean().item() < 0.02 * b.std().item()       # (a chaotic random network amplifies the one-ulp flips; the pinned test has the tight bound)
-    # float32 input still takes the three launches (the fused kernel reads uint8 frames)
-    x = torch.rand((4, 3, 256, 384), generator=g)
-    assert all(torch.equal(a, b) for a, b in zip(det(x)[0].raw(), ref(x)[0].raw()))

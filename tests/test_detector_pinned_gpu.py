@@ -88,7 +88,7 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     assert any(n.startswith("igemm<256,") for n in names) or os.environ.get("Y7T_CONV_PATCH_S2") == "1", hist     # 256-pixel tiles (the 640^2 stride-2 layer)
     if os.environ.get("Y7T_CONV_WS", "1") != "0":                        # the 64 -> 64 layers with the filter bank in registers
         assert fam["ws64"] == 7 and fam["patch_mt"] == 0, fam
-    assert names[0] == ("stem_block_u8<8,16>" if os.environ.get("Y7T_STEM_BLOCK", "0") == "1" else "stem_u8<direct>"), names[0]      # uint8 frame -> stem conv (-> 3x3/2 -> twin 1x1) in one kernel
+    assert names[0] == "stem_u8<direct>", names[0]                       # uint8 frame -> stem conv in one kernel
     assert any(n.startswith("igemm<128,128,32,2> 1x1") for n in names), hist
     assert sum("upsample-on-read" in n for n in names) == 3 and "upsample2x" not in names, hist
     det(torch.from_numpy(bench_det[1]).cuda())       # launch_list re-ran the ops in place; leave the arena as a clean forward
@@ -115,18 +115,9 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
     torch.cuda.synchronize()
     worst = collections.defaultdict(float)
     n_conv = n_other = n_up = 0
-    fused_block = names[0].startswith("stem_block")      # ops 0..2 are one kernel: the stem's and the stride-2 conv's outputs do not exist
     for oi, op in enumerate(p.ops):
         H, W, Cin = int(op["H"]), int(op["W"]), int(op["Cin"])
-        if fused_block and oi < 2:
-            assert int(op["type"]) == 0 and names[1] == names[2] == "fused:stem_block"
-            ci += 1
-            continue
-        if fused_block and oi == 2:      # no teacher forcing inside the fused kernel: the oracle's own chain from the frame, fp16 after every layer like its LDS tiles
-            w0, w1 = p.wlayout[0], p.wlayout[1]
-            y0 = dt._conv_bn_act(re16[:, :12], sd, w0["wkey"], 3, 1, 1, w0["act"], fp16=True)
-            x = dt._conv_bn_act(y0, sd, w1["wkey"], 3, 2, 1, w1["act"], fp16=True)
-        elif oi == 0 and int(op["in_buf"]) == 0:
+        if oi == 0 and int(op["in_buf"]) == 0:
             x = re16.clone()                                        # op 0 reads the frame: BGR -> RGB, /255, ReOrg, fp16 (whether or not that tensor exists in HBM)
         else:
             x = _slice(det, int(op["in_buf"]), int(op["in_ld"]), int(op["in_coff"]), Cin, H, W, fr).float().cpu().permute(0, 3, 1, 2).contiguous()
@@ -153,8 +144,6 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             ref, absum = ref.permute(0, 2, 3, 1), absum.permute(0, 2, 3, 1)
             err = (got - ref).abs()
             tol = 3e-4 + 6e-4 * ref.abs() + 2 * float(Cin * k * k) ** 0.5 * 2.0 ** -24 * absum      # |SiLU'| <= 1.1: the pre-activation bound carries over
-            if fused_block and oi == 2:      # + intermediates that land on the other fp16 neighbour (summation order): 2^-11 of a few of the sum's terms
-                tol = tol + 2.0 ** -10 * absum / float(Cin) ** 0.5 + 1e-3
             bad = err > tol
             if bool(bad.any()):
                 w_ = int(torch.argmax((err / tol).flatten()))
@@ -171,7 +160,7 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             got = _slice(det, int(op["out_buf"]), int(op["out_ld"]), int(op["out_coff"]), Cin, ref.shape[2], ref.shape[3], fr).float().cpu()
             assert torch.equal(got, ref.permute(0, 2, 3, 1)), "op %d %s" % (oi, names[oi])
             n_other += 1
-    assert ci == len(p.wlayout) and n_conv >= 94 and n_other + n_up >= 6 and n_up == 3      # w6: all three upsamples are read through
+    assert ci == len(p.wlayout) and n_conv >= 96 and n_other + n_up >= 6 and n_up == 3      # w6: all three upsamples are read through
     print("per-op worst err / tol by kernel:", {k: "%.2e" % v for k, v in sorted(worst.items())})
 
 

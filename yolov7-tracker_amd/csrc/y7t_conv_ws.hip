@@ -6,19 +6,20 @@
 // streams a weight panel through the vector-memory path (36 of the 63 buffer->LDS pieces of a tile carry WEIGHTS that are the same for every tile),
 // takes a workgroup barrier every 8 MFMAs per wave, and reads one LDS fragment per MFMA.
 //
-// Here the whole filter bank of the layer -- 64 x 576 fp16 = 72 KiB, as MFMA A-fragments: 288 VGPRs per lane -- is loaded ONCE per workgroup into the
-// registers of each of its four waves (gfx950: 512 unified VGPR/AGPR per lane at one wave per SIMD), and a persistent workgroup per CU walks a
-// contiguous range of 16 x 16-pixel tiles:
+// Here the filter bank of the layer -- 64 x 576 fp16 = 72 KiB as MFMA A-fragments -- is loaded ONCE per workgroup into registers: each of the four waves
+// keeps the 36 fragments of its 32 output channels (144 VGPRs per lane; gfx950 has 512 unified VGPR/AGPR per lane at one wave per SIMD), and a persistent
+// workgroup per CU walks a contiguous range of 16 x 16-pixel tiles:
 //   * vector-memory traffic per tile = the input patch only: 18 x 18 pixels x 64 channels, every pixel one full 128-byte line (50 pieces instead of
 //     63 half-line pieces + 36 weight pieces);
 //   * the patch sits in a THREE-buffer LDS ring (3 x 50 KiB): while tile T is multiplied, tile T+1 has landed or is landing and tile T+2 is being
 //     requested -- up to 100 KiB in flight per CU, which is what keeping HBM busy at ~1 us of loaded latency takes;
 //   * ONE workgroup barrier per tile (144 MFMAs per wave) instead of one per 8;
-//   * 0.5 ds_read_b128 per MFMA (pixel fragments only), every address = lane base + immediate (144-byte pixel pitch: 9 sixteen-byte slots, 8 data +
+//   * one ds_read_b128 per MFMA (pixel fragments only), every address = lane base + immediate (144-byte pixel pitch: 9 sixteen-byte slots, 8 data +
 //     1 pad; 36 x mod 64 is a bijection over the 16 lanes of a service group, the row pitch is a multiple of 256 B so the two image rows of an MFMA
 //     tile interleave -- conflict-free);
-//   * epilogue straight from registers (bias + activation + permlane32_swap -> 16-byte NHWC stores); maps of whole tiles only, so that every store
-//     is issued and `s_waitcnt vmcnt` can count them next to the pieces.
+//   * epilogue straight from registers (bias + activation + permlane32_swap -> 16-byte NHWC stores), of the PREVIOUS tile, interleaved with this tile's
+//     MFMAs (two accumulator sets: with one wave per SIMD nothing else would cover it); maps of whole tiles only, so that every store is issued and
+//     `s_waitcnt vmcnt` can count them next to the pieces.
 // Weight layout (korder 5, detector/weights.py::pack_ws): fragment f = (tap * 4 + ks) * 2 + i is 1 KiB, lane l holds W[i*32 + l%32][tap][ks*16 + 8*(l/32) .. +7].
 #include "y7t_common.h"
 #include "y7t_conv_common.h"
@@ -39,9 +40,9 @@ struct WsCfg {
     static constexpr int BIAS_OFF = NBUF * PATCH_BYTES;
     static constexpr int LDS = BIAS_OFF + 64 * 4;
     static constexpr int NSUB = 36;                                   // k16 substeps per tile: 9 taps x 4
-    static constexpr int NFRAG = NSUB * 2;                            // A fragments (two 32-channel halves per substep)
 };
 
+template <int ACT>      // the activation is a template parameter: the epilogue is instantiated eight times inside each of the two tile bodies
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = WsCfg;
@@ -89,15 +90,19 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + buf * C::PATCH_BYTES + I * 1024), 16, piece_src(ta, i), 0, 0, 0);
     };
 
-    // ---- the filter bank: 72 A-fragments per lane, straight from memory (each fragment is 1 KiB of consecutive bytes), resident for the whole launch ----
-    half8 wreg[C::NFRAG];
+    // ---- the filter bank.  Wave w owns output channels 32 (w & 1) .. +31 of the 128 pixels of tile half (w >> 1): 36 A-fragments per lane (144 VGPRs), straight
+    // from memory (a fragment is 1 KiB of consecutive bytes), resident for the whole launch.  (A first version gave each wave all 64 channels of 64 pixels --
+    // 288 VGPRs of weights, no room for a second accumulator set: its epilogue, ~3 000 cycles of bias + SiLU + pack per tile, ran with the matrix pipe idle,
+    // 312 us per 320^2 layer against 358 us for the multi-tile patch kernel.  Here the previous tile's epilogue is interleaved with this tile's MFMAs.) ----
+    const int chh = wave & 1, pxh = wave >> 1;
+    half8 wreg[C::NSUB];
     {
-        const half8* wp = (const half8*)p.w + lane;
+        const half8* wp = (const half8*)p.w + chh * 64 + lane;
 #pragma unroll
-        for (int f = 0; f < C::NFRAG; ++f) wreg[f] = wp[f * 64];
+        for (int f = 0; f < C::NSUB; ++f) wreg[f] = wp[f * 128];
     }
     if (tid < 64) ((float*)(smem + C::BIAS_OFF))[tid] = p.bias[tid];
-    const float* lbias = (const float*)(smem + C::BIAS_OFF);
+    const float* lbias = (const float*)(smem + C::BIAS_OFF) + chh * 32;
 
     {
         const TileAt t0 = tile_at(pt_first), t1 = tile_at(pt_first + 1);
@@ -107,96 +112,94 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         for (int i = 0; i < NPW; ++i) issue_piece(1, t1, i);
     }
 
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fragment base of this lane inside a patch buffer: wave w owns image rows 4w .. 4w+3 of the tile (two 32-pixel MFMA tiles of two rows each)
-    const int plane_off = (wave * 4 + (l31 >> 4)) * RP + (l31 & 15) * PIXB + hi32 * 16;
+    // fragment base of this lane inside a patch buffer: four 32-pixel MFMA tiles of two image rows each, rows 8 pxh + 2j, + 1
+    const int plane_off = (pxh * 8 + (l31 >> 4)) * RP + (l31 & 15) * PIXB + hi32 * 16;
     half_t* outp = (half_t*)p.out;
     typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-    constexpr int NST = 8;                   // 16-byte stores per lane and tile (2 MFMA tiles x 2 channel halves x 2 group pairs): every one is issued,
-                                             // for every tile (the launcher admits maps of whole 16 x 16 tiles only), so that `s_waitcnt vmcnt` can COUNT
-    int buf = 0;                             // ring position of the tile being multiplied
-    for (int t = 0; t < nt; ++t) {
-        // Pieces of tile t landed (this wave's): younger than them are exactly tile t+1's NPW pieces and -- from the second tile on -- the previous
-        // tile's NST stores.  Then everybody's: one barrier per tile; behind it nobody reads the buffer of tile t-1 any more, it takes tile t+2.
-        if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
-        __builtin_amdgcn_s_barrier();
+    typedef __attribute__((ext_vector_type(4))) float float4v;
+    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+    constexpr int NST = 8;                   // 16-byte stores per lane and tile (4 MFMA tiles x 2 group pairs): every one is issued, for every tile (the launcher
+                                             // admits maps of whole 16 x 16 tiles only), so that `s_waitcnt vmcnt` can COUNT them next to the pieces
+
+    // one eighth of a finished tile: group pair gp of MFMA tile j -> bias + activation -> 8 channels of one pixel -> one 16-byte NHWC store
+    auto store_group = [&](const floatx16 (&a)[4], int pt, int j, int gp) __attribute__((always_inline)) {
+        int q = pt;
+        const int txi = q % tiles_x; q /= tiles_x;
+        const int tyi = q % tiles_y, b = q / tiles_y;
+        const int gy = tyi * TH + pxh * 8 + 2 * j + (l31 >> 4), gx = txi * TW + (l31 & 15);
+        half_t* orow = outp + ((size_t)((b * p.H + gy) * p.W + gx)) * p.ldout + p.cout_off + chh * 32;
+        unsigned w[2][2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g = gp * 2 + gg;
+            const float4v bv = *(const float4v*)(lbias + 8 * g + 4 * hi32);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(a[j][g * 4 + e] + bv[e]);
+            half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
+            w[gg][0] = __builtin_bit_cast(unsigned, h0v);
+            w[gg][1] = __builtin_bit_cast(unsigned, h1v);
+        }
+        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        const uint4v v4 = {r0[0], r1[0], r0[1], r1[1]};
+        *(uint4v*)(orow + 8 * (gp * 2 + hi32)) = v4;
+    };
+
+    // One tile: its 144 MFMAs into `cur`, the PREVIOUS tile's eight store groups (out of `prev`) spread between them, tile t+2's pieces spread between them.
+    // vmcnt at the top: younger than this wave's pieces of tile t are exactly what tile t-1 issued: NPW pieces (tile t+1's) and, if tile t-1 had a
+    // predecessor to store, NST stores.
+    auto tile_body = [&](int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
+        if (t >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
-        const TileAt tn = tile_at(pt_first + t + 2);      // (once per tile: the decode is a few dozen scalar operations)
+        const TileAt tn = tile_at(pt_first + t + 2);
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
-        half8 xf[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xf[0][j] = *(const half8*)(pb + j * 2 * RP);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
+            for (int e = 0; e < 16; ++e) cur[j][e] = 0.f;
+        half8 xf[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[0][j] = *(const half8*)(pb + j * 2 * RP);
+#pragma clang loop unroll(full)
         for (int s = 0; s < C::NSUB; ++s) {
-            const int cur = s & 1;
+            const int cb = s & 1;
             if (s + 1 < C::NSUB) {           // fragments of the next substep: tap (kh, kw), 16-channel group ks
                 const int sn = s + 1, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xf[cur ^ 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
+                for (int j = 0; j < 4; ++j) xf[cb ^ 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s * 2 + i], xf[cur][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf[cb][j], cur[j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            // tile t+2's pieces, spread over the tile: one every third substep (12) + the last one
-            if (s % 3 == 0 && s / 3 < NPW) issue_piece(nbuf, tn, s / 3);
+            if (s % 3 == 0 && s / 3 < NPW) issue_piece(nbuf, tn, s / 3);      // tile t+2's pieces: one every third substep (12) + the last one
             if (s == C::NSUB - 2 && NPW > 12) issue_piece(nbuf, tn, 12);
+            if (t > 0 && s % 4 == 1 && s / 4 < NST) store_group(prev, pt_first + t - 1, (s / 4) >> 1, (s / 4) & 1);      // substeps 1, 5, ..., 29
         }
-        // ---- tile done: bias + activation, 16-byte NHWC pieces straight from the registers ----
-        {
-            int q = pt_first + t;
-            const int txi = q % tiles_x; q /= tiles_x;
-            const int tyi = q % tiles_y, b = q / tiles_y, h0 = tyi * TH, w0 = txi * TW;
-            act_dispatch(p.act, [&](auto act_c) {
-            constexpr int ACT = decltype(act_c)::value;
-            typedef __attribute__((ext_vector_type(4))) float float4v;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pix = (wave * 2 + j) * 32 + l31;
-                const int r = pix / TW, x = pix - r * TW;
-                half_t* orow = outp + ((size_t)((b * p.H + h0 + r) * p.W + w0 + x)) * p.ldout + p.cout_off;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        unsigned w[2][2];
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const int g = gp * 2 + gg;
-                            const int nl = i * 32 + 8 * g + 4 * hi32;
-                            float v[4];
-                            const float4v bv = *(const float4v*)(lbias + nl);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bv[e]);
-                            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                            half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
-                            w[gg][0] = __builtin_bit_cast(unsigned, h0v);
-                            w[gg][1] = __builtin_bit_cast(unsigned, h1v);
-                        }
-                        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                        const uint4v v4 = {r0[0], r1[0], r0[1], r1[1]};
-                        *(uint4v*)(orow + i * 32 + 8 * (gp * 2 + hi32)) = v4;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                }
-            }
-            });
-        }
+    };
+
+    floatx16 accA[4], accB[4];
+    int buf = 0;
+    for (int t = 0; t < nt; t += 2) {
+        tile_body(t, buf, accA, accB);
         buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
+        if (t + 1 < nt) {
+            tile_body(t + 1, buf, accB, accA);
+            buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's zero-filling pieces have landed before this workgroup's LDS is handed on
+    // the last tile's results (its stores overlap nothing)
+    if (nt & 1) {
+#pragma unroll
+        for (int g8 = 0; g8 < NST; ++g8) store_group(accA, pt_first + nt - 1, g8 >> 1, g8 & 1);
+    } else {
+#pragma unroll
+        for (int g8 = 0; g8 < NST; ++g8) store_group(accB, pt_first + nt - 1, g8 >> 1, g8 & 1);
+    }
 #endif
 }
 
@@ -214,7 +217,9 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     static int ncu = -1;      // one persistent workgroup per compute unit (150 KiB of LDS each)
@@ -226,7 +231,9 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    hipLaunchKernelGGL(k_conv3x3_c64_ws, dim3(grid), dim3(256), C::LDS, s, a);
+    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_SILU>, dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_NONE>, dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("ws64<16,16>");
     return 0;

@@ -138,38 +138,6 @@ extern "C" int y7t_det_forward_stem_u8(y7t_det* d, const void* frames_u8, int B,
                               (_Float16*)(d->arena + d->bufs[op.out_buf]), op.out_ld, op.out_coff, op.act, (hipStream_t)stream);
 }
 
-// ---- ops 0..2 as one kernel (csrc/y7t_stem_block.hip): ReOrg + stem, the 3x3 / stride-2 64 -> 128 conv behind it, and the twin 1x1 128 -> 128 behind that ----
-int y7t_stem_block_u8_launch(const void* frames_u8, int B, int H0, int W0, const _Float16* w0, int K0_pad, const _Float16* wfrag, const float* b0, const float* b1,
-                             const float* b2, _Float16* out, int ldout, int cout_off, int act0, int act1, int act2, hipStream_t s);
-
-static bool stem_block_fusable(const y7t_det* d) {
-    if (!stem_fusable(d) || d->ops.size() < 3) return false;
-    const y7t_op &o0 = d->ops[0], &o1 = d->ops[1], &o2 = d->ops[2];
-    const bool chain1 = o1.type == Y7T_OP_CONV && o1.in_buf == o0.out_buf && o1.in_coff == o0.out_coff && o1.in_ld == o0.out_ld && o1.Cin == 64 && o1.KH == 3 &&
-                        o1.KW == 3 && o1.stride == 2 && o1.pad == 1 && o1.Cout == 128 && !o1.out_f32 && o1.up_C == 0 && o1.detect_level < 0 && o1.H == o0.Ho &&
-                        o1.W == o0.Wo;
-    const bool chain2 = o2.type == Y7T_OP_CONV && o2.in_buf == o1.out_buf && o2.in_coff == o1.out_coff && o2.in_ld == o1.out_ld && o2.Cin == 128 && o2.KH == 1 &&
-                        o2.KW == 1 && o2.stride == 1 && o2.pad == 0 && o2.Cout == 128 && !o2.out_f32 && o2.up_C == 0 && o2.detect_level < 0 &&
-                        o2.out_ld % 8 == 0 && o2.out_coff % 8 == 0 && o2.H == o1.Ho && o2.W == o1.Wo;
-    if (!chain1 || !chain2) return false;
-    for (size_t k = 3; k < d->ops.size(); ++k)      // nobody else reads the two tensors that will not exist
-        if (d->ops[k].in_buf == o0.out_buf || d->ops[k].in_buf == o1.out_buf || (d->ops[k].up_C > 0 && (d->ops[k].up_buf == o0.out_buf || d->ops[k].up_buf == o1.out_buf)))
-            return false;
-    return true;
-}
-
-extern "C" int y7t_det_stem_block_fusable(const y7t_det* d) { return d && stem_block_fusable(d) ? 1 : 0; }
-
-extern "C" int y7t_det_forward_stem_block_u8(y7t_det* d, const void* frames_u8, int B, int H0, int W0, const void* wfrag, y7t_stream stream) {
-    Y7T_ARG_CHECK(d && frames_u8 && wfrag && B > 0 && B <= d->max_batch);
-    if (!stem_block_fusable(d)) { y7t_set_error("the plan does not start with ReOrg + stem + 3x3/2 64->128 + 1x1 128->128 consumed by nobody else"); return Y7T_E_STATE; }
-    const y7t_op &o0 = d->ops[0], &o1 = d->ops[1], &o2 = d->ops[2];
-    if (H0 != o0.H * 2 || W0 != o0.W * 2) { y7t_set_error("stem block: frames must have the network's geometry (%dx%d), got %dx%d", o0.H * 2, o0.W * 2, H0, W0); return Y7T_E_ARG; }
-    return y7t_stem_block_u8_launch(frames_u8, B, H0, W0, d->w + o0.w_off, o0.K_pad, (const _Float16*)wfrag, d->bias + o0.bias_off, d->bias + o1.bias_off,
-                                    d->bias + o2.bias_off, (_Float16*)(d->arena + d->bufs[o2.out_buf]), o2.out_ld, o2.out_coff, o0.act, o1.act, o2.act,
-                                    (hipStream_t)stream);
-}
-
 extern "C" int y7t_det_set_detect(y7t_det* d, int nl, int na, int no, const float* strides, const float* anchors) {
     Y7T_ARG_CHECK(d && nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && strides && anchors);
     d->nl = nl; d->na = na; d->no = no;

@@ -185,14 +185,6 @@ class Detector:
             _lib.check(self._L.y7t_det_set_detect(h, len(plan.heads), plan.det["na"], plan.det["no"], plan.strides, plan.anchors))
             plan.detect_ops = [i for i, op in enumerate(plan.ops) if int(op["type"]) == 0 and int(op["detect_level"]) >= 0]
             plan.stem_fused = bool(self._L.y7t_det_stem_fusable(h)) and os.environ.get("Y7T_STEM_FUSED", "1") != "0"
-            # ops 0..2 (stem, 3x3/2 64->128, the first ELAN block's twin 1x1) as ONE kernel for uint8 frames of the network's geometry (csrc/y7t_stem_block.hip):
-            # the two inner filter banks as MFMA A-fragments.  Opt-in (Y7T_STEM_BLOCK=1) until measured; batch-1 plans keep the three launches (400 tiles).
-            plan.stem_block = (plan.stem_fused and bool(self._L.y7t_det_stem_block_fusable(h)) and os.environ.get("Y7T_STEM_BLOCK", "0") == "1"
-                               and self.max_batch * (hw[0] // 32) * (hw[1] // 64) >= int(os.environ.get("Y7T_STEM_BLOCK_MIN_TILES", "1024")))
-            if plan.stem_block:
-                W1, _ = weights.folded(plan.wlayout[1], self._sd)
-                W2, _ = weights.folded(plan.wlayout[2], self._sd)
-                plan.stem_block_w = torch.from_numpy(weights.pack_stem_block(W1, W2).view(np.int16)).cuda()
             plan.fusable = plan.det["na"] * plan.det["no"] <= 64 and all(int(plan.ops[i]["Cin"]) % 64 == 0 for i in plan.detect_ops)
             self._plans[hw] = plan
         self.plan = self._plans[hw]
@@ -265,9 +257,6 @@ class Detector:
             if fuse_decode is not None:     # the fused Detect epilogues append to counters that op 0 would have zeroed
                 _lib.check(self._L.y7t_det_forward_fused(p.handle, B, 0, 0, float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(p.post[pset].ws),
                                                          p.post[pset].ws.numel(), s))
-            if p.stem_block:                # frame -> stem -> 3x3/2 -> twin 1x1 in one kernel: the next op to run is 3
-                _lib.check(self._L.y7t_det_forward_stem_block_u8(p.handle, _lib.ptr(img), B, H, W, _lib.ptr(p.stem_block_w), s))
-                return 3
             _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(img), B, H, W, H, W, 0, 0, s))
             return 1
         _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
@@ -336,13 +325,6 @@ class Detector:
         img = getattr(self, "_img_keep", None)
         u8_native = img is not None and img.dtype == torch.uint8 and tuple(img.shape[1:3]) == (p.H, p.W) and img.shape[0] >= B
         for i in range(int(self._L.y7t_det_num_ops(p.handle))):
-            if i < 3 and p.stem_block and u8_native:      # ops 0..2 are ONE launch for such frames (their two intermediate tensors are never written)
-                if i == 0:
-                    _lib.check(self._L.y7t_det_forward_stem_block_u8(p.handle, _lib.ptr(img), B, p.H, p.W, _lib.ptr(p.stem_block_w), s))
-                    names.append(self._L.y7t_last_kernel().decode())
-                else:
-                    names.append("fused:stem_block")
-                continue
             if i == 0 and p.stem_fused and u8_native:
                 _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(img), B, p.H, p.W, p.H, p.W, 0, 0, s))   # how uint8 frames enter
             else:

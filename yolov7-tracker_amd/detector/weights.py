@@ -174,17 +174,6 @@ def pack_ws(blk):
     return np.ascontiguousarray(a).reshape(64, 576)
 
 
-def pack_stem_block(W1, W2):
-    """the two inner filter banks of csrc/y7t_stem_block.hip as MFMA A-fragments (fp16): W1 = the folded 3x3 / stride-2 conv (128, 64, 3, 3), W2 = the folded
-    twin 1x1 (128, 128[, 1, 1]).  Wave w owns output channels 32w .. 32w+31; a fragment is 1 KiB = 64 lanes x 8 halves, lane l holding
-    W[32w + l % 32][k0 + 8 (l // 32) .. +7]:   conv1 [w][tap * 4 + ks]: k0 = channel ks * 16 of tap (kh, kw);   twin [w][ks]: k0 = input channel ks * 16."""
-    W1 = np.asarray(W1, np.float64).reshape(128, 64, 3, 3).transpose(0, 2, 3, 1).reshape(4, 32, 9, 4, 2, 8)      # [w][l31][tap][ks][hi][8]
-    W2 = np.asarray(W2, np.float64).reshape(128, 128).reshape(4, 32, 8, 2, 8)                                    # [w][l31][ks][hi][8]
-    f1 = W1.transpose(0, 2, 3, 4, 1, 5)      # [w][tap][ks][hi][l31][8]
-    f2 = W2.transpose(0, 2, 3, 1, 4)         # [w][ks][hi][l31][8]
-    return np.concatenate([f1.reshape(-1), f2.reshape(-1)]).astype(np.float16)
-
-
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
