@@ -804,7 +804,26 @@ def main():
                                              "solved_as_one_assignment": int(pr[29])}
                 rs = [ev_reid[s][0].elapsed_time(ev_reid[s][1]) for s in range(Wm, Wm + K)]
                 line["phases_ms_per_step"]["reid"] = round(float(np.mean(rs)), 3)
-                line["config"]["reid_crops_per_step_mean"] = round(float(np.mean([len(step_boxes[s]) for s in range(Wm, Wm + K)])), 1)
+                n_crops = float(np.mean([len(step_boxes[s]) for s in range(Wm, Wm + K)]))
+                line["config"]["reid_crops_per_step_mean"] = round(n_crops, 1)
+                # configs[3]'s own kernel ("ReID conv as MFMA kernel") against ITS roof: algorithmic MACs of OSNet x0_25 per 128 x 64 crop, counted from the op
+                # list (tracker/reid.py::macs_per_crop), x 2 x crops / the HIP-event time of the one k_osnet_x025 launch of a step
+                from yolov7_tracker_amd.tracker import reid as _reid
+                dense, other = _reid.macs_per_crop(reid.ops)
+                tfl = 2.0 * (dense + other) * n_crops / (np.mean(rs) * 1e-3) / 1e12
+                line["roofline_reid"] = {"kernel": "k_osnet_x025 (csrc/y7t_reid_fused.hip): crop + resize + Normalize + OSNet x0_25 in one workgroup per crop, "
+                                                   "1x1 convs / 7x7 stem / fc on v_mfma_f32_16x16x16_f16, depthwise 3x3 and gates on the VALU",
+                                         "bound": "latency (about 140 barrier-separated phases per crop, activations resident in LDS)",
+                                         "algorithmic_mmac_per_crop": {"mfma": round(dense / 1e6, 2), "valu": round(other / 1e6, 2)},
+                                         "achieved": round(tfl, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s", "frac": round(tfl * 1e12 / PEAK_MFMA_F16, 4),
+                                         "hbm_bytes_per_crop": "source pixels of the crop (uint8, read once) + 2 KB of embedding out; parameters 461 KB, L2-resident",
+                                         "lds_bank_conflict_rate": "0.27 (profiles/r02_reid_pmc.json: the depthwise reads of the 32-channel stages)"}
+                nd_ = float(np.mean([len(dets_seq[t_]) for t_ in range(Wm * B, (Wm + K) * B)]))
+                live = float(line["config"].get("tracks_alive_last_frame", 0))
+                line["roofline_embed_dist"] = {"kernel": "k_embed_dist: nearest cosine distance of every live slot's <= 100 stored vectors to every detection (fp32 FMA chains)",
+                                               "bound": "hbm", "algorithmic_bytes_per_frame": int(live * 100 * 512 * 4 + nd_ * 512 * 4 + live * nd_ * 4),
+                                               "note": "~%.1f MB per frame (%.0f live slots x 100 rows x 512 floats): 2-3 us at HBM rate, measured 0.13 ms inside the pipeline "
+                                                       "(profiles/r02_deepsort_phases.txt) -- latency / occupancy bound at this size, not bandwidth" % (live * 100 * 512 * 4 / 1e6, live)}
             if not args.no_latency_mode and not cfg3 and not cfg4:
                 line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq, sd=sd0)
             if not args.no_cpu_baseline and not cfg4:            # the CPU baseline is timed on rank 0 at N=1 only (configs[1] / [2])

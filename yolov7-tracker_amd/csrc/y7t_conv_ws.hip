@@ -65,29 +65,43 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
 
-    // source of this lane's 16 bytes of piece i of pixel tile `pt` -- kOOB outside the image / in the pad slot / past this workgroup's last tile.
-    // Computed when the piece is issued (a dozen VALU operations beside 11 MFMAs): holding a tile's 13 offsets would cost 13 of the registers the
-    // filter bank needs.
-    struct TileAt { int base, h0, w0; bool live; };      // base = b * H (image row index of the tile's image), wave-uniform
+    // Source of this lane's 16 bytes of piece i of a tile = a per-lane CONSTANT (where its 16-byte slot sits inside the 18 x 18 patch, as a byte offset from
+    // the patch's first pixel) + a wave-uniform tile offset: one v_add per piece for the tiles whose patch lies inside the image (81 % of a 320 x 320 map).
+    // The kernel is bound by INSTRUCTION ISSUE (one wave per SIMD: ~7 issue slots per MFMA; a first version that decoded the tile and recomputed the slot
+    // for every piece and every store ran 695 VALU + 369 SALU per 144 MFMAs -- 52 % of the wave's cycles issuing, the matrix pipe 37 % busy), so everything
+    // that does not depend on the tile is computed once.  Slots that are never read (the pad chunk of a pixel, the tail of a patch row) fetch the
+    // patch's first bytes.  Tiles on the image border take the per-lane bounds check (zero fill through an out-of-range offset).
+    struct TileAt { int org, h0, w0; bool live, inner; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1) (interior tiles)
     auto tile_at = [&](int pt) -> TileAt {
         int q = pt;
         const int txi = q % tiles_x; q /= tiles_x;
         const int tyi = q % tiles_y, b = q / tiles_y;
-        return TileAt{b * p.H, tyi * TH, txi * TW, pt < pt_first + nt};
+        const int h0 = tyi * TH, w0 = txi * TW;
+        return TileAt{((((b * p.H + h0 - 1) * p.W + w0 - 1) * p.ldin) + p.cin_off) * 2, h0, w0, pt < pt_first + nt,
+                      tyi > 0 && tyi < tiles_y - 1 && txi > 0 && txi < tiles_x - 1};
     };
-    auto piece_src = [&](const TileAt& ta, int i) -> unsigned {
+    int pc_r[NPW], pc_x[NPW];      // (border tiles only; the compiler keeps what it needs)
+    unsigned pconst[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
         int I = wave + 4 * i;
         if (I >= C::PATCH_DMA) I = C::PATCH_DMA - 1;
         const int byte = I * 1024 + lane * 16;
         const int r = byte / RP, rb = byte - r * RP;
         const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
-        const int gy = ta.h0 + r - 1, gx = ta.w0 + x - 1;
-        const bool ok = ta.live && r < TH + 2 && x < TW + 2 && cs < 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        return ok ? (unsigned)(((((ta.base + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2) : kOOB;
-    };
-    auto issue_piece = [&](int buf, const TileAt& ta, int i) {
+        const bool used = r < TH + 2 && x < TW + 2 && cs < 8;
+        pconst[i] = used ? (unsigned)(((r * p.W + x) * p.ldin + cs * 8) * 2) : 0u;
+        pc_r[i] = used ? r : -0x10000; pc_x[i] = x;
+    }
+    auto issue_piece = [&](int buf, const TileAt& ta, int i) __attribute__((always_inline)) {
         const int I = (wave + 4 * i < C::PATCH_DMA) ? wave + 4 * i : C::PATCH_DMA - 1;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + buf * C::PATCH_BYTES + I * 1024), 16, piece_src(ta, i), 0, 0, 0);
+        unsigned v;
+        if (ta.inner && ta.live) v = pconst[i] + (unsigned)ta.org;                       // (wave-uniform branch)
+        else {
+            const int gy = ta.h0 + pc_r[i] - 1, gx = ta.w0 + pc_x[i] - 1;
+            v = (ta.live && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? pconst[i] + (unsigned)ta.org : kOOB;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + buf * C::PATCH_BYTES + I * 1024), 16, v, 0, 0, 0);
     };
 
     // ---- the filter bank.  Wave w owns output channels 32 (w & 1) .. +31 of the 128 pixels of tile half (w >> 1): 36 A-fragments per lane (144 VGPRs), straight
@@ -121,13 +135,17 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     constexpr int NST = 8;                   // 16-byte stores per lane and tile (4 MFMA tiles x 2 group pairs): every one is issued, for every tile (the launcher
                                              // admits maps of whole 16 x 16 tiles only), so that `s_waitcnt vmcnt` can COUNT them next to the pieces
 
-    // one eighth of a finished tile: group pair gp of MFMA tile j -> bias + activation -> 8 channels of one pixel -> one 16-byte NHWC store
-    auto store_group = [&](const floatx16 (&a)[4], int pt, int j, int gp) __attribute__((always_inline)) {
+    // one eighth of a finished tile: group pair gp of MFMA tile j -> bias + activation -> 8 channels of one pixel -> one 16-byte NHWC store at
+    // (wave-uniform tile / row-pair base) + (per-lane constant)
+    const unsigned ovoff = (unsigned)(((((pxh * 8 + (l31 >> 4)) * p.W + (l31 & 15)) * p.ldout) + chh * 32 + 8 * hi32) * 2);
+    auto out_base = [&](int pt) -> char* {
         int q = pt;
         const int txi = q % tiles_x; q /= tiles_x;
         const int tyi = q % tiles_y, b = q / tiles_y;
-        const int gy = tyi * TH + pxh * 8 + 2 * j + (l31 >> 4), gx = txi * TW + (l31 & 15);
-        half_t* orow = outp + ((size_t)((b * p.H + gy) * p.W + gx)) * p.ldout + p.cout_off + chh * 32;
+        return (char*)outp + ((size_t)((b * p.H + tyi * TH) * p.W + txi * TW) * p.ldout + p.cout_off) * 2;
+    };
+    const int jstep = 2 * p.W * p.ldout * 2;      // bytes between the row pairs of consecutive MFMA tiles
+    auto store_group = [&](const floatx16 (&a)[4], char* obase, int j, int gp) __attribute__((always_inline)) {
         unsigned w[2][2];
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
@@ -143,7 +161,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
         const uint4v v4 = {r0[0], r1[0], r0[1], r1[1]};
-        *(uint4v*)(orow + 8 * (gp * 2 + hi32)) = v4;
+        *(uint4v*)(obase + (size_t)j * jstep + gp * 32 + ovoff) = v4;
     };
 
     // One tile: its 144 MFMAs into `cur`, the PREVIOUS tile's eight store groups (out of `prev`) spread between them, tile t+2's pieces spread between them.
@@ -155,6 +173,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
         const TileAt tn = tile_at(pt_first + t + 2);
+        char* const ob = out_base(pt_first + t - 1);
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -171,13 +190,11 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xf[cb ^ 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
             }
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf[cb][j], cur[j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < 4; ++j) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf[cb][j], cur[j], 0, 0, 0);      // (one wave per SIMD: no s_setprio)
             if (s % 3 == 0 && s / 3 < NPW) issue_piece(nbuf, tn, s / 3);      // tile t+2's pieces: one every third substep (12) + the last one
             if (s == C::NSUB - 2 && NPW > 12) issue_piece(nbuf, tn, 12);
-            if (t > 0 && s % 4 == 1 && s / 4 < NST) store_group(prev, pt_first + t - 1, (s / 4) >> 1, (s / 4) & 1);      // substeps 1, 5, ..., 29
+            if (t > 0 && s % 4 == 1 && s / 4 < NST) store_group(prev, ob, (s / 4) >> 1, (s / 4) & 1);      // substeps 1, 5, ..., 29
         }
     };
 
@@ -193,12 +210,13 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's zero-filling pieces have landed before this workgroup's LDS is handed on
     // the last tile's results (its stores overlap nothing)
+    char* const obl = out_base(pt_first + nt - 1);
     if (nt & 1) {
 #pragma unroll
-        for (int g8 = 0; g8 < NST; ++g8) store_group(accA, pt_first + nt - 1, g8 >> 1, g8 & 1);
+        for (int g8 = 0; g8 < NST; ++g8) store_group(accA, obl, g8 >> 1, g8 & 1);
     } else {
 #pragma unroll
-        for (int g8 = 0; g8 < NST; ++g8) store_group(accB, pt_first + nt - 1, g8 >> 1, g8 & 1);
+        for (int g8 = 0; g8 < NST; ++g8) store_group(accB, obl, g8 >> 1, g8 & 1);
     }
 #endif
 }

@@ -191,6 +191,23 @@ def lower(sd, spec, in_h=128, in_w=64):
     return np.array(L.ops, dtype=OP_DTYPE), L.bufs, np.concatenate(L.w)
 
 
+def macs_per_crop(ops):
+    """multiply-accumulates of one crop through an op list: (dense on the matrix cores, everything else) -- the algorithmic work the cfg4 bench line prices the
+    fused OSNet kernel with (OSNet x0_25 at 128 x 64: 1x1 convs + the 7x7 stem + fc on MFMA, depthwise 3x3 / gates / pools on the VALU)"""
+    dense = other = 0
+    for o in ops:
+        t = int(o["type"])
+        if t == CONV:
+            dense += int(o["Ho"]) * int(o["Wo"]) * int(o["Co"]) * int(o["k"]) ** 2 * int(o["C"])
+        elif t == FC:
+            dense += int(o["C"]) * int(o["Co"])
+        elif t == DWCONV3:
+            other += int(o["Ho"]) * int(o["Wo"]) * int(o["C"]) * 9
+        elif t == GATE_ACC:
+            other += int(o["H"]) * int(o["W"]) * int(o["C"]) * 2 + 2 * int(o["C"]) * int(o["R"])
+    return dense, other
+
+
 def deepsort_net_random_state_dict(seed=0):
     """seeded `net_dict` of the reference's DeepSORT embedding network (reid_models/deepsort_reid.py:62-110; the classifier is not part of the
     reid=True forward and is left out)"""
