@@ -216,11 +216,6 @@ int y7t_input_layout(const void* img, int is_u8, int B, int H, int W, int reorg,
  * y7t_letterbox_layout_u8 / y7t_input_layout followed by op 0 compute, without the fp16 layout tensor in between.  Continue with
  * y7t_det_forward_ops / y7t_det_forward_fused from op 1. */
 int y7t_det_stem_fusable(const y7t_det* det);
-/* The same on frames [b0, b0 + B) of a larger resident batch (frames_u8 = the batch's first frame; every arena tensor is [max_batch][H][W][C]).  A batched
- * forward walks the large-map front of its launch list a few frames at a time so that each producer's output is still in the 256 MiB Infinity Cache when
- * its consumer reads it; the reference itself runs one frame per forward (tracker/track.py:144). */
-int y7t_det_forward_ops_at(y7t_det* det, int b0, int B, int first, int last, y7t_stream stream);
-int y7t_det_forward_stem_u8_at(y7t_det* det, const void* frames_u8, int b0, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream);
 int y7t_det_forward_stem_u8(y7t_det* det, const void* frames_u8, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream);
 
 /* TrackerLoader._letterbox (tracker/tracker_dataloader.py:100-130) fused with the layout above, for raw (B,H0,W0,3) uint8 BGR

@@ -12,7 +12,6 @@
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
 #   profile         rocprofv3 kernel stats of the bench command, per-op table of the launch list, HBM traffic (2 PMC passes), MFMA busy -> stamped JSONs
-#   exp_chunk       chunked front (Y7T_CHUNK_FRAMES / Y7T_CHUNK_MIN_HW): equality test, bench line for several chunk sizes
 #   exp_ws          weights-stationary 64 -> 64 kernel (default; Y7T_CONV_WS=0 = the patch kernels): layer parity, parity inside the pinned list, per-layer timing, bench line
 #   (round 3's first call also had exp_s2 / exp_nw8 / exp_late / exp_fixup / exp_next -- the kernels prepared at the end of round 2; their results are in
 #    profiles/r03_conv_variants.txt and the losing variants are no longer in the source)
@@ -109,19 +108,6 @@ exp_ws)
   timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_ws.json 2> $O/bench_ws.err
   Y7T_CONV_WS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_nows.json 2> $O/bench_nows.err
   benchsum ws nows
-  ;;
-
-exp_chunk)
-  say "exp_chunk: the 640^2 / 320^2 front of the launch list N frames at a time (Infinity-Cache-sized chunks), bench A/B in one session"
-  timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k chunked > $O/t_chunk.log 2>&1; echo "rc=$?" >> $O/t_chunk.log; tailsum $O/t_chunk.log
-  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
-  timeout 300 python bench.py $X > $O/bench_c0.json 2> $O/bench_c0.err
-  for c in 1 2 4 8; do Y7T_CHUNK_FRAMES=$c timeout 300 python bench.py $X > $O/bench_c$c.json 2> $O/bench_c$c.err; done
-  Y7T_CHUNK_FRAMES=2 Y7T_CHUNK_MIN_HW=160 timeout 300 python bench.py $X > $O/bench_c2_160.json 2> $O/bench_c2_160.err
-  Y7T_CHUNK_FRAMES=4 Y7T_CHUNK_MIN_HW=160 timeout 300 python bench.py $X > $O/bench_c4_160.json 2> $O/bench_c4_160.err
-  Y7T_CHUNK_FRAMES=8 Y7T_CHUNK_MIN_HW=80 timeout 300 python bench.py $X > $O/bench_c8_80.json 2> $O/bench_c8_80.err
-  timeout 300 python bench.py $X > $O/bench_c0b.json 2> $O/bench_c0b.err
-  benchsum c0 c1 c2 c4 c8 c2_160 c4_160 c8_80 c0b
   ;;
 
 pmc_queues)

@@ -428,27 +428,3 @@ def test_attempt_load_state_dict_checkpoint(tmp_path):
         attempt_load(str(tmp_path / "bare.pt"), img_size=128)          # a bare state dict needs the architecture
     with pytest.raises(FileNotFoundError):
         attempt_load(str(tmp_path / "missing.pt"), cfg="yolov7-tiny")
-
-
-def test_chunked_front_equals_the_whole_batch(monkeypatch):
-    """the large-map front of the launch list walked a few frames at a time (y7t_det_forward_stem_u8_at / y7t_det_forward_ops_at: frame ranges are pointer
-    offsets into the [max_batch][H][W][C] tensors) gives the heads of the whole-batch forward bit for bit: every output value is computed by the same
-    instructions on the same operands, only the launch's frame range differs (split-K, which picks its split from the launch's tile count, is off here)"""
-    monkeypatch.setenv("Y7T_CONV_SPLITK", "0")
-    g = torch.Generator().manual_seed(41)
-    frames = torch.randint(0, 256, (6, 256, 384, 3), dtype=torch.uint8, generator=g).cuda()
-    det = build("yolov7-w6", 10, (256, 384), 6)
-    want = [t.clone() for t in det(frames)[0].raw()]
-    monkeypatch.setenv("Y7T_CHUNK_FRAMES", "4")          # 6 frames -> chunks of 4 + 2
-    monkeypatch.setenv("Y7T_CHUNK_MIN_HW", "64")         # at 256 x 384 the "large maps" are 128 x 192 and 64 x 96
-    k, bc = det.chunked_front(6)
-    assert bc == 4 and 9 <= k < 30
-    got = det(frames)[0].raw()
-    assert all(torch.equal(a, b) for a, b in zip(got, want))
-    out = det.forward(frames, fuse_decode=0.01)           # and with the fused Detect epilogues behind the chunked front
-    d1, n1 = det.postprocess(out, 0.01, 0.45, None)
-    d1, n1 = d1.clone(), n1.clone()
-    monkeypatch.setenv("Y7T_CHUNK_FRAMES", "0")
-    out = det.forward(frames, fuse_decode=0.01)
-    d0, n0 = det.postprocess(out, 0.01, 0.45, None)
-    assert torch.equal(n0, n1) and torch.equal(d0, d1)

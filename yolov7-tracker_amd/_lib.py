@@ -58,8 +58,6 @@ SIGNATURES = {
     "y7t_reid_forward_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "y7t_reid_fused_blob_size": (ctypes.c_size_t, []),
     "y7t_reid_set_fused": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
-    "y7t_det_forward_ops_at": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "y7t_det_forward_stem_u8_at": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y7t_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
     "y7t_stream_destroy": (c_int, [c_void_p]),
     "y7t_conv2d_nhwc_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

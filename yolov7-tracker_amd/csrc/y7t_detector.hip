@@ -65,15 +65,14 @@ extern "C" int y7t_det_num_ops(const y7t_det* d) { return d ? (int)d->ops.size()
 
 extern "C" int y7t_det_forward(y7t_det* d, int B, y7t_stream stream) { return y7t_det_forward_ops(d, B, 0, -1, stream); }
 
-// ops [first, last) on frames [b0, b0 + B) of the plan's tensors (every arena buffer is [max_batch][H][W][C]: a frame range is a pointer offset)
-static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* fused, hipStream_t s, int b0 = 0) {
-    Y7T_ARG_CHECK(d && B > 0 && b0 >= 0 && b0 + B <= d->max_batch);
+static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* fused, hipStream_t s) {
+    Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
     if (last < 0) last = (int)d->ops.size();
     Y7T_ARG_CHECK(first >= 0 && first <= last && last <= (int)d->ops.size());
     for (int oi = first; oi < last; ++oi) {
         const y7t_op& op = d->ops[oi];
-        const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]) + (size_t)b0 * op.H * op.W * op.in_ld;
-        void* outp = d->arena + d->bufs[op.out_buf] + (size_t)b0 * op.Ho * op.Wo * op.out_ld * (op.out_f32 ? 4 : 2);
+        const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);
+        void* outp = d->arena + d->bufs[op.out_buf];
         int rc = 0;
         if (op.type == Y7T_OP_CONV) {
             Y7TConvArgs a;
@@ -86,7 +85,7 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
             a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.korder; a.force_patch = 0;
             a.splitk_ws = d->splitk_ws;
             if (op.up_C > 0) {
-                a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]) + (size_t)b0 * (op.H / 2) * (op.W / 2) * op.up_ld;
+                a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]);
                 a.ldin2 = op.up_ld; a.cin2_off = op.up_coff; a.up_c0 = op.up_c0; a.up_C = op.up_C;
             }
             if (fused && op.detect_level >= 0) {
@@ -101,8 +100,7 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
                         q.row0 += d->na * d->ops[k].Ho * d->ops[k].Wo;
                 for (int k = 0; k < d->na; ++k) { q.aw[k] = d->anchors[(l * d->na + k) * 2]; q.ah[k] = d->anchors[(l * d->na + k) * 2 + 1]; }
                 q.conf_thres = fused->conf_thres; q.cap = fused->cap;
-                q.cbox = fused->ws.cbox + (size_t)b0 * fused->cap * 4; q.cscore = fused->ws.cscore + (size_t)b0 * fused->cap;
-                q.ccls = fused->ws.ccls + (size_t)b0 * fused->cap; q.cidx = fused->ws.cidx + (size_t)b0 * fused->cap; q.count = fused->ws.count + b0;
+                q.cbox = fused->ws.cbox; q.cscore = fused->ws.cscore; q.ccls = fused->ws.ccls; q.cidx = fused->ws.cidx; q.count = fused->ws.count;
             }
             rc = y7t_conv_launch(a, s);
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
@@ -118,12 +116,6 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
 
 extern "C" int y7t_det_forward_ops(y7t_det* d, int B, int first, int last, y7t_stream stream) {
     return forward_impl(d, B, first, last, nullptr, (hipStream_t)stream);
-}
-
-// Frame ranges.  The reference runs one frame per forward (tracker/track.py:144); a batched forward may walk the large-map front of the launch list a few frames
-// at a time so that a producer's output is still in the 256 MiB Infinity Cache when its consumer reads it ("chunked front").
-extern "C" int y7t_det_forward_ops_at(y7t_det* d, int b0, int B, int first, int last, y7t_stream stream) {
-    return forward_impl(d, B, first, last, nullptr, (hipStream_t)stream, b0);
 }
 
 static bool stem_fusable(const y7t_det* d) {
@@ -144,17 +136,6 @@ extern "C" int y7t_det_forward_stem_u8(y7t_det* d, const void* frames_u8, int B,
     Y7T_ARG_CHECK(top + new_h <= H && left + new_w <= W);
     return y7t_stem_u8_launch(frames_u8, B, H0, W0, H, W, new_h, new_w, top, left, d->w + op.w_off, op.K_pad, d->bias + op.bias_off,
                               (_Float16*)(d->arena + d->bufs[op.out_buf]), op.out_ld, op.out_coff, op.act, (hipStream_t)stream);
-}
-
-extern "C" int y7t_det_forward_stem_u8_at(y7t_det* d, const void* frames_u8, int b0, int B, int H0, int W0, int new_h, int new_w, int top, int left, y7t_stream stream) {
-    Y7T_ARG_CHECK(d && frames_u8 && B > 0 && b0 >= 0 && b0 + B <= d->max_batch && H0 > 0 && W0 > 0 && new_h > 0 && new_w > 0 && top >= 0 && left >= 0);
-    if (!stem_fusable(d)) { y7t_set_error("the plan's first op is not a ReOrg + 3x3 -> 64 stem: use y7t_input_layout + y7t_det_forward"); return Y7T_E_STATE; }
-    const y7t_op& op = d->ops[0];
-    const int H = op.H * 2, W = op.W * 2;
-    Y7T_ARG_CHECK(top + new_h <= H && left + new_w <= W);
-    return y7t_stem_u8_launch((const char*)frames_u8 + (size_t)b0 * H0 * W0 * 3, B, H0, W0, H, W, new_h, new_w, top, left, d->w + op.w_off, op.K_pad,
-                              d->bias + op.bias_off, (_Float16*)(d->arena + d->bufs[op.out_buf]) + (size_t)b0 * op.Ho * op.Wo * op.out_ld, op.out_ld, op.out_coff,
-                              op.act, (hipStream_t)stream);
 }
 
 extern "C" int y7t_det_set_detect(y7t_det* d, int nl, int na, int no, const float* strides, const float* anchors) {

@@ -257,32 +257,10 @@ class Detector:
             if fuse_decode is not None:     # the fused Detect epilogues append to counters that op 0 would have zeroed
                 _lib.check(self._L.y7t_det_forward_fused(p.handle, B, 0, 0, float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(p.post[pset].ws),
                                                          p.post[pset].ws.numel(), s))
-            k, bc = self.chunked_front(B)
-            if k > 1:       # the large-map front of the list, `bc` frames at a time: a producer's output is still in the Infinity Cache when its consumer reads it
-                for b0 in range(0, B, bc):
-                    n = min(bc, B - b0)
-                    _lib.check(self._L.y7t_det_forward_stem_u8_at(p.handle, _lib.ptr(img), b0, n, H, W, H, W, 0, 0, s))
-                    _lib.check(self._L.y7t_det_forward_ops_at(p.handle, b0, n, 1, k, s))
-                return k
             _lib.check(self._L.y7t_det_forward_stem_u8(p.handle, _lib.ptr(img), B, H, W, H, W, 0, 0, s))
             return 1
         _lib.check(self._L.y7t_input_layout(_lib.ptr(img), int(is_u8), B, H, W, int(p.reorg), _lib.ptr(p.arena), p.in_ld, s))
         return 0
-
-    def chunked_front(self, B):
-        """-> (k, frames per chunk): ops [0, k) of the launch list run `frames per chunk` frames at a time (k <= 1: no chunking).  The ops on the maps of at
-        least Y7T_CHUNK_MIN_HW pixels a side, never a Detect op.  Y7T_CHUNK_FRAMES (0 = off) frames per chunk."""
-        p = self.plan
-        bc = int(os.environ.get("Y7T_CHUNK_FRAMES", "0"))
-        if bc <= 0 or B <= bc:
-            return 0, B
-        hw = int(os.environ.get("Y7T_CHUNK_MIN_HW", "320"))
-        k = 0
-        for op in p.ops:
-            if int(op["detect_level"]) >= 0 or min(int(op["H"]), int(op["W"])) < hw:
-                break
-            k += 1
-        return k, bc
 
     def forward_part(self, img, first, last, fuse_decode=None, pset=0):
         """ops [first, last) of the current plan's launch list on the current stream (last < 0: to the end); with `img` (uint8
