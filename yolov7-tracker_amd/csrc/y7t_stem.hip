@@ -59,27 +59,28 @@ __device__ __forceinline__ void lb_pixel(const StemArgs& p, int b, int y, int x,
     }
 }
 
-// LDS map: two input patches | the 64 x 144 filter bank as MFMA A-fragments (tap, channel half: 1 KiB each) | 64 biases.
-// (Rounds 1-2 kept the filter bank and the biases in registers: 228 VGPRs, two waves per SIMD.  PMC, round 3 (profiles/r03_pmc_kernels.txt): 17.8 VALU per
-// MFMA -- bias + SiLU of 64 values per 36 MFMAs, the uint8 conversion -- and 44 % of the wave cycles issue-stalled on their own results with the VALU port
-// 47 % busy: the kernel wants more waves, not fewer instructions.  From LDS the bank costs one extra ds_read_b128 per MFMA pair and frees 104 registers.)
-constexpr int W_OFF = 2 * PATCH_BYTES, W_BYTES = 9 * 2 * 1024, B_OFF = W_OFF + W_BYTES, STEM_LDS = B_OFF + 64 * 4;
-
 template <bool RESIZE>
-__global__ void __launch_bounds__(256, 3) k_stem_u8(const StemArgs p) {
+__global__ void __launch_bounds__(256, 2) k_stem_u8(const StemArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two patches
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi32 = lane >> 5;
     const int Hr = p.H >> 1, Wr = p.W >> 1;
     const float sy = (float)p.H0 / (float)p.new_h, sx = (float)p.W0 / (float)p.new_w;
 
-    // ---- weights: A operand (lane: output channel i*32 + l31, k half hi32 of tap t), staged once per workgroup as fragments [tap][i][lane] ----
-    for (int f = tid >> 6; f < 18; f += 4)
-        *(half8*)(smem + W_OFF + f * 1024 + lane * 16) = *(const half8*)(p.w + (size_t)((f & 1) * 32 + l31) * p.K_pad + (f >> 1) * 16 + hi32 * 8);
-    if (tid < 64) ((float*)(smem + B_OFF))[tid] = p.bias[tid];
-    const char* wfrag = smem + W_OFF + lane * 16;
-    const float* lbias = (const float*)(smem + B_OFF);
+    // ---- weights: A operand, resident in registers.  Lane: output channel i*32 + l31, k half hi32 of tap t ----
+    half8 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[t][i] = *(const half8*)(p.w + (size_t)(i * 32 + l31) * p.K_pad + t * 16 + hi32 * 8);
+    float bv[2][4][4];      // bias of the 4 channels this lane owns per (channel tile, group)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[i][g][e] = p.bias[i * 32 + 8 * g + 4 * hi32 + e];
 
     // A lane builds patch pixels tid and tid + 256 (< 324).  RESIZE = false (the frame already has the network's geometry up to padding,
     // W0 and `left` even): the 2 x 2 source pixels of a reorg pixel are two runs of 6 contiguous, 2-byte aligned bytes -> six UNCONDITIONAL
@@ -189,11 +190,9 @@ __global__ void __launch_bounds__(256, 3) k_stem_u8(const StemArgs p) {
                 xf[j] = *(const half8*)(patch + ((row + kh) * PS + x + kw) * PIXB + hi32 * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const half8 wf = *(const half8*)(wfrag + (t * 2 + i) * 1024);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t][i], xf[j], acc[i][j], 0, 0, 0);
         }
         // ---- epilogue: bias + activation, 16-byte NHWC pieces straight from the registers ----
         int tt = tile;
@@ -215,10 +214,8 @@ __global__ void __launch_bounds__(256, 3) k_stem_u8(const StemArgs p) {
                         for (int gg = 0; gg < 2; ++gg) {
                             const int g = gp * 2 + gg;
                             float v[4];
-                            typedef __attribute__((ext_vector_type(4))) float float4v;
-                            const float4v bq = *(const float4v*)(lbias + i * 32 + 8 * g + 4 * hi32);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bq[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[i][j][g * 4 + e] + bv[i][g][e]);
                             typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
                             half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
                             w[gg][0] = __builtin_bit_cast(unsigned, h0v);
@@ -254,15 +251,15 @@ int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int 
     a.w = w; a.K_pad = K_pad; a.bias = bias; a.out = out; a.ldout = ldout; a.cout_off = cout_off; a.act = act;
     a.tiles_x = (W / 2 + TS - 1) / TS; a.tiles_y = (H / 2 + TS - 1) / TS; a.n_tiles = B * a.tiles_x * a.tiles_y;
     const bool resize = !(new_h == H0 && new_w == W0 && (left & 1) == 0 && (W0 & 1) == 0 && W0 >= 2);   // (odd geometry: the generic sampler)
-    int grid = a.n_tiles < 2304 ? a.n_tiles : 2304;      // three workgroups per CU (LDS 49 KB, 156 VGPRs) x 256 CUs x 3 rounds
+    int grid = a.n_tiles < 2048 ? a.n_tiles : 2048;
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
         attr = true;
     }
-    if (resize) hipLaunchKernelGGL(k_stem_u8<true>, dim3(grid), dim3(256), STEM_LDS, s, a);
-    else hipLaunchKernelGGL(k_stem_u8<false>, dim3(grid), dim3(256), STEM_LDS, s, a);
+    if (resize) hipLaunchKernelGGL(k_stem_u8<true>, dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
+    else hipLaunchKernelGGL(k_stem_u8<false>, dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("stem_u8<%s>", resize ? "letterbox-resize" : "direct");
     return 0;
