@@ -12,9 +12,6 @@
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
-#ifndef Y7T_TRACKER_PRIO
-#define Y7T_TRACKER_PRIO 3
-#endif
 
 static thread_local char g_err[512] = "";
 void y7t_set_error(const char* fmt, ...) {
@@ -177,11 +174,6 @@ __global__ void k_tracker_step(void* const* states, const float* const* dets, co
 
 __global__ void k_tracker_step1(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count,
                                 unsigned fast_bytes, const double* warp) {
-    // One latency-bound workgroup that, in the pipelined loop, shares its CU with convolution workgroups whose MFMA bursts run at s_setprio 1: without a
-    // priority of its own its waves get the issue slots those leave (185 us alone, 390 us beside the detector).  Y7T_TRACKER_PRIO (build-time, default 3).
-#if defined(__HIP_DEVICE_COMPILE__) && Y7T_TRACKER_PRIO > 0
-    __builtin_amdgcn_s_setprio(Y7T_TRACKER_PRIO);
-#endif
     const Y7TExec ex = make_exec(fast_bytes);
     y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
 }
@@ -278,9 +270,6 @@ __global__ void __launch_bounds__(256) k_ds_store(void* fblob, const float* __re
 
 __global__ void k_tracker_step_deepsort(void* state, void* fblob, const float* dets, int n, const float* det_feats, double* out_rows,
                                         int out_cap, int* out_count, unsigned fast_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__) && Y7T_TRACKER_PRIO > 0
-    __builtin_amdgcn_s_setprio(Y7T_TRACKER_PRIO);      // (as k_tracker_step1)
-#endif
     const Y7TExec ex = make_exec(fast_bytes);
     y7t_tracker_step_deepsort(ex, state, fblob, dets, n, det_feats, out_rows, out_cap, out_count);
 }
