@@ -60,7 +60,8 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
 
 
-@pytest.mark.parametrize("name,workload", [("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"), ("r02_bench_line_cfg4.json", "configs[3]")])
+@pytest.mark.parametrize("name,workload", [("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),
+                                           ("r02_bench_line_cfg4.json", "configs[3]")])
 def test_committed_bench_lines_keep_the_contract(name, workload):
     l = _line(name)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
@@ -88,7 +89,16 @@ def test_committed_bench_lines_keep_the_contract(name, workload):
 
 
 def test_headline_line_carries_parity_and_reference_semantics_fps():
-    l = _line("r02_bench_line.json")
-    p = l["parity"]["well_conditioned"]
-    assert p["boxes_matched_same_class_1px_conf5e-3"] >= 0.95 * p["boxes_oracle"] and max(p["heads_mean_abs_err_over_logit_std"]) < 0.01
+    """round 3: `parity` describes the TIMED weights -- raw heads, every pre-NMS candidate at SURVEY 8a's bar, the final boxes -- and says which third-party
+    kernels are unpinned; traffic is only printed for the launch list it was measured on"""
+    l = _line("r03_bench_line.json")
+    p = l["parity"]
+    assert p["weights"] == "conditioned" and max(p["heads_mean_abs_err_over_logit_std"]) < 0.004
+    c = p["candidates_before_nms"]
+    assert c["n_both"] >= 1000 and c["frac_within_bar"] == 1.0 and c["n_class_differs"] == 0 and c["max_dcoord"] <= 1.0 and c["max_dconf"] <= 5e-3
+    assert c["n_only_one_side"] <= 0.02 * c["n_both"] and c["max_margin_only_one_side"] <= 1e-3
+    assert p["boxes_matched_same_class_1px_conf5e-3"] >= 0.97 * p["boxes_oracle"] and p["third_party"].startswith("unpinned")
     assert l["latency_mode"]["f32_chw_host"] and l["latency_mode"]["u8_hwc_host"] and l["fps_incl_h2d"]["value"] < l["value"] * 1.05
+    r, t = l["roofline"], json.load(open(os.path.join(ROOT, "profiles", "r03_conv_hbm_traffic.json")))
+    assert len(l["config"]["launch_list_sha"]) == 16 and t["launch_list_sha"] and t["commit"] != "unknown"
+    assert (r["traffic"] is None) == (t["launch_list_sha"] != l["config"]["launch_list_sha"] or "not reported" in (r["traffic_note"] or ""))
