@@ -2,7 +2,7 @@
 (HIP events, N reps), print TFLOP/s and algorithmic GB/s."""
 import sys, ctypes, collections
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov7_tracker_amd import _lib
 from yolov7_tracker_amd.detector import arch, graph
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

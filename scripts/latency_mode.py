@@ -4,7 +4,7 @@ Reports fps for (a) float32 CHW host frames exactly like the reference loader ha
 (c) uint8 frames already resident in HBM; each eager and with the detector+NMS chain replayed as a hipGraph."""
 import sys, time, types
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov7_tracker_amd import synth
 from yolov7_tracker_amd.detector import arch, model
 from yolov7_tracker_amd.tracker.basetrack import BaseTrack

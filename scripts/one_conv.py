@@ -1,6 +1,6 @@
 """run ONE conv shape repeatedly (for rocprofv3 --pmc): python scripts/one_conv.py H W Cin Cout k s [B reps]"""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov7_tracker_amd import _lib
 H, W, Cin, Cout, k, s = [int(v) for v in sys.argv[1:7]]
 B = int(sys.argv[7]) if len(sys.argv) > 7 else 8
