@@ -61,6 +61,8 @@ def parse():
                     help="seeded random weights of the timed detector.  conditioned (default): BatchNorm shifts ~ +2, statistics calibrated on frame 0, damped "
                          "width / height logits -- a random network that does not amplify rounding noise, so that `parity` (heads, pre-NMS candidates, boxes "
                          "against the fp32 oracle) describes the TIMED weights; chaotic: iid zero-mean weights (rounds 1-2)")
+    ap.add_argument("--tracker_launch", default="per_frame", choices=["per_frame", "frames"],
+                    help="frames: the tracker frame steps of a step's frames as ONE launch per sequence (y7t_tracker_step_frames) instead of one launch per frame")
     ap.add_argument("--cu_reserve", type=int, default=0, help="N > 0: the tracker chain's stream owns N compute units (hipExtStreamCreateWithCUMask), the "
                     "detector's stream the rest -- the single-workgroup frame steps no longer share CUs with 256-thread convolution workgroups")
     ap.add_argument("--cu_reserve_nms", type=int, default=0, help="1: rank sort + NMS run on the reserved compute units too")
@@ -522,7 +524,12 @@ def main():
             with torch.cuda.stream(st):
                 if q:
                     st.wait_event(fork)
-                for i in range(q * Bq, (q + 1) * Bq):
+                if args.tracker_launch == "frames" and not cfg4:      # one launch for the sequence's frames of this step (pointer tables built before the timed region)
+                    trks[q]._launch_frames(frame_tables[(s, q)])
+                    continue_frames = False
+                else:
+                    continue_frames = True
+                for i in (range(q * Bq, (q + 1) * Bq) if continue_frames else ()):
                     t = s * B + i
                     if cfg3:
                         trks[q]._launch(dets_dev[t], out=results[t], warp=warps_dev[t])
@@ -534,6 +541,12 @@ def main():
                     j = torch.cuda.Event()
                     j.record(st)
                     cur.wait_event(j)          # join: the step's chain is complete on the caller's stream
+    frame_tables = {}
+    if args.tracker_launch == "frames" and not cfg4:
+        for s_ in range(n_frames // B):
+            for q in range(S):
+                ts = [s_ * B + i for i in range(q * Bq, (q + 1) * Bq)]
+                frame_tables[(s_, q)] = trks[q].frames_table([dets_dev[t] for t in ts], [results[t] for t in ts], [warps_dev[t] for t in ts] if cfg3 else None)
     tracker_name = "botsort" if cfg3 else "deepsort" if cfg4 else "bytetrack"
     metric_name = "end-to-end fps (detect+track) YOLOv7-w6@1280 " + ("BoT-SORT, 500-object stress" if cfg3 else
                                                                      "DeepSORT + OSNet x0_25 ReID (128x64 crops)" if cfg4 else "ByteTrack")

@@ -120,6 +120,12 @@ int y7t_tracker_step_batch(void* const* states, const float* const* dets, const 
                            int* out_count, int out_cap, int batch, int threads, const double* const* gmc_warps,
                            y7t_stream stream);
 
+/* n_frames CONSECUTIVE frames of one tracker in one launch (the per-frame loop of tracker/track.py:138-179 for a caller that already holds a batch's
+ * detections, e.g. `--batch N`): frame f = dets[f] / n_dets[f] (read on the device) -> out_rows[f], *out_count[f]; all five are DEVICE arrays of
+ * n_frames entries (gmc_warps may be NULL).  Exactly the frames y7t_tracker_step would produce one by one. */
+int y7t_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
+                            int n_frames, int threads, const double* const* gmc_warps, y7t_stream stream);
+
 /* convenience for batch == 1 with host-known n (n < 0: update_without_detection, basetrack.py:489-537) */
 int y7t_tracker_step(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count, int threads,
                      const double* gmc_warp, y7t_stream stream);

@@ -599,3 +599,35 @@ def test_nms_max_det_beyond_the_lds_budget_is_an_argument_error():
     rc = L.y7t_det_postprocess(None, None, None, None, None, 4, 3, 15, B, ctypes.c_float(0.01), ctypes.c_float(0.45), 4000, 30000, cap, _lib.ptr(lb),
                                _lib.ptr(dets), _lib.ptr(nd), _lib.ptr(keep), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     assert rc == -1 and b"max_det" in L.y7t_last_error()
+
+
+@pytest.mark.parametrize("kind,fmt", [("bytetrack", "default"), ("botsort", "botsort")])
+def test_frames_in_one_launch_equal_frame_by_frame(kind, fmt):
+    """y7t_tracker_step_frames: a batch of consecutive frames of one tracker in ONE launch gives exactly the rows that one launch per frame gives
+    (empty frames and warps included); the oracle pins both"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.botsort import BoTSORT
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    n_frames, chunk = 36, 12
+    dets = synth.make_detections(n_frames, 60, 640, seq_idx=9, miss=0.1, fp=0.1)
+    dets[7] = np.zeros((0, 6), np.float32)
+    warps = synth.make_warps(n_frames, seq_idx=9) if kind == "botsort" else None
+    want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
+    BaseTrack._count = 0
+    t = (BoTSORT if kind == "botsort" else ByteTrack)(make_opts(kalman_format=fmt), frame_rate=30)
+    dd = [torch.from_numpy(d).cuda() for d in dets]
+    ww = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64).reshape(6)).cuda() for w in warps] if warps is not None else None
+    outs = torch.zeros((n_frames, t.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    for f0 in range(0, n_frames, chunk):
+        tab = t.frames_table(dd[f0:f0 + chunk], [outs[f] for f in range(f0, f0 + chunk)], ww[f0:f0 + chunk] if ww is not None else None)
+        t._launch_frames(tab)
+    torch.cuda.synchronize()
+    h = outs.cpu().numpy()
+    got = []
+    for f in range(n_frames):
+        c = int(h[f, t.cap_t].view(np.int32)[0])
+        got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
+    util.assert_same_tracks(got, want, "%s, %d frames in launches of %d" % (kind, n_frames, chunk))
+    assert t.frame_id == n_frames

@@ -30,6 +30,7 @@ SIGNATURES = {
     "y7t_tracker_state_bytes": (c_size_t, [c_int, c_int]),
     "y7t_tracker_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p,
                                  c_void_p]),
+    "y7t_tracker_step_frames": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y7t_tracker_step_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "y7t_tracker_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "y7t_deepsort_feature_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

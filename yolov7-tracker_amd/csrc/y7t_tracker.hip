@@ -178,6 +178,17 @@ __global__ void k_tracker_step1(void* state, const float* dets, int n, double* o
     y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
 }
 
+// n_frames consecutive frames of ONE tracker in one launch: the same frame step, frame after frame, by the same workgroup (the state stays hot in
+// this CU's caches and nothing is launched between frames).  For pipelines that have a whole batch's detections before the tracker runs.
+__global__ void k_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
+                                      int n_frames, unsigned fast_bytes, const double* const* warps) {
+    const Y7TExec ex = make_exec(fast_bytes);
+    for (int f = 0; f < n_frames; ++f) {
+        y7t_tracker_step(ex, state, dets[f], n_dets[f], out_rows[f], out_cap, out_count[f], warps ? warps[f] : nullptr);
+        y7t_sync(ex);
+    }
+}
+
 // ---- DeepSORT (y7t_track_deepsort.h) ----
 __global__ void k_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budget) {
     Y7TExec ex;
@@ -534,6 +545,25 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
     const unsigned fb = step_fast_bytes(n);
     hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
                        out_count, fb, gmc_warp);
+    Y7T_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int y7t_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
+                                       int n_frames, int threads, const double* const* gmc_warps, y7t_stream stream) {
+    Y7T_ARG_CHECK(state && out_cap >= 0 && n_frames >= 0);
+    if (n_frames == 0) return 0;
+    Y7T_ARG_CHECK(dets && n_dets && out_rows && out_count);
+    const int nt = step_threads(threads);
+    Y7T_ARG_CHECK(nt > 0);
+    if (state_kind(state) == Y7T_DEEPSORT) {
+        y7t_set_error("y7t_tracker_step_frames: a DeepSORT pool steps through y7t_tracker_step_deepsort (appearance rings)");
+        return Y7T_E_STATE;
+    }
+    static bool attr_done = false;
+    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_frames, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    hipLaunchKernelGGL(k_tracker_step_frames, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
+                       kFastBytes, gmc_warps);
     Y7T_LAUNCH_CHECK();
     return 0;
 }

@@ -366,6 +366,31 @@ class BaseTracker(object):
         self.frame_id += 1
         self._snap_cache = None
 
+    def frames_table(self, dets_dev, outs, warps=None):
+        """device pointer tables of y7t_tracker_step_frames for a fixed set of consecutive frames (build once, launch many times):
+        dets_dev = list of (n, 6) float32 device tensors, outs = list of (cap_t + 1, 8) float64 device tensors (row cap_t receives the count),
+        warps = optional list of 2x3 float64 device tensors"""
+        ds = [d.reshape(-1, 6) for d in dets_dev]
+        for d in ds:
+            if d.device.type != "cuda" or d.dtype != torch.float32 or not d.is_contiguous():
+                raise _lib.Y7TError("frames_table: detections must be contiguous float32 device tensors")
+            if d.shape[0] > self.cap_d:
+                raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (d.shape[0], self.cap_d))
+        n = len(ds)
+        tab = torch.tensor([[d.data_ptr() for d in ds], [o.data_ptr() for o in outs], [o.data_ptr() + self.cap_t * 8 * 8 for o in outs],
+                            [w.data_ptr() for w in warps] if warps is not None else [0] * n], dtype=torch.int64).cuda()
+        cnt = torch.tensor([d.shape[0] for d in ds], dtype=torch.int32).cuda()
+        return (tab, cnt, n, warps is not None, (ds, outs, warps))      # (the last entry keeps the buffers alive)
+
+    def _launch_frames(self, table):
+        """enqueue the frame steps of several CONSECUTIVE frames as ONE launch (y7t_tracker_step_frames; `table` from frames_table): exactly what `_launch`
+        frame by frame produces -- for pipelines that hold a batch's detections before the tracker runs (bench.py, track.py --batch)"""
+        tab, cnt, n, has_warps, _ = table
+        _lib.check(self._L.y7t_tracker_step_frames(_lib.ptr(self._state), _lib.ptr(tab[0]), _lib.ptr(cnt), _lib.ptr(tab[1]), _lib.ptr(tab[2]), self.cap_t, n,
+                                                   self.threads, _lib.ptr(tab[3]) if has_warps else None, _lib.stream_ptr()))
+        self.frame_id += n
+        self._snap_cache = None
+
     def _collect(self):
         self._out_host.copy_(self._out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
