@@ -61,7 +61,7 @@ def parse():
                     help="seeded random weights of the timed detector.  conditioned (default): BatchNorm shifts ~ +2, statistics calibrated on frame 0, damped "
                          "width / height logits -- a random network that does not amplify rounding noise, so that `parity` (heads, pre-NMS candidates, boxes "
                          "against the fp32 oracle) describes the TIMED weights; chaotic: iid zero-mean weights (rounds 1-2)")
-    ap.add_argument("--tracker_launch", default="per_frame", choices=["per_frame", "frames"],
+    ap.add_argument("--tracker_launch", default="frames", choices=["per_frame", "frames"],
                     help="frames: the tracker frame steps of a step's frames as ONE launch per sequence (y7t_tracker_step_frames) instead of one launch per frame")
     ap.add_argument("--cu_reserve", type=int, default=0, help="N > 0: the tracker chain's stream owns N compute units (hipExtStreamCreateWithCUMask), the "
                     "detector's stream the rest -- the single-workgroup frame steps no longer share CUs with 256-thread convolution workgroups")

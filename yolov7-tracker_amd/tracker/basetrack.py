@@ -380,14 +380,16 @@ class BaseTracker(object):
         tab = torch.tensor([[d.data_ptr() for d in ds], [o.data_ptr() for o in outs], [o.data_ptr() + self.cap_t * 8 * 8 for o in outs],
                             [w.data_ptr() for w in warps] if warps is not None else [0] * n], dtype=torch.int64).cuda()
         cnt = torch.tensor([d.shape[0] for d in ds], dtype=torch.int32).cuda()
-        return (tab, cnt, n, warps is not None, (ds, outs, warps))      # (the last entry keeps the buffers alive)
+        nmax = max([d.shape[0] for d in ds] + [0])
+        threads = self.threads if self.threads else (1024 if nmax > 384 else 256)      # the library's rule for one frame (csrc/y7t_tracker.hip::step_threads)
+        return (tab, cnt, n, warps is not None, (ds, outs, warps), threads)      # (the buffers stay alive with the table)
 
     def _launch_frames(self, table):
         """enqueue the frame steps of several CONSECUTIVE frames as ONE launch (y7t_tracker_step_frames; `table` from frames_table): exactly what `_launch`
         frame by frame produces -- for pipelines that hold a batch's detections before the tracker runs (bench.py, track.py --batch)"""
-        tab, cnt, n, has_warps, _ = table
+        tab, cnt, n, has_warps, _, threads = table
         _lib.check(self._L.y7t_tracker_step_frames(_lib.ptr(self._state), _lib.ptr(tab[0]), _lib.ptr(cnt), _lib.ptr(tab[1]), _lib.ptr(tab[2]), self.cap_t, n,
-                                                   self.threads, _lib.ptr(tab[3]) if has_warps else None, _lib.stream_ptr()))
+                                                   threads, _lib.ptr(tab[3]) if has_warps else None, _lib.stream_ptr()))
         self.frame_id += n
         self._snap_cache = None
 
