@@ -110,6 +110,20 @@ exp_ws)
   benchsum ws nows
   ;;
 
+exp_ws4)
+  say "exp_ws4 a: hand-scheduled weights-stationary kernel: layer parity vs torch fp32, then inside the benchmarked list (teacher-forced)"
+  timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k weights_stationary > $O/t_ws.log 2>&1; echo "rc=$?" >> $O/t_ws.log; tailsum $O/t_ws.log
+  timeout 400 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_ws_pinned.log 2>&1; echo "rc=$?" >> $O/t_ws_pinned.log; tailsum $O/t_ws_pinned.log
+  say "exp_ws4 b: per-layer timing at 32 frames"
+  timeout 200 python scripts/bench_conv.py 32 > $O/b_ws.txt 2>&1
+  grep "  64->64 \|TOTAL" $O/b_ws.txt | tee -a $O/summary.txt
+  say "exp_ws4 c: issue counters of the kernel"
+  OUT=$O/pmc_ws bash scripts/pmc_kernel.sh c64_ws python scripts/forward_only.py 2 > $O/pmc_ws.txt 2>&1; grep -v "^pass" $O/pmc_ws/summary.txt | awk '{print $1, $2, $4}' | sort -u | tee -a $O/summary.txt
+  say "exp_ws4 d: bench line"
+  timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_ws.json 2> $O/bench_ws.err
+  benchsum ws
+  ;;
+
 pmc_queues)
   say "pmc_queues: TA / TCP / TCC / SQ counters of the 1x1 (80x80 1024->512), stride-2 (160x160 256->512) generic layers and the patch kernel (80x80 256->256)"
   OUT=$O/pmc_raw SHAPES="${SHAPES:-1x1 s2 patch}" bash scripts/pmc_queues.sh > $O/pmc_queues.txt 2>&1

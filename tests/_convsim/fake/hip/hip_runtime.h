@@ -14,6 +14,9 @@
 #include <vector>
 
 #define __HIP_DEVICE_COMPILE__ 1
+#define Y7T_CONVSIM 1
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __global__
 #define __device__
 #define __host__

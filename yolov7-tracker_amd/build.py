@@ -22,7 +22,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(os.path.dirname(HERE), "include")]
 # per-file overrides (the conv kernels want contraction: fp32 accumulate of fp16 products)
-FILE_FLAGS = {"y7t_conv.hip": ["-ffp-contract=fast"], "y7t_conv_patch.hip": ["-ffp-contract=fast"], "y7t_conv_patch_s2.hip": ["-ffp-contract=fast"], "y7t_conv_ws.hip": ["-ffp-contract=fast"], "y7t_post.hip": []}
+FILE_FLAGS = {"y7t_conv.hip": ["-ffp-contract=fast"], "y7t_conv_patch.hip": ["-ffp-contract=fast"], "y7t_conv_patch_s2.hip": ["-ffp-contract=fast"], "y7t_conv_ws.hip": ["-ffp-contract=fast", "-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_post.hip": []}
 
 
 def _sources():

@@ -71,17 +71,25 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     // for every piece and every store ran 695 VALU + 369 SALU per 144 MFMAs -- 52 % of the wave's cycles issuing, the matrix pipe 37 % busy), so everything
     // that does not depend on the tile is computed once.  Slots that are never read (the pad chunk of a pixel, the tail of a patch row) fetch the
     // patch's first bytes.  Tiles on the image border take the per-lane bounds check (zero fill through an out-of-range offset).
-    struct TileAt { int org, h0, w0; bool live, inner; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1) (interior tiles)
-    auto tile_at = [&](int pt) -> TileAt {
+    // Tiles are walked in order, so their coordinates are stepped, not decoded (two integer divisions per tile were ~50 scalar instructions with the matrix pipe
+    // idle): P = index of the tile's first pixel in the NHWC map, (ty, tx) = its place in the tile grid, n = tiles of this workgroup's range still ahead of it.
+    struct TileIt { int P, ty, tx, n; };
+    auto tile_it = [&](int pt) -> TileIt {
         int q = pt;
         const int txi = q % tiles_x; q /= tiles_x;
         const int tyi = q % tiles_y, b = q / tiles_y;
-        const int h0 = tyi * TH, w0 = txi * TW;
-        return TileAt{((((b * p.H + h0 - 1) * p.W + w0 - 1) * p.ldin) + p.cin_off) * 2, h0, w0, pt < pt_first + nt,
-                      tyi > 0 && tyi < tiles_y - 1 && txi > 0 && txi < tiles_x - 1};
+        return TileIt{(b * p.H + tyi * TH) * p.W + txi * TW, tyi, txi, pt_first + nt - pt};
     };
-    int pc_r[NPW], pc_x[NPW];      // (border tiles only; the compiler keeps what it needs)
-    unsigned pconst[NPW];
+    auto tile_next = [&](TileIt& it) __attribute__((always_inline)) {
+        it.P += TW; it.n -= 1;
+        if (++it.tx == tiles_x) { it.tx = 0; it.P += (TH - 1) * p.W; if (++it.ty == tiles_y) it.ty = 0; }      // (maps are whole tiles: the next image follows the last row)
+    };
+    struct TileAt { int org, ty, tx; bool live; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1)
+    auto tile_at = [&](const TileIt& it) -> TileAt { return TileAt{((it.P - p.W - 1) * p.ldin + p.cin_off) * 2, it.ty, it.tx, it.n > 0}; };
+    // per-lane constants of piece i: pconst = where its 16-byte slot sits inside the 18 x 18 patch (byte offset from the patch's first pixel); pedge = which
+    // halo sides the slot lies on (bit 0 top row, 1 bottom row, 2 left column, 3 right column), four bits per piece -- maps are whole tiles, so a slot can be
+    // outside the image only through the halo of a tile that touches that border.  Slots that are never read (pad chunk, row tail) fetch the patch's first bytes.
+    unsigned pconst[NPW], pedge_lo = 0, pedge_hi = 0;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         int I = wave + 4 * i;
@@ -91,23 +99,34 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
         const bool used = r < TH + 2 && x < TW + 2 && cs < 8;
         pconst[i] = used ? (unsigned)(((r * p.W + x) * p.ldin + cs * 8) * 2) : 0u;
-        pc_r[i] = used ? r : -0x10000; pc_x[i] = x;
+        const unsigned e = used ? (unsigned)((r == 0) | ((r == TH + 1) << 1) | ((x == 0) << 2) | ((x == TW + 1) << 3)) : 0u;
+        if (i < 8) pedge_lo |= e << (4 * i); else pedge_hi |= e << (4 * (i - 8));
     }
-    auto issue_piece = [&](int buf, const TileAt& ta, int i) __attribute__((always_inline)) {
-        const int I = (wave + 4 * i < C::PATCH_DMA) ? wave + 4 * i : C::PATCH_DMA - 1;
-        unsigned v;
-        if (ta.inner && ta.live) v = pconst[i] + (unsigned)ta.org;                       // (wave-uniform branch)
-        else {
-            const int gy = ta.h0 + pc_r[i] - 1, gx = ta.w0 + pc_x[i] - 1;
-            v = (ta.live && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? pconst[i] + (unsigned)ta.org : kOOB;
+    // the 13 source offsets of a tile's pieces, computed once per tile under ONE wave-uniform branch (the piece issue itself is then M0 + one instruction)
+    auto piece_offsets = [&](const TileAt& ta, unsigned (&pv)[NPW]) __attribute__((always_inline)) {
+        const unsigned tmask = (unsigned)((ta.ty == 0) | ((ta.ty == tiles_y - 1) << 1) | ((ta.tx == 0) << 2) | ((ta.tx == tiles_x - 1) << 3));
+        if (!ta.live) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) pv[i] = kOOB;
+        } else if (tmask == 0) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) pv[i] = pconst[i] + (unsigned)ta.org;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const unsigned e = ((i < 8 ? pedge_lo >> (4 * i) : pedge_hi >> (4 * (i - 8))) & tmask);
+                pv[i] = e ? kOOB : pconst[i] + (unsigned)ta.org;
+            }
         }
+    };
+    auto issue_piece = [&](int buf, unsigned v, int i) __attribute__((always_inline)) {
+        const int I = (wave + 4 * i < C::PATCH_DMA) ? wave + 4 * i : C::PATCH_DMA - 1;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(smem + buf * C::PATCH_BYTES + I * 1024), 16, v, 0, 0, 0);
     };
 
-    // ---- the filter bank.  Wave w owns output channels 32 (w & 1) .. +31 of the 128 pixels of tile half (w >> 1): 36 A-fragments per lane (144 VGPRs), straight
+    // ---- the filter bank.  Wave w owns output channels 32 (w & 1) .. +31 of the 128 pixels of tile half (w >> 1): 36 A-fragments per lane (144 registers), straight
     // from memory (a fragment is 1 KiB of consecutive bytes), resident for the whole launch.  (A first version gave each wave all 64 channels of 64 pixels --
-    // 288 VGPRs of weights, no room for a second accumulator set: its epilogue, ~3 000 cycles of bias + SiLU + pack per tile, ran with the matrix pipe idle,
-    // 312 us per 320^2 layer against 358 us for the multi-tile patch kernel.  Here the previous tile's epilogue is interleaved with this tile's MFMAs.) ----
+    // 288 registers of weights, no room for a second accumulator set: its epilogue, ~3 000 cycles of bias + SiLU + pack per tile, ran with the matrix pipe idle.) ----
     const int chh = wave & 1, pxh = wave >> 1;
     half8 wreg[C::NSUB];
     {
@@ -115,108 +134,174 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
 #pragma unroll
         for (int f = 0; f < C::NSUB; ++f) wreg[f] = wp[f * 128];
     }
-    if (tid < 64) ((float*)(smem + C::BIAS_OFF))[tid] = p.bias[tid];
-    const float* lbias = (const float*)(smem + C::BIAS_OFF) + chh * 32;
+    // the bias enters as the C operand of a tile's first MFMA: row 8 g + 4 (lane / 32) + e of the wave's 32 channels sits in accumulator element 4 g + e
+    floatx16 biasv;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) biasv[g * 4 + e] = p.bias[chh * 32 + 8 * g + 4 * hi32 + e];
 
+    unsigned pv[NPW];
+    TileIt itn = tile_it(pt_first), ito = itn;      // itn: the tile whose pieces are issued next (t + 2); ito: the tile whose results are stored next (t - 1)
     {
-        const TileAt t0 = tile_at(pt_first), t1 = tile_at(pt_first + 1);
+        const TileAt t0 = tile_at(itn);
+        tile_next(itn);
+        const TileAt t1 = tile_at(itn);
+        tile_next(itn);
+        piece_offsets(t0, pv);
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) issue_piece(0, t0, i);
+        for (int i = 0; i < NPW; ++i) issue_piece(0, pv[i], i);
+        piece_offsets(t1, pv);
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) issue_piece(1, t1, i);
+        for (int i = 0; i < NPW; ++i) issue_piece(1, pv[i], i);
     }
 
     // fragment base of this lane inside a patch buffer: four 32-pixel MFMA tiles of two image rows each, rows 8 pxh + 2j, + 1
     const int plane_off = (pxh * 8 + (l31 >> 4)) * RP + (l31 & 15) * PIXB + hi32 * 16;
     half_t* outp = (half_t*)p.out;
     typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-    typedef __attribute__((ext_vector_type(4))) float float4v;
+    typedef __attribute__((ext_vector_type(2))) float f2;
     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
     constexpr int NST = 8;                   // 16-byte stores per lane and tile (4 MFMA tiles x 2 group pairs): every one is issued, for every tile (the launcher
                                              // admits maps of whole 16 x 16 tiles only), so that `s_waitcnt vmcnt` can COUNT them next to the pieces
-
-    // one eighth of a finished tile: group pair gp of MFMA tile j -> bias + activation -> 8 channels of one pixel -> one 16-byte NHWC store at
-    // (wave-uniform tile / row-pair base) + (per-lane constant)
     const unsigned ovoff = (unsigned)(((((pxh * 8 + (l31 >> 4)) * p.W + (l31 & 15)) * p.ldout) + chh * 32 + 8 * hi32) * 2);
-    auto out_base = [&](int pt) -> char* {
-        int q = pt;
-        const int txi = q % tiles_x; q /= tiles_x;
-        const int tyi = q % tiles_y, b = q / tiles_y;
-        return (char*)outp + ((size_t)((b * p.H + tyi * TH) * p.W + txi * TW) * p.ldout + p.cout_off) * 2;
-    };
+    auto out_base = [&](const TileIt& it) -> char* { return (char*)outp + ((size_t)it.P * p.ldout + p.cout_off) * 2; };
     const int jstep = 2 * p.W * p.ldout * 2;      // bytes between the row pairs of consecutive MFMA tiles
-    auto store_group = [&](const floatx16 (&a)[4], char* obase, int j, int gp) __attribute__((always_inline)) {
-        unsigned w[2][2];
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            const int g = gp * 2 + gg;
-            const float4v bv = *(const float4v*)(lbias + 8 * g + 4 * hi32);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(a[j][g * 4 + e] + bv[e]);
-            half2v h0v = {(half_t)v[0], (half_t)v[1]}, h1v = {(half_t)v[2], (half_t)v[3]};
-            w[gg][0] = __builtin_bit_cast(unsigned, h0v);
-            w[gg][1] = __builtin_bit_cast(unsigned, h1v);
-        }
-        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-        const uint4v v4 = {r0[0], r1[0], r0[1], r1[1]};
-        *(uint4v*)(obase + (size_t)j * jstep + gp * 32 + ovoff) = v4;
-    };
 
-    // One tile: its 144 MFMAs into `cur`, the PREVIOUS tile's eight store groups (out of `prev`) spread between them, tile t+2's pieces spread between them.
-    // vmcnt at the top: younger than this wave's pieces of tile t are exactly what tile t-1 issued: NPW pieces (tile t+1's) and, if tile t-1 had a
-    // predecessor to store, NST stores.
-    auto tile_body = [&](int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
-        if (t >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
+    // ---- the epilogue of a finished tile as a MICRO-PROGRAM, one step per MFMA slot of the next tile.  The kernel is bound by instruction issue (one wave per
+    // SIMD, an MFMA every 32 cycles: ~7 issue slots per MFMA, a transcendental costs several), and the compiler's own schedule put the fragment reads one MFMA
+    // ahead of their use (s_waitcnt lgkmcnt(1) in front of every MFMA: the matrix pipe 40 % busy, ~74 cycles per MFMA).  So the order is spelled out: slot
+    // k = 4 s + j of a tile holds MFMA (s, j), the LDS read of fragment (s + 2, j) into the register pair that MFMA just consumed, at most ONE transcendental and
+    // one or two packed-fp32 operations of the previous tile's epilogue, and now and then a piece or a store; __builtin_amdgcn_sched_barrier(0) between slots.
+    // A store group G (8 of them per tile) = 8 values = 4 fp32 pairs of MFMA tile j = G / 2, accumulator elements 8 (G & 1) + 2 q, + 1 (pair q):
+    //   T = x * -log2(e) [pk_mul] -> E = exp2(T) [2 trans] -> D = E + 1 [pk_add] -> R = rcp(D) [2 trans] -> Y = x * R [pk_mul] -> fp16 pair [cvt_pk]
+    //   -> permlane32_swap x 2 -> one 16-byte NHWC store.
+    // Period G (slots 16 G + 1 .. 16 G + 16): the 8 exp2 then the 8 rcp of group G, its D / Y / cvt steps as their inputs appear, T of group G + 1, and the
+    // tail (Y3, cvt3, swaps, store) of group G - 1.
+    f2 T[4], E[4], D[4], R[4], Y[4];
+    unsigned Wd[4];
+    decltype(__builtin_amdgcn_permlane32_swap(0u, 0u, false, false)) sw0, sw1;
+    constexpr float NL2E = -1.44269504088896f;
+    auto xpair = [&](const floatx16 (&a)[4], int G, int q) __attribute__((always_inline)) -> f2 {
+        const int e0 = 8 * (G & 1) + 2 * q;
+        return f2{a[G >> 1][e0], a[G >> 1][e0 + 1]};
+    };
+    auto act_pre = [&](f2 x) __attribute__((always_inline)) -> f2 { return ACT == Y7T_ACT_SILU ? x * NL2E : x; };
+    auto epi_step = [&](const floatx16 (&prev)[4], char* ob, int k) __attribute__((always_inline)) {
+        if (k == 0) {
+            if (ACT == Y7T_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[q] = xpair(prev, 0, q) * NL2E;
+            }
+            return;
+        }
+        const int kk = k - 1, G = kk >> 4, i = kk & 15;
+        if (G < 8) {
+            if (ACT == Y7T_ACT_SILU) {
+                if (i < 8) E[i >> 1][i & 1] = __builtin_amdgcn_exp2f(T[i >> 1][i & 1]);
+                else R[(i - 8) >> 1][(i - 8) & 1] = __builtin_amdgcn_rcpf(D[(i - 8) >> 1][(i - 8) & 1]);
+                if (i == 2 || i == 4 || i == 6 || i == 8) D[(i - 2) >> 1] = E[(i - 2) >> 1] + 1.0f;
+                if (i == 10 || i == 12 || i == 14) Y[(i - 10) >> 1] = xpair(prev, G, (i - 10) >> 1) * R[(i - 10) >> 1];
+                if (i >= 12 && G < 7) T[i - 12] = xpair(prev, G + 1, i - 12) * NL2E;
+            } else {
+                if (i == 10 || i == 12 || i == 14) {
+                    const f2 x = xpair(prev, G, (i - 10) >> 1);
+                    Y[(i - 10) >> 1] = f2{act_t<ACT>(x[0]), act_t<ACT>(x[1])};
+                }
+            }
+            if (i == 11 || i == 13 || i == 15) {
+                const f2 y = Y[(i - 11) >> 1];
+                const half2v h = {(half_t)y[0], (half_t)y[1]};
+                Wd[(i - 11) >> 1] = __builtin_bit_cast(unsigned, h);
+            }
+        }
+        if (G >= 1 && G <= 8) {
+            const int Gp = G - 1;
+            if (i == 0) {
+                const f2 x = xpair(prev, Gp, 3);
+                Y[3] = ACT == Y7T_ACT_SILU ? x * R[3] : f2{act_t<ACT>(x[0]), act_t<ACT>(x[1])};
+            }
+            if (i == 1) {
+                const half2v h = {(half_t)Y[3][0], (half_t)Y[3][1]};
+                Wd[3] = __builtin_bit_cast(unsigned, h);
+            }
+            if (i == 2) sw0 = __builtin_amdgcn_permlane32_swap(Wd[0], Wd[2], false, false);
+            if (i == 3) sw1 = __builtin_amdgcn_permlane32_swap(Wd[1], Wd[3], false, false);
+            if (i == 4) {
+                const uint4v v4 = {sw0[0], sw1[0], sw0[1], sw1[1]};
+                *(uint4v*)(ob + (size_t)(Gp >> 1) * jstep + (Gp & 1) * 32 + ovoff) = v4;
+            }
+        }
+    };
+    constexpr int EPI_SLOTS = 16 * 8 + 1 + 5;      // the last step of the micro-program is slot 133 of 144
+
+    // One tile: its 144 MFMAs into `cur` (the bias as the C operand of the first), the PREVIOUS tile's epilogue out of `prev`, tile t+2's pieces.
+    // vmcnt at the top: younger than this wave's pieces of tile t are what tile t-1 issued -- NPW pieces (tile t+1's) and, if tile t-1 had a predecessor to
+    // store, NST stores -- and at most two late stores of tile t-2 (waiting for those as well is harmless).
+    auto tile_body = [&](const bool FIRST, int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
-        const TileAt tn = tile_at(pt_first + t + 2);
-        char* const ob = out_base(pt_first + t - 1);
+        piece_offsets(tile_at(itn), pv);
+        tile_next(itn);
+        char* const ob = FIRST ? nullptr : out_base(ito);
+        if (!FIRST) tile_next(ito);
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cur[j][e] = 0.f;
+        if (FIRST || t < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
         half8 xf[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[0][j] = *(const half8*)(pb + j * 2 * RP);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[s][j] = *(const half8*)(pb + (s & 3) * 32 + j * 2 * RP);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
-        for (int s = 0; s < C::NSUB; ++s) {
-            const int cb = s & 1;
-            if (s + 1 < C::NSUB) {           // fragments of the next substep: tap (kh, kw), 16-channel group ks
-                const int sn = s + 1, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xf[cb ^ 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
+        for (int s = 0; s < C::NSUB; ++s)
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            const int k = s * 4 + j;
+#if defined(Y7T_CONVSIM)
+            cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf[s & 1][j], s == 0 ? biasv : cur[j], 0, 0, 0);
+#else       // the MFMA spelled out: accumulators in VGPRs (the epilogue's packed-fp32 operations read them directly), the stationary weights in ACC registers
+            // (the builtin keeps the weights in VGPRs and the accumulators in ACC registers -- one v_accvgpr_read per epilogue value -- or, in VGPR form,
+            // copies every weight fragment out of the ACC file before its substep).  What the compiler cannot see through the asm is covered by construction:
+            // an accumulator is rewritten four MFMAs (>= 96 cycles) later and read by VALU code a whole tile later.
+            if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
+            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
+#endif
+            if (s + 2 < C::NSUB) {          // fragment (s + 2, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
+                const int sn = s + 2, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
+                xf[s & 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf[cb][j], cur[j], 0, 0, 0);      // (one wave per SIMD: no s_setprio)
-            if (s % 3 == 0 && s / 3 < NPW) issue_piece(nbuf, tn, s / 3);      // tile t+2's pieces: one every third substep (12) + the last one
-            if (s == C::NSUB - 2 && NPW > 12) issue_piece(nbuf, tn, 12);
-            if (t > 0 && s % 4 == 1 && s / 4 < NST) store_group(prev, ob, (s / 4) >> 1, (s / 4) & 1);      // substeps 1, 5, ..., 29
+            if (!FIRST) epi_step(prev, ob, k);
+            {       // tile t+2's pieces: two per period of the micro-program, where it has no packed operation
+                const int kk = k - 1, G = kk >> 4, i = kk & 15;
+                if (k >= 1 && (i == 5 || i == 9) && G * 2 + (i == 9) < NPW) issue_piece(nbuf, pv[G * 2 + (i == 9)], G * 2 + (i == 9));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     floatx16 accA[4], accB[4];
-    int buf = 0;
-    for (int t = 0; t < nt; t += 2) {
-        tile_body(t, buf, accA, accB);
+    tile_body(true, 0, 0, accA, accB);
+    int buf = 1;
+    for (int t = 1; t < nt; t += 2) {
+        tile_body(false, t, buf, accB, accA);
         buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
         if (t + 1 < nt) {
-            tile_body(t + 1, buf, accB, accA);
+            tile_body(false, t + 1, buf, accA, accB);
             buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's zero-filling pieces have landed before this workgroup's LDS is handed on
-    // the last tile's results (its stores overlap nothing)
-    char* const obl = out_base(pt_first + nt - 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // the tail's zero-filling pieces have landed before this workgroup's LDS is
+                                                                                           // handed on; the last MFMAs' results are readable by VALU code
+    // the last tile's results (its stores overlap nothing): the same micro-program, back to back
+    char* const obl = out_base(ito);
     if (nt & 1) {
 #pragma unroll
-        for (int g8 = 0; g8 < NST; ++g8) store_group(accA, obl, g8 >> 1, g8 & 1);
+        for (int k = 0; k < EPI_SLOTS; ++k) epi_step(accA, obl, k);
     } else {
 #pragma unroll
-        for (int g8 = 0; g8 < NST; ++g8) store_group(accB, obl, g8 >> 1, g8 & 1);
+        for (int k = 0; k < EPI_SLOTS; ++k) epi_step(accB, obl, k);
     }
 #endif
 }
