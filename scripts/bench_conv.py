@@ -19,8 +19,10 @@ for op in plan.ops:
 zeros = torch.zeros(256, dtype=torch.float16, device="cuda")
 tot_t = tot_f = 0.0
 print("%-34s %3s %9s %8s %8s %8s" % ("shape (HxW Cin->Cout k/s)", "x", "us", "TF/s", "GB/s", "blocks"))
+ONLY = os.environ.get("ONLY")      # "H,Cin,Cout,k,s": that shape only (long runs for scripts/power_sample.sh)
 for key, cnt in shapes.items():
     H, W, Cin, Cout, Cout_pad, k, s, pad, f32, in_ld, out_ld = key
+    if ONLY and [int(v) for v in ONLY.split(",")] != [H, Cin, Cout, k, s]: continue
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     K = k * k * Cin; K_pad = (K + 63) // 64 * 64
     x = torch.randn((B, H, W, in_ld), device="cuda").half()

@@ -124,6 +124,16 @@ exp_ws4)
   benchsum ws
   ;;
 
+power)
+  say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
+  for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do
+    echo "-- layer $sh" | tee -a $O/summary.txt
+    ONLY=$sh timeout 120 bash scripts/power_sample.sh $O/power_$sh.txt python scripts/bench_conv.py 32 6000 2>&1 | grep -v "^shape" | tee -a $O/summary.txt
+  done
+  echo "-- bench (200 steps)" | tee -a $O/summary.txt
+  timeout 200 bash scripts/power_sample.sh $O/power_bench.txt python bench.py --steps 200 --warmup 5 --no_cpu_baseline --no_latency_mode 2>/dev/null | cut -c1-300 | tee -a $O/summary.txt
+  ;;
+
 pmc_queues)
   say "pmc_queues: TA / TCP / TCC / SQ counters of the 1x1 (80x80 1024->512), stride-2 (160x160 256->512) generic layers and the patch kernel (80x80 256->256)"
   OUT=$O/pmc_raw SHAPES="${SHAPES:-1x1 s2 patch}" bash scripts/pmc_queues.sh > $O/pmc_queues.txt 2>&1

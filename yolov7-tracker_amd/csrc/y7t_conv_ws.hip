@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         piece_offsets(t1, pv);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) issue_piece(1, pv[i], i);
+        piece_offsets(tile_at(itn), pv);      // tile 2's, issued by the first tile body; every body leaves the next one's behind
+        tile_next(itn);
     }
 
     // fragment base of this lane inside a patch buffer: four 32-pixel MFMA tiles of two image rows each, rows 8 pxh + 2j, + 1
@@ -240,8 +242,6 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     // store, NST stores -- and at most two late stores of tile t-2 (waiting for those as well is harmless).
     auto tile_body = [&](const bool FIRST, int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
-        piece_offsets(tile_at(itn), pv);
-        tile_next(itn);
         char* const ob = FIRST ? nullptr : out_base(ito);
         if (!FIRST) tile_next(ito);
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
@@ -279,6 +279,14 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The source offsets of the NEXT body's pieces (tile t + 3), here rather than at its top: >= 13 vector instructions that touch no accumulator, between the
+        // tile's last MFMAs and whatever follows the body.  The compiler cannot see the MFMAs inside the asm statements, so it inserts no wait states for them --
+        // and at the loop's exit it copies one accumulator set onto the other's registers (VALU writes of registers the last two MFMAs are still writing:
+        // a write-after-write race that corrupted the last tile of a workgroup on the device; 8-pass MFMA -> VALU needs 11 wait states).
+        piece_offsets(tile_at(itn), pv);
+        tile_next(itn);
+        asm volatile("s_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     floatx16 accA[4], accB[4];
