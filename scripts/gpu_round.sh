@@ -124,6 +124,14 @@ exp_ws4)
   benchsum ws
   ;;
 
+exp_issue)
+  say "exp_issue a: what one wave issues in the shadow of its MFMAs (scripts/ubench/issue_model.hip)"
+  timeout 120 scripts/ubench/issue_model > $O/issue_model.txt 2>&1; cat $O/issue_model.txt | tee -a $O/summary.txt
+  say "exp_issue b: ws64 with the accumulators in arch VGPRs (default) / in ACC registers (Y7T_WS_ACC=a): parity of the latter, per-layer time of both"
+  Y7T_WS_ACC=a timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k weights_stationary > $O/t_ws_acca.log 2>&1; echo "rc=$?" >> $O/t_ws_acca.log; tailsum $O/t_ws_acca.log
+  for v in v a; do echo "-- acc=$v"; ONLY=320,64,64,3,1 Y7T_WS_ACC=$v timeout 100 python scripts/bench_conv.py 32 200 2>&1 | grep "64->64"; done | tee -a $O/summary.txt
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do

@@ -42,7 +42,10 @@ struct WsCfg {
     static constexpr int NSUB = 36;                                   // k16 substeps per tile: 9 taps x 4
 };
 
-template <int ACT>      // the activation is a template parameter: the epilogue is instantiated eight times inside each of the two tile bodies
+// ACT: the activation (the epilogue is instantiated inside each tile body).  ACCA: where the accumulators live -- 0: arch VGPRs (weights in ACC registers; the
+// epilogue's packed operations read the accumulators directly), 1: ACC registers (weights in arch VGPRs; one v_accvgpr_read per epilogue value, but the matrix
+// pipe's 16 + 16 accumulator register accesses per MFMA stay off the arch-VGPR ports the epilogue's VALU work uses) -- an A/B switch (Y7T_WS_ACC=a).
+template <int ACT, int ACCA>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = WsCfg;
@@ -265,8 +268,13 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
             // (the builtin keeps the weights in VGPRs and the accumulators in ACC registers -- one v_accvgpr_read per epilogue value -- or, in VGPR form,
             // copies every weight fragment out of the ACC file before its substep).  What the compiler cannot see through the asm is covered by construction:
             // an accumulator is rewritten four MFMAs (>= 96 cycles) later and read by VALU code a whole tile later.
-            if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
-            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
+            if (ACCA) {
+                if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(cur[j]) : "v"(wreg[s]), "v"(xf[s & 1][j]), "a"(biasv));
+                else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(cur[j]) : "v"(wreg[s]), "v"(xf[s & 1][j]));
+            } else {
+                if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
+                else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
+            }
 #endif
             if (s + 2 < C::NSUB) {          // fragment (s + 2, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
                 const int sn = s + 2, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
@@ -327,10 +335,14 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
         return Y7T_E_ARG;
     }
     static bool attr = false;
+    static int acca = 0;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        const char* e = getenv("Y7T_WS_ACC");
+        acca = e && e[0] == 'a';
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     static int ncu = -1;      // one persistent workgroup per compute unit (150 KiB of LDS each)
@@ -342,9 +354,10 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_SILU>, dim3(grid), dim3(256), C::LDS, s, a);
-    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, dim3(grid), dim3(256), C::LDS, s, a);
-    else hipLaunchKernelGGL(k_conv3x3_c64_ws<Y7T_ACT_NONE>, dim3(grid), dim3(256), C::LDS, s, a);
+    if (a.act == Y7T_ACT_SILU && acca) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 1>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 0>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0>), dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_NONE, 0>), dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("ws64<16,16>");
     return 0;
