@@ -132,6 +132,20 @@ exp_issue)
   for v in v a; do echo "-- acc=$v"; ONLY=320,64,64,3,1 Y7T_WS_ACC=$v timeout 100 python scripts/bench_conv.py 32 200 2>&1 | grep "64->64"; done | tee -a $O/summary.txt
   ;;
 
+exp_noslp)
+  say "exp_noslp a: conv translation units without SLP vectorisation (no packed-fp32 epilogue instructions) + ws64 with a plain-fp32 micro-program: parity"
+  timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -x > $O/t_det.log 2>&1; echo "rc=$?" >> $O/t_det.log; tailsum $O/t_det.log
+  timeout 600 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu > $O/t_pinned.log 2>&1; echo "rc=$?" >> $O/t_pinned.log; tailsum $O/t_pinned.log
+  say "exp_noslp b: per-layer timing at 32 frames: previous library (lib/liby7t_prev.so) vs this one, same session"
+  Y7T_LIB=$LIBD/liby7t_prev.so timeout 200 python scripts/bench_conv.py 32 > $O/b_prev.txt 2>&1
+  timeout 200 python scripts/bench_conv.py 32 > $O/b_new.txt 2>&1
+  paste <(cut -c1-52 $O/b_prev.txt) <(cut -c36-52 $O/b_new.txt) | tee -a $O/summary.txt
+  say "exp_noslp c: bench lines, previous library then this one"
+  Y7T_LIB=$LIBD/liby7t_prev.so timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_prev.json 2> $O/bench_prev.err
+  timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_new.json 2> $O/bench_new.err
+  benchsum prev new
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do

@@ -42,10 +42,7 @@ struct WsCfg {
     static constexpr int NSUB = 36;                                   // k16 substeps per tile: 9 taps x 4
 };
 
-// ACT: the activation (the epilogue is instantiated inside each tile body).  ACCA: where the accumulators live -- 0: arch VGPRs (weights in ACC registers; the
-// epilogue's packed operations read the accumulators directly), 1: ACC registers (weights in arch VGPRs; one v_accvgpr_read per epilogue value, but the matrix
-// pipe's 16 + 16 accumulator register accesses per MFMA stay off the arch-VGPR ports the epilogue's VALU work uses) -- an A/B switch (Y7T_WS_ACC=a).
-template <int ACT, int ACCA>
+template <int ACT>      // the activation is a template parameter: the epilogue is instantiated inside each tile body
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = WsCfg;
@@ -173,72 +170,68 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     auto out_base = [&](const TileIt& it) -> char* { return (char*)outp + ((size_t)it.P * p.ldout + p.cout_off) * 2; };
     const int jstep = 2 * p.W * p.ldout * 2;      // bytes between the row pairs of consecutive MFMA tiles
 
-    // ---- the epilogue of a finished tile as a MICRO-PROGRAM, one step per MFMA slot of the next tile.  The kernel is bound by instruction issue (one wave per
-    // SIMD, an MFMA every 32 cycles: ~7 issue slots per MFMA, a transcendental costs several), and the compiler's own schedule put the fragment reads one MFMA
-    // ahead of their use (s_waitcnt lgkmcnt(1) in front of every MFMA: the matrix pipe 40 % busy, ~74 cycles per MFMA).  So the order is spelled out: slot
-    // k = 4 s + j of a tile holds MFMA (s, j), the LDS read of fragment (s + 2, j) into the register pair that MFMA just consumed, at most ONE transcendental and
-    // one or two packed-fp32 operations of the previous tile's epilogue, and now and then a piece or a store; __builtin_amdgcn_sched_barrier(0) between slots.
-    // A store group G (8 of them per tile) = 8 values = 4 fp32 pairs of MFMA tile j = G / 2, accumulator elements 8 (G & 1) + 2 q, + 1 (pair q):
-    //   T = x * -log2(e) [pk_mul] -> E = exp2(T) [2 trans] -> D = E + 1 [pk_add] -> R = rcp(D) [2 trans] -> Y = x * R [pk_mul] -> fp16 pair [cvt_pk]
-    //   -> permlane32_swap x 2 -> one 16-byte NHWC store.
-    // Period G (slots 16 G + 1 .. 16 G + 16): the 8 exp2 then the 8 rcp of group G, its D / Y / cvt steps as their inputs appear, T of group G + 1, and the
-    // tail (Y3, cvt3, swaps, store) of group G - 1.
-    f2 T[4], E[4], D[4], R[4], Y[4];
+    // ---- the epilogue of a finished tile as a MICRO-PROGRAM, one step per MFMA slot of the next tile.  What a wave can issue in the shadow of its own MFMA
+    // (scripts/ubench/issue_classes.hip, profiles/r03_issue_classes.txt; a bare MFMA slot is 15.6 ns): up to two plain fp32 / integer VALU instructions and up
+    // to two transcendentals cost nothing; ONE packed-fp32 instruction (v_pk_mul / add / fma_f32) costs +9 ns -- they hold the matrix pipe off, from either
+    // wave of a SIMD -- and the compiler's SLP vectoriser had turned every epilogue of this library into them; one ds_read_b128 costs +4.7 ns (four waves x 1 KiB
+    // per 32-cycle slot IS the LDS bandwidth of a CU).  The compiler's own schedule had also put the fragment reads one MFMA ahead of their use (s_waitcnt
+    // lgkmcnt(1) in front of every MFMA).  So the order is spelled out: slot k = 4 s + j of a tile holds MFMA (s, j), the LDS read of fragment (s + 2, j) into the
+    // registers that MFMA just consumed, at most ONE transcendental and TWO plain VALU instructions of the previous tile's epilogue, now and then a piece or a
+    // store; __builtin_amdgcn_sched_barrier(0) between slots; the translation unit is compiled with -fno-slp-vectorize.
+    // A store group G (8 of them per tile) = the 8 accumulator elements 8 (G & 1) + v of MFMA tile G / 2:
+    //   T = x * -log2(e) -> E = exp2(T) [trans] -> D = E + 1 -> R = rcp(D) [trans] -> Y = x * R -> fp16 pairs [cvt_pk] -> permlane32_swap x 2 -> one 16-byte store.
+    // Period G = slots 4 + 16 G + i, i = 0 .. 15: E_v at i = v, R_v at i = 8 + v; the plain steps as their inputs appear (table below), T of group G + 1, and the tail
+    // of group G - 1 (Y6, Y7, cvt3, swaps, store) in its first five slots.
+    float T[8], ED[8], R[8], Y[8];
     unsigned Wd[4];
     decltype(__builtin_amdgcn_permlane32_swap(0u, 0u, false, false)) sw0, sw1;
     constexpr float NL2E = -1.44269504088896f;
-    auto xpair = [&](const floatx16 (&a)[4], int G, int q) __attribute__((always_inline)) -> f2 {
-        const int e0 = 8 * (G & 1) + 2 * q;
-        return f2{a[G >> 1][e0], a[G >> 1][e0 + 1]};
+    constexpr bool SILU = ACT == Y7T_ACT_SILU;
+    auto xval = [&](const floatx16 (&a)[4], int G, int v) __attribute__((always_inline)) -> float { return a[G >> 1][8 * (G & 1) + v]; };
+    auto cvt2 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+        const half2v h = {(half_t)lo, (half_t)hi};
+        return __builtin_bit_cast(unsigned, h);
     };
-    auto act_pre = [&](f2 x) __attribute__((always_inline)) -> f2 { return ACT == Y7T_ACT_SILU ? x * NL2E : x; };
+    constexpr int EPI_PRE = 4;                      // slots 0 .. 3: T of group 0, two per slot
+    constexpr int EPI_SLOTS = EPI_PRE + 16 * 8 + 5; // the last step (group 7's store) is slot 136 of 144
     auto epi_step = [&](const floatx16 (&prev)[4], char* ob, int k) __attribute__((always_inline)) {
-        if (k == 0) {
-            if (ACT == Y7T_ACT_SILU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) T[q] = xpair(prev, 0, q) * NL2E;
-            }
+        if (k < EPI_PRE) {
+            if (SILU) { T[2 * k] = xval(prev, 0, 2 * k) * NL2E; T[2 * k + 1] = xval(prev, 0, 2 * k + 1) * NL2E; }
             return;
         }
-        const int kk = k - 1, G = kk >> 4, i = kk & 15;
+        const int kk = k - EPI_PRE, G = kk >> 4, i = kk & 15;
         if (G < 8) {
-            if (ACT == Y7T_ACT_SILU) {
-                if (i < 8) E[i >> 1][i & 1] = __builtin_amdgcn_exp2f(T[i >> 1][i & 1]);
-                else R[(i - 8) >> 1][(i - 8) & 1] = __builtin_amdgcn_rcpf(D[(i - 8) >> 1][(i - 8) & 1]);
-                if (i == 2 || i == 4 || i == 6 || i == 8) D[(i - 2) >> 1] = E[(i - 2) >> 1] + 1.0f;
-                if (i == 10 || i == 12 || i == 14) Y[(i - 10) >> 1] = xpair(prev, G, (i - 10) >> 1) * R[(i - 10) >> 1];
-                if (i >= 12 && G < 7) T[i - 12] = xpair(prev, G + 1, i - 12) * NL2E;
-            } else {
-                if (i == 10 || i == 12 || i == 14) {
-                    const f2 x = xpair(prev, G, (i - 10) >> 1);
-                    Y[(i - 10) >> 1] = f2{act_t<ACT>(x[0]), act_t<ACT>(x[1])};
+            if (SILU) {
+                if (i < 8) ED[i] = __builtin_amdgcn_exp2f(T[i]);
+                else R[i - 8] = __builtin_amdgcn_rcpf(ED[i - 8]);
+                if (i >= 1 && i <= 8) ED[i - 1] = ED[i - 1] + 1.0f;                                   // D_v one slot behind E_v
+                if (i >= 9 && i <= 14) Y[i - 9] = xval(prev, G, i - 9) * R[i - 9];                    // Y_0 .. Y_5 one slot behind R_v
+                if (G < 7) {                                                                           // T of the next group: slots 5 - 10, 12, 14
+                    const int tv = (i >= 5 && i <= 10) ? i - 5 : i == 12 ? 6 : i == 14 ? 7 : -1;
+                    if (tv >= 0) T[tv] = xval(prev, G + 1, tv) * NL2E;
                 }
+            } else {
+                if (i >= 9 && i <= 14) Y[i - 9] = act_t<ACT>(xval(prev, G, i - 9));
             }
-            if (i == 11 || i == 13 || i == 15) {
-                const f2 y = Y[(i - 11) >> 1];
-                const half2v h = {(half_t)y[0], (half_t)y[1]};
-                Wd[(i - 11) >> 1] = __builtin_bit_cast(unsigned, h);
-            }
+            if (i == 11) Wd[0] = cvt2(Y[0], Y[1]);
+            if (i == 13) Wd[1] = cvt2(Y[2], Y[3]);
+            if (i == 15) Wd[2] = cvt2(Y[4], Y[5]);
         }
-        if (G >= 1 && G <= 8) {
+        if (G >= 1 && G <= 8) {      // the tail of group G - 1
             const int Gp = G - 1;
             if (i == 0) {
-                const f2 x = xpair(prev, Gp, 3);
-                Y[3] = ACT == Y7T_ACT_SILU ? x * R[3] : f2{act_t<ACT>(x[0]), act_t<ACT>(x[1])};
+                Y[6] = SILU ? xval(prev, Gp, 6) * R[6] : act_t<ACT>(xval(prev, Gp, 6));
+                Y[7] = SILU ? xval(prev, Gp, 7) * R[7] : act_t<ACT>(xval(prev, Gp, 7));
             }
-            if (i == 1) {
-                const half2v h = {(half_t)Y[3][0], (half_t)Y[3][1]};
-                Wd[3] = __builtin_bit_cast(unsigned, h);
-            }
-            if (i == 2) sw0 = __builtin_amdgcn_permlane32_swap(Wd[0], Wd[2], false, false);
-            if (i == 3) sw1 = __builtin_amdgcn_permlane32_swap(Wd[1], Wd[3], false, false);
+            if (i == 1) Wd[3] = cvt2(Y[6], Y[7]);
+            if (i == 2) sw0 = __builtin_amdgcn_permlane32_swap(Wd[0], Wd[2], false, false);      // pairs (e 0,1) of the two 4-row groups
+            if (i == 3) sw1 = __builtin_amdgcn_permlane32_swap(Wd[1], Wd[3], false, false);      // pairs (e 2,3)
             if (i == 4) {
                 const uint4v v4 = {sw0[0], sw1[0], sw0[1], sw1[1]};
                 *(uint4v*)(ob + (size_t)(Gp >> 1) * jstep + (Gp & 1) * 32 + ovoff) = v4;
             }
         }
     };
-    constexpr int EPI_SLOTS = 16 * 8 + 1 + 5;      // the last step of the micro-program is slot 133 of 144
 
     // One tile: its 144 MFMAs into `cur` (the bias as the C operand of the first), the PREVIOUS tile's epilogue out of `prev`, tile t+2's pieces.
     // vmcnt at the top: younger than this wave's pieces of tile t are what tile t-1 issued -- NPW pieces (tile t+1's) and, if tile t-1 had a predecessor to
@@ -268,22 +261,17 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
             // (the builtin keeps the weights in VGPRs and the accumulators in ACC registers -- one v_accvgpr_read per epilogue value -- or, in VGPR form,
             // copies every weight fragment out of the ACC file before its substep).  What the compiler cannot see through the asm is covered by construction:
             // an accumulator is rewritten four MFMAs (>= 96 cycles) later and read by VALU code a whole tile later.
-            if (ACCA) {
-                if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(cur[j]) : "v"(wreg[s]), "v"(xf[s & 1][j]), "a"(biasv));
-                else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(cur[j]) : "v"(wreg[s]), "v"(xf[s & 1][j]));
-            } else {
-                if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
-                else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
-            }
+            if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
+            else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
 #endif
             if (s + 2 < C::NSUB) {          // fragment (s + 2, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
                 const int sn = s + 2, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
                 xf[s & 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
             }
             if (!FIRST) epi_step(prev, ob, k);
-            {       // tile t+2's pieces: two per period of the micro-program, where it has no packed operation
-                const int kk = k - 1, G = kk >> 4, i = kk & 15;
-                if (k >= 1 && (i == 5 || i == 9) && G * 2 + (i == 9) < NPW) issue_piece(nbuf, pv[G * 2 + (i == 9)], G * 2 + (i == 9));
+            {       // tile t+2's pieces: two per period of the micro-program, in slots that carry one plain instruction
+                const int kk = k - EPI_PRE, G = kk >> 4, i = kk & 15;
+                if (k >= EPI_PRE && (i == 11 || i == 15) && G * 2 + (i == 15) < NPW) issue_piece(nbuf, pv[G * 2 + (i == 15)], G * 2 + (i == 15));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -335,14 +323,10 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
         return Y7T_E_ARG;
     }
     static bool attr = false;
-    static int acca = 0;
     if (!attr) {
-        const char* e = getenv("Y7T_WS_ACC");
-        acca = e && e[0] == 'a';
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     static int ncu = -1;      // one persistent workgroup per compute unit (150 KiB of LDS each)
@@ -354,10 +338,9 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    if (a.act == Y7T_ACT_SILU && acca) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 1>), dim3(grid), dim3(256), C::LDS, s, a);
-    else if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 0>), dim3(grid), dim3(256), C::LDS, s, a);
-    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0>), dim3(grid), dim3(256), C::LDS, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_NONE, 0>), dim3(grid), dim3(256), C::LDS, s, a);
+    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("ws64<16,16>");
     return 0;
