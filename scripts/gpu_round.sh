@@ -146,6 +146,15 @@ exp_noslp)
   benchsum prev new
   ;;
 
+exp_clock)
+  say "exp_clock a: shader clock per kernel of the per-layer benchmark at 32 frames (GRBM_GUI_ACTIVE / 8 / duration)"
+  OUT=$O bash scripts/clock_probe.sh python scripts/bench_conv.py 32 10 > $O/clock_probe.log 2>&1; tail -40 $O/clock_probe.log | cut -c1-110 | tee -a $O/summary.txt
+  say "exp_clock b: issue counters of the ws64 kernel on the 320 x 320 layer at 32 frames"
+  ONLY=320,64,64,3,1 OUT=$O/pmc_ws32 bash scripts/pmc_kernel.sh c64_ws python scripts/bench_conv.py 32 2 > $O/pmc_ws32.txt 2>&1; awk '{print $(NF-2), $NF}' $O/pmc_ws32/summary.txt | tee -a $O/summary.txt
+  say "exp_clock c: what the matrix pipe sustains on random operands by operand ORDER (scripts/ubench/mfma_patterns.hip)"
+  timeout 100 scripts/ubench/mfma_patterns 2>&1 | tee -a $O/summary.txt
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do
