@@ -155,6 +155,11 @@ exp_clock)
   timeout 100 scripts/ubench/mfma_patterns 2>&1 | tee -a $O/summary.txt
   ;;
 
+exp_wsprobe)
+  say "exp_wsprobe: the ws64 layer by data (operand power), layout (dense / slices of wider tensors) and working set"
+  timeout 300 python scripts/ws_probe.py > $O/ws_probe.txt 2>&1; grep -v amdgpu.ids $O/ws_probe.txt | tee -a $O/summary.txt
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do
