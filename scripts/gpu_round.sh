@@ -160,6 +160,11 @@ exp_wsprobe)
   timeout 300 python scripts/ws_probe.py > $O/ws_probe.txt 2>&1; grep -v amdgpu.ids $O/ws_probe.txt | tee -a $O/summary.txt
   ;;
 
+exp_wsabl)
+  say "exp_wsabl: timing ablations of the ws64 kernel (wrong results): 1 no epilogue, 2 no pieces, 4 no fragment reads, 8 no wait / barrier; 320 x 320, 32 frames"
+  for a in 0 1 2 4 8 3 7 15; do echo "-- ablate $a"; Y7T_WS_ABLATE=$a QUICK=1 timeout 100 python scripts/ws_probe.py 2>&1 | grep -v amdgpu.ids; done | tee -a $O/summary.txt
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do

@@ -32,8 +32,13 @@ def run(H, B, in_ld, out_ld, data):
     print("%4dx%-4d B=%-3d ld %3d->%-3d %-5s  %8.1f us  %6.2f us/round  %7.1f TFLOP/s  (%d tiles, %d rounds, %.0f MB in + %.0f MB out touched)"
           % (H, H, B, in_ld, out_ld, data, us, us / rounds, 2.0 * B * H * H * 64 * 576 / us / 1e6, tiles, rounds, B * H * H * 128 / 1e6, B * H * H * 128 / 1e6))
     assert L.y7t_last_kernel().decode().startswith("ws64")
+    sys.stdout.flush()
 
 
+if os.environ.get("QUICK"):       # one line per data kind (ablation sweeps: Y7T_WS_ABLATE=n QUICK=1)
+    for data in ("randn", "zeros"):
+        run(320, 32, 256, 256, data)
+    sys.exit(0)
 for data in ("randn", "zeros"):
     for (in_ld, out_ld) in ((64, 64), (256, 64), (64, 256), (256, 256)):
         run(320, 32, in_ld, out_ld, data)

@@ -42,7 +42,9 @@ struct WsCfg {
     static constexpr int NSUB = 36;                                   // k16 substeps per tile: 9 taps x 4
 };
 
-template <int ACT>      // the activation is a template parameter: the epilogue is instantiated inside each tile body
+// ACT: the activation, a template parameter (the epilogue is instantiated inside each tile body).  ABL: timing ablations with WRONG results (Y7T_WS_ABLATE, scripts/ws_probe.py):
+// 1 no interleaved epilogue (no stores either), 2 no pieces in the loop (the ring keeps the prologue's tiles), 4 no fragment reads, 8 no vmcnt wait / barrier per tile.
+template <int ACT, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = WsCfg;
@@ -241,9 +243,11 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         char* const ob = FIRST ? nullptr : out_base(ito);
         if (!FIRST) tile_next(ito);
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
+        if (!(ABL & 8)) {
         if (FIRST || t < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
-        __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
+        __builtin_amdgcn_s_barrier();
+        }          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
         half8 xf[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -264,14 +268,14 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
             if (s == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]), "v"(biasv));
             else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cur[j]) : "a"(wreg[s]), "v"(xf[s & 1][j]));
 #endif
-            if (s + 2 < C::NSUB) {          // fragment (s + 2, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
+            if (s + 2 < C::NSUB && !(ABL & 4)) {          // fragment (s + 2, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
                 const int sn = s + 2, tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
                 xf[s & 1][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
             }
-            if (!FIRST) epi_step(prev, ob, k);
+            if (!FIRST && !(ABL & 1)) epi_step(prev, ob, k);
             {       // tile t+2's pieces: two per period of the micro-program, in slots that carry one plain instruction
                 const int kk = k - EPI_PRE, G = kk >> 4, i = kk & 15;
-                if (k >= EPI_PRE && (i == 11 || i == 15) && G * 2 + (i == 15) < NPW) issue_piece(nbuf, pv[G * 2 + (i == 15)], G * 2 + (i == 15));
+                if (!(ABL & 2) && k >= EPI_PRE && (i == 11 || i == 15) && G * 2 + (i == 15) < NPW) issue_piece(nbuf, pv[G * 2 + (i == 15)], G * 2 + (i == 15));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -338,6 +342,23 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("Y7T_WS_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl && a.act == Y7T_ACT_SILU) {
+#define Y7T_WS_ABL_CASE(N) \
+        case N: \
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
+            hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, N>), dim3(grid), dim3(256), C::LDS, s, a); \
+            break;
+        switch (abl) {
+            Y7T_WS_ABL_CASE(1) Y7T_WS_ABL_CASE(2) Y7T_WS_ABL_CASE(4) Y7T_WS_ABL_CASE(8) Y7T_WS_ABL_CASE(3) Y7T_WS_ABL_CASE(7) Y7T_WS_ABL_CASE(15)
+            default: y7t_set_error("conv: unknown Y7T_WS_ABLATE value"); return Y7T_E_ARG;
+        }
+#undef Y7T_WS_ABL_CASE
+        Y7T_LAUNCH_CHECK();
+        y7t_note_kernel("ws64<16,16> ablated");
+        return 0;
+    }
     if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
     else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
     else hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
