@@ -165,6 +165,13 @@ exp_wsabl)
   for a in ${ABLS:-0 1 2 3 16 32 18 34}; do echo "-- ablate $a"; Y7T_WS_ABLATE=$a QUICK=1 timeout 100 python scripts/ws_probe.py 2>&1 | grep -v amdgpu.ids; done | tee -a $O/summary.txt
   ;;
 
+exp_latency)
+  say "exp_latency a: per-layer timing of the launch list at ONE frame"
+  timeout 200 python scripts/bench_conv.py 1 50 > $O/b_one_frame.txt 2>&1; grep -v amdgpu.ids $O/b_one_frame.txt | tee -a $O/summary.txt
+  say "exp_latency b: kernel trace of the batch-1 latency mode (uint8 host frames, hipGraph replay)"
+  OUT=$O bash scripts/latency_trace.sh > $O/latency_trace.log 2>&1; cat $O/latency_trace.txt | cut -c1-120 | tee -a $O/summary.txt; tail -3 $O/latency_mode_under_rocprof.log | tee -a $O/summary.txt
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do

@@ -53,6 +53,8 @@ def run(mode, graph):
     return N / tot
 
 
+ONLY = os.environ.get("ONLY")      # e.g. "u8,1": that combination only (scripts/latency_trace.sh)
 for mode in ("f32", "u8", "u8_resident"):
     for graph in (0, 1):
+        if ONLY and ONLY != "%s,%d" % (mode, graph): continue
         print("latency mode  input=%-12s hipgraph=%d  ->  %.1f fps (%.2f ms/frame)" % (mode, graph, run(mode, graph), 1e3 / run(mode, graph)))
