@@ -44,7 +44,7 @@ struct WsCfg {
 
 // ACT: the activation, a template parameter (the epilogue is instantiated inside each tile body).  ABL: timing ablations with WRONG results (Y7T_WS_ABLATE, scripts/ws_probe.py):
 // 1 no interleaved epilogue (no stores either), 2 no pieces in the loop (the ring keeps the prologue's tiles), 4 no fragment reads, 8 no vmcnt wait / barrier per tile,
-// 16 the epilogue's arithmetic without its stores, 32 its stores (of whatever the registers hold) without the arithmetic.
+// 16 the epilogue's arithmetic without its stores.
 template <int ACT, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -198,14 +198,6 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     constexpr int EPI_PRE = 4;                      // slots 0 .. 3: T of group 0, two per slot
     constexpr int EPI_SLOTS = EPI_PRE + 16 * 8 + 5; // the last step (group 7's store) is slot 136 of 144
     auto epi_step = [&](const floatx16 (&prev)[4], char* ob, int k) __attribute__((always_inline)) {
-        if (ABL & 32) {
-            if (k >= EPI_PRE + 16 && ((k - EPI_PRE) & 15) == 4) {
-                const int Gp = ((k - EPI_PRE) >> 4) - 1;
-                const uint4v v4 = {sw0[0], sw1[0], sw0[1], sw1[1]};
-                *(uint4v*)(ob + (size_t)(Gp >> 1) * jstep + (Gp & 1) * 32 + ovoff) = v4;
-            }
-            return;
-        }
         if (k < EPI_PRE) {
             if (SILU) { T[2 * k] = xval(prev, 0, 2 * k) * NL2E; T[2 * k + 1] = xval(prev, 0, 2 * k + 1) * NL2E; }
             return;
@@ -361,7 +353,7 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, N>), dim3(grid), dim3(256), C::LDS, s, a); \
             break;
         switch (abl) {
-            Y7T_WS_ABL_CASE(1) Y7T_WS_ABL_CASE(2) Y7T_WS_ABL_CASE(3) Y7T_WS_ABL_CASE(16) Y7T_WS_ABL_CASE(32) Y7T_WS_ABL_CASE(18) Y7T_WS_ABL_CASE(34)
+            Y7T_WS_ABL_CASE(1) Y7T_WS_ABL_CASE(2) Y7T_WS_ABL_CASE(3) Y7T_WS_ABL_CASE(4) Y7T_WS_ABL_CASE(8) Y7T_WS_ABL_CASE(16) Y7T_WS_ABL_CASE(18)
             default: y7t_set_error("conv: unknown Y7T_WS_ABLATE value"); return Y7T_E_ARG;
         }
 #undef Y7T_WS_ABL_CASE
