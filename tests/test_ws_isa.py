@@ -1,0 +1,109 @@
+"""Static checks on the gfx950 instruction stream of the weights-stationary kernel (hipcc cross-compiles without a GPU).
+
+The kernel writes its MFMAs as asm statements (accumulators in arch VGPRs, weights in ACC registers), so the compiler's hazard recogniser does not see them:
+the first device run of that form copied accumulator registers at the loop exit while the last MFMAs of a tile were still writing them.  What protects the
+kernel now is structural -- >= 11 wait states of instructions that touch no accumulator behind every tile's last MFMA -- and this test pins it, together with
+the properties the schedule was built for: no packed-fp32 VALU instructions (they hold the matrix pipe off, profiles/r03_issue_classes.txt), no scratch, one
+LDS fragment read and at most one transcendental per MFMA slot.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _regs(tok):
+    """VGPR numbers named by an operand token: v7, v[4:7]"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    import importlib
+    build = importlib.import_module("yolov7_tracker_amd.build")
+    out = str(tmp_path_factory.mktemp("isa") / "ws.s")
+    src = os.path.join(build.CSRC, "y7t_conv_ws.hip")
+    cmd = [HIPCC] + [f for f in build.FLAGS if f != "-fPIC"] + build.FILE_FLAGS["y7t_conv_ws.hip"] + ["-S", "--cuda-device-only", "-o", out, src]
+    subprocess.run(cmd, check=True, capture_output=True)
+    text = open(out).read()
+    ks = {}
+    for m in re.finditer(r"^(_ZN\S*k_conv3x3_c64_ws\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        body = [l.strip() for l in m.group(2).split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        ks[m.group(1)] = body
+    meta = {n: (int(re.search(r"\.name:\s+%s\n.*?\.private_segment_fixed_size:\s+(\d+)" % re.escape(n), text, re.S).group(1)),
+                int(re.search(r"\.name:\s+%s\n.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(n), text, re.S).group(1))) for n in ks}
+    return ks, meta
+
+
+def _default(ks):
+    d = {n: b for n, b in ks.items() if re.search(r"wsILi\dELi0EE", n)}          # ABL = 0 instances (one per activation)
+    assert len(d) == 3, sorted(ks)
+    return d
+
+
+def test_no_packed_fp32_no_scratch(kernels):
+    ks, meta = kernels
+    d = _default(ks)
+    assert len(d) == 3
+    for n, body in d.items():
+        assert not [i for i in body if re.match(r"v_pk_(mul|add|fma)_f32", i)], n
+        assert not [i for i in body if i.startswith("scratch_")], n
+        assert meta[n] == (0, 0), (n, meta[n])
+
+
+def test_tile_bodies_have_the_spelled_out_slot_structure(kernels):
+    ks, _ = kernels
+    for n, body in _default(ks).items():
+        bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
+        assert len(bars) == 3, (n, len(bars))                                     # first tile, and the two alternating bodies of the loop
+        for bi, b0 in enumerate(bars):
+            b1 = bars[bi + 1] if bi + 1 < len(bars) else len(body)
+            seg = body[b0:b1]
+            mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]
+            assert len(mf) == 144, (n, bi, len(mf))
+            seg = seg[:mf[-1] + 1]
+            assert sum(ins.startswith("ds_read_b128") for ins in seg) == 144                      # 8 up front + one behind each of the first 136 MFMAs
+            assert sum(ins.startswith("buffer_load_dwordx4") for ins in seg) == 13               # the pieces of tile t + 2
+            assert sum(ins.startswith("global_store_dwordx4") for ins in seg) == (0 if bi == 0 else 8)
+            # a slot holds one transcendental and at most two other VALU instructions; the MFMA may sit anywhere inside its slot, so between two
+            # consecutive MFMAs of the steady state (slots 8 .. 135) there are at most two slots' worth
+            for a, b in zip(mf[8:136], mf[9:137]):
+                slot = seg[a + 1:b]
+                assert sum(ins.startswith(("v_exp_f32", "v_rcp_f32")) for ins in slot) <= 2, (n, bi, slot)
+                assert sum(ins.startswith("v_") and not ins.startswith(("v_exp_f32", "v_rcp_f32")) for ins in slot) <= 6, (n, bi, slot)
+
+
+def test_nothing_touches_an_accumulator_for_eleven_wait_states_behind_a_tiles_last_mfma(kernels):
+    ks, _ = kernels
+    for n, body in _default(ks).items():
+        bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
+        for bi, b0 in enumerate(bars):
+            b1 = bars[bi + 1] if bi + 1 < len(bars) else len(body)
+            seg = body[b0:b1]
+            mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]
+            acc = set()
+            for i in mf[-4:]:
+                acc |= _regs(seg[i].split()[1].rstrip(","))                        # the four accumulators of the body (vdst of its last four MFMAs)
+            assert len(acc) == 64
+            waited, j = 0, mf[-1] + 1
+            flat = body[b0 + j:]                                                    # follow the fall-through path past the body's end
+            for ins in flat:
+                if waited >= 11:
+                    break
+                ops = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", ins)
+                touched = set().union(*[_regs(o) for o in ops]) if ops else set()
+                assert not (touched & acc), (n, bi, ins)
+                m = re.match(r"s_nop (\d+)", ins)
+                waited += (int(m.group(1)) + 1) if m else 1
+            assert waited >= 11
