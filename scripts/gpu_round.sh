@@ -172,6 +172,16 @@ exp_latency)
   OUT=$O bash scripts/latency_trace.sh > $O/latency_trace.log 2>&1; cat $O/latency_trace.txt | cut -c1-120 | tee -a $O/summary.txt; tail -3 $O/latency_mode_under_rocprof.log | tee -a $O/summary.txt
   ;;
 
+exp_arena)
+  say "exp_arena a: the tracker's index lists in LDS for the length of a frames launch: tracker tests on the device"
+  timeout 600 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x > $O/t_trk.log 2>&1; echo "rc=$?" >> $O/t_trk.log; tailsum $O/t_trk.log
+  say "exp_arena b: bench lines (cfg2, cfg3) with the arena (default) and without (Y7T_TRACKER_ARENA=0), same session"
+  for w in cfg2 cfg3; do for a in 1 0; do
+    Y7T_TRACKER_ARENA=$a timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode --workload $w > $O/bench_${w}_arena$a.json 2> $O/bench_${w}_arena$a.err
+  done; done
+  benchsum cfg2_arena1 cfg2_arena0 cfg3_arena1 cfg3_arena0
+  ;;
+
 power)
   say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
   for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do

@@ -38,6 +38,8 @@ def lib():
         L.hs_tracker_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.hs_kf_gmc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_tracker_status.argtypes = [ctypes.c_void_p]
+        L.hs_arena_begin.argtypes = [ctypes.c_void_p]
+        L.hs_arena_end.argtypes = [ctypes.c_void_p]
         L.hs_lapjv.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_lapsap.argtypes = L.hs_lapjv.argtypes
         L.hs_laplit.argtypes = L.hs_lapjv.argtypes
@@ -129,6 +131,15 @@ class HostSimTracker:
         return [(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in self.out[:cnt]]
 
 
-def run(kind, dets_per_frame, warps=None, **kw):
+def run(kind, dets_per_frame, warps=None, arena_frames=0, **kw):
+    """arena_frames > 0: the frames run in groups of that many with the index lists in the launch-long arena (y7t_arena_load ... frames ... y7t_arena_store),
+    like the frames of one k_tracker_step_frames launch on the device"""
     trk = HostSimTracker(kind, **kw)
-    return [trk.update(d, None if warps is None else warps[i]) for i, d in enumerate(dets_per_frame)]
+    out = []
+    for i, d in enumerate(dets_per_frame):
+        if arena_frames and i % arena_frames == 0:
+            assert lib().hs_arena_begin(trk.blob.ctypes.data)
+        out.append(trk.update(d, None if warps is None else warps[i]))
+        if arena_frames and (i % arena_frames == arena_frames - 1 or i == len(dets_per_frame) - 1):
+            lib().hs_arena_end(trk.blob.ctypes.data)
+    return out

@@ -18,7 +18,15 @@ static int g_next_stat[4] = {0};
 // so the placement logic (work arrays / cost matrix / candidate lists in fast scratch when they fit) runs on the host too
 static char g_fast[160 * 1024] __attribute__((aligned(64)));
 static unsigned g_fast_bytes = 0;
-static Y7TExec hs_ex() { Y7TExec e; e.tid = 0; e.nt = 1; e.rv = 0; e.ri = 0; e.fast = g_fast_bytes ? g_fast : 0; e.fast_bytes = g_fast_bytes; return e; }
+// the launch-long home of the index lists (LDS on the device, k_tracker_step_frames): hs_arena_begin(blob) loads the lists into it and every step until
+// hs_arena_end(blob) runs on them, like the frames of one device launch
+static char g_arena[160 * 1024] __attribute__((aligned(64)));
+static unsigned g_arena_bytes = 0;
+static Y7TExec hs_ex() {
+    Y7TExec e; e.tid = 0; e.nt = 1; e.rv = 0; e.ri = 0; e.fast = g_fast_bytes ? g_fast : 0; e.fast_bytes = g_fast_bytes;
+    e.arena = g_arena_bytes ? g_arena : 0; e.arena_bytes = g_arena_bytes;
+    return e;
+}
 
 extern "C" {
 size_t hs_tracker_bytes(int cap_t, int cap_d) { return y7t_trk_layout(cap_t, cap_d).total; }
@@ -38,6 +46,20 @@ int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int 
 }
 void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(H, mean, cov); }
 
+int hs_arena_begin(void* blob) {
+    const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;
+    const size_t need = y7t_arena_bytes(h->cfg.cap_t, h->cfg.cap_d);
+    if (need > sizeof(g_arena)) return 0;
+    memset(g_arena, 0xA5, sizeof(g_arena));      // (nothing may depend on what the arena held before the load)
+    g_arena_bytes = (unsigned)sizeof(g_arena);
+    y7t_arena_load(hs_ex(), blob);
+    return 1;
+}
+void hs_arena_end(void* blob) {
+    if (!g_arena_bytes) return;
+    y7t_arena_store(hs_ex(), blob);
+    g_arena_bytes = 0;
+}
 int hs_tracker_status(void* blob) { return ((Y7TTrkHdr*)blob)->status; }
 int hs_literal_calls() { return g_literal_calls; }
 void hs_set_fast_bytes(int n) { g_fast_bytes = n < 0 ? 0 : (n > (int)sizeof(g_fast) ? (unsigned)sizeof(g_fast) : (unsigned)n); }

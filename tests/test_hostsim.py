@@ -18,6 +18,16 @@ def test_hostsim_tracker_matches_reference_golden(name):
     util.assert_same_tracks(got, want, name)
 
 
+@pytest.mark.parametrize("name", util.TRACKER_CASES)
+@pytest.mark.parametrize("frames", [1, 7, 32])
+def test_hostsim_tracker_with_launch_long_list_arena_matches_reference_golden(name, frames):
+    """the frames of one k_tracker_step_frames launch keep the pool's index lists in workgroup memory (y7t_arena_load / y7t_arena_store around them): same
+    tracks as the reference, for launches of 1, 7 and 32 frames (the arena is poisoned before every load)"""
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    got = hs.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name), arena_frames=frames)
+    util.assert_same_tracks(got, want, "%s, arena over %d frames" % (name, frames))
+
+
 @pytest.mark.parametrize("name", util.DEEPSORT_CASES)
 def test_hostsim_deepsort_matches_reference_golden(name):
     """DeepSORT's workgroup program (csrc/y7t_track_deepsort.h): matching cascade over the gated appearance cost, the IoU fallbacks, the
@@ -207,6 +217,8 @@ def test_hostsim_tracker_equals_oracle_on_random_scenes(kind, fmt):
         want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
         got = hs.run(kind, dets, kalman_format=fmt, warps=warps)
         util.assert_same_tracks(got, want, "%s/%s scene %d (%d objects, %d frames, gap %d)" % (kind, fmt, scene, n_obj, n_frames, gap))
+        got = hs.run(kind, dets, kalman_format=fmt, warps=warps, arena_frames=1 + scene % 5)      # the same with the index lists in the launch-long arena
+        util.assert_same_tracks(got, want, "%s/%s scene %d, list arena" % (kind, fmt, scene))
 
 
 def test_hostsim_cfg3_full_size_botsort_equals_oracle():

@@ -48,6 +48,8 @@ struct Y7TExec {
     int* ri;
     char* fast;         // workgroup-private fast scratch (LDS) or null
     size_t fast_bytes;
+    char* arena;        // workgroup-private home of the step's index lists for the duration of a launch (LDS; y7t_track_step.h: y7t_arena_*) or null
+    size_t arena_bytes;
 };
 
 Y7T_FN void y7t_sync(const Y7TExec&) {

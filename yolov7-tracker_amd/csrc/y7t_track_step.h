@@ -103,6 +103,51 @@ Y7T_FN Y7TTrk y7t_trk_bind(void* blob, int cap_t, int cap_d) {
     return s;
 }
 
+// ---- the index lists in workgroup memory for the length of a launch -------------------------------------------------------------------------
+// A frame step is ~60 barrier-separated passes over short integer lists (tracked / lost / per-frame work lists, marks, assignment vectors); every barrier
+// waits for the pass's global stores to be acknowledged (~1-2 us beside a running detector), which is most of the step's time at 80 objects.  A kernel that
+// runs many frames of one tracker (k_tracker_step_frames) therefore keeps those lists in LDS: y7t_arena_load copies them in once, the steps run on a
+// Y7TTrk whose list pointers lead into the arena (same code, same order of operations: results are bit-identical), y7t_arena_store copies them back.
+// Between launches the state blob in global memory is the only truth (the host-side STrack accessors read it).
+#define Y7T_ARENA_T_LISTS 13      // tracked, lost, mark, pool, unconf, rem, actl, refind, lostn, removedl, tmpa, tmpb, xrow
+#define Y7T_ARENA_D_LISTS 3       // dhi, dlo, left
+Y7T_HD size_t y7t_arena_bytes(int cap_t, int cap_d) {
+    return ((size_t)Y7T_ARENA_T_LISTS * cap_t + (size_t)Y7T_ARENA_D_LISTS * cap_d + (size_t)(cap_t > cap_d ? cap_t : cap_d)) * sizeof(int);
+}
+
+// the arrays that move, as (pointer-to-member, length) pairs in arena order
+#define Y7T_ARENA_FOREACH(X, T, D, M) \
+    X(tracked, T) X(lost, T) X(mark, T) X(pool, T) X(unconf, T) X(rem, T) X(actl, T) X(refind, T) X(lostn, T) X(removedl, T) X(tmpa, T) X(tmpb, T) X(xrow, T) \
+    X(dhi, D) X(dlo, D) X(left, D) X(ycol, M)
+
+Y7T_FN bool y7t_arena_fits(const Y7TExec& ex, int cap_t, int cap_d) { return ex.arena && ex.arena_bytes >= y7t_arena_bytes(cap_t, cap_d); }
+
+// bind a state blob; with an arena in `ex` the index lists point into it (the caller has loaded it)
+Y7T_FN Y7TTrk y7t_trk_bind_ex(const Y7TExec& ex, void* blob, int cap_t, int cap_d) {
+    Y7TTrk s = y7t_trk_bind(blob, cap_t, cap_d);
+    if (!y7t_arena_fits(ex, cap_t, cap_d)) return s;
+    int* a = (int*)ex.arena;
+    const int T = cap_t, D = cap_d, M = cap_t > cap_d ? cap_t : cap_d;
+#define Y7T_X(f, n) s.f = a; a += (n);
+    Y7T_ARENA_FOREACH(Y7T_X, T, D, M)
+#undef Y7T_X
+    return s;
+}
+
+Y7T_FN void y7t_arena_copy(const Y7TExec& ex, void* blob, bool load) {
+    Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
+    const int T = h->cfg.cap_t, D = h->cfg.cap_d, M = T > D ? T : D;
+    if (!y7t_arena_fits(ex, T, D)) return;
+    const Y7TTrk g = y7t_trk_bind(blob, T, D), l = y7t_trk_bind_ex(ex, blob, T, D);
+    y7t_sync(ex);
+#define Y7T_X(f, n) for (int k = ex.tid; k < (n); k += ex.nt) { if (load) l.f[k] = g.f[k]; else g.f[k] = l.f[k]; }
+    Y7T_ARENA_FOREACH(Y7T_X, T, D, M)
+#undef Y7T_X
+    y7t_sync(ex);
+}
+Y7T_FN void y7t_arena_load(const Y7TExec& ex, void* blob) { y7t_arena_copy(ex, blob, true); }
+Y7T_FN void y7t_arena_store(const Y7TExec& ex, void* blob) { y7t_arena_copy(ex, blob, false); }
+
 enum { Y7T_ERR_CAP_T = 1, Y7T_ERR_CAP_D = 2, Y7T_ERR_OUT = 4, Y7T_ERR_KIND = 8 /* a DeepSORT pool stepped with detections by the plain step */ };
 
 #if !Y7T_DEVICE
@@ -639,7 +684,7 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
                                 int* out_count, const double* gmc_warp) {
     Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
     const Y7TTrkCfg cfg = h->cfg;
-    const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);
+    const Y7TTrk s = y7t_trk_bind_ex(ex, blob, cfg.cap_t, cfg.cap_d);
     const int kf = cfg.kf;
     if (cfg.tracker == Y7T_DEEPSORT && n >= 0) {      // frames with detections of a DeepSORT pool belong to y7t_tracker_step_deepsort (appearance rings); refuse, loudly
         if (ex.tid == 0) { h->status |= Y7T_ERR_KIND; if (out_count) *out_count = 0; }

@@ -127,6 +127,7 @@ __device__ __forceinline__ Y7TExec make_exec(unsigned fast_bytes) {
     ex.rv = (double*)y7t_smem; ex.ri = (int*)(y7t_smem + 512);
     ex.fast = fast_bytes ? y7t_smem + Y7T_LDS_HDR : nullptr;
     ex.fast_bytes = fast_bytes;
+    ex.arena = nullptr; ex.arena_bytes = 0;
     return ex;
 }
 
@@ -161,7 +162,7 @@ __global__ void k_lapjv(const double* __restrict__ cost, int nr, int nc, double 
 
 __global__ void k_tracker_init(void* blob, Y7TTrkCfg cfg, unsigned long long idc) {
     Y7TExec ex;
-    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
     y7t_tracker_init(ex, blob, cfg, idc);
 }
 
@@ -181,18 +182,21 @@ __global__ void k_tracker_step1(void* state, const float* dets, int n, double* o
 // n_frames consecutive frames of ONE tracker in one launch: the same frame step, frame after frame, by the same workgroup (the state stays hot in
 // this CU's caches and nothing is launched between frames).  For pipelines that have a whole batch's detections before the tracker runs.
 __global__ void k_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
-                                      int n_frames, unsigned fast_bytes, const double* const* warps) {
-    const Y7TExec ex = make_exec(fast_bytes);
+                                      int n_frames, unsigned fast_bytes, unsigned arena_bytes, const double* const* warps) {
+    Y7TExec ex = make_exec(fast_bytes);
+    if (arena_bytes) { ex.arena = y7t_smem + Y7T_LDS_HDR + fast_bytes; ex.arena_bytes = arena_bytes; }      // the index lists live in LDS for the whole launch
+    y7t_arena_load(ex, state);
     for (int f = 0; f < n_frames; ++f) {
         y7t_tracker_step(ex, state, dets[f], n_dets[f], out_rows[f], out_cap, out_count[f], warps ? warps[f] : nullptr);
         y7t_sync(ex);
     }
+    y7t_arena_store(ex, state);
 }
 
 // ---- DeepSORT (y7t_track_deepsort.h) ----
 __global__ void k_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budget) {
     Y7TExec ex;
-    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
     y7t_feat_init(ex, fblob, cap_t, cap_d, dim, budget);
 }
 
@@ -200,7 +204,7 @@ __global__ void k_feat_init(void* fblob, int cap_t, int cap_d, int dim, int budg
 __global__ void __launch_bounds__(256) k_ds_normalize(void* fblob, const float* __restrict__ det_feats, int n) {
     const Y7TFeat f = y7t_feat_bind(fblob);
     Y7TExec ex;
-    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
     if (n > f.h->cap_d) n = f.h->cap_d;      // (the step reports Y7T_ERR_CAP_D; nothing is written past the state)
     y7t_feat_normalize_dets(ex, f, det_feats, n);
 }
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
     if (dim & 31) {      // feature dimensions that are not a multiple of the k chunk: the plain form, one workgroup per slot
         if (blockIdx.y == 0) {
             Y7TExec ex;
-            ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+            ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
             y7t_embed_slot(ex, f, slot, n, s.tsu[slot]);
         }
         return;
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
 __global__ void __launch_bounds__(256) k_ds_store(void* fblob, const float* __restrict__ det_feats) {
     const Y7TFeat f = y7t_feat_bind(fblob);
     Y7TExec ex;
-    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0;
+    ex.tid = blockIdx.x * blockDim.x + threadIdx.x; ex.nt = gridDim.x * blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
     y7t_feat_store_pending(ex, f, det_feats);
 }
 
@@ -458,7 +462,17 @@ extern "C" int y7t_lapjv_f64_host(const double* cost_host, int n, int m, double 
 // occupant's vectors.  Only the predict-only form (n < 0) is shared between the trackers.
 static std::mutex g_kind_mu;
 static std::unordered_map<const void*, int> g_state_kind;
-static void note_state_kind(const void* state, int kind) { std::lock_guard<std::mutex> l(g_kind_mu); g_state_kind[state] = kind; }
+static std::unordered_map<const void*, size_t> g_state_arena;      // bytes of LDS the pool's index lists take (y7t_arena_bytes of its capacities)
+static void note_state_kind(const void* state, int kind, int cap_t = 0, int cap_d = 0) {
+    std::lock_guard<std::mutex> l(g_kind_mu);
+    g_state_kind[state] = kind;
+    g_state_arena[state] = cap_t > 0 ? y7t_arena_bytes(cap_t, cap_d) : 0;
+}
+static size_t state_arena_bytes(const void* state) {
+    std::lock_guard<std::mutex> l(g_kind_mu);
+    auto it = g_state_arena.find(state);
+    return it == g_state_arena.end() ? 0 : it->second;
+}
 static int state_kind(const void* state) {
     std::lock_guard<std::mutex> l(g_kind_mu);
     auto it = g_state_kind.find(state);
@@ -490,7 +504,7 @@ extern "C" int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kin
     c.iou_thresh = iou_thresh;
     hipLaunchKernelGGL(k_tracker_init, dim3(1), dim3(256), 0, S(stream), state, c, (unsigned long long)(uintptr_t)id_counter);
     Y7T_LAUNCH_CHECK();
-    note_state_kind(state, tracker_kind);
+    note_state_kind(state, tracker_kind, cap_t, cap_d);
     return 0;
 }
 
@@ -560,10 +574,18 @@ extern "C" int y7t_tracker_step_frames(void* state, const float* const* dets, co
         y7t_set_error("y7t_tracker_step_frames: a DeepSORT pool steps through y7t_tracker_step_deepsort (appearance rings)");
         return Y7T_E_STATE;
     }
+    // LDS of the launch: header | fast scratch (cost matrix, assignment work arrays) | the pool's index lists for the length of the launch (y7t_arena_*), when the
+    // CU's 160 KiB hold them beside at least 64 KiB of fast scratch (the default capacities, 1024 tracks x 1024 detections: 68 KiB of lists, 91 KiB of scratch)
+    static const unsigned kLdsMax = 160 * 1024;
+    static int use_arena = -1;
+    if (use_arena < 0) { const char* e = getenv("Y7T_TRACKER_ARENA"); use_arena = e ? atoi(e) : 1; }
+    const size_t ab = use_arena ? state_arena_bytes(state) : 0;
+    unsigned arena = 0, fast = kFastBytes;
+    if (ab && ab + 64 * 1024 + Y7T_LDS_HDR <= kLdsMax) { arena = (unsigned)((ab + 15) & ~(size_t)15); fast = (kLdsMax - Y7T_LDS_HDR - arena) & ~15u; if (fast > kFastBytes) fast = kFastBytes; }
     static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_frames, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
-    hipLaunchKernelGGL(k_tracker_step_frames, dim3(1), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
-                       kFastBytes, gmc_warps);
+    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_frames, kLdsMax)) return e; attr_done = true; }
+    hipLaunchKernelGGL(k_tracker_step_frames, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
+                       fast, arena, gmc_warps);
     Y7T_LAUNCH_CHECK();
     return 0;
 }
