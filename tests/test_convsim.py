@@ -136,20 +136,20 @@ def test_patch_kernel_source_on_the_host(case):
     assert name.startswith("patch"), name
 
 
-def test_patch_kernel_spread_reads_schedule_on_the_host():
-    """Y7T_CONV_ABLATE=1024 (read once per process, hence the subprocess): the instances of the patch kernels whose fragment reads are spread over the step's
-    MFMAs (a schedule experiment with correct results) -- every PATCH_CASES shape, same reference"""
+def test_patch_kernel_burst_reads_schedule_on_the_host():
+    """Y7T_CONV_ABLATE=2048 (read once per process, hence the subprocess): the instances of the patch kernels that read a step's fragments as one burst behind the
+    barrier (the form of rounds 1-3a, kept for A/B runs; the default spreads them over the step's MFMAs) -- every PATCH_CASES shape, same reference"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from tests import test_convsim as t, _convsim as cs\n"
             "for B, H, W, Cin, Cout, act, korder, kw in t.PATCH_CASES:\n"
             "    name = t.run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=1, **kw)\n"
-            "    assert name.endswith('spread-reads') or name.startswith('patch_mt'), name\n"
+            "    assert name.endswith('burst-reads') or name.startswith('patch_mt'), name\n"
             "    print(name)\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y7T_CONV_ABLATE="1024"), capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y7T_CONV_ABLATE="2048"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("spread-reads") >= 4, r.stdout
+    assert r.stdout.count("burst-reads") >= 4, r.stdout
 
 
 # the stride-2 LDS-patch kernel (csrc/y7t_conv_patch_s2.hip; korder 4): B, H, W, Cin, Cout, act, extras

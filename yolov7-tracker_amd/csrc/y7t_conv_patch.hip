@@ -268,8 +268,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     //     MFMAs of k-substep 1                   -- they cover the latency of those reads and of the barrier
     // A weight wave always has exactly W(u+2) younger than the panel it waits for (tail steps issue zero-filling DMAs); a patch
     // wave waits only at a chunk's last tap, for everything.
-    // ABL bit 10 (1024) is not an ablation but a SCHEDULE experiment with correct results (Y7T_CONV_ABLATE=1024): the step's fragment reads are spread over its MFMAs
-    // instead of issued as one burst of 12 behind the barrier.  The timing ablations of the current form (scripts/patch_ablations.sh, profiles/r03_patch_ablations.txt)
+    // The step's fragment reads are SPREAD over its MFMAs instead of issued as one burst of 12 behind the barrier (the form of rounds 1-3a; kept for the timing
+    // ablations, whose instances carry other ABL bits, and selectable with Y7T_CONV_ABLATE=2048 for A/B runs).  Measured (profiles/r03_patch_ablations.txt, same session,
+    // 32 frames): 160^2 128->128 258.8 -> 250.8 us, 80^2 256->256 225.1 -> 221.8, 40^2 384->384 148.3 -> 143.1, 160^2 128->256 465.5 -> 448.0.  The timing ablations of the current form (scripts/patch_ablations.sh, profiles/r03_patch_ablations.txt)
     // price the fragment reads at 22-25 % of the layer although LDS is only ~40 % busy on average: eight waves x 12 KiB right behind every barrier take ~770 LDS
     // cycles to serve, longer than the second MFMA half that is meant to cover them.  Here the 8 patch fragments of step u+1 go out one per MFMA during the FIRST half
     // of step u (the patch is resident for the whole chunk; only at a chunk's last tap the next patch is not visible before the barrier), the 4 weight fragments
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
         for (int u = 0; u < 18; ++u) {
             const int cc = u / 9, t = u % 9;   // compile-time after unrolling
             const int c = c0 + cc, cur = u & 1;
-            if (ABL & 1024) {
+            if (ABL == 0) {
                 const int un = u + 1, tn = un % 9, kh = tn / 3, kw = tn % 3;
                 const char* ps = plane + ((un / 9) & 1) * C::PATCH_BYTES + kh * RP + kw * PIXB;
                 const char* ws0 = wlane0 + (un % 3) * C::W_BYTES;
@@ -670,8 +671,8 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     const int tiles = ptiles * (a.Cout_pad / BN);
     hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    if (C::FLAT) y7t_note_kernel("patch_strip<%d,%d>%s", C::PW, BN, ABL == 1024 ? " spread-reads" : "");
-    else y7t_note_kernel("patch<%d,%d,%d>%s", TW, TH, BN, ABL == 1024 ? " spread-reads" : "");
+    if (C::FLAT) y7t_note_kernel("patch_strip<%d,%d>%s", C::PW, BN, ABL == 2048 ? " burst-reads" : "");
+    else y7t_note_kernel("patch<%d,%d,%d>%s", TW, TH, BN, ABL == 2048 ? " burst-reads" : "");
     return 0;
 }
 
@@ -700,20 +701,20 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
     if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;
     const int abl = a.ablate;      // (ABL = 512, the step's DMAs behind its MFMAs, was measured in round 3: 15.98 vs 16.02 ms for the list -- not instantiated any more)
-    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && (!abl || abl == 1024)) {
+    if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && (!abl || abl == 2048)) {
         int rcf;
-        if (abl == 1024) {
-            if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128, 1024>(a, s) : launch_patch<0, 42, 64, 1024>(a, s);
-            else rcf = wide ? launch_patch<0, 22, 128, 1024>(a, s) : launch_patch<0, 22, 64, 1024>(a, s);
+        if (abl == 2048) {
+            if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128, 2048>(a, s) : launch_patch<0, 42, 64, 2048>(a, s);
+            else rcf = wide ? launch_patch<0, 22, 128, 2048>(a, s) : launch_patch<0, 22, 64, 2048>(a, s);
         } else if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
         else rcf = wide ? launch_patch<0, 22, 128>(a, s) : launch_patch<0, 22, 64>(a, s);
         return rcf ? rcf : 1;
     }
     if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     int rc;
-    if (abl == 1024) {      // schedule experiment (correct results): the fragment reads spread over the step's MFMAs
-        if (use16) rc = wide ? launch_patch<16, 16, 128, 1024>(a, s) : launch_patch<16, 16, 64, 1024>(a, s);
-        else rc = wide ? launch_patch<32, 8, 128, 1024>(a, s) : launch_patch<32, 8, 64, 1024>(a, s);
+    if (abl == 2048) {      // A/B: the burst-read form (rounds 1-3a) of the default kernels, correct results
+        if (use16) rc = wide ? launch_patch<16, 16, 128, 2048>(a, s) : launch_patch<16, 16, 64, 2048>(a, s);
+        else rc = wide ? launch_patch<32, 8, 128, 2048>(a, s) : launch_patch<32, 8, 64, 2048>(a, s);
         return rc ? rc : 1;
     }
     if (abl && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
