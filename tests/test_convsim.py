@@ -172,22 +172,6 @@ def test_stride2_patch_kernel_source_on_the_host(case):
     assert name == "patch_s2<%d>" % (256 if cp % 256 == 0 else 128), name
 
 
-def test_stride2_patch_kernel_spread_reads_order_on_the_host():
-    """Y7T_CONV_PATCH_S2_ORDER=2 (read once per process, hence the subprocess): the stride-2 patch kernel with its fragment reads spread over the step's MFMAs
-    (A/B switch) -- every S2_CASES shape, same reference"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from tests import test_convsim as t, _convsim as cs\n"
-            "for B, H, W, Cin, Cout, act, kw in t.S2_CASES:\n"
-            "    name = t.run_case(cs.lib(), B, H, W, Cin, Cout, 3, 2, act, 0, korder=4, **kw)\n"
-            "    assert name.endswith('spread-reads'), name\n"
-            "    print(name)\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y7T_CONV_PATCH_S2_ORDER="2"), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("spread-reads") == len(S2_CASES), r.stdout
-
-
 def test_stride2_patch_kernel_rejects_what_it_cannot_run():
     """korder 4 weights are readable by the stride-2 patch kernel only: a stride-1 layer carrying them is an error, not a silent fallback"""
     L = cs.lib()

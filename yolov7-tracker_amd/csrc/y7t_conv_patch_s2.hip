@@ -190,48 +190,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(co
         for (int u = 0; u < 18; ++u) {
             const int cc = u / 9, t = u % 9;   // compile-time after unrolling
             const int c = c0 + cc, cur = u & 1;
-            if (ORD == 2) {      // the step's fragment reads spread over its MFMAs (as y7t_conv_patch.hip since round 3: -1.5 ... -3.8 % per layer there)
-                const int un = u + 1, tn = un % 9, kh = tn / 3, kw = tn % 3;
-                const char* ps = plane + ((un / 9) & 1) * C::PATCH_BYTES + kh * RP + (kw == 1 ? C::O_OFF : kw == 2 ? PIXB : 0);
-                const char* ws = wlane + (un % NWS) * C::W_BYTES;
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {           // first half: MFMA j, then patch fragment j of the next step (the patch is resident for the whole chunk)
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][0], xf[cur][j], acc[0][j], 0, 0, 0);
-                    if (t < 8) xf[cur ^ 1][j] = *(const half8*)(ps + j * C::JOFF);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                // LDS returns in order: with at most the TM patch reads in flight, the reads of W(u) -- whose ring slot is refilled behind the barrier -- have returned
-                if (t < 8) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * C::NWX) : "memory");
-                else if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (wrole) {
-                    const int unw = u + NWS, ccn = unw / 9;
-                    issue_w(u % NWS, cbase + unw * C::W_BYTES, c0 + ccn < nc16);
-                } else if (t < 7) {
-#pragma unroll
-                    for (int q = 0; q < C::PPT; ++q)
-                        if (t * C::PPT + q < C::NPX) issue_patch_piece(cc ^ 1, c + 1, t * C::PPT + q, c + 1 < nc16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                // second half: the two weight fragments of the next step first (their panel is visible behind the barrier; the half's MFMAs cover them), then MFMA j
-                // (and, at a chunk's last tap, patch fragment j of the next chunk)
-                wf[cur ^ 1][0] = *(const half8*)(ws);
-                wf[cur ^ 1][1] = *(const half8*)(ws + 32 * C::WROWB);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][1], xf[cur][j], acc[1][j], 0, 0, 0);
-                    if (t == 8) xf[cur ^ 1][j] = *(const half8*)(ps + j * C::JOFF);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                continue;
-            }
             mfma_half(cur, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (wrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * C::NWX) : "memory");
@@ -327,7 +285,7 @@ int launch_s2_ord(const Y7TConvArgs& a, hipStream_t s) {
     const int ptiles = a.B * ((a.Ho + C::TH - 1) / C::TH) * ((a.Wo + C::TW - 1) / C::TW);
     hipLaunchKernelGGL((k_conv3x3s2_patch<BN, NW, ORD>), dim3(ptiles * (a.Cout_pad / BN)), dim3(C::NT), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    if (NW == 4) y7t_note_kernel("patch_s2<%d>%s", BN, ORD == 2 ? " spread-reads" : ORD ? " dma-late" : "");
+    if (NW == 4) y7t_note_kernel("patch_s2<%d>%s", BN, ORD ? " dma-late" : "");
     else y7t_note_kernel("patch_s2<%d,%d>%s", BN, NW, ORD ? " dma-late" : "");
     return 0;
 }
@@ -336,9 +294,7 @@ template <int BN, int NW>
 int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
     // (ORD = 1 -- the step's DMAs behind its MFMAs -- and NW = 8 -- 512 threads, 16 x 16 output pixels, one workgroup per CU -- were measured in round 3:
     //  within +-1 % resp. 3-20 % slower than this form, profiles/r03_conv_variants.txt; they are no longer instantiated)
-    static int ord = -1;      // Y7T_CONV_PATCH_S2_ORDER=2: the fragment reads spread over the step's MFMAs (A/B switch; measured at the end of round 3)
-    if (ord < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_ORDER"); ord = e ? atoi(e) : 0; }
-    return ord == 2 ? launch_s2_ord<BN, NW, 2>(a, s) : launch_s2_ord<BN, NW, 0>(a, s);
+    return launch_s2_ord<BN, NW, 0>(a, s);
 }
 
 }   // namespace
