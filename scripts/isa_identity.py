@@ -15,7 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", "-S", "--cuda-device-only"]      # (the conv translation units' flags, yolov7-tracker_amd/build.py)
 
 
 def asm(csrc, include, f, out):

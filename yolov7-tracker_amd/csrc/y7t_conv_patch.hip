@@ -144,12 +144,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
                 }
             } else {
             const int r = byte / RP, rb = byte - r * RP;
-            int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
-            if (ABL & 128) { x = (rb >> 6) % (TW + 2); cs = (rb >> 4) & 3; }   // diagnostics: lane quads = whole 64-byte pixel rows (wrong data)
-            const int gy = ((ABL & 64) ? 0 : h0) + r - 1, gx = ((ABL & 64) ? 0 : w0) + x - 1;   // 64: every workgroup reads image 0's first patch
+            const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
+            const int gy = h0 + r - 1, gx = w0 + x - 1;
             const bool ok = r < TH + 2 && x < TW + 2 && cs < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            if (ABL & 256) v = (unsigned)(byte & 0xffff);   // diagnostics: contiguous, cache-resident source (wrong data)
-            else if (ok) v = (unsigned)(((((((ABL & 64) ? 0 : b) * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2);
+            if (ok) v = (unsigned)(((((b * p.H + gy) * p.W + gx) * p.ldin + p.cin_off) + cs * 8) * 2);
             }
         }
         off[i] = v;
@@ -717,35 +715,16 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
         else rc = wide ? launch_patch<32, 8, 128, 2048>(a, s) : launch_patch<32, 8, 64, 2048>(a, s);
         return rc ? rc : 1;
     }
-    if (abl && use16 && !wide) {   // diagnostics: ablated instances of the 16x16x64 kernel (the 64-channel layers at 320x320 / 160x160)
-        switch (abl) {
-        case 1: return launch_patch<16, 16, 64, 1>(a, s) ? -1 : 1;
-        case 2: return launch_patch<16, 16, 64, 2>(a, s) ? -1 : 1;
-        case 7: return launch_patch<16, 16, 64, 7>(a, s) ? -1 : 1;
-        case 8: return launch_patch<16, 16, 64, 8>(a, s) ? -1 : 1;
-        case 15: return launch_patch<16, 16, 64, 15>(a, s) ? -1 : 1;
-        default: break;
-        }
-    }
-    if (abl && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel
+    if (abl && use16 && wide) {   // diagnostics: compile-time ablated instances of the 16x16x128 kernel in its burst-read form (scripts/patch_ablations.sh)
         switch (abl) {
         case 1: return launch_patch<16, 16, 128, 1>(a, s) ? -1 : 1;
         case 2: return launch_patch<16, 16, 128, 2>(a, s) ? -1 : 1;
-        case 3: return launch_patch<16, 16, 128, 3>(a, s) ? -1 : 1;
         case 4: return launch_patch<16, 16, 128, 4>(a, s) ? -1 : 1;
-        case 5: return launch_patch<16, 16, 128, 5>(a, s) ? -1 : 1;
-        case 6: return launch_patch<16, 16, 128, 6>(a, s) ? -1 : 1;
-        case 7: return launch_patch<16, 16, 128, 7>(a, s) ? -1 : 1;
         case 8: return launch_patch<16, 16, 128, 8>(a, s) ? -1 : 1;
         case 15: return launch_patch<16, 16, 128, 15>(a, s) ? -1 : 1;
         case 16: return launch_patch<16, 16, 128, 16>(a, s) ? -1 : 1;
         case 32: return launch_patch<16, 16, 128, 32>(a, s) ? -1 : 1;
         case 48: return launch_patch<16, 16, 128, 48>(a, s) ? -1 : 1;
-        case 64: return launch_patch<16, 16, 128, 64>(a, s) ? -1 : 1;
-        case 128: return launch_patch<16, 16, 128, 128>(a, s) ? -1 : 1;
-        case 256: return launch_patch<16, 16, 128, 256>(a, s) ? -1 : 1;
-        case 272: return launch_patch<16, 16, 128, 272>(a, s) ? -1 : 1;
-        case 80: return launch_patch<16, 16, 128, 80>(a, s) ? -1 : 1;
         default: break;
         }
     }
