@@ -28,6 +28,16 @@ def test_hostsim_tracker_with_launch_long_list_arena_matches_reference_golden(na
     util.assert_same_tracks(got, want, "%s, arena over %d frames" % (name, frames))
 
 
+def test_hostsim_list_arena_with_unequal_capacities():
+    """the arena's layout follows the pool's capacities (13 track-sized lists, 3 detection-sized ones, one of the larger size): a pool with fewer track slots than
+    detection slots and one with more, against the same golden sequence"""
+    name = util.TRACKER_CASES[0]
+    trk, fmt, dets, want = util.load_tracker_case(name)
+    for cap_t, cap_d in ((256, 640), (768, 192)):
+        got = hs.run(trk, dets, kalman_format=fmt, warps=util.load_tracker_warps(name), arena_frames=4, cap_t=cap_t, cap_d=cap_d)
+        util.assert_same_tracks(got, want, "%s, arena, capacities %d x %d" % (name, cap_t, cap_d))
+
+
 @pytest.mark.parametrize("name", util.DEEPSORT_CASES)
 def test_hostsim_deepsort_matches_reference_golden(name):
     """DeepSORT's workgroup program (csrc/y7t_track_deepsort.h): matching cascade over the gated appearance cost, the IoU fallbacks, the
