@@ -19,7 +19,7 @@ for op in plan.ops:
 zeros = torch.zeros(256, dtype=torch.float16, device="cuda")
 tot_t = tot_f = 0.0
 print("%-34s %3s %9s %8s %8s %8s" % ("shape (HxW Cin->Cout k/s)", "x", "us", "TF/s", "GB/s", "blocks"))
-ONLY = os.environ.get("ONLY")      # "H,Cin,Cout,k,s": that shape only (long runs for scripts/power_sample.sh)
+ONLY = os.environ.get("ONLY")      # "H,Cin,Cout,k,s": that shape only (long or profiled runs of one layer)
 for key, cnt in shapes.items():
     H, W, Cin, Cout, Cout_pad, k, s, pad, f32, in_ld, out_ld = key
     if ONLY and [int(v) for v in ONLY.split(",")] != [H, Cin, Cout, k, s]: continue

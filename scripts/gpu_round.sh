@@ -15,6 +15,13 @@
 #   exp_ws          weights-stationary 64 -> 64 kernel (default; Y7T_CONV_WS=0 = the patch kernels): layer parity, parity inside the pinned list, per-layer timing, bench line
 #   (round 3's first call also had exp_s2 / exp_nw8 / exp_late / exp_fixup / exp_next -- the kernels prepared at the end of round 2; their results are in
 #    profiles/r03_conv_variants.txt and the losing variants are no longer in the source)
+#   exp_ws4         ws64 with the instruction order spelled out: parity, per-layer time, issue counters, bench line
+#   exp_issue       scripts/ubench/issue_model: what a wave issues in the shadow of its own MFMAs
+#   exp_noslp       the library against lib/liby7t_prev.so (a copy of an earlier build, Y7T_LIB): parity suite, per-layer table of both, bench lines of both
+#   exp_clock       shader clock per kernel (scripts/clock_probe.sh), ws64 counters at 32 frames, MFMA operand-order micro-benchmark
+#   exp_wsprobe     the ws64 layer by data / layout / working set (scripts/ws_probe.py);   exp_wsabl: its timing ablations (Y7T_WS_ABLATE)
+#   exp_latency     one-frame per-layer table + kernel trace of the batch-1 latency mode (scripts/latency_trace.sh)
+#   exp_arena       tracker index lists in LDS for the length of a frames launch: tracker tests, bench lines with / without (Y7T_TRACKER_ARENA=0)
 #   pmc_queues      which queue of the buffer->LDS path the generic kernel waits in (TA / TCP / TCC / SQ counters on three layers)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -180,16 +187,6 @@ exp_arena)
     Y7T_TRACKER_ARENA=$a timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode --workload $w > $O/bench_${w}_arena$a.json 2> $O/bench_${w}_arena$a.err
   done; done
   benchsum cfg2_arena1 cfg2_arena0 cfg3_arena1 cfg3_arena0
-  ;;
-
-power)
-  say "power: board power and shader clock (sysfs, 50 ms samples) while one layer runs back to back for a few seconds, and during the bench"
-  for sh in 320,64,64,3,1 80,256,256,3,1 320,128,128,1,1 80,1024,512,1,1 160,256,512,3,2; do
-    echo "-- layer $sh" | tee -a $O/summary.txt
-    ONLY=$sh timeout 120 bash scripts/power_sample.sh $O/power_$sh.txt python scripts/bench_conv.py 32 6000 2>&1 | grep -v "^shape" | tee -a $O/summary.txt
-  done
-  echo "-- bench (200 steps)" | tee -a $O/summary.txt
-  timeout 200 bash scripts/power_sample.sh $O/power_bench.txt python bench.py --steps 200 --warmup 5 --no_cpu_baseline --no_latency_mode 2>/dev/null | cut -c1-300 | tee -a $O/summary.txt
   ;;
 
 pmc_queues)

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("Y7T_LIB") or os.path.join(_HERE, "lib", "liby7t.so")   # Y7T_LIB: kernel experiments (scripts/ablate)
+LIB_PATH = os.environ.get("Y7T_LIB") or os.path.join(_HERE, "lib", "liby7t.so")   # Y7T_LIB: A/B runs against another build of the library (scripts/gpu_round.sh exp_noslp)
 
 c_void_p, c_int, c_double, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_float
 
