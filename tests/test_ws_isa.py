@@ -1,4 +1,5 @@
-"""Static checks on the gfx950 instruction stream of the weights-stationary kernel (hipcc cross-compiles without a GPU).
+"""Static checks on the gfx950 instruction streams of the weights-stationary kernels (hipcc cross-compiles without a GPU): the 64 -> 64 kernel of the launch list
+(csrc/y7t_conv_ws.hip) and its 128-channel sibling (csrc/y7t_conv_ws128.hip, a prepared experiment).
 
 The kernel writes its MFMAs as asm statements (accumulators in arch VGPRs, weights in ACC registers), so the compiler's hazard recogniser does not see them:
 the first device run of that form copied accumulator registers at the loop exit while the last MFMAs of a tile were still writing them.  What protects the
@@ -26,56 +27,58 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-@pytest.fixture(scope="module")
-def kernels(tmp_path_factory):
+# file, kernel name, pieces per wave and tile, stores per wave and tile, accumulator registers of one set
+KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0EE", 13, 8, 64), "ws128": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dEE", 8, 4, 32)}
+
+
+@pytest.fixture(scope="module", params=sorted(KERNELS))
+def kernels(request, tmp_path_factory):
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("hipcc not available")
     import importlib
     build = importlib.import_module("yolov7_tracker_amd.build")
-    out = str(tmp_path_factory.mktemp("isa") / "ws.s")
-    src = os.path.join(build.CSRC, "y7t_conv_ws.hip")
-    cmd = [HIPCC] + [f for f in build.FLAGS if f != "-fPIC"] + build.FILE_FLAGS["y7t_conv_ws.hip"] + ["-S", "--cuda-device-only", "-o", out, src]
+    fname, kname, inst, npw, nst, nacc = KERNELS[request.param]
+    out = str(tmp_path_factory.mktemp("isa") / (request.param + ".s"))
+    src = os.path.join(build.CSRC, fname)
+    cmd = [HIPCC] + [f for f in build.FLAGS if f != "-fPIC"] + build.FILE_FLAGS[fname] + ["-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, capture_output=True)
     text = open(out).read()
     ks = {}
-    for m in re.finditer(r"^(_ZN\S*k_conv3x3_c64_ws\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN\S*%s\w*):[^\n]*\n(.*?)s_endpgm" % kname, text, re.S | re.M):
         body = [l.strip() for l in m.group(2).split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";"))]
         ks[m.group(1)] = body
+    ks = {n: b for n, b in ks.items() if re.search(inst, n)}          # the instances without timing ablations (one per activation)
+    assert len(ks) == 3, sorted(ks)
     meta = {n: (int(re.search(r"\.name:\s+%s\n.*?\.private_segment_fixed_size:\s+(\d+)" % re.escape(n), text, re.S).group(1)),
                 int(re.search(r"\.name:\s+%s\n.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(n), text, re.S).group(1))) for n in ks}
-    return ks, meta
-
-
-def _default(ks):
-    d = {n: b for n, b in ks.items() if re.search(r"wsILi\dELi0EE", n)}          # ABL = 0 instances (one per activation)
-    assert len(d) == 3, sorted(ks)
-    return d
+    return ks, meta, (npw, nst, nacc)
 
 
 def test_no_packed_fp32_no_scratch(kernels):
-    ks, meta = kernels
-    d = _default(ks)
-    assert len(d) == 3
-    for n, body in d.items():
+    ks, meta, _ = kernels
+    for n, body in ks.items():
         assert not [i for i in body if re.match(r"v_pk_(mul|add|fma)_f32", i)], n
         assert not [i for i in body if i.startswith("scratch_")], n
         assert meta[n] == (0, 0), (n, meta[n])
 
 
+def _bodies(body):
+    bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
+    assert len(bars) == 3, len(bars)                                              # first tile, and the two alternating bodies of the loop
+    for bi, b0 in enumerate(bars):
+        yield bi, b0, body[b0:(bars[bi + 1] if bi + 1 < len(bars) else len(body))]
+
+
 def test_tile_bodies_have_the_spelled_out_slot_structure(kernels):
-    ks, _ = kernels
-    for n, body in _default(ks).items():
-        bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
-        assert len(bars) == 3, (n, len(bars))                                     # first tile, and the two alternating bodies of the loop
-        for bi, b0 in enumerate(bars):
-            b1 = bars[bi + 1] if bi + 1 < len(bars) else len(body)
-            seg = body[b0:b1]
+    ks, _, (npw, nst, _) = kernels
+    for n, body in ks.items():
+        for bi, _, seg in _bodies(body):
             mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]
             assert len(mf) == 144, (n, bi, len(mf))
             seg = seg[:mf[-1] + 1]
-            assert sum(ins.startswith("ds_read_b128") for ins in seg) == 144                      # 8 up front + one behind each of the first 136 MFMAs
-            assert sum(ins.startswith("buffer_load_dwordx4") for ins in seg) == 13               # the pieces of tile t + 2
-            assert sum(ins.startswith("global_store_dwordx4") for ins in seg) == (0 if bi == 0 else 8)
+            assert sum(ins.startswith("ds_read_b128") for ins in seg) == 144                      # a few up front + one behind each MFMA until the tile's last substeps
+            assert sum(ins.startswith("buffer_load_dwordx4") for ins in seg) == npw               # the pieces of tile t + 2
+            assert sum(ins.startswith("global_store_dwordx4") for ins in seg) == (0 if bi == 0 else nst)
             # a slot holds one transcendental and at most two other VALU instructions; the MFMA may sit anywhere inside its slot, so between two
             # consecutive MFMAs of the steady state (slots 8 .. 135) there are at most two slots' worth
             for a, b in zip(mf[8:136], mf[9:137]):
@@ -85,20 +88,16 @@ def test_tile_bodies_have_the_spelled_out_slot_structure(kernels):
 
 
 def test_nothing_touches_an_accumulator_for_eleven_wait_states_behind_a_tiles_last_mfma(kernels):
-    ks, _ = kernels
-    for n, body in _default(ks).items():
-        bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
-        for bi, b0 in enumerate(bars):
-            b1 = bars[bi + 1] if bi + 1 < len(bars) else len(body)
-            seg = body[b0:b1]
+    ks, _, (_, _, nacc) = kernels
+    for n, body in ks.items():
+        for bi, b0, seg in _bodies(body):
             mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]
             acc = set()
             for i in mf[-4:]:
-                acc |= _regs(seg[i].split()[1].rstrip(","))                        # the four accumulators of the body (vdst of its last four MFMAs)
-            assert len(acc) == 64
-            waited, j = 0, mf[-1] + 1
-            flat = body[b0 + j:]                                                    # follow the fall-through path past the body's end
-            for ins in flat:
+                acc |= _regs(seg[i].split()[1].rstrip(","))                        # the accumulators of the body (vdst of its last four MFMAs)
+            assert len(acc) == nacc
+            waited = 0
+            for ins in body[b0 + mf[-1] + 1:]:                                      # follow the fall-through path past the body's end
                 if waited >= 11:
                     break
                 ops = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", ins)
