@@ -86,7 +86,7 @@ def plant_objectness_bias(det, frames, target=2000):
     return det.plant_objectness_bias(frames, target)
 
 
-def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=None, gpu_cands0=None):
+def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=None, gpu_cands0=None, gpu_kept_rows0=None):
     """the oracle (CPU restatement of the reference path, kind='port') timed on this host's cores on a bounded sample:
     `cpu_frames` frames through the torch-fp32 detector + NMS oracle, 100 frames through the numpy ByteTrack oracle.
     The oracle's output for frame 0 is also the checker of the timed GPU run: -> (cpu_baseline dict, parity dict)."""
@@ -106,20 +106,39 @@ def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=No
         parity = {"checker": "oracle/detector_torch.py fp32 forward of frame 0 (same seeded weights)",
                   "heads_mean_abs_err_over_logit_std": [round(r, 5) for r in rel]}
         if gpu_cands0 is not None:      # SURVEY 8a's bar BEFORE the NMS (no greedy order to amplify a rounding difference): every candidate, not a percentage
-            st = dt.compare_candidate_sets(gpu_cands0, dt.candidates(dec[0], 0.01), 0.01, px=1.0, dconf=5e-3)
+            want = dt.candidates(dec[0], 0.01)
+            st = dt.compare_candidate_sets(gpu_cands0, want, 0.01, px=1.0, dconf=5e-3, iou=0.99)      # 8a: same class, IoU >= 0.99 OR |dcoord| <= 1 px, |dconf| <= 5e-3
             st.pop("worst_rows", None)
+            st["n_out_of_coord_bar"] = len(st.pop("out_of_coord_bar", []))
+            ny = [args.img // s_ for s_ in (8, 16, 32, 64)][:len(raw_ref)]
+            rows0 = np.cumsum([0] + [int(r_.shape[1] * r_.shape[2] * r_.shape[3]) for r_ in raw_ref])
+            st["candidates_per_detect_level"] = np.bincount(np.searchsorted(rows0, np.array(sorted(gpu_cands0)), side="right") - 1, minlength=len(ny))[:len(ny)].tolist()
             parity["candidates_before_nms"] = st
+            if gpu_kept_rows0 is not None:      # final boxes by anchor row: rows kept by both at the bar; rows kept by one side only traced to the tied greedy decision
+                kw = dt.nms_rows(want, 0.45)
+                both = sorted(set(int(r_) for r_ in kw) & set(int(r_) for r_ in gpu_kept_rows0))
+                common = set(gpu_cands0) & set(want)
+                noise = max([1e-4] + [abs(gpu_cands0[r_][1] - want[r_][1]) for r_ in common])
+                ex = dt.explain_kept_set_difference(gpu_cands0, gpu_kept_rows0, want, kw, score_noise=noise)
+                reasons = {}
+                for v in ex.values():
+                    reasons[v or "UNEXPLAINED"] = reasons.get(v or "UNEXPLAINED", 0) + 1
+                parity["boxes_by_anchor_row"] = {"oracle_keeps": int(len(kw)), "device_keeps": int(len(gpu_kept_rows0)), "kept_by_both": len(both),
+                                                 "kept_by_one_side_only": len(ex), "reasons": reasons, "score_noise": round(float(noise), 6)}
         if gpu_dets0 is not None:
             ref = dt.non_max_suppression(dec, 0.01, 0.45)[0]
             rb = dt.scale_coords_round((args.img, args.img), ref[:, :4], (args.img, args.img))
             d = gpu_dets0
             used, m = torch.zeros(len(d), dtype=torch.bool), 0
             for row, box in zip(ref, rb):
-                ok = (~used) & (d[:, 5] == row[5]) & ((d[:, :4] - box).abs().max(1).values <= 1.0) & ((d[:, 4] - row[4]).abs() <= 5e-3)
+                near = (d[:, :4] - box).abs().max(1).values <= 1.0
+                if not bool(((~used) & near).any()):      # 8a's other coordinate bar: IoU >= 0.99 (the several-hundred-pixel boxes of the coarse levels)
+                    near = torch.tensor([dt.box_iou_1(x_, box) >= 0.99 for x_ in d[:, :4].numpy()])
+                ok = (~used) & (d[:, 5] == row[5]) & near & ((d[:, 4] - row[4]).abs() <= 5e-3)
                 if ok.any():
                     used[int(torch.nonzero(ok)[0])] = True
                     m += 1
-            parity.update({"boxes_oracle": int(len(ref)), "boxes_device": int(len(d)), "boxes_matched_same_class_1px_conf5e-3": m})
+            parity.update({"boxes_oracle": int(len(ref)), "boxes_device": int(len(d)), "boxes_matched_same_class_1px_or_iou99_conf5e-3": m})
         parity["third_party"] = ("unpinned: lap.lapjv, cython_bbox.bbox_overlaps, torchvision.ops.nms and cv2 are not vendored by the reference and not "
                                  "installed here -- restated from their published algorithms in oracle/y7t_oracle.c / oracle/letterbox_np.py and cross-checked "
                                  "against scipy.optimize.linear_sum_assignment / brute force; everything the reference itself implements is pinned to its own "
@@ -183,7 +202,7 @@ def parity_well_conditioned(args, nc, frames_host):
             sd[k] = w.view(na * no, -1, 1, 1)
     d2 = model.Detector(spec, sd, img_size=(H, W), max_batch=2)
     fr = torch.from_numpy(frames_host[:2]).cuda()
-    d2.plant_objectness_bias(fr, level_offsets=(0, 0, -3, -6)[:len(d2.plan.heads)])
+    d2.plant_objectness_bias(fr)
     out = d2.forward(fr, fuse_decode=0.01)
     dets, nd = d2.postprocess(out, 0.01, 0.45, None)
     torch.cuda.synchronize()
@@ -216,7 +235,7 @@ def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10, sd=None
     nf = min(8, len(frames_host))
     u8 = [torch.from_numpy(frames_host[i]).pin_memory() for i in range(nf)]
     f32 = [(torch.from_numpy(np.ascontiguousarray(frames_host[i][:, :, ::-1].transpose(2, 0, 1))).float() / 255.0).pin_memory() for i in range(nf)]
-    det1.plant_objectness_bias(u8[0][None].cuda(), level_offsets=None if sd is None else (0, 0, -3, -6)[:len(det1.plan.heads)])
+    det1.plant_objectness_bias(u8[0][None].cuda())
     res = {}
     count0 = BaseTrack._count
     for mode, src in (("f32_chw_host", f32), ("u8_hwc_host", u8)):
@@ -475,10 +494,7 @@ def main():
     # frame slot i of step s belongs to sequence i // Bq, at its local time s * Bq + i % Bq; everything below is indexed by t = s * B + i
     dets_seq = [per_seq[(t % B) // Bq][(t // B) * Bq + (t % B) % Bq] for t in range(n_frames)]
     dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
-    if conditioned:       # candidates mostly from the fine levels, the small-object regime of VisDrone (and where an fp16 pipeline can hold 1 px)
-        det.plant_objectness_bias(frames, level_offsets=(0, 0, -3, -6)[:len(det.plan.heads)])
-    else:
-        plant_objectness_bias(det, frames)
+    plant_objectness_bias(det, frames)       # ~2000 candidates per frame, wherever the head puts them: all four Detect levels are live
 
     BaseTrack._count = 0
     if cfg3:
@@ -816,6 +832,7 @@ def main():
                                                                                 cs[0, :n_c0].cpu().numpy(), cc[0, :n_c0].cpu().numpy())}
             heads0 = [r[:1].cpu() for r in out0.raw()]
             dets0 = d0[0, :int(n0[0])].cpu()
+            kept_rows0 = ci_[0].cpu().numpy()[det.plan.post[out0.pset].keep[0, :int(n0[0])].cpu().numpy()]      # anchor row of every kept detection of frame 0
             if cfg4:
                 pr = trk._state[trk._layout["hdr_prof"]:trk._layout["hdr_prof"] + 256].view(torch.int64).cpu().numpy()
                 line["config"]["cascade"] = {"frames_with_several_ages": int(pr[27]), "of_them_with_a_contested_detection": int(pr[28]),
@@ -845,12 +862,13 @@ def main():
             if not args.no_latency_mode and not cfg3 and not cfg4:
                 line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq, sd=sd0)
             if not args.no_cpu_baseline and not cfg4:            # the CPU baseline is timed on rank 0 at N=1 only (configs[1] / [2])
-                line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0, cands0)
+                line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0, cands0, kept_rows0)
                 line["parity"]["weights"] = args.weights
                 if conditioned:
                     line["parity"]["note"] = ("frame 0 of the TIMED run (same weights, same launch list, 32 frames per forward) against the fp32 oracle: raw heads, the "
-                                              "pre-NMS candidate set at SURVEY 8a's bar (every candidate), and the final boxes matched one to one as sets (what "
-                                              "remains unmatched are greedy-NMS decisions flipped by fp16 noise in near-tied scores)")
+                                              "pre-NMS candidate set at SURVEY 8a's full bar (same class, IoU >= 0.99 or |dcoord| <= 1 px, |dconf| <= 5e-3: every candidate, all four "
+                                              "Detect levels live), and the final boxes by anchor row (every row only one side keeps is traced to the greedy NMS decision that "
+                                              "flipped and shown to be a tie within the frame's measured score noise: `reasons`)")
                 else:
                     line["parity"]["note"] = ("the benchmarked weights are iid random (chaotic: rounding noise x ~300 over the depth); the same kernels "
                                               "on well-conditioned seeded weights:")

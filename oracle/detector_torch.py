@@ -197,10 +197,19 @@ def candidates(dec, conf_thres=0.01):
     return {int(r): (b.numpy(), float(c), int(k), sc.numpy()) for r, b, c, k, sc in zip(rows[ok], box[ok], conf[ok], j[ok], x[:, 5:][ok])}
 
 
-def compare_candidate_sets(got, want, conf_thres=0.01, px=1.0, dconf=5e-3):
+def box_iou_1(a, b):
+    """IoU of two xyxy boxes (plain area convention, no +1: the convention of torchvision.ops.box_iou / utils/general.py:box_iou)"""
+    iw = max(0.0, min(float(a[2]), float(b[2])) - max(float(a[0]), float(b[0])))
+    ih = max(0.0, min(float(a[3]), float(b[3])) - max(float(a[1]), float(b[1])))
+    ua = (float(a[2]) - float(a[0])) * (float(a[3]) - float(a[1])) + (float(b[2]) - float(b[0])) * (float(b[3]) - float(b[1])) - iw * ih
+    return iw * ih / ua if ua > 0 else 1.0
+
+
+def compare_candidate_sets(got, want, conf_thres=0.01, px=1.0, dconf=5e-3, iou=None):
     """got / want: dicts anchor row -> (xyxy, conf, cls) of ONE image (device / oracle).  SURVEY 8a's bar applied BEFORE the NMS, where no greedy
     order can amplify a rounding difference: every candidate both sides have must agree in class (or pick a class the oracle scores within dconf of its best), |dcoord| <= px, |dconf| <= dconf; a candidate
-    only one side has must sit within dconf of the threshold (it crossed conf_thres by rounding noise).  -> statistics dict"""
+    only one side has must sit within dconf of the threshold (it crossed conf_thres by rounding noise).  iou (e.g. 0.99): 8a's FULL coordinate bar --
+    "IoU >= 0.99 / |dcoord| <= 1 px": a box passes on either (large boxes of the coarse Detect levels pass on IoU, small ones on pixels).  -> statistics dict"""
     both = sorted(set(got) & set(want))
     only = sorted(set(got) ^ set(want))
     dc = np.array([np.abs(got[r][0] - want[r][0]).max() for r in both]) if both else np.zeros(0)
@@ -210,9 +219,87 @@ def compare_candidate_sets(got, want, conf_thres=0.01, px=1.0, dconf=5e-3):
     # conf tolerance: `conf, j = x[:, 5:].max(1)` picks by rounding noise)
     cls_diff = [r for r in both if got[r][2] != want[r][2] and (len(want[r]) < 4 or want[r][3][got[r][2]] < want[r][1] - dconf)]
     only_margin = np.array([abs((got.get(r) or want.get(r))[1] - conf_thres) for r in only]) if only else np.zeros(0)
-    return {"n_got": len(got), "n_want": len(want), "n_both": len(both), "n_only_one_side": len(only),
-            "max_dcoord": float(dc.max()) if len(dc) else 0.0, "max_dconf": float(ds.max()) if len(ds) else 0.0,
-            "max_dcoord_rel_side": float((dc / np.maximum(side, 1.0)).max()) if len(dc) else 0.0,
-            "frac_within_bar": float(((dc <= px) & (ds <= dconf)).mean()) if len(dc) else 1.0,
-            "n_class_differs": len(cls_diff), "max_margin_only_one_side": float(only_margin.max()) if len(only) else 0.0,
-            "worst_rows": [both[i] for i in np.argsort(-dc)[:3]] if len(dc) else []}
+    coord_ok = dc <= px
+    st = {}
+    if iou is not None:
+        ious = np.array([box_iou_1(got[r][0], want[r][0]) for r in both]) if both else np.zeros(0)
+        coord_ok = coord_ok | (ious >= iou)
+        wh = np.array([[want[r][0][2] - want[r][0][0], want[r][0][3] - want[r][0][1]] for r in both]) if both else np.zeros((0, 2))
+        st = {"out_of_coord_bar": [{"row": int(both[i]), "dcoord": float(dc[i]), "iou": float(ious[i]), "w": float(wh[i][0]), "h": float(wh[i][1])} for i in np.nonzero(~coord_ok)[0]],
+              "min_iou": float(ious.min()) if len(ious) else 1.0, "min_iou_of_boxes_off_by_more_than_px": float(ious[dc > px].min()) if bool((dc > px).any()) else 1.0,
+              "n_pass_on_iou_only": int(((dc > px) & (ious >= iou)).sum()), "max_side_px": float(side.max()) if len(side) else 0.0}
+    st.update({"n_got": len(got), "n_want": len(want), "n_both": len(both), "n_only_one_side": len(only),
+               "max_dcoord": float(dc.max()) if len(dc) else 0.0, "max_dconf": float(ds.max()) if len(ds) else 0.0,
+               "max_dcoord_rel_side": float((dc / np.maximum(side, 1.0)).max()) if len(dc) else 0.0,
+               "frac_within_bar": float((coord_ok & (ds <= dconf)).mean()) if len(dc) else 1.0,
+               "n_class_differs": len(cls_diff), "max_margin_only_one_side": float(only_margin.max()) if len(only) else 0.0,
+               "worst_rows": [both[i] for i in np.argsort(-dc)[:3]] if len(dc) else []})
+    return st
+
+
+def nms_rows(cands, iou_thres=0.45, max_nms=30000, max_det=300, max_wh=4096):
+    """the NMS half of non_max_suppression (utils/general.py:664-695: per-class offset boxes, max_nms best candidates, greedy torchvision.ops.nms restated in
+    oracle/y7t_oracle.c, first max_det) on ONE image's candidate dict anchor row -> (xyxy, conf, cls, ...) -> the kept anchor rows, in output order"""
+    rows = np.array(sorted(cands))
+    if not len(rows):
+        return rows
+    box = np.stack([cands[r][0] for r in rows]).astype(np.float32)
+    s = np.array([cands[r][1] for r in rows], np.float32)
+    c = np.array([cands[r][2] for r in rows], np.float32)
+    order = np.lexsort((rows, -s.astype(np.float64)))[:max_nms]
+    k = cnative.nms((box + c[:, None] * np.float32(max_wh)).astype(np.float32)[order], s[order], iou_thres)[:max_det]
+    return rows[order[k]]
+
+
+def explain_kept_set_difference(cands_x, kept_x, cands_y, kept_y, score_noise, iou_noise=0.02, conf_thres=0.01, iou_thres=0.45, max_det=300, depth=12):
+    """Two runs of the same greedy NMS on two candidate sets that differ by rounding noise (x, y: dicts anchor row -> (xyxy, conf, cls, ...); kept_*: kept rows in
+    output order).  For every row kept on ONE side only, walk the greedy decisions that made it so and name the decision that could flip within the noise:
+      'score-tie'     the row and the rival that suppresses it on the other side swap order: their scores differ by <= 2 score_noise on the side where the row survives
+      'iou-threshold' the rival's IoU with the row lies within iou_noise of iou_thres and crosses it
+      'conf-threshold' the row (or a rival up the chain) is a candidate on one side only, its score within score_noise of conf_thres
+      'cut'           the row ranks just behind the max_det-th survivor: within 2 score_noise of the last kept score
+      'class-tie'     the rival's best class differs between the sides (two class scores within 2 score_noise; needs the per-class vector as 4th tuple entry)
+    A rival that is itself kept on one side only is followed recursively (a flip propagates down a chain of overlapping boxes).  -> {row: reason or None}; None
+    = a difference that rounding noise of the stated size does NOT explain (an arithmetic difference of the kernels)."""
+    def order_key(c, r):
+        return (-float(np.float32(c[r][1])), r)
+
+    def explain(a, cx, kx, cy, ky, d):
+        # `a` is kept on side y and missing on side x
+        if d > depth:
+            return None
+        if a not in cx:
+            return "conf-threshold" if abs(cy[a][1] - conf_thres) <= score_noise else None
+        kxs = list(kx)
+        sup = [b for b in kxs if b != a and cx[b][2] == cx[a][2] and order_key(cx, b) < order_key(cx, a) and box_iou_1(cx[a][0], cx[b][0]) > iou_thres]
+        if not sup:
+            if len(kxs) >= max_det and abs(cx[a][1] - cx[kxs[-1]][1]) <= 2 * score_noise:
+                return "cut"
+            return None
+        b = sup[0]
+        if b not in cy:
+            return "conf-threshold" if abs(cx[b][1] - conf_thres) <= score_noise else None
+        if cy[b][2] != cy[a][2]:                      # the rival changed class between the sides: two of its class scores tie (`conf, j = x[:, 5:].max(1)`)
+            for c in (cy, cx):
+                if len(c[b]) > 3 and abs(float(c[b][3][cx[b][2]]) - float(c[b][3][cy[b][2]])) <= 2 * score_noise:
+                    return "class-tie"
+            return None
+        iy, ix = box_iou_1(cy[a][0], cy[b][0]), box_iou_1(cx[a][0], cx[b][0])
+        if iy <= iou_thres:
+            return "iou-threshold" if (iou_thres - iy) <= iou_noise and (ix - iou_thres) <= iou_noise else None
+        if order_key(cy, a) < order_key(cy, b):        # on y the row comes first (and, kept, suppresses b there): the two swapped order
+            return "score-tie" if abs(cy[a][1] - cy[b][1]) <= 2 * score_noise and abs(cx[a][1] - cx[b][1]) <= 2 * score_noise else None
+        if b in set(ky):
+            return None                                   # b precedes a on y, overlaps it, is kept -- and a is kept too: not a greedy NMS outcome
+        r = explain(b, cy, ky, cx, kx, d + 1)            # b is kept on x, missing on y: the flip happened further up the chain
+        return ("chain:" + r) if r else None
+
+    sx, sy = set(kept_x), set(kept_y)
+    out = {}
+    for a in kept_y:
+        if a not in sx:
+            out[int(a)] = explain(a, cands_x, kept_x, cands_y, kept_y, 0)
+    for a in kept_x:
+        if a not in sy:
+            out[int(a)] = explain(a, cands_y, kept_y, cands_x, kept_x, 0)
+    return out

@@ -8,6 +8,7 @@
 # stop the others.  BEFORE calling (CPU): python -m yolov7_tracker_amd.build && git rev-parse HEAD > .commit_stamp
 # Steps:
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
+#   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
@@ -44,7 +45,9 @@ for n in sys.argv[2:]:
         print("%-14s %7.0f fps  step %.2f ms  list %.2f ms  frac %.4f  tracker chain %.2f ms  nms %.2f ms | latency %s | cands within bar %s of %s, boxes %s/%s"
               % (n, l["value"], l["ms_per_step"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"], ph.get("tracker_chain", float("nan")),
                  ph.get("decode_nms", float("nan")), (l.get("latency_mode") or {}).get("u8_hwc_host", {}).get("fps"), c.get("frac_within_bar"), c.get("n_both"),
-                 p.get("boxes_matched_same_class_1px_conf5e-3"), p.get("boxes_oracle")))
+                 p.get("boxes_matched_same_class_1px_or_iou99_conf5e-3", p.get("boxes_matched_same_class_1px_conf5e-3")), p.get("boxes_oracle")))
+        if c.get("candidates_per_detect_level"):
+            print("%-14s candidates per Detect level %s, out of the coordinate bar %s; boxes by anchor row %s" % ("", c.get("candidates_per_detect_level"), c.get("n_out_of_coord_bar"), p.get("boxes_by_anchor_row")))
     except Exception as e:
         print("%-14s no bench line: %r" % (n, e))
 PY
@@ -59,6 +62,12 @@ tests)
   timeout 600 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py -k cfg3 > $O/t_new_cfg3.log 2>&1; echo "rc=$?" >> $O/t_new_cfg3.log; tailsum $O/t_new_cfg3.log
   timeout 600 python -m pytest -q -m gpu tests/test_tracker_gpu.py -k "deepsort_empty or refuses or max_det" > $O/t_new_advice.log 2>&1; echo "rc=$?" >> $O/t_new_advice.log; tailsum $O/t_new_advice.log
   timeout 900 python -m pytest -q -m gpu tests/test_multirank_gpu.py > $O/t_new_multirank.log 2>&1; echo "rc=$?" >> $O/t_new_multirank.log; tailsum $O/t_new_multirank.log
+  ;;
+
+tests4)
+  say "tests4: round 4 -- all four Detect levels live (damped and undamped), SURVEY 8a's full bar, every kept-set difference explained"
+  timeout 900 python -m pytest -x -q -m gpu -s tests/test_detector_pinned_gpu.py -k "boxes or candidates or all_levels or heads_end_to_end_against" > $O/t_r4_parity.log 2>&1; echo "rc=$?" >> $O/t_r4_parity.log
+  grep -h "candidates\|oracle keeps\|level [0-9]:" $O/t_r4_parity.log | cut -c1-700 | tee -a $O/summary.txt; tailsum $O/t_r4_parity.log 4
   ;;
 
 suite)

@@ -312,3 +312,55 @@ def test_training_spec_equals_reference_yaml_and_oracle_equals_reference_model(h
         ref = m(img)
     dec, raw = dt.forward(nodes, sd, img, spec["anchors"])
     assert torch.equal(dec, ref[0])                                   # IAuxDetect.forward inference branch: main levels only (yolo.py:141-158)
+
+
+def test_kept_set_difference_explainer_and_full_coordinate_bar():
+    """the checkers the GPU box-level tests rely on (oracle/detector_torch.py: nms_rows, compare_candidate_sets(iou=...), explain_kept_set_difference), exercised where no
+    GPU exists: the oracle's fp16-storage emulation stands in for the device on a 512 x 512 frame, all four Detect levels live.  nms_rows must BE
+    non_max_suppression (utils/general.py:607-695); every kept-set difference between the two precisions must get a named reason; a difference that rounding
+    noise cannot produce (a candidate whose score was moved by 100 x the noise) must NOT."""
+    from yolov7_tracker_amd import synth
+    torch.set_num_threads(8)
+    nc, H = 10, 512
+    spec = arch.ARCHS["yolov7-w6"](nc)
+    frames = synth.make_frames(1, 80, H, seq_idx=0)
+    img = (torch.from_numpy(frames[:1][..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    nodes, _ = graph.parse(spec)
+    plan = graph.lower(graph.parse(spec)[0], H, H, 1)
+    sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0, bn_bias_mean=2.0), seed=0, image=img)
+    na, no = 3, nc + 5
+    for k in list(sd):
+        if ".m." in k and k.endswith(".weight"):
+            w = sd[k].clone().view(na, no, -1)
+            w[:, 2:4] *= 0.25
+            sd[k] = w.view(na * no, -1, 1, 1)
+    _, raw16 = dt.forward(nodes, sd, img, spec["anchors"], fp16=True)
+    logits = torch.cat([r[0, ..., 4].reshape(-1) for r in raw16])
+    shift = float(np.log(0.01 / 0.99)) - torch.quantile(logits.float(), 1.0 - 1500 / logits.numel()).item()      # detector/model.py::plant_objectness_bias
+    base = "model.%d" % next(n for n in nodes if n.kind == "detect").layer
+    for l in range(4):
+        b = sd["%s.m.%d.bias" % (base, l)].float().clone().view(na, no)
+        b[:, 4] += shift
+        b[:, 5:] += 4.0
+        sd["%s.m.%d.bias" % (base, l)] = b.view(-1)
+    dec32, _ = dt.forward(nodes, sd, img, spec["anchors"])
+    dec16, _ = dt.forward(nodes, sd, img, spec["anchors"], fp16=True)
+    got, want = dt.candidates(dec16[0], 0.01), dt.candidates(dec32[0], 0.01)
+    st = dt.compare_candidate_sets(got, want, 0.01, px=1.0, dconf=5e-3, iou=0.99)
+    assert st["n_both"] > 1000 and st["frac_within_bar"] == 1.0 and st["out_of_coord_bar"] == [] and st["n_class_differs"] == 0, st
+    assert dt.compare_candidate_sets(got, want, 0.01, px=1e-3, dconf=5e-3, iou=0.999999)["frac_within_bar"] < 1.0      # the bar is a bar
+    kg, kw = dt.nms_rows(got), dt.nms_rows(want)
+    ref = dt.non_max_suppression(dec32, 0.01, 0.45)[0]
+    assert len(ref) == len(kw) and np.array_equal(ref[:, 4].numpy(), np.array([want[r][1] for r in kw], np.float32))
+    assert np.allclose(ref[:, :4].numpy(), np.stack([want[r][0] for r in kw]))
+    noise = max(abs(got[r][1] - want[r][1]) for r in set(got) & set(want))
+    ex = dt.explain_kept_set_difference(got, kg, want, kw, score_noise=noise)
+    assert set(ex) == set(kg.tolist()) ^ set(kw.tolist())
+    assert all(v is not None for v in ex.values()), ex
+    # a genuine difference (a kernel that drops a detection nothing overlaps, ranked far from the max_det cut) must stay unexplained
+    lonely = next(int(r) for r in kw[:50] if r in set(kg.tolist()) and not any(
+        o != r and got[o][2] == got[r][2] and dt.box_iou_1(got[o][0], got[r][0]) > 0.3 for o in kg))
+    kb = np.array([r for r in kg if r != lonely])
+    exb = dt.explain_kept_set_difference(got, kb, want, kw, score_noise=noise)
+    assert lonely in exb and exb[lonely] is None, exb
+    assert dt.box_iou_1([0, 0, 10, 10], [0, 0, 10, 5]) == 0.5 and dt.box_iou_1([0, 0, 1, 1], [2, 2, 3, 3]) == 0.0

@@ -45,10 +45,11 @@ def bench_det():
     return det, frames_host, out
 
 
-@pytest.fixture(scope="module")
-def smooth_det():
-    """the same launch list on well-conditioned weights (BatchNorm shifts ~ +2, statistics calibrated on frame 0 of the scene) with a
-    VisDrone-like head: width/height logits damped (boxes of roughly anchor size, 40-120 px) and the candidates planted on the fine levels"""
+def _conditioned_detector(damp_wh):
+    """the benchmarked launch list on well-conditioned weights (BatchNorm shifts ~ +2, statistics calibrated on frame 0 of the scene); ALL FOUR Detect levels
+    live (no per-level objectness offsets: ~2000 candidates per frame wherever the head puts them).  damp_wh: factor on the width / height rows of the Detect
+    convs -- 0.25 gives boxes of roughly anchor size (19 ... 1000 px: what a trained head produces), 1.0 leaves the random head's logits as they are
+    (sigmoids saturate: boxes of up to 4 x the anchor, 2000+ px on the coarse levels)"""
     from yolov7_tracker_amd import synth
     from yolov7_tracker_amd.detector import arch, graph, model, weights
     spec = arch.ARCHS["yolov7-w6"](10)
@@ -57,17 +58,30 @@ def smooth_det():
     nodes, _ = graph.parse(spec)
     plan = graph.lower(graph.parse(spec)[0], 1280, 1280, 1)
     sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0, bn_bias_mean=2.0), seed=0, image=cal)
-    for k in list(sd):
-        if ".m." in k and k.endswith(".weight"):                 # Detect 1x1 convs: rows (anchor, [x, y, w, h, obj, cls...])
-            w = sd[k].clone().view(3, 15, -1)
-            w[:, 2:4] *= 0.25
-            sd[k] = w.view(45, -1, 1, 1)
+    if damp_wh != 1.0:
+        for k in list(sd):
+            if ".m." in k and k.endswith(".weight"):                 # Detect 1x1 convs: rows (anchor, [x, y, w, h, obj, cls...])
+                w = sd[k].clone().view(3, 15, -1)
+                w[:, 2:4] *= damp_wh
+                sd[k] = w.view(45, -1, 1, 1)
     det = model.Detector(spec, sd, img_size=(1280, 1280), max_batch=B_BENCH)
     frames = torch.from_numpy(frames_host).cuda()
-    det.plant_objectness_bias(frames, level_offsets=(0, 0, -3, -6))
+    det.plant_objectness_bias(frames)
     out = det(frames)[0]
     torch.cuda.synchronize()
     return det, frames_host, out
+
+
+@pytest.fixture(scope="module")
+def smooth_det():
+    """anchor-sized boxes (width / height logits x 0.25), all four Detect levels live: the weights bench.py times (`--weights conditioned`)"""
+    return _conditioned_detector(0.25)
+
+
+@pytest.fixture(scope="module")
+def all_levels_det():
+    """all four Detect levels live AND undamped width / height logits"""
+    return _conditioned_detector(1.0)
 
 
 def _slice(det, buf, ld, coff, c, H, W, frames):
@@ -198,39 +212,62 @@ def test_heads_end_to_end_against_fp32_oracle(smooth_det):
         assert e32.mean().item() < 4e-3 * scale and e32.max().item() < 4e-2 * scale, l
 
 
-def test_boxes_end_to_end_against_fp32_oracle(smooth_det):
-    """(c) image -> (n, 6) rows [x1, y1, x2, y2, conf, cls]: device decode + NMS + scale_coords + round on the fp16 network's heads vs
-    oracle/detector_torch (fp32 network, utils/general.py:607-695 NMS, general.py:319-340, track.py:240) on the same frames, at the
-    bar SURVEY.md 8a states: same count, same class, |dcoord| <= 1 px after .round(), |dconf| <= 5e-3, matched one to one as SETS (the
-    scores of the 300 survivors of ~2000 candidates are spaced closer than the fp16 noise, so rank order is not comparable).  At most
-    3 % of the boxes may fail to find their partner: greedy-NMS decisions and the 300-cut flip where two scores tie within that noise."""
+def _kept_rows_check(det, frames_host, fr, coord_rel=0.0):
+    """image -> final boxes, device vs fp32 oracle, by ANCHOR ROW (the device reports which candidate every kept detection is): rows kept on both sides must agree
+    at SURVEY 8a's bar (same class, |dcoord| <= 1 px after round OR IoU >= 0.99 [OR, coord_rel > 0, |dcoord| <= 1 px + coord_rel x the box's larger side],
+    |dconf| <= 5e-3); every row kept on ONE side only must be explained by a named greedy decision that flips within the measured score noise
+    (oracle/detector_torch.py::explain_kept_set_difference: score tie with its rival, IoU at the NMS threshold, class tie of the rival, the max_det cut, conf_thres)."""
     from oracle import detector_torch as dt
-    det, frames_host, out = smooth_det
-    fr = [0, 31]
+    from tests import util
+    out = det.forward(torch.from_numpy(frames_host).cuda(), fuse_decode=0.01)          # what bench.py times
     dets, nd = det.postprocess(out, 0.01, 0.45, None)
     torch.cuda.synchronize()
     det.check_overflow()
-    assert 1000 < int(det.plan.cand[fr].min()) and int(det.plan.cand[fr].max()) < 8000          # a VisDrone-like candidate load
+    keep = det.plan.post[out.pset].keep.cpu().numpy()
+    cidx = det.candidate_arrays(out.pset)[3].cpu().numpy()
     dec, _ = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
-    ref = dt.non_max_suppression(dec, 0.01, 0.45)
+    stats = []
     for i, b in enumerate(fr):
-        d = dets[b, :int(nd[b])].cpu()
-        r = ref[i].clone()
-        r[:, :4] = dt.scale_coords_round((1280, 1280), r[:, :4], (1280, 1280))
-        assert len(r) >= 100 and len(d) == len(r), (len(d), len(r))
-        used = torch.zeros(len(d), dtype=torch.bool)
-        matched, dconf, dcoord = 0, 0.0, 0.0
-        for row in r:
-            ok = (~used) & (d[:, 5] == row[5]) & ((d[:, :4] - row[:4]).abs().max(1).values <= 1.0) & ((d[:, 4] - row[4]).abs() <= 5e-3)
-            if ok.any():
-                j = int(torch.nonzero(ok)[0])
-                used[j] = True
-                matched += 1
-                dconf, dcoord = max(dconf, abs(float(d[j, 4] - row[4]))), max(dcoord, float((d[j, :4] - row[:4]).abs().max()))
-        size = (r[:, 2:4] - r[:, :2]).max(1).values
-        print("frame %d: %d boxes (sides %.0f..%.0f px, %d classes), %d matched at the 8a bar, max |dconf| %.2e, max |dcoord| %.0f px" % (
-            b, len(r), float(size.min()), float(size.max()), len(torch.unique(r[:, 5])), matched, dconf, dcoord))
-        assert matched >= 0.97 * len(r)
+        got, want = _device_candidates(det, out.pset, b), util.oracle_candidates(dec[i], 0.01)
+        n = int(nd[b])
+        kd = cidx[b][keep[b, :n]]                                   # device: kept anchor rows in output order
+        kw = dt.nms_rows(want, 0.45)                                # oracle: utils/general.py:664-695 on its own candidates
+        ref = dt.non_max_suppression(dec[i:i + 1], 0.01, 0.45)[0]
+        assert len(ref) == len(kw) and np.array_equal(ref[:, 4].numpy(), np.array([want[r][1] for r in kw], np.float32))      # nms_rows IS non_max_suppression
+        d = dets[b, :n].cpu().numpy()
+        rb = dt.scale_coords_round((1280, 1280), ref[:, :4], (1280, 1280)).numpy()
+        pos_d = {int(r): j for j, r in enumerate(kd)}
+        both, worst_c, worst_s, n_iou = 0, 0.0, 0.0, 0
+        for j, r in enumerate(kw):
+            if int(r) not in pos_d:
+                continue
+            both += 1
+            row = d[pos_d[int(r)]]
+            dc, ds = float(np.abs(row[:4] - rb[j]).max()), abs(float(row[4]) - float(ref[j, 4]))
+            side = float(max(rb[j][2] - rb[j][0], rb[j][3] - rb[j][1]))
+            ok_c = dc <= 1.0 or dt.box_iou_1(row[:4], rb[j]) >= 0.99 or dc <= 1.0 + coord_rel * side
+            n_iou += dc > 1.0
+            assert ok_c and ds <= 5e-3 and (row[5] == float(ref[j, 5]) or want[int(r)][3][int(row[5])] >= want[int(r)][1] - 5e-3), (b, int(r), row, rb[j], ref[j])
+            worst_c, worst_s = max(worst_c, dc if dc <= 1.0 else 0.0), max(worst_s, ds)
+        common = sorted(set(got) & set(want))
+        noise = max(1e-4, max(abs(got[r][1] - want[r][1]) for r in common))      # the measured score noise of this frame's candidates
+        ex = dt.explain_kept_set_difference(got, kd, want, kw, score_noise=noise)
+        reasons = collections.Counter(v or "UNEXPLAINED" for v in ex.values())
+        print("frame %d: oracle keeps %d, device %d, %d rows kept by both (all at the 8a bar: max |dcoord| %.0f px among the <= 1 px ones, %d pass on IoU >= 0.99, max |dconf| %.2e); "
+              "%d rows kept on one side only: %s (score noise %.2e)" % (b, len(kw), n, both, worst_c, n_iou, worst_s, len(ex), dict(reasons), noise))
+        assert len(kw) >= 100 and both >= 0.9 * len(kw)
+        assert all(v is not None for v in ex.values()), {k: v for k, v in ex.items() if v is None}
+        stats.append((len(kw), n, both, dict(reasons)))
+    return stats
+
+
+def test_boxes_end_to_end_against_fp32_oracle(smooth_det):
+    """(c) image -> (n, 6) rows [x1, y1, x2, y2, conf, cls]: device decode + NMS + scale_coords + round on the fp16 network's heads vs
+    oracle/detector_torch (fp32 network, utils/general.py:607-695 NMS, general.py:319-340, track.py:240) on the same frames, all four Detect levels live.
+    VERDICT r3 weak 2: no budget of unmatched boxes -- every kept row both sides share is at SURVEY 8a's bar, and every row only one side keeps is traced to
+    the greedy decision that flipped and shown to be a tie within the frame's measured score noise."""
+    det, frames_host, _ = smooth_det
+    _kept_rows_check(det, frames_host, [0, 31])
 
 
 def _device_candidates(det, pset, b):
@@ -265,10 +302,10 @@ def test_candidates_before_nms_against_fp32_oracle(smooth_det):
     for i, b in enumerate(fr):
         got = _device_candidates(det, out.pset, b)
         want = util.oracle_candidates(dec[i], 0.01)
-        st = util.compare_candidate_sets(got, want, 0.01, px=1.0, dconf=5e-3)
+        st = util.compare_candidate_sets(got, want, 0.01, px=1.0, dconf=5e-3, iou=0.99)      # 8a: IoU >= 0.99 / |dcoord| <= 1 px (the 400 ... 1700 px boxes of levels 2-3 pass on IoU)
         print("frame %d candidates:" % b, st)
         assert st["n_both"] >= 1000 and st["n_only_one_side"] <= 0.02 * st["n_both"], st
-        assert st["frac_within_bar"] == 1.0 and st["max_dcoord"] <= 1.0 and st["max_dconf"] <= 5e-3, st
+        assert st["frac_within_bar"] == 1.0 and st["out_of_coord_bar"] == [] and st["max_dconf"] <= 5e-3, st
         assert st["n_class_differs"] == 0 and st["max_margin_only_one_side"] <= 1e-3, st
         # greedy NMS (utils/general.py:664-695 + torchvision.ops.nms restated in oracle/y7t_oracle.c) on identical candidates: bit-exact keep list
         rows = np.array(sorted(got)); n = len(rows)
@@ -278,6 +315,48 @@ def test_candidates_before_nms_against_fp32_oracle(smooth_det):
         cidx = det.candidate_arrays(out.pset)[3][b].cpu().numpy()
         assert int(nd[b]) == len(k)
         np.testing.assert_array_equal(rows[order[k]], cidx[keep[b, :int(nd[b])]])
+
+
+def test_all_levels_undamped_candidates_at_the_full_8a_bar(all_levels_det):
+    """the configuration the other tests make easy, made hard -- all four Detect levels live (no per-level objectness offsets) and the
+    random head's width / height logits UNDAMPED (std 2-3: the sigmoids saturate, boxes reach (2 s)^2 = 4 x the anchor: 2000+ px on levels 2-3, and ~0 px wide
+    ones), 32 frames at 1280^2, fused Detect epilogues.  Against the fp32 oracle, for EVERY candidate both sides have (models/yolo.py:39-57, utils/general.py:629-662):
+      * same class (or one the oracle scores within 5e-3 of its best) and |dconf| <= 5e-3 -- all of them;
+      * coordinates at SURVEY 8a's full bar, IoU >= 0.99 OR |dcoord| <= 1 px: >= 98 % of them (the oracle's own fp16-storage emulation, scripts/parity_all_levels_cpu.py,
+        says 98.9 %: a box edge moves by w (1 - s) 2 dt for a logit error dt, and dt -- fp16 storage of ~60 tensors, 0.13 % of the logit spread -- is what it is);
+      * every candidate outside that bar is one no detector would emit and is still tight: larger than the 1280-px image or thinner than 1 : 20, with
+        |dcoord| <= 1 px + 0.5 % of its larger side.
+    Candidates only one side has sit within 1e-3 of conf_thres."""
+    from oracle import detector_torch as dt
+    from tests import util
+    det, frames_host, _ = all_levels_det
+    fr = [0, 31]
+    out = det.forward(torch.from_numpy(frames_host).cuda(), fuse_decode=0.01)
+    dets, nd = det.postprocess(out, 0.01, 0.45, None)
+    torch.cuda.synchronize()
+    det.check_overflow()
+    dec, _ = dt.forward(det.nodes, det._sd, _imgs(frames_host, fr), det.spec["anchors"])
+    rows0 = np.cumsum([0] + [3 * (1280 // s) ** 2 for s in (8, 16, 32, 64)])
+    for i, b in enumerate(fr):
+        got, want = _device_candidates(det, out.pset, b), util.oracle_candidates(dec[i], 0.01)
+        st = util.compare_candidate_sets(got, want, 0.01, px=1.0, dconf=5e-3, iou=0.99)
+        oob = st.pop("out_of_coord_bar")
+        per_level = np.bincount(np.searchsorted(rows0, np.array(sorted(got)), side="right") - 1, minlength=4)[:4].tolist()
+        print("frame %d, all levels undamped: candidates per level %s;" % (b, per_level), st, "| outside the coordinate bar:", oob[:6])
+        assert st["n_both"] >= 1000 and st["n_only_one_side"] <= 0.02 * st["n_both"] and st["max_margin_only_one_side"] <= 1e-3, st
+        assert sum(v > 0 for v in per_level) >= 3 and per_level[2] + per_level[3] >= 100, per_level          # the coarse levels are really in play
+        assert st["n_class_differs"] == 0 and st["max_dconf"] <= 5e-3, st
+        assert st["frac_within_bar"] >= 0.98, st
+        for o in oob:
+            big, small = max(o["w"], o["h"]), min(o["w"], o["h"])
+            assert o["dcoord"] <= 1.0 + 0.005 * big and (big > 1280 or small * 20 < big), o
+
+
+def test_all_levels_undamped_boxes_every_difference_explained(all_levels_det):
+    """... and image -> final boxes in that configuration: rows both sides keep agree at the 8a bar (boxes larger than the image: 1 px + 0.5 % of the side), every row only
+    one side keeps is traced to a greedy NMS decision tied within the measured score noise (see _kept_rows_check)."""
+    det, frames_host, _ = all_levels_det
+    _kept_rows_check(det, frames_host, [0, 31], coord_rel=0.005)
 
 
 def test_training_graph_checkpoint_on_the_device():
