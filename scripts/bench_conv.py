@@ -25,14 +25,12 @@ for key, cnt in shapes.items():
     if ONLY and [int(v) for v in ONLY.split(",")] != [H, Cin, Cout, k, s]: continue
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     K = k * k * Cin; K_pad = (K + 63) // 64 * 64
-    if graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): Cout_pad = (Cout + 127) // 128 * 128
     x = torch.randn((B, H, W, in_ld), device="cuda").half()
     w = (torch.randn((Cout_pad, K_pad), device="cuda") / K ** 0.5).half()
     b = torch.randn(Cout_pad, device="cuda")
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
     # `act` bits of y7t_conv2d_nhwc_f16 = the weight packing the plan would give this layer (the weights are random: only the kernel choice matters here)
-    if graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 16384          # opt-in: Y7T_CONV_WS128=1 (prepared experiment)
-    elif graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
+    if graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
     elif graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = 1 | 1024
     elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32, B * Ho * Wo): code = 1 | 4096          # stride-2 patch kernel where it measured faster
     elif k == 3 and Cin % 64 == 0: code = 1 | (KORDER << 8)

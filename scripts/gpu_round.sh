@@ -21,7 +21,6 @@
 #   exp_noslp       the library against lib/liby7t_prev.so (a copy of an earlier build, Y7T_LIB): parity suite, per-layer table of both, bench lines of both
 #   exp_clock       shader clock per kernel (scripts/clock_probe.sh), ws64 counters at 32 frames, MFMA operand-order micro-benchmark
 #   exp_wsprobe     the ws64 layer by data / layout / working set (scripts/ws_probe.py);   exp_wsabl: its timing ablations (Y7T_WS_ABLATE)
-#   exp_ws128       the 128-channel weights-stationary kernel (prepared experiment, Y7T_CONV_WS128=1): parity, per-layer time, bench lines against the default
 #   exp_latency     one-frame per-layer table + kernel trace of the batch-1 latency mode (scripts/latency_trace.sh)
 #   exp_arena       tracker index lists in LDS for the length of a frames launch: tracker tests, bench lines with / without (Y7T_TRACKER_ARENA=0)
 #   pmc_queues      which queue of the buffer->LDS path the generic kernel waits in (TA / TCP / TCC / SQ counters on three layers)
@@ -180,20 +179,6 @@ exp_wsprobe)
 exp_wsabl)
   say "exp_wsabl: timing ablations of the ws64 kernel (wrong results): 1 no epilogue, 2 no pieces, 4 no fragment reads, 8 no wait / barrier, 16 no stores; 320 x 320, 32 frames"
   for a in ${ABLS:-0 1 2 3 4 8 16 18}; do echo "-- ablate $a"; Y7T_WS_ABLATE=$a QUICK=1 timeout 100 python scripts/ws_probe.py 2>&1 | grep -v amdgpu.ids; done | tee -a $O/summary.txt
-  ;;
-
-exp_ws128)
-  say "exp_ws128 a: the 128-channel weights-stationary kernel (csrc/y7t_conv_ws128.hip, prepared at the end of round 3): layer parity vs torch fp32, then inside the benchmarked list"
-  Y7T_CONV_WS128=1 timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k weights_stationary_128 > $O/t_ws128.log 2>&1; echo "rc=$?" >> $O/t_ws128.log; tailsum $O/t_ws128.log
-  Y7T_CONV_WS128=1 timeout 400 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_ws128_pinned.log 2>&1; echo "rc=$?" >> $O/t_ws128_pinned.log; tailsum $O/t_ws128_pinned.log
-  say "exp_ws128 b: per-layer timing at 32 frames (128 -> 128 / 256 3/1 rows): default (patch kernels) vs ws128"
-  timeout 200 python scripts/bench_conv.py 32 > $O/b_default.txt 2>&1
-  Y7T_CONV_WS128=1 timeout 200 python scripts/bench_conv.py 32 > $O/b_ws128.txt 2>&1
-  for f in default ws128; do echo "-- $f"; grep " 128->128 \| 128->256  3/1\|TOTAL" $O/b_$f.txt; done | tee -a $O/summary.txt
-  say "exp_ws128 c: bench lines"
-  timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_default.json 2> $O/bench_default.err
-  Y7T_CONV_WS128=1 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $O/bench_ws128.json 2> $O/bench_ws128.err
-  benchsum default ws128
   ;;
 
 exp_latency)

@@ -43,9 +43,6 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 5:   # register-fragment order of the weights-stationary 64 -> 64 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.pack_ws(blk)
-    if korder == 6:   # ... of its 128-channel sibling
-        from yolov7_tracker_amd.detector import weights
-        blk = weights.pack_ws128(blk)
     return blk
 
 
@@ -100,7 +97,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 6 if act & 16384 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    korder = 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
     cout_pad = (Cout + 63) // 64 * 64 if korder not in (4, 6) else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
@@ -147,25 +144,6 @@ def test_weights_stationary_kernel_matches_torch_fp32(L, case):
     from yolov7_tracker_amd import _lib
     test_conv_layer_matches_torch_fp32(L, case)
     assert L.y7t_last_kernel().decode() == "ws64<16,16>"
-
-
-# csrc/y7t_conv_ws128.hip: the 128-channel sibling (act bit 14: korder 6).  A PREPARED EXPERIMENT that has not run on a GPU yet: these cases run only when
-# Y7T_CONV_WS128=1 (scripts/gpu_round.sh exp_ws128), so that the default suite contains nothing that was never measured.
-WS128_CASES = [
-    # B, H, W, Cin, Cout, k, s, act (bit 14), in_ld, in_coff, out_ld, out_coff, out_f32
-    (1, 4, 16, 128, 128, 3, 1, 1 | 16384, 128, 0, 128, 0, 0),
-    (1, 48, 80, 128, 128, 3, 1, 1 | 16384, 128, 0, 128, 0, 0),
-    (3, 160, 160, 128, 128, 3, 1, 2 | 16384, 256, 128, 512, 128, 0),
-    (5, 80, 80, 128, 256, 3, 1, 0 | 16384, 128, 0, 256, 0, 0),
-    (8, 160, 160, 128, 128, 3, 1, 1 | 16384, 512, 0, 128, 0, 0),
-]
-
-
-@pytest.mark.skipif(os.environ.get("Y7T_CONV_WS128") != "1", reason="prepared experiment (csrc/y7t_conv_ws128.hip): opt-in with Y7T_CONV_WS128=1")
-@pytest.mark.parametrize("case", WS128_CASES)
-def test_weights_stationary_128_kernel_matches_torch_fp32(L, case):
-    test_conv_layer_matches_torch_fp32(L, case)
-    assert L.y7t_last_kernel().decode() == "ws128<4,16>"
 
 
 # csrc/y7t_conv_patch_s2.hip: the stride-2 LDS-patch kernel (parity-split patch columns, 16-channel chunks; korder 4 = act bit 12), 128- and 256-channel panels

@@ -237,7 +237,7 @@ def _kept_rows_check(det, frames_host, fr, coord_rel=0.0):
         d = dets[b, :n].cpu().numpy()
         rb = dt.scale_coords_round((1280, 1280), ref[:, :4], (1280, 1280)).numpy()
         pos_d = {int(r): j for j, r in enumerate(kd)}
-        both, worst_c, worst_s, n_iou = 0, 0.0, 0.0, 0
+        both, worst_c, worst_s, n_iou, n_preclip = 0, 0.0, 0.0, 0, 0
         for j, r in enumerate(kw):
             if int(r) not in pos_d:
                 continue
@@ -246,6 +246,13 @@ def _kept_rows_check(det, frames_host, fr, coord_rel=0.0):
             dc, ds = float(np.abs(row[:4] - rb[j]).max()), abs(float(row[4]) - float(ref[j, 4]))
             side = float(max(rb[j][2] - rb[j][0], rb[j][3] - rb[j][1]))
             ok_c = dc <= 1.0 or dt.box_iou_1(row[:4], rb[j]) >= 0.99 or dc <= 1.0 + coord_rel * side
+            if not ok_c:
+                # scale_coords' clip (utils/general.py:331-340) can cut a box that straddles the image border down to a fraction of itself: the same edge error is then
+                # a larger share of what is left (a 781-px box clipped to 543 px: 2 px on one edge = IoU 0.9887).  The decode's own output -- the candidate before
+                # clip / round -- is what 8a's bar is about there: it must pass (clip and round are exact integer operations on both sides)
+                g, w_ = got[int(r)][0], want[int(r)][0]
+                ok_c = (float(np.abs(g - w_).max()) <= 1.0 or dt.box_iou_1(g, w_) >= 0.99) and dc <= 3.0
+                n_preclip += ok_c
             n_iou += dc > 1.0
             assert ok_c and ds <= 5e-3 and (row[5] == float(ref[j, 5]) or want[int(r)][3][int(row[5])] >= want[int(r)][1] - 5e-3), (b, int(r), row, rb[j], ref[j])
             worst_c, worst_s = max(worst_c, dc if dc <= 1.0 else 0.0), max(worst_s, ds)
@@ -253,8 +260,8 @@ def _kept_rows_check(det, frames_host, fr, coord_rel=0.0):
         noise = max(1e-4, max(abs(got[r][1] - want[r][1]) for r in common))      # the measured score noise of this frame's candidates
         ex = dt.explain_kept_set_difference(got, kd, want, kw, score_noise=noise)
         reasons = collections.Counter(v or "UNEXPLAINED" for v in ex.values())
-        print("frame %d: oracle keeps %d, device %d, %d rows kept by both (all at the 8a bar: max |dcoord| %.0f px among the <= 1 px ones, %d pass on IoU >= 0.99, max |dconf| %.2e); "
-              "%d rows kept on one side only: %s (score noise %.2e)" % (b, len(kw), n, both, worst_c, n_iou, worst_s, len(ex), dict(reasons), noise))
+        print("frame %d: oracle keeps %d, device %d, %d rows kept by both (all at the 8a bar: max |dcoord| %.0f px among the <= 1 px ones, %d pass on IoU >= 0.99 -- %d of them on the box before scale_coords' clip --, max |dconf| %.2e); "
+              "%d rows kept on one side only: %s (score noise %.2e)" % (b, len(kw), n, both, worst_c, n_iou, n_preclip, worst_s, len(ex), dict(reasons), noise))
         assert len(kw) >= 100 and both >= 0.9 * len(kw)
         assert all(v is not None for v in ex.values()), {k: v for k, v in ex.items() if v is None}
         stats.append((len(kw), n, both, dict(reasons)))

@@ -1,5 +1,4 @@
-"""Static checks on the gfx950 instruction streams of the weights-stationary kernels (hipcc cross-compiles without a GPU): the 64 -> 64 kernel of the launch list
-(csrc/y7t_conv_ws.hip) and its 128-channel sibling (csrc/y7t_conv_ws128.hip, a prepared experiment).
+"""Static checks on the gfx950 instruction streams of the weights-stationary 64 -> 64 kernel of the launch list (csrc/y7t_conv_ws.hip; hipcc cross-compiles without a GPU).
 
 The kernel writes its MFMAs as asm statements (accumulators in arch VGPRs, weights in ACC registers), so the compiler's hazard recogniser does not see them:
 the first device run of that form copied accumulator registers at the loop exit while the last MFMAs of a tile were still writing them.  What protects the
@@ -28,7 +27,7 @@ def _regs(tok):
 
 
 # file, kernel name, pieces per wave and tile, stores per wave and tile, accumulator registers of one set
-KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0EE", 13, 8, 64), "ws128": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dEE", 8, 4, 32)}
+KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0EE", 13, 8, 64)}
 
 
 @pytest.fixture(scope="module", params=sorted(KERNELS))

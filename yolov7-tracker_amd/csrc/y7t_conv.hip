@@ -554,7 +554,6 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
 int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_ws.hip (korder 5: 64 -> 64 3x3 layers, weights stationary in registers)
-int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s);      // y7t_conv_ws128.hip (korder 6: 128 -> 128 k 3x3 layers, the same idea; prepared experiment, opt-in)
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
@@ -573,7 +572,6 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
     }
     if (a.korder == 4) return y7t_conv_patch_s2_launch(a, s);   // stride-2 LDS-patch kernel's panels: only that kernel reads them
     if (a.korder == 5) return y7t_conv_ws_launch(a, s);         // register-fragment order: only the weights-stationary kernel reads it
-    if (a.korder == 6) return y7t_conv_ws128_launch(a, s);      // ... and its 128-channel sibling
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
