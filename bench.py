@@ -33,12 +33,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16 = 2.5e15      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12           # HBM3E, same guide (6.3 TB/s achievable)
 GFLOP_PER_FRAME_W6 = 354.9   # 177.45 GMAC x 2, yolov7-w6 deploy graph, nc=10, 1280x1280
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs (= ranks) of this node; default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per step (consecutive frames of the sequence)")
@@ -54,6 +55,7 @@ def parse():
                     "tracker and stream (their frame-step chains run side by side); default 1 = one sequence per GPU (the metric's configuration)")
     ap.add_argument("--tracker_threads", type=int, default=0, help="threads of the tracker step workgroup (64 / 256 / 1024; 0 = the library's rule)")
     ap.add_argument("--prio", type=int, default=0, help="1: the detector forward runs on a high-priority HIP stream (measured: no gain); 2: the tracker chain's stream does")
+    ap.add_argument("--rotate_batches", type=int, default=4, help="distinct resident input batches consumed round-robin by the timed steps (1 = the same batch every step)")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
@@ -70,7 +72,13 @@ def parse():
     ap.add_argument("--mode", default="sequences", choices=["sequences", "frames"],
                     help="sequences (default): one sequence per GPU, weak scaling, no data-path exchange.  frames: ONE sequence, batches of "
                          "frames detected round-robin over the GPUs, detections sent to the tracker on rank 0 (strong scaling, SURVEY 8e)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # under a launcher (torchrun / the driver's torch.distributed.run / SLURM: WORLD_SIZE with RANK or LOCAL_RANK) the world size comes from the environment and
+    # --gpus, if given, must agree; WORLD_SIZE=1 without a rank variable is a container default, not a launcher
+    args.launched = "WORLD_SIZE" in os.environ and ("RANK" in os.environ or "LOCAL_RANK" in os.environ or int(os.environ["WORLD_SIZE"]) > 1)
+    if args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"]) if args.launched else 1
+    return args
 
 
 TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (four waves up to 384 detections, sixteen beyond: csrc/y7t_tracker.hip::step_threads)
@@ -158,9 +166,61 @@ def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=No
     t_trk = (time.perf_counter() - t0) / n
     fps = 1.0 / (t_det + t_nms + t_trk)
     return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "reference_over_port": {"as_its_cli_runs_it_no_no_grad": 0.27, "with_no_grad": 0.56,
+                                    "note": "fps of the reference's OWN Model + non_max_suppression + ByteTrack divided by this port's, same job, the 8-core build container "
+                                            "(the reference does not exist on the GPU box): 0.45 and 0.93 fps vs 1.65 fps, outputs equal -- profiles/r03_cpu_reference_vs_port.txt. "
+                                            "`value` is the PORT's speed: the reference itself is 1.8-3.7x slower"},
             "sample": "%d frames 1280x1280 through the torch-fp32 detector oracle (%.2f s/frame, %d threads) + 1 NMS call on 2000 "
                       "candidates (%.1f ms) + %d frames through the numpy tracker oracle (%.2f ms/frame, 1 thread)"
                       % (args.cpu_frames, t_det, ncores, t_nms * 1e3, n, t_trk * 1e3)}, parity
+
+
+def roofline_tracker(det, frames, nc, img):
+    """SURVEY 8d / VERDICT r3 missing 5: the tracker-side pieces against THEIR roof (HBM), each launched alone on an idle GPU, device time by HIP events over `reps`
+    back-to-back launches, algorithmic bytes as SURVEY 8d counts them: multi_predict 1152 B per track (mean + covariance read and written, tracker/kalman_filter.py:289-329),
+    IoU cost 32 (N + M) B in + 8 N M B out (tracker/matching.py:44-82), decode + NMS 102 000 x (5 + nc) x 4 B of head tensors read per 1280^2 frame
+    (utils/general.py:607-695; the unfused y7t_det_postprocess path -- in the timed pipeline the decode sits in the Detect convs' epilogue and those tensors are never written).
+    These are KB-to-MB working sets: launch latency bounds them, the GB/s figure says how far from the 8 TB/s roof that leaves them."""
+    from yolov7_tracker_amd import _lib
+    L = _lib.load()
+    out = {"peak": PEAK_HBM / 1e9, "unit": "GB/s", "bound": "hbm (latency-bound at these sizes)", "pieces": {}}
+
+    def timed(fn, reps=200):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps       # us per launch
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n_trk, n_det in ((100, 80), (500, 500)):
+        mean = torch.rand((n_trk, 8), dtype=torch.float64, device="cuda", generator=g) * 100 + 50
+        a = torch.rand((n_trk, 8, 8), dtype=torch.float64, device="cuda", generator=g)
+        cov = a @ a.transpose(1, 2) + torch.eye(8, dtype=torch.float64, device="cuda")
+        us = timed(lambda: _lib.check(L.y7t_kf_multi_predict_f64(0, _lib.ptr(mean), _lib.ptr(cov), None, n_trk, _lib.stream_ptr())))
+        by = 1152 * n_trk
+        out["pieces"]["kf_multi_predict_%d_tracks" % n_trk] = {"us_per_frame": round(us, 2), "algorithmic_bytes": by, "achieved": round(by / us / 1e3, 3)}
+        xy = torch.rand((n_trk + n_det, 2), dtype=torch.float64, device="cuda", generator=g) * 1000
+        wh = torch.rand((n_trk + n_det, 2), dtype=torch.float64, device="cuda", generator=g) * 80 + 10
+        bx = torch.cat([xy, xy + wh], 1).contiguous()
+        ta, tb = bx[:n_trk].contiguous(), bx[n_trk:].contiguous()
+        cost = torch.empty((n_trk, n_det), dtype=torch.float64, device="cuda")
+        us = timed(lambda: _lib.check(L.y7t_iou_cost_f64(_lib.ptr(ta), n_trk, _lib.ptr(tb), n_det, _lib.ptr(cost), _lib.stream_ptr())))
+        by = 32 * (n_trk + n_det) + 8 * n_trk * n_det
+        out["pieces"]["iou_cost_%dx%d" % (n_trk, n_det)] = {"us_per_frame": round(us, 2), "algorithmic_bytes": by, "achieved": round(by / us / 1e3, 3)}
+    B = frames.shape[0]
+    o = det.forward(frames)                  # plain forward: the four head tensors are written
+    torch.cuda.synchronize()
+    us = timed(lambda: det.postprocess(o, 0.01, 0.45, None), reps=10) / B
+    by = sum(3 * (img // s_) ** 2 for s_ in (8, 16, 32, 64)) * (5 + nc) * 4
+    out["pieces"]["decode_nms_unfused"] = {"us_per_frame": round(us, 2), "algorithmic_bytes": by, "achieved": round(by / us / 1e3, 3), "frames_per_launch": int(B),
+                                            "candidates_per_frame": int(det.plan.cand[:B].float().mean().item())}
+    return out
 
 
 def conditioned_state_dict(args, nc, frames_host):
@@ -440,11 +500,14 @@ def main():
     global TRACKER_THREADS
     args = parse()
     TRACKER_THREADS = args.tracker_threads
+    launched = args.launched
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args))
-    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+    if not launched:
+        os.environ.pop("WORLD_SIZE", None)
+        if args.gpus > 1:
+            sys.exit(self_launch(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit("bench.py --gpus %d was started under a launcher with WORLD_SIZE=%s: the two must agree (one rank per GPU)"
                          % (args.gpus, os.environ.get("WORLD_SIZE")))
     cfg3, cfg4 = args.workload == "cfg3", args.workload == "cfg4"
@@ -611,7 +674,7 @@ def main():
     if args.cu_reserve > 0:    # the tracker chain on compute units of its own (include/y7t.h: y7t_stream_create_cu_mask)
         from yolov7_tracker_amd import _lib as _y7t_lib
         sA, sB = _y7t_lib.cu_masked_streams(args.cu_reserve)
-        sC = _y7t_lib.cu_masked_streams(args.cu_reserve)[1 if args.cu_reserve_nms else 0]      # (an unmasked stream would be free to use the reserved CUs)
+        sC = sB if args.cu_reserve_nms else sA      # NMS on the reserved CUs beside the tracker chain, or on the detector's share (an unmasked stream would be free to use the reserved CUs)
     NS = 2 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory
     ev_staged = [torch.cuda.Event() for _ in range(NS)]
     ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -646,6 +709,15 @@ def main():
                     det.forward_part(None, k_mid, -1, fuse_decode=CONF, pset=ps_i)
                 fwd_graphs.append((g1, g2))
     host_feed = None      # pass 1: (pinned host batch, two device batches)
+    # the timed steps do not re-read ONE resident batch (157 MB of uint8 < the 256 MB Infinity Cache: the stem's reads could be cache hits).
+    # N_ROT distinct batches (the scene's frames shifted in time and space: other bytes at other addresses, 4 x 157 MB = 629 MB) are consumed round-robin.
+    N_ROT = max(1, args.rotate_batches) if (graph is None and fwd_graphs is None) else 1
+    frames_rot = [frames] + [torch.roll(frames, shifts=(5 * k, 96 * k, 160 * k), dims=(0, 1, 2)).contiguous() for k in range(1, N_ROT)]
+    # the reference's timer stops when tracker.update has returned HOST objects (tracker/track.py:151-174): every step's result rows are copied
+    # to pinned host memory inside the timed region (own stream, behind the step's tracker chain, two buffers)
+    sD = torch.cuda.Stream()
+    host_rows = [torch.empty((B,) + tuple(results.shape[1:]), dtype=results.dtype).pin_memory() for _ in range(2)]
+    ev_d2h = [torch.cuda.Event() for _ in range(NS)]
 
     def finish(prev, gate):
         """rank sort + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
@@ -661,6 +733,12 @@ def main():
             ev_trk0[ps].record(sB)
             launch_step(ps)
             ev_trk1[ps].record(sB)
+        with torch.cuda.stream(sD):            # the step's track rows -> host
+            sD.wait_event(ev_trk1[ps])
+            if ps >= 2:
+                sD.wait_event(ev_d2h[ps - 2])
+            host_rows[ps % 2].copy_(results[ps * B:(ps + 1) * B], non_blocking=True)
+            ev_d2h[ps].record(sD)
 
     def step(s):
         if graph is not None:
@@ -675,7 +753,7 @@ def main():
                 launch_step(s)
                 ev_trk1[s].record(sB)
             return
-        src = frames
+        src = frames_rot[s % N_ROT]
         if host_feed is not None:              # this batch comes over PCIe: copy on its own stream into the buffer the forward two steps back used
             src = host_feed[1][s % 2]
             with torch.cuda.stream(sH):
@@ -735,20 +813,21 @@ def main():
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_s = float(tmax.item())
-        # result gather (the only collective, after the timed steps): per-rank id counts -> exclusive prefix (id re-basing so
-        # the ids equal a single-process run with the reference's global BaseTrack._count), rows to rank 0
-        cnt = torch.tensor([BaseTrack._count], dtype=torch.int64, device=cdev)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        base = int(sum(int(c.item()) for c in allc[:rank]))
-        ids = results[:, :trk.cap_t, 0]                      # row cap_t of every frame holds the row count, not a track
-        ids += base * (ids > 0)
-        payload = results if cdev == "cuda" else results.cpu()
-        gathered = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
-        dist.gather(payload, gathered, dst=0)
+        # result gather (the only collective, after the timed steps): sharding.rebase_and_gather -- the code the world-size-2 gloo test proves -- does the id
+        # re-basing (per-rank id counts -> exclusive prefix: the ids of a single-process run with the reference's global BaseTrack._count) and ONE
+        # gather of compact 28-byte rows (frame, id, x, y, w, h, cls) to rank 0.  Each rank's sequences travel as one block keyed by its rank.
+        from yolov7_tracker_amd import sharding as _sh
+        live = results[:, :trk.cap_t, 0] > 0                  # row cap_t of every frame holds the row count, not a track
+        fi, ri = torch.nonzero(live, as_tuple=True)
+        rr = results[fi, ri]                                  # (n, 8) [id, x, y, w, h, cls, score, slot]
+        rows = torch.cat([(fi + 1).to(torch.float64)[:, None], rr[:, :6]], 1)      # [frame (1-based, in this rank's frame order), id (local), x, y, w, h, cls]
+        rows = rows if cdev == "cuda" else rows.cpu()
+        gathered = _sh.rebase_and_gather({rank: rows}, {rank: int(BaseTrack._count)}, world, device=cdev)
         if rank == 0:
-            n_rows = [int((g[:, :trk.cap_t, 0] > 0).sum().item()) for g in gathered]
-            gathered_info = {"rows_per_rank": n_rows, "id_base_per_rank": [int(sum(int(c.item()) for c in allc[:r])) for r in range(world)]}
+            st = dict(_sh.last_gather_stats)
+            gathered_info = {"rows_per_rank": st["rows_per_rank"], "bytes_per_row": st["bytes_per_row"], "payload_bytes_per_rank": st["payload_bytes_per_rank"],
+                             "id_base_per_rank": st["id_offset_per_seq"],
+                             "via": "yolov7_tracker_amd.sharding.rebase_and_gather (2 all_reduce of 2 x world int64 + 1 gather)"}
     torch.cuda.synchronize()
     det.check_overflow()
 
@@ -775,6 +854,7 @@ def main():
                                     "configs[1]: YOLOv7-w6 1280x1280 + ByteTrack") + ", %d synthetic VisDrone-shape sequence%s per GPU, %d objects per frame "
                                    "(10 %% missed, 5 %% false positives, reflected at the border)" % (S, "" if S == 1 else "s (their tracker chains side by side)", args.n_obj), "frames_per_step": B, "arch": args.arch, "nc": nc,
                        "tracker": tracker_name, "sequences_per_gpu": S,
+                       "input_batches_rotated": N_ROT, "track_rows_copied_to_host_inside_the_timed_region": graph is None,
                        "tracks_alive_last_frame": n_tracks_last, "nms_candidates_last": int(det.plan.cand.max().item()),
                        "parallelism": "sequence-sharded x%d" % world, "collective_backend": backend if world > 1 else None,
                        "result_gather": gathered_info if world > 1 else None},
@@ -861,6 +941,8 @@ def main():
                                                        "(profiles/r02_deepsort_phases.txt) -- latency / occupancy bound at this size, not bandwidth" % (live * 100 * 512 * 4 / 1e6, live)}
             if not args.no_latency_mode and not cfg3 and not cfg4:
                 line["latency_mode"] = latency_mode(args, nc, frames_host, dets_seq, sd=sd0)
+            if not args.no_latency_mode and not cfg4:            # (same switch: the extras of the driver's default line)
+                line["roofline_tracker"] = roofline_tracker(det, frames, nc, args.img)
             if not args.no_cpu_baseline and not cfg4:            # the CPU baseline is timed on rank 0 at N=1 only (configs[1] / [2])
                 line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0, cands0, kept_rows0)
                 line["parity"]["weights"] = args.weights

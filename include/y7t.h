@@ -108,6 +108,10 @@ int y7t_tracker_init(void* state, size_t state_bytes, int tracker_kind, int kalm
                      double conf_thresh, double iou_thresh, int max_time_lost, int flags, int* id_counter,
                      y7t_stream stream);
 
+/* the end of a tracker object's life (the reference: garbage collection of the BaseTracker instance, tracker/track.py:132 creates one per sequence): call before
+ * freeing or re-purposing `state`; the library forgets the host-side notes it keeps per initialised blob (tracker kind, LDS arena size) */
+int y7t_tracker_release(void* state);
+
 /* ByteTrack.update / BaseTracker.update (tracker/bytetrack.py:41-204, tracker/basetrack.py:368-487) as ONE
  * kernel launch, one workgroup per tracker.  `batch` trackers step together (independent sequences):
  *   states[b]   state blob of tracker b

@@ -58,6 +58,13 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+    # under an external launcher WITHOUT --gpus the world size is the launcher's (`torchrun --nproc-per-node 8 bench.py`) ...
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], env=dict(env, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert "must agree" not in (r.stdout + r.stderr)
+    # ... and a container's stray WORLD_SIZE=1 (no RANK / LOCAL_RANK) is not a launcher: --gpus N still starts its own N ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", Y7T_BENCH_DRYRUN_LAUNCH="1"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and "--nproc-per-node 2" in " ".join(json.loads(r.stdout.strip().splitlines()[-1])["launch"]), r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("name,workload", [("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),

@@ -57,6 +57,8 @@ def test_two_ranks_sequence_sharded_equals_single_process():
         rows.append(n)
     assert g["rows_per_rank"] == rows, (g, rows)
     assert g["id_base_per_rank"] == bases, (g, bases)
+    # the gather bench.py runs IS sharding.rebase_and_gather (the code the gloo test proves): 28-byte rows, one padded block per rank
+    assert "sharding.rebase_and_gather" in g["via"] and g["bytes_per_row"] == 28 and g["payload_bytes_per_rank"] == 28 * max(rows), g
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(d, open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu_sequences.json"), "w"), indent=1)
 
@@ -113,4 +115,4 @@ def test_rccl_two_ranks_on_two_devices():
         bases.append(BaseTrack._count)
         t = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5, max_tracks=512, max_dets=512))
         rows.append(sum(len(t.update(det, None)) for det in synth.make_detections(3 * 4, 40, 640, seq_idx=seq, bounce=True)))
-    assert g["rows_per_rank"] == rows and g["id_base_per_rank"] == bases
+    assert g["rows_per_rank"] == rows and g["id_base_per_rank"] == bases and g["payload_bytes_per_rank"] == 28 * max(rows)

@@ -28,6 +28,7 @@ SIGNATURES = {
     "y7t_lapjv_f64": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "y7t_lapjv_f64_host": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "y7t_tracker_state_bytes": (c_size_t, [c_int, c_int]),
+    "y7t_tracker_release": (c_int, [c_void_p]),
     "y7t_tracker_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p,
                                  c_void_p]),
     "y7t_tracker_step_frames": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

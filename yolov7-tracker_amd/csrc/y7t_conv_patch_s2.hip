@@ -32,7 +32,8 @@ constexpr unsigned kOOB = 0xFF000000u;   // voffset of a zero-filled lane: out o
 
 // NW = 4: 256 threads, 8 x 16 output pixels, two workgroups per CU.  NW = 8: 512 threads, 16 x 16 output pixels, ONE workgroup per CU (two waves per SIMD
 // either way): twice the pixels per weight panel and a 33 x 33 patch (1.06 input pixels fetched per input pixel used instead of 1.10) -- the fewest
-// buffer->LDS pieces per MFMA of the forms that fit in LDS; selected at run time with Y7T_CONV_PATCH_S2_NW=8.
+// buffer->LDS pieces per MFMA of the forms that fit in LDS.  Measured in round 3 (profiles/r03_conv_variants.txt): NW = 8 lost or tied on every layer, so only NW = 4 is
+// instantiated; the parameter stays so that the configuration struct documents both.
 template <int BN, int NW>
 struct S2Cfg {
     static constexpr int TW = 16, TH = NW == 8 ? 16 : 8;                  // output tile: 128 / 256 pixels
@@ -64,7 +65,7 @@ struct S2Cfg {
 
 // ORD = 0: behind the barrier the DMAs go out first, then the next step's fragment reads, then the MFMAs (the order y7t_conv_patch.hip was tuned to).
 // ORD = 1: fragment reads, the MFMAs, THEN the DMAs -- a buffer->LDS piece costs its wave 60-185 clocks of issue, most when the phase also carries ds_reads
-// (MI355X_MICROARCH.md), and in this order the matrix pipe has the step's MFMAs queued while they go out.  Y7T_CONV_PATCH_S2_ORDER=1 at launch time.
+// (MI355X_MICROARCH.md), and in this order the matrix pipe has the step's MFMAs queued while they go out.  Measured equal or slower (round 3): only ORD = 0 is instantiated.
 template <int BN, int NW, int ORD>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         if (++it.tx == tiles_x) { it.tx = 0; it.P += (TH - 1) * p.W; if (++it.ty == tiles_y) it.ty = 0; }      // (maps are whole tiles: the next image follows the last row)
     };
     struct TileAt { int org, ty, tx; bool live; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1)
-    auto tile_at = [&](const TileIt& it) -> TileAt { return TileAt{((it.P - p.W - 1) * p.ldin + p.cin_off) * 2, it.ty, it.tx, it.n > 0}; };
+    auto tile_at = [&](const TileIt& it) -> TileAt {      // (unsigned arithmetic: P keeps stepping past the last live tile, and wrap-around must be defined behaviour)
+        return TileAt{(int)((((unsigned)it.P - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, it.n > 0};
+    };
     // per-lane constants of piece i: pconst = where its 16-byte slot sits inside the 18 x 18 patch (byte offset from the patch's first pixel); pedge = which
     // halo sides the slot lies on (bit 0 top row, 1 bottom row, 2 left column, 3 right column), four bits per piece -- maps are whole tiles, so a slot can be
     // outside the image only through the halo of a tile that touches that border.  Slots that are never read (pad chunk, row tail) fetch the patch's first bytes.
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
 int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     using C = WsCfg;
     const bool ok = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout_pad == 64 && !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) &&
-                    !(a.cout_off & 7) && !(a.ldin & 7) && !(a.cin_off & 7) && a.Ho == a.H && a.Wo == a.W && a.in_bytes <= kOOB - (1u << 24) && a.Cout == 64 &&
+                    !(a.cout_off & 7) && !(a.ldin & 7) && !(a.cin_off & 7) && a.Ho == a.H && a.Wo == a.W && a.in_bytes < 0x80000000u && a.Cout == 64 &&      // (32-bit byte offsets: tensors below 2 GiB, as y7t_conv_launch enforces)
                     a.H % C::TH == 0 && a.W % C::TW == 0;      // whole tiles only: the kernel counts its stores (s_waitcnt vmcnt), none may be predicated off
     if (!ok) {
         y7t_set_error("conv: weights are in register-fragment order (korder 5) but the layer is not a 3x3 / stride 1 / 64 -> 64 convolution on a map of whole 16 x 16 tiles with an aligned fp16 output");

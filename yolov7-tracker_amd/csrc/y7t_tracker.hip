@@ -10,6 +10,7 @@
 #include "y7t_track_deepsort.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -322,6 +323,17 @@ static int ensure_lds(K kernel, unsigned bytes) {
     Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// the attribute is per device and the callers may be threads of several trackers: done-bits per device, set after the call succeeded
+template <class K>
+static int ensure_lds_once(K kernel, unsigned bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    Y7T_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    if (int e = ensure_lds(kernel, bytes)) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 extern "C" int y7t_iou_cost_f64(const double* a, int n, const double* b, int m, double* cost, y7t_stream stream) {
     Y7T_ARG_CHECK(n >= 0 && m >= 0);
@@ -414,8 +426,8 @@ extern "C" int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit
         return 0;
     }
     Y7T_ARG_CHECK(cost && x && y && workspace);
-    static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_lapjv, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = ensure_lds_once(k_lapjv, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
     const int nn = n + m;
     const int threads = nn <= 128 ? 64 : (nn <= 512 ? 256 : 1024);
     static int jv = -1;
@@ -479,6 +491,15 @@ static int state_kind(const void* state) {
     return it == g_state_kind.end() ? -1 : it->second;
 }
 
+// the caller is about to free / reuse `state`: forget what the host side knows about it, so that a later blob at the same address is judged by its own
+// y7t_tracker_init (the registry only ever grew, and a stale DEEPSORT entry made the plain step refuse a valid pool)
+extern "C" int y7t_tracker_release(void* state) {
+    std::lock_guard<std::mutex> l(g_kind_mu);
+    g_state_kind.erase(state);
+    g_state_arena.erase(state);
+    return 0;
+}
+
 extern "C" size_t y7t_tracker_state_bytes(int cap_t, int cap_d) {
     if (cap_t <= 0 || cap_d <= 0) return 0;
     return y7t_trk_layout(cap_t, cap_d).total;
@@ -535,8 +556,8 @@ extern "C" int y7t_tracker_step_batch(void* const* states, const float* const* d
     Y7T_ARG_CHECK(states && dets && n_dets && out_rows && out_count);
     const int nt = step_threads(threads);
     Y7T_ARG_CHECK(nt > 0);
-    static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_tracker_step, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = ensure_lds_once(k_tracker_step, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
     hipLaunchKernelGGL(k_tracker_step, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows,
                        out_count, out_cap, kFastBytes, gmc_warps);
     Y7T_LAUNCH_CHECK();
@@ -554,8 +575,8 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
                       "(appearance rings); only the predict-only step (n < 0) is shared");
         return Y7T_E_STATE;
     }
-    static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_tracker_step1, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = ensure_lds_once(k_tracker_step1, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
     const unsigned fb = step_fast_bytes(n);
     hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
                        out_count, fb, gmc_warp);
@@ -577,13 +598,12 @@ extern "C" int y7t_tracker_step_frames(void* state, const float* const* dets, co
     // LDS of the launch: header | fast scratch (cost matrix, assignment work arrays) | the pool's index lists for the length of the launch (y7t_arena_*), when the
     // CU's 160 KiB hold them beside at least 64 KiB of fast scratch (the default capacities, 1024 tracks x 1024 detections: 68 KiB of lists, 91 KiB of scratch)
     static const unsigned kLdsMax = 160 * 1024;
-    static int use_arena = -1;
-    if (use_arena < 0) { const char* e = getenv("Y7T_TRACKER_ARENA"); use_arena = e ? atoi(e) : 1; }
+    static const int use_arena = []() { const char* e = getenv("Y7T_TRACKER_ARENA"); return e ? atoi(e) : 1; }();      // (thread-safe static initialisation)
     const size_t ab = use_arena ? state_arena_bytes(state) : 0;
     unsigned arena = 0, fast = kFastBytes;
     if (ab && ab + 64 * 1024 + Y7T_LDS_HDR <= kLdsMax) { arena = (unsigned)((ab + 15) & ~(size_t)15); fast = (kLdsMax - Y7T_LDS_HDR - arena) & ~15u; if (fast > kFastBytes) fast = kFastBytes; }
-    static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_frames, kLdsMax)) return e; attr_done = true; }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = ensure_lds_once(k_tracker_step_frames, kLdsMax, attr_done)) return e;
     hipLaunchKernelGGL(k_tracker_step_frames, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
                        fast, arena, gmc_warps);
     Y7T_LAUNCH_CHECK();
@@ -609,8 +629,8 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
     Y7T_ARG_CHECK(n == 0 || (dets && det_feats));
     const int nt = step_threads(threads, n);
     Y7T_ARG_CHECK(nt > 0);
-    static bool attr_done = false;
-    if (!attr_done) { if (int e = ensure_lds(k_tracker_step_deepsort, kFastBytes + Y7T_LDS_HDR)) return e; attr_done = true; }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = ensure_lds_once(k_tracker_step_deepsort, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
     if (n > 0) {
         hipLaunchKernelGGL(k_ds_normalize, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats, n);      // a wave per detection
         Y7T_LAUNCH_CHECK();

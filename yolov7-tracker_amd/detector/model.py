@@ -211,6 +211,7 @@ class Detector:
             _lib.check(self._L.y7t_det_forward_ops(p.handle, B, int(first), int(last), s))
         else:
             ps = p.post[pset]
+            ps.last_B = B
             _lib.check(self._L.y7t_det_forward_fused(p.handle, B, int(first), int(last), float(fuse_decode), self.max_cand, MAX_NMS, _lib.ptr(ps.ws),
                                                      ps.ws.numel(), s))
 
@@ -398,6 +399,7 @@ class Detector:
             p.lb[:B].copy_(torch.from_numpy(lb))
             p._lb_key = key
         ps = p.post[out.pset]
+        ps.last_B = B                    # the workspace arrays are laid out for THIS batch (y7t_post_cand_ws): candidate_arrays needs it
         if out.fused is not None:
             if abs(float(conf_thres) - float(out.fused)) > 1e-12:
                 raise ValueError("this forward fused the Detect decode with conf_thres=%g; post-processing it with %g needs a plain forward"
@@ -411,12 +413,16 @@ class Detector:
                                                ps.ws.numel(), _lib.stream_ptr()))
         return ps.dets, ps.ndets
 
-    def candidate_arrays(self, pset=0):
+    def candidate_arrays(self, pset=0, B=None):
         """device views of post-processing set `pset`'s candidate arrays (the head of y7t_det_postprocess' workspace, each 256-byte aligned):
         -> (cbox (B, cap, 4) f32 xyxy, cscore (B, cap) f32, ccls (B, cap) f32, cidx (B, cap) i32 anchor row, count (B,) i32).  What the fused Detect
         epilogues / the decode pass wrote = `x` of utils/general.py:662 before the NMS; for parity checks and callers that want raw candidates."""
         p = self.plan
-        B, cap, ws = self.max_batch, self.max_cand, p.post[pset].ws
+        # y7t_post_cand_ws lays the arrays out with the batch of the forward / post-process that filled them, not with max_batch (ADVICE r3)
+        B = B if B is not None else getattr(p.post[pset], "last_B", self.max_batch)
+        if not 1 <= B <= self.max_batch:
+            raise ValueError("candidate_arrays: batch %d outside [1, %d]" % (B, self.max_batch))
+        cap, ws = self.max_cand, p.post[pset].ws
         rup = lambda n: (n + 255) // 256 * 256
         o1 = rup(B * cap * 16); o2 = o1 + rup(B * cap * 4); o3 = o2 + rup(B * cap * 4); o4 = o3 + rup(B * cap * 4)
         return (ws[:B * cap * 16].view(torch.float32).view(B, cap, 4), ws[o1:o1 + B * cap * 4].view(torch.float32).view(B, cap),

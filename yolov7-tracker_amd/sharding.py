@@ -5,7 +5,7 @@ the ids equal the reference's single-process run, whose BaseTrack._count is glob
 (/root/reference/tracker/basetrack.py:22,43-46; new tracker per sequence at tracker/track.py:132):
 
     rank r owns sequences {s : s mod world == r} (sorted order, track.py:108), tracks each with a LOCAL id counter
-    starting at 0, records n_ids[s];  all_gather(n_ids)  ->  exclusive prefix sum in sequence order  ->  id += offset;
+    starting at 0, records n_ids[s];  all_reduce(n_ids)  ->  exclusive prefix sum in sequence order  ->  id += offset;
     gather rows (frame, id, x, y, w, h, cls) to rank 0.   Payload: KBs to a few MB -> latency-bound, one hop per peer.
 """
 import torch
@@ -16,38 +16,67 @@ def owned_sequences(n_seqs, rank, world):
     return [s for s in range(n_seqs) if s % world == rank]
 
 
+ROW_WORDS = 7            # a result row on the wire: frame:int32, id:int32, x, y, w, h:float32, cls:int32 = 28 bytes -- what the reference writes per row
+                         # (`frame,id,x,y,w,h,1.0,-1,-1,-1` with %.2f, tracker/track.py:257-270) and nothing else
+last_gather_stats = {}   # filled by rebase_and_gather: rows / payload bytes of the last call (tests, bench line)
+
+
+def pack_rows(rows):
+    """(n, >= 7) float rows [frame, id, x, y, w, h, cls, ...] -> (n, 7) int32 words (boxes as float32 bit patterns)"""
+    out = torch.empty((rows.shape[0], ROW_WORDS), dtype=torch.int32, device=rows.device)
+    if rows.shape[0]:
+        out[:, 0:2] = rows[:, 0:2].to(torch.int32)
+        out[:, 2:6] = rows[:, 2:6].to(torch.float32).contiguous().view(torch.int32)
+        out[:, 6] = rows[:, 6].to(torch.int32)
+    return out
+
+
+def unpack_rows(words):
+    """(n, 7) int32 words -> (n, 7) float64 rows [frame, id, x, y, w, h, cls]"""
+    out = torch.empty((words.shape[0], ROW_WORDS), dtype=torch.float64, device=words.device)
+    if words.shape[0]:
+        out[:, 0:2] = words[:, 0:2].to(torch.float64)
+        out[:, 2:6] = words[:, 2:6].contiguous().view(torch.float32).to(torch.float64)
+        out[:, 6] = words[:, 6].to(torch.float64)
+    return out
+
+
 def rebase_and_gather(rows_by_seq, n_ids_by_seq, n_seqs, group=None, device="cpu"):
-    """rows_by_seq: {seq index: float64 tensor (n, 8) [frame, id(local, 1-based), x, y, w, h, cls, score]} of THIS rank;
-    n_ids_by_seq: {seq index: ids handed out in that sequence}.  Returns on rank 0 the list (per sequence) of rows with
-    global ids; None elsewhere."""
+    """rows_by_seq: {seq index: float tensor (n, >= 7) [frame, id(local, 1-based), x, y, w, h, cls, ...]} of THIS rank;
+    n_ids_by_seq: {seq index: ids handed out in that sequence}.  Returns on rank 0 the list (per sequence) of float64 rows
+    (n, 7) [frame, id(global), x, y, w, h, cls] (boxes at the float32 precision they travel in); None elsewhere.
+    Two small collectives (id counts + row counts, one all_reduce each) and ONE gather of 28-byte rows."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    counts = torch.zeros(n_seqs, dtype=torch.int64, device=device)
-    for s, n in n_ids_by_seq.items():
-        counts[s] = int(n)
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)      # every sequence has exactly one owner
-    offsets = torch.cumsum(counts, 0) - counts                           # exclusive prefix, sequence order
     mine = owned_sequences(n_seqs, rank, world)
-    sizes = torch.zeros(n_seqs, dtype=torch.int64, device=device)
-    rebased = {}
+    meta = torch.zeros((2, n_seqs), dtype=torch.int64, device=device)      # row 0: ids handed out, row 1: result rows -- every sequence has exactly one owner
+    for s, n in n_ids_by_seq.items():
+        meta[0, s] = int(n)
     for s in mine:
-        r = rows_by_seq[s].to(device=device, dtype=torch.float64).clone()
-        if r.numel():
-            r[:, 1] += float(offsets[s].item())
-        rebased[s] = r
-        sizes[s] = r.shape[0]
-    if world == 1:
-        return [rebased[s] for s in range(n_seqs)]
-    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
-    # one flat gather: every rank contributes its sequences' rows padded to the per-rank maximum
+        meta[1, s] = rows_by_seq[s].shape[0]
+    if world > 1:
+        dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+    counts, sizes = meta[0].cpu(), meta[1].cpu()
+    offsets = torch.cumsum(counts, 0) - counts                              # exclusive prefix, sequence order: the reference's global BaseTrack._count
+    packed = {}
+    for s in mine:
+        w = pack_rows(rows_by_seq[s].to(device))
+        if w.shape[0]:
+            w[:, 1] += int(offsets[s].item())
+        packed[s] = w
     per_rank = [int(sum(int(sizes[s].item()) for s in owned_sequences(n_seqs, r, world))) for r in range(world)]
+    last_gather_stats.clear()
+    last_gather_stats.update({"rows_per_rank": per_rank, "bytes_per_row": 4 * ROW_WORDS, "world": world, "id_offset_per_seq": [int(v) for v in offsets.tolist()],
+                              "payload_bytes_per_rank": 4 * ROW_WORDS * max(per_rank + [1]) if world > 1 else 0})
+    if world == 1:
+        return [unpack_rows(packed[s]) for s in range(n_seqs)]
+    # one flat gather: every rank contributes its sequences' rows padded to the per-rank maximum
     pad = max(per_rank + [1])
-    flat = torch.zeros((pad, 8), dtype=torch.float64, device=device)
+    flat = torch.zeros((pad, ROW_WORDS), dtype=torch.int32, device=device)
     o = 0
     for s in mine:
-        n = rebased[s].shape[0]
-        flat[o:o + n] = rebased[s]
+        n = packed[s].shape[0]
+        flat[o:o + n] = packed[s]
         o += n
     out = [torch.zeros_like(flat) for _ in range(world)] if rank == 0 else None
     dist.gather(flat, out, dst=0, group=group)
@@ -58,7 +87,7 @@ def rebase_and_gather(rows_by_seq, n_ids_by_seq, n_seqs, group=None, device="cpu
         o = 0
         for s in owned_sequences(n_seqs, r, world):
             n = int(sizes[s].item())
-            res[s] = out[r][o:o + n].clone()
+            res[s] = unpack_rows(out[r][o:o + n])
             o += n
     return res
 

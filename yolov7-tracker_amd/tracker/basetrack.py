@@ -339,6 +339,15 @@ class BaseTracker(object):
         self._det_keep = None
 
     # ------------------------------------------------------------------------------------------
+
+    def __del__(self):
+        # the state blob is about to return to the allocator: the library drops its host-side notes for that address (y7t_tracker_release)
+        try:
+            if getattr(self, "_state", None) is not None and self._L is not None:
+                self._L.y7t_tracker_release(_lib.ptr(self._state))
+        except Exception:
+            pass
+
     def _launch(self, det_results, out=None, n_dev=None, warp=None):
         """enqueue one frame step (asynchronous).  out: optional (cap_t + 1, 8) float64 device tensor that receives the
         returned rows (row cap_t holds the count) instead of the tracker's own buffer -- lets a pipeline keep every

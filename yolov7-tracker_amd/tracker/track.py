@@ -52,6 +52,30 @@ def save_results(results_root, folder_name, seq_name, results, data_type='mot17'
     return folder_name
 
 
+def sequence_list(opts, cfgs):
+    """track.py:93-109: the sequences to track -> (sorted names, folder that holds them or None).  'origin': the sub-folders of the dataset's sequence folder;
+    'yolo': the parent-folder names of the image paths listed in ./<dataset>/test.txt.  IGNORE_SEQS / CERTAIN_SEQS of the dataset yaml apply to both."""
+    DATASET_ROOT, CERTAIN_SEQS, IGNORE_SEQS = cfgs['DATASET_ROOT'], cfgs['CERTAIN_SEQS'], cfgs['IGNORE_SEQS']
+    if opts.data_format == 'yolo':
+        DATA_ROOT = None
+        seqs = []
+        with open(os.path.join(getattr(opts, 'yolo_root', './'), opts.dataset, 'test.txt'), 'r') as f:
+            for line in f.readlines():
+                elems = line.split('/')      # the sequence name is elems[-2]
+                if len(elems) >= 2 and elems[-2] not in seqs:
+                    seqs.append(elems[-2])
+    elif opts.data_format == 'origin':
+        DATA_ROOT = os.path.join(DATASET_ROOT, cfgs.get('SEQ_SUBDIR', 'VisDrone2019-MOT-test-dev/sequences'))
+        seqs = os.listdir(DATA_ROOT)
+    else:
+        raise NotImplementedError
+    seqs = sorted(seqs)
+    seqs = [s for s in seqs if s not in IGNORE_SEQS]
+    if None not in CERTAIN_SEQS:
+        seqs = CERTAIN_SEQS
+    return seqs, DATA_ROOT
+
+
 def main(opts, cfgs):
     DATASET_ROOT, CERTAIN_SEQS, IGNORE_SEQS = cfgs['DATASET_ROOT'], cfgs['CERTAIN_SEQS'], cfgs['IGNORE_SEQS']
     if opts.tracker not in TRACKER_DICT:
@@ -66,13 +90,7 @@ def main(opts, cfgs):
     if synthetic:
         seqs = ['synthetic-%03d' % i for i in range(opts.synthetic_seqs)]
     else:
-        if opts.data_format != 'origin':
-            raise NotImplementedError
-        DATA_ROOT = os.path.join(DATASET_ROOT, cfgs.get('SEQ_SUBDIR', 'VisDrone2019-MOT-test-dev/sequences'))
-        seqs = sorted(os.listdir(DATA_ROOT))
-        seqs = [s for s in seqs if s not in IGNORE_SEQS]
-        if None not in CERTAIN_SEQS:
-            seqs = CERTAIN_SEQS
+        seqs, DATA_ROOT = sequence_list(opts, cfgs)
     print(f'Seqs will be evalueated, total{len(seqs)}:')
     print(seqs)
     folder_name = strftime("%Y-%d-%m %H:%M:%S", gmtime())[5:-3].replace('-', '_').replace(' ', '_').replace(':', '_')
@@ -83,9 +101,12 @@ def main(opts, cfgs):
             loader = tracker_dataloader.SyntheticLoader(opts.synthetic_frames, opts.synthetic_objs, opts.img_size, si,
                                                         device_preprocess=opts.device_preprocess)
         else:
-            loader = tracker_dataloader.TrackerLoader(os.path.join(DATA_ROOT, seq), opts.img_size, opts.data_format, seq,
+            # track.py:126: the sequence folder ('origin') or the path file every sequence is filtered out of ('yolo')
+            path = os.path.join(DATA_ROOT, seq) if opts.data_format == 'origin' else os.path.join(opts.yolo_root, opts.dataset, 'test.txt')
+            loader = tracker_dataloader.TrackerLoader(path, opts.img_size, opts.data_format, seq,
                                                       pre_process_method='v7', model_stride=stride,
-                                                      device_preprocess=opts.device_preprocess)
+                                                      device_preprocess=opts.device_preprocess,
+                                                      yolo_data_root=cfgs.get('YOLO_DATA_ROOT', DATASET_ROOT))
         data_loader = torch.utils.data.DataLoader(loader, batch_size=max(1, opts.batch))
         tracker = TRACKER_DICT[opts.tracker](opts, frame_rate=30, gamma=opts.gamma)
         results, frame_id, i = [], 0, -1
@@ -198,6 +219,7 @@ def build_parser():
     parser.add_argument('--synthetic_objs', type=int, default=80)
     parser.add_argument('--synthetic_seqs', type=int, default=1)
     parser.add_argument('--results_root', type=str, default='./tracker/results')
+    parser.add_argument('--yolo_root', type=str, default='./', help="(extension) where ./<dataset>/test.txt of --data_format yolo lives (the reference: the working directory)")
     return parser
 
 

@@ -56,15 +56,30 @@ def _resize_linear(img, new_h, new_w):
 
 
 class TrackerLoader(torch.utils.data.Dataset):
-    def __init__(self, path, img_size=1280, format='origin', seq=None, pre_process_method='v7', model_stride=32, device_preprocess=False):
+    def __init__(self, path, img_size=1280, format='origin', seq=None, pre_process_method='v7', model_stride=32, device_preprocess=False,
+                 yolo_data_root=''):
+        """tracker_dataloader.py:21-62.  format 'origin': `path` is one sequence's folder of frames.  format 'yolo': `path` is the path FILE (test.txt) whose lines
+        are image paths relative to the data root; the frames of sequence `seq` are the lines whose parent folder name is contained in `seq` (the reference's
+        `elems[-2] in seq`, :50).  The reference hard-codes its data root ('/data/wujiapeng/datasets/', :33); here it comes from the dataset yaml
+        (YOLO_DATA_ROOT, default DATASET_ROOT)."""
         super().__init__()
         self.device_preprocess = device_preprocess   # True: hand over only the raw frame; letterbox runs on the GPU (Detector.forward_frames)
-        self.DATA_ROOT = path
+        self.DATA_ROOT = yolo_data_root if format == 'yolo' else path
         self.format, self.pre_process_method, self.model_stride = format, pre_process_method, model_stride
-        if format != 'origin':
-            raise NotImplementedError("data_format %r (only 'origin' folders of frames)" % format)
-        assert os.path.isdir(path), f'your path is {path}, path must be your dataset path'
-        self.img_files = sorted(os.listdir(path))
+        self.img_files = []
+        if format == 'origin':
+            assert os.path.isdir(path), f'your path is {path}, path must be your dataset path'
+            self.img_files = sorted(os.listdir(path))
+        elif format == 'yolo':
+            assert os.path.isfile(path), f'your path is {path}, path must be your path file'
+            with open(path, 'r') as f:
+                for line in f.readlines():
+                    line = line.strip()
+                    elems = line.split('/')
+                    if len(elems) >= 2 and elems[-2] in seq:
+                        self.img_files.append(os.path.join(self.DATA_ROOT, line))      # absolute path (os.path.join keeps an absolute `line` as it is)
+        else:
+            raise NotImplementedError("data_format %r" % format)
         if isinstance(img_size, int):
             self.width, self.height = img_size, img_size
         else:
@@ -72,7 +87,7 @@ class TrackerLoader(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         from PIL import Image
-        p = os.path.join(self.DATA_ROOT, self.img_files[index])
+        p = os.path.join(self.DATA_ROOT, self.img_files[index]) if self.format == 'origin' else self.img_files[index]
         ori_img = np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1].copy()   # (H, W, C) BGR like cv2.imread
         if self.device_preprocess:
             return torch.empty(0), torch.from_numpy(ori_img)
