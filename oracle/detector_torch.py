@@ -255,14 +255,30 @@ def explain_kept_set_difference(cands_x, kept_x, cands_y, kept_y, score_noise, i
     """Two runs of the same greedy NMS on two candidate sets that differ by rounding noise (x, y: dicts anchor row -> (xyxy, conf, cls, ...); kept_*: kept rows in
     output order).  For every row kept on ONE side only, walk the greedy decisions that made it so and name the decision that could flip within the noise:
       'score-tie'     the row and the rival that suppresses it on the other side swap order: their scores differ by <= 2 score_noise on the side where the row survives
-      'iou-threshold' the rival's IoU with the row lies within iou_noise of iou_thres and crosses it
+      'iou-threshold' the rival's IoU with the row crosses iou_thres by less than iou_noise + what the pair's own coordinate deviation can move it (4 d / shortest side)
       'conf-threshold' the row (or a rival up the chain) is a candidate on one side only, its score within score_noise of conf_thres
       'cut'           the row ranks just behind the max_det-th survivor: within 2 score_noise of the last kept score
       'class-tie'     the rival's best class differs between the sides (two class scores within 2 score_noise; needs the per-class vector as 4th tuple entry)
     A rival that is itself kept on one side only is followed recursively (a flip propagates down a chain of overlapping boxes).  -> {row: reason or None}; None
     = a difference that rounding noise of the stated size does NOT explain (an arithmetic difference of the kernels)."""
+    f32 = np.float32
+
     def order_key(c, r):
-        return (-float(np.float32(c[r][1])), r)
+        return (-float(f32(c[r][1])), r)
+
+    def iou(c, a, b):
+        """IoU as the NMS computes it (oracle/y7t_oracle.c:281-305 = torchvision.ops.nms): float32 arithmetic on the class-offset boxes (+ cls * max_wh,
+        utils/general.py:675) -- near the threshold that rounding decides, and the explanation must look at the number the decision was made on"""
+        A = (np.asarray(c[a][0], f32) + f32(c[a][2]) * f32(4096)).astype(f32)
+        B = (np.asarray(c[b][0], f32) + f32(c[b][2]) * f32(4096)).astype(f32)
+        w = max(f32(0), f32(min(A[2], B[2]) - max(A[0], B[0])))
+        h = max(f32(0), f32(min(A[3], B[3]) - max(A[1], B[1])))
+        inter = f32(w * h)
+        ua = f32(f32(f32(A[2] - A[0]) * f32(A[3] - A[1])) + f32(f32(B[2] - B[0]) * f32(B[3] - B[1]))) - inter
+        return float(inter / ua) if ua > 0 else 0.0
+
+    def class_tie(c, r, k1, k2):
+        return len(c[r]) > 3 and abs(float(c[r][3][k1]) - float(c[r][3][k2])) <= 2 * score_noise
 
     def explain(a, cx, kx, cy, ky, d):
         # `a` is kept on side y and missing on side x
@@ -270,8 +286,10 @@ def explain_kept_set_difference(cands_x, kept_x, cands_y, kept_y, score_noise, i
             return None
         if a not in cx:
             return "conf-threshold" if abs(cy[a][1] - conf_thres) <= score_noise else None
+        if cx[a][2] != cy[a][2]:                       # the row itself changed class between the sides (it competes in another class group there)
+            return "class-tie" if (class_tie(cy, a, cx[a][2], cy[a][2]) or class_tie(cx, a, cx[a][2], cy[a][2])) else None
         kxs = list(kx)
-        sup = [b for b in kxs if b != a and cx[b][2] == cx[a][2] and order_key(cx, b) < order_key(cx, a) and box_iou_1(cx[a][0], cx[b][0]) > iou_thres]
+        sup = [b for b in kxs if b != a and cx[b][2] == cx[a][2] and order_key(cx, b) < order_key(cx, a) and iou(cx, a, b) > iou_thres]
         if not sup:
             if len(kxs) >= max_det and abs(cx[a][1] - cx[kxs[-1]][1]) <= 2 * score_noise:
                 return "cut"
@@ -280,13 +298,15 @@ def explain_kept_set_difference(cands_x, kept_x, cands_y, kept_y, score_noise, i
         if b not in cy:
             return "conf-threshold" if abs(cx[b][1] - conf_thres) <= score_noise else None
         if cy[b][2] != cy[a][2]:                      # the rival changed class between the sides: two of its class scores tie (`conf, j = x[:, 5:].max(1)`)
-            for c in (cy, cx):
-                if len(c[b]) > 3 and abs(float(c[b][3][cx[b][2]]) - float(c[b][3][cy[b][2]])) <= 2 * score_noise:
-                    return "class-tie"
-            return None
-        iy, ix = box_iou_1(cy[a][0], cy[b][0]), box_iou_1(cx[a][0], cx[b][0])
+            return "class-tie" if (class_tie(cy, b, cx[b][2], cy[b][2]) or class_tie(cx, b, cx[b][2], cy[b][2])) else None
+        iy, ix = iou(cy, a, b), iou(cx, a, b)
         if iy <= iou_thres:
-            return "iou-threshold" if (iou_thres - iy) <= iou_noise and (ix - iou_thres) <= iou_noise else None
+            # how far the two sides' coordinates of THIS pair can move its IoU: an edge shift d changes the overlap by <= d / (shortest side) per edge -- the random
+            # head also emits slivers (0.03 px wide, 130 px tall) whose IoU with a neighbour goes from 0.77 to 0.25 on a 0.016 px shift
+            dxy = max(float(np.abs(np.asarray(cx[r][0], np.float64) - np.asarray(cy[r][0], np.float64)).max()) for r in (a, b))
+            ms = min(min(float(c[r][0][2] - c[r][0][0]), float(c[r][0][3] - c[r][0][1])) for c in (cx, cy) for r in (a, b))
+            tol = iou_noise + 4.0 * (dxy + 0.004) / max(ms, 1e-6)          # + 2 float32 ulps of a class-offset coordinate (28672 + x: 2^-9 px)
+            return "iou-threshold" if (iou_thres - iy) <= tol and (ix - iou_thres) <= tol else None
         if order_key(cy, a) < order_key(cy, b):        # on y the row comes first (and, kept, suppresses b there): the two swapped order
             return "score-tie" if abs(cy[a][1] - cy[b][1]) <= 2 * score_noise and abs(cx[a][1] - cx[b][1]) <= 2 * score_noise else None
         if b in set(ky):
