@@ -9,6 +9,7 @@
 # Steps:
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
+#   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0)
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
@@ -67,6 +68,22 @@ tests4)
   say "tests4: round 4 -- all four Detect levels live (damped and undamped), SURVEY 8a's full bar, every kept-set difference explained"
   timeout 900 python -m pytest -x -q -m gpu -s tests/test_detector_pinned_gpu.py -k "boxes or candidates or all_levels or heads_end_to_end_against" > $O/t_r4_parity.log 2>&1; echo "rc=$?" >> $O/t_r4_parity.log
   grep -h "candidates\|oracle keeps\|level [0-9]:" $O/t_r4_parity.log | cut -c1-700 | tee -a $O/summary.txt; tailsum $O/t_r4_parity.log 4
+  ;;
+
+exp_p8)
+  say "exp_p8 a: the 256 x 256 x 64 ping-pong 1x1 kernel (csrc/y7t_conv_p8.hip): layer parity vs torch fp32, determinism under load, the DUAL loader inside a network, then inside the benchmarked list"
+  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k pingpong > $O/t_p8.log 2>&1; echo "rc=$?" >> $O/t_p8.log; tailsum $O/t_p8.log 3
+  timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_p8_pinned.log 2>&1; echo "rc=$?" >> $O/t_p8_pinned.log; tailsum $O/t_p8_pinned.log 3
+  say "exp_p8 b: per-layer timing at 32 frames, 1x1 rows: igemm<128,128,32,2> (Y7T_CONV_P8=0) vs p8"
+  Y7T_CONV_P8=0 timeout 200 python scripts/bench_conv.py 32 > $O/b_nop8.txt 2>&1
+  timeout 200 python scripts/bench_conv.py 32 > $O/b_p8.txt 2>&1
+  paste <(grep " 1/1 \|TOTAL" $O/b_nop8.txt | cut -c1-62) <(grep " 1/1 \|TOTAL" $O/b_p8.txt | cut -c36-62) | tee -a $O/summary.txt
+  say "exp_p8 c: bench lines (same session): p8, then Y7T_CONV_P8=0, then p8 again"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  timeout 300 python bench.py $X > $O/bench_p8.json 2> $O/bench_p8.err
+  Y7T_CONV_P8=0 timeout 300 python bench.py $X > $O/bench_nop8.json 2> $O/bench_nop8.err
+  timeout 300 python bench.py $X > $O/bench_p8b.json 2> $O/bench_p8b.err
+  benchsum p8 nop8 p8b
   ;;
 
 suite)

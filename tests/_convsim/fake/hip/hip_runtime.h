@@ -1,8 +1,8 @@
 // tests/_convsim/fake/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
 // A host stand-in for the HIP runtime and the gfx950 builtins that csrc/y7t_conv.hip uses, so that the REAL kernel source can be compiled for the CPU and
 // run thread by thread (one OS thread per work-item, real barriers): the kernel's index arithmetic -- load geometry, LDS swizzle, fragment mapping, epilogue
-// transposition, tile order -- is checked against a plain convolution without a GPU (tests/test_convsim.py).  What it does NOT model: timing, the vmcnt /
-// lgkmcnt waits (loads complete at once), LDS bank conflicts, register pressure.
+// transposition, tile order -- is checked against a plain convolution without a GPU (tests/test_convsim.py).  What it does NOT model: timing, the lgkmcnt waits, LDS bank
+// conflicts, register pressure.  The buffer->LDS DMAs land at once, or (cs_dma_deferred, for kernels that mark their vmcnt waits) as late as their waits allow.
 #pragma once
 #include <math.h>
 #include <pthread.h>
@@ -69,16 +69,29 @@ static inline cs_rsrc cs_make_rsrc(void* p, int, unsigned bytes, unsigned) { ret
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) cs_make_rsrc((void*)(p), stride, bytes, flags)
 // every lane fetches `size` bytes at base + voffset + soffset + imm (dwords past num_records read as zero -- the hardware range check) and the wave writes
 // them to LDS at ldsbase + lane * size (M0-based, lane order)
+// cs_dma_deferred = 0: the bytes land at issue (the EARLIEST a DMA can land: a re-staged buffer that is still being read shows up as wrong results);
+// cs_dma_deferred = 1: they land when the issuing lane's own counted wait forces them -- cs_vmcnt(n), what `s_waitcnt vmcnt(n)` stands for in a kernel that marks its
+// waits with a macro -- the LATEST they can land: a fragment read that is not covered by a wait + barrier reads the 0xAB fill.  Together the two runs bracket every
+// landing time the hardware can produce for a schedule whose LDS accesses are ordered by its barriers.
+struct cs_dma { cs_rsrc r; char* dst; int size; unsigned off; };
+extern int cs_dma_deferred;
+extern thread_local std::vector<cs_dma> cs_dmaq;
+static inline void cs_dma_land(const cs_dma& q) {
+    for (int d = 0; d < q.size; d += 4) {
+        const unsigned long long o = (unsigned long long)q.off + d;
+        uint32_t w = 0;
+        if (o + 4 <= q.r.bytes) memcpy(&w, q.r.base + o, 4);
+        memcpy(q.dst + d, &w, 4);
+    }
+}
 static inline void cs_buffer_load_lds(cs_rsrc r, void* ldsbase, int size, int voffset, int soffset, int imm, int) {
     const int lane = threadIdx.x & 63;
-    const unsigned off = (unsigned)voffset + (unsigned)soffset + (unsigned)imm;
-    char* dst = (char*)ldsbase + lane * size;
-    for (int d = 0; d < size; d += 4) {
-        const unsigned long long o = (unsigned long long)off + d;
-        uint32_t w = 0;
-        if (o + 4 <= r.bytes) memcpy(&w, r.base + o, 4);
-        memcpy(dst + d, &w, 4);
-    }
+    const cs_dma q{r, (char*)ldsbase + lane * size, size, (unsigned)voffset + (unsigned)soffset + (unsigned)imm};
+    if (cs_dma_deferred) cs_dmaq.push_back(q);
+    else cs_dma_land(q);
+}
+static inline void cs_vmcnt(int n) {      // at most n of this lane's DMAs stay in flight: the older ones land now, in issue order
+    while ((int)cs_dmaq.size() > n) { cs_dma_land(cs_dmaq.front()); cs_dmaq.erase(cs_dmaq.begin()); }
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, size, voff, soff, imm, aux) cs_buffer_load_lds(r, (void*)(lds), size, voff, soff, imm, aux)
 

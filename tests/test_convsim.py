@@ -31,6 +31,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder == 4:      # the stride-2 patch kernel's panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_s2(blk, cin_pad)
+    if korder == 7:      # the 256 x 64 panels of the ping-pong 1x1 kernel
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_p8(blk)
     return blk
 
 
@@ -40,7 +43,7 @@ def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    cp = (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
+    cp = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
     wp = pack_w(Wt, Cin, cp, korder)
     bp = np.zeros(cp, np.float32)
     bp[:Cout] = bias
@@ -117,6 +120,71 @@ def test_upsample_on_read_loader_on_the_host(korder, Cout, lat_first, force):
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))
     ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(out.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
+# the 256 x 256 x 64 ping-pong 1x1 kernel (csrc/y7t_conv_p8.hip, korder 7): B, H, W, Cin, Cout, act, extras.  Every case runs twice: with the buffer->LDS DMAs landing at
+# issue (the earliest they can: a half-tile re-staged while somebody still reads it gives wrong results) and landing only when the issuing lane's own `vmcnt` wait forces
+# them (the latest: a fragment read that no wait + barrier covers sees the 0xAB fill) -- the two ends of what the hardware can do with the kernel's schedule.
+P8_CASES = [
+    (1, 16, 20, 128, 256, 1, {}),                                                       # two K-tiles; 320 pixels = one full and one ragged pixel tile
+    (1, 16, 16, 64, 512, 2, {"in_ld": 128, "in_coff": 64, "out_ld": 768, "out_coff": 256}),   # ONE K-tile (prologue + zero-fill tail only), two channel tiles, slices, LeakyReLU
+    (1, 15, 20, 192, 256, 0, {}),                                                       # three K-tiles (odd: the loop ends on buffer 0), 300 pixels, no activation
+    (2, 12, 16, 320, 256, 1, {"out_ld": 512, "out_coff": 0}),                           # five K-tiles, 384 pixels over two images
+]
+
+
+@pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
+@pytest.mark.parametrize("case", P8_CASES, ids=lambda c: "%dx%dx%d_%d-%d" % c[:5])
+def test_pingpong_1x1_kernel_source_on_the_host(case, deferred):
+    B, H, W, Cin, Cout, act, kw = case
+    L = cs.lib()
+    L.cs_set_dma_deferred(deferred)
+    try:
+        name = run_case(L, B, H, W, Cin, Cout, 1, 1, act, 0, korder=7, seed=B * 1000 + H + W + Cin, **kw)
+    finally:
+        L.cs_set_dma_deferred(0)
+    assert name == "p8<256,256,64> 1x1", name
+
+
+@pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
+@pytest.mark.parametrize("lat_first", [True, False])
+def test_pingpong_1x1_upsample_on_read_on_the_host(lat_first, deferred):
+    """the DUAL instance: K-tiles of the upsampled channel range DMA pixel (y >> 1, x >> 1) of the half-resolution tensor (cfg/deploy/yolov7-w6.yaml:75,89,103)"""
+    from yolov7_tracker_amd.detector import weights
+    L = cs.lib()
+    rng = np.random.default_rng(11)
+    B, H, W, C_lat, C_up, Cout = 2, 10, 14, 64, 128, 256
+    Cin = C_lat + C_up
+    up_c0 = C_lat if lat_first else 0
+    lat = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float16)            # the concat buffer: the upsampled channel range is never written (garbage) ...
+    half = rng.normal(0, 1, (B, H // 2, W // 2, 192)).astype(np.float16)  # ... it lives at half resolution, as channels [32, 32 + C_up) of a wider buffer
+    Wt = (rng.normal(0, 1, (Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.normal(0, 0.5, Cout).astype(np.float32)
+    wp = pack_w(Wt, Cin, Cout, 7)
+    out = np.full((B, H, W, Cout), 7.0, np.float16)
+    L.cs_set_dma_deferred(deferred)
+    try:
+        rc = L.cs_conv_dual(lat.ctypes.data, Cin, 0, half.ctypes.data, 192, 32, up_c0, C_up, B, H, W, Cin, wp.ctypes.data, bias.ctypes.data, out.ctypes.data, Cout, 0, Cout, Cout, 1, 7, 0)
+    finally:
+        L.cs_set_dma_deferred(0)
+    assert rc == 0, L.cs_last_error().decode()
+    assert L.cs_last_kernel().decode() == "p8<256,256,64> 1x1 upsample-on-read"
+    x = lat.astype(np.float32)
+    x[..., up_c0:up_c0 + C_up] = np.repeat(np.repeat(half[..., 32:32 + C_up].astype(np.float32), 2, axis=1), 2, axis=2)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(out.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_pingpong_panel_packing_is_the_documented_lds_image():
+    from yolov7_tracker_amd.detector import weights
+    blk = np.random.default_rng(2).permutation(512 * 192).astype(np.float64).reshape(512, 192)
+    out = weights.panel_pack_p8(blk).ravel()
+    assert np.array_equal(np.sort(out), np.sort(blk.ravel()))
+    for tile, kt, h, r, s_ in ((0, 0, 0, 0, 0), (1, 2, 1, 127, 7), (0, 1, 1, 37, 3), (1, 0, 0, 70, 5)):
+        o = ((((tile * 3 + kt) * 2 + h) * 128 + r) * 8 + s_) * 8
+        ch, oct_ = tile * 256 + (r // 32) * 64 + h * 32 + r % 32, s_ ^ ((r >> 1) & 7)
+        assert np.array_equal(out[o:o + 8], blk[ch, kt * 64 + oct_ * 8:][:8])
 
 
 # the LDS-patch kernels (csrc/y7t_conv_patch.hip; 3x3 / stride 1): B, H, W, Cin, Cout, act, korder, extras -- forced onto the patch kernel like the GPU layer tests

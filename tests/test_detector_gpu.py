@@ -43,6 +43,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 5:   # register-fragment order of the weights-stationary 64 -> 64 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.pack_ws(blk)
+    if korder == 7:   # 256 x 64 panels of the ping-pong 1x1 kernel
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_p8(blk)
     return blk
 
 
@@ -97,8 +100,8 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
-    cout_pad = (Cout + 63) // 64 * 64 if korder not in (4, 6) else (Cout + 127) // 128 * 128
+    korder = 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful
@@ -144,6 +147,71 @@ def test_weights_stationary_kernel_matches_torch_fp32(L, case):
     from yolov7_tracker_amd import _lib
     test_conv_layer_matches_torch_fp32(L, case)
     assert L.y7t_last_kernel().decode() == "ws64<16,16>"
+
+
+# csrc/y7t_conv_p8.hip: the 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline (act bit 15: korder 7).  Shapes: one K-tile (prologue + tail only), odd and
+# even K-tile counts, ragged pixel tiles, several channel tiles, thousands of tiles (every CU runs many workgroups back to back), slices of concat buffers, the activations,
+# and two layers of the benchmarked list at 8 frames.
+P8_CASES = [
+    # B, H, W, Cin, Cout, k, s, act (bit 15), in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 16, 16, 64, 256, 1, 1, 1 | 32768, 64, 0, 256, 0, 0),
+    (1, 15, 20, 192, 256, 1, 1, 0 | 32768, 192, 0, 256, 0, 0),
+    (2, 33, 47, 128, 512, 1, 1, 2 | 32768, 256, 128, 1024, 256, 0),
+    (3, 80, 80, 512, 256, 1, 1, 1 | 32768, 512, 0, 512, 256, 0),
+    (8, 80, 80, 1024, 512, 1, 1, 1 | 32768, 1024, 0, 512, 0, 0),
+    (8, 40, 40, 1536, 768, 1, 1, 1 | 32768, 1536, 0, 768, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", P8_CASES)
+def test_pingpong_1x1_kernel_matches_torch_fp32(L, case):
+    test_conv_layer_matches_torch_fp32(L, case)
+    assert L.y7t_last_kernel().decode() == "p8<256,256,64> 1x1"
+
+
+def test_pingpong_1x1_kernel_is_deterministic_under_load(L):
+    """the schedule keeps four half-tiles of DMA in flight across its barriers: a race would show as run-to-run differences (rare wrong tiles that come and go with memory
+    load, cdna_hip_programming.md section 5) -- the same launch 20 times on 6400 tiles while a copy kernel streams beside it on another stream: bit-identical outputs"""
+    from yolov7_tracker_amd import _lib
+    from yolov7_tracker_amd.detector import weights
+    B, H, W, Cin, Cout = 8, 160, 160, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=g).half()
+    wt = (torch.randn((Cout, Cin), device="cuda", generator=g) / Cin ** 0.5).half()
+    wp = torch.from_numpy(weights.panel_pack_p8(wt.cpu().numpy())).cuda()
+    b = torch.randn(Cout, device="cuda", generator=g)
+    zeros = torch.zeros(128, dtype=torch.float16, device="cuda")
+    big = torch.empty((2, 64 << 20), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    outs = []
+    for it in range(20):
+        out = torch.zeros((B, H, W, Cout), dtype=torch.float16, device="cuda")
+        with torch.cuda.stream(side):
+            big[1].copy_(big[0], non_blocking=True)
+        _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), Cin, 0, B, H, W, Cin, _lib.ptr(wp), _lib.ptr(b), _lib.ptr(out), Cout, 0, 0, Cout, Cout, 1, 1, 1, 0, 1 | 32768,
+                                         _lib.ptr(zeros), _lib.stream_ptr()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert L.y7t_last_kernel().decode() == "p8<256,256,64> 1x1"
+    ref = F.silu(x.float().view(-1, Cin) @ wt.float().t() + b).view(B, H, W, Cout)
+    assert torch.allclose(outs[0].float(), ref, rtol=6e-4, atol=3e-4)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_pingpong_1x1_upsample_on_read_equals_materialised_upsample(monkeypatch):
+    """the DUAL instance inside a network: with the ping-pong kernel taking every eligible 1x1 layer of a small forward (Y7T_CONV_P8_MIN_TILES=1), the plan that reads the
+    three upsampled tensors through the loader equals the plan that materialises them, bit for bit (same kernel, same K order on both sides)"""
+    monkeypatch.setenv("Y7T_CONV_P8_MIN_TILES", "1")
+    img = torch.rand((2, 3, 256, 320), generator=torch.Generator().manual_seed(9))
+    det = build("yolov7-w6", 10, (256, 320), 2)
+    names = det.launch_list(2)
+    assert sum(n == "p8<256,256,64> 1x1 upsample-on-read" for n in names) == 3 and sum(n.startswith("p8<") for n in names) >= 14, names
+    a = [t.clone() for t in det(img)[0].raw()]
+    monkeypatch.setenv("Y7T_UPSAMPLE_ON_READ", "0")
+    ref = build("yolov7-w6", 10, (256, 320), 2)
+    assert sum(int(o["type"]) == 1 for o in ref.plan.ops) == 3
+    b = ref(img)[0].raw()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
 # csrc/y7t_conv_patch_s2.hip: the stride-2 LDS-patch kernel (parity-split patch columns, 16-channel chunks; korder 4 = act bit 12), 128- and 256-channel panels

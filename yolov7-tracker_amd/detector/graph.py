@@ -180,6 +180,20 @@ def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_c
             and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
+def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20, up=None, detect=False):
+    """mirror of y7t_conv_p8_launch (csrc/y7t_conv_p8.hip): the 1x1 layers whose Cout is a multiple of 256, on the 256 x 256 x 64 ping-pong pipeline -- where the layer has
+    at least a tile per compute unit (the 20 x 20 maps at 32 frames have 100-200 tiles of that size and stay on the 128-pixel tiles).  up = (up_c0, up_C) of an
+    upsample-on-read layer.  Y7T_CONV_P8=0 switches it off (A/B inside one session)."""
+    if os.environ.get("Y7T_CONV_P8", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0" or detect:
+        return False
+    tiles = -(-(B * H * W) // 256) * (cout // 256 if cout % 256 == 0 else 0)
+    ok = (k == 1 and s == 1 and cin % 64 == 0 and cout % 256 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0
+          and tiles >= int(os.environ.get("Y7T_CONV_P8_MIN_TILES", "256")))
+    if up is not None:
+        ok = ok and up[0] % 64 == 0 and up[1] % 64 == 0 and H % 2 == 0 and W % 2 == 0
+    return bool(ok)
+
+
 def lower(nodes, H, W, max_batch=1):
     det = next(n for n in nodes if n.kind == "detect")
     # ---- liveness: only what reaches the (main) Detect inputs ----
@@ -302,6 +316,9 @@ def lower(nodes, H, W, max_batch=1):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch * n.h * n.w):
             korder = 4                               # stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
+        elif p8_eligible(src.h, src.w, cin, cout, n.k, n.s, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch,
+                         up=(src.virt_up[1], src.virt_up[0].c) if getattr(src, "virt_up", None) is not None else None, detect=level >= 0):
+            korder = 7                               # 1x1, Cout % 256 == 0, a tile per CU: 256 x 64 panels of the ping-pong pipeline (weights.panel_pack_p8)
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level

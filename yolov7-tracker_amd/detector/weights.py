@@ -142,6 +142,22 @@ def panel_pack_linear(blk):
     return np.ascontiguousarray(a).reshape(cout_pad, K)
 
 
+def panel_pack_p8(blk):
+    """[Cout_pad][K] block of a 1x1 layer (Cout_pad % 256 == 0, K % 64 == 0) -> the panel order of csrc/y7t_conv_p8.hip (korder 7):
+    [channel tile of 256][K-tile of 64][half h][row r of 128][eight 16-byte slots] = per (tile, K-tile) one contiguous 32 KiB block that IS the LDS image of the two
+    channel half-tiles: row r of half h holds channel tile * 256 + (r // 32) * 64 + h * 32 + r % 32 (a wave's 64 output channels are contiguous), slot s of row r holds
+    channel octet s ^ ((r >> 1) & 7) of the K-tile (the swizzle of the kernel's fragment reads)."""
+    cout_pad, K = blk.shape
+    assert cout_pad % 256 == 0 and K % 64 == 0
+    a = blk.reshape(cout_pad // 256, 4, 2, 32, K // 64, 8, 8)            # [tile][wq][h][r % 32][ktile][octet][8]     channel = tile*256 + wq*64 + h*32 + r32
+    a = a.transpose(0, 4, 2, 1, 3, 5, 6)                                  # [tile][ktile][h][wq][r32][octet][8]        row r = wq * 32 + r32
+    a = np.ascontiguousarray(a).reshape(cout_pad // 256, K // 64, 2, 128, 8, 8)
+    r = np.arange(128)
+    src = np.arange(8)[None, :] ^ ((r[:, None] >> 1) & 7)
+    a = np.take_along_axis(a, src[None, None, None, :, :, None], axis=4)
+    return np.ascontiguousarray(a).reshape(cout_pad, K)
+
+
 def s2_panel_width(cout_pad):
     """panel width of the stride-2 patch kernel for a layer (csrc/y7t_conv_patch_s2.hip::s2_bn, same rule)"""
     import os
@@ -197,6 +213,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = panel_pack_s2(blk, w["cin_pad"])
         elif w.get("korder") == 5:
             blk = pack_ws(blk)
+        elif w.get("korder") == 7:
+            blk = panel_pack_p8(blk)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
