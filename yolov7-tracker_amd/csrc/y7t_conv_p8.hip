@@ -53,7 +53,10 @@ struct P8 {
     static constexpr unsigned OOB = 0xFF000000u;  // voffset of a zero-filled lane: out of range with or without the (< 16 MiB) scalar offset
 };
 
-template <int ACT, bool DUAL>
+// VAR 0: a phase's prefetch (two DMA pieces per wave) is issued in front of the phase's first barrier, next to the fragment reads, then `vmcnt(8)`.
+// VAR 1: the two pieces are issued INSIDE the phase's MFMA block (behind its 2nd and 5th MFMA) and the wait -- `vmcnt(6)`: three half-tiles stay in flight -- closes the block:
+//        a piece costs its wave 60-185 clocks of issue (MI355X_MICROARCH.md), which in VAR 0 lengthens the half of the phase the partner wave's 256-clock MFMA block has to cover.
+template <int ACT, bool DUAL, int VAR>
 __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = P8;
@@ -99,25 +102,22 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         }
     const int wvo = tile_n * nk * (2 * C::HALF) + wave * 1024 + lane * 16;      // this lane's 16 bytes of piece (wave) of round 0 of C0 of K-tile 0
 
-    auto stage_p = [&](int h, int b, int T) __attribute__((always_inline)) {      // pixel half h of K-tile T -> buffer b   (T >= nk: zeros into a half nobody reads)
-        char* dst = smem + b * C::BUF + h * C::HALF + wave * 1024;
+    // piece rd (0 / 1: rows 0-63 / 64-127) of pixel half h of K-tile T -> buffer b   (T >= nk: zeros into a half nobody reads)
+    auto stage_p1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {
+        char* dst = smem + b * C::BUF + h * C::HALF + wave * 1024 + rd * 8192;
         const bool live = T < nk;
         const int ci = T * C::BK;
         const bool up = DUAL && live && ci >= p.up_c0 && ci < p.up_c0 + p.up_C;    // wave-uniform: a K-tile lies in one source (up_c0, up_C multiples of 64)
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            if (up) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (LDS_AS void*)(dst + rd * 8192), 16, xoff2[DUAL ? h : 0][rd], (ci - p.up_c0) * 2, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)(dst + rd * 8192), 16, live ? xoff[h][rd] : (int)C::OOB, live ? ci * 2 : 0, 0, 0);
-        }
+        if (up) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (LDS_AS void*)dst, 16, xoff2[DUAL ? h : 0][rd], (ci - p.up_c0) * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)dst, 16, live ? xoff[h][rd] : (int)C::OOB, live ? ci * 2 : 0, 0, 0);
     };
-    auto stage_c = [&](int h, int b, int T) __attribute__((always_inline)) {      // channel half h of K-tile T -> buffer b
-        char* dst = smem + b * C::BUF + (2 + h) * C::HALF + wave * 1024;
+    auto stage_c1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {      // ... of channel half h
+        char* dst = smem + b * C::BUF + (2 + h) * C::HALF + wave * 1024 + rd * 8192;
         const bool live = T < nk;
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)(dst + rd * 8192), 16, live ? wvo + h * C::HALF + rd * 8192 : (int)C::OOB,
-                                                     live ? T * (2 * C::HALF) : 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)dst, 16, live ? wvo + h * C::HALF + rd * 8192 : (int)C::OOB, live ? T * (2 * C::HALF) : 0, 0, 0);
     };
+    auto stage_p = [&](int h, int b, int T) __attribute__((always_inline)) { stage_p1(h, b, T, 0); stage_p1(h, b, T, 1); };
+    auto stage_c = [&](int h, int b, int T) __attribute__((always_inline)) { stage_c1(h, b, T, 0); stage_c1(h, b, T, 1); };
 
     // ---- fragment geometry: lane (l31, hi32) reads row base + l31, logical chunk 2 ks + hi32 of k-substep ks ----
     const int swl = (l31 >> 1) & 7;
@@ -134,19 +134,28 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const half8*)(smem + b * C::BUF + (2 + hC) * C::HALF + crow + (((ks * 2 + hi32) ^ swl) << 4));
     };
     floatx16 acc[2][2][2];      // [pixel half][32-pixel block][channel half]
-    auto mma = [&](int hP, const half8 (&cf)[4], int hC) __attribute__((always_inline)) {
+    // a phase's MFMA block; VAR 1: piece(0) behind the 2nd MFMA, piece(1) behind the 5th
+    auto mma = [&](int hP, const half8 (&cf)[4], int hC, auto piece) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) {
+                acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
+                if (VAR == 1 && (ks * 2 + j == 1 || ks * 2 + j == 4)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(ks * 2 + j == 1 ? 0 : 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: the bias, K-tile 0 and the first two halves of K-tile 1 (what phases (-1, 2) and (-1, 3) of the steady state would have staged) ----
     __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (LDS_AS void*)(smem + C::BIAS + wq * 256), 4, (n0 + wq * 64 + lane) * 4, 0, 0, 0);      // (both groups: same bytes)
     stage_p(0, 0, 0); stage_c(0, 0, 0); stage_c(1, 0, 0); stage_p(1, 0, 0); stage_p(0, 1, 1); stage_c(0, 1, 1);
-    P8_VMCNT(8);                          // 13 issued: the bias, P0 and C0 of K-tile 0 have landed (this wave's pieces)
+    if (VAR == 0) P8_VMCNT(8);            // 13 issued: the bias, P0 and C0 of K-tile 0 have landed (this wave's pieces)
+    else P8_VMCNT(4);                     // VAR 1 waits at the END of a phase: group 0 reads C1 / P1 of K-tile 0 before group 1 has been through one -> all of K-tile 0 here
     __builtin_amdgcn_s_barrier();         // ... everybody's
 #pragma unroll
     for (int hC = 0; hC < 2; ++hC)
@@ -168,30 +177,30 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         constexpr int b = decltype(bc)::value;
         // phase 0: quadrant (P0, C0); prefetch C1 of K-tile T + 1 (that half of the other buffer was last read in phase 1 of K-tile T - 1)
         read_p(0, b); read_c(c0, 0, b);
-        stage_c(1, b ^ 1, T + 1);
-        P8_VMCNT(8);
+        if (VAR == 0) { stage_c(1, b ^ 1, T + 1); P8_VMCNT(8); }
         __builtin_amdgcn_s_barrier();
-        mma(0, c0, 0);
+        mma(0, c0, 0, [&](int rd) __attribute__((always_inline)) { stage_c1(1, b ^ 1, T + 1, rd); });
+        if (VAR == 1) P8_VMCNT(6);
         __builtin_amdgcn_s_barrier();
         // phase 1: (P0, C1); prefetch P1 of T + 1
         read_c(c1, 1, b);
-        stage_p(1, b ^ 1, T + 1);
-        P8_VMCNT(8);
+        if (VAR == 0) { stage_p(1, b ^ 1, T + 1); P8_VMCNT(8); }
         __builtin_amdgcn_s_barrier();
-        mma(0, c1, 1);
+        mma(0, c1, 1, [&](int rd) __attribute__((always_inline)) { stage_p1(1, b ^ 1, T + 1, rd); });
+        if (VAR == 1) P8_VMCNT(6);
         __builtin_amdgcn_s_barrier();
         // phase 2: (P1, C1); prefetch P0 of T + 2 into THIS buffer (its P0 was read in phase 0)
         read_p(1, b);
-        stage_p(0, b, T + 2);
-        P8_VMCNT(8);
+        if (VAR == 0) { stage_p(0, b, T + 2); P8_VMCNT(8); }
         __builtin_amdgcn_s_barrier();
-        mma(1, c1, 1);
+        mma(1, c1, 1, [&](int rd) __attribute__((always_inline)) { stage_p1(0, b, T + 2, rd); });
+        if (VAR == 1) P8_VMCNT(6);
         __builtin_amdgcn_s_barrier();
         // phase 3: (P1, C0) with the C0 fragments of phase 0; prefetch C0 of T + 2
-        stage_c(0, b, T + 2);
-        P8_VMCNT(8);
+        if (VAR == 0) { stage_c(0, b, T + 2); P8_VMCNT(8); }
         __builtin_amdgcn_s_barrier();
-        mma(1, c0, 0);
+        mma(1, c0, 0, [&](int rd) __attribute__((always_inline)) { stage_c1(0, b, T + 2, rd); });
+        if (VAR == 1) P8_VMCNT(6);
         __builtin_amdgcn_s_barrier();
     };
     for (int T = 0; T < nk; T += 2) {
@@ -263,21 +272,29 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-#define P8_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+#define P8_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
+                           Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         P8_ATTR(Y7T_ACT_NONE, false) P8_ATTR(Y7T_ACT_SILU, false) P8_ATTR(Y7T_ACT_LEAKY, false) P8_ATTR(Y7T_ACT_NONE, true) P8_ATTR(Y7T_ACT_SILU, true) P8_ATTR(Y7T_ACT_LEAKY, true)
 #undef P8_ATTR
         attr = true;
     }
     const int grid = ((a.M + C::BM - 1) / C::BM) * (a.Cout_pad / C::BN);
     const bool dual = a.up_C > 0;
-#define P8_GO(ACT) \
-    do { if (dual) hipLaunchKernelGGL((k_conv1x1_p8<ACT, true>), dim3(grid), dim3(C::NT), C::LDS, s, a); \
-         else hipLaunchKernelGGL((k_conv1x1_p8<ACT, false>), dim3(grid), dim3(C::NT), C::LDS, s, a); } while (0)
+    static int var = -1;
+#if defined(Y7T_CONVSIM)
+    var = -1;      // (the host model switches variants between cases)
+#endif
+    if (var < 0) { const char* e = getenv("Y7T_P8_VARIANT"); var = e ? atoi(e) : 0; }
+#define P8_GO2(ACT, DUAL) \
+    do { if (var == 1) hipLaunchKernelGGL((k_conv1x1_p8<ACT, DUAL, 1>), dim3(grid), dim3(C::NT), C::LDS, s, a); \
+         else hipLaunchKernelGGL((k_conv1x1_p8<ACT, DUAL, 0>), dim3(grid), dim3(C::NT), C::LDS, s, a); } while (0)
+#define P8_GO(ACT) do { if (dual) P8_GO2(ACT, true); else P8_GO2(ACT, false); } while (0)
     if (a.act == Y7T_ACT_SILU) P8_GO(Y7T_ACT_SILU);
     else if (a.act == Y7T_ACT_LEAKY) P8_GO(Y7T_ACT_LEAKY);
     else P8_GO(Y7T_ACT_NONE);
 #undef P8_GO
+#undef P8_GO2
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("p8<256,256,64> 1x1%s", dual ? " upsample-on-read" : "");
+    y7t_note_kernel("p8<256,256,64> 1x1%s%s", dual ? " upsample-on-read" : "", var == 1 ? " v1" : "");
     return 0;
 }
