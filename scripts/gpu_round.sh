@@ -121,6 +121,13 @@ PY
   benchsum p8v1 p8v0
   ;;
 
+exp_p8abl)
+  say "exp_p8abl: timing ablations of the p8 kernel (wrong results): Y7T_CONV_ABLATE 0 full, 1 no in-loop DMAs, 2 no MFMAs, 4 no fragment reads, 6 neither, 7 barriers only, 8 no setprio, 16 no stores"
+  for shape in ${P8SHAPES:-80,1024,512,1,1 160,512,256,1,1 40,1536,768,1,1}; do
+    for a in 0 1 2 4 6 7 8 16; do echo "-- $shape ablate $a: $(ONLY=$shape Y7T_CONV_ABLATE=$a timeout 100 python scripts/bench_conv.py 32 100 2>&1 | grep -v amdgpu | grep ' 1/1 ' | cut -c1-70)"; done
+  done | tee -a $O/summary.txt
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

@@ -56,7 +56,8 @@ struct P8 {
 // VAR 0: a phase's prefetch (two DMA pieces per wave) is issued in front of the phase's first barrier, next to the fragment reads, then `vmcnt(8)`.
 // VAR 1: the two pieces are issued INSIDE the phase's MFMA block (behind its 2nd and 5th MFMA) and the wait -- `vmcnt(6)`: three half-tiles stay in flight -- closes the block:
 //        a piece costs its wave 60-185 clocks of issue (MI355X_MICROARCH.md), which in VAR 0 lengthens the half of the phase the partner wave's 256-clock MFMA block has to cover.
-template <int ACT, bool DUAL, int VAR>
+// ABL (timing ablations, wrong results; Y7T_CONV_ABLATE): 1 no prefetch DMAs in the loop, 2 no MFMAs, 4 no fragment reads, 8 no s_setprio, 16 no output stores
+template <int ACT, bool DUAL, int VAR, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = P8;
@@ -103,7 +104,9 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
     const int wvo = tile_n * nk * (2 * C::HALF) + wave * 1024 + lane * 16;      // this lane's 16 bytes of piece (wave) of round 0 of C0 of K-tile 0
 
     // piece rd (0 / 1: rows 0-63 / 64-127) of pixel half h of K-tile T -> buffer b   (T >= nk: zeros into a half nobody reads)
+    bool in_loop = false;      // (ABL 1: the prologue's DMAs stay)
     auto stage_p1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {
+        if ((ABL & 1) && in_loop) return;
         char* dst = smem + b * C::BUF + h * C::HALF + wave * 1024 + rd * 8192;
         const bool live = T < nk;
         const int ci = T * C::BK;
@@ -112,6 +115,7 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)dst, 16, live ? xoff[h][rd] : (int)C::OOB, live ? ci * 2 : 0, 0, 0);
     };
     auto stage_c1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {      // ... of channel half h
+        if ((ABL & 1) && in_loop) return;
         char* dst = smem + b * C::BUF + (2 + h) * C::HALF + wave * 1024 + rd * 8192;
         const bool live = T < nk;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)dst, 16, live ? wvo + h * C::HALF + rd * 8192 : (int)C::OOB, live ? T * (2 * C::HALF) : 0, 0, 0);
@@ -124,31 +128,34 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
     const int prow = (grp * 64 + l31) * C::ROWB, crow = (wq * 32 + l31) * C::ROWB;
     half8 pf[2][4], c0[4], c1[4];
     auto read_p = [&](int hP, int b) __attribute__((always_inline)) {
+        if (ABL & 4) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) pf[j][ks] = *(const half8*)(smem + b * C::BUF + hP * C::HALF + prow + j * 32 * C::ROWB + (((ks * 2 + hi32) ^ swl) << 4));
     };
     auto read_c = [&](half8 (&cf)[4], int hC, int b) __attribute__((always_inline)) {
+        if (ABL & 4) return;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const half8*)(smem + b * C::BUF + (2 + hC) * C::HALF + crow + (((ks * 2 + hi32) ^ swl) << 4));
     };
     floatx16 acc[2][2][2];      // [pixel half][32-pixel block][channel half]
     // a phase's MFMA block; VAR 1: piece(0) behind the 2nd MFMA, piece(1) behind the 5th
     auto mma = [&](int hP, const half8 (&cf)[4], int hC, auto piece) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
+                if (ABL & 2) asm volatile("" :: "v"(cf[ks]), "v"(pf[j][ks]));      // (keeps the fragment reads alive)
+                else acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
                 if (VAR == 1 && (ks * 2 + j == 1 || ks * 2 + j == 4)) {
                     __builtin_amdgcn_sched_barrier(0);
                     piece(ks * 2 + j == 1 ? 0 : 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: the bias, K-tile 0 and the first two halves of K-tile 1 (what phases (-1, 2) and (-1, 3) of the steady state would have staged) ----
@@ -171,6 +178,11 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
                     for (int e = 0; e < 4; ++e) acc[hP][j][hC][g * 4 + e] = bv[e];
         }
     if (grp == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind: its fragment reads / DMAs fall into group 0's MFMA blocks and vice versa
+    in_loop = true;
+    if (ABL & 4) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { c0[ks] = c1[ks] = pf[0][ks] = pf[1][ks] = half8{1, 1, 1, 1, 1, 1, 1, 1}; }
+    }
 
     // ---- one K-tile = four phases; b (its buffer) is a compile-time constant of each instance ----
     auto ktile = [&](int T, auto bc) __attribute__((always_inline)) {
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         const int px = k * 8 + (lane >> 3), ch = lane & 7;
         const uint4v v = *(const uint4v*)(scr + px * 128 + ((ch ^ (px & 7)) << 4));
         const int m = m0 + grp * 128 + px, n = n0 + wq * 64 + ch * 8;
-        if (m < p.M && n < p.Cout) *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+        if (m < p.M && n < p.Cout && !(ABL & 16)) *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
     }
 #endif
 }
@@ -280,6 +292,15 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int grid = ((a.M + C::BM - 1) / C::BM) * (a.Cout_pad / C::BN);
     const bool dual = a.up_C > 0;
+    if (a.ablate && a.act == Y7T_ACT_SILU && !dual) {      // timing ablations of the plain SiLU instance (Y7T_CONV_ABLATE=1|2|4|8|16; wrong results)
+#define P8_ABL(N) case N: Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<Y7T_ACT_SILU, false, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
+                          hipLaunchKernelGGL((k_conv1x1_p8<Y7T_ACT_SILU, false, 0, N>), dim3(grid), dim3(C::NT), C::LDS, s, a); break;
+        switch (a.ablate) { P8_ABL(1) P8_ABL(2) P8_ABL(4) P8_ABL(8) P8_ABL(16) P8_ABL(6) P8_ABL(7) default: y7t_set_error("conv: unknown p8 ablation %d", a.ablate); return Y7T_E_ARG; }
+#undef P8_ABL
+        Y7T_LAUNCH_CHECK();
+        y7t_note_kernel("p8<256,256,64> 1x1 ablated");
+        return 0;
+    }
     static int var = -1;
 #if defined(Y7T_CONVSIM)
     var = -1;      // (the host model switches variants between cases)
