@@ -9,7 +9,7 @@
 # Steps:
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
-#   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0)
+#   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
@@ -84,41 +84,6 @@ exp_p8)
   Y7T_CONV_P8=0 timeout 300 python bench.py $X > $O/bench_nop8.json 2> $O/bench_nop8.err
   timeout 300 python bench.py $X > $O/bench_p8b.json 2> $O/bench_p8b.err
   benchsum p8 nop8 p8b
-  ;;
-
-exp_p8v)
-  say "exp_p8v a: p8 variants (Y7T_P8_VARIANT: 0 = DMAs before the phase barrier, 1 = inside the MFMA block, vmcnt(6)): layer parity + determinism of each"
-  for v in ${P8VARS:-1}; do Y7T_P8_VARIANT=$v timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "pingpong_1x1_kernel" > $O/t_p8v$v.log 2>&1; echo "rc=$?" >> $O/t_p8v$v.log; echo "-- variant $v"; tailsum $O/t_p8v$v.log 2; done
-  say "exp_p8v b: per-layer timing at 32 frames, p8 rows, per variant (and Y7T_CONV_P8=0 = igemm<128,128,32,2>)"
-  Y7T_CONV_P8=0 timeout 200 python scripts/bench_conv.py 32 > $O/b_nop8.txt 2>&1
-  for v in 0 ${P8VARS:-1}; do Y7T_P8_VARIANT=$v timeout 200 python scripts/bench_conv.py 32 > $O/b_p8v$v.txt 2>&1; done
-  python3 - $O 0 ${P8VARS:-1} <<'PY' | tee -a $O/summary.txt
-import sys, re
-o, vs = sys.argv[1], sys.argv[2:]
-def rows(f):
-    r = {}
-    for l in open(f):
-        m = re.match(r"\s*(\d+x\d+\s+\d+->\d+\s+\d/\d\s+ld\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", l)
-        if m: r[m.group(1)] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
-        if l.startswith("TOTAL"): r["TOTAL"] = l.strip()
-    return r
-base = rows(o + "/b_nop8.txt")
-var = {v: rows("%s/b_p8v%s.txt" % (o, v)) for v in vs}
-print("%-40s %3s %9s | " % ("layer", "x", "igemm us") + " | ".join("v%s us (TF/s)" % v for v in vs))
-tot = {v: 0.0 for v in vs}; tb = 0.0
-for k, (n, us, tf) in base.items() if False else [(k, base[k]) for k in base if k != "TOTAL"]:
-    ch = [var[v].get(k) for v in vs]
-    if " 1/1 " in k and any(c and abs(c[1] - us) / us > 0.03 for c in ch):
-        print("%-40s %3d %9.1f | " % (k, n, us) + " | ".join("%7.1f (%4.0f)" % (c[1], c[2]) for c in ch))
-    tb += n * us
-    for v, c in zip(vs, ch): tot[v] += n * (c[1] if c else us)
-print("sum over the list (us): igemm %.0f | " % tb + " | ".join("v%s %.0f" % (v, tot[v]) for v in vs))
-PY
-  say "exp_p8v c: bench lines: variant ${P8BENCH:-1}, then variant 0"
-  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
-  Y7T_P8_VARIANT=${P8BENCH:-1} timeout 300 python bench.py $X > $O/bench_p8v1.json 2> $O/bench_p8v1.err
-  Y7T_P8_VARIANT=0 timeout 300 python bench.py $X > $O/bench_p8v0.json 2> $O/bench_p8v0.err
-  benchsum p8v1 p8v0
   ;;
 
 exp_p8abl)

@@ -133,25 +133,22 @@ P8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["dma-before-barrier", "dma-inside-mfma-block"])
 @pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
 @pytest.mark.parametrize("case", P8_CASES, ids=lambda c: "%dx%dx%d_%d-%d" % c[:5])
-def test_pingpong_1x1_kernel_source_on_the_host(case, deferred, variant, monkeypatch):
+def test_pingpong_1x1_kernel_source_on_the_host(case, deferred):
     B, H, W, Cin, Cout, act, kw = case
     L = cs.lib()
-    monkeypatch.setenv("Y7T_P8_VARIANT", str(variant))      # (the host build of the launcher reads it at every call)
     L.cs_set_dma_deferred(deferred)
     try:
         name = run_case(L, B, H, W, Cin, Cout, 1, 1, act, 0, korder=7, seed=B * 1000 + H + W + Cin, **kw)
     finally:
         L.cs_set_dma_deferred(0)
-    assert name == "p8<256,256,64> 1x1" + (" v1" if variant else ""), name
+    assert name == "p8<256,256,64> 1x1", name
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["dma-before-barrier", "dma-inside-mfma-block"])
 @pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
 @pytest.mark.parametrize("lat_first", [True, False])
-def test_pingpong_1x1_upsample_on_read_on_the_host(lat_first, deferred, variant, monkeypatch):
+def test_pingpong_1x1_upsample_on_read_on_the_host(lat_first, deferred):
     """the DUAL instance: K-tiles of the upsampled channel range DMA pixel (y >> 1, x >> 1) of the half-resolution tensor (cfg/deploy/yolov7-w6.yaml:75,89,103)"""
     from yolov7_tracker_amd.detector import weights
     L = cs.lib()
@@ -165,14 +162,13 @@ def test_pingpong_1x1_upsample_on_read_on_the_host(lat_first, deferred, variant,
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
     wp = pack_w(Wt, Cin, Cout, 7)
     out = np.full((B, H, W, Cout), 7.0, np.float16)
-    monkeypatch.setenv("Y7T_P8_VARIANT", str(variant))
     L.cs_set_dma_deferred(deferred)
     try:
         rc = L.cs_conv_dual(lat.ctypes.data, Cin, 0, half.ctypes.data, 192, 32, up_c0, C_up, B, H, W, Cin, wp.ctypes.data, bias.ctypes.data, out.ctypes.data, Cout, 0, Cout, Cout, 1, 7, 0)
     finally:
         L.cs_set_dma_deferred(0)
     assert rc == 0, L.cs_last_error().decode()
-    assert L.cs_last_kernel().decode() == "p8<256,256,64> 1x1 upsample-on-read" + (" v1" if variant else "")
+    assert L.cs_last_kernel().decode() == "p8<256,256,64> 1x1 upsample-on-read"
     x = lat.astype(np.float32)
     x[..., up_c0:up_c0 + C_up] = np.repeat(np.repeat(half[..., 32:32 + C_up].astype(np.float32), 2, axis=1), 2, axis=2)
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))

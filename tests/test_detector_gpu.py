@@ -166,7 +166,7 @@ P8_CASES = [
 @pytest.mark.parametrize("case", P8_CASES)
 def test_pingpong_1x1_kernel_matches_torch_fp32(L, case):
     test_conv_layer_matches_torch_fp32(L, case)
-    assert L.y7t_last_kernel().decode() == "p8<256,256,64> 1x1" + (" v1" if os.environ.get("Y7T_P8_VARIANT") == "1" else "")
+    assert L.y7t_last_kernel().decode() == "p8<256,256,64> 1x1"
 
 
 def test_pingpong_1x1_kernel_is_deterministic_under_load(L):

@@ -37,9 +37,11 @@ namespace {
 #if defined(Y7T_CONVSIM)      // tests/_convsim: the DMA queue of the host model (fake/hip/hip_runtime.h); lanes of a wave are separate OS threads there
 #define P8_VMCNT(n) cs_vmcnt(n)
 #define P8_WAVE_SYNC() cs_wave_barrier(threadIdx.x >> 6)
+#define P8_KEEP(a, b) ((void)0)
 #else
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_WAVE_SYNC() ((void)0)      // LDS instructions of one wave execute in order
+#define P8_KEEP(a, b) asm volatile("" :: "v"(a), "v"(b))      // (timing ablations: keeps the fragment reads alive without the MFMAs)
 #endif
 
 struct P8 {
@@ -53,11 +55,9 @@ struct P8 {
     static constexpr unsigned OOB = 0xFF000000u;  // voffset of a zero-filled lane: out of range with or without the (< 16 MiB) scalar offset
 };
 
-// VAR 0: a phase's prefetch (two DMA pieces per wave) is issued in front of the phase's first barrier, next to the fragment reads, then `vmcnt(8)`.
-// VAR 1: the two pieces are issued INSIDE the phase's MFMA block (behind its 2nd and 5th MFMA) and the wait -- `vmcnt(6)`: three half-tiles stay in flight -- closes the block:
-//        a piece costs its wave 60-185 clocks of issue (MI355X_MICROARCH.md), which in VAR 0 lengthens the half of the phase the partner wave's 256-clock MFMA block has to cover.
+// (a variant with the two DMA pieces of a phase issued INSIDE the MFMA block and `vmcnt(6)` at its end measured the same: profiles/r04_p8_measurements.txt)
 // ABL (timing ablations, wrong results; Y7T_CONV_ABLATE): 1 no prefetch DMAs in the loop, 2 no MFMAs, 4 no fragment reads, 8 no s_setprio, 16 no output stores
-template <int ACT, bool DUAL, int VAR, int ABL = 0>
+template <int ACT, bool DUAL, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = P8;
@@ -140,20 +140,14 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const half8*)(smem + b * C::BUF + (2 + hC) * C::HALF + crow + (((ks * 2 + hi32) ^ swl) << 4));
     };
     floatx16 acc[2][2][2];      // [pixel half][32-pixel block][channel half]
-    // a phase's MFMA block; VAR 1: piece(0) behind the 2nd MFMA, piece(1) behind the 5th
-    auto mma = [&](int hP, const half8 (&cf)[4], int hC, auto piece) __attribute__((always_inline)) {
+    auto mma = [&](int hP, const half8 (&cf)[4], int hC) __attribute__((always_inline)) {      // a phase's MFMA block
         if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (ABL & 2) asm volatile("" :: "v"(cf[ks]), "v"(pf[j][ks]));      // (keeps the fragment reads alive)
+                if (ABL & 2) P8_KEEP(cf[ks], pf[j][ks]);
                 else acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
-                if (VAR == 1 && (ks * 2 + j == 1 || ks * 2 + j == 4)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    piece(ks * 2 + j == 1 ? 0 : 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
         if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
     };
@@ -161,8 +155,7 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
     // ---- prologue: the bias, K-tile 0 and the first two halves of K-tile 1 (what phases (-1, 2) and (-1, 3) of the steady state would have staged) ----
     __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (LDS_AS void*)(smem + C::BIAS + wq * 256), 4, (n0 + wq * 64 + lane) * 4, 0, 0, 0);      // (both groups: same bytes)
     stage_p(0, 0, 0); stage_c(0, 0, 0); stage_c(1, 0, 0); stage_p(1, 0, 0); stage_p(0, 1, 1); stage_c(0, 1, 1);
-    if (VAR == 0) P8_VMCNT(8);            // 13 issued: the bias, P0 and C0 of K-tile 0 have landed (this wave's pieces)
-    else P8_VMCNT(4);                     // VAR 1 waits at the END of a phase: group 0 reads C1 / P1 of K-tile 0 before group 1 has been through one -> all of K-tile 0 here
+    P8_VMCNT(8);                          // 13 issued: the bias, P0 and C0 of K-tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();         // ... everybody's
 #pragma unroll
     for (int hC = 0; hC < 2; ++hC)
@@ -189,30 +182,30 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         constexpr int b = decltype(bc)::value;
         // phase 0: quadrant (P0, C0); prefetch C1 of K-tile T + 1 (that half of the other buffer was last read in phase 1 of K-tile T - 1)
         read_p(0, b); read_c(c0, 0, b);
-        if (VAR == 0) { stage_c(1, b ^ 1, T + 1); P8_VMCNT(8); }
+        stage_c(1, b ^ 1, T + 1);
+        P8_VMCNT(8);
         __builtin_amdgcn_s_barrier();
-        mma(0, c0, 0, [&](int rd) __attribute__((always_inline)) { stage_c1(1, b ^ 1, T + 1, rd); });
-        if (VAR == 1) P8_VMCNT(6);
+        mma(0, c0, 0);
         __builtin_amdgcn_s_barrier();
         // phase 1: (P0, C1); prefetch P1 of T + 1
         read_c(c1, 1, b);
-        if (VAR == 0) { stage_p(1, b ^ 1, T + 1); P8_VMCNT(8); }
+        stage_p(1, b ^ 1, T + 1);
+        P8_VMCNT(8);
         __builtin_amdgcn_s_barrier();
-        mma(0, c1, 1, [&](int rd) __attribute__((always_inline)) { stage_p1(1, b ^ 1, T + 1, rd); });
-        if (VAR == 1) P8_VMCNT(6);
+        mma(0, c1, 1);
         __builtin_amdgcn_s_barrier();
         // phase 2: (P1, C1); prefetch P0 of T + 2 into THIS buffer (its P0 was read in phase 0)
         read_p(1, b);
-        if (VAR == 0) { stage_p(0, b, T + 2); P8_VMCNT(8); }
+        stage_p(0, b, T + 2);
+        P8_VMCNT(8);
         __builtin_amdgcn_s_barrier();
-        mma(1, c1, 1, [&](int rd) __attribute__((always_inline)) { stage_p1(0, b, T + 2, rd); });
-        if (VAR == 1) P8_VMCNT(6);
+        mma(1, c1, 1);
         __builtin_amdgcn_s_barrier();
         // phase 3: (P1, C0) with the C0 fragments of phase 0; prefetch C0 of T + 2
-        if (VAR == 0) { stage_c(0, b, T + 2); P8_VMCNT(8); }
+        stage_c(0, b, T + 2);
+        P8_VMCNT(8);
         __builtin_amdgcn_s_barrier();
-        mma(1, c0, 0, [&](int rd) __attribute__((always_inline)) { stage_c1(0, b, T + 2, rd); });
-        if (VAR == 1) P8_VMCNT(6);
+        mma(1, c0, 0);
         __builtin_amdgcn_s_barrier();
     };
     for (int T = 0; T < nk; T += 2) {
@@ -284,8 +277,7 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-#define P8_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
-                           Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+#define P8_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         P8_ATTR(Y7T_ACT_NONE, false) P8_ATTR(Y7T_ACT_SILU, false) P8_ATTR(Y7T_ACT_LEAKY, false) P8_ATTR(Y7T_ACT_NONE, true) P8_ATTR(Y7T_ACT_SILU, true) P8_ATTR(Y7T_ACT_LEAKY, true)
 #undef P8_ATTR
         attr = true;
@@ -293,29 +285,22 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
     const int grid = ((a.M + C::BM - 1) / C::BM) * (a.Cout_pad / C::BN);
     const bool dual = a.up_C > 0;
     if (a.ablate && a.act == Y7T_ACT_SILU && !dual) {      // timing ablations of the plain SiLU instance (Y7T_CONV_ABLATE=1|2|4|8|16; wrong results)
-#define P8_ABL(N) case N: Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<Y7T_ACT_SILU, false, 0, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
-                          hipLaunchKernelGGL((k_conv1x1_p8<Y7T_ACT_SILU, false, 0, N>), dim3(grid), dim3(C::NT), C::LDS, s, a); break;
+#define P8_ABL(N) case N: Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<Y7T_ACT_SILU, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
+                          hipLaunchKernelGGL((k_conv1x1_p8<Y7T_ACT_SILU, false, N>), dim3(grid), dim3(C::NT), C::LDS, s, a); break;
         switch (a.ablate) { P8_ABL(1) P8_ABL(2) P8_ABL(4) P8_ABL(8) P8_ABL(16) P8_ABL(6) P8_ABL(7) default: y7t_set_error("conv: unknown p8 ablation %d", a.ablate); return Y7T_E_ARG; }
 #undef P8_ABL
         Y7T_LAUNCH_CHECK();
         y7t_note_kernel("p8<256,256,64> 1x1 ablated");
         return 0;
     }
-    static int var = -1;
-#if defined(Y7T_CONVSIM)
-    var = -1;      // (the host model switches variants between cases)
-#endif
-    if (var < 0) { const char* e = getenv("Y7T_P8_VARIANT"); var = e ? atoi(e) : 0; }
-#define P8_GO2(ACT, DUAL) \
-    do { if (var == 1) hipLaunchKernelGGL((k_conv1x1_p8<ACT, DUAL, 1>), dim3(grid), dim3(C::NT), C::LDS, s, a); \
-         else hipLaunchKernelGGL((k_conv1x1_p8<ACT, DUAL, 0>), dim3(grid), dim3(C::NT), C::LDS, s, a); } while (0)
-#define P8_GO(ACT) do { if (dual) P8_GO2(ACT, true); else P8_GO2(ACT, false); } while (0)
+#define P8_GO(ACT) \
+    do { if (dual) hipLaunchKernelGGL((k_conv1x1_p8<ACT, true>), dim3(grid), dim3(C::NT), C::LDS, s, a); \
+         else hipLaunchKernelGGL((k_conv1x1_p8<ACT, false>), dim3(grid), dim3(C::NT), C::LDS, s, a); } while (0)
     if (a.act == Y7T_ACT_SILU) P8_GO(Y7T_ACT_SILU);
     else if (a.act == Y7T_ACT_LEAKY) P8_GO(Y7T_ACT_LEAKY);
     else P8_GO(Y7T_ACT_NONE);
 #undef P8_GO
-#undef P8_GO2
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("p8<256,256,64> 1x1%s%s", dual ? " upsample-on-read" : "", var == 1 ? " v1" : "");
+    y7t_note_kernel("p8<256,256,64> 1x1%s", dual ? " upsample-on-read" : "");
     return 0;
 }

@@ -181,14 +181,18 @@ def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_c
 
 
 def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20, up=None, detect=False):
-    """mirror of y7t_conv_p8_launch (csrc/y7t_conv_p8.hip): the 1x1 layers whose Cout is a multiple of 256, on the 256 x 256 x 64 ping-pong pipeline -- where the layer has
-    at least a tile per compute unit (the 20 x 20 maps at 32 frames have 100-200 tiles of that size and stay on the 128-pixel tiles).  up = (up_c0, up_C) of an
-    upsample-on-read layer.  Y7T_CONV_P8=0 switches it off (A/B inside one session)."""
-    if os.environ.get("Y7T_CONV_P8", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0" or detect:
+    """mirror of y7t_conv_p8_launch (csrc/y7t_conv_p8.hip): 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline -- WHERE IT MEASURED FASTER than
+    igemm<128,128,32,2> on two boxes (profiles/r04_p8_measurements.txt): deep reductions (Cin >= 1024: 16+ K-tiles amortise the tile's ~8 us of prologue / epilogue /
+    drain) and Cin >= 512 on grids of >= 3000 tiles (many rounds: little quantisation loss).  The shallower layers tie or lose and stay on the 128-pixel tiles.
+    up = (up_c0, up_C) of an upsample-on-read layer.  Y7T_CONV_P8=0 switches it off, Y7T_CONV_P8=all takes every eligible shape (A/B inside one session)."""
+    mode = os.environ.get("Y7T_CONV_P8", "1")
+    if mode == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0" or detect:
         return False
     tiles = -(-(B * H * W) // 256) * (cout // 256 if cout % 256 == 0 else 0)
     ok = (k == 1 and s == 1 and cin % 64 == 0 and cout % 256 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0
           and tiles >= int(os.environ.get("Y7T_CONV_P8_MIN_TILES", "256")))
+    if mode != "all" and "Y7T_CONV_P8_MIN_TILES" not in os.environ:
+        ok = ok and (cin >= 1024 or (cin >= 512 and tiles >= 3000))
     if up is not None:
         ok = ok and up[0] % 64 == 0 and up[1] % 64 == 0 and H % 2 == 0 and W % 2 == 0
     return bool(ok)
