@@ -10,6 +10,7 @@
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
+#   exp_r4misc      round 4's small experiments: stem with full-line stores, LDS max-pool, 64-channel tiles instead of split-K -- parity + per-op tables per variant
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
 #   bench_variants  default vs --weights chaotic vs --cu_reserve 8 / 16 / 8+nms in ONE session (A/B deltas are only meaningful inside a session)
@@ -91,6 +92,37 @@ exp_p8abl)
   for shape in ${P8SHAPES:-80,1024,512,1,1 160,512,256,1,1 40,1536,768,1,1}; do
     for a in 0 1 2 4 6 7 8 16; do echo "-- $shape ablate $a: $(ONLY=$shape Y7T_CONV_ABLATE=$a timeout 100 python scripts/bench_conv.py 32 100 2>&1 | grep -v amdgpu | grep ' 1/1 ' | cut -c1-70)"; done
   done | tee -a $O/summary.txt
+  ;;
+
+exp_r4misc)
+  say "exp_r4misc a: parity of the experiments -- stem with full-line stores (Y7T_STEM_LINES=1), LDS max-pool (default), 64-channel tiles instead of split-K (Y7T_CONV_NARROW=1)"
+  Y7T_STEM_LINES=1 timeout 300 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "fused_stem or whole_network" > $O/t_stemlines.log 2>&1; echo "rc=$?" >> $O/t_stemlines.log; tailsum $O/t_stemlines.log 2
+  Y7T_STEM_LINES=1 Y7T_CONV_NARROW=1 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_misc_pinned.log 2>&1; echo "rc=$?" >> $O/t_misc_pinned.log; tailsum $O/t_misc_pinned.log 2
+  say "exp_r4misc b: per-op tables of the launch list, one variant per run (same session)"
+  for v in default:X=1 stemlines:Y7T_STEM_LINES=1 narrow:Y7T_CONV_NARROW=1 poolgeneric:Y7T_POOL_LDS=0 default2:X=1; do
+    n=${v%%:*}; e=${v#*:}; env $e NAME=$n OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  done
+  python3 - $O <<'PY' | tee -a $O/summary.txt
+import sys, re
+o = sys.argv[1]
+def rows(n):
+    r = {}
+    try:
+        for l in open("%s/per_layer_%s.txt" % (o, n)):
+            m = re.match(r"\s*(\d+) (.+?)\s+(\d+x\d+)\s+(\d+)->(\d+)\s+(\d)/(\d)\s+([\d.]+) us", l)
+            if m: r[int(m.group(1))] = (m.group(2).strip(), m.group(3), m.group(4), m.group(5), m.group(6) + "/" + m.group(7), float(m.group(8)))
+    except Exception as e:
+        print("no table", n, e)
+    return r
+base = rows("default")
+for n in ("stemlines", "narrow", "poolgeneric", "default2"):
+    v = rows(n)
+    if not v or not base: continue
+    diff = [(i, base[i], v[i]) for i in base if i in v and (abs(v[i][5] - base[i][5]) > 0.04 * base[i][5] or base[i][0] != v[i][0])]
+    print("-- %s vs default: list %.1f -> %.1f us" % (n, sum(x[5] for x in base.values()), sum(x[5] for x in v.values())))
+    for i, b, w in diff[:14]:
+        print("   op %3d %-38s %9s %4s->%-4s %s  %8.1f -> %8.1f us  (%s)" % (i, b[0], b[1], b[2], b[3], b[4], b[5], w[5], w[0]))
+PY
   ;;
 
 suite)

@@ -7,6 +7,7 @@
 //     (utils/general.py:607-665), rank sort by confidence, class-offset bitmask NMS with torchvision's greedy
 //     semantics (general.py:676-682), top-300, scale_coords + clip + round (general.py:319-340, tracker/track.py:234-244)
 #include "y7t_common.h"
+#include <stdlib.h>
 #include "y7t_det.h"
 #include <string.h>
 
@@ -165,6 +166,47 @@ __global__ void __launch_bounds__(256) k_maxpool(const half_t* __restrict__ in, 
     }
 }
 
+// The SPPCSPC pools (models/common.py:262-280: MaxPool2d(5 / 9 / 13, 1, k // 2) of one 20 x 20 tensor, run as the cascade 5 o 5 o 5): k x k / stride 1 on a map small
+// enough for a workgroup to hold one image's 16-channel slab in LDS -- load it once (one full 32-byte piece per pixel), row maxima, column maxima (separable: 2 k instead
+// of k^2 comparisons, no bounds branches around global loads).  The generic kernel above needs 31 us for 6.5 M elements (25 dependent, predicated 16-byte loads per
+// thread); this one is bound by its launch.  Same -inf padding semantics: out-of-range taps are skipped.
+template <int K>
+__global__ void __launch_bounds__(256) k_maxpool_s1_lds(const half_t* __restrict__ in, int ldin, int cin_off, int H, int W, int C, half_t* __restrict__ out, int ldout,
+                                                        int cout_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* A = (half8*)smem;
+    const int HW = H * W, n = HW * 2, C16 = C / 16;
+    half8* R = A + n;
+    const int b = blockIdx.x / C16, cg = blockIdx.x - b * C16;
+    const size_t ibase = (size_t)b * HW * ldin + cin_off + cg * 16, obase = (size_t)b * HW * ldout + cout_off + cg * 16;
+    for (int i = threadIdx.x; i < n; i += 256) A[i] = *(const half8*)(in + ibase + (size_t)(i >> 1) * ldin + (i & 1) * 8);
+    __syncthreads();
+    constexpr int P = K / 2;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i >> 1, y = px / W, x = px - y * W;
+        const int x0 = x - P < 0 ? 0 : x - P, x1 = x + P >= W ? W - 1 : x + P;
+        half8 m = A[(y * W + x0) * 2 + (i & 1)];
+        for (int xx = x0 + 1; xx <= x1; ++xx) {
+            const half8 v = A[(y * W + xx) * 2 + (i & 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = m[e] > v[e] ? m[e] : v[e];
+        }
+        R[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i >> 1, y = px / W, x = px - y * W;
+        const int y0 = y - P < 0 ? 0 : y - P, y1 = y + P >= H ? H - 1 : y + P;
+        half8 m = R[(y0 * W + x) * 2 + (i & 1)];
+        for (int yy = y0 + 1; yy <= y1; ++yy) {
+            const half8 v = R[(yy * W + x) * 2 + (i & 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = m[e] > v[e] ? m[e] : v[e];
+        }
+        *(half8*)(out + obase + (size_t)px * ldout + (i & 1) * 8) = m;
+    }
+}
+
 int y7t_upsample_launch(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, half_t* out, int ldout, int cout_off, hipStream_t s) {
     if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("upsample: channel alignment"); return Y7T_E_ARG; }
     const long long tot = (long long)B * 4 * H * W * (C / 8);
@@ -179,6 +221,17 @@ int y7t_maxpool_launch(const half_t* in, int ldin, int cin_off, int B, int H, in
                        int cout_off, hipStream_t s) {
     if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("maxpool: channel alignment"); return Y7T_E_ARG; }
     const int Ho = (H + 2 * pd - k) / st + 1, Wo = (W + 2 * pd - k) / st + 1;
+    static const int lds_pool = []() { const char* e = getenv("Y7T_POOL_LDS"); return e ? atoi(e) : 1; }();
+    if (lds_pool && (k == 5 || k == 9 || k == 13) && st == 1 && pd == k / 2 && C % 16 == 0 && H * W <= 1024) {
+        const dim3 grid(B * (C / 16)), blk(256);
+        const size_t lds = (size_t)H * W * 64;
+        if (k == 5) hipLaunchKernelGGL(k_maxpool_s1_lds<5>, grid, blk, lds, s, in, ldin, cin_off, H, W, C, out, ldout, cout_off);
+        else if (k == 9) hipLaunchKernelGGL(k_maxpool_s1_lds<9>, grid, blk, lds, s, in, ldin, cin_off, H, W, C, out, ldout, cout_off);
+        else hipLaunchKernelGGL(k_maxpool_s1_lds<13>, grid, blk, lds, s, in, ldin, cin_off, H, W, C, out, ldout, cout_off);
+        Y7T_LAUNCH_CHECK();
+        y7t_note_kernel("maxpool<%d,%d> lds", k, st);
+        return 0;
+    }
     const long long tot = (long long)B * Ho * Wo * (C / 8);
     int blocks = (int)((tot + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_maxpool, dim3(blocks), dim3(256), 0, s, in, ldin, cin_off, B, H, W, C, k, st, pd, out, ldout, cout_off, Ho, Wo);

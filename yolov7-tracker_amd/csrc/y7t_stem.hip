@@ -13,6 +13,7 @@
 // ds_read_b128 for a 32-byte payload.  The patch of tile t+1 is fetched (global loads in flight) while tile t is multiplied and stored.
 #include "y7t_common.h"
 #include "y7t_conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -59,7 +60,9 @@ __device__ __forceinline__ void lb_pixel(const StemArgs& p, int b, int y, int x,
     }
 }
 
-template <bool RESIZE>
+// LINES: the epilogue transposes a wave's 32 pixels x 64 channels through 4 KiB of its own LDS and stores full 128-byte lines (8 pixels per instruction) instead of four
+// 32-byte pieces per pixel straight from the registers
+template <bool RESIZE, bool LINES>
 __global__ void __launch_bounds__(256, 2) k_stem_u8(const StemArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];      // two patches
@@ -205,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) k_stem_u8(const StemArgs p) {
                 const int gy = tyi * TS + (wave * 2 + j) * 2 + (l31 >> 4), gx = txi * TS + (l31 & 15);
                 const bool okp = gy < Hr && gx < Wr;
                 half_t* orow = p.out + ((size_t)(b * Hr + gy) * Wr + gx) * p.ldout + p.cout_off;
+                char* scr = smem + 2 * PATCH_BYTES + wave * 4096;      // (LINES) this wave's 32 pixels x 128 bytes, slot = chunk ^ (pixel & 7)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -226,8 +230,19 @@ __global__ void __launch_bounds__(256, 2) k_stem_u8(const StemArgs p) {
                         typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
                         const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
                         const int nn = i * 32 + 8 * (gp * 2 + hi32);          // first of this lane's 8 channels
-                        if (okp) *(uint4v*)(orow + nn) = pk;
+                        if (LINES) *(uint4v*)(scr + l31 * 128 + (((nn >> 3) ^ (l31 & 7)) << 4)) = pk;
+                        else if (okp) *(uint4v*)(orow + nn) = pk;
                     }
+                if (LINES) {      // wave-private: LDS instructions of one wave execute in order
+                    typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int px = k * 8 + (lane >> 3), ch = lane & 7;
+                        const uint4v v4 = *(const uint4v*)(scr + px * 128 + ((ch ^ (px & 7)) << 4));
+                        const int py = tyi * TS + (wave * 2 + j) * 2 + (px >> 4), pxx = txi * TS + (px & 15);
+                        if (py < Hr && pxx < Wr) *(uint4v*)(p.out + ((size_t)(b * Hr + py) * Wr + pxx) * p.ldout + p.cout_off + ch * 8) = v4;
+                    }
+                }
             }
         });
         // the next tile's patch goes into the other buffer; one barrier per tile (the buffer being overwritten was last read a tile ago)
@@ -253,13 +268,17 @@ int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int 
     const bool resize = !(new_h == H0 && new_w == W0 && (left & 1) == 0 && (W0 & 1) == 0 && W0 >= 2);   // (odd geometry: the generic sampler)
     int grid = a.n_tiles < 2048 ? a.n_tiles : 2048;
     static bool attr = false;
+    constexpr int LDSL = 2 * PATCH_BYTES + 4 * 4096;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSL));
         attr = true;
     }
-    if (resize) hipLaunchKernelGGL(k_stem_u8<true>, dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
-    else hipLaunchKernelGGL(k_stem_u8<false>, dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
+    static const int lines = []() { const char* e = getenv("Y7T_STEM_LINES"); return e ? atoi(e) : 0; }();      // experiment: full-line stores through LDS
+    if (resize) hipLaunchKernelGGL((k_stem_u8<true, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
+    else if (lines) hipLaunchKernelGGL((k_stem_u8<false, true>), dim3(grid), dim3(256), LDSL, s, a);
+    else hipLaunchKernelGGL((k_stem_u8<false, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("stem_u8<%s>", resize ? "letterbox-resize" : "direct");
     return 0;
