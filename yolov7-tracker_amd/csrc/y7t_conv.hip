@@ -604,8 +604,9 @@ static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
         // stride-2 3x3 on the large maps: 256-pixel tiles with 32-deep stages measured 5-7 % ahead (profiles/r01_conv_variants.txt)
         if (a.stride == 2 && big256) return wide ? launch_conv<256, 128, 32, 2>(a, s) : launch_conv<256, 64, 32, 2>(a, s);
         // small maps whose 128-channel tiles do not fill the chip but whose 64-channel tiles do (the 20 x 20 256-channel 3x3 layers at 32 frames: 200 vs 400 tiles):
-        // twice the workgroups instead of split-K partial sums + a reduce launch (Y7T_CONV_NARROW=0: the split-K path)
-        static const int narrow = []() { const char* e = getenv("Y7T_CONV_NARROW"); return e ? atoi(e) : 0; }();
+        // twice the workgroups instead of split-K partial sums + a reduce launch: 229 -> 191 us for those four launches (profiles/r04_small_experiments.txt;
+        // Y7T_CONV_NARROW=0: the split-K path)
+        static const int narrow = []() { const char* e = getenv("Y7T_CONV_NARROW"); return e ? atoi(e) : 1; }();
         const int tm = (a.M + 127) / 128;
         if (narrow && wide && tm * (a.Cout_pad / 128) < 256 && tm * (a.Cout_pad / 64) >= 256) return launch_conv<128, 64, 64, 2>(a, s);
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);

@@ -275,7 +275,7 @@ int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int 
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSL));
         attr = true;
     }
-    static const int lines = []() { const char* e = getenv("Y7T_STEM_LINES"); return e ? atoi(e) : 0; }();      // experiment: full-line stores through LDS
+    static const int lines = []() { const char* e = getenv("Y7T_STEM_LINES"); return e ? atoi(e) : 1; }();      // full-line stores through LDS: 597 -> 546 us at 32 frames (profiles/r04_small_experiments.txt); 0 = straight from the registers
     if (resize) hipLaunchKernelGGL((k_stem_u8<true, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
     else if (lines) hipLaunchKernelGGL((k_stem_u8<false, true>), dim3(grid), dim3(256), LDSL, s, a);
     else hipLaunchKernelGGL((k_stem_u8<false, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
