@@ -178,7 +178,8 @@ typedef struct y7t_op {
     int32_t korder;                     /* weight packing: 0 k = (kh*KW+kw)*Cin + ci; 1 (kh, 64-ch chunk, kw); 2 LDS-patch panels; 3 1x1 panels;
                                            4 stride-2 LDS-patch panels (detector/weights.py::panel_pack_s2); 5 the 64 -> 64 filter bank as MFMA A-fragments
                                            (weights-stationary kernel, pack_ws); 7 1x1 layers with Cout % 256 == 0: per (channel tile, 64-deep K-tile) the swizzled LDS image of the 256 x 64 panel
-                                           (csrc/y7t_conv_p8.hip, weights.py::panel_pack_p8) */
+                                           (csrc/y7t_conv_p8.hip, weights.py::panel_pack_p8); 8 the 64 -> 128 3x3 / stride 2 filter bank as MFMA A-fragments
+                                           (csrc/y7t_conv_ws_s2.hip, pack_ws_s2) */
     int32_t detect_level;               /* -1: ordinary layer.  l >= 0: the 1x1 conv of Detect level l (models/yolo.py:46); in a fused forward
                                            (y7t_det_forward_fused) its epilogue decodes + filters instead of writing the head tensor */
     int64_t w_off;                      /* element offset into the fp16 weight blob */

@@ -125,6 +125,20 @@ for n in ("stemlines", "narrow", "poolgeneric", "default2"):
 PY
   ;;
 
+exp_ws_s2)
+  say "exp_ws_s2 a: the stride-2 weights-stationary kernel for the 640^2 64 -> 128 layer (csrc/y7t_conv_ws_s2.hip): layer parity vs torch fp32, then inside the benchmarked list"
+  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "stride2_weights_stationary" > $O/t_ws_s2.log 2>&1; echo "rc=$?" >> $O/t_ws_s2.log; tailsum $O/t_ws_s2.log 3
+  timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_ws_s2_pinned.log 2>&1; echo "rc=$?" >> $O/t_ws_s2_pinned.log; tailsum $O/t_ws_s2_pinned.log 3
+  say "exp_ws_s2 b: the layer alone at 32 frames: generic kernel (Y7T_CONV_WS_S2=0) vs ws_s2, with 256 / 248 / 512 workgroups"
+  for v in "Y7T_CONV_WS_S2=0" "X=1" "Y7T_CONV_WS_WGS=248" "Y7T_CONV_WS_WGS=512"; do echo "-- $v: $(env $v ONLY=640,64,128,3,2 timeout 120 python scripts/bench_conv.py 32 50 2>&1 | grep ' 3/2 ' | cut -c1-70)"; done | tee -a $O/summary.txt
+  say "exp_ws_s2 c: bench lines: with, without (Y7T_CONV_WS_S2=0), with"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  timeout 300 python bench.py $X > $O/bench_ws2.json 2> $O/bench_ws2.err
+  Y7T_CONV_WS_S2=0 timeout 300 python bench.py $X > $O/bench_nows2.json 2> $O/bench_nows2.err
+  timeout 300 python bench.py $X > $O/bench_ws2b.json 2> $O/bench_ws2b.err
+  benchsum ws2 nows2 ws2b
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

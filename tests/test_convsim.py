@@ -34,6 +34,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder == 7:      # the 256 x 64 panels of the ping-pong 1x1 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_p8(blk)
+    if korder == 8:      # register-fragment order of the stride-2 weights-stationary kernel
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws_s2(blk)
     return blk
 
 
@@ -43,7 +46,7 @@ def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    cp = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
+    cp = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 8) else (Cout + 127) // 128 * 128
     wp = pack_w(Wt, Cin, cp, korder)
     bp = np.zeros(cp, np.float32)
     bp[:Cout] = bias
@@ -174,6 +177,47 @@ def test_pingpong_1x1_upsample_on_read_on_the_host(lat_first, deferred):
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(Wt.astype(np.float16).astype(np.float32)), torch.from_numpy(bias))
     ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(out.astype(np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
+# the stride-2 weights-stationary kernel for the 64 -> 128 down-sampling layer (csrc/y7t_conv_ws_s2.hip, korder 8): B, H, W, act, extras.  2 x 32 output tiles; the host
+# model's three workgroups walk ranges of them through the three-buffer patch ring; both DMA landing times, as for the ping-pong kernel
+WS_S2_CASES = [
+    (1, 4, 64, 1, {}),                                                                  # one tile
+    (1, 12, 64, 1, {}),                                                                 # three tiles, one per workgroup: top / middle / bottom rows
+    (2, 8, 128, 2, {"in_ld": 128, "in_coff": 64, "out_ld": 256, "out_coff": 128}),      # 2 images x 2 x 2 tiles = 8 tiles on 3 workgroups (the ring wraps), slices, LeakyReLU
+    (1, 20, 192, 0, {}),                                                                # 5 x 3 = 15 tiles: left / interior / right columns, no activation
+]
+
+
+@pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
+@pytest.mark.parametrize("case", WS_S2_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
+def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred):
+    B, H, W, act, kw = case
+    L = cs.lib()
+    L.cs_set_dma_deferred(deferred)
+    try:
+        name = run_case(L, B, H, W, 64, 128, 3, 2, act, 0, korder=8, seed=B * 1000 + H + W, **kw)
+    finally:
+        L.cs_set_dma_deferred(0)
+    assert name == "ws_s2<2,32>", name
+
+
+def test_stride2_weights_stationary_fragment_reads_are_bank_conflict_free_and_packing():
+    """144-byte pixels: the 16 lanes of a ds_read_b128 service group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) are 16 columns of ONE patch row -> 16 different
+    16-byte bank quads for every tap plane and k-substep; and korder 8 is the documented permutation"""
+    from yolov7_tracker_amd.detector import weights
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for hi in (0, 1):
+        for g in groups:
+            for plane in (0, 33 * 144, 144):
+                for ks in range(4):
+                    assert len({((l * 144 + hi * 16 + plane + ks * 32) // 16) % 16 for l in g}) == 16
+    blk = np.random.default_rng(4).permutation(128 * 576).astype(np.float64).reshape(128, 576)
+    out = weights.pack_ws_s2(blk).ravel()
+    assert np.array_equal(np.sort(out), np.sort(blk.ravel()))
+    for tap, ks, q, lane in ((0, 0, 0, 0), (8, 3, 3, 63), (4, 2, 1, 37), (7, 1, 2, 5)):
+        f = (tap * 4 + ks) * 4 + q
+        assert np.array_equal(out[(f * 64 + lane) * 8:(f * 64 + lane) * 8 + 8], blk[q * 32 + lane % 32, tap * 64 + ks * 16 + 8 * (lane // 32):][:8])
 
 
 def test_pingpong_panel_packing_is_the_documented_lds_image():

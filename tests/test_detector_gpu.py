@@ -46,6 +46,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 7:   # 256 x 64 panels of the ping-pong 1x1 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_p8(blk)
+    if korder == 8:   # register-fragment order of the stride-2 weights-stationary kernel
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws_s2(blk)
     return blk
 
 
@@ -100,8 +103,8 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
-    cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder != 4 else (Cout + 127) // 128 * 128
+    korder = 8 if act & 65536 else 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 8) else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful
@@ -147,6 +150,25 @@ def test_weights_stationary_kernel_matches_torch_fp32(L, case):
     from yolov7_tracker_amd import _lib
     test_conv_layer_matches_torch_fp32(L, case)
     assert L.y7t_last_kernel().decode() == "ws64<16,16>"
+
+
+# csrc/y7t_conv_ws_s2.hip: the 64 -> 128 3x3 / stride 2 layer with the filter bank resident in registers, a persistent workgroup per compute unit walking 2 x 32 output
+# tiles through a three-buffer patch ring (act bit 16: korder 8).  Shapes: fewer tiles than compute units, thousands of tiles (uneven ranges, the ring wraps), slices of
+# wider buffers, the activations, and the benchmarked layer itself (640 x 640 -> 320 x 320, 8 frames).
+WS_S2_CASES = [
+    # B, H, W, Cin, Cout, k, s, act (bit 16), in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 4, 64, 64, 128, 3, 2, 1 | 65536, 64, 0, 128, 0, 0),
+    (1, 96, 192, 64, 128, 3, 2, 1 | 65536, 64, 0, 128, 0, 0),
+    (3, 160, 320, 64, 128, 3, 2, 2 | 65536, 128, 64, 256, 128, 0),
+    (5, 100, 128, 64, 128, 3, 2, 0 | 65536, 64, 0, 128, 0, 0),
+    (8, 640, 640, 64, 128, 3, 2, 1 | 65536, 64, 0, 128, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS_S2_CASES)
+def test_stride2_weights_stationary_kernel_matches_torch_fp32(L, case):
+    test_conv_layer_matches_torch_fp32(L, case)
+    assert L.y7t_last_kernel().decode() == "ws_s2<2,32>"
 
 
 # csrc/y7t_conv_p8.hip: the 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline (act bit 15: korder 7).  Shapes: one K-tile (prologue + tail only), odd and

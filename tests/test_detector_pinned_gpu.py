@@ -99,7 +99,10 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     assert fam["patch"] >= 10 and (fam["patch_mt"] >= 4 or fam["ws64"] == 7) and fam["patch_strip"] >= 8, fam
     # the stride-2 patch kernel where it measured faster than the generic kernel (four of the eight down-sampling layers; detector/graph.py::patch_s2_eligible)
     assert fam["patch_s2"] == {"auto": 4, "0": 0, "1": 8}[os.environ.get("Y7T_CONV_PATCH_S2", "auto")], fam
-    assert any(n.startswith("igemm<256,") for n in names) or os.environ.get("Y7T_CONV_PATCH_S2") == "1", hist     # 256-pixel tiles (the 640^2 stride-2 layer)
+    if os.environ.get("Y7T_CONV_WS_S2", "1") != "0":
+        assert names[1] == "ws_s2<2,32>", names[1]                       # the 640^2 64 -> 128 stride-2 layer: filter bank in registers
+    else:
+        assert any(n.startswith("igemm<256,") for n in names) or os.environ.get("Y7T_CONV_PATCH_S2") == "1", hist     # 256-pixel tiles
     if os.environ.get("Y7T_CONV_WS", "1") != "0":                        # the 64 -> 64 layers with the filter bank in registers
         assert fam["ws64"] == 7 and fam["patch_mt"] == 0, fam
     if os.environ.get("Y7T_CONV_P8", "1") not in ("0", "all"):           # the five deep 1x1 layers (Cin >= 1024, or 512 on >= 3000 tiles) where the 256 x 256 x 64 ping-pong pipeline measured faster

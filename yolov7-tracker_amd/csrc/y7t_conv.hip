@@ -554,9 +554,11 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
 int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_ws.hip (korder 5: 64 -> 64 3x3 layers, weights stationary in registers)
+int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s);      // y7t_conv_ws_s2.hip (korder 8: the 64 -> 128 3x3 / stride 2 layer, weights stationary in registers)
 int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_p8.hip (korder 7: 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline)
 
 static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+    if (a.korder == 8) return y7t_conv_ws_s2_launch(a, s);      // stride-2 register-fragment order: only that kernel reads it
     if (a.korder == 7) return y7t_conv_p8_launch(a, s);         // 256 x 64 weight panels: only that kernel reads them (plain and upsample-on-read)
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
         const bool fast = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24) &&

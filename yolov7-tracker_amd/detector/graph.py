@@ -180,6 +180,16 @@ def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_c
             and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
+def ws_s2_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
+    """mirror of y7t_conv_ws_s2_launch (csrc/y7t_conv_ws_s2.hip): the 64 -> 128 3x3 / stride 2 layer (the first down-sampling conv of yolov7-w6) with its filter bank in
+    registers and a persistent workgroup per compute unit; needs enough 2 x 32 output tiles to give every compute unit a few.  Y7T_CONV_WS_S2=0 switches it off."""
+    if os.environ.get("Y7T_CONV_WS_S2", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+        return False
+    Ho, Wo = H // 2, W // 2
+    return (k == 3 and s == 2 and p == 1 and cin == 64 and cout == 128 and H % 2 == 0 and W % 2 == 0 and Ho % 2 == 0 and Wo % 32 == 0 and not out_f32
+            and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and B * (Ho // 2) * (Wo // 32) >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
+
+
 def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20, up=None, detect=False):
     """mirror of y7t_conv_p8_launch (csrc/y7t_conv_p8.hip): 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline -- WHERE IT MEASURED FASTER than
     igemm<128,128,32,2> on two boxes (profiles/r04_p8_measurements.txt): deep reductions (Cin >= 1024: 16+ K-tiles amortise the tile's ~8 us of prologue / epilogue /
@@ -316,6 +326,8 @@ def lower(nodes, H, W, max_batch=1):
         korder = int(n.k == 3 and cin % 64 == 0)     # (kh, 64-channel chunk, kw) K order: consecutive K-steps reuse input lines
         if ws_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
             korder = 5                               # weights-stationary kernel: the filter bank as MFMA A-fragments (weights.pack_ws)
+        elif ws_s2_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
+            korder = 8                               # ... and its stride-2 sibling for the 64 -> 128 down-sampling layer (weights.pack_ws_s2)
         elif patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
         elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch * n.h * n.w):

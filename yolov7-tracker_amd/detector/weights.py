@@ -190,6 +190,15 @@ def pack_ws(blk):
     return np.ascontiguousarray(a).reshape(64, 576)
 
 
+def pack_ws_s2(blk):
+    """[128][576] block of the 64 -> 128 3x3 / stride 2 layer with k = (kh*3 + kw)*64 + ci  ->  the register-fragment order of csrc/y7t_conv_ws_s2.hip (korder 8):
+    fragment f = (tap * 4 + ks) * 4 + q is 1 KiB = 64 lanes x 8 halves, lane l holding W[q*32 + l % 32][tap][ks*16 + 8*(l // 32) .. +7] (wave q keeps channels 32 q .. + 31)."""
+    assert blk.shape == (128, 576)
+    a = blk.reshape(4, 32, 9, 4, 2, 8)          # [q][l31][tap][ks][hi][8]
+    a = a.transpose(2, 3, 0, 4, 1, 5)           # [tap][ks][q][hi][l31][8]   (lane = hi * 32 + l31)
+    return np.ascontiguousarray(a).reshape(128, 576)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -215,6 +224,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = pack_ws(blk)
         elif w.get("korder") == 7:
             blk = panel_pack_p8(blk)
+        elif w.get("korder") == 8:
+            blk = pack_ws_s2(blk)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
