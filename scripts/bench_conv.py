@@ -30,11 +30,11 @@ for key, cnt in shapes.items():
     b = torch.randn(Cout_pad, device="cuda")
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
     # `act` bits of y7t_conv2d_nhwc_f16 = the weight packing the plan would give this layer (the weights are random: only the kernel choice matters here)
-    if graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
+    if graph.ws_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 65536      # the 64 -> 128 stride-2 layer, weights stationary (Y7T_CONV_WS_S2=0: off)
+    elif graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
     elif graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = 1 | 1024
     elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32, B * Ho * Wo): code = 1 | 4096          # stride-2 patch kernel where it measured faster
     elif k == 3 and Cin % 64 == 0: code = 1 | (KORDER << 8)
-    elif graph.ws_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 65536      # the 64 -> 128 stride-2 layer, weights stationary (Y7T_CONV_WS_S2=0: off)
     elif graph.p8_eligible(H, W, Cin, Cout, k, s, out_ld, 0, f32, in_ld, 0, B): code = 1 | 32768            # 1x1, Cout % 256 == 0: the 256 x 256 x 64 ping-pong pipeline (Y7T_CONV_P8=0: off)
     elif k == 1 and Cin % 32 == 0 and KORDER and os.environ.get('Y7T_CONV_WPANEL', '1') != '0': code = 1 | 2048
     else: code = 1

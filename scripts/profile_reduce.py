@@ -8,7 +8,7 @@ try:
     META = json.loads([l for l in open(out + "/forward_only.log") if l.startswith("{")][-1])
 except Exception:
     META = {}
-FWD = ("k_conv", "k_stem", "k_splitk", "k_maxpool", "k_upsample")
+FWD = ("k_conv", "k_stem", "k_splitk", "k_maxpool", "k_upsample", "k_spp3")
 def last_forward(d, n_fwd):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     if not f: return None
@@ -63,8 +63,16 @@ try:
     # map dispatches to ops: a split-K conv is followed by its reduce
     it = iter(zip(last, dur))
     lines, tot_us, tot_gf = [], 0.0, 0.0
+    spp_skip = 0
     for op in meta["ops"]:
+        if spp_skip:                      # the second and third pool of an SPP cascade ran inside the first one's launch (k_spp3_lds)
+            spp_skip -= 1
+            lines.append("%3d %-44s %4dx%-4d %4d->%-4d %d/%d %9s    (in the launch of the row above)" % (op["op"], op["kernel"], op["H"], op["W"], op["Cin"], op["Cout"], op["k"], op["s"], "-"))
+            continue
         r, d = next(it)
+        if "k_spp3" in r["Kernel_Name"]:
+            spp_skip = 2
+            op = dict(op, kernel="spp3<5,5,5> lds")
         if "splitK" in op["kernel"]:
             r2, d2 = next(it); d += d2
         gf, by = op.get("gflop", 0.0), op.get("bytes", 0)

@@ -56,6 +56,7 @@ int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int 
                        const float* bias, _Float16* out, int ldout, int cout_off, int act, hipStream_t s);
 
 int y7t_upsample_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, _Float16* out, int ldout, int cout_off, hipStream_t s);
+int y7t_spp3_try(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, _Float16* out, int ldout, int cout_off, hipStream_t s);   // 0 done, 1 not applicable
 int y7t_maxpool_launch(const _Float16* in, int ldin, int cin_off, int B, int H, int W, int C, int k, int st, int pd, _Float16* out, int ldout,
                        int cout_off, hipStream_t s);
 

@@ -106,8 +106,20 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
             rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
         } else {
-            rc = y7t_maxpool_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, op.KH, op.stride, op.pad, (_Float16*)outp, op.out_ld,
-                                    op.out_coff, s);
+            // SPPCSPC (models/common.py:262-280): three 5 x 5 / 1 pools in cascade, each reading its predecessor's slice and writing the next slice of the same concat
+            // buffer -> one launch that keeps the slab in LDS (when the whole chain is inside the requested op range)
+            auto chained = [&](const y7t_op& a, const y7t_op& b2) {
+                return b2.type == Y7T_OP_MAXPOOL && b2.KH == 5 && b2.stride == 1 && b2.pad == 2 && b2.H == a.H && b2.W == a.W && b2.Cin == a.Cin && b2.in_buf == a.out_buf &&
+                       b2.in_ld == a.out_ld && b2.in_coff == a.out_coff && b2.out_buf == a.out_buf && b2.out_ld == a.out_ld && b2.out_coff == a.out_coff + a.Cin;
+            };
+            rc = 1;
+            if (op.KH == 5 && op.stride == 1 && op.pad == 2 && oi + 2 < last && chained(op, d->ops[oi + 1]) && chained(d->ops[oi + 1], d->ops[oi + 2]) &&
+                (op.in_buf != op.out_buf || op.in_coff + op.Cin <= op.out_coff || op.out_coff + 3 * op.Cin <= op.in_coff))
+                rc = y7t_spp3_try(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
+            if (rc == 0) oi += 2;
+            else if (rc == 1)
+                rc = y7t_maxpool_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, op.KH, op.stride, op.pad, (_Float16*)outp, op.out_ld,
+                                        op.out_coff, s);
         }
         if (rc) return rc;
     }

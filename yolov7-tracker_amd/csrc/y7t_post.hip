@@ -207,6 +207,56 @@ __global__ void __launch_bounds__(256) k_maxpool_s1_lds(const half_t* __restrict
     }
 }
 
+// ... and the whole SPPCSPC cascade 5 o 5 o 5 (= the 5 / 9 / 13 pools of models/common.py:262-280) in ONE launch: the slab stays in LDS between the three pools, each
+// result goes to its own channel slice (out + k * C channels further for pool k of the cascade: the three results are consecutive slices of the concat buffer).
+__global__ void __launch_bounds__(256) k_spp3_lds(const half_t* __restrict__ in, int ldin, int cin_off, int H, int W, int C, half_t* __restrict__ out, int ldout, int cout_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* A = (half8*)smem;
+    const int HW = H * W, n = HW * 2, C16 = C / 16;
+    half8* R = A + n;
+    const int b = blockIdx.x / C16, cg = blockIdx.x - b * C16;
+    const size_t ibase = (size_t)b * HW * ldin + cin_off + cg * 16, obase = (size_t)b * HW * ldout + cout_off + cg * 16;
+    for (int i = threadIdx.x; i < n; i += 256) A[i] = *(const half8*)(in + ibase + (size_t)(i >> 1) * ldin + (i & 1) * 8);
+    __syncthreads();
+    for (int pool = 0; pool < 3; ++pool) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int px = i >> 1, y = px / W, x = px - y * W;
+            const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= W ? W - 1 : x + 2;
+            half8 m = A[(y * W + x0) * 2 + (i & 1)];
+            for (int xx = x0 + 1; xx <= x1; ++xx) {
+                const half8 v = A[(y * W + xx) * 2 + (i & 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = m[e] > v[e] ? m[e] : v[e];
+            }
+            R[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int px = i >> 1, y = px / W, x = px - y * W;
+            const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= H ? H - 1 : y + 2;
+            half8 m = R[(y0 * W + x) * 2 + (i & 1)];
+            for (int yy = y0 + 1; yy <= y1; ++yy) {
+                const half8 v = R[(yy * W + x) * 2 + (i & 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = m[e] > v[e] ? m[e] : v[e];
+            }
+            A[i] = m;      // (every thread rewrites exactly the entries it read nothing else of: its own i; the row pass of the next pool starts behind the barrier)
+            *(half8*)(out + obase + (size_t)pool * C + (size_t)px * ldout + (i & 1) * 8) = m;
+        }
+        __syncthreads();
+    }
+}
+
+// the three cascaded 5 x 5 / 1 pools of an SPP block as one launch; 1 if it cannot run this shape (the caller launches them one by one)
+int y7t_spp3_try(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, half_t* out, int ldout, int cout_off, hipStream_t s) {
+    static const int on = []() { const char* e = getenv("Y7T_SPP3"); return e ? atoi(e) : 1; }();
+    if (!on || C % 16 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8 || H * W > 1024) return 1;
+    hipLaunchKernelGGL(k_spp3_lds, dim3(B * (C / 16)), dim3(256), (size_t)H * W * 64, s, in, ldin, cin_off, H, W, C, out, ldout, cout_off);
+    Y7T_LAUNCH_CHECK();
+    y7t_note_kernel("spp3<5,5,5> lds");
+    return 0;
+}
+
 int y7t_upsample_launch(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, half_t* out, int ldout, int cout_off, hipStream_t s) {
     if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("upsample: channel alignment"); return Y7T_E_ARG; }
     const long long tot = (long long)B * 4 * H * W * (C / 8);
