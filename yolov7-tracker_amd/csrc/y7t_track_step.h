@@ -250,7 +250,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                                                         //  rows + columns, which never come here: na * nb >= Y7T_SPARSE_MIN)
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
     // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
-    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 7 * nb + 16) * sizeof(int);
     const size_t list_bytes = (size_t)na * MC * (sizeof(int) + sizeof(double));
     const size_t T = (size_t)s.h->cfg.cap_t, D = (size_t)s.h->cfg.cap_d, blob_bytes = T * (T > D ? T : D) * sizeof(double);
     char* wbase = (char*)s.cost;
@@ -272,7 +272,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [4] overflow / at-limit pair, changed, duplicate cost inside a component, column-list allocator
+    int* flag = nextcol + nb;                                 // [16] overflow / at-limit pair, changed, duplicate cost inside a component, column-list allocator
+    int* cls = flag + 16;                                     // [nb] column lists of the large components (step 4a)
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
@@ -345,8 +346,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         y7t_sync(ex);
     }
     Y7T_SPROF(4);
-    // ---- 4a. LARGE components (more than Y7T_COOP_MIN rows: the crowd of a 500-object frame is one component of a few hundred rows, and one lane walking it
-    // serially was 40 % of that frame's step, profiles/r03_tracker_phases.txt): one WAVE per component.  The same shortest-augmenting-path loop, rows in ascending
+    // ---- 4a. LARGE components (more than Y7T_COOP_MIN rows).  A 500-object frame has ~200 components; all but one to three have <= 8 rows, the largest 10-20 -- and
+    // that one, walked serially by ONE lane (rows x searches x candidates of dependent LDS reads), was the critical path of the frame's association: 890 of the
+    // step's 2217 kcycles (profiles/r03_tracker_phases.txt).  So: one WAVE per large component.  The same shortest-augmenting-path loop, rows in ascending
     // order, but the frontier minimum runs over the component's column list a lane per column (lexicographic (distance, column) minimum by a wave reduction: the
     // serial loop's "ties to the lowest column index"), a row's candidates are relaxed a lane per candidate, prices and marks are updated a lane per column.  Every
     // lane of the wave executes the same control flow on the same scalars; the work arrays must sit in the workgroup's LDS (a wave's LDS accesses execute in
@@ -357,6 +359,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #endif
     int* csz = nextrow;                                        // [na] rows of the component led by row i
     bool coop = false;
+    int cw = 0;                                                // waves busy with large components (device); they skip 4b
 #ifndef Y7T_COOP_MIN
 #define Y7T_COOP_MIN 8
 #endif
@@ -373,16 +376,22 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #else
         coop = nbig > 0 && nbig <= nb;
 #endif
-        if (coop) {
+        // the large components go to the first `cw` waves (at most half of them), the others start on the small ones (4b) at once: the frame's critical path
+        // is its largest component either way -- serial on one lane it was ~20 rows x 20 searches of dependent LDS reads (890 of 2217 kcycles at 500 objects)
 #if Y7T_DEVICE
-            const int WL = 64, lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+        const int WL = 64, lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+        coop = coop && nwv >= 2;
+        cw = coop ? (nbig < nwv / 2 ? nbig : nwv / 2) : 0;
 #else
-            const int WL = 1, lane = 0, wv = 0, nwv = 1;
+        const int WL = 1, lane = 0, wv = 0, nwv = 1;
+        cw = coop ? 1 : 0;
 #endif
-            for (int bi = wv; bi < nbig; bi += nwv) {
+        (void)nwv;
+        if (coop && wv < cw) {
+            for (int bi = wv; bi < nbig; bi += cw) {
                 const int lead = big[bi];
                 Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
-                // the component's columns, compacted into a segment of nextcol[] (components partition the columns: the segments add up to <= nb)
+                // the component's columns, compacted into a segment of cls[] (components partition the columns: the segments add up to <= nb) -- its own array: the other waves use nextcol[] for the small components meanwhile)
                 int ncl = 0;
 #if Y7T_DEVICE
                 for (int base = 0; base < nb; base += WL) {
@@ -392,7 +401,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 int seg = 0;
                 if (lane == 0) seg = Y7T_FETCH_ADD(flag + 3, ncl);
                 seg = __builtin_amdgcn_readfirstlane(seg);
-                int* cl = nextcol + seg;
+                int* cl = cls + seg;
                 {
                     int pos = 0;
                     for (int base = 0; base < nb; base += WL) {
@@ -404,7 +413,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     }
                 }
 #else
-                int* cl = nextcol + flag[3];
+                int* cl = cls + flag[3];
                 for (int j = 0; j < nb; ++j) if (collab[j] == lead) cl[ncl++] = j;
                 flag[3] += ncl;
 #endif
@@ -467,10 +476,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 }
             }
         }
-        y7t_sync(ex);
+#if !Y7T_DEVICE
+        cw = 0;                                                  // (one thread: it goes on to the small components itself)
+#endif
     }
     // ---- 4b. one lane per (remaining) component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
-    for (int lead = tid; lead < na; lead += nt) {
+    for (int lead = tid - cw * 64; lead < na && tid >= cw * 64; lead += nt - cw * 64) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
         if (coop && csz[lead] > Y7T_COOP_MIN) continue;
         {   // tie watch: two candidate edges of this component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
@@ -544,7 +555,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 
 template <class ColFn, class CostFn>
 Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
-    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 7 * nb + 16) * sizeof(int);
     int mc = Y7T_MAXC;
     if (ex.fast && work_bytes + 64 <= ex.fast_bytes)
         while (mc > 8 && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc -= 4;      // 24, 20, 16, 12, 8
