@@ -836,7 +836,7 @@ def main():
     gflop_frame = det.gflop_per_frame
     conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
     traffic, traffic_meta = None, {}
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
     if tpath:      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed WITH the launch list they were taken on
         traffic_meta = json.load(open(tpath))
     if rank == 0:
@@ -864,8 +864,9 @@ def main():
                          "sustained_peak_note": "register-only v_mfma_f32_32x32x16_f16 loop with random operands (power-limited clock; "
                                                 "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
                          "traffic_note": None,
-                         "kernel": "k_conv_igemm<BM,BN,BK,NST> + k_conv3x3_patch<TW,TH,BN> (the conv launch list of one forward: 107 convs in 96 launches; "
-                                   "nearest-x2 upsamples folded into their consumers' loaders, Detect decode + candidate filter in the Detect convs' epilogues)",
+                         "kernel": "the conv launch list of one forward (107 convs in 96 launches + 1 pool launch: k_stem_u8, k_conv3x3s2_c64_ws, k_conv3x3_c64_ws, k_conv3x3_patch*, "
+                                   "k_conv3x3s2_patch, k_conv1x1_p8, k_conv_igemm, k_spp3_lds; nearest-x2 upsamples folded into their consumers' loaders, Detect decode + "
+                                   "candidate filter in the Detect convs' epilogues)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
                          "launch_list_ms": round(float(np.mean(fwd_ms)), 3)},
             "phases_ms_per_step": {"detector_forward": round(float(np.mean(fwd_ms)), 3), "decode_nms": round(float(np.mean(nms_ms)), 3),

@@ -139,18 +139,6 @@ exp_ws_s2)
   benchsum ws2 nows2 ws2b
   ;;
 
-exp_coop)
-  say "exp_coop a: large connected components of the sparse association solved a wave each (csrc/y7t_track_step.h step 4a): tracker tests on the device (goldens, random scenes, cfg3 at full size vs the oracle)"
-  timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x > $O/t_trk.log 2>&1; echo "rc=$?" >> $O/t_trk.log; tailsum $O/t_trk.log 3
-  say "exp_coop b: frame step alone (scripts/time_tracker.py): latency, kernel time, phase breakdown at 80 / 500 objects"
-  timeout 300 python scripts/time_tracker.py > $O/time_tracker.txt 2>&1; grep -v amdgpu $O/time_tracker.txt | tee -a $O/summary.txt
-  say "exp_coop c: bench lines cfg2 / cfg3"
-  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
-  timeout 300 python bench.py $X > $O/bench_cfg2.json 2> $O/bench_cfg2.err
-  timeout 400 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_latency_mode --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-  benchsum cfg2 cfg3
-  ;;
-
 exp_spp3)
   say "exp_spp3: the three SPPCSPC pools as one launch (k_spp3_lds): whole-network + teacher-forced parity, per-op table"
   timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "whole_network or upsample_on_read" > $O/t_spp3.log 2>&1; echo "rc=$?" >> $O/t_spp3.log; tailsum $O/t_spp3.log 2

@@ -239,11 +239,5 @@ def test_hostsim_cfg3_full_size_botsort_equals_oracle():
     warps = synth.make_warps(300, seq_idx=0)
     from oracle import tracker_np
     want = tracker_np.run("botsort", dets, kalman_format="botsort", warps=warps)
-    L = hs.lib()
-    L.hs_next_stat.argtypes = [ctypes.c_int]
-    before = L.hs_next_stat(2)
     got = hs.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
     util.assert_same_tracks(got, want, "cfg3 full size")
-    # round 4: connected components of more than 8 rows are solved by the wave-cooperative form of the sparse search (y7t_track_step.h step 4a; on the host its lane
-    # loops run serially): this scene must have gone through it, hundreds of times
-    assert L.hs_next_stat(2) - before > 300, L.hs_next_stat(2) - before

@@ -250,7 +250,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                                                         //  rows + columns, which never come here: na * nb >= Y7T_SPARSE_MIN)
     // scratch: the work arrays and, when they fit, the candidate lists live in the workgroup's fast scratch (LDS) -- the per-component
     // solves are chains of dependent reads -- otherwise in the (unused) dense cost matrix of the state blob
-    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 7 * nb + 16) * sizeof(int);
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
     const size_t list_bytes = (size_t)na * MC * (sizeof(int) + sizeof(double));
     const size_t T = (size_t)s.h->cfg.cap_t, D = (size_t)s.h->cfg.cap_d, blob_bytes = T * (T > D ? T : D) * sizeof(double);
     char* wbase = (char*)s.cost;
@@ -272,13 +272,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [16] overflow / at-limit pair, changed, duplicate cost inside a component, column-list allocator
-    int* cls = flag + 16;                                     // [nb] column lists of the large components (step 4a)
+    int* flag = nextcol + nb;                                 // [3] overflow / at-limit pair, changed, duplicate cost inside a component
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; }
     y7t_sync(ex);
     // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix) ----
     {
@@ -346,144 +345,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         y7t_sync(ex);
     }
     Y7T_SPROF(4);
-    // ---- 4a. LARGE components (more than Y7T_COOP_MIN rows).  A 500-object frame has ~200 components; all but one to three have <= 8 rows, the largest 10-20 -- and
-    // that one, walked serially by ONE lane (rows x searches x candidates of dependent LDS reads), was the critical path of the frame's association: 890 of the
-    // step's 2217 kcycles (profiles/r03_tracker_phases.txt).  So: one WAVE per large component.  The same shortest-augmenting-path loop, rows in ascending
-    // order, but the frontier minimum runs over the component's column list a lane per column (lexicographic (distance, column) minimum by a wave reduction: the
-    // serial loop's "ties to the lowest column index"), a row's candidates are relaxed a lane per candidate, prices and marks are updated a lane per column.  Every
-    // lane of the wave executes the same control flow on the same scalars; the work arrays must sit in the workgroup's LDS (a wave's LDS accesses execute in
-    // program order, so what one lane stores the next instruction of any lane reads) -- otherwise, and on the host build (one thread: the loops below degenerate
-    // to the serial algorithm, which is how the goldens exercise this code), the component falls through to 4b.
-#ifndef Y7T_NEXT_STAT
-#define Y7T_NEXT_STAT(k) do { } while (0)
-#endif
-    int* csz = nextrow;                                        // [na] rows of the component led by row i
-    bool coop = false;
-    int cw = 0;                                                // waves busy with large components (device); they skip 4b
-#ifndef Y7T_COOP_MIN
-#define Y7T_COOP_MIN 8
-#endif
-    {
-        for (int i = tid; i < na; i += nt) csz[i] = 0;
-        y7t_sync(ex);
-        for (int i = tid; i < na; i += nt) if (x[i] == -1) Y7T_ATOMIC_ADD(csz + rowlab[i], 1);
-        if (tid == 0) flag[3] = 0;                              // bump allocator of the per-component column lists (segments of nextcol[])
-        y7t_sync(ex);
-        int* big = colcnt;                                       // (colcnt is dead behind the forced decisions)
-        const int nbig = y7t_compact(ex, na, [&](int i) { return x[i] == -1 && rowlab[i] == i && csz[i] > Y7T_COOP_MIN; }, big, 0);
-#if Y7T_DEVICE
-        coop = nbig > 0 && nbig <= nb && wbase == ex.fast && nt >= 64;
-#else
-        coop = nbig > 0 && nbig <= nb;
-#endif
-        // the large components go to the first `cw` waves (at most half of them), the others start on the small ones (4b) at once: the frame's critical path
-        // is its largest component either way -- serial on one lane it was ~20 rows x 20 searches of dependent LDS reads (890 of 2217 kcycles at 500 objects)
-#if Y7T_DEVICE
-        const int WL = 64, lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
-        coop = coop && nwv >= 2;
-        cw = coop ? (nbig < nwv / 2 ? nbig : nwv / 2) : 0;
-#else
-        const int WL = 1, lane = 0, wv = 0, nwv = 1;
-        cw = coop ? 1 : 0;
-#endif
-        (void)nwv;
-        if (coop && wv < cw) {
-            for (int bi = wv; bi < nbig; bi += cw) {
-                const int lead = big[bi];
-                Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
-                // the component's columns, compacted into a segment of cls[] (components partition the columns: the segments add up to <= nb) -- its own array: the other waves use nextcol[] for the small components meanwhile)
-                int ncl = 0;
-#if Y7T_DEVICE
-                for (int base = 0; base < nb; base += WL) {
-                    const int j = base + lane;
-                    ncl += __popcll(__ballot(j < nb && collab[j] == lead));
-                }
-                int seg = 0;
-                if (lane == 0) seg = Y7T_FETCH_ADD(flag + 3, ncl);
-                seg = __builtin_amdgcn_readfirstlane(seg);
-                int* cl = cls + seg;
-                {
-                    int pos = 0;
-                    for (int base = 0; base < nb; base += WL) {
-                        const int j = base + lane;
-                        const bool f = j < nb && collab[j] == lead;
-                        const unsigned long long b = __ballot(f);
-                        if (f) cl[pos + __popcll(b & ((1ull << lane) - 1ull))] = j;
-                        pos += __popcll(b);
-                    }
-                }
-#else
-                int* cl = cls + flag[3];
-                for (int j = 0; j < nb; ++j) if (collab[j] == lead) cl[ncl++] = j;
-                flag[3] += ncl;
-#endif
-                for (int start = lead; start < na; ++start) {
-                    if (rowlab[start] != lead || x[start] != -1) continue;                  // (uniform: every lane reads the same words)
-                    double d_null = 0.0; int pred_null = start;
-                    for (int k = lane; k < rowcnt[start]; k += WL) {
-                        const int j = ccol[(size_t)start * MC + k];
-                        dd[j] = ccost[(size_t)start * MC + k] - thresh - v[j]; pred[j] = start; st[j] = 1;
-                    }
-                    int final_j = -2; double mind = 0.0;
-                    for (;;) {
-                        double mv = HUGE_VAL; int mj = 0x7fffffff;
-                        for (int k = lane; k < ncl; k += WL) {
-                            const int j = cl[k];
-                            if (st[j] == 1 && (dd[j] < mv || (dd[j] == mv && j < mj))) { mv = dd[j]; mj = j; }
-                        }
-#if Y7T_DEVICE
-                        {
-                            const double m = y7t_wave_min_d(mv);
-                            mj = y7t_wave_min_i(mv == m ? mj : 0x7fffffff);
-                            mv = m;
-                        }
-#endif
-                        if (d_null < mv) { mv = d_null; mj = nb; }          // the null column is index nb: a real column at the same distance wins the tie (j < nb), as in 4b
-                        mind = mv;
-                        if (mj == nb || y[mj] < 0) { final_j = mj; break; }
-                        if (lane == 0) st[mj] = 2;
-                        const int i = y[mj];
-                        double cij = 0.0;
-                        bool has = false;
-                        for (int k = lane; k < rowcnt[i]; k += WL) if (ccol[(size_t)i * MC + k] == mj) { cij = ccost[(size_t)i * MC + k]; has = true; }
-#if Y7T_DEVICE
-                        cij = __shfl(cij, __ffsll((long long)__ballot(has)) - 1);      // from the one lane that holds the edge (i, mj) to every lane
-#else
-                        (void)has;
-#endif
-                        const double hh = cij - thresh - v[mj] - mind;
-                        for (int k = lane; k < rowcnt[i]; k += WL) {
-                            const int j = ccol[(size_t)i * MC + k];
-                            if (j == mj || st[j] == 2) continue;
-                            const double cred = ccost[(size_t)i * MC + k] - thresh - v[j] - hh;
-                            if (st[j] == 0) { dd[j] = cred; pred[j] = i; st[j] = 1; }
-                            else if (cred < dd[j]) { dd[j] = cred; pred[j] = i; }
-                        }
-                        if (-hh < d_null) { d_null = -hh; pred_null = i; }
-                    }
-                    for (int k = lane; k < ncl; k += WL) { const int j = cl[k]; if (st[j] == 2) v[j] += dd[j] - mind; }
-                    if (lane == 0) {                                          // augment
-                        int i = -1, j = final_j;
-                        while (i != start) {
-                            i = (j == nb) ? pred_null : pred[j];
-                            if (j != nb) y[j] = i;
-                            const int t = j;
-                            j = x[i];
-                            x[i] = t;
-                        }
-                    }
-                    for (int k = lane; k < ncl; k += WL) st[cl[k]] = 0;
-                }
-            }
-        }
-#if !Y7T_DEVICE
-        cw = 0;                                                  // (one thread: it goes on to the small components itself)
-#endif
-    }
-    // ---- 4b. one lane per (remaining) component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
-    for (int lead = tid - cw * 64; lead < na && tid >= cw * 64; lead += nt - cw * 64) {
+    // ---- 4. one lane per component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
+    for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
-        if (coop && csz[lead] > Y7T_COOP_MIN) continue;
         {   // tie watch: two candidate edges of this component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
             int crow[8], ncr = 0;
             for (int a = lead; a < na && ncr < 9; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
@@ -555,7 +419,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 
 template <class ColFn, class CostFn>
 Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
-    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 7 * nb + 16) * sizeof(int);
+    const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
     int mc = Y7T_MAXC;
     if (ex.fast && work_bytes + 64 <= ex.fast_bytes)
         while (mc > 8 && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc -= 4;      // 24, 20, 16, 12, 8
