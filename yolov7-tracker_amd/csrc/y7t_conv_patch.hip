@@ -196,9 +196,14 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
     // De-phasing: the first 512 workgroups of a launch start together, two per CU, and would run prologue, K loop and epilogue in
     // lock step (exposed read / write bursts, idle matrix pipe).  The second 256 (the second slot of every CU) wait about half a
     // tile once; every later workgroup inherits the shift from the slot it takes over.
+    // (dephase > 0: "the second 256" by launch order; dephase < -1: by the wave slot the hardware gave this wave -- HW_ID[3:0], odd = the CU's second
+    // workgroup -- for -dephase units.  Y7T_CONV_DEPHASE, off by default: an experiment until measured.)
     if (p.dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
 #pragma unroll 1
         for (int z = 0; z < p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
+    } else if (p.dephase < -1 && blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) {
+#pragma unroll 1
+        for (int z = 0; z < -p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
     }
     // the epilogue's biases: fetched now, beside the first DMAs, into an LDS corner no stage ever touches (a global load at the
     // end of a workgroup that lives for a few microseconds is pure exposed latency)
