@@ -139,30 +139,17 @@ exp_ws_s2)
   benchsum ws2 nows2 ws2b
   ;;
 
-exp_ws2pipe)
-  say "exp_ws2pipe a: ws_s2 with the previous tile's epilogue between the current tile's MFMAs (Y7T_WS_S2_PIPE=1): layer parity vs torch fp32, whole network"
-  Y7T_WS_S2_PIPE=1 timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "stride2_weights_stationary" > $O/t_ws2pipe.log 2>&1; echo "rc=$?" >> $O/t_ws2pipe.log; tailsum $O/t_ws2pipe.log 3
-  Y7T_WS_S2_PIPE=1 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_ws2pipe_pinned.log 2>&1; echo "rc=$?" >> $O/t_ws2pipe_pinned.log; tailsum $O/t_ws2pipe_pinned.log 3
-  say "exp_ws2pipe b: per-op tables (the launch list alone), epilogue behind / pipelined / behind"
-  NAME=ws2seq OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_WS_S2_PIPE=1 NAME=ws2pipe OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  NAME=ws2seq2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  grep -h "ws_s2\|TOTAL" $O/per_layer_ws2seq.txt $O/per_layer_ws2pipe.txt $O/per_layer_ws2seq2.txt | cut -c1-120 | tee -a $O/summary.txt
-  say "exp_ws2pipe c: bench lines: behind, pipelined, behind"
-  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
-  timeout 300 python bench.py $X > $O/bench_seq.json 2> $O/bench_seq.err
-  Y7T_WS_S2_PIPE=1 timeout 300 python bench.py $X > $O/bench_pipe.json 2> $O/bench_pipe.err
-  timeout 300 python bench.py $X > $O/bench_seq2.json 2> $O/bench_seq2.err
-  benchsum seq pipe seq2
-  ;;
-
-exp_dephase)
-  say "exp_dephase: the patch kernels' two workgroups per CU started half a tile apart (Y7T_CONV_DEPHASE: n > 0 by launch order, n < -1 by hardware wave slot): per-op tables, same session"
-  for v in 0 4 -4 -8 0; do
-    Y7T_CONV_DEPHASE=$v NAME=dephase_$v OUT=$O bash scripts/per_layer_table.sh | sed "s/^/DEPHASE=$v: /" | tee -a $O/summary.txt
-    cp $O/per_layer_dephase_$v.txt $O/per_layer_dephase_${v}_$(date +%s).txt
-  done
-  for v in 0 4 -4 -8; do echo "DEPHASE=$v patch rows: $(grep 'patch' $O/per_layer_dephase_$v.txt | awk '{for(i=1;i<=NF;i++) if($i=="us") s+=$(i-1)} END {print s}') us" | tee -a $O/summary.txt; done
+exp_smallmap)
+  say "exp_smallmap a: 20x20 3x3 layers on the LDS-patch strip kernel (Y7T_CONV_PATCH_MIN_PIX=20000), 128- or 64-row panels (Y7T_CONV_PATCH_PANEL64_BELOW): layer parity, whole network"
+  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer_matches" > $O/t_smallmap.log 2>&1; echo "rc=$?" >> $O/t_smallmap.log; tailsum $O/t_smallmap.log 3
+  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=256 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_smallmap_pinned.log 2>&1; echo "rc=$?" >> $O/t_smallmap_pinned.log; tailsum $O/t_smallmap_pinned.log 3
+  say "exp_smallmap b: per-op tables: default | MIN_PIX=20000 | + PANEL64_BELOW=150 | + PANEL64_BELOW=256 | default"
+  NAME=sm_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_MIN_PIX=20000 NAME=sm_wide OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=150 NAME=sm_n150 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=256 NAME=sm_n256 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  NAME=sm_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  for n in sm_default sm_wide sm_n150 sm_n256 sm_default2; do echo "-- $n"; grep -E "^ *(31|34|43|86|87|89|94) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
   ;;
 
 exp_spp3)

@@ -55,7 +55,6 @@ void cs_launch(const std::function<void()>& kernel, dim3 grid, dim3 block);
 #define __builtin_amdgcn_s_barrier() cs_wg_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
-#define __builtin_amdgcn_s_getreg(x) 0
 #define __builtin_amdgcn_readfirstlane(x) (x)          /* (only applied to wave-uniform values) */
 #define __threadfence() ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)   /* (workgroups run one after the other here) */

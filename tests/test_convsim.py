@@ -22,9 +22,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
         Wt = Wt.reshape(cout, k, k, cin_pad // 64, 64).transpose(0, 1, 3, 2, 4)
     blk = np.zeros((cout_pad, Kp), np.float16)
     blk[:cout, :K] = Wt.reshape(cout, -1).astype(np.float16)
-    if korder == 2:      # the patch kernel's panel order
+    if korder in (2, 9):      # the patch kernel's panel order (9: 64-row panels although Cout_pad % 128 == 0)
         from yolov7_tracker_amd.detector import weights
-        blk = weights.panel_pack(blk, cin_pad)
+        blk = weights.panel_pack(blk, cin_pad, narrow=korder == 9)
     if korder == 5:      # the weights-stationary kernel's register-fragment order
         from yolov7_tracker_amd.detector import weights
         blk = weights.pack_ws(blk)
@@ -189,13 +189,11 @@ WS_S2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("pipe", [0, 1], ids=["epilogue-behind", "epilogue-pipelined"])
 @pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
 @pytest.mark.parametrize("case", WS_S2_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
-def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred, pipe, monkeypatch):
+def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred):
     B, H, W, act, kw = case
     L = cs.lib()
-    monkeypatch.setenv("Y7T_WS_S2_PIPE", str(pipe))      # (the host build of the launcher reads it at every call)
     L.cs_set_dma_deferred(deferred)
     try:
         name = run_case(L, B, H, W, 64, 128, 3, 2, act, 0, korder=8, seed=B * 1000 + H + W, **kw)
@@ -240,6 +238,8 @@ PATCH_CASES = [
     (1, 37, 53, 64, 128, 1, 2, {"out_ld": 192, "out_coff": 64}),                      # ragged edges, panel-packed weights, output slice
     (2, 40, 40, 64, 128, 1, 2, {}),                                                   # strip tiling of the 40-wide map
     (3, 20, 20, 128, 64, 1, 1, {}),                                                   # strip tiling, 20-wide, 64 channels
+    (2, 20, 20, 64, 128, 1, 9, {}),                                                   # korder 9: 64-row panels on a 128-channel layer, strip tiling
+    (1, 24, 32, 64, 256, 2, 9, {"out_ld": 320, "out_coff": 64}),                      # ... 16x16 tiles, four panels, output slice
 ]
 
 

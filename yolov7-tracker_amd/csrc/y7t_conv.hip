@@ -547,7 +547,6 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     b.splitk = 1; b.ksteps = b.K_pad; b.partial = nullptr;
     { static int to = -1; if (to < 0) { const char* e = getenv("Y7T_CONV_TILE_ORDER"); to = e ? atoi(e) : 1; } b.tile_order = to; }
     { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
-    { static int dp = -2; if (dp == -2) { const char* e = getenv("Y7T_CONV_DEPHASE"); dp = e ? atoi(e) : -1; } b.dephase = dp; }
     return conv_dispatch(b, s);
 }
 
@@ -557,7 +556,9 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv
 int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s);      // y7t_conv_ws_s2.hip (korder 8: the 64 -> 128 3x3 / stride 2 layer, weights stationary in registers)
 int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_p8.hip (korder 7: 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline)
 
-static int conv_dispatch(const Y7TConvArgs& a, hipStream_t s) {
+static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
+    Y7TConvArgs a = a0;
+    if (a.korder == 9) { a.korder = 2; a.panel64 = 1; }          // the patch kernel's panel order with 64-row panels
     if (a.korder == 8) return y7t_conv_ws_s2_launch(a, s);      // stride-2 register-fragment order: only that kernel reads it
     if (a.korder == 7) return y7t_conv_p8_launch(a, s);         // 256 x 64 weight panels: only that kernel reads them (plain and upsample-on-read)
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only

@@ -193,18 +193,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // De-phasing: the first 512 workgroups of a launch start together, two per CU, and would run prologue, K loop and epilogue in
-    // lock step (exposed read / write bursts, idle matrix pipe).  The second 256 (the second slot of every CU) wait about half a
-    // tile once; every later workgroup inherits the shift from the slot it takes over.
-    // (dephase > 0: "the second 256" by launch order; dephase < -1: by the wave slot the hardware gave this wave -- HW_ID[3:0], odd = the CU's second
-    // workgroup -- for -dephase units.  Y7T_CONV_DEPHASE, off by default: an experiment until measured.)
-    if (p.dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-        for (int z = 0; z < p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
-    } else if (p.dephase < -1 && blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) {
-#pragma unroll 1
-        for (int z = 0; z < -p.dephase; ++z) __builtin_amdgcn_s_sleep(64);
-    }
     // the epilogue's biases: fetched now, beside the first DMAs, into an LDS corner no stage ever touches (a global load at the
     // end of a workgroup that lives for a few microseconds is pure exposed latency)
     if (tid < BN) ((float*)(smem + C::BIAS_OFF))[tid] = p.bias[n0 + tid];
@@ -699,7 +687,7 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     };
     const double e16 = eff(16, 16), e32 = eff(32, 8);
     const bool use16 = e16 >= e32;
-    const bool wide = a.Cout_pad % 128 == 0;
+    const bool wide = a.Cout_pad % 128 == 0 && !a.panel64;
     const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
     // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
     if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;

@@ -50,7 +50,7 @@ struct Ws2 {
     static constexpr unsigned OOB = 0xFF000000u;
 };
 
-template <int ACT, bool PIPE>
+template <int ACT>
 __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Ws2;
@@ -141,99 +141,72 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
     const int plane_off = l31 * PIXB + hi32 * 16;
     half_t* outp = (half_t*)p.out;
     typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
-    // chunk c (0 .. 3) of a finished tile's epilogue: MFMA tile j = c / 2, group pair gp = c % 2 -> activation, fp16, v_permlane32_swap, one 16-byte piece per lane into
-    // the output gather (row = pixel, 256 B, slot = chunk ^ (pixel & 15))
-    char* og = smem + C::OUT_OFF;
-    auto epi_chunk = [&](const floatx16 (&a)[2], int c) __attribute__((always_inline)) {
-        const int j = c >> 1, gp = c & 1, pix = j * 32 + l31;
-        unsigned w[2][2];
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            const int g = gp * 2 + gg;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(a[j][g * 4 + e]);
-            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-            half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-            w[gg][0] = __builtin_bit_cast(unsigned, h0);
-            w[gg][1] = __builtin_bit_cast(unsigned, h1);
-        }
-        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-        const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-        const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
-        *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
-    };
-    auto store_tile = [&](const TileIt& it) __attribute__((always_inline)) {      // the gathered tile out as full lines: 64 pixels x 16 chunks, 4 pieces per thread
-        const int oy = it.ty * TH, ox = it.tx * TW;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = k * 256 + tid, pix = c >> 4, ch = c & 15;
-            const uint4v v = *(const uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
-            const int gy = oy + (pix >> 5), gx = ox + (pix & 31);
-            *(uint4v*)(outp + ((size_t)(it.b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + ch * 8) = v;
-        }
-    };
-    // One tile: its 72 MFMAs into `cur`; PIPE: the PREVIOUS tile's epilogue (out of `prev`) in four chunks between them -- with one wave per SIMD nothing else would
-    // cover its ~1000 clocks of VALU work -- then the barrier and the previous tile's stores; !PIPE: this tile's epilogue, barrier and stores behind its MFMAs.
-    // vmcnt at the top (device): younger than this wave's pieces of tile t are, in issue order, 4 stores + the 12 pieces of tile t + 1 + 4 stores (fewer for the first tiles).
-    auto tile_body = [&](int t, int buf, floatx16 (&cur)[2], floatx16 (&prev)[2]) __attribute__((always_inline)) {
+
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
+        // this wave's pieces of tile t have landed.  Younger than them, in issue order: the 4 output stores of tile t - 2, the NPW pieces of tile t + 1, the 4 stores
+        // of tile t - 1 (every thread issues exactly 4 per tile: maps of whole tiles only)
         static_assert(NPW == 12, "the waits below count the pieces and stores of a tile");
-        if (t <= (PIPE ? 1 : 0)) WS2_VMCNT(12, 12);
-        else if (t == (PIPE ? 2 : 1)) WS2_VMCNT(16, 12);
+        if (t == 0) WS2_VMCNT(12, 12);
+        else if (t == 1) WS2_VMCNT(16, 12);
         else WS2_VMCNT(20, 12);
-        __builtin_amdgcn_s_barrier();      // everybody's pieces of tile t are visible; nobody reads the buffer of tile t - 1 or the output gather any more
+        __builtin_amdgcn_s_barrier();      // everybody's pieces of tile t are visible; nobody reads the buffer of tile t - 1 or the output gather of tile t - 1 any more
         piece_offsets(itn, pv);            // tile t + 2 goes into the buffer tile t - 1 used
 #pragma unroll
         for (int i = 0; i < NPW; ++i) issue_piece(nbuf, pv[i], i);
         tile_next(itn);
+
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
+        floatx16 acc[2];
 #pragma unroll
         for (int s = 0; s < C::NSUB; ++s) {
             const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const half8 xf = *(const half8*)(pb + (2 * j + kh) * RP + (kw == 1 ? C::O_OFF : kw == 2 ? PIXB : 0) + ks * 32);
-                cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf, s == 0 ? biasv : cur[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf, s == 0 ? biasv : acc[j], 0, 0, 0);
             }
-            if (PIPE && t > 0 && s % 9 == 3) epi_chunk(prev, s / 9);
         }
-        if (PIPE) {
-            if (t > 0) {
-                __builtin_amdgcn_s_barrier();      // the four waves' pieces of every pixel of tile t - 1 are in place
-                store_tile(ito);
-                tile_next(ito);
-            }
-        } else {
+        // ---- epilogue: activation, fp16, v_permlane32_swap -> 16-byte pieces into the tile's output gather (row = pixel, 256 B, slot = chunk ^ (pixel & 15)) ----
+        char* og = smem + C::OUT_OFF;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) epi_chunk(cur, c);
-            __builtin_amdgcn_s_barrier();
-            store_tile(ito);
-            tile_next(ito);
+        for (int j = 0; j < 2; ++j) {
+            const int pix = j * 32 + l31;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned w[2][2];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = gp * 2 + gg;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[j][g * 4 + e]);
+                    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                    w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                    w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                }
+                auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
+                *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
+            }
         }
-    };
-    floatx16 accA[2], accB[2];
-    int buf = 0;
-    for (int t = 0; t < nt; t += 2) {
-        tile_body(t, buf, accA, accB);
+        __builtin_amdgcn_s_barrier();      // the four waves' pieces of every pixel are in place
+        {
+            const int oy = ito.ty * TH, ox = ito.tx * TW;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                     // 64 pixels x 16 chunks = 1024 pieces of 16 bytes: 4 per thread, 16 lanes per pixel (two full lines)
+                const int c = k * 256 + tid, pix = c >> 4, ch = c & 15;
+                const uint4v v = *(const uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
+                const int gy = oy + (pix >> 5), gx = ox + (pix & 31);
+                *(uint4v*)(outp + ((size_t)(ito.b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + ch * 8) = v;
+            }
+        }
+        tile_next(ito);
         buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
-        if (t + 1 < nt) {
-            tile_body(t + 1, buf, accB, accA);
-            buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
-        }
-    }
-    if (PIPE) {      // the last tile's results
-        __builtin_amdgcn_s_barrier();      // (nobody reads the output gather of the tile before it any more)
-        if (nt & 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) epi_chunk(accA, c);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) epi_chunk(accB, c);
-        }
-        __builtin_amdgcn_s_barrier();
-        store_tile(ito);
     }
     WS2_VMCNT(0, 0);      // the tail's zero-filling pieces have landed before this workgroup's LDS is handed on
 #endif
@@ -254,10 +227,9 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-#define WS2_ATTR(ACT) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
-                      Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        WS2_ATTR(Y7T_ACT_NONE) WS2_ATTR(Y7T_ACT_SILU) WS2_ATTR(Y7T_ACT_LEAKY)
-#undef WS2_ATTR
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr = true;
     }
     static int ncu = -1;      // one persistent workgroup per compute unit (154 KiB of LDS, 144 + registers of weights per lane)
@@ -269,17 +241,9 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    static int pipe = -1;      // 1: the previous tile's epilogue between this tile's MFMAs (experiment until measured; Y7T_WS_S2_PIPE)
-#if defined(Y7T_CONVSIM)
-    pipe = -1;                 // (the host model switches between cases)
-#endif
-    if (pipe < 0) { const char* e = getenv("Y7T_WS_S2_PIPE"); pipe = e ? atoi(e) : 0; }
-#define WS2_GO(ACT) do { if (pipe) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<ACT, true>), dim3(grid), dim3(256), C::LDS, s, a); \
-                         else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<ACT, false>), dim3(grid), dim3(256), C::LDS, s, a); } while (0)
-    if (a.act == Y7T_ACT_SILU) WS2_GO(Y7T_ACT_SILU);
-    else if (a.act == Y7T_ACT_LEAKY) WS2_GO(Y7T_ACT_LEAKY);
-    else WS2_GO(Y7T_ACT_NONE);
-#undef WS2_GO
+    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("ws_s2<2,32>");
     return 0;

@@ -135,12 +135,23 @@ class Plan:
     """result of `lower`: ops (structured array), buffer table, weight layout, head description"""
 
 
+def patch_panel_rows(H, W, cout, B):
+    """rows of a weight panel (= output channels of a workgroup) of the LDS-patch kernel: 128 when Cout allows -- unless (Y7T_CONV_PATCH_PANEL64_BELOW=n, an
+    experiment, default off) that leaves fewer than n workgroups of 256 pixels for the whole batch: then 64 (korder 9), twice the workgroups"""
+    cout_pad = -(-cout // 64) * 64
+    if cout_pad % 128:
+        return 64
+    below = int(os.environ.get("Y7T_CONV_PATCH_PANEL64_BELOW", "0"))
+    return 64 if B * H * W // 256 * (cout_pad // 128) < below else 128
+
+
 def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 20):
     """mirror of y7t_conv_patch_try (csrc/y7t_conv_patch.hip): 3x3 / stride 1 / pad 1, Cin % 64 == 0, 16-byte aligned fp16 output,
     a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 256 workgroups of 256 pixels x 128 (64)
     channels at batch B (below that -- batch-1 latency mode -- the generic kernel with split-K fills the chip better)"""
     cout_pad = -(-cout // 64) * 64
-    if B * H * W * (cout_pad // (128 if cout_pad % 128 == 0 else 64)) < 256 * 256:
+    bn = patch_panel_rows(H, W, cout, B)
+    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(256 * 256))):      # (the switch: A/B of the threshold)
         return False
     if os.environ.get("Y7T_CONV_PATCH", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
@@ -330,6 +341,8 @@ def lower(nodes, H, W, max_batch=1):
             korder = 8                               # ... and its stride-2 sibling for the 64 -> 128 down-sampling layer (weights.pack_ws_s2)
         elif patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
+            if cout_pad % 128 == 0 and patch_panel_rows(src.h, src.w, cout, max_batch) == 64:
+                korder = 9                           # ... with 64-row panels
         elif patch_s2_eligible(cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch * n.h * n.w):
             korder = 4                               # stride-2 LDS-patch kernel, weights in its panel order (weights.panel_pack_s2)
         elif p8_eligible(src.h, src.w, cin, cout, n.k, n.s, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch,

@@ -112,14 +112,14 @@ def folded(w, sd):
     return W, b
 
 
-def panel_pack(blk, cin_pad):
+def panel_pack(blk, cin_pad, narrow=False):
     """[Cout_pad][K_pad] block with k = (kh*3 + kw)*Cin + ci  ->  the patch kernel's PANEL order (csrc/y7t_conv_patch.hip, korder 2):
     [n-tile of BN rows][K-step = 32-channel chunk * 9 + tap][row][four 16-byte slots], slot s of row r holding channel octet
     s ^ ((r >> 2) & 3) of the chunk -- byte for byte the image the kernel's buffer->LDS DMA leaves in LDS, so each K-step's
     panel is one contiguous run of full cache lines.  BN = 128 when Cout_pad allows, else 64."""
     cout_pad, K = blk.shape
     assert K == 9 * cin_pad and cin_pad % 64 == 0
-    BN = 128 if cout_pad % 128 == 0 else 64
+    BN = 128 if cout_pad % 128 == 0 and not narrow else 64      # (narrow: korder 9)
     nc32 = cin_pad // 32
     a = blk.reshape(cout_pad // BN, BN, 9, nc32, 4, 8)           # [tile][row][tap][chunk][octet][8]
     a = a.transpose(0, 3, 2, 1, 4, 5)                            # [tile][chunk][tap][row][octet][8]
@@ -214,8 +214,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             Wt = Wt.reshape(cout, k, k, w["cin_pad"] // 64, 64).transpose(0, 1, 3, 2, 4)
         blk = np.zeros((w["cout_pad"], w["K_pad"]), np.float16)
         blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
-        if w.get("korder") == 2:
-            blk = panel_pack(blk, w["cin_pad"])
+        if w.get("korder") in (2, 9):
+            blk = panel_pack(blk, w["cin_pad"], narrow=w["korder"] == 9)
         elif w.get("korder") == 3:
             blk = panel_pack_linear(blk)
         elif w.get("korder") == 4:
