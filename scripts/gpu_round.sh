@@ -152,6 +152,27 @@ exp_smallmap)
   for n in sm_default sm_wide sm_n150 sm_n256 sm_default2; do echo "-- $n"; grep -E "^ *(31|34|43|86|87|89|94) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
   ;;
 
+exp_r4l)
+  say "exp_r4l a: new lowering defaults (20x20 3x3 layers on the strip kernel, 64-row panels) + ws_s2 column order (Y7T_WS_S2_YFAST=1): detector tests"
+  timeout 600 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -x > $O/t_det.log 2>&1; echo "rc=$?" >> $O/t_det.log; tailsum $O/t_det.log 3
+  Y7T_WS_S2_YFAST=1 timeout 400 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -k "stride2_weights_stationary or every_op or launch_list" > $O/t_yfast.log 2>&1; echo "rc=$?" >> $O/t_yfast.log; tailsum $O/t_yfast.log 3
+  say "exp_r4l b: per-op tables: default | YFAST=1 | round-3 lowering thresholds | default"
+  NAME=l_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_WS_S2_YFAST=1 NAME=l_yfast OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_MIN_PIX=65536 Y7T_CONV_PATCH_PANEL64_BELOW=0 NAME=l_old OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_PANEL64_BELOW=1000 NAME=l_n1000 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  Y7T_CONV_PATCH_PANEL64_BELOW=2000 NAME=l_n2000 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  NAME=l_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  for n in l_default l_yfast l_old l_n1000 l_n2000 l_default2; do echo "-- $n"; grep -E "^ *(1|3|17|31|57|58|73|86|87) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
+  say "exp_r4l c: bench lines with latency mode: default | round-3 thresholds | YFAST=1 | default"
+  X="--steps 20 --warmup 5 --no_cpu_baseline"
+  timeout 400 python bench.py $X > $O/bench_new.json 2> $O/bench_new.err
+  Y7T_CONV_PATCH_MIN_PIX=65536 Y7T_CONV_PATCH_PANEL64_BELOW=0 timeout 400 python bench.py $X > $O/bench_old.json 2> $O/bench_old.err
+  Y7T_WS_S2_YFAST=1 timeout 400 python bench.py $X > $O/bench_yfast.json 2> $O/bench_yfast.err
+  timeout 400 python bench.py $X > $O/bench_new2.json 2> $O/bench_new2.err
+  benchsum new old yfast new2
+  ;;
+
 exp_spp3)
   say "exp_spp3: the three SPPCSPC pools as one launch (k_spp3_lds): whole-network + teacher-forced parity, per-op table"
   timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "whole_network or upsample_on_read" > $O/t_spp3.log 2>&1; echo "rc=$?" >> $O/t_spp3.log; tailsum $O/t_spp3.log 2

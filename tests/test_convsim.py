@@ -189,11 +189,13 @@ WS_S2_CASES = [
 ]
 
 
+@pytest.mark.parametrize("yfast", [0, 1], ids=["rows-of-tiles", "columns-of-tiles"])
 @pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
 @pytest.mark.parametrize("case", WS_S2_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
-def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred):
+def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred, yfast, monkeypatch):
     B, H, W, act, kw = case
     L = cs.lib()
+    monkeypatch.setenv("Y7T_WS_S2_YFAST", str(yfast))      # (the host build of the launcher reads it at every call)
     L.cs_set_dma_deferred(deferred)
     try:
         name = run_case(L, B, H, W, 64, 128, 3, 2, act, 0, korder=8, seed=B * 1000 + H + W, **kw)

@@ -245,7 +245,9 @@ def test_patch_eligibility_rule():
     from yolov7_tracker_amd.detector import graph
     ok = lambda H, W, ci, co, B, **kw: graph.patch_eligible(H, W, ci, co, kw.get("k", 3), kw.get("s", 1), kw.get("p", 1), co, 0, 0, B)
     assert ok(80, 80, 256, 256, 32) and ok(320, 320, 64, 64, 32) and ok(40, 40, 384, 384, 32) and ok(20, 20, 512, 1024, 32)
-    assert not ok(20, 20, 512, 512, 32)                # 32 * 400 pixels * 4 channel tiles: below 256 workgroups' worth of 256-pixel tiles
+    assert ok(20, 20, 512, 512, 32) and ok(20, 20, 256, 256, 32)      # round 4: 64-row panels (korder 9) where 128 rows give fewer than 256 workgroups, threshold 200
+    assert graph.patch_panel_rows(20, 20, 512, 32) == 64 and graph.patch_panel_rows(20, 20, 1024, 32) == 128 and graph.patch_panel_rows(80, 80, 192, 32) == 64
+    assert not ok(20, 20, 512, 512, 8)                 # 8 * 400 pixels * 8 panels: below 200 workgroups' worth of 256-pixel tiles
     assert not ok(80, 80, 256, 256, 1)                 # batch 1: too few workgroups, the split-K generic kernel is used
     assert not ok(80, 80, 256, 256, 32, s=2) and not ok(80, 80, 256, 256, 32, k=1, p=0)
     assert not ok(80, 80, 96, 256, 32)                 # Cin % 64

@@ -136,22 +136,26 @@ class Plan:
 
 
 def patch_panel_rows(H, W, cout, B):
-    """rows of a weight panel (= output channels of a workgroup) of the LDS-patch kernel: 128 when Cout allows -- unless (Y7T_CONV_PATCH_PANEL64_BELOW=n, an
-    experiment, default off) that leaves fewer than n workgroups of 256 pixels for the whole batch: then 64 (korder 9), twice the workgroups"""
+    """rows of a weight panel (= output channels of a workgroup) of the LDS-patch kernel: 128 when Cout allows -- unless that leaves fewer than 256 workgroups of
+    256 pixels for the whole batch: then 64 (korder 9), twice the workgroups.  Measured at 32 frames (round 4, profiles/r04_smallmap_patch.txt): the 20x20 layers with
+    256 output channels 71 -> 51 us and 39 -> 28 us against the generic kernel, 61 / 36 us with 128-row panels.  Y7T_CONV_PATCH_PANEL64_BELOW=0 switches the rule off."""
     cout_pad = -(-cout // 64) * 64
     if cout_pad % 128:
         return 64
-    below = int(os.environ.get("Y7T_CONV_PATCH_PANEL64_BELOW", "0"))
+    below = int(os.environ.get("Y7T_CONV_PATCH_PANEL64_BELOW", "256"))
     return 64 if B * H * W // 256 * (cout_pad // 128) < below else 128
+
+
+PATCH_MIN_PIX = 200 * 256      # (round 3: 256 * 256; round 4 measured the 20x20 512 -> 512 layers -- 244 / 488 workgroups -- 91 -> 70 us on the strip kernel)
 
 
 def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 20):
     """mirror of y7t_conv_patch_try (csrc/y7t_conv_patch.hip): 3x3 / stride 1 / pad 1, Cin % 64 == 0, 16-byte aligned fp16 output,
-    a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 256 workgroups of 256 pixels x 128 (64)
+    a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 200 workgroups of 256 pixels x 128 (64)
     channels at batch B (below that -- batch-1 latency mode -- the generic kernel with split-K fills the chip better)"""
     cout_pad = -(-cout // 64) * 64
     bn = patch_panel_rows(H, W, cout, B)
-    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(256 * 256))):      # (the switch: A/B of the threshold)
+    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(PATCH_MIN_PIX))):      # (the switch: A/B of the threshold)
         return False
     if os.environ.get("Y7T_CONV_PATCH", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
