@@ -139,38 +139,16 @@ exp_ws_s2)
   benchsum ws2 nows2 ws2b
   ;;
 
-exp_smallmap)
-  say "exp_smallmap a: 20x20 3x3 layers on the LDS-patch strip kernel (Y7T_CONV_PATCH_MIN_PIX=20000), 128- or 64-row panels (Y7T_CONV_PATCH_PANEL64_BELOW): layer parity, whole network"
-  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer_matches" > $O/t_smallmap.log 2>&1; echo "rc=$?" >> $O/t_smallmap.log; tailsum $O/t_smallmap.log 3
-  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=256 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_smallmap_pinned.log 2>&1; echo "rc=$?" >> $O/t_smallmap_pinned.log; tailsum $O/t_smallmap_pinned.log 3
-  say "exp_smallmap b: per-op tables: default | MIN_PIX=20000 | + PANEL64_BELOW=150 | + PANEL64_BELOW=256 | default"
-  NAME=sm_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_MIN_PIX=20000 NAME=sm_wide OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=150 NAME=sm_n150 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_MIN_PIX=20000 Y7T_CONV_PATCH_PANEL64_BELOW=256 NAME=sm_n256 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  NAME=sm_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  for n in sm_default sm_wide sm_n150 sm_n256 sm_default2; do echo "-- $n"; grep -E "^ *(31|34|43|86|87|89|94) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
-  ;;
-
-exp_r4l)
-  say "exp_r4l a: new lowering defaults (20x20 3x3 layers on the strip kernel, 64-row panels) + ws_s2 column order (Y7T_WS_S2_YFAST=1): detector tests"
-  timeout 600 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -x > $O/t_det.log 2>&1; echo "rc=$?" >> $O/t_det.log; tailsum $O/t_det.log 3
-  Y7T_WS_S2_YFAST=1 timeout 400 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -k "stride2_weights_stationary or every_op or launch_list" > $O/t_yfast.log 2>&1; echo "rc=$?" >> $O/t_yfast.log; tailsum $O/t_yfast.log 3
-  say "exp_r4l b: per-op tables: default | YFAST=1 | round-3 lowering thresholds | default"
-  NAME=l_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_WS_S2_YFAST=1 NAME=l_yfast OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_MIN_PIX=65536 Y7T_CONV_PATCH_PANEL64_BELOW=0 NAME=l_old OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_PANEL64_BELOW=1000 NAME=l_n1000 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  Y7T_CONV_PATCH_PANEL64_BELOW=2000 NAME=l_n2000 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  NAME=l_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  for n in l_default l_yfast l_old l_n1000 l_n2000 l_default2; do echo "-- $n"; grep -E "^ *(1|3|17|31|57|58|73|86|87) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
-  say "exp_r4l c: bench lines with latency mode: default | round-3 thresholds | YFAST=1 | default"
-  X="--steps 20 --warmup 5 --no_cpu_baseline"
-  timeout 400 python bench.py $X > $O/bench_new.json 2> $O/bench_new.err
-  Y7T_CONV_PATCH_MIN_PIX=65536 Y7T_CONV_PATCH_PANEL64_BELOW=0 timeout 400 python bench.py $X > $O/bench_old.json 2> $O/bench_old.err
-  Y7T_WS_S2_YFAST=1 timeout 400 python bench.py $X > $O/bench_yfast.json 2> $O/bench_yfast.err
-  timeout 400 python bench.py $X > $O/bench_new2.json 2> $O/bench_new2.err
-  benchsum new old yfast new2
+exp_1x1narrow)
+  say "exp_1x1narrow a: 1x1 layers with 64-row weight panels (korder 10) where 128-row tiles are few (Y7T_CONV_1X1_PANEL64_BELOW=n tiles), split-K threshold (Y7T_CONV_SPLITK_TILES): parity"
+  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer_matches" > $O/t_layer.log 2>&1; echo "rc=$?" >> $O/t_layer.log; tailsum $O/t_layer.log 3
+  Y7T_CONV_1X1_PANEL64_BELOW=2500 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_pinned.log 2>&1; echo "rc=$?" >> $O/t_pinned.log; tailsum $O/t_pinned.log 3
+  say "exp_1x1narrow b: per-op tables: default | BELOW=1000 | BELOW=1300 | BELOW=2500 | SPLITK_TILES=512 | default"
+  NAME=n_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  for v in 1000 1300 2500; do Y7T_CONV_1X1_PANEL64_BELOW=$v NAME=n_$v OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt; done
+  Y7T_CONV_SPLITK_TILES=512 NAME=n_sk512 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  NAME=n_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  for n in n_default n_1000 n_1300 n_2500 n_sk512 n_default2; do echo "-- $n"; grep -E "^ *(23|30|35|36|38|42|46|47|53|54|78|83|85|90) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
   ;;
 
 exp_spp3)

@@ -25,6 +25,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder in (2, 9):      # the patch kernel's panel order (9: 64-row panels although Cout_pad % 128 == 0)
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack(blk, cin_pad, narrow=korder == 9)
+    if korder in (3, 10):      # the 1x1 panel order (10: 64-row panels although Cout_pad % 128 == 0)
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.panel_pack_linear(blk, narrow=korder == 10)
     if korder == 5:      # the weights-stationary kernel's register-fragment order
         from yolov7_tracker_amd.detector import weights
         blk = weights.pack_ws(blk)
@@ -81,6 +84,8 @@ CASES = [
     (1, 17, 17, 64, 256, 3, 1, 1, 256256064, {}),                                      # the 256 x 256 tile
     (1, 10, 10, 128, 128, 3, 1, 1, 128128064, {"splitk": 1}),                          # split-K + k_splitk_reduce
     (1, 12, 12, 64, 128, 3, 1, 1, 128128364, {}),                                      # three-stage ring
+    (2, 9, 9, 128, 128, 1, 1, 1, 0, {"korder": 3}),                                   # 1x1 panels through the dispatch rules: 128-row panels
+    (2, 9, 9, 128, 256, 1, 1, 2, 0, {"korder": 10, "out_ld": 320, "out_coff": 64}),      # ... 64-row panels on a 256-channel layer (korder 10)
 ]
 
 
@@ -189,13 +194,11 @@ WS_S2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("yfast", [0, 1], ids=["rows-of-tiles", "columns-of-tiles"])
 @pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
 @pytest.mark.parametrize("case", WS_S2_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
-def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred, yfast, monkeypatch):
+def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred):
     B, H, W, act, kw = case
     L = cs.lib()
-    monkeypatch.setenv("Y7T_WS_S2_YFAST", str(yfast))      # (the host build of the launcher reads it at every call)
     L.cs_set_dma_deferred(deferred)
     try:
         name = run_case(L, B, H, W, 64, 128, 3, 2, act, 0, korder=8, seed=B * 1000 + H + W, **kw)

@@ -34,9 +34,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder in (2, 9):   # patch-kernel panel order (9: 64-row panels although Cout_pad % 128 == 0)
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack(blk, cin_pad, narrow=korder == 9)
-    if korder == 3:   # 1x1 panel order
+    if korder in (3, 10):   # 1x1 panel order (10: 64-row panels although Cout_pad % 128 == 0)
         from yolov7_tracker_amd.detector import weights
-        blk = weights.panel_pack_linear(blk)
+        blk = weights.panel_pack_linear(blk, narrow=korder == 10)
     if korder == 4:   # stride-2 patch-kernel panel order (opt-in experiment)
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_s2(blk, cin_pad)
@@ -87,6 +87,8 @@ CONV_CASES = [
     (3, 48, 48, 64, 64, 3, 1, 1 | 512 | 1024, 64, 0, 64, 0, 0),
     (5, 20, 20, 256, 256, 3, 1, 1 | 131072, 256, 0, 256, 0, 0),          # korder 9: the patch kernel's 64-row panels on a layer whose Cout would allow 128 (strip tiling)
     (2, 32, 48, 64, 128, 3, 1, 2 | 131072, 64, 0, 256, 128, 0),          # ... 16x16 tiles, output slice
+    (3, 20, 20, 256, 256, 1, 1, 1 | 262144, 256, 0, 256, 0, 0),          # korder 10: 64-row 1x1 panels on a layer whose Cout would allow 128
+    (1, 24, 24, 96, 128, 1, 1, 2 | 262144, 256, 64, 384, 192, 0),        # ... slices, LeakyReLU
     (1, 37, 70, 192, 64, 3, 1, 2 | 512 | 256, 256, 64, 192, 64, 0),
     (2, 24, 64, 64, 192, 3, 1, 1 | 512, 64, 0, 192, 0, 0),
     # 1x1 layers with panel-packed weights (act bit 11): 128- and 64-row panels, Cin % 64 == 32, split-K on a small map, fp32 head
@@ -105,7 +107,7 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 9 if act & 131072 else 8 if act & 65536 else 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    korder = 10 if act & 262144 else 9 if act & 131072 else 8 if act & 65536 else 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
     cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 8) else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255

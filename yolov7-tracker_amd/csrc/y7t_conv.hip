@@ -485,8 +485,10 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     Y7TConvArgs b = a;
     const int nk = a.K_pad / BK;
     int S = 1;
-    if (a.allow_splitk && EPI == 0 && tiles < 256 && nk >= 8) {
-        S = (512 + tiles - 1) / tiles;
+    static int skt = -1;      // split K below this many output tiles (Y7T_CONV_SPLITK_TILES: A/B of the threshold; 256 = one tile per CU)
+    if (skt < 0) { const char* e = getenv("Y7T_CONV_SPLITK_TILES"); skt = e ? atoi(e) : 256; }
+    if (a.allow_splitk && EPI == 0 && tiles < skt && nk >= 8) {
+        S = (2 * skt + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;
         while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes) --S;
@@ -559,9 +561,11 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv
 static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     Y7TConvArgs a = a0;
     if (a.korder == 9) { a.korder = 2; a.panel64 = 1; }          // the patch kernel's panel order with 64-row panels
+    if (a.korder == 10) { a.korder = 3; a.panel64 = 1; }         // the 1x1 panel order with 64-row panels (small maps: twice the workgroups)
     if (a.korder == 8) return y7t_conv_ws_s2_launch(a, s);      // stride-2 register-fragment order: only that kernel reads it
     if (a.korder == 7) return y7t_conv_p8_launch(a, s);         // 256 x 64 weight panels: only that kernel reads them (plain and upsample-on-read)
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
+        if (a.panel64) { y7t_set_error("conv: korder 10 (64-row 1x1 panels) is for plain 1x1 layers, not Detect-decode / upsample-on-read"); return Y7T_E_ARG; }
         const bool fast = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 64 == 0 && a.in_bytes <= 0xFF000000u - (1u << 24) &&
                           (a.korder == 3 || a.korder == 0);
         if (!fast) { y7t_set_error("conv: Detect-decode / upsample-on-read need a 1x1 stride-1 layer with Cin %% 64 == 0"); return Y7T_E_ARG; }
@@ -579,7 +583,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     if (a.korder == 5) return y7t_conv_ws_launch(a, s);         // register-fragment order: only the weights-stationary kernel reads it
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
-        return a.Cout_pad % 128 == 0 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
+        return a.Cout_pad % 128 == 0 && !a.panel64 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);
     }
     if ((conv_variant() == 0 && !a.no_patch) || a.korder == 2) {   // 3x3 / stride 1 on a large map: LDS-resident patch kernel
         const int rc = y7t_conv_patch_try(a, s);

@@ -73,24 +73,16 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
 
-    // tile iterator: stepped, not decoded.  tile_order 2 walks DOWN a column of tiles (y fastest): a tile's top patch row is the bottom row of the tile before it -- one
-    // of its five rows comes out of L2 instead of HBM; with x fastest (tile_order 1) that row was read ten tiles (and 20 MB of the XCD's traffic) ago.
+    // tile iterator: (b, ty, tx) stepped, not decoded
     struct TileIt { int b, ty, tx, n; };
-    const bool yfast = p.tile_order == 2;
     auto tile_it = [&](int pt) -> TileIt {
         int q = pt;
-        if (yfast) {
-            const int tyi = q % tiles_y; q /= tiles_y;
-            return TileIt{q / tiles_x, tyi, q % tiles_x, pt_first + nt - pt};
-        }
         const int txi = q % tiles_x; q /= tiles_x;
         return TileIt{q / tiles_y, q % tiles_y, txi, pt_first + nt - pt};
     };
     auto tile_next = [&](TileIt& it) __attribute__((always_inline)) {
         it.n -= 1;
-        if (yfast) {
-            if (++it.ty == tiles_y) { it.ty = 0; if (++it.tx == tiles_x) { it.tx = 0; ++it.b; } }
-        } else if (++it.tx == tiles_x) { it.tx = 0; if (++it.ty == tiles_y) { it.ty = 0; ++it.b; } }
+        if (++it.tx == tiles_x) { it.tx = 0; if (++it.ty == tiles_y) { it.ty = 0; ++it.b; } }
     };
     // Source of this lane's 16 bytes of piece i = per-lane constant (its slot's place in the 5 x 65 patch as a byte offset from input pixel (2 h0 - 1, 2 w0 - 1))
     // + tile origin; pedge: the slot lies in the patch's top row (bit 0) / first column (bit 1) -- the only sides that can fall outside an even-sized image.
@@ -249,16 +241,9 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    static int yfast = -1;      // Y7T_WS_S2_YFAST=1: a workgroup's tiles in column order (experiment until measured)
-#if defined(Y7T_CONVSIM)
-    yfast = -1;                 // (the host model switches between cases)
-#endif
-    if (yfast < 0) { const char* e = getenv("Y7T_WS_S2_YFAST"); yfast = e ? atoi(e) : 0; }
-    Y7TConvArgs b = a;
-    b.tile_order = yfast ? 2 : 1;
-    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, b);
-    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, b);
-    else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, b);
+    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
     y7t_note_kernel("ws_s2<2,32>");
     return 0;

@@ -36,7 +36,7 @@ struct Y7TConvArgs {
     float* splitk_ws;                   // caller's split-K workspace of Y7T_SPLITK_WS_BYTES (a detector owns one, so detectors on different streams
                                         // never share slabs), or null: one process-wide workspace (the single-layer entry point; one stream at a time)
     int korder;   // 1: weights packed in (kh, 64-channel chunk, kw) K order (3x3, Cin % 64 == 0); 2: LDS-patch panels (9: the same with 64-row panels); 3: 1x1 panels; 4: stride-2 LDS-patch panels; 5 / 8: weights-stationary fragments; 7: p8 panels
-    int panel64;       // patch kernel: 64-row weight panels although Cout_pad % 128 == 0 (korder 9: small maps, where 128-row panels would leave most CUs without a workgroup)
+    int panel64;       // 64-row weight panels although Cout_pad % 128 == 0 (korder 9: patch kernel, korder 10: 1x1 panels; small maps, where 128-row panels would leave most CUs without a workgroup)
     int force_patch;   // tests: run an eligible 3x3/s1 layer on k_conv3x3_patch whatever its tile efficiency
     int no_patch;      // host-side: keep this launch on the generic implicit-GEMM kernel
     int ablate;   // debug: bit0 skip DMA loads, bit1 skip MFMAs, bit2 skip the whole compute phase  // extents for the buffer descriptors (filled by y7t_conv_launch)

@@ -129,12 +129,12 @@ def panel_pack(blk, cin_pad, narrow=False):
     return np.ascontiguousarray(a).reshape(cout_pad, K)
 
 
-def panel_pack_linear(blk):
+def panel_pack_linear(blk, narrow=False):
     """[Cout_pad][K_pad] block of a 1x1 layer -> panel order of the 32-deep generic kernel (csrc/y7t_conv.hip, korder 3):
     [n-tile of BN rows][K-step of 32 channels][row][four 16-byte slots], slot s of row r = channel octet s ^ ((r >> 2) & 3)."""
     cout_pad, K = blk.shape
     assert K % 32 == 0
-    BN = 128 if cout_pad % 128 == 0 else 64
+    BN = 128 if cout_pad % 128 == 0 and not narrow else 64      # (narrow: korder 10)
     a = blk.reshape(cout_pad // BN, BN, K // 32, 4, 8).transpose(0, 2, 1, 3, 4)      # [tile][kstep][row][octet][8]
     r = np.arange(BN)
     src = np.arange(4)[None, :] ^ ((r[:, None] >> 2) & 3)
@@ -216,8 +216,8 @@ def pack(wlayout, sd, w_elems, b_elems):
         blk[:cout, :w["K"]] = Wt.reshape(cout, -1).astype(np.float16)
         if w.get("korder") in (2, 9):
             blk = panel_pack(blk, w["cin_pad"], narrow=w["korder"] == 9)
-        elif w.get("korder") == 3:
-            blk = panel_pack_linear(blk)
+        elif w.get("korder") in (3, 10):
+            blk = panel_pack_linear(blk, narrow=w["korder"] == 10)
         elif w.get("korder") == 4:
             blk = panel_pack_s2(blk, w["cin_pad"])
         elif w.get("korder") == 5:
