@@ -139,16 +139,27 @@ exp_ws_s2)
   benchsum ws2 nows2 ws2b
   ;;
 
-exp_1x1narrow)
-  say "exp_1x1narrow a: 1x1 layers with 64-row weight panels (korder 10) where 128-row tiles are few (Y7T_CONV_1X1_PANEL64_BELOW=n tiles), split-K threshold (Y7T_CONV_SPLITK_TILES): parity"
-  timeout 400 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "conv_layer_matches" > $O/t_layer.log 2>&1; echo "rc=$?" >> $O/t_layer.log; tailsum $O/t_layer.log 3
-  Y7T_CONV_1X1_PANEL64_BELOW=2500 timeout 500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_pinned.log 2>&1; echo "rc=$?" >> $O/t_pinned.log; tailsum $O/t_pinned.log 3
-  say "exp_1x1narrow b: per-op tables: default | BELOW=1000 | BELOW=1300 | BELOW=2500 | SPLITK_TILES=512 | default"
-  NAME=n_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  for v in 1000 1300 2500; do Y7T_CONV_1X1_PANEL64_BELOW=$v NAME=n_$v OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt; done
-  Y7T_CONV_SPLITK_TILES=512 NAME=n_sk512 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  NAME=n_default2 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
-  for n in n_default n_1000 n_1300 n_2500 n_sk512 n_default2; do echo "-- $n"; grep -E "^ *(23|30|35|36|38|42|46|47|53|54|78|83|85|90) " $O/per_layer_$n.txt | cut -c1-120; grep TOTAL $O/per_layer_$n.txt; done | tee -a $O/summary.txt
+exp_r4n)
+  say "exp_r4n a: detector device tests with the 1x1 64-row-panel rule (threshold 500 tiles) as the default"
+  timeout 600 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -x > $O/t_det.log 2>&1; echo "rc=$?" >> $O/t_det.log; tailsum $O/t_det.log 3
+  say "exp_r4n b: bench lines with latency mode: default | Y7T_CONV_1X1_PANEL64_BELOW=0 | default"
+  X="--steps 20 --warmup 5 --no_cpu_baseline"
+  timeout 400 python bench.py $X > $O/bench_n500.json 2> $O/bench_n500.err
+  Y7T_CONV_1X1_PANEL64_BELOW=0 timeout 400 python bench.py $X > $O/bench_n0.json 2> $O/bench_n0.err
+  timeout 400 python bench.py $X > $O/bench_n500b.json 2> $O/bench_n500b.err
+  benchsum n500 n0 n500b
+  ;;
+
+exp_wswgs)
+  say "exp_wswgs: the persistent weights-stationary kernels on fewer workgroups than CUs (Y7T_CONV_WS_WGS): inside the pipeline, where one CU hosts the tracker's workgroup"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  for v in 256 255 254 252 248 256; do
+    Y7T_CONV_WS_WGS=$v timeout 300 python bench.py $X > $O/bench_wgs${v}.json 2> $O/bench_wgs${v}.err; benchsum wgs${v}
+  done
+  say "exp_wswgs b: kernel stats of the bench under rocprofv3, 256 vs 255 (the ws64 rows)"
+  ( cd /tmp; export TMPDIR=/tmp
+    for v in 256 255; do rm -rf /tmp/ks_$v; Y7T_CONV_WS_WGS=$v timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$v -- python $ROOT/bench.py $X > /tmp/ks_$v.log 2>&1
+      f=$(find /tmp/ks_$v -name "*kernel_stats.csv" | head -1); echo "-- WGS=$v"; grep -E "c64_ws|Name" $f | cut -c1-160; done ) | tee -a $O/summary.txt
   ;;
 
 exp_spp3)

@@ -485,10 +485,8 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     Y7TConvArgs b = a;
     const int nk = a.K_pad / BK;
     int S = 1;
-    static int skt = -1;      // split K below this many output tiles (Y7T_CONV_SPLITK_TILES: A/B of the threshold; 256 = one tile per CU)
-    if (skt < 0) { const char* e = getenv("Y7T_CONV_SPLITK_TILES"); skt = e ? atoi(e) : 256; }
-    if (a.allow_splitk && EPI == 0 && tiles < skt && nk >= 8) {
-        S = (2 * skt + tiles - 1) / tiles;
+    if (a.allow_splitk && EPI == 0 && tiles < 256 && nk >= 8) {      // (below 512 tiles, measured in round 4: the 20x20 1x1 layers 34 -> 57 us, 61 -> 67 us)
+        S = (512 + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;
         while (S > 1 && (size_t)S * a.M * a.Cout_pad * 4 > kSplitKWsBytes) --S;

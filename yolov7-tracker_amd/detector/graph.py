@@ -355,8 +355,9 @@ def lower(nodes, H, W, max_batch=1):
         elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
             if (cout_pad % 128 == 0 and level < 0 and getattr(src, "virt_up", None) is None and
-                    -(-max_batch * n.h * n.w // 128) * (cout_pad // 128) < int(os.environ.get("Y7T_CONV_1X1_PANEL64_BELOW", "0"))):
-                korder = 10                          # ... as 64-row panels: twice the workgroups on the small maps (an experiment, default off)
+                    -(-max_batch * n.h * n.w // 128) * (cout_pad // 128) < int(os.environ.get("Y7T_CONV_1X1_PANEL64_BELOW", "500"))):
+                korder = 10                          # ... as 64-row panels where 128-row tiles number fewer than 500 (round 4, profiles/r04_smallmap_patch.txt: the 20x20
+                                                     # layers with <= 512 output channels 34 -> 30, 61 -> 53, 20 -> 18 us; at 800 tiles and above 64 rows lose)
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level
         if getattr(src, "virt_up", None) is not None:      # upsample-on-read: part of this concat exists only at half resolution
             un, uoff = src.virt_up
