@@ -10,6 +10,7 @@
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
+#   exp_lowering    round 4's small-map lowering rules against round 3's thresholds (per-op tables, bench lines with latency mode)
 #   exp_r4misc      round 4's small experiments: stem with full-line stores, LDS max-pool, 64-channel tiles instead of split-K -- parity + per-op tables per variant
 #   suite           the whole `-m gpu` suite, as the driver runs it
 #   bench           the driver's bench line (python bench.py --steps 20 --warmup 5) -> bench_line.json
@@ -139,27 +140,16 @@ exp_ws_s2)
   benchsum ws2 nows2 ws2b
   ;;
 
-exp_r4n)
-  say "exp_r4n a: detector device tests with the 1x1 64-row-panel rule (threshold 500 tiles) as the default"
-  timeout 600 python -m pytest tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -q -m gpu -x > $O/t_det.log 2>&1; echo "rc=$?" >> $O/t_det.log; tailsum $O/t_det.log 3
-  say "exp_r4n b: bench lines with latency mode: default | Y7T_CONV_1X1_PANEL64_BELOW=0 | default"
+exp_lowering)
+  say "exp_lowering: round 4's lowering rules for the small maps (3x3 on the strip kernel from 200 workgroups, 64-row panels below 256 workgroups / 500 1x1 tiles) against round 3's thresholds: per-op tables + bench lines"
+  R3="Y7T_CONV_PATCH_MIN_PIX=65536 Y7T_CONV_PATCH_PANEL64_BELOW=0 Y7T_CONV_1X1_PANEL64_BELOW=0"
+  NAME=low_default OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  env $R3 NAME=low_r3 OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
   X="--steps 20 --warmup 5 --no_cpu_baseline"
-  timeout 400 python bench.py $X > $O/bench_n500.json 2> $O/bench_n500.err
-  Y7T_CONV_1X1_PANEL64_BELOW=0 timeout 400 python bench.py $X > $O/bench_n0.json 2> $O/bench_n0.err
-  timeout 400 python bench.py $X > $O/bench_n500b.json 2> $O/bench_n500b.err
-  benchsum n500 n0 n500b
-  ;;
-
-exp_wswgs)
-  say "exp_wswgs: the persistent weights-stationary kernels on fewer workgroups than CUs (Y7T_CONV_WS_WGS): inside the pipeline, where one CU hosts the tracker's workgroup"
-  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
-  for v in 256 255 254 252 248 256; do
-    Y7T_CONV_WS_WGS=$v timeout 300 python bench.py $X > $O/bench_wgs${v}.json 2> $O/bench_wgs${v}.err; benchsum wgs${v}
-  done
-  say "exp_wswgs b: kernel stats of the bench under rocprofv3, 256 vs 255 (the ws64 rows)"
-  ( cd /tmp; export TMPDIR=/tmp
-    for v in 256 255; do rm -rf /tmp/ks_$v; Y7T_CONV_WS_WGS=$v timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$v -- python $ROOT/bench.py $X > /tmp/ks_$v.log 2>&1
-      f=$(find /tmp/ks_$v -name "*kernel_stats.csv" | head -1); echo "-- WGS=$v"; grep -E "c64_ws|Name" $f | cut -c1-160; done ) | tee -a $O/summary.txt
+  timeout 400 python bench.py $X > $O/bench_low.json 2> $O/bench_low.err
+  env $R3 timeout 400 python bench.py $X > $O/bench_lowr3.json 2> $O/bench_lowr3.err
+  timeout 400 python bench.py $X > $O/bench_low2.json 2> $O/bench_low2.err
+  benchsum low lowr3 low2
   ;;
 
 exp_spp3)
