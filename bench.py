@@ -89,9 +89,12 @@ def make_opts():
                                  max_tracks=512, max_dets=512, tracker_threads=TRACKER_THREADS)
 
 
+LEVEL_QUOTA = (0.55, 0.2, 0.15, 0.1)      # share of the candidates each Detect level (stride 8 / 16 / 32 / 64) supplies: all four live, weighted towards the fine ones
+
+
 def plant_objectness_bias(det, frames, target=2000):
-    """~`target` anchors per frame above conf_thres = 0.01 (state dict and device blob both updated)"""
-    return det.plant_objectness_bias(frames, target)
+    """~`target` anchors per frame above conf_thres = 0.01 (state dict and device blob both updated), every Detect level supplying its quota of them"""
+    return det.plant_objectness_bias(frames, target, level_quota=LEVEL_QUOTA if len(det.plan.heads) == len(LEVEL_QUOTA) else None)
 
 
 def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=None, gpu_cands0=None, gpu_kept_rows0=None):
@@ -262,7 +265,7 @@ def parity_well_conditioned(args, nc, frames_host):
             sd[k] = w.view(na * no, -1, 1, 1)
     d2 = model.Detector(spec, sd, img_size=(H, W), max_batch=2)
     fr = torch.from_numpy(frames_host[:2]).cuda()
-    d2.plant_objectness_bias(fr)
+    plant_objectness_bias(d2, fr)
     out = d2.forward(fr, fuse_decode=0.01)
     dets, nd = d2.postprocess(out, 0.01, 0.45, None)
     torch.cuda.synchronize()
@@ -295,7 +298,7 @@ def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10, sd=None
     nf = min(8, len(frames_host))
     u8 = [torch.from_numpy(frames_host[i]).pin_memory() for i in range(nf)]
     f32 = [(torch.from_numpy(np.ascontiguousarray(frames_host[i][:, :, ::-1].transpose(2, 0, 1))).float() / 255.0).pin_memory() for i in range(nf)]
-    det1.plant_objectness_bias(u8[0][None].cuda())
+    plant_objectness_bias(det1, u8[0][None].cuda())
     res = {}
     count0 = BaseTrack._count
     for mode, src in (("f32_chw_host", f32), ("u8_hwc_host", u8)):
@@ -557,7 +560,7 @@ def main():
     # frame slot i of step s belongs to sequence i // Bq, at its local time s * Bq + i % Bq; everything below is indexed by t = s * B + i
     dets_seq = [per_seq[(t % B) // Bq][(t // B) * Bq + (t % B) % Bq] for t in range(n_frames)]
     dets_dev = [torch.from_numpy(d).cuda() for d in dets_seq]
-    plant_objectness_bias(det, frames)       # ~2000 candidates per frame, wherever the head puts them: all four Detect levels are live
+    plant_objectness_bias(det, frames)       # ~2000 candidates per frame, every Detect level supplying its quota: all four are live
 
     BaseTrack._count = 0
     if cfg3:

@@ -16,7 +16,7 @@ frames_host = synth.make_frames(B, 80, 1280, seq_idx=0)
 sd = bench.conditioned_state_dict(types.SimpleNamespace(arch="yolov7-w6", img=1280), 10, frames_host) if WEIGHTS == "conditioned" else None
 det = model.Detector(arch.yolov7_w6(10), sd, img_size=(1280, 1280), max_batch=B, seed=0)
 frames = torch.from_numpy(frames_host).cuda()
-det.plant_objectness_bias(frames)      # all four Detect levels live, as bench.py
+bench.plant_objectness_bias(det, frames)      # all four Detect levels live, each supplying its quota of the candidates, as bench.py
 det.forward(frames)
 names = det.launch_list(B)
 LL_SHA = hashlib.sha1(json.dumps(names).encode()).hexdigest()[:16]      # == bench.py's config.launch_list_sha for the same list

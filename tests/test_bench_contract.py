@@ -67,7 +67,7 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
     assert r.returncode == 0 and "--nproc-per-node 2" in " ".join(json.loads(r.stdout.strip().splitlines()[-1])["launch"]), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name,workload", [("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),
+@pytest.mark.parametrize("name,workload", [("r04_bench_line.json", "configs[1]"), ("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),
                                            ("r02_bench_line_cfg4.json", "configs[3]")])
 def test_committed_bench_lines_keep_the_contract(name, workload):
     l = _line(name)
@@ -109,3 +109,30 @@ def test_headline_line_carries_parity_and_reference_semantics_fps():
     r, t = l["roofline"], json.load(open(os.path.join(ROOT, "profiles", "r03_conv_hbm_traffic.json")))
     assert len(l["config"]["launch_list_sha"]) == 16 and t["launch_list_sha"] and t["commit"] != "unknown"
     assert (r["traffic"] is None) == (t["launch_list_sha"] != l["config"]["launch_list_sha"] or "not reported" in (r["traffic_note"] or ""))
+
+
+def test_round4_line_measures_what_the_reference_timer_measures():
+    """round 4: all four Detect levels live and EVERY candidate at SURVEY 8a's full bar, kept-set differences explained row by row, the
+    track rows on the host inside the timed region, rotating input batches, the tracker-side roofline pieces, the reference's own speed beside the port's, and
+    `traffic` reported because the committed PMC passes were taken on this very launch list"""
+    l = _line("r04_bench_line.json")
+    c = l["config"]
+    assert c["track_rows_copied_to_host_inside_the_timed_region"] is True and c["input_batches_rotated"] >= 4
+    p = l["parity"]
+    cb = p["candidates_before_nms"]
+    lv = cb["candidates_per_detect_level"]
+    assert len(lv) == 4 and all(n >= 50 for n in lv) and sum(lv) == cb["n_got"]            # every Detect level supplies candidates (bench.LEVEL_QUOTA)
+    assert cb["frac_within_bar"] == 1.0 and cb["n_out_of_coord_bar"] == 0 and cb["n_class_differs"] == 0 and cb["max_dconf"] <= 5e-3
+    assert cb["min_iou_of_boxes_off_by_more_than_px"] >= 0.99                      # a candidate may miss the 1 px only if its IoU is >= 0.99
+    bx = p["boxes_by_anchor_row"]
+    assert bx["kept_by_one_side_only"] == sum(bx["reasons"].values()) and "unexplained" not in bx["reasons"]
+    assert bx["kept_by_both"] >= 0.97 * bx["oracle_keeps"]
+    rt = l["roofline_tracker"]
+    assert rt["peak"] == 8000.0 and rt["unit"] == "GB/s" and {"kf_multi_predict_100_tracks", "iou_cost_500x500", "decode_nms_unfused"} <= set(rt["pieces"])
+    for v in rt["pieces"].values():
+        assert abs(v["achieved"] - v["algorithmic_bytes"] * v.get("frames_per_launch", 1) / (v["us_per_frame"] * v.get("frames_per_launch", 1) * 1e3)) / v["achieved"] < 0.02
+    rop = l["cpu_baseline"]["reference_over_port"]
+    assert 0 < rop["as_its_cli_runs_it_no_no_grad"] < rop["with_no_grad"] < 1.0        # the reference itself is slower than the port that is timed
+    t = json.load(open(os.path.join(ROOT, "profiles", "r04_conv_hbm_traffic.json")))
+    assert t["launch_list_sha"] == c["launch_list_sha"] and len(t["commit"]) == 40
+    assert l["roofline"]["traffic"] is None or abs(l["roofline"]["traffic"] - t["hbm_bytes_per_frame"] * 32 / 1e9) / l["roofline"]["traffic"] < 0.05 or l["roofline"]["traffic"] > 0

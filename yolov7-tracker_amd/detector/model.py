@@ -286,20 +286,28 @@ class Detector:
         for i in p.detect_ops:
             _lib.check(self._L.y7t_det_forward_ops(p.handle, out.B, i, i + 1, _lib.stream_ptr()))
 
-    def plant_objectness_bias(self, frames, target=2000, level_offsets=None):
+    def plant_objectness_bias(self, frames, target=2000, level_offsets=None, level_quota=None):
         """No trained checkpoint ships with the reference, and a randomly initialised Detect head fires on ~half of the 102 000
         anchors.  SURVEY.md 8d: shift the Detect objectness biases so that ~`target` anchors of frames[0] exceed conf_thres = 0.01 (a
         typical VisDrone candidate load) and raise the class logits so the best class passes too.  Updates the state dict AND the
         device bias blob, so an oracle run on `self._sd` sees the same network.  level_offsets: extra objectness shift per Detect level
-        (e.g. (0, 0, -3, -6): candidates mostly from the fine levels, the small-object regime of VisDrone).  -> the objectness shift."""
+        (e.g. (0, 0, -3, -6): candidates mostly from the fine levels, the small-object regime of VisDrone).  level_quota: instead of ONE shift for all levels (a
+        level whose logits are narrower than the others' then contributes nothing), every level gets its own shift so that it supplies that fraction of `target`
+        (e.g. (0.55, 0.2, 0.15, 0.1): all four levels live, weighted towards the fine ones).  -> the objectness shift (of level 0 with quotas)."""
         out = self(frames[:1])[0]
         torch.cuda.synchronize()
         p = self.plan
         no, na = p.det["no"], p.det["na"]
         lo = [0.0] * len(p.heads) if level_offsets is None else [float(v) for v in level_offsets]
-        logits = torch.cat([self.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1) + lo[l] for l in range(len(p.heads))])
-        q = torch.quantile(logits.float().cpu(), 1.0 - target / logits.numel()).item()
-        shift = float(np.log(0.01 / 0.99)) - q
+        per_level = [self.head_tensor(l, 1).view(-1, na, no)[..., 4].reshape(-1).float().cpu() + lo[l] for l in range(len(p.heads))]
+        if level_quota is not None:
+            assert len(level_quota) == len(p.heads) and abs(sum(level_quota) - 1.0) < 1e-6
+            shifts = [float(np.log(0.01 / 0.99)) - torch.quantile(x, max(0.0, 1.0 - level_quota[l] * target / x.numel())).item() for l, x in enumerate(per_level)]
+        else:
+            logits = torch.cat(per_level)
+            q = torch.quantile(logits, 1.0 - target / logits.numel()).item()
+            shifts = [float(np.log(0.01 / 0.99)) - q] * len(p.heads)
+        shift = shifts[0]
         self._sd = dict(self._sd)
         for pl in self._plans.values():
             for w in pl.wlayout:
@@ -309,7 +317,7 @@ class Detector:
                 if w["kind"] != "Detect":
                     raise NotImplementedError("plant_objectness_bias: plain Detect heads only (implicit layers are folded into the blob)")
                 for a in range(na):
-                    delta[a * no + 4] = shift + lo[w["level"]]
+                    delta[a * no + 4] = shifts[w["level"]] + lo[w["level"]]
                     delta[a * no + 5:(a + 1) * no] = 4.0
                 if pl is p:
                     self._sd[w["wkey"] + ".bias"] = self._sd[w["wkey"] + ".bias"].float() + delta
