@@ -20,7 +20,7 @@ def last_forward(d, n_fwd):
     per = None
     # the forwards are the trailing n_fwd identical runs: find the period
     names = [disp[i]["name"] for i in ids]
-    for L in range(60, 200):
+    for L in range(60, 400):
         if len(names) >= 2 * L and names[-L:] == names[-2 * L:-L]:
             per = L; break
     if per is None: return None
@@ -57,7 +57,7 @@ try:
     meta = json.loads([l for l in open(out + "/forward_only.log") if l.startswith("{")][-1])
     rows = [r for r in csv.DictReader(open(out + "/forward_kernel_trace.csv")) if any(k in r["Kernel_Name"] for k in FWD)]
     names = [r["Kernel_Name"] for r in rows]
-    per = next(L for L in range(60, 200) if names[-L:] == names[-2 * L:-L])
+    per = next(L for L in range(60, 400) if len(names) >= 2 * L and names[-L:] == names[-2 * L:-L])      # (batch 1: ~190 launches with the split-K reduces)
     last = rows[-per:]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
     # map dispatches to ops: a split-K conv is followed by its reduce
