@@ -9,5 +9,5 @@ T=/tmp/plt_$NAME; rm -rf $T /tmp/kt_$NAME; mkdir -p $T $OUT
 ( cd /tmp; export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$NAME -- python $ROOT/scripts/forward_only.py 4 > $T/forward_only.log 2>&1
   f=$(find /tmp/kt_$NAME -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $T/forward_kernel_trace.csv
-  python3 $ROOT/scripts/profile_reduce.py $T "" unknown 2>&1 | grep "per-layer" )
-cp $T/conv_per_layer_b32.txt $OUT/per_layer_$NAME.txt 2>/dev/null || { echo "no table for $NAME"; tail -5 $T/forward_only.log; }
+  python3 $ROOT/scripts/profile_reduce.py $T "" unknown > $T/reduce.log 2>&1; grep "per-layer" $T/reduce.log )
+cp $T/conv_per_layer_b32.txt $OUT/per_layer_$NAME.txt 2>/dev/null || { echo "no table for $NAME"; cat $T/reduce.log | cut -c1-12000; tail -5 $T/forward_only.log | cut -c1-300; }

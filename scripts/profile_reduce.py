@@ -56,6 +56,7 @@ if mb:
 try:
     meta = json.loads([l for l in open(out + "/forward_only.log") if l.startswith("{")][-1])
     rows = [r for r in csv.DictReader(open(out + "/forward_kernel_trace.csv")) if any(k in r["Kernel_Name"] for k in FWD)]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))      # (the trace file is not in launch order when kernels last a few microseconds: batch 1)
     names = [r["Kernel_Name"] for r in rows]
     per = next(L for L in range(60, 400) if len(names) >= 2 * L and names[-L:] == names[-2 * L:-L])      # (batch 1: ~190 launches with the split-K reduces)
     last = rows[-per:]
@@ -84,3 +85,11 @@ try:
     print("per-layer table: TOTAL %.3f ms -> %.1f TFLOP/s" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
 except Exception as e:
     print("per-layer table failed:", repr(e))
+    try:      # what did not line up: dispatches of the last forward against the ops the launch list expects
+        print("  dispatches in the trace: %d, period %s; ops %d, of them flagged splitK %d" % (len(names), locals().get("per"), len(meta["ops"]), sum("splitK" in o["kernel"] for o in meta["ops"])))
+        short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:60]
+        tail = [short(n) for n in names[-(locals().get("per") or 220):]]
+        print("  last dispatches:", " | ".join(tail))
+        print("  expected:", " | ".join(o["kernel"][:40] for o in meta["ops"]))
+    except Exception as e2:
+        print("  (no diagnostics:", repr(e2), ")")

@@ -247,8 +247,9 @@ def test_patch_eligibility_rule():
     assert ok(80, 80, 256, 256, 32) and ok(320, 320, 64, 64, 32) and ok(40, 40, 384, 384, 32) and ok(20, 20, 512, 1024, 32)
     assert ok(20, 20, 512, 512, 32) and ok(20, 20, 256, 256, 32)      # round 4: 64-row panels (korder 9) where 128 rows give fewer than 256 workgroups, threshold 200
     assert graph.patch_panel_rows(20, 20, 512, 32) == 64 and graph.patch_panel_rows(20, 20, 1024, 32) == 128 and graph.patch_panel_rows(80, 80, 192, 32) == 64
-    assert not ok(20, 20, 512, 512, 8)                 # 8 * 400 pixels * 8 panels: below 200 workgroups' worth of 256-pixel tiles
-    assert not ok(80, 80, 256, 256, 1)                 # batch 1: too few workgroups, the split-K generic kernel is used
+    assert ok(20, 20, 512, 512, 8) and not ok(20, 20, 512, 512, 4)      # 100 workgroups' worth of 256-pixel tiles (64-row panels): 8 * 400 * 8; 4 frames are too few
+    assert ok(80, 80, 256, 256, 1) and not ok(80, 80, 256, 128, 1)      # batch 1 (round 4, profiles/r04_latency_lowering.txt): 100 workgroups win against split-K, 50 with Cin = 256 lose
+    assert ok(80, 80, 128, 128, 1) and not ok(40, 40, 128, 128, 1)      # ... 50 are enough when K is short (Cin <= 128)
     assert not ok(80, 80, 256, 256, 32, s=2) and not ok(80, 80, 256, 256, 32, k=1, p=0)
     assert not ok(80, 80, 96, 256, 32)                 # Cin % 64
     assert not ok(24, 24, 256, 256, 64)                # 24x24: 16x16 tiles 56 %, 32x8 tiles 75 %, no strip tiling for this width

@@ -146,16 +146,21 @@ def patch_panel_rows(H, W, cout, B):
     return 64 if B * H * W // 256 * (cout_pad // 128) < below else 128
 
 
-PATCH_MIN_PIX = 200 * 256      # (round 3: 256 * 256; round 4 measured the 20x20 512 -> 512 layers -- 244 / 488 workgroups -- 91 -> 70 us on the strip kernel)
+# fewest workgroups (of 256 pixels x one weight panel) the LDS-patch kernel is given.  Round 3: 256.  Round 4 measured the 20x20 layers at 32 frames (200 ... 488 workgroups:
+# 91 -> 70, 39 -> 28 us, profiles/r04_smallmap_patch.txt) and the batch-1 list (profiles/r04_latency_lowering.txt): against the generic kernel + split-K the patch kernel
+# wins from 100 workgroups (80^2 256 -> 256: 34.8 -> 26.3 us), and from 50 when K is short (Cin <= 128: 80^2 128 -> 128 20.8 -> 15.9, 160^2 64 -> 64 20.4 -> 11.8);
+# with 50 workgroups and Cin = 256 it loses (23.5 -> 26.0 us), as does the 40-wide strip with 84 (35.8 -> 38.1)
+PATCH_MIN_PIX = 100 * 256
+PATCH_MIN_PIX_SHALLOW = 50 * 256
 
 
 def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 20):
     """mirror of y7t_conv_patch_try (csrc/y7t_conv_patch.hip): 3x3 / stride 1 / pad 1, Cin % 64 == 0, 16-byte aligned fp16 output,
-    a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 200 workgroups of 256 pixels x 128 (64)
+    a 16x16 / 32x8 / strip tiling that computes at least 80 % useful pixels, and at least 100 (Cin <= 128: 50) workgroups of 256 pixels x 128 (64)
     channels at batch B (below that -- batch-1 latency mode -- the generic kernel with split-K fills the chip better)"""
     cout_pad = -(-cout // 64) * 64
     bn = patch_panel_rows(H, W, cout, B)
-    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(PATCH_MIN_PIX))):      # (the switch: A/B of the threshold)
+    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(PATCH_MIN_PIX_SHALLOW if cin <= 128 else PATCH_MIN_PIX))):      # (the switch: ONE threshold for the A/B)
         return False
     if os.environ.get("Y7T_CONV_PATCH", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
         return False
