@@ -337,6 +337,11 @@ class BaseTracker(object):
         self._layout = {self._L.y7t_tracker_field_name(i).decode(): int(offs[i]) for i in range(n)}
         self._snap_cache = None
         self._det_keep = None
+        # the frame-by-frame path (update(): one device round trip per frame, the reference's Timer semantics): detections go up through a pinned staging
+        # buffer and the pool's status word comes down beside the rows -- ONE synchronisation per frame instead of a pageable copy + two round trips
+        self._det_host = torch.zeros((self.cap_d, 6), dtype=torch.float32).pin_memory()
+        self._det_dev = torch.zeros((self.cap_d, 6), dtype=torch.float32, device="cuda")
+        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
 
     # ------------------------------------------------------------------------------------------
 
@@ -348,7 +353,7 @@ class BaseTracker(object):
         except Exception:
             pass
 
-    def _launch(self, det_results, out=None, n_dev=None, warp=None):
+    def _launch(self, det_results, out=None, n_dev=None, warp=None, staged=False):
         """enqueue one frame step (asynchronous).  out: optional (cap_t + 1, 8) float64 device tensor that receives the
         returned rows (row cap_t holds the count) instead of the tracker's own buffer -- lets a pipeline keep every
         frame's result on the device without a per-frame host round trip."""
@@ -359,6 +364,13 @@ class BaseTracker(object):
                 d = det_results.detach()
                 if d.device.type != "cuda" or d.dtype != torch.float32 or not d.is_contiguous():
                     d = d.to(device="cuda", dtype=torch.float32).contiguous()
+            elif staged:      # (the caller synchronises before the next frame: the staging buffers are free again by then)
+                a = np.asarray(det_results, dtype=np.float32).reshape(-1, 6)
+                if a.shape[0] > self.cap_d:
+                    raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (a.shape[0], self.cap_d))
+                self._det_host[:a.shape[0]].numpy()[...] = a
+                d = self._det_dev[:a.shape[0]]
+                d.copy_(self._det_host[:a.shape[0]], non_blocking=True)
             else:
                 d = torch.as_tensor(np.ascontiguousarray(det_results, dtype=np.float32)).cuda()
             d = d.reshape(-1, 6)
@@ -403,11 +415,13 @@ class BaseTracker(object):
         self._snap_cache = None
 
     def _collect(self):
+        off = self._layout["hdr_status"]
         self._out_host.copy_(self._out, non_blocking=True)
+        self._status_host.copy_(self._state[off:off + 4].view(torch.int32), non_blocking=True)
         torch.cuda.current_stream().synchronize()
         host = self._out_host.numpy()
         cnt = int(host[self.cap_t].view(np.int32)[0])
-        st = self._status()
+        st = int(self._status_host[0])
         if st:
             raise _lib.Y7TError("device track pool overflow (status %d): raise opts.max_tracks / opts.max_dets" % st)
         rows = host[:cnt]
@@ -419,7 +433,7 @@ class BaseTracker(object):
 
     def update(self, det_results, ori_img=None):
         """(N,6) [x1,y1,x2,y2,conf,cls] tensor/ndarray -> list of tracks (basetrack.py:368-487)."""
-        self._launch(det_results)
+        self._launch(det_results, staged=True)
         return self._collect()
 
     def update_without_detection(self, det_results=None, ori_img=None):
