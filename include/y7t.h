@@ -179,7 +179,9 @@ typedef struct y7t_op {
                                            4 stride-2 LDS-patch panels (detector/weights.py::panel_pack_s2); 5 the 64 -> 64 filter bank as MFMA A-fragments
                                            (weights-stationary kernel, pack_ws); 7 1x1 layers with Cout % 256 == 0: per (channel tile, 64-deep K-tile) the swizzled LDS image of the 256 x 64 panel
                                            (csrc/y7t_conv_p8.hip, weights.py::panel_pack_p8); 8 the 64 -> 128 3x3 / stride 2 filter bank as MFMA A-fragments
-                                           (csrc/y7t_conv_ws_s2.hip, pack_ws_s2) */
+                                           (csrc/y7t_conv_ws_s2.hip, pack_ws_s2); 9 / 10 as 2 / 3 with 64-row panels although Cout_pad % 128 == 0 (small maps);
+                                           11 as 8 FOLLOWED by the 128 -> 128 bank of the twin 1x1 convolution that consumes the layer (pack_ws_s2_tail) and its 128 biases
+                                           behind the layer's own: one launch computes both, Cout / out_* describe the 1x1 layer's output, the tensor between them is never written */
     int32_t detect_level;               /* -1: ordinary layer.  l >= 0: the 1x1 conv of Detect level l (models/yolo.py:46); in a fused forward
                                            (y7t_det_forward_fused) its epilogue decodes + filters instead of writing the head tensor */
     int64_t w_off;                      /* element offset into the fp16 weight blob */

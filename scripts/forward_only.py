@@ -33,7 +33,10 @@ for oi, op in enumerate(p.ops):
     d = {"op": oi, "kernel": names[oi], "H": int(op["H"]), "W": int(op["W"]), "Cin": int(op["Cin"]), "Cout": int(op["Cout"]), "k": int(op["KH"]), "s": int(op["stride"])}
     if int(op["type"]) == 0:
         wl = p.wlayout[ci]; ci += 1
-        d["gflop"] = 2 * wl["macs"] * B / 1e9
+        macs = wl["macs"]
+        if wl.get("fused_next"):      # korder 11: the stride-2 layer + the twin 1x1 behind it are ONE launch (two weight banks)
+            macs += p.wlayout[ci]["macs"]; ci += 1
+        d["gflop"] = 2 * macs * B / 1e9
         cin_bytes = (int(op["Cin"]) - int(op["up_C"])) * int(op["H"]) * int(op["W"]) + int(op["up_C"]) * int(op["H"]) * int(op["W"]) // 4
         if oi == 0 and p.stem_fused:
             cin_bytes = 3 * 1280 * 1280 // 2          # uint8 frame (bytes), expressed in fp16 elements

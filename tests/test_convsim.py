@@ -207,6 +207,45 @@ def test_stride2_weights_stationary_kernel_source_on_the_host(case, deferred):
     assert name == "ws_s2<2,32>", name
 
 
+@pytest.mark.parametrize("deferred", [0, 1], ids=["dma-at-issue", "dma-at-wait"])
+@pytest.mark.parametrize("case", WS_S2_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
+def test_stride2_weights_stationary_kernel_with_the_twin_1x1_behind_it_on_the_host(case, deferred):
+    """korder 11 (csrc/y7t_conv_ws_s2.hip, FUSE): 3x3 / stride 2 64 -> 128, activation, fp16 -- in the LDS gather, never in memory -- then the 128 -> 128 1x1 convolution
+    (the two 1x1 layers that open the next ELAN block as one) + activation.  Reference: the two layers one after the other with the tensor between them rounded to fp16."""
+    from yolov7_tracker_amd.detector import weights
+    B, H, W, act, kw = case
+    in_ld, in_coff = kw.get("in_ld", 64), kw.get("in_coff", 0)
+    out_ld, out_coff = kw.get("out_ld", 128), kw.get("out_coff", 0)
+    rng = np.random.default_rng(B * 1000 + H + W + 7)
+    x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
+    W1 = (rng.normal(0, 1, (128, 64, 3, 3)) / np.sqrt(576)).astype(np.float32)
+    W2 = (rng.normal(0, 1, (128, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
+    b1, b2 = rng.normal(0, 0.5, 128).astype(np.float32), rng.normal(0, 0.5, 128).astype(np.float32)
+    blk1 = W1.transpose(0, 2, 3, 1).reshape(128, 576).astype(np.float16)
+    blk2 = W2.reshape(128, 128).astype(np.float16)
+    wp = np.concatenate([weights.pack_ws_s2(blk1).ravel(), weights.pack_ws_s2_tail(blk2).ravel()])
+    bp = np.concatenate([b1, b2])
+    Ho, Wo = H // 2, W // 2
+    out = np.full((B, Ho, Wo, out_ld), 7.0, np.float16)
+    L = cs.lib()
+    L.cs_set_dma_deferred(deferred)
+    try:
+        rc = L.cs_conv(x.ctypes.data, in_ld, in_coff, B, H, W, 64, wp.ctypes.data, bp.ctypes.data, out.ctypes.data, out_ld, out_coff, 0, 128, 128, 3, 3, 2, 1, act, 11, 0, 0, 0)
+    finally:
+        L.cs_set_dma_deferred(0)
+    assert rc == 0, L.cs_last_error().decode()
+    assert L.cs_last_kernel().decode() == "ws_s2<2,32> + 1x1"
+    f = (lambda t: torch.nn.functional.silu(t)) if act == 1 else (lambda t: torch.nn.functional.leaky_relu(t, 0.1)) if act == 2 else (lambda t: t)
+    xt = torch.from_numpy(x[..., in_coff:in_coff + 64].astype(np.float32)).permute(0, 3, 1, 2)
+    mid = f(torch.nn.functional.conv2d(xt, torch.from_numpy(W1.astype(np.float16).astype(np.float32)), torch.from_numpy(b1), 2, 1)).half().float()
+    ref = f(torch.nn.functional.conv2d(mid, torch.from_numpy(W2.astype(np.float16).astype(np.float32)), torch.from_numpy(b2))).permute(0, 2, 3, 1).numpy()
+    got = out[..., out_coff:out_coff + 128].astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3)       # fp16 output rounding + the 1-ulp differences of the fp16 tensor between the layers (summation order)
+    other = np.ones(out_ld, bool)
+    other[out_coff:out_coff + 128] = False
+    assert np.all(out[..., other] == 7.0)
+
+
 def test_stride2_weights_stationary_fragment_reads_are_bank_conflict_free_and_packing():
     """144-byte pixels: the 16 lanes of a ds_read_b128 service group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) are 16 columns of ONE patch row -> 16 different
     16-byte bank quads for every tap plane and k-substep; and korder 8 is the documented permutation"""
@@ -220,6 +259,10 @@ def test_stride2_weights_stationary_fragment_reads_are_bank_conflict_free_and_pa
     blk = np.random.default_rng(4).permutation(128 * 576).astype(np.float64).reshape(128, 576)
     out = weights.pack_ws_s2(blk).ravel()
     assert np.array_equal(np.sort(out), np.sort(blk.ravel()))
+    blk2 = np.arange(128 * 128, dtype=np.float64).reshape(128, 128)          # the fused twin 1x1 bank: fragment (ks, q), lane l -> W2[q*32 + l%32][ks*16 + 8*(l//32) .. +7]
+    t = weights.pack_ws_s2_tail(blk2).reshape(8, 4, 64, 8)
+    for ks, q, l in ((0, 0, 0), (3, 2, 45), (7, 3, 63)):
+        assert np.array_equal(t[ks, q, l], blk2[q * 32 + l % 32, ks * 16 + 8 * (l // 32):ks * 16 + 8 * (l // 32) + 8])
     for tap, ks, q, lane in ((0, 0, 0, 0), (8, 3, 3, 63), (4, 2, 1, 37), (7, 1, 2, 5)):
         f = (tap * 4 + ks) * 4 + q
         assert np.array_equal(out[(f * 64 + lane) * 8:(f * 64 + lane) * 8 + 8], blk[q * 32 + lane % 32, tap * 64 + ks * 16 + 8 * (lane // 32):][:8])

@@ -451,6 +451,41 @@ def test_fused_detect_forward_equals_plain_forward():
         det._materialise_heads(out_b)                                     # the arena has moved on
 
 
+@pytest.mark.parametrize("B,H,W,act,kw", [(1, 4, 64, 1, {}), (2, 8, 128, 2, {"in_ld": 128, "in_coff": 64, "out_ld": 256, "out_coff": 128}), (3, 64, 192, 1, {}), (1, 640, 640, 1, {})],
+                         ids=["one-tile", "slices-leaky", "many-tiles", "640x640"])
+def test_stride2_weights_stationary_with_the_twin_1x1_behind_it(L, B, H, W, act, kw):
+    """korder 11 through the C ABI (y7t_conv2d_nhwc_f16, act bit 19): 3x3 / stride 2 64 -> 128 + activation, then -- on the tile in LDS, the tensor between the layers never
+    reaches memory -- the 128 -> 128 1x1 convolution + activation.  Reference: the two layers one after the other in fp32 on the fp16 weights, middle tensor rounded to fp16."""
+    from yolov7_tracker_amd import _lib
+    from yolov7_tracker_amd.detector import weights
+    in_ld, in_coff = kw.get("in_ld", 64), kw.get("in_coff", 0)
+    out_ld, out_coff = kw.get("out_ld", 128), kw.get("out_coff", 0)
+    rng = np.random.default_rng(B * 1000 + H + W + 11)
+    x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
+    W1 = (rng.normal(0, 1, (128, 64, 3, 3)) / np.sqrt(576)).astype(np.float32)
+    W2 = (rng.normal(0, 1, (128, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
+    b1, b2 = rng.normal(0, 0.5, 128).astype(np.float32), rng.normal(0, 0.5, 128).astype(np.float32)
+    wp = np.concatenate([weights.pack_ws_s2(W1.transpose(0, 2, 3, 1).reshape(128, 576).astype(np.float16)).ravel(),
+                         weights.pack_ws_s2_tail(W2.reshape(128, 128).astype(np.float16)).ravel()])
+    xd, wd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(wp).cuda(), torch.from_numpy(np.concatenate([b1, b2])).cuda()
+    out = torch.full((B, H // 2, W // 2, out_ld), 7.0, dtype=torch.float16, device="cuda")
+    zeros = torch.zeros(128, dtype=torch.float16, device="cuda")
+    _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(xd), in_ld, in_coff, B, H, W, 64, _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), out_ld, out_coff, 0, 128, 128, 3, 3, 2, 1,
+                                     act | 524288, _lib.ptr(zeros), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert L.y7t_last_kernel().decode() == "ws_s2<2,32> + 1x1"
+    f = F.silu if act == 1 else (lambda t: F.leaky_relu(t, 0.1))
+    xs = torch.from_numpy(x[..., in_coff:in_coff + 64].astype(np.float32)).permute(0, 3, 1, 2).cuda()
+    mid = f(F.conv2d(xs, torch.from_numpy(W1.astype(np.float16).astype(np.float32)).cuda(), torch.from_numpy(b1).cuda(), stride=2, padding=1)).half().float()
+    ref = f(F.conv2d(mid, torch.from_numpy(W2.astype(np.float16).astype(np.float32)).cuda(), torch.from_numpy(b2).cuda())).permute(0, 2, 3, 1).cpu().numpy()
+    got = out.float().cpu().numpy()
+    # the 1-ulp differences of the fp16 tensor between the layers (the device sums in another order than cuDNN-style fp32 conv) reach the output through 128 weights of
+    # size ~ 1 / sqrt(128): a few 1e-4 of the output scale, on top of the output's own fp16 rounding
+    np.testing.assert_allclose(got[..., out_coff:out_coff + 128], ref, rtol=2e-3, atol=2e-3)
+    mask = np.ones(out_ld, bool); mask[out_coff:out_coff + 128] = False
+    assert np.all(got[..., mask] == 7.0)
+
+
 def test_upsample_on_read_equals_materialised_upsample(monkeypatch):
     """nn.Upsample folded into the consuming 1x1 convs' loader (cfg/deploy/yolov7-w6.yaml:75,89,103) changes no value: heads bit-exact
     against the plan that materialises the three upsampled tensors"""

@@ -1,6 +1,8 @@
 """CPU: the torch-fp32 detector oracle (oracle/detector_torch.py) and the graph host logic, pinned against the
 reference: (a) golden vectors recorded from the reference's models.yolo.Model / utils.general.non_max_suppression
 (tests/golden/detector.npz), (b) the live reference where /root/reference exists."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,7 +40,8 @@ def test_graph_census_matches_survey():
     p = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, 1)
     n_convs = lambda pl: sum(len(w["wkey"]) if isinstance(w["wkey"], tuple) else 1 for w in pl.wlayout)
     assert n_convs(p) == 107 and abs(p.macs / 1e9 - 177.45) < 0.01
-    assert (p.ops["type"] == 0).sum() == 107 - 11       # the 11 twin 1x1 pairs of the ELAN blocks run as one launch each
+    fused_s2 = int(os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0")      # ... and the stride-2 64 -> 128 layer with the first twin pair behind it (korder 11)
+    assert (p.ops["type"] == 0).sum() == 107 - 11 - fused_s2       # the 11 twin 1x1 pairs of the ELAN blocks run as one launch each
     assert [h["stride"] for h in p.heads] == [8, 16, 32, 64] and sum(3 * h["ny"] * h["nx"] for h in p.heads) == 102000
     p = graph.lower(graph.parse(arch.yolov7_tiny(80))[0], 640, 640, 1)
     assert n_convs(p) == 58 and abs(p.macs / 1e9 - 6.85) < 0.01
@@ -260,7 +263,7 @@ def test_training_graph_spec_and_liveness():
     computed and discarded at inference (models/yolo.py:141-153) -- never reaches the launch list; the main head folds ImplicitA / ImplicitM"""
     dep = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, 1)
     trn = graph.lower(graph.parse(arch.yolov7_w6_training(10))[0], 1280, 1280, 1)
-    assert len(trn.ops) == len(dep.ops) == 99 and abs(trn.macs - dep.macs) < 1 and trn.arena_bytes == dep.arena_bytes
+    assert len(trn.ops) == len(dep.ops) == (98 if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0" else 99) and abs(trn.macs - dep.macs) < 1 and trn.arena_bytes == dep.arena_bytes
     assert [w["kind"] for w in trn.wlayout if w["kind"] != "conv"] == ["IAuxDetect"] * 4
     sd = util.training_checkpoint_state_dict(arch.yolov7_w6_training(10), graph.lower(graph.parse(arch.yolov7_w6_training(10))[0], 128, 128, 1))
     w = next(w for w in trn.wlayout if w["kind"] == "IAuxDetect")

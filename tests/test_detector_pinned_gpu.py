@@ -102,7 +102,7 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     # the stride-2 patch kernel where it measured faster than the generic kernel (four of the eight down-sampling layers; detector/graph.py::patch_s2_eligible)
     assert fam["patch_s2"] == {"auto": 4, "0": 0, "1": 8}[os.environ.get("Y7T_CONV_PATCH_S2", "auto")], fam
     if os.environ.get("Y7T_CONV_WS_S2", "1") != "0":
-        assert names[1] == "ws_s2<2,32>", names[1]                       # the 640^2 64 -> 128 stride-2 layer: filter bank in registers
+        assert names[1] == ("ws_s2<2,32> + 1x1" if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0" else "ws_s2<2,32>"), names[1]      # the 640^2 64 -> 128 stride-2 layer: filter bank in registers
     else:
         assert any(n.startswith("igemm<256,") for n in names) or os.environ.get("Y7T_CONV_PATCH_S2") == "1", hist     # 256-pixel tiles
     if os.environ.get("Y7T_CONV_WS", "1") != "0":                        # the 64 -> 64 layers with the filter bank in registers
@@ -152,7 +152,18 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             ci += 1
             x = x[:, :wl["cin"]]                                   # the stem's 12 real channels of the 16-channel layout
             k, s_, pd = int(op["KH"]), int(op["stride"]), int(op["pad"])
-            if wl["kind"] == "conv":
+            extra_tol = 0.0
+            if wl["kind"] == "conv" and wl.get("fused_next"):      # korder 11: the stride-2 layer + the twin 1x1 behind it in one launch; the tensor between them is never written
+                w2 = p.wlayout[ci]
+                ci += 1
+                assert int(op["korder"]) == 11 and w2.get("fused_prev") and isinstance(w2["wkey"], tuple)
+                mid = dt._conv_bn_act(x, sd, wl["wkey"], k, s_, pd, wl["act"], fp16=True, round_out=True)        # (fp16 in LDS, as it would be in memory)
+                ref = torch.cat([dt._conv_bn_act(mid, sd, key, 1, 1, 0, w2["act"], fp16=True, round_out=False) for key in w2["wkey"]], 1)
+                absum = torch.cat([dt.conv_abs_sum(mid, sd, key, 1, 0) for key in w2["wkey"]], 1)
+                extra_tol = 2.0 ** -11      # a 1-ulp difference of a middle value (other summation order) times its weight: bounded by 2^-11 sum |w x|
+                got = _slice(det, int(op["out_buf"]), int(op["out_ld"]), int(op["out_coff"]), int(op["Cout"]), int(op["Ho"]), int(op["Wo"]), fr)
+                got = got.float().cpu()
+            elif wl["kind"] == "conv":
                 keys = wl["wkey"] if isinstance(wl["wkey"], tuple) else (wl["wkey"],)
                 ref = torch.cat([dt._conv_bn_act(x, sd, key, k, s_, pd, wl["act"], fp16=True, round_out=False) for key in keys], 1)
                 absum = torch.cat([dt.conv_abs_sum(x, sd, key, s_, pd) for key in keys], 1)      # sum_k |w_k x_k| (+ |b|) per output
@@ -164,7 +175,7 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
                 got = det.head_tensor(wl["level"], B_BENCH)[fr].cpu()
             ref, absum = ref.permute(0, 2, 3, 1), absum.permute(0, 2, 3, 1)
             err = (got - ref).abs()
-            tol = 3e-4 + 6e-4 * ref.abs() + 2 * float(Cin * k * k) ** 0.5 * 2.0 ** -24 * absum      # |SiLU'| <= 1.1: the pre-activation bound carries over
+            tol = 3e-4 + 6e-4 * ref.abs() + (2 * float(Cin * k * k) ** 0.5 * 2.0 ** -24 + extra_tol) * absum      # |SiLU'| <= 1.1: the pre-activation bound carries over
             bad = err > tol
             if bool(bad.any()):
                 w_ = int(torch.argmax((err / tol).flatten()))
@@ -181,7 +192,7 @@ def test_every_op_matches_the_oracle_teacher_forced(bench_det):
             got = _slice(det, int(op["out_buf"]), int(op["out_ld"]), int(op["out_coff"]), Cin, ref.shape[2], ref.shape[3], fr).float().cpu()
             assert torch.equal(got, ref.permute(0, 2, 3, 1)), "op %d %s" % (oi, names[oi])
             n_other += 1
-    assert ci == len(p.wlayout) and n_conv >= 96 and n_other + n_up >= 6 and n_up == 3      # w6: all three upsamples are read through
+    assert ci == len(p.wlayout) and n_conv >= 95 and n_other + n_up >= 6 and n_up == 3      # w6: all three upsamples are read through
     print("per-op worst err / tol by kernel:", {k: "%.2e" % v for k, v in sorted(worst.items())})
 
 
@@ -382,7 +393,7 @@ def test_training_graph_checkpoint_on_the_device():
     """VERDICT r2 missing 2: the checkpoints the reference's training saves are cfg/training/yolov7-w6.yaml models -- IAuxDetect with ImplicitA /
     ImplicitM (models/yolo.py:111-158, common.py:433-456) and an aux branch that inference computes and discards (yaml :156-162).  A state dict of
     that shape (seeded, BatchNorm calibrated, non-trivial implicit layers, aux parameters present) through the product: (a) the launch list is the
-    deploy graph's (aux branch dropped: 99 ops), (b) every Detect level, teacher-forced on its actual fp16 input, equals im * (W (x + ia) + b) at
+    deploy graph's (aux branch dropped: 98 ops, the stride-2 layer + twin 1x1 pair being one), (b) every Detect level, teacher-forced on its actual fp16 input, equals im * (W (x + ia) + b) at
     the layer tolerance, (c) the raw heads end to end against the fp32 oracle (== the reference Model bit for bit on this graph,
     tests/test_detector_oracle.py) on well-conditioned weights."""
     from oracle import detector_torch as dt
@@ -395,7 +406,7 @@ def test_training_graph_checkpoint_on_the_device():
     sd = util.training_checkpoint_state_dict(spec, plan0, seed=2, bn_bias_mean=2.0, calib_image=img[:1])
     det = model.Detector(spec, sd, img_size=(H, W), max_batch=B)
     dep = model.Detector(arch.yolov7_w6(10), None, img_size=(H, W), max_batch=B)
-    assert len(det.plan.ops) == len(dep.plan.ops) == 99 and det.launch_list(B) == dep.launch_list(B)
+    assert len(det.plan.ops) == len(dep.plan.ops) == (98 if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0" else 99) and det.launch_list(B) == dep.launch_list(B)
     out = det(img)[0]
     raw = [r.cpu() for r in out.raw()]
     p = det.plan

@@ -560,7 +560,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     Y7TConvArgs a = a0;
     if (a.korder == 9) { a.korder = 2; a.panel64 = 1; }          // the patch kernel's panel order with 64-row panels
     if (a.korder == 10) { a.korder = 3; a.panel64 = 1; }         // the 1x1 panel order with 64-row panels (small maps: twice the workgroups)
-    if (a.korder == 8) return y7t_conv_ws_s2_launch(a, s);      // stride-2 register-fragment order: only that kernel reads it
+    if (a.korder == 8 || a.korder == 11) return y7t_conv_ws_s2_launch(a, s);      // stride-2 register-fragment order (11: with the twin 1x1 behind it): only that kernel reads it
     if (a.korder == 7) return y7t_conv_p8_launch(a, s);         // 256 x 64 weight panels: only that kernel reads them (plain and upsample-on-read)
     if (a.epi || a.up_C > 0) {   // fused Detect epilogue / upsample-on-read loader: instances of the 1x1 fast path only
         if (a.panel64) { y7t_set_error("conv: korder 10 (64-row 1x1 panels) is for plain 1x1 layers, not Detect-decode / upsample-on-read"); return Y7T_E_ARG; }

@@ -50,7 +50,12 @@ struct Ws2 {
     static constexpr unsigned OOB = 0xFF000000u;
 };
 
-template <int ACT>
+// FUSE: the layer's only consumers are the two 1x1 convolutions that open the next ELAN block (cfg/deploy/yolov7-w6.yaml:19-21: 128 -> 64 twice, one launch of 128 -> 128
+// in this library) -- then the 320 x 320 x 128 tensor between them is never written: a tile's activated fp16 output sits in the LDS gather anyway (64 pixels x 128
+// channels = exactly the 1x1 conv's B operand), the 1x1 filter bank is 8 more A-fragments per lane (32 registers), 16 more MFMAs per wave and tile, and the gather is
+// reused for the result.  korder 11: the 1x1 bank follows the 3x3 bank in memory (fragment (36 + ks) * 4 + q: lane l holds W2[q * 32 + l % 32][ks * 16 + 8 * (l / 32) .. + 7]),
+// its 128 biases follow the 3x3 layer's.  Saves the write and the read of 0.84 GB per 32 frames and one launch.
+template <int ACT, bool FUSE>
 __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Ws2;
@@ -126,6 +131,18 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
 #pragma unroll
         for (int e = 0; e < 4; ++e) biasv[g * 4 + e] = p.bias[wave * 32 + 8 * g + 4 * hi32 + e];
 
+    half8 w2reg[FUSE ? 8 : 1];
+    floatx16 bias2v;
+    if (FUSE) {
+        const half8* wp2 = (const half8*)p.w + C::NSUB * 256 + wave * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w2reg[ks] = wp2[ks * 256];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias2v[g * 4 + e] = p.bias[128 + wave * 32 + 8 * g + 4 * hi32 + e];
+    }
+
     unsigned pv[NPW];
     TileIt itn = tile_it(pt_first), ito = itn;      // itn: the tile whose pieces are issued next; ito: the tile being computed
     piece_offsets(itn, pv);
@@ -170,29 +187,46 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
         }
         // ---- epilogue: activation, fp16, v_permlane32_swap -> 16-byte pieces into the tile's output gather (row = pixel, 256 B, slot = chunk ^ (pixel & 15)) ----
         char* og = smem + C::OUT_OFF;
+        auto gather = [&](const floatx16 (&a)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pix = j * 32 + l31;
+            for (int j = 0; j < 2; ++j) {
+                const int pix = j * 32 + l31;
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                unsigned w[2][2];
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned w[2][2];
 #pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int g = gp * 2 + gg;
-                    float v[4];
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = gp * 2 + gg;
+                        float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[j][g * 4 + e]);
-                    typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-                    w[gg][0] = __builtin_bit_cast(unsigned, h0);
-                    w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                        for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(a[j][g * 4 + e]);
+                        typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                        half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                        w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                        w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                    }
+                    auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                    const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
+                    *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
                 }
-                auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-                const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
-                *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
             }
+        };
+        gather(acc);
+        if (FUSE) {
+            __builtin_amdgcn_s_barrier();      // the 64 pixels x 128 channels of the 3x3 layer's output are in the gather: the 1x1 layer's B operand
+            floatx16 acc2[2];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pix = j * 32 + l31, ch = ks * 2 + hi32;      // channels 16 ks + 8 (lane / 32) .. + 7 of pixel `pix`
+                    const half8 xf = *(const half8*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2reg[ks], xf, ks == 0 ? bias2v : acc2[j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_barrier();      // everybody has read the gather: it takes the 1x1 layer's output now
+            gather(acc2);
         }
         __builtin_amdgcn_s_barrier();      // the four waves' pieces of every pixel are in place
         {
@@ -227,9 +261,10 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+#define WS2_ATTR(ACT) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
+                      Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        WS2_ATTR(Y7T_ACT_NONE) WS2_ATTR(Y7T_ACT_SILU) WS2_ATTR(Y7T_ACT_LEAKY)
+#undef WS2_ATTR
         attr = true;
     }
     static int ncu = -1;      // one persistent workgroup per compute unit (154 KiB of LDS, 144 + registers of weights per lane)
@@ -241,10 +276,14 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
     }
     const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
-    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
-    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
-    else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
+    const bool fuse = a.korder == 11;      // + the twin 1x1 convolution behind it (its bank and biases follow this layer's)
+#define WS2_GO(ACT) do { if (fuse) hipLaunchKernelGGL((k_conv3x3s2_c64_ws<ACT, true>), dim3(grid), dim3(256), C::LDS, s, a); \
+                         else hipLaunchKernelGGL((k_conv3x3s2_c64_ws<ACT, false>), dim3(grid), dim3(256), C::LDS, s, a); } while (0)
+    if (a.act == Y7T_ACT_SILU) WS2_GO(Y7T_ACT_SILU);
+    else if (a.act == Y7T_ACT_LEAKY) WS2_GO(Y7T_ACT_LEAKY);
+    else WS2_GO(Y7T_ACT_NONE);
+#undef WS2_GO
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("ws_s2<2,32>");
+    y7t_note_kernel(fuse ? "ws_s2<2,32> + 1x1" : "ws_s2<2,32>");
     return 0;
 }

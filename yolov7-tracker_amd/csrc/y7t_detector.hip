@@ -203,7 +203,7 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Cout = Cout; a.Cout_pad = Cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act & 0xff; a.zeros = (const _Float16*)zeros16;
-    a.korder = (act >> 18) & 1 ? 10 : (act >> 17) & 1 ? 9 : (act >> 16) & 1 ? 8 : (act >> 15) & 1 ? 7 : (act >> 13) & 1 ? 5 : (act >> 12) & 1 ? 4 : (act >> 11) & 1 ? 3 : (act >> 10) & 1 ? 2 : (act >> 8) & 1;   // `act` bit 8: (kh, chunk, kw) K order; bit 10: patch-kernel panels; bit 11: 1x1 panels; bit 12: stride-2 patch-kernel panels; bit 13: register-fragment order of the weights-stationary 64 -> 64 kernel
+    a.korder = (act >> 19) & 1 ? 11 : (act >> 18) & 1 ? 10 : (act >> 17) & 1 ? 9 : (act >> 16) & 1 ? 8 : (act >> 15) & 1 ? 7 : (act >> 13) & 1 ? 5 : (act >> 12) & 1 ? 4 : (act >> 11) & 1 ? 3 : (act >> 10) & 1 ? 2 : (act >> 8) & 1;   // `act` bit 8: (kh, chunk, kw) K order; bit 10: patch-kernel panels; bit 11: 1x1 panels; bit 12: stride-2 patch-kernel panels; bit 13: register-fragment order of the weights-stationary 64 -> 64 kernel
     a.force_patch = (act >> 9) & 1;   // bit 9: force the LDS-patch kernel for an eligible 3x3/s1 layer (tests)
     return y7t_conv_launch(a, (hipStream_t)stream);
 }

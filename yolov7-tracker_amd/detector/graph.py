@@ -328,7 +328,9 @@ def lower(nodes, H, W, max_batch=1):
     w_off = b_off = 0
     heads = []
 
-    def emit_conv(n, src, out_buf, out_ld, out_coff, out_f32, cout, act, wkey, kind="conv", level=-1):
+    def emit_conv(n, src, out_buf, out_ld, out_coff, out_f32, cout, act, wkey, kind="conv", level=-1, fuse_twin=None):
+        """fuse_twin = (a, b): `n` is the 64 -> 128 stride-2 layer and its only consumers are the twin 1x1 convs a, b -- ONE op (korder 11, csrc/y7t_conv_ws_s2.hip) whose
+        output is the twins' concat slice; the tensor between them is never written.  Two wlayout entries (the 3x3 bank, then the 1x1 bank: adjacent in the blobs)."""
         nonlocal w_off, b_off
         cin_real = src.c
         cin = _rup(cin_real, 8) if src.kind not in ("input", "reorg") else in_ld
@@ -363,7 +365,20 @@ def lower(nodes, H, W, max_batch=1):
                     -(-max_batch * n.h * n.w // 128) * (cout_pad // 128) < int(os.environ.get("Y7T_CONV_1X1_PANEL64_BELOW", "500"))):
                 korder = 10                          # ... as 64-row panels where 128-row tiles number fewer than 500 (round 4, profiles/r04_smallmap_patch.txt: the 20x20
                                                      # layers with <= 512 output channels 34 -> 30, 61 -> 53, 20 -> 18 us; at 800 tiles and above 64 rows lose)
+        if fuse_twin is not None:
+            assert korder == 8 and cout == 128 and K_pad == K
+            korder = 11
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level
+        if fuse_twin is not None:
+            ta, tb = fuse_twin
+            ops.append(op)
+            wlayout.append(dict(korder=8, wkey=wkey, cin=cin_real, cin_pad=cin, cout=n.c, cout_pad=128, k=n.k, K=K, K_pad=K_pad, w_off=w_off, b_off=b_off, kind=kind, act=act,
+                                macs=n.h * n.w * n.c * n.k * n.k * cin_real, fused_next=True))
+            wlayout.append(dict(korder=12, wkey=(ta.wkey, tb.wkey), cin=n.c, cin_pad=n.c, cout=ta.c + tb.c, cout_pad=128, k=1, K=n.c, K_pad=n.c, w_off=w_off + 128 * K_pad,
+                                b_off=b_off + 128, kind=kind, act=act, macs=n.h * n.w * (ta.c + tb.c) * n.c, fused_prev=True))
+            w_off += 128 * K_pad + 128 * n.c
+            b_off += 256
+            return
         if getattr(src, "virt_up", None) is not None:      # upsample-on-read: part of this concat exists only at half resolution
             un, uoff = src.virt_up
             t = nodes[un.src[0]]
@@ -408,15 +423,34 @@ def lower(nodes, H, W, max_batch=1):
     pending_copies = {}
     for j, cidx, off in extra_copies:
         pending_copies.setdefault(j, []).append((cidx, off))
+    # ---- the 64 -> 128 stride-2 layer + the twin 1x1 behind it as one op (csrc/y7t_conv_ws_s2.hip, FUSE): when the twins are the layer's ONLY consumers ----
+    fuse_s2 = {}       # idx of the 3x3 node -> (a, b); the twin op is not emitted
+    if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0":      # (measured, round 4: 667 + 328 us as two launches -> 913 us as one; in the pipeline the list -0.15 ms)
+        consumers = {}
+        for m in nodes:
+            if m.idx in live or m.kind == "detect":
+                for j in m.src:
+                    consumers.setdefault(j, set()).add(m.idx)
+        for first_idx, (ta, tb) in twins.items():
+            j = ta.src[0]
+            t = nodes[j]
+            if (t.kind == "conv" and t.k == 3 and t.s == 2 and t.c == 128 and ta.c + tb.c == 128 and ta.act == t.act == tb.act and consumers.get(j) == {ta.idx, tb.idx}
+                    and j not in pending_copies and ta.idx not in pending_copies and tb.idx not in pending_copies and nodes[t.src[0]].c == 64
+                    and ws_s2_eligible(nodes[t.src[0]].h, nodes[t.src[0]].w, 64, 128, 3, 2, t.p, ta.ld, ta.coff, 0, nodes[t.src[0]].ld, nodes[t.src[0]].coff, max_batch)):
+                fuse_s2[j] = (ta, tb)
+    fused_twin_done = {min(ta.idx, tb.idx) for ta, tb in fuse_s2.values()}
     for n in nodes:
         if n.idx not in live and n.kind != "detect":
             continue
         if n.kind in ("input", "reorg", "concat"):
             pass
         elif n.kind == "conv":
-            if n.idx in fused_into:
+            if n.idx in fused_into or n.idx in fused_twin_done:
                 continue
-            if n.idx in twins:
+            if n.idx in fuse_s2:
+                ta, tb = fuse_s2[n.idx]
+                emit_conv(n, nodes[n.src[0]], ta.home, ta.ld, ta.coff, 0, ta.c + tb.c, n.act, n.wkey, fuse_twin=(ta, tb))
+            elif n.idx in twins:
                 a, b = twins[n.idx]
                 fn = Node("conv", n.src, a.c + b.c, 1, 1, 0, n.act)
                 fn.h, fn.w = n.h, n.w

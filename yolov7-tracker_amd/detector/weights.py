@@ -199,6 +199,15 @@ def pack_ws_s2(blk):
     return np.ascontiguousarray(a).reshape(128, 576)
 
 
+def pack_ws_s2_tail(blk):
+    """[128][128] block of the twin 1x1 convolution fused behind the stride-2 layer (korder 11 ops; wlayout korder 12)  ->  its 8 x 4 A-fragments behind the 3x3 bank:
+    fragment (ks, q) is 1 KiB, lane l holding W2[q*32 + l % 32][ks*16 + 8*(l // 32) .. +7]"""
+    assert blk.shape == (128, 128)
+    a = blk.reshape(4, 32, 8, 2, 8)             # [q][l31][ks][hi][8]
+    a = a.transpose(2, 0, 3, 1, 4)              # [ks][q][hi][l31][8]
+    return np.ascontiguousarray(a).reshape(128, 128)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -226,6 +235,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = panel_pack_p8(blk)
         elif w.get("korder") == 8:
             blk = pack_ws_s2(blk)
+        elif w.get("korder") == 12:
+            blk = pack_ws_s2_tail(blk)
         wb[w["w_off"]:w["w_off"] + blk.size] = blk.reshape(-1)
         bb[w["b_off"]:w["b_off"] + cout] = b.astype(np.float32)
     return wb, bb
