@@ -406,7 +406,8 @@ def test_training_graph_checkpoint_on_the_device():
     sd = util.training_checkpoint_state_dict(spec, plan0, seed=2, bn_bias_mean=2.0, calib_image=img[:1])
     det = model.Detector(spec, sd, img_size=(H, W), max_batch=B)
     dep = model.Detector(arch.yolov7_w6(10), None, img_size=(H, W), max_batch=B)
-    assert len(det.plan.ops) == len(dep.plan.ops) == (98 if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0" else 99) and det.launch_list(B) == dep.launch_list(B)
+    n_fused = int((dep.plan.ops["korder"] == 11).sum())      # (the stride-2 layer + twin 1x1 pair is one op where the map is large enough for that kernel)
+    assert len(det.plan.ops) == len(dep.plan.ops) == 99 - n_fused and det.launch_list(B) == dep.launch_list(B)
     out = det(img)[0]
     raw = [r.cpu() for r in out.raw()]
     p = det.plan
