@@ -159,6 +159,52 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
     half_t* outp = (half_t*)p.out;
     typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
 
+    // ---- epilogue pieces: activation, fp16, v_permlane32_swap -> 16-byte pieces into the tile's output gather (row = pixel, 256 B, slot = chunk ^ (pixel & 15)) ----
+    char* og = smem + C::OUT_OFF;
+    // chunk c of 8 ACTIVATED values y[0..7] of a lane (MFMA tile j = c / 2, group pair gp = c % 2) -> fp16, lanes paired, one 16-byte piece into the gather
+    auto put_chunk = [&](const float* y, int c) __attribute__((always_inline)) {
+        const int j = c >> 1, gp = c & 1, pix = j * 32 + l31;
+        typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+        unsigned w[2][2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            half2v h0 = {(half_t)y[gg * 4 + 0], (half_t)y[gg * 4 + 1]}, h1 = {(half_t)y[gg * 4 + 2], (half_t)y[gg * 4 + 3]};
+            w[gg][0] = __builtin_bit_cast(unsigned, h0);
+            w[gg][1] = __builtin_bit_cast(unsigned, h1);
+        }
+        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+        const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
+        *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
+    };
+    auto gather = [&](const floatx16 (&a)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = act_t<ACT>(a[c >> 1][(c & 1) * 8 + e]);
+            put_chunk(y, c);
+        }
+    };
+    auto store_tile = [&](const TileIt& it) __attribute__((always_inline)) {      // the gathered tile out as full lines: 64 pixels x 16 chunks = 1024 pieces of 16 bytes, 4 per thread
+        const int oy = it.ty * TH, ox = it.tx * TW;
+        uint4v v[4];      // the four reads first, then the four stores (left alone the compiler waits for each read in front of its store)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = k * 256 + tid, pix = c >> 4, ch = c & 15;
+            v[k] = *(const uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = k * 256 + tid, pix = c >> 4, ch = c & 15;
+            const int gy = oy + (pix >> 5), gx = ox + (pix & 31);
+            *(uint4v*)(outp + ((size_t)(it.b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + ch * 8) = v[k];
+        }
+    };
+    floatx16 acc2[2];
+
     int buf = 0;
     for (int t = 0; t < nt; ++t) {
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
@@ -168,7 +214,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
         if (t == 0) WS2_VMCNT(12, 12);
         else if (t == 1) WS2_VMCNT(16, 12);
         else WS2_VMCNT(20, 12);
-        __builtin_amdgcn_s_barrier();      // everybody's pieces of tile t are visible; nobody reads the buffer of tile t - 1 or the output gather of tile t - 1 any more
+        __builtin_amdgcn_s_barrier();      // everybody's pieces of tile t are visible; nobody reads the buffer of tile t - 1 or the output gather (as the 1x1 layer's operand) any more
         piece_offsets(itn, pv);            // tile t + 2 goes into the buffer tile t - 1 used
 #pragma unroll
         for (int i = 0; i < NPW; ++i) issue_piece(nbuf, pv[i], i);
@@ -176,69 +222,54 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3s2_c64_ws(const Y7TConvArgs p
 
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
         floatx16 acc[2];
+        auto frag = [&](int sn, int j) __attribute__((always_inline)) -> half8 {      // pixel fragment of substep sn = tap * 4 + ks for MFMA tile j
+            const int tap = sn >> 2, ks = sn & 3, kh = tap / 3, kw = tap - kh * 3;
+            return *(const half8*)(pb + (2 * j + kh) * RP + (kw == 1 ? C::O_OFF : kw == 2 ? PIXB : 0) + ks * 32);
+        };
+        // The fragment reads run three substeps ahead BY HAND and the order of a slot (MFMA, the read for three substeps on, ...) is pinned with sched_barrier: left
+        // to itself the compiler put most reads right in front of their MFMA behind an s_waitcnt lgkmcnt(0) -- one LDS round trip (~100 clocks) per 32-clock MFMA
+        // (round 4: the kernel ran at 40 % of its MFMA time for that reason, not for its DMAs)
+        half8 xq[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xq[q][j] = frag(q, j);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < C::NSUB; ++s) {
-            const int tap = s >> 2, ks = s & 3, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const half8 xf = *(const half8*)(pb + (2 * j + kh) * RP + (kw == 1 ? C::O_OFF : kw == 2 ? PIXB : 0) + ks * 32);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xf, s == 0 ? biasv : acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], xq[s % 3][j], s == 0 ? biasv : acc[j], 0, 0, 0);
+                if (s + 3 < C::NSUB) xq[s % 3][j] = frag(s + 3, j);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- epilogue: activation, fp16, v_permlane32_swap -> 16-byte pieces into the tile's output gather (row = pixel, 256 B, slot = chunk ^ (pixel & 15)) ----
-        char* og = smem + C::OUT_OFF;
-        auto gather = [&](const floatx16 (&a)[2]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pix = j * 32 + l31;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    unsigned w[2][2];
-#pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const int g = gp * 2 + gg;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(a[j][g * 4 + e]);
-                        typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-                        half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
-                        w[gg][0] = __builtin_bit_cast(unsigned, h0);
-                        w[gg][1] = __builtin_bit_cast(unsigned, h1);
-                    }
-                    auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                    const uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
-                    const int ch = wave * 4 + gp * 2 + hi32;      // 16-byte chunk (8 channels) of the pixel's 128 channels
-                    *(uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4)) = pk;
-                }
-            }
-        };
         gather(acc);
         if (FUSE) {
             __builtin_amdgcn_s_barrier();      // the 64 pixels x 128 channels of the 3x3 layer's output are in the gather: the 1x1 layer's B operand
-            floatx16 acc2[2];
+            auto frag2 = [&](int ks, int j) __attribute__((always_inline)) -> half8 {      // channels 16 ks + 8 (lane / 32) .. + 7 of pixel j * 32 + lane % 32
+                const int pix = j * 32 + l31, ch = ks * 2 + hi32;
+                return *(const half8*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
+            };
+            half8 x2[3][2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) x2[q][j] = frag2(q, j);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int pix = j * 32 + l31, ch = ks * 2 + hi32;      // channels 16 ks + 8 (lane / 32) .. + 7 of pixel `pix`
-                    const half8 xf = *(const half8*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2reg[ks], xf, ks == 0 ? bias2v : acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2reg[ks], x2[ks % 3][j], ks == 0 ? bias2v : acc2[j], 0, 0, 0);
+                    if (ks + 3 < 8) x2[ks % 3][j] = frag2(ks + 3, j);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             __builtin_amdgcn_s_barrier();      // everybody has read the gather: it takes the 1x1 layer's output now
             gather(acc2);
         }
         __builtin_amdgcn_s_barrier();      // the four waves' pieces of every pixel are in place
-        {
-            const int oy = ito.ty * TH, ox = ito.tx * TW;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                     // 64 pixels x 16 chunks = 1024 pieces of 16 bytes: 4 per thread, 16 lanes per pixel (two full lines)
-                const int c = k * 256 + tid, pix = c >> 4, ch = c & 15;
-                const uint4v v = *(const uint4v*)(og + pix * 256 + ((ch ^ (pix & 15)) << 4));
-                const int gy = oy + (pix >> 5), gx = ox + (pix & 31);
-                *(uint4v*)(outp + ((size_t)(ito.b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + ch * 8) = v;
-            }
-        }
+        store_tile(ito);
         tile_next(ito);
         buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
     }
