@@ -250,12 +250,23 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
         }
     P8_WAVE_SYNC();
     half_t* outp = (half_t*)p.out;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int px = k * 8 + (lane >> 3), ch = lane & 7;
-        const uint4v v = *(const uint4v*)(scr + px * 128 + ((ch ^ (px & 7)) << 4));
-        const int m = m0 + grp * 128 + px, n = n0 + wq * 64 + ch * 8;
-        if (m < p.M && n < p.Cout && !(ABL & 16)) *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v;
+    // 16 pieces of 16 bytes per lane, eight at a time: the LDS reads of a group first, then its stores (left alone the compiler waited for every read in front of its
+    // store -- and with one workgroup per CU nothing else runs meanwhile; round 4, as y7t_conv_patch.hip)
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16; k0 += 8) {
+        uint4v v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = (k0 + k) * 8 + (lane >> 3), ch = lane & 7;
+            v[k] = *(const uint4v*)(scr + px * 128 + ((ch ^ (px & 7)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = (k0 + k) * 8 + (lane >> 3), ch = lane & 7;
+            const int m = m0 + grp * 128 + px, n = n0 + wq * 64 + ch * 8;
+            if (m < p.M && n < p.Cout && !(ABL & 16)) *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v[k];
+        }
     }
 #endif
 }

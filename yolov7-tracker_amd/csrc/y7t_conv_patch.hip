@@ -383,21 +383,32 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_patch(const Y7TConvArgs p) {
         typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
         constexpr int CPP = BN / 8;
         half_t* outp = (half_t*)p.out;
-#pragma unroll 4
-        for (int cidx = tid; cidx < 256 * CPP; cidx += 256) {
-            const int pix = cidx / CPP, ch = cidx - pix * CPP;
-            const int n = n0 + ch * 8;
-            long long opix;
-            if (FLAT) opix = otab[pix];
-            else {
-                constexpr int TWd = FLAT ? 1 : TW;
-                const int r = pix / TWd, x = pix - r * TWd;
-                const int gy = h0 + r, gx = w0 + x;
-                opix = (gy < p.H && gx < p.W) ? (long long)(b * p.H + gy) * p.W + gx : -1;
+        // CPP pieces of 16 bytes per thread, in groups of GRP: the group's LDS reads first (every address is inside the tile), then its stores -- left alone the
+        // compiler put every read right in front of its store behind s_waitcnt lgkmcnt(0): 8 or 16 LDS round trips in a row at the end of every workgroup
+        constexpr int GRP = CPP < 8 ? CPP : 8;
+        static_assert(CPP % GRP == 0, "whole groups");
+#pragma unroll 1
+        for (int c0 = 0; c0 < CPP; c0 += GRP) {
+            uint4v v[GRP];
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int cidx = tid + (c0 + k) * 256, pix = cidx / CPP, ch = cidx - pix * CPP;
+                v[k] = *(const uint4v*)(smem + pix * OROW + ch * 16);
             }
-            if (opix >= 0 && n < p.Cout) {
-                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
-                *(uint4v*)(outp + (size_t)opix * p.ldout + p.cout_off + n) = v;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int cidx = tid + (c0 + k) * 256, pix = cidx / CPP, ch = cidx - pix * CPP;
+                const int n = n0 + ch * 8;
+                long long opix;
+                if (FLAT) opix = otab[pix];
+                else {
+                    constexpr int TWd = FLAT ? 1 : TW;
+                    const int r = pix / TWd, x = pix - r * TWd;
+                    const int gy = h0 + r, gx = w0 + x;
+                    opix = (gy < p.H && gx < p.W) ? (long long)(b * p.H + gy) * p.W + gx : -1;
+                }
+                if (opix >= 0 && n < p.Cout) *(uint4v*)(outp + (size_t)opix * p.ldout + p.cout_off + n) = v[k];
             }
         }
     }

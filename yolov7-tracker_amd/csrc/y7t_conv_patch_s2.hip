@@ -261,14 +261,24 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(co
         typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
         constexpr int CPP = BN / 8;
         half_t* outp = (half_t*)p.out;
-#pragma unroll 4
-        for (int cidx = tid; cidx < TW * TH * CPP; cidx += C::NT) {
-            const int pix = cidx / CPP, ch = cidx - pix * CPP;
-            const int n = n0 + ch * 8;
-            const int gy = h0 + (pix >> 4), gx = w0 + (pix & 15);
-            if (gy < p.Ho && gx < p.Wo && n < p.Cout) {
-                const uint4v v = *(const uint4v*)(smem + pix * OROW + ch * 16);
-                *(uint4v*)(outp + ((size_t)(b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + n) = v;
+        // the pieces of 16 bytes of a thread in groups: a group's LDS reads first (every address is inside the tile), then its stores (as y7t_conv_patch.hip, round 4)
+        constexpr int PER = TW * TH * CPP / C::NT, GRP = PER % 8 == 0 ? 8 : PER % 4 == 0 ? 4 : 1;
+        static_assert(TW * TH * CPP % C::NT == 0, "whole pieces per thread");
+#pragma unroll 1
+        for (int g0 = 0; g0 < PER; g0 += GRP) {
+            uint4v v[GRP];
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int cidx = tid + (g0 + k) * C::NT, pix = cidx / CPP, ch = cidx - pix * CPP;
+                v[k] = *(const uint4v*)(smem + pix * OROW + ch * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int cidx = tid + (g0 + k) * C::NT, pix = cidx / CPP, ch = cidx - pix * CPP;
+                const int n = n0 + ch * 8;
+                const int gy = h0 + (pix >> 4), gx = w0 + (pix & 15);
+                if (gy < p.Ho && gx < p.Wo && n < p.Cout) *(uint4v*)(outp + ((size_t)(b * p.Ho + gy) * p.Wo + gx) * p.ldout + p.cout_off + n) = v[k];
             }
         }
     }
