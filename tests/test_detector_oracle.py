@@ -258,6 +258,24 @@ def test_patch_eligibility_rule():
     assert not ok(24, 24, 256, 256, 64)                # 24x24: 16x16 tiles 56 %, 32x8 tiles 75 %, no strip tiling for this width
 
 
+def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
+    """Which kernel family each conv of the benchmarked configuration (w6 @ 1280, 32 frames) is lowered to, as `korder` counts -- every rule behind them was set by
+    an in-session A/B on the device (profiles/r03_*, r04_*); a change here is a change of the measured launch list.  And the batch-1 list."""
+    for k in ("Y7T_CONV_WS_S2_FUSE", "Y7T_CONV_PATCH_MIN_PIX", "Y7T_CONV_PATCH_PANEL64_BELOW", "Y7T_CONV_1X1_PANEL64_BELOW", "Y7T_CONV_P8", "Y7T_CONV_WS", "Y7T_CONV_WS_S2",
+              "Y7T_CONV_PATCH_S2", "Y7T_CONV_PATCH", "Y7T_CONV_VARIANT", "Y7T_CONV_WPANEL"):
+        monkeypatch.delenv(k, raising=False)
+    import collections
+    hist = lambda B: dict(sorted(collections.Counter(int(o["korder"]) for o in graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, B).ops if int(o["type"]) == 0).items()))
+    # 0 stem (fused frame -> conv kernel); 1 generic 3x3 (three stride-2 layers); 2 LDS-patch (16x16 tiles + 40-wide strips); 3 1x1 panels (incl. 3 upsample-on-read, 4 Detect);
+    # 4 stride-2 LDS-patch; 5 weights-stationary 64 -> 64; 7 p8; 9 patch with 64-row panels (the 20x20 layers); 10 1x1 with 64-row panels (< 500 tiles);
+    # 11 the stride-2 weights-stationary layer + the twin 1x1 behind it in one launch
+    assert hist(32) == {0: 1, 1: 3, 2: 33, 3: 24, 4: 4, 5: 7, 7: 5, 9: 10, 10: 7, 11: 1}
+    h1 = hist(1)
+    assert h1 == {0: 1, 1: 33, 2: 8, 3: 8, 9: 16, 10: 28, 11: 1} and h1.get(5, 0) == 0 and h1.get(7, 0) == 0 and h1.get(4, 0) == 0      # one frame: no persistent 64 -> 64 / p8 / stride-2 patch launches
+    monkeypatch.setenv("Y7T_CONV_WS_S2_FUSE", "0")
+    assert hist(32)[8] == 1 and 11 not in hist(32) and hist(32)[3] == 25
+
+
 def test_training_graph_spec_and_liveness():
     """cfg/training/yolov7-w6.yaml (what the reference's training saves, README.md:101): the aux branch -- convs 118-121 and IAuxDetect's m2 convs,
     computed and discarded at inference (models/yolo.py:141-153) -- never reaches the launch list; the main head folds ImplicitA / ImplicitM"""
