@@ -161,6 +161,20 @@ exp_spp3)
   grep -h "maxpool\|spp3\|ws_s2\| 0 stem\|TOTAL" $O/per_layer_spp3.txt $O/per_layer_nospp3.txt | cut -c1-120 | tee -a $O/summary.txt
   ;;
 
+r5_chained)
+  say "r5_chained: the chained detect -> NMS -> ByteTrack parity run (tests/test_chained_gpu.py, VERDICT r4 next 1)"
+  timeout 900 python -m pytest -x -q -m gpu -s tests/test_chained_gpu.py > $O/t_chained.log 2>&1; echo "rc=$?" >> $O/t_chained.log
+  grep -h "hand-over of\|graded against" $O/t_chained.log | cut -c1-700 | tee -a $O/summary.txt; tailsum $O/t_chained.log 6
+  ;;
+
+r5_wgs)
+  say "r5_wgs: persistent kernels over-decomposed (Y7T_CONV_WS_WGS = 256 default / 512 / 1024: the hardware dispatcher as the dynamic scheduler), bench lines in one session"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  for w in 256 512 1024 256; do
+    Y7T_CONV_WS_WGS=$w timeout 300 python bench.py $X > $O/bench_wgs$w.json 2> $O/bench_wgs$w.err; benchsum wgs$w
+  done
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

@@ -29,6 +29,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 B_BENCH = 32
+# the score noise the kept-set explanations may invoke is an A-PRIORI bound, not the run's own maximum (a larger kernel error must not widen its own
+# tolerance): SURVEY 8a's confidence bar is 5e-3; ~60 fp16-stored tensors in a row predict 0.2 % of the logit spread = ~2e-3 in confidence at the sigmoid's steepest
+# point, the worst value ever measured on this network is 3.3e-3
+SCORE_NOISE = 4e-3
 CHECK_FRAMES = [0, 13, 31]      # frames whose every pixel is compared (first / middle / last M rows of every tile grid)
 
 
@@ -46,11 +50,12 @@ def bench_det():
     return det, frames_host, out
 
 
-def _conditioned_detector(damp_wh):
+def _conditioned_detector(damp_wh, obj_gain=1.0, level_quota=None):
     """the benchmarked launch list on well-conditioned weights (BatchNorm shifts ~ +2, statistics calibrated on frame 0 of the scene); ALL FOUR Detect levels
     live (no per-level objectness offsets: ~2000 candidates per frame wherever the head puts them).  damp_wh: factor on the width / height rows of the Detect
     convs -- 0.25 gives boxes of roughly anchor size (19 ... 1000 px: what a trained head produces), 1.0 leaves the random head's logits as they are
-    (sigmoids saturate: boxes of up to 4 x the anchor, 2000+ px on the coarse levels)"""
+    (sigmoids saturate: boxes of up to 4 x the anchor, 2000+ px on the coarse levels).  obj_gain: factor on the objectness rows (a head that is CONFIDENT about some of
+    its ~2000 candidates -- what the tracker's 0.2 / 0.3 thresholds need: tests/test_chained_gpu.py); level_quota: share of the candidates per Detect level (default bench.LEVEL_QUOTA)"""
     from yolov7_tracker_amd import synth
     from yolov7_tracker_amd.detector import arch, graph, model, weights
     spec = arch.ARCHS["yolov7-w6"](10)
@@ -59,16 +64,20 @@ def _conditioned_detector(damp_wh):
     nodes, _ = graph.parse(spec)
     plan = graph.lower(graph.parse(spec)[0], 1280, 1280, 1)
     sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, 0, bn_bias_mean=2.0), seed=0, image=cal)
-    if damp_wh != 1.0:
+    if damp_wh != 1.0 or obj_gain != 1.0:
         for k in list(sd):
             if ".m." in k and k.endswith(".weight"):                 # Detect 1x1 convs: rows (anchor, [x, y, w, h, obj, cls...])
                 w = sd[k].clone().view(3, 15, -1)
                 w[:, 2:4] *= damp_wh
+                w[:, 4] *= obj_gain
                 sd[k] = w.view(45, -1, 1, 1)
     det = model.Detector(spec, sd, img_size=(1280, 1280), max_batch=B_BENCH)
     frames = torch.from_numpy(frames_host).cuda()
     import bench
-    bench.plant_objectness_bias(det, frames)                             # all four Detect levels live (bench.LEVEL_QUOTA)
+    if level_quota is None:
+        bench.plant_objectness_bias(det, frames)                         # all four Detect levels live (bench.LEVEL_QUOTA)
+    else:
+        det.plant_objectness_bias(frames, 2000, level_quota=level_quota)
     out = det(frames)[0]
     torch.cuda.synchronize()
     return det, frames_host, out
@@ -275,12 +284,13 @@ def _kept_rows_check(det, frames_host, fr, coord_rel=0.0):
             assert ok_c and ds <= 5e-3 and (row[5] == float(ref[j, 5]) or want[int(r)][3][int(row[5])] >= want[int(r)][1] - 5e-3), (b, int(r), row, rb[j], ref[j])
             worst_c, worst_s = max(worst_c, dc if dc <= 1.0 else 0.0), max(worst_s, ds)
         common = sorted(set(got) & set(want))
-        noise = max(1e-4, max(abs(got[r][1] - want[r][1]) for r in common))      # the measured score noise of this frame's candidates
-        ex = dt.explain_kept_set_difference(got, kd, want, kw, score_noise=noise)
+        noise = max(abs(got[r][1] - want[r][1]) for r in common)                 # the measured score noise of this frame's candidates ...
+        assert noise <= SCORE_NOISE, (b, noise)                                  # ... must be inside the a-priori bound the explanations are allowed to use
+        ex = dt.explain_kept_set_difference(got, kd, want, kw, score_noise=SCORE_NOISE)
         reasons = collections.Counter(v or "UNEXPLAINED" for v in ex.values())
         print("frame %d: oracle keeps %d, device %d, %d rows kept by both (all at the 8a bar: max |dcoord| %.0f px among the <= 1 px ones, %d pass on IoU >= 0.99 -- %d of them on the box before scale_coords' clip --, max |dconf| %.2e); "
-              "%d rows kept on one side only: %s (score noise %.2e)" % (b, len(kw), n, both, worst_c, n_iou, n_preclip, worst_s, len(ex), dict(reasons), noise))
-        assert len(kw) >= 100 and both >= 0.9 * len(kw)
+              "%d rows kept on one side only: %s (measured score noise %.2e, allowed %.1e)" % (b, len(kw), n, both, worst_c, n_iou, n_preclip, worst_s, len(ex), dict(reasons), noise, SCORE_NOISE))
+        assert len(kw) >= 100 and both >= 0.95 * len(kw)      # (measured: 290-298 of 300)
         if not all(v is not None for v in ex.values()):      # leave the two candidate sets behind for an off-line look (gpurun_out/ travels back from the GPU box)
             import pickle
             os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
