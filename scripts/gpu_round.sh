@@ -175,6 +175,23 @@ r5_wgs)
   done
   ;;
 
+r5_dyn)
+  say "r5_dyn a: parity -- ws64 / ws128 layer cases (static partition through the single-layer entry point), the tile-counter forms inside a plan, then the benchmarked list op by op (ws64 dyn; and with Y7T_CONV_WS128=1)"
+  timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "weights_stationary" > $O/t_dyn_layers.log 2>&1; echo "rc=$?" >> $O/t_dyn_layers.log; tailsum $O/t_dyn_layers.log 3
+  timeout 600 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op or launch_list" > $O/t_dyn_pinned.log 2>&1; echo "rc=$?" >> $O/t_dyn_pinned.log; tailsum $O/t_dyn_pinned.log 3
+  Y7T_CONV_WS128=1 timeout 600 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -k "every_op" > $O/t_dyn_pinned128.log 2>&1; echo "rc=$?" >> $O/t_dyn_pinned128.log; tailsum $O/t_dyn_pinned128.log 3
+  say "r5_dyn b: bench lines in one session: ws64 on the tile counter (default) | static (Y7T_CONV_WS_DYN=0) | + ws128 on the counter | + ws128 static | default again"
+  X="--steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode"
+  for v in dyn:X=1 static:Y7T_CONV_WS_DYN=0 dyn128:Y7T_CONV_WS128=1 static128:Y7T_CONV_WS128=1,Y7T_CONV_WS_DYN=0 dyn2:X=1 dyn128b:Y7T_CONV_WS128=1; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } timeout 300 python bench.py $X > $O/bench_$n.json 2> $O/bench_$n.err; benchsum $n
+  done
+  say "r5_dyn c: per-op tables of the launch list alone on the chip (through the plan: tile counters live): default, static, + ws128"
+  for v in dyn:X=1 static:Y7T_CONV_WS_DYN=0 dyn128:Y7T_CONV_WS128=1; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } NAME=$n OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  done
+  grep -h "ws64\|ws128\|patch<16,16,128>\|TOTAL\|total" $O/per_layer_dyn.txt $O/per_layer_static.txt $O/per_layer_dyn128.txt 2>/dev/null | cut -c1-200 | tee -a $O/summary.txt
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

@@ -17,7 +17,7 @@ def build(defs=()):
     tag = "".join(c for c in "".join(defs) if c.isalnum()) or "default"
     bdir = os.path.join(_HERE, "build_" + tag)
     so = os.path.join(bdir, "libconvsim.so")
-    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip", "y7t_conv_ws.hip", "y7t_conv_p8.hip", "y7t_conv_ws_s2.hip")]
+    srcs = [os.path.join(_CSRC, f) for f in ("y7t_conv.hip", "y7t_conv_common.h", "y7t_det.h", "y7t_common.h", "y7t_conv_patch.hip", "y7t_conv_patch_s2.hip", "y7t_conv_ws.hip", "y7t_conv_p8.hip", "y7t_conv_ws_s2.hip", "y7t_conv_ws128.hip")]
     deps = srcs + [os.path.join(_HERE, "runtime.inc"), os.path.join(_HERE, "fake", "hip", "hip_runtime.h"), os.path.abspath(__file__)]
     if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
@@ -57,10 +57,15 @@ def build(defs=()):
     ws2, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", ws2)
     assert n == 1
     open(os.path.join(bdir, "convsim_ws_s2.cpp"), "w").write(ws2)
+    ws128 = re.sub(r"asm volatile\([^;]*\);", ";", open(srcs[9]).read())    # the 128-channel weights-stationary kernel: same treatment as the 64-channel one
+    assert "asm volatile" not in ws128
+    ws128, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", ws128)
+    assert n == 1
+    open(os.path.join(bdir, "convsim_ws128.cpp"), "w").write(ws128)
     cmd = [_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-I", os.path.join(_HERE, "fake"), "-I", _CSRC,
            "-I", os.path.join(_ROOT, "include")] + list(defs) + ["-o", so, os.path.join(bdir, "convsim.cpp"), os.path.join(bdir, "convsim_patch.cpp"),
                                                                           os.path.join(bdir, "convsim_patch_s2.cpp"), os.path.join(bdir, "convsim_ws.cpp"),
-                                                                          os.path.join(bdir, "convsim_p8.cpp"), os.path.join(bdir, "convsim_ws_s2.cpp")]
+                                                                          os.path.join(bdir, "convsim_p8.cpp"), os.path.join(bdir, "convsim_ws_s2.cpp"), os.path.join(bdir, "convsim_ws128.cpp")]
     subprocess.check_call(cmd)
     return so
 

@@ -61,6 +61,7 @@ void cs_launch(const std::function<void()>& kernel, dim3 grid, dim3 block);
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 // ---- buffer resources and the buffer -> LDS DMA ------------------------------------------------------------------
 struct cs_rsrc { const char* base; unsigned bytes; };

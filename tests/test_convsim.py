@@ -34,6 +34,9 @@ def pack_w(W, cin_pad, cout_pad, korder=0):
     if korder == 4:      # the stride-2 patch kernel's panel order
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_s2(blk, cin_pad)
+    if korder == 6:      # the 128-channel weights-stationary kernel's register-fragment order
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws128(blk)
     if korder == 7:      # the 256 x 64 panels of the ping-pong 1x1 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_p8(blk)
@@ -49,7 +52,7 @@ def run_case(L, B, H, W, Cin, Cout, k, s, act, tile, in_ld=None, in_coff=0, out_
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    cp = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 8) else (Cout + 127) // 128 * 128
+    cp = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 6, 8) else (Cout + 127) // 128 * 128
     wp = pack_w(Wt, Cin, cp, korder)
     bp = np.zeros(cp, np.float32)
     bp[:Cout] = bias
@@ -393,6 +396,72 @@ def test_weights_stationary_kernel_source_on_the_host(case):
     B, H, W, act, kw = case
     name = run_case(cs.lib(), B, H, W, 64, 64, 3, 1, act, 0, korder=5, seed=B * 1000 + H + W, **kw)
     assert name == "ws64<16,16>", name
+
+
+# the same kernel on the tile counter (DYN, round 5): the fake device runs its 3 workgroups one after the other, which is the most lopsided schedule there is --
+# workgroup 0 takes its two static chunks and then EVERY chunk of the counter, workgroups 1 and 2 find it exhausted after their static chunks.  Cases: one chunk for one
+# workgroup; an odd tile count (the last chunk holds one tile); fewer chunks than two per workgroup (chunk 1 dead from the start); many chunks (the ring of ids wraps);
+# a map whose tile rows are odd (a chunk straddles two tile rows / two images)
+WS_DYN_CASES = WS_CASES + [
+    (1, 16, 32, 1, {}),                                                                # 2 tiles = 1 chunk, one workgroup
+    (3, 48, 48, 1, {}),                                                                # 27 tiles: 14 chunks, tile rows of 3 (chunks straddle rows and images), last chunk of one tile
+    (1, 96, 64, 2, {"in_ld": 128, "in_coff": 64}),                                     # 24 tiles: 12 chunks, 6 static, 6 from the counter
+]
+
+
+@pytest.mark.parametrize("case", WS_DYN_CASES, ids=lambda c: "%dx%dx%d_act%d" % c[:4])
+def test_weights_stationary_kernel_on_the_tile_counter_on_the_host(case):
+    B, H, W, act, kw = case
+    L = cs.lib()
+    L.cs_set_dyn(1)
+    try:
+        name = run_case(L, B, H, W, 64, 64, 3, 1, act, 0, korder=5, seed=B * 1000 + H + W, **kw)
+        assert name == "ws64<16,16> dyn", name
+        assert all(L.cs_tile_counter(i) == 0 for i in range(8))          # the last workgroup to leave handed the counter back at zero
+        name = run_case(L, B, H, W, 64, 64, 3, 1, act, 0, korder=5, seed=B * 1000 + H + W + 1, **kw)      # ... so the next launch starts from it
+        assert name == "ws64<16,16> dyn" and all(L.cs_tile_counter(i) == 0 for i in range(8))
+    finally:
+        L.cs_set_dyn(0)
+
+
+# B, H, W, Cout, act, slices -- the 128-channel sibling (csrc/y7t_conv_ws128.hip, korder 6): 4 x 16 tiles, four waves on the same 64 pixels with 32 output channels
+# each, two channel tiles for Cout = 256 (the fake device's three workgroups split 2 + 1 over them)
+WS128_CASES = [
+    (1, 4, 16, 128, 1, {}),                                                            # one tile, one workgroup
+    (1, 12, 32, 128, 1, {}),                                                           # 6 tiles on 3 workgroups: top / bottom / side borders
+    (2, 16, 48, 128, 2, {"in_ld": 192, "in_coff": 64, "out_ld": 256, "out_coff": 128}),   # 24 tiles, two images, slices of wider buffers, LeakyReLU
+    (1, 28, 32, 256, 1, {}),                                                           # 14 tiles x 2 channel tiles: workgroups 0 and 2 share channel tile 0, workgroup 1 walks all 14
+    (3, 4, 16, 128, 0, {"out_ld": 128}),                                               # 3 tiles over 3 workgroups, no activation
+]
+
+
+@pytest.mark.parametrize("dyn", [0, 1], ids=["static", "tile_counter"])
+@pytest.mark.parametrize("case", WS128_CASES, ids=lambda c: "%dx%dx%d_%d_act%d" % c[:5])
+def test_weights_stationary_128_kernel_source_on_the_host(case, dyn):
+    """static partition (the single-layer entry point) and on the tile counter (a detector's plan): with Cout = 256 the two channel tiles draw from two counters"""
+    B, H, W, Cout, act, kw = case
+    L = cs.lib()
+    L.cs_set_dyn(dyn)
+    try:
+        for rep in range(1 + dyn):      # (tile counter: the second launch starts from the counters the first one handed back)
+            name = run_case(L, B, H, W, 128, Cout, 3, 1, act, 0, korder=6, seed=B * 1000 + H + W + rep, **kw)
+            assert name == ("ws128<4,16> dyn" if dyn else "ws128<4,16>"), name
+            assert all(L.cs_tile_counter(i) == 0 for i in range(8))
+    finally:
+        L.cs_set_dyn(0)
+
+
+def test_weights_stationary_128_fragment_reads_are_bank_conflict_free():
+    """272-byte pixels (17 sixteen-byte slots), 5 KiB rows: the 16 addresses of a ds_read_b128 service group fall on 16 different 16-byte bank quads"""
+    PIXB, RP = 272, 5120
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for hi in (0, 1):
+        for g in groups:
+            for kw in range(3):
+                for ks in range(8):
+                    addr = [((l >> 4) * RP + (l & 15) * PIXB + hi * 16 + kw * PIXB + ks * 32) for l in g]
+                    assert len({(a // 16) % 16 for a in addr}) == 16
+    assert RP % 256 == 0 and RP >= 18 * PIXB
 
 
 def test_weights_stationary_kernel_rejects_what_it_cannot_run():

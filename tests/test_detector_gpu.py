@@ -43,6 +43,9 @@ def pack_w(W, cin_pad, cout_pad, korder=False):
     if korder == 5:   # register-fragment order of the weights-stationary 64 -> 64 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.pack_ws(blk)
+    if korder == 6:   # ... of its 128-channel sibling
+        from yolov7_tracker_amd.detector import weights
+        blk = weights.pack_ws128(blk)
     if korder == 7:   # 256 x 64 panels of the ping-pong 1x1 kernel
         from yolov7_tracker_amd.detector import weights
         blk = weights.panel_pack_p8(blk)
@@ -107,8 +110,8 @@ def test_conv_layer_matches_torch_fp32(L, case):
     x = rng.normal(0, 1, (B, H, W, in_ld)).astype(np.float16)
     Wt = (rng.normal(0, 1, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
     bias = rng.normal(0, 0.5, Cout).astype(np.float32)
-    korder = 10 if act & 262144 else 9 if act & 131072 else 8 if act & 65536 else 7 if act & 32768 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
-    cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 8) else (Cout + 127) // 128 * 128
+    korder = 10 if act & 262144 else 9 if act & 131072 else 8 if act & 65536 else 7 if act & 32768 else 6 if act & 16384 else 5 if act & 8192 else 4 if act & 4096 else 3 if act & 2048 else 2 if act & 1024 else int(bool(act & 256))
+    cout_pad = (Cout + 255) // 256 * 256 if korder == 7 else (Cout + 63) // 64 * 64 if korder not in (4, 6, 8) else (Cout + 127) // 128 * 128
     act_code = act
     act = act & 255
     if k == 3 and s == 1 and Cin % 64 == 0:    # the dispatcher must send these to the patch kernel when tiles are >= 80 % useful
@@ -154,6 +157,57 @@ def test_weights_stationary_kernel_matches_torch_fp32(L, case):
     from yolov7_tracker_amd import _lib
     test_conv_layer_matches_torch_fp32(L, case)
     assert L.y7t_last_kernel().decode() == "ws64<16,16>"
+
+
+# csrc/y7t_conv_ws128.hip: the 128-channel sibling (act bit 14: korder 6), here through the single-layer entry point = its statically partitioned form; the tile-counter
+# form runs inside a plan (test_weights_stationary_kernels_on_the_tile_counter_inside_a_plan below, tests/test_detector_pinned_gpu.py with Y7T_CONV_WS128=1)
+WS128_CASES = [
+    # B, H, W, Cin, Cout, k, s, act (bit 14), in_ld, in_coff, out_ld, out_coff, out_f32
+    (1, 4, 16, 128, 128, 3, 1, 1 | 16384, 128, 0, 128, 0, 0),
+    (1, 48, 80, 128, 128, 3, 1, 1 | 16384, 128, 0, 128, 0, 0),
+    (3, 160, 160, 128, 128, 3, 1, 2 | 16384, 256, 128, 512, 128, 0),
+    (5, 80, 80, 128, 256, 3, 1, 0 | 16384, 128, 0, 256, 0, 0),
+    (8, 160, 160, 128, 128, 3, 1, 1 | 16384, 512, 0, 128, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS128_CASES)
+def test_weights_stationary_128_kernel_matches_torch_fp32(L, case):
+    test_conv_layer_matches_torch_fp32(L, case)
+    assert L.y7t_last_kernel().decode() == "ws128<4,16>"
+
+
+def test_weights_stationary_kernels_on_the_tile_counter_inside_a_plan(monkeypatch):
+    """round 5: inside a detector's plan the persistent kernels take their tiles from the op's tile counter (Y7TConvArgs::tile_ctr, csrc/y7t_conv_ws.hip DYN).  A w6 plan
+    at 16 frames of 640 x 640 with the 128-channel kernel switched on: the launch list names the tile-counter forms; three forwards in a row (the counters must come back
+    to zero by themselves) give bit-identical heads, and those equal the heads of the same network lowered WITHOUT the weights-stationary kernels to within the fp16
+    rounding of the intermediate tensors (different kernels accumulate in another order); the counters read zero afterwards."""
+    from yolov7_tracker_amd.detector import arch, model
+    B, S = 16, 640
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy(rng.random((B, 3, S, S), dtype=np.float32))
+    monkeypatch.setenv("Y7T_CONV_WS128", "1")
+    det = model.Detector(arch.ARCHS["yolov7-w6"](10), None, img_size=(S, S), max_batch=B, seed=0, bn_bias_mean=2.0, calib_image=img[:1])
+    names = det.launch_list(B)
+    assert sum(n == "ws64<16,16> dyn" for n in names) >= 3 and sum(n == "ws128<4,16> dyn" for n in names) >= 4, names
+    heads = []
+    for _ in range(3):
+        out = det(img)[0]
+        torch.cuda.synchronize()
+        heads.append([r.clone() for r in out.raw()])
+    for h in heads[1:]:
+        for a, b in zip(heads[0], h):
+            assert torch.equal(a, b)
+    monkeypatch.setenv("Y7T_CONV_WS128", "0")
+    monkeypatch.setenv("Y7T_CONV_WS", "0")
+    ref = model.Detector(arch.ARCHS["yolov7-w6"](10), det._sd, img_size=(S, S), max_batch=B)
+    assert not any(n.startswith(("ws64", "ws128")) for n in ref.launch_list(B))
+    want = ref(img)[0].raw()
+    torch.cuda.synchronize()
+    for l, (a, b) in enumerate(zip(heads[0], want)):
+        scale = b.float().std().item()
+        err = (a.float() - b.float()).abs()
+        assert err.mean().item() < 2e-3 * scale and err.max().item() < 4e-2 * scale, (l, err.mean().item(), err.max().item(), scale)
 
 
 # csrc/y7t_conv_ws_s2.hip: the 64 -> 128 3x3 / stride 2 layer with the filter bank resident in registers, a persistent workgroup per compute unit walking 2 x 32 output

@@ -219,6 +219,30 @@ def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
     assert sum(int(op["korder"]) == 4 for op in wide.ops) == 7          # all but the 64 -> 128 layer at 640x640
 
 
+def test_weights_stationary_128_packing_and_lowering(monkeypatch):
+    """CPU: korder 6 = the filter bank of a 128 -> 128 k 3x3 layer as MFMA A-fragments per 128-channel output tile (csrc/y7t_conv_ws128.hip): a permutation with the
+    documented index map; with Y7T_CONV_WS128=1 the lowering gives it the 128 -> 128 / 256 layers on maps of whole 4 x 16 tiles and nothing else changes; =0 leaves the
+    plan without it"""
+    from yolov7_tracker_amd.detector import arch, graph, weights
+    blk = np.random.default_rng(1).permutation(256 * 1152).astype(np.float64).reshape(256, 1152)
+    out = weights.pack_ws128(blk).ravel()
+    assert np.array_equal(np.sort(out), np.sort(blk.ravel()))
+    for n, tap, ks, q, lane in ((0, 0, 0, 0, 0), (1, 8, 7, 3, 63), (0, 4, 2, 1, 37), (1, 7, 5, 2, 5)):
+        f = (n * 72 + tap * 8 + ks) * 4 + q
+        assert np.array_equal(out[(f * 64 + lane) * 8:(f * 64 + lane) * 8 + 8], blk[n * 128 + q * 32 + lane % 32, tap * 128 + ks * 16 + 8 * (lane // 32):][:8])
+    low = lambda: graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
+    monkeypatch.setenv("Y7T_CONV_WS128", "0")
+    base = low()
+    assert not any(int(op["korder"]) == 6 for op in base.ops)
+    monkeypatch.setenv("Y7T_CONV_WS128", "1")
+    exp = low()
+    took = [(int(op["H"]), int(op["Cin"]), int(op["Cout"])) for op in exp.ops if int(op["korder"]) == 6]
+    assert sorted(took) == sorted([(160, 128, 128)] * 4 + [(80, 128, 128)] * 6 + [(160, 128, 256)]), took
+    for a, b in zip(base.ops, exp.ops):
+        for f in a.dtype.names:
+            assert f == "korder" or a[f] == b[f] or (f in ("Cout_pad", "w_off", "bias_off") and int(b["korder"]) == 6), (f, a[f], b[f])
+
+
 def test_weights_stationary_packing_and_lowering(monkeypatch):
     """CPU: korder 5 = the 64 x 576 filter bank of a 64 -> 64 3x3 layer as MFMA A-fragments (csrc/y7t_conv_ws.hip): a permutation with the documented
     index map; the lowering sends exactly the seven 64 -> 64 layers on the 320^2 / 160^2 maps to it and nothing else changes"""

@@ -1,4 +1,5 @@
-"""Static checks on the gfx950 instruction streams of the weights-stationary 64 -> 64 kernel of the launch list (csrc/y7t_conv_ws.hip; hipcc cross-compiles without a GPU).
+"""Static checks on the gfx950 instruction streams of the weights-stationary kernels (hipcc cross-compiles without a GPU): the 64 -> 64 kernel of the launch list
+(csrc/y7t_conv_ws.hip) and its 128-channel sibling (csrc/y7t_conv_ws128.hip), each in its statically partitioned form and on the tile counter.
 
 The kernel writes its MFMAs as asm statements (accumulators in arch VGPRs, weights in ACC registers), so the compiler's hazard recogniser does not see them:
 the first device run of that form copied accumulator registers at the loop exit while the last MFMAs of a tile were still writing them.  What protects the
@@ -27,7 +28,8 @@ def _regs(tok):
 
 
 # file, kernel name, pieces per wave and tile, stores per wave and tile, accumulator registers of one set
-KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0EE", 13, 8, 64)}
+KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0ELb[01]EE", 13, 8, 64),
+           "ws128": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dELb[01]EE", 8, 4, 32)}
 
 
 @pytest.fixture(scope="module", params=sorted(KERNELS))
@@ -46,8 +48,8 @@ def kernels(request, tmp_path_factory):
     for m in re.finditer(r"^(_ZN\S*%s\w*):[^\n]*\n(.*?)s_endpgm" % kname, text, re.S | re.M):
         body = [l.strip() for l in m.group(2).split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";"))]
         ks[m.group(1)] = body
-    ks = {n: b for n, b in ks.items() if re.search(inst, n)}          # the instances without timing ablations (one per activation)
-    assert len(ks) == 3, sorted(ks)
+    ks = {n: b for n, b in ks.items() if re.search(inst, n)}          # the instances without timing ablations (one per activation, static partition and tile counter)
+    assert len(ks) == 6, sorted(ks)
     meta = {n: (int(re.search(r"\.name:\s+%s\n.*?\.private_segment_fixed_size:\s+(\d+)" % re.escape(n), text, re.S).group(1)),
                 int(re.search(r"\.name:\s+%s\n.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(n), text, re.S).group(1))) for n in ks}
     return ks, meta, (npw, nst, nacc)
@@ -58,7 +60,33 @@ def test_no_packed_fp32_no_scratch(kernels):
     for n, body in ks.items():
         assert not [i for i in body if re.match(r"v_pk_(mul|add|fma)_f32", i)], n
         assert not [i for i in body if i.startswith("scratch_")], n
-        assert meta[n] == (0, 0), (n, meta[n])
+        # static partition: nothing spilled.  Tile-counter instances: no scratch either; the SiLU one parks two VGPRs (a store base address) in spare ACC registers
+        # (v_accvgpr_write / read, eight moves per two tiles of 288 MFMAs)
+        assert meta[n][0] == 0 and meta[n][1] <= (2 if "Lb1EE" in n else 0), (n, meta[n])
+
+
+def test_the_tile_counter_fetch_lands_in_registers_the_compiler_does_not_use(kernels):
+    """DYN instances (dynamic tile scheduling): the chunk fetch is an asm atomic whose result arrives asynchronously in a255 (a254 carries the increment); it is read back
+    behind the counted wait of the next tile body.  Nothing else in the kernel may name those two registers (the compiler knows them only as clobbers of the two asm
+    statements), the atomic must not be followed by a wait of the compiler's (`s_waitcnt vmcnt(0)` on the spot is what the builtin atomicAdd produced), and the ring of
+    chunk ids is accessed with LDS instructions (a generic pointer made it flat loads with vmcnt(0) waits)."""
+    ks, _, _ = kernels
+    dyn = {n: b for n, b in ks.items() if "Lb1EE" in n}
+    assert len(dyn) == 3
+    for n, body in dyn.items():
+        named = [i for i, ins in enumerate(body) if re.search(r"\ba25[45]\b|a\[\d+:25[45]\]", ins)]
+        kinds = [body[i].split()[0] for i in named]
+        assert sorted(set(kinds)) == ["global_atomic_add", "v_accvgpr_read_b32", "v_accvgpr_write_b32"], (n, kinds)
+        assert kinds.count("global_atomic_add") == 2 and kinds.count("v_accvgpr_read_b32") == 1, (n, kinds)      # first tile + the loop's even body; the loop's odd body reads
+        for i in named:
+            if body[i].startswith("global_atomic_add"):
+                assert "a255" in body[i].split()[1] and "sc0" in body[i]
+                nxt = [ins for ins in body[i + 1:i + 12] if ins.startswith("s_waitcnt")]
+                assert not [w for w in nxt if "vmcnt(0)" in w], (n, nxt)
+        assert not [ins for ins in body if ins.startswith("flat_")], n
+    for n, body in ks.items():
+        if n not in dyn:
+            assert not [ins for ins in body if re.search(r"\ba25[45]\b", ins) or ins.startswith("global_atomic")], n
 
 
 def _bodies(body):

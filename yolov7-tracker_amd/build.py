@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 # pipe off for ~9 ns -- from either wave of a SIMD -- where two plain fp32 instructions per MFMA cost nothing (scripts/ubench/issue_classes.hip, profiles/r03_issue_classes.txt)
 _CONV = ["-ffp-contract=fast", "-fno-slp-vectorize"]
 FILE_FLAGS = {"y7t_conv.hip": _CONV, "y7t_conv_patch.hip": _CONV, "y7t_conv_patch_s2.hip": _CONV, "y7t_stem.hip": ["-fno-slp-vectorize"],
-              "y7t_conv_ws.hip": _CONV + ["-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_conv_p8.hip": _CONV, "y7t_conv_ws_s2.hip": _CONV + ["-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_post.hip": []}
+              "y7t_conv_ws.hip": _CONV + ["-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_conv_ws128.hip": _CONV + ["-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_conv_p8.hip": _CONV, "y7t_conv_ws_s2.hip": _CONV + ["-mllvm", "-pragma-unroll-threshold=10000000"], "y7t_post.hip": []}
 
 
 def _sources():

@@ -26,3 +26,30 @@ void y7t_note_kernel(const char* fmt, ...);   // see y7t_last_kernel()
     } while (0)
 
 #define Y7T_LAUNCH_CHECK() Y7T_HIP_CHECK(hipGetLastError())
+
+// One-time set-up that is PER DEVICE (kernel attributes such as hipFuncAttributeMaxDynamicSharedMemorySize; the CU count): a done-bit per device, set after the
+// call succeeded, so that a second device of the process -- or two threads racing -- never skip it (ADVICE r3 for the tracker, r4 for the conv / stem kernels).
+#include <atomic>
+struct Y7TOncePerDevice { std::atomic<unsigned long long> done{0}; };
+template <class F>
+static inline int y7t_once_per_device(Y7TOncePerDevice& o, F&& setup) {
+    int dev = 0;
+    Y7T_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (o.done.load(std::memory_order_acquire) & bit) return 0;
+    if (int e = setup()) return e;
+    o.done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+// compute units of the current device (cached per device)
+static inline int y7t_num_cus() {
+    static std::atomic<int> ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int v = ncu[dev & 63].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ncu[dev & 63].store(v, std::memory_order_relaxed);
+    return v;
+}

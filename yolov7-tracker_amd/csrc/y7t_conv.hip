@@ -564,6 +564,7 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch.hip
 int y7t_conv_patch_s2_launch(const Y7TConvArgs& a, hipStream_t s);   // y7t_conv_patch_s2.hip (korder 4: opt-in experiment, Y7T_CONV_PATCH_S2=1)
 int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_ws.hip (korder 5: 64 -> 64 3x3 layers, weights stationary in registers)
+int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s);      // y7t_conv_ws128.hip (korder 6: 128 -> 128 k 3x3 layers, the same idea on the tile counter)
 int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s);      // y7t_conv_ws_s2.hip (korder 8: the 64 -> 128 3x3 / stride 2 layer, weights stationary in registers)
 int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s);         // y7t_conv_p8.hip (korder 7: 1x1 layers with Cout % 256 == 0 on the 256 x 256 x 64 ping-pong pipeline)
 
@@ -590,6 +591,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     }
     if (a.korder == 4) return y7t_conv_patch_s2_launch(a, s);   // stride-2 LDS-patch kernel's panels: only that kernel reads them
     if (a.korder == 5) return y7t_conv_ws_launch(a, s);         // register-fragment order: only the weights-stationary kernel reads it
+    if (a.korder == 6) return y7t_conv_ws128_launch(a, s);      // ... and its 128-channel sibling
     if (a.korder == 3) {   // panel-packed 1x1 weights: only the 32-deep generic kernel reads that layout
         if (a.KH != 1 || a.KW != 1 || a.Cin % 32) { y7t_set_error("conv: korder 3 (panel-packed weights) needs a 1x1 layer with Cin %% 32 == 0"); return Y7T_E_ARG; }
         return a.Cout_pad % 128 == 0 && !a.panel64 ? launch_conv<128, 128, 32, 2>(a, s) : launch_conv<128, 64, 32, 2>(a, s);

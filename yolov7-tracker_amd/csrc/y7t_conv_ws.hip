@@ -38,14 +38,27 @@ struct WsCfg {
     static constexpr int NPW = (PATCH_DMA + 3) / 4;                   // pieces per wave per tile (13; a slot past the patch repeats its last KiB)
     static constexpr int NBUF = 3;
     static constexpr int BIAS_OFF = NBUF * PATCH_BYTES;
-    static constexpr int LDS = BIAS_OFF + 64 * 4;
+    static constexpr int RING_OFF = BIAS_OFF + 64 * 4;                // DYN: the chunk ids handed to this workgroup, a ring of four
+    static constexpr int LDS = RING_OFF + 64;
+    static constexpr int CH = 2;                                      // DYN: tiles per chunk of the tile counter
     static constexpr int NSUB = 36;                                   // k16 substeps per tile: 9 taps x 4
 };
 
 // ACT: the activation, a template parameter (the epilogue is instantiated inside each tile body).  ABL: timing ablations with WRONG results (Y7T_WS_ABLATE, scripts/ws_probe.py):
 // 1 no interleaved epilogue (no stores either), 2 no pieces in the loop (the ring keeps the prologue's tiles), 4 no fragment reads, 8 no vmcnt wait / barrier per tile,
 // 16 the epilogue's arithmetic without its stores.
-template <int ACT, int ABL = 0>
+//
+// DYN (round 5): DYNAMIC TILE SCHEDULING.  A statically partitioned persistent workgroup loses in the pipeline whatever it gained alone: the CU that also
+// hosts the tracker's workgroup or NMS workgroups finishes its range late and the launch ends with it (profiles/r04_ws128_measurement.txt: the list pays 0.43 ms for
+// co-running work with 4-per-CU kernels, 0.81 ms with a persistent one).  Here a workgroup takes CHUNKS of CH = 2 x-adjacent tiles from a counter in memory
+// (Y7TConvArgs::tile_ctr): chunks 0 and 1 of a workgroup are static (blockIdx.x, gridDim.x + blockIdx.x: the pipeline is three tiles deep and must be primed without a
+// round trip), every later one is 2 gridDim.x + atomicAdd(ctr, 1).  The fetch is software-pipelined like everything else in this kernel: lane 0 of wave 0 issues the atomic
+// for chunk k + 2 behind the barrier of chunk k's first tile -- OLDER than that tile body's pieces, so the counted `s_waitcnt vmcnt` at the top of the next body already
+// covers it --, writes the id into a four-entry LDS ring in front of that body's barrier, and every wave reads it behind the barrier when its iterators hop (the issue
+// iterator three tiles ahead, the store iterator one tile behind).  Chunk ids are decoded with multiply-high by precomputed reciprocals (ids < 2^16).  A chunk id past the
+// end makes the tile dead (zero-filling pieces, as the tail of the static form); the loop ends at the first dead tile.  The last workgroup to leave resets the counter
+// (ctr[Y7T_TILE_CTR_DONE] counts leavers), so a launch list -- or a captured hipGraph -- needs no memset.
+template <int ACT, int ABL = 0, bool DYN = false>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = WsCfg;
@@ -62,9 +75,12 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int per = (ptiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int pt_first = bid * per;
-    const int nt = (ptiles - pt_first) < per ? (ptiles - pt_first) : per;
-    if (nt <= 0) return;
+    const int pt_first = DYN ? 0 : bid * per;
+    int nt = DYN ? 0 : ((ptiles - pt_first) < per ? (ptiles - pt_first) : per);
+    if (!DYN && nt <= 0) return;
+    constexpr int CH = C::CH;
+    const unsigned magic_x = 0xFFFFFFFFu / (unsigned)tiles_x + 1u, magic_y = 0xFFFFFFFFu / (unsigned)tiles_y + 1u;      // exact quotients for numerators < 2^16 (the launcher checks)
+    volatile LDS_AS int* const ring = (volatile LDS_AS int*)(smem + C::RING_OFF);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
 
@@ -76,6 +92,9 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     // patch's first bytes.  Tiles on the image border take the per-lane bounds check (zero fill through an out-of-range offset).
     // Tiles are walked in order, so their coordinates are stepped, not decoded (two integer divisions per tile were ~50 scalar instructions with the matrix pipe
     // idle): P = index of the tile's first pixel in the NHWC map, (ty, tx) = its place in the tile grid, n = tiles of this workgroup's range still ahead of it.
+    // DYN: n = tiles of the current CHUNK still ahead (this one included).  Every chunk is walked as CH tiles -- the last one may hold fewer: its missing tile, like every
+    // tile of a chunk past the end, decodes / steps to a pixel index beyond the batch and is DEAD (zero-filling pieces; the loop ends at the first dead tile) -- so the
+    // tile parity the ring's timing rests on (even local tile = first tile of a chunk) always holds and a tile's liveness needs no state of its own.
     struct TileIt { int P, ty, tx, n; };
     auto tile_it = [&](int pt) -> TileIt {
         int q = pt;
@@ -83,13 +102,26 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         const int tyi = q % tiles_y, b = q / tiles_y;
         return TileIt{(b * p.H + tyi * TH) * p.W + txi * TW, tyi, txi, pt_first + nt - pt};
     };
-    auto tile_next = [&](TileIt& it) __attribute__((always_inline)) {
+    auto chunk_it = [&](int id) __attribute__((always_inline)) -> TileIt {      // (id wave-uniform; ids stay below 2^16 + a few hundred: the quotients are exact)
+        const unsigned pt = (unsigned)id * CH;
+        const unsigned q = tiles_x == 1 ? pt : __umulhi(pt, magic_x), txi = pt - q * (unsigned)tiles_x;      // (the reciprocal of 1 does not fit 32 bits)
+        const unsigned b = tiles_y == 1 ? q : __umulhi(q, magic_y), tyi = q - b * (unsigned)tiles_y;
+        return TileIt{(int)((b * (unsigned)p.H + tyi * TH) * (unsigned)p.W + txi * TW), (int)tyi, (int)txi, CH};
+    };
+    // DYN: `hop` = the place in this workgroup's chunk sequence of the chunk that follows when the current one is used up (its id is in the ring: written >= one barrier
+    // ago, see tile_body)
+    auto tile_next = [&](TileIt& it, int hop) __attribute__((always_inline)) {
+        if (DYN && it.n == 1) {
+            it = chunk_it(__builtin_amdgcn_readfirstlane(ring[hop & 3]));
+            return;
+        }
         it.P += TW; it.n -= 1;
         if (++it.tx == tiles_x) { it.tx = 0; it.P += (TH - 1) * p.W; if (++it.ty == tiles_y) it.ty = 0; }      // (maps are whole tiles: the next image follows the last row)
     };
     struct TileAt { int org, ty, tx; bool live; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1)
+    const unsigned npix = (unsigned)(p.B * p.H * p.W);
     auto tile_at = [&](const TileIt& it) -> TileAt {      // (unsigned arithmetic: P keeps stepping past the last live tile, and wrap-around must be defined behaviour)
-        return TileAt{(int)((((unsigned)it.P - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, it.n > 0};
+        return TileAt{(int)((((unsigned)it.P - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, DYN ? (unsigned)it.P < npix : it.n > 0};
     };
     // per-lane constants of piece i: pconst = where its 16-byte slot sits inside the 18 x 18 patch (byte offset from the patch's first pixel); pedge = which
     // halo sides the slot lies on (bit 0 top row, 1 bottom row, 2 left column, 3 right column), four bits per piece -- maps are whole tiles, so a slot can be
@@ -147,20 +179,26 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         for (int e = 0; e < 4; ++e) biasv[g * 4 + e] = p.bias[chh * 32 + 8 * g + 4 * hi32 + e];
 
     unsigned pv[NPW];
-    TileIt itn = tile_it(pt_first), ito = itn;      // itn: the tile whose pieces are issued next (t + 2); ito: the tile whose results are stored next (t - 1)
+    unsigned lv = 0;        // DYN: bit i = tile (next body + i) is live
+    int fetched = 0;        // DYN, lane 0 of wave 0: the counter value behind the chunk id in flight
+    if (DYN) {              // chunks 0 and 1 of this workgroup are static; both ids go into the ring for the iterators' hops (every wave writes the same two words)
+        ring[0] = bid; ring[1] = (int)gridDim.x + bid;
+    }
+    TileIt itn = DYN ? chunk_it(bid) : tile_it(pt_first), ito = itn;      // itn: the tile whose pieces are issued next (t + 2); ito: the tile whose results are stored next (t - 1)
     {
         const TileAt t0 = tile_at(itn);
-        tile_next(itn);
+        tile_next(itn, 0);
         const TileAt t1 = tile_at(itn);
-        tile_next(itn);
+        tile_next(itn, 1);
         piece_offsets(t0, pv);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) issue_piece(0, pv[i], i);
         piece_offsets(t1, pv);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) issue_piece(1, pv[i], i);
-        piece_offsets(tile_at(itn), pv);      // tile 2's, issued by the first tile body; every body leaves the next one's behind
-        tile_next(itn);
+        const TileAt t2 = tile_at(itn);
+        piece_offsets(t2, pv);      // tile 2's, issued by the first tile body; every body leaves the next one's behind (itn stays on the last tile it has priced)
+        lv = 1u | ((unsigned)t1.live << 1) | ((unsigned)t2.live << 2);      // (tile 0 is live: the grid has at most one workgroup per chunk)
     }
 
     // fragment base of this lane inside a patch buffer: four 32-pixel MFMA tiles of two image rows each, rows 8 pxh + 2j, + 1
@@ -242,15 +280,38 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     // One tile: its 144 MFMAs into `cur` (the bias as the C operand of the first), the PREVIOUS tile's epilogue out of `prev`, tile t+2's pieces.
     // vmcnt at the top: younger than this wave's pieces of tile t are what tile t-1 issued -- NPW pieces (tile t+1's) and, if tile t-1 had a predecessor to
     // store, NST stores -- and at most two late stores of tile t-2 (waiting for those as well is harmless).
-    auto tile_body = [&](const bool FIRST, int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
+    // DYN: EVEN = t is even, i.e. the first tile of chunk t / 2 of this workgroup: behind its barrier lane 0 of wave 0 asks for chunk t / 2 + 2; the odd body after it
+    // publishes the answer in front of ITS barrier (the counted wait has covered the atomic: it is older than every piece and store of the even body).
+    auto tile_body = [&](const bool FIRST, const bool EVEN, int t, int buf, floatx16 (&cur)[4], floatx16 (&prev)[4]) __attribute__((always_inline)) {
         const int nbuf = (buf + 2 >= C::NBUF) ? buf + 2 - C::NBUF : buf + 2;
         char* const ob = FIRST ? nullptr : out_base(ito);
-        if (!FIRST) tile_next(ito);
+        if (!FIRST) tile_next(ito, t >> 1);            // (DYN: a hop at the top of an even body t, into chunk t / 2)
         const char* pb = smem + buf * C::PATCH_BYTES + plane_off;
         if (!(ABL & 8)) {
+#if defined(Y7T_CONVSIM)
+        if (DYN && !EVEN && wave == 0 && lane == 0) ring[((t >> 1) + 2) & 3] = 2 * (int)gridDim.x + fetched;
+        __builtin_amdgcn_s_barrier();
+        if (DYN && EVEN && wave == 0 && lane == 0) fetched = atomicAdd(p.tile_ctr, 1);
+#else
         if (FIRST || t < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW + NST) : "memory");
+        if (DYN && !EVEN && wave == 0) {
+            if (lane == 0) {
+                asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(fetched) : : "memory");      // (volatile asm statements keep their order: behind the counted wait)
+                ring[((t >> 1) + 2) & 3] = 2 * (int)gridDim.x + fetched;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
+        // The fetch as an asm statement: the compiler's atomic optimiser turns atomicAdd on a uniform address into mbcnt + atomic + readfirstlane and WAITS for the result
+        // on the spot (s_waitcnt vmcnt(0): every piece in flight + one L2 round trip, every other tile).  Spelled out, the result arrives whenever it arrives -- in a
+        // register the compiler must not know about, or it copies it (to make room, or into the operand register of the statement that consumes it) BEFORE the value
+        // is there: both were seen in the first build.  So the destination is a255 by name (an atomic's data and destination are both ACC registers or both VGPRs:
+        // a254 carries the 1), which the allocator -- lowest numbers first, ~200 ACC registers in use -- never reaches; tests/test_ws_isa.py pins that no other
+        // instruction of the kernel names a254 / a255.
+        if (DYN && EVEN && wave == 0 && lane == 0)
+            asm volatile("v_accvgpr_write_b32 a254, 1\n\ts_nop 4\n\tglobal_atomic_add a255, %0, a254, %1 sc0" : : "v"(0), "s"(p.tile_ctr) : "memory", "a254", "a255");
+#endif
         }          // everybody's pieces of tile t are visible; nobody reads the buffer of tile t-1 any more: it takes tile t+2
         half8 xf[2][4];
 #pragma unroll
@@ -287,21 +348,40 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
         // tile's last MFMAs and whatever follows the body.  The compiler cannot see the MFMAs inside the asm statements, so it inserts no wait states for them --
         // and at the loop's exit it copies one accumulator set onto the other's registers (VALU writes of registers the last two MFMAs are still writing:
         // a write-after-write race that corrupted the last tile of a workgroup on the device; 8-pass MFMA -> VALU needs 11 wait states).
-        piece_offsets(tile_at(itn), pv);
-        tile_next(itn);
+        tile_next(itn, (t + 3) >> 1);                  // (DYN: a hop at the bottom of an odd body t, into the chunk of tile t + 3)
+        {
+            const TileAt tn = tile_at(itn);
+            piece_offsets(tn, pv);
+            if (DYN) lv = (lv >> 1) | ((unsigned)tn.live << 2);
+        }
         asm volatile("s_nop 7" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
     floatx16 accA[4], accB[4];
-    tile_body(true, 0, 0, accA, accB);
+    tile_body(true, true, 0, 0, accA, accB);
     int buf = 1;
+    if (!DYN) {
     for (int t = 1; t < nt; t += 2) {
-        tile_body(false, t, buf, accB, accA);
+        tile_body(false, false, t, buf, accB, accA);
         buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
         if (t + 1 < nt) {
-            tile_body(false, t + 1, buf, accA, accB);
+            tile_body(false, true, t + 1, buf, accA, accB);
             buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
+        }
+    }
+    } else {      // until the first dead tile (lv bit 0 = the next body's tile is live; dead tiles are never followed by live ones).  Same loop shape as the static form:
+                  // the register allocation of this kernel is only as good as its control flow is simple
+        nt = 1;
+        while (lv & 1) {
+            tile_body(false, false, nt, buf, accB, accA);
+            buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
+            ++nt;
+            if (lv & 1) {
+                tile_body(false, true, nt, buf, accA, accB);
+                buf = (buf + 1 == C::NBUF) ? 0 : buf + 1;
+                ++nt;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // the tail's zero-filling pieces have landed before this workgroup's LDS is
@@ -314,6 +394,9 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     } else {
 #pragma unroll
         for (int k = 0; k < EPI_SLOTS; ++k) epi_step(accB, obl, k);
+    }
+    if (DYN && tid == 0) {      // every fetch of this workgroup has returned (vmcnt(0) above); the last workgroup to leave hands the counter back at zero
+        if (atomicAdd(p.tile_ctr + Y7T_TILE_CTR_DONE, 1) == (int)gridDim.x - 1) { p.tile_ctr[0] = 0; p.tile_ctr[Y7T_TILE_CTR_DONE] = 0; }
     }
 #endif
 }
@@ -330,22 +413,25 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_set_error("conv: weights are in register-fragment order (korder 5) but the layer is not a 3x3 / stride 1 / 64 -> 64 convolution on a map of whole 16 x 16 tiles with an aligned fp16 output");
         return Y7T_E_ARG;
     }
-    static bool attr = false;
-    if (!attr) {
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr = true;
-    }
-    static int ncu = -1;      // one persistent workgroup per compute unit (150 KiB of LDS each)
-    if (ncu < 0) {
-        const char* e = getenv("Y7T_CONV_WS_WGS");
-        int dev = 0; hipDeviceProp_t prop;
-        ncu = e ? atoi(e) : (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256);
-        if (ncu <= 0) ncu = 256;
-    }
+    static Y7TOncePerDevice attr;
+    if (int e = y7t_once_per_device(attr, []() -> int {
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_NONE, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_SILU, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            return 0;
+        })) return e;
+    static int wgs_env = -2;      // Y7T_CONV_WS_WGS: workgroups of a launch (default: one persistent workgroup per compute unit -- 150 KiB of LDS each)
+    if (wgs_env == -2) { const char* e = getenv("Y7T_CONV_WS_WGS"); wgs_env = e ? atoi(e) : -1; }
+    const int ncu = wgs_env > 0 ? wgs_env : y7t_num_cus();
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
-    const int grid = ptiles < ncu ? ptiles : ncu;
+    static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied a tile counter (A/B)
+    if (dyn_env < 0) { const char* e = getenv("Y7T_CONV_WS_DYN"); dyn_env = e ? atoi(e) : 1; }
+    const bool dyn = a.tile_ctr && dyn_env && ptiles < 65536;
+    const int nchunks = (ptiles + C::CH - 1) / C::CH;
+    const int grid = dyn ? (nchunks < ncu ? nchunks : ncu) : (ptiles < ncu ? ptiles : ncu);
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("Y7T_WS_ABLATE"); abl = e ? atoi(e) : 0; }
     if (abl && a.act == Y7T_ACT_SILU) {
@@ -361,6 +447,14 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
 #undef Y7T_WS_ABL_CASE
         Y7T_LAUNCH_CHECK();
         y7t_note_kernel("ws64<16,16> ablated");
+        return 0;
+    }
+    if (dyn) {
+        if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 0, true>), dim3(grid), dim3(256), C::LDS, s, a);
+        else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0, true>), dim3(grid), dim3(256), C::LDS, s, a);
+        else hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_NONE, 0, true>), dim3(grid), dim3(256), C::LDS, s, a);
+        Y7T_LAUNCH_CHECK();
+        y7t_note_kernel("ws64<16,16> dyn");
         return 0;
     }
     if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);

@@ -46,7 +46,13 @@ struct Y7TConvArgs {
     const _Float16* in2;
     int ldin2, cin2_off, up_c0, up_C;
     unsigned in2_bytes;
+    // dynamic tile scheduling of the persistent kernels (y7t_conv_ws.hip, y7t_conv_ws128.hip): Y7T_TILE_CTR_INTS ints, zero between launches -- [0 .. 3] chunks handed
+    // out (one counter per output-channel tile of the launch), [Y7T_TILE_CTR_DONE] workgroups that have left (the last one resets them all).  One set per op of a
+    // detector's plan (y7t_detector.hip); null = static partition (the single-layer entry point).
+    int* tile_ctr;
 };
+#define Y7T_TILE_CTR_DONE 4
+#define Y7T_TILE_CTR_INTS 8
 
 #define Y7T_SPLITK_WS_BYTES (128ull << 20)
 int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s);

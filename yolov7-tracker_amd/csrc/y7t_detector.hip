@@ -16,6 +16,7 @@ struct y7t_det {
     const _Float16* w; const float* bias;
     _Float16* zeros;
     float* splitk_ws = nullptr;
+    int* tile_ctr = nullptr;      // Y7T_TILE_CTR_INTS ints per op, zero between launches: the tile counters of the persistent conv kernels (Y7TConvArgs::tile_ctr)
     int max_batch;
     // Detect levels (y7t_det_set_detect)
     int nl = 0, na = 0, no = 0;
@@ -49,12 +50,21 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
         y7t_set_error("y7t_det_create: cannot allocate the split-K workspace");
         return Y7T_E_HIP;
     }
+    if (hipMalloc((void**)&d->tile_ctr, sizeof(int) * Y7T_TILE_CTR_INTS * (size_t)n_ops) != hipSuccess || hipMemset(d->tile_ctr, 0, sizeof(int) * Y7T_TILE_CTR_INTS * (size_t)n_ops) != hipSuccess) {
+        (void)hipFree(d->zeros);
+        (void)hipFree(d->splitk_ws);
+        if (d->tile_ctr) (void)hipFree(d->tile_ctr);
+        delete d;
+        y7t_set_error("y7t_det_create: cannot allocate the tile counters");
+        return Y7T_E_HIP;
+    }
     *out = d;
     return 0;
 }
 
 extern "C" int y7t_det_destroy(y7t_det* d) {
     if (!d) return 0;
+    if (d->tile_ctr) (void)hipFree(d->tile_ctr);
     if (d->zeros) (void)hipFree(d->zeros);
     if (d->splitk_ws) (void)hipFree(d->splitk_ws);
     delete d;
@@ -84,6 +94,7 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
             a.KH = op.KH; a.KW = op.KW; a.stride = op.stride; a.pad = op.pad; a.K = op.K; a.K_pad = op.K_pad;
             a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.korder; a.force_patch = 0;
             a.splitk_ws = d->splitk_ws;
+            a.tile_ctr = d->tile_ctr + Y7T_TILE_CTR_INTS * oi;
             if (op.up_C > 0) {
                 a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]);
                 a.ldin2 = op.up_ld; a.cin2_off = op.up_coff; a.up_c0 = op.up_c0; a.up_C = op.up_C;
@@ -203,7 +214,7 @@ extern "C" int y7t_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, int B
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Cout = Cout; a.Cout_pad = Cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.K = KH * KW * Cin; a.K_pad = (a.K + 63) / 64 * 64; a.M = B * a.Ho * a.Wo; a.act = act & 0xff; a.zeros = (const _Float16*)zeros16;
-    a.korder = (act >> 19) & 1 ? 11 : (act >> 18) & 1 ? 10 : (act >> 17) & 1 ? 9 : (act >> 16) & 1 ? 8 : (act >> 15) & 1 ? 7 : (act >> 13) & 1 ? 5 : (act >> 12) & 1 ? 4 : (act >> 11) & 1 ? 3 : (act >> 10) & 1 ? 2 : (act >> 8) & 1;   // `act` bit 8: (kh, chunk, kw) K order; bit 10: patch-kernel panels; bit 11: 1x1 panels; bit 12: stride-2 patch-kernel panels; bit 13: register-fragment order of the weights-stationary 64 -> 64 kernel
+    a.korder = (act >> 19) & 1 ? 11 : (act >> 18) & 1 ? 10 : (act >> 17) & 1 ? 9 : (act >> 16) & 1 ? 8 : (act >> 15) & 1 ? 7 : (act >> 14) & 1 ? 6 : (act >> 13) & 1 ? 5 : (act >> 12) & 1 ? 4 : (act >> 11) & 1 ? 3 : (act >> 10) & 1 ? 2 : (act >> 8) & 1;   // `act` bit 8: (kh, chunk, kw) K order; bit 10: patch-kernel panels; bit 11: 1x1 panels; bit 12: stride-2 patch-kernel panels; bit 13: register-fragment order of the weights-stationary 64 -> 64 kernel
     a.force_patch = (act >> 9) & 1;   // bit 9: force the LDS-patch kernel for an eligible 3x3/s1 layer (tests)
     return y7t_conv_launch(a, (hipStream_t)stream);
 }

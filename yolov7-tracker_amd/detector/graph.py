@@ -228,6 +228,20 @@ def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff
     return bool(ok)
 
 
+WS128_DEFAULT = "0"      # until the tile-counter form has been measured in the pipeline (round 5)
+
+
+def ws128_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
+    """mirror of y7t_conv_ws128_launch (csrc/y7t_conv_ws128.hip): the 128 -> 128 k 3x3 / stride 1 layers with a 128-channel output tile's filter bank in the
+    registers of a persistent workgroup, tiles taken from the op's tile counter.  Round 4 measured its statically partitioned form: 5-19 % faster alone, 0.2 ms slower
+    in the pipeline (profiles/r04_ws128_measurement.txt).  Y7T_CONV_WS128=0 / 1."""
+    if os.environ.get("Y7T_CONV_WS128", WS128_DEFAULT) != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+        return False
+    tiles = B * (H // 4) * (W // 16)
+    return (k == 3 and s == 1 and p == 1 and cin == 128 and cout % 128 == 0 and cout <= 512 and H % 4 == 0 and W % 16 == 0 and not out_f32 and out_ld % 8 == 0
+            and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
+
+
 def lower(nodes, H, W, max_batch=1):
     det = next(n for n in nodes if n.kind == "detect")
     # ---- liveness: only what reaches the (main) Detect inputs ----
@@ -350,6 +364,8 @@ def lower(nodes, H, W, max_batch=1):
             korder = 5                               # weights-stationary kernel: the filter bank as MFMA A-fragments (weights.pack_ws)
         elif ws_s2_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
             korder = 8                               # ... and its stride-2 sibling for the 64 -> 128 down-sampling layer (weights.pack_ws_s2)
+        elif ws128_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
+            korder = 6                               # ... and its 128-channel sibling (weights.pack_ws128)
         elif patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
             if cout_pad % 128 == 0 and patch_panel_rows(src.h, src.w, cout, max_batch) == 64:

@@ -208,6 +208,17 @@ def pack_ws_s2_tail(blk):
     return np.ascontiguousarray(a).reshape(128, 128)
 
 
+def pack_ws128(blk):
+    """[Cout_pad][1152] block of a 128 -> 128 k 3x3 layer (Cout_pad a multiple of 128) with k = (kh*3 + kw)*128 + ci  ->  the register-fragment order of
+    csrc/y7t_conv_ws128.hip (korder 6): per 128-channel output tile n, fragment f = (n*72 + tap*8 + ks)*4 + q is 1 KiB = 64 lanes x 8 halves, lane l holding
+    W[n*128 + q*32 + l % 32][tap][ks*16 + 8*(l // 32) .. +7]"""
+    cp = blk.shape[0]
+    assert blk.shape[1] == 1152 and cp % 128 == 0
+    a = blk.reshape(cp // 128, 4, 32, 9, 8, 2, 8)      # [n][q][l31][tap][ks][hi][8]
+    a = a.transpose(0, 3, 4, 1, 5, 2, 6)               # [n][tap][ks][q][hi][l31][8]   (lane = hi * 32 + l31)
+    return np.ascontiguousarray(a).reshape(cp, 1152)
+
+
 def pack(wlayout, sd, w_elems, b_elems):
     """-> (fp16 weight blob [w_elems], fp32 bias blob [b_elems]) in the kernel's [Cout_pad][K_pad] layout,
     k = (kh*KW + kw)*Cin_pad + ci"""
@@ -231,6 +242,8 @@ def pack(wlayout, sd, w_elems, b_elems):
             blk = panel_pack_s2(blk, w["cin_pad"])
         elif w.get("korder") == 5:
             blk = pack_ws(blk)
+        elif w.get("korder") == 6:
+            blk = pack_ws128(blk)
         elif w.get("korder") == 7:
             blk = panel_pack_p8(blk)
         elif w.get("korder") == 8:
