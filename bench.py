@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
+    ap.add_argument("--chained_frames", type=int, default=8, help="frames of the chained detect -> NMS -> ByteTrack parity run in `parity.chained` (0: off)")
+    ap.add_argument("--no_other_workloads", action="store_true", help="skip the short cfg3 / cfg4 runs behind the headline line (`other_workloads`)")
     ap.add_argument("--weights", default="conditioned", choices=["conditioned", "chaotic"],
                     help="seeded random weights of the timed detector.  conditioned (default): BatchNorm shifts ~ +2, statistics calibrated on frame 0, damped "
                          "width / height logits -- a random network that does not amplify rounding noise, so that `parity` (heads, pre-NMS candidates, boxes "
@@ -283,6 +285,90 @@ def parity_well_conditioned(args, nc, frames_host):
             m += 1
     return {"heads_mean_abs_err_over_logit_std": [round(v, 5) for v in rel], "boxes_oracle": int(len(r)), "boxes_device": int(len(d)),
             "boxes_matched_same_class_1px_conf5e-3": m}
+
+
+def chained_parity(args, nc, frames_host, n_frames):
+    """VERDICT r4 next 1, the bench-line form of tests/test_chained_gpu.py: the reference's per-frame loop as ONE chain (tracker/track.py:138-174,234-244) on the first
+    `n_frames` frames of the scene -- DEVICE forward -> decode + NMS -> scale_coords / round -> ByteTrack.update (the detector's own output feeds the tracker: no synthetic
+    detections) against the ORACLE chain (fp32 network, NMS restatement, numpy ByteTrack).  Conditioned weights with the objectness rows x 2.75 (a head that is confident
+    about ~100 of its ~2000 candidates per frame; otherwise no row ever exceeds the tracker's 0.2 / 0.3 thresholds), candidates from the two fine Detect levels (the
+    small-object regime).  Reports: the seam (oracle tracker on the device's hand-over == device tracker: ids / classes exact, tlwh 1e-6), how the two hand-overs differ,
+    and HOTA / IDF1 / MOTA of the device chain's tracks scored against the oracle chain's through the TrackEval-style harness."""
+    import tempfile
+    import types as _types
+    from oracle import chained
+    from yolov7_tracker_amd.detector import arch, model
+    from yolov7_tracker_amd.tracker import track as cli
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    gain, quota = 2.75, (0.9, 0.1, 0.0, 0.0)
+    H = W = args.img
+    fh = frames_host[:n_frames]
+    sd = conditioned_state_dict(args, nc, frames_host)
+    na, no = 3, nc + 5
+    for k in list(sd):
+        if ".m." in k and k.endswith(".weight"):
+            w = sd[k].clone().view(na, no, -1)
+            w[:, 4] *= gain
+            sd[k] = w.view(na * no, -1, 1, 1)
+    det = model.Detector(arch.ARCHS[args.arch](nc), sd, img_size=(H, W), max_batch=n_frames)
+    fr = torch.from_numpy(fh).cuda()
+    det.plant_objectness_bias(fr, 2000, level_quota=quota)
+    count0 = BaseTrack._count
+    BaseTrack._count = 0
+    trk = ByteTrack(_types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=args.img, iou_thresh=0.5, max_tracks=1024, max_dets=1024))
+    head = det.forward(fr, fuse_decode=0.01)            # conf_thres of post_process_v7 (tracker/track.py:239)
+    outs = cli.post_process_v7(head, img_size=(H, W), ori_img_size=(H, W, 3), all_images=True)
+    handed, dev = [], []
+    for k in range(n_frames):
+        handed.append(outs[k].detach().cpu().numpy().copy())
+        dev.append([(t.track_id, np.asarray(t.tlwh, np.float64), float(t.cls), float(t.score)) for t in trk.update(outs[k], None)])
+    BaseTrack._count = count0
+    seam = chained.track("bytetrack", handed)
+    seam_ok = len(seam) == len(dev) and all(
+        [a[0] for a in fa] == [b[0] for b in fb] and all(a[2] == b[2] and np.allclose(a[1], b[1], rtol=1e-6, atol=1e-5) for a, b in zip(fa, fb)) for fa, fb in zip(dev, seam))
+    ora = chained.oracle_detections(det.nodes, det._sd, det.spec["anchors"], fh, chunk=4)
+    diff = [chained.detection_set_difference(a, b) for a, b in zip(ora, handed)]
+    ora_tracks = chained.track("bytetrack", ora)
+    with tempfile.TemporaryDirectory() as tmp:
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):      # (the harness prints its tables; the bench prints ONE line)
+            g = chained.grade(tmp, ora_tracks, dev)
+    return {"frames": n_frames, "checker": "oracle/chained.py: fp32 oracle network -> NMS -> scale_coords/round -> numpy ByteTrack; graded by yolov7-tracker_amd/tracker/trackeval",
+            "seam_device_tracker_equals_oracle_tracker_on_the_devices_handover": bool(seam_ok),
+            "handover_rows_per_frame_mean": round(float(np.mean([len(h) for h in handed])), 1),
+            "handover_rows_without_partner_at_8a_bar": {"oracle_only": int(sum(len(a) for a, _ in diff)), "device_only": int(sum(len(b) for _, b in diff))},
+            "frames_with_identical_handover": int(sum(chained.same_detections(a, b) for a, b in zip(ora, handed))),
+            "track_rows": {"device": int(sum(len(f) for f in dev)), "oracle": int(sum(len(f) for f in ora_tracks))},
+            "device_chain_graded_against_oracle_chain": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in g.items()},
+            "objectness_gain": gain, "level_quota": list(quota)}
+
+
+def other_workloads(args):
+    """configs[2] (BoT-SORT, 500 objects) and configs[3] (DeepSORT + OSNet ReID) in the driver's default run -- two short runs of this script
+    (--steps 5, no CPU baseline, no latency mode) as child processes AFTER the headline's timed region, their lines reduced to the figures that matter."""
+    import subprocess
+    out = {}
+    for wl in ("cfg3", "cfg4"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", "5", "--warmup", "2", "--no_cpu_baseline", "--no_latency_mode",
+               "--no_other_workloads", "--batch", str(args.batch), "--img", str(args.img), "--arch", args.arch]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            l = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+            ph = l.get("phases_ms_per_step", {})
+            o = {"workload": l["config"]["workload"].split(",")[0], "fps": l["value"], "ms_per_step": l["ms_per_step"], "steps": l["steps"],
+                 "launch_list_ms": l["roofline"].get("launch_list_ms"), "tracker_chain_ms": ph.get("tracker_chain"),
+                 "tracks_alive_last_frame": l["config"].get("tracks_alive_last_frame"), "dets_per_frame": l["config"].get("dets_per_frame_timed_mean")}
+            if wl == "cfg4":
+                o["reid_ms"] = ph.get("reid")
+                o["reid_crops_per_step"] = l["config"].get("reid_crops_per_step_mean")
+                o["roofline_reid"] = {k: l.get("roofline_reid", {}).get(k) for k in ("achieved", "peak", "unit", "frac", "bound")}
+            out[wl] = o
+        except Exception as e:      # a failed child must not take the headline line with it
+            out[wl] = {"error": repr(e)[:300]}
+    out["note"] = "short child runs of this script (--workload cfg3 / cfg4 --steps 5) behind the headline's timed region; never part of `value`"
+    return out
 
 
 def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10, sd=None):
@@ -867,7 +953,7 @@ def main():
                          "sustained_peak_note": "register-only v_mfma_f32_32x32x16_f16 loop with random operands (power-limited clock; "
                                                 "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
                          "traffic_note": None,
-                         "kernel": "the conv launch list of one forward (107 convs in 96 launches + 1 pool launch: k_stem_u8, k_conv3x3s2_c64_ws, k_conv3x3_c64_ws, k_conv3x3_patch*, "
+                         "kernel": "the conv launch list of one forward (107 convs in 96 launches + 1 pool launch: k_stem_u8, k_conv3x3s2_c64_ws, k_conv3x3_c64_ws, k_conv3x3_c128_ws, k_conv3x3_patch*, "
                                    "k_conv3x3s2_patch, k_conv1x1_p8, k_conv_igemm, k_spp3_lds; nearest-x2 upsamples folded into their consumers' loaders, Detect decode + "
                                    "candidate filter in the Detect convs' epilogues)",
                          "algorithmic_gflop_per_launch_list": round(gflop_frame * B, 1),
@@ -959,6 +1045,10 @@ def main():
                     line["parity"]["note"] = ("the benchmarked weights are iid random (chaotic: rounding noise x ~300 over the depth); the same kernels "
                                               "on well-conditioned seeded weights:")
                     line["parity"]["well_conditioned"] = parity_well_conditioned(args, nc, frames_host)
+                if args.chained_frames > 0 and not cfg3 and len(frames_host) >= args.chained_frames:
+                    line["parity"]["chained"] = chained_parity(args, nc, frames_host, args.chained_frames)
+            if not args.no_other_workloads and not cfg3 and not cfg4:
+                line["other_workloads"] = other_workloads(args)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

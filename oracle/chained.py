@@ -18,13 +18,15 @@ def images(frames_host):
     return (torch.from_numpy(np.ascontiguousarray(frames_host[..., ::-1])).permute(0, 3, 1, 2).float() / 255.0).contiguous()
 
 
-def oracle_detections(nodes, sd, anchors, frames_host, chunk=4, conf_thres=0.01, iou_thres=0.45, keep_candidates=False):
+def oracle_detections(nodes, sd, anchors, frames_host, chunk=4, conf_thres=0.01, iou_thres=0.45, keep_candidates=False, fp16=False):
     """fp32 network -> decode -> NMS -> scale_coords -> round for every frame: list of float32 (n, 6) [x1, y1, x2, y2, conf, cls] (track.py:234-244);
-    keep_candidates: also per frame (candidate dict by anchor row, kept anchor rows in output order) for explain_kept_set_difference"""
+    keep_candidates: also per frame (candidate dict by anchor row, kept anchor rows in output order) for explain_kept_set_difference.
+    fp16=True: the oracle's own emulation of the device arithmetic (fp16 weights / activations, fp32 accumulate: detector_torch.forward(fp16=True)) -- the noise floor
+    a chained comparison can be held to"""
     H, W = frames_host.shape[1:3]
     out, cands = [], []
     for lo in range(0, len(frames_host), chunk):
-        dec, _ = dt.forward(nodes, sd, images(frames_host[lo:lo + chunk]), anchors)
+        dec, _ = dt.forward(nodes, sd, images(frames_host[lo:lo + chunk]), anchors, fp16=fp16)
         res = dt.non_max_suppression(dec, conf_thres, iou_thres)
         for i, r in enumerate(res):
             r = r.clone()

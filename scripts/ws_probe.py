@@ -3,6 +3,8 @@
    layout    dense (ld 64 -> 64), in-slice (ld 256 -> 64), out-slice (ld 64 -> 256), both slices (ld 256 -> 256)
    frames    working set inside / outside the 256 MB Infinity Cache
 prints us per launch, us per tile ROUND (ceil(tiles / 256) rounds per launch: one persistent workgroup per CU), TFLOP/s."""
+import os as _os
+_os.environ.setdefault('Y7T_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'yolov7-tracker_amd', 'lib', 'liby7t_ablate.so'))      # Y7T_WS_ABLATE instances live in the measuring build
 import sys, os, math
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -67,3 +67,52 @@ def test_integration_doc_shows_every_entry_point():
     syms = sorted(set(re.findall(r"\b(y7t_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "y7t.h")).read())))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     assert len(syms) >= 40 and not [s for s in syms if s not in doc]
+
+
+def _strings(path):
+    import re
+    data = open(path, "rb").read()
+    return [m.group().decode() for m in re.finditer(rb"[\x20-\x7e]{8,}", data)]
+
+
+def test_the_product_library_carries_no_ablation_or_variant_instance():
+    """lib/liby7t.so = the measured defaults only.  The timing-ablation instances ("wrong results": ABL template arguments of the weights-stationary,
+    LDS-patch and ping-pong kernels), the tile / ring variants of the generic kernel (Y7T_CONV_VARIANT) and the code that reads experiment switches from the
+    environment exist only in lib/liby7t_ablate.so (the same sources with -DY7T_ABLATE_BUILD; Y7T_LIB=<path>).  Checked on the kernel names the HIP runtime registers."""
+    import re
+    from yolov7_tracker_amd import build
+    build.build()
+    prod, abl = _strings(build.LIB), _strings(build.LIB_ABLATE)
+    ablated = [r"k_conv3x3_c64_wsILi\dELi[1-9]", r"k_conv3x3_patchILi\d+ELi\d+ELi\d+ELi[1-9]", r"k_conv1x1_p8ILi\dELb[01]ELi[1-9]",
+               r"k_conv_igemmILi256ELi256", r"k_conv_igemmILi128ELi128ELi64ELi3", r"k_conv_igemmILi128ELi128ELi32ELi[34]"]
+    for pat in ablated:
+        assert not [x for x in prod if re.search(pat, x)], pat
+        assert [x for x in abl if re.search(pat, x)], pat                  # ... and the measuring build really has them
+    exp = ["Y7T_CONV_VARIANT", "Y7T_CONV_ABLATE", "Y7T_WS_ABLATE", "Y7T_CONV_XCD", "Y7T_STEM_LINES", "Y7T_POOL_LDS", "Y7T_SPP3", "Y7T_CONV_NARROW", "Y7T_CONV_WS_WGS"]
+    env_prod = sorted({x for x in prod if re.fullmatch(r"Y7T_[A-Z0-9_]+", x)})
+    assert not set(exp) & set(env_prod), env_prod                          # experiment switches are not even named in the product library
+    assert set(exp) <= {x for x in abl if re.fullmatch(r"Y7T_[A-Z0-9_]+", x)}
+    assert env_prod == ["Y7T_CONV_WS_DYN", "Y7T_TRACKER_ARENA"], env_prod   # the two switches the product library itself reads
+
+
+def test_readme_lists_the_product_switches():
+    """... and the package's run-time switches are the ten of _lib.PRODUCT_SWITCHES, each named in README.md; any other Y7T_* variable is honoured by the lowering only
+    beside the measuring build"""
+    from yolov7_tracker_amd import _lib
+    assert len(_lib.PRODUCT_SWITCHES) <= 10
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for name in _lib.PRODUCT_SWITCHES:
+        assert name in readme, name
+    old = os.environ.get("Y7T_LIB")
+    try:
+        os.environ.pop("Y7T_LIB", None)
+        os.environ["Y7T_CONV_PATCH_MIN_PIX"] = "1"
+        if not _lib.ablate_build():
+            assert _lib.switch("Y7T_CONV_PATCH_MIN_PIX", "25600") == "25600"
+        os.environ["Y7T_LIB"] = "/x/liby7t_ablate.so"
+        assert _lib.switch("Y7T_CONV_PATCH_MIN_PIX", "25600") == "1"
+    finally:
+        os.environ.pop("Y7T_CONV_PATCH_MIN_PIX", None)
+        os.environ.pop("Y7T_LIB", None)
+        if old is not None:
+            os.environ["Y7T_LIB"] = old

@@ -107,7 +107,9 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     print("launch list @ B=%d:" % B_BENCH, dict(hist))
     fam = collections.Counter(n.split("<")[0] for n in names)
     # the kernel families 45 % of the bench's conv time runs on (profiles/r01_bench_kernel_stats.csv) are all in this list
-    assert fam["patch"] >= 10 and (fam["patch_mt"] >= 4 or fam["ws64"] == 7) and fam["patch_strip"] >= 8, fam
+    assert fam["patch"] + fam["ws128"] >= 10 and (fam["patch_mt"] >= 4 or fam["ws64"] == 7) and fam["patch_strip"] >= 8, fam
+    if os.environ.get("Y7T_CONV_WS128", "1") != "0":                     # the 128 -> 128 k layers with the filter bank in registers, tiles from the op's tile counter (round 5)
+        assert fam["ws128"] == 11 and all(n.endswith(" dyn") for n in names if n.startswith(("ws64", "ws128"))), hist
     # the stride-2 patch kernel where it measured faster than the generic kernel (four of the eight down-sampling layers; detector/graph.py::patch_s2_eligible)
     assert fam["patch_s2"] == {"auto": 4, "0": 0, "1": 8}[os.environ.get("Y7T_CONV_PATCH_S2", "auto")], fam
     if os.environ.get("Y7T_CONV_WS_S2", "1") != "0":

@@ -9,6 +9,25 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("Y7T_LIB") or os.path.join(_HERE, "lib", "liby7t.so")   # Y7T_LIB: A/B runs against another build of the library (scripts/gpu_round.sh exp_noslp)
 
+# Run-time switches (README "switches").  The product keeps ten, read wherever they apply; every other Y7T_* variable is an EXPERIMENT switch -- lowering thresholds,
+# tile variants, timing ablations -- and is honoured only when the measuring build is loaded (Y7T_LIB=.../liby7t_ablate.so, the same sources with -DY7T_ABLATE_BUILD:
+# csrc/y7t_common.h).  With the product library they answer their measured default whatever the environment says.
+PRODUCT_SWITCHES = ("Y7T_LIB", "Y7T_CONV_WS", "Y7T_CONV_WS_S2", "Y7T_CONV_WS128", "Y7T_CONV_WS_DYN", "Y7T_CONV_P8", "Y7T_CONV_PATCH_S2", "Y7T_UPSAMPLE_ON_READ",
+                    "Y7T_STEM_FUSED", "Y7T_TRACKER_ARENA")
+
+
+def ablate_build():
+    """True when the loaded library is the measuring build (liby7t_ablate.so)"""
+    return "ablate" in os.path.basename(os.environ.get("Y7T_LIB") or LIB_PATH)
+
+
+def switch(name, default):
+    """value of a Y7T_* switch as the lowering should see it (a string, like os.environ.get)"""
+    if name in PRODUCT_SWITCHES or ablate_build():
+        return os.environ.get(name, default)
+    return default
+
+
 c_void_p, c_int, c_double, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); kept in sync with include/y7t.h (tests/test_abi.py checks the header)

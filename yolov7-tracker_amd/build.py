@@ -1,7 +1,10 @@
-"""Build liby7t.so (all HIP translation units of csrc/) for gfx950 with hipcc, in-tree.
+"""Build liby7t.so (all HIP translation units of csrc/) for gfx950 with hipcc, in-tree -- and liby7t_ablate.so, the same sources with -DY7T_ABLATE_BUILD:
+the measuring build that reads the experiment switches from the environment and carries the timing-ablation / tile-variant instances ("wrong results" kernels
+among them), which the product library does not (csrc/y7t_common.h; load it with Y7T_LIB=<path>).
 
-    python -m yolov7_tracker_amd.build          # incremental
+    python -m yolov7_tracker_amd.build          # incremental, both libraries
     python -m yolov7_tracker_amd.build --force
+    python -m yolov7_tracker_amd.build --product-only
 
 hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container; the
 resulting yolov7-tracker_amd/lib/liby7t.so travels to the GPU box with the repo snapshot.
@@ -16,6 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liby7t.so")
+OBJ_ABLATE = os.path.join(HERE, "build_ablate")
+LIB_ABLATE = os.path.join(LIBDIR, "liby7t_ablate.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: the float64 tracker arithmetic must round like the plain-C oracle
@@ -39,35 +44,44 @@ def _headers():
     return hs
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(src, force, ablate=False):
+    obj = os.path.join(OBJ_ABLATE if ablate else OBJ, src[:-4] + ".o")
     spath = os.path.join(CSRC, src)
     newest = max([os.path.getmtime(spath)] + [os.path.getmtime(h) for h in _headers()])
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", spath, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (["-DY7T_ABLATE_BUILD"] if ablate else []) + ["-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     return obj, True
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def _build_one(force, verbose, ablate):
+    obj_dir, lib = (OBJ_ABLATE, LIB_ABLATE) if ablate else (OBJ, LIB)
+    os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force, ablate), srcs))
     objs = [o for o, _ in res]
-    if force or any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or any(c for _, c in res) or not os.path.exists(lib):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
-            print("built", LIB)
-    return LIB
+            print("built", lib)
+    return lib
+
+
+def build(force=False, verbose=False, ablate=True):
+    """-> path of the product library; ablate=True also (re)builds lib/liby7t_ablate.so"""
+    lib = _build_one(force, verbose, False)
+    if ablate:
+        _build_one(force, verbose, True)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablate="--product-only" not in sys.argv))

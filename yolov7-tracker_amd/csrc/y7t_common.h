@@ -27,6 +27,19 @@ void y7t_note_kernel(const char* fmt, ...);   // see y7t_last_kernel()
 
 #define Y7T_LAUNCH_CHECK() Y7T_HIP_CHECK(hipGetLastError())
 
+// Run-time switches.  The PRODUCT library (lib/liby7t.so) answers every EXPERIMENT switch with its measured default -- it does not read the environment for them and
+// carries none of the timing-ablation ("wrong results") or tile-variant instances; the same sources built with -DY7T_ABLATE_BUILD give lib/liby7t_ablate.so, which
+// does (load it with Y7T_LIB=<path>; scripts/*ablat*.sh, scripts/sweep_conv.py).  y7t_switch(): the handful of switches the product itself keeps (README).
+#include <stdlib.h>
+static inline int y7t_switch(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#if defined(Y7T_ABLATE_BUILD)
+#define Y7T_ABLATE 1
+static inline int y7t_exp_switch(const char* name, int dflt) { return y7t_switch(name, dflt); }
+#else
+#define Y7T_ABLATE 0
+static inline int y7t_exp_switch(const char*, int dflt) { return dflt; }
+#endif
+
 // One-time set-up that is PER DEVICE (kernel attributes such as hipFuncAttributeMaxDynamicSharedMemorySize; the CU count): a done-bit per device, set after the
 // call succeeded, so that a second device of the process -- or two threads racing -- never skip it (ADVICE r3 for the tracker, r4 for the conv / stem kernels).
 #include <atomic>

@@ -487,11 +487,11 @@ template <int BM, int BN, int BK, int NST, bool UT, int KM = 0, int EPI = 0, boo
 static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     constexpr unsigned lds_stage = NST * (BM + BN) * BK * 2, lds_epi = EPI == 1 ? BM * (BN + 1) * 4 : BM * (BN * 2 + 16);
     constexpr unsigned lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + BN * 4;   // + the bias corner
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv_igemm<BM, BN, BK, NST, UT, KM, EPI, DUAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.Cout_pad / BN, tiles = tiles_m * tiles_n;
     Y7TConvArgs b = a;
     const int nk = a.K_pad / BK;
@@ -532,7 +532,7 @@ static int launch_conv(const Y7TConvArgs& a, hipStream_t s) {
 
 static int conv_variant() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("Y7T_CONV_VARIANT"); v = e ? atoi(e) : 0; }
+    if (v < 0) v = y7t_exp_switch("Y7T_CONV_VARIANT", 0);
     return v;
 }
 
@@ -553,11 +553,11 @@ int y7t_conv_launch(const Y7TConvArgs& a, hipStream_t s) {
     b.in_bytes = (unsigned)((long long)a.B * a.H * a.W * a.ldin * 2);
     b.w_bytes = (unsigned)((long long)a.Cout_pad * a.K_pad * 2);
     b.in2_bytes = a.up_C > 0 ? (unsigned)((long long)a.B * (a.H / 2) * (a.W / 2) * a.ldin2 * 2) : 0u;
-    { static int xs = -1; if (xs < 0) { const char* e = getenv("Y7T_CONV_XCD"); xs = e ? atoi(e) : 1; } b.xcd_swizzle = xs; }
-    { static int sk = -1; if (sk < 0) { const char* e = getenv("Y7T_CONV_SPLITK"); sk = e ? atoi(e) : 1; } b.allow_splitk = sk; }
+    { static int xs = -1; if (xs < 0) xs = y7t_exp_switch("Y7T_CONV_XCD", 1); b.xcd_swizzle = xs; }
+    { static int sk = -1; if (sk < 0) sk = y7t_exp_switch("Y7T_CONV_SPLITK", 1); b.allow_splitk = sk; }
     b.splitk = 1; b.ksteps = b.K_pad; b.partial = nullptr;
-    { static int to = -1; if (to < 0) { const char* e = getenv("Y7T_CONV_TILE_ORDER"); to = e ? atoi(e) : 1; } b.tile_order = to; }
-    { static int ab = -1; if (ab < 0) { const char* e = getenv("Y7T_CONV_ABLATE"); ab = e ? atoi(e) : 0; } b.ablate = ab; }
+    { static int to = -1; if (to < 0) to = y7t_exp_switch("Y7T_CONV_TILE_ORDER", 1); b.tile_order = to; }
+    { static int ab = -1; if (ab < 0) ab = y7t_exp_switch("Y7T_CONV_ABLATE", 0); b.ablate = ab; }      // (always 0 in the product library)
     return conv_dispatch(b, s);
 }
 
@@ -603,6 +603,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     const bool wide = a.Cout_pad % 128 == 0;
     const int var = conv_variant();
     switch (var > 8 ? 0 : var) {
+#if Y7T_ABLATE      // the tile / ring variants of the generic kernel (rounds 1-3 sweeps, scripts/sweep_conv.py): liby7t_ablate.so only
     case 1: return wide ? launch_conv<128, 128, 64, 3>(a, s) : launch_conv<128, 64, 64, 3>(a, s);
     case 2: return wide ? launch_conv<128, 128, 32, 3>(a, s) : launch_conv<128, 64, 32, 3>(a, s);
     case 3: return wide ? launch_conv<128, 128, 32, 4>(a, s) : launch_conv<128, 64, 32, 4>(a, s);
@@ -611,6 +612,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
     case 6: return wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
     case 8: return a.Cout_pad % 256 == 0 ? launch_conv<256, 256, 64, 2>(a, s) : wide ? launch_conv<256, 128, 64, 2>(a, s) : launch_conv<256, 64, 64, 2>(a, s);
     case 7: return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);
+#endif
     default: {
         const bool big256 = (long long)(a.M / 256) * (a.Cout_pad / (wide ? 128 : 64)) >= 2048;   // enough 256-pixel tiles to fill the chip 4x
         // measured per-layer (scripts/bench_conv.py): the HBM-bound 1x1 layers prefer the lighter 32-deep stages (4 blocks/CU),
@@ -624,7 +626,7 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
         // small maps whose 128-channel tiles do not fill the chip but whose 64-channel tiles do (the 20 x 20 256-channel 3x3 layers at 32 frames: 200 vs 400 tiles):
         // twice the workgroups instead of split-K partial sums + a reduce launch: 229 -> 191 us for those four launches (profiles/r04_small_experiments.txt;
         // Y7T_CONV_NARROW=0: the split-K path)
-        static const int narrow = []() { const char* e = getenv("Y7T_CONV_NARROW"); return e ? atoi(e) : 1; }();
+        static const int narrow = y7t_exp_switch("Y7T_CONV_NARROW", 1);
         const int tm = (a.M + 127) / 128;
         if (narrow && wide && tm * (a.Cout_pad / 128) < 256 && tm * (a.Cout_pad / 64) >= 256) return launch_conv<128, 64, 64, 2>(a, s);
         return wide ? launch_conv<128, 128, 64, 2>(a, s) : launch_conv<128, 64, 64, 2>(a, s);

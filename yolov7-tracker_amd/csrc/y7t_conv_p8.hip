@@ -286,15 +286,16 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
                       a.up_c0 + a.up_C);
         return Y7T_E_ARG;
     }
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
 #define P8_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<ACT, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         P8_ATTR(Y7T_ACT_NONE, false) P8_ATTR(Y7T_ACT_SILU, false) P8_ATTR(Y7T_ACT_LEAKY, false) P8_ATTR(Y7T_ACT_NONE, true) P8_ATTR(Y7T_ACT_SILU, true) P8_ATTR(Y7T_ACT_LEAKY, true)
 #undef P8_ATTR
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     const int grid = ((a.M + C::BM - 1) / C::BM) * (a.Cout_pad / C::BN);
     const bool dual = a.up_C > 0;
+#if Y7T_ABLATE      // liby7t_ablate.so only
     if (a.ablate && a.act == Y7T_ACT_SILU && !dual) {      // timing ablations of the plain SiLU instance (Y7T_CONV_ABLATE=1|2|4|8|16; wrong results)
 #define P8_ABL(N) case N: Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<Y7T_ACT_SILU, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
                           hipLaunchKernelGGL((k_conv1x1_p8<Y7T_ACT_SILU, false, N>), dim3(grid), dim3(C::NT), C::LDS, s, a); break;
@@ -304,6 +305,7 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_note_kernel("p8<256,256,64> 1x1 ablated");
         return 0;
     }
+#endif
 #define P8_GO(ACT) \
     do { if (dual) hipLaunchKernelGGL((k_conv1x1_p8<ACT, true>), dim3(grid), dim3(C::NT), C::LDS, s, a); \
          else hipLaunchKernelGGL((k_conv1x1_p8<ACT, false>), dim3(grid), dim3(C::NT), C::LDS, s, a); } while (0)

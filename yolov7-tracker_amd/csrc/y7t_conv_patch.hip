@@ -649,11 +649,11 @@ int launch_patch_mt(const Y7TConvArgs& a, hipStream_t s) {
     using C0 = PatchCfg<TW, TH, 64>;
     constexpr int lds = 3 * C0::W_BYTES + 2 * C0::PATCH_BYTES + 64 * 4;       // weight ring | patch A | patch B | biases
     static_assert(lds <= 81920, "two workgroups per CU");
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch_mt<TW, TH, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     const int ptiles = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     hipLaunchKernelGGL((k_conv3x3_patch_mt<TW, TH, MT>), dim3(((ptiles + MT - 1) / MT) * (a.Cout_pad / 64)), dim3(256), lds, s, a);
     Y7T_LAUNCH_CHECK();
@@ -664,11 +664,11 @@ int launch_patch_mt(const Y7TConvArgs& a, hipStream_t s) {
 template <int TW, int TH, int BN, int ABL = 0>
 int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
     using C = PatchCfg<TW, TH, BN>;
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_patch<TW, TH, BN, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     const int ptiles = C::FLAT ? (a.B * (a.H + 2) * C::PW + 255) / 256 : a.B * ((a.H + TH - 1) / TH) * ((a.W + (C::FLAT ? 1 : TW) - 1) / (C::FLAT ? 1 : TW));
     const int tiles = ptiles * (a.Cout_pad / BN);
     hipLaunchKernelGGL((k_conv3x3_patch<TW, TH, BN, ABL>), dim3(tiles), dim3(256), C::LDS, s, a);
@@ -683,7 +683,7 @@ int launch_patch(const Y7TConvArgs& a, hipStream_t s) {
 // 1 if the layer was launched on the patch kernel, 0 if it is not eligible (caller falls back to k_conv_igemm), < 0 on error
 int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("Y7T_CONV_PATCH"); mode = e ? atoi(e) : 1; }
+    if (mode < 0) mode = y7t_exp_switch("Y7T_CONV_PATCH", 1);
     const bool eligible = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 64 == 0 && !a.out_f32 && !(a.Cout & 7) && !(a.ldout & 7) &&
                           !(a.cout_off & 7) && a.Ho == a.H && a.Wo == a.W && a.in_bytes <= kOOB - (1u << 24) && a.w_bytes <= kOOB - (1u << 24);
     if (a.korder == 2 && (!eligible || !mode)) {   // panel-packed weights only make sense to this kernel
@@ -702,18 +702,22 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
     const double eflat = (a.W == 40 || a.W == 20) ? (double)(a.W * a.H) / ((a.W + 2) * (a.H + 2)) : 0.0;   // strip tiling (instantiated for W = 20, 40)
     // too few workgroups for 256 CUs (batch-1 latency mode): the generic kernel with split-K fills the chip better
     if (!a.force_patch && a.korder != 2 && (long long)a.B * a.H * a.W * (a.Cout_pad / (wide ? 128 : 64)) < 256ll * 256) return 0;
-    const int abl = a.ablate;      // (ABL = 512, the step's DMAs behind its MFMAs, was measured in round 3: 15.98 vs 16.02 ms for the list -- not instantiated any more)
+    const int abl = Y7T_ABLATE ? a.ablate : 0;      // (ABL = 512, the step's DMAs behind its MFMAs, was measured in round 3: 15.98 vs 16.02 ms for the list -- not instantiated any more)
     if (eflat > (use16 ? e16 : e32) && eflat >= 0.8 && (!abl || abl == 2048)) {
         int rcf;
+#if Y7T_ABLATE
         if (abl == 2048) {
             if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128, 2048>(a, s) : launch_patch<0, 42, 64, 2048>(a, s);
             else rcf = wide ? launch_patch<0, 22, 128, 2048>(a, s) : launch_patch<0, 22, 64, 2048>(a, s);
-        } else if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
+        } else
+#endif
+        if (a.W == 40) rcf = wide ? launch_patch<0, 42, 128>(a, s) : launch_patch<0, 42, 64>(a, s);
         else rcf = wide ? launch_patch<0, 22, 128>(a, s) : launch_patch<0, 22, 64>(a, s);
         return rcf ? rcf : 1;
     }
     if (!a.force_patch && a.korder != 2 && (use16 ? e16 : e32) < 0.8) return 0;
     int rc;
+#if Y7T_ABLATE      // liby7t_ablate.so only: the burst-read form and the timing ablations ("wrong results") of the 16 x 16 x 128 kernel
     if (abl == 2048) {      // A/B: the burst-read form (rounds 1-3a) of the default kernels, correct results
         if (use16) rc = wide ? launch_patch<16, 16, 128, 2048>(a, s) : launch_patch<16, 16, 64, 2048>(a, s);
         else rc = wide ? launch_patch<32, 8, 128, 2048>(a, s) : launch_patch<32, 8, 64, 2048>(a, s);
@@ -732,8 +736,9 @@ int y7t_conv_patch_try(const Y7TConvArgs& a, hipStream_t s) {
         default: break;
         }
     }
+#endif
     static int mt = -1;
-    if (mt < 0) { const char* e = getenv("Y7T_CONV_PATCH_MT"); mt = e ? atoi(e) : 1; }
+    if (mt < 0) mt = y7t_exp_switch("Y7T_CONV_PATCH_MT", 1);
     const int ptiles = a.B * ((a.H + (use16 ? 15 : 7)) / (use16 ? 16 : 8)) * ((a.W + (use16 ? 15 : 31)) / (use16 ? 16 : 32));
     if (!wide && mt && !abl && (ptiles * (a.Cout_pad / 64) >= 4 * 2048 || a.force_patch)) {   // (force_patch: tests)   // 64-channel panels on big maps: multi-tile workgroups
         rc = use16 ? launch_patch_mt<16, 16, 4>(a, s) : launch_patch_mt<32, 8, 4>(a, s);

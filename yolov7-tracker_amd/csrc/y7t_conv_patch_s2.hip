@@ -288,11 +288,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_conv3x3s2_patch(co
 template <int BN, int NW, int ORD>
 int launch_s2_ord(const Y7TConvArgs& a, hipStream_t s) {
     using C = S2Cfg<BN, NW>;
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_patch<BN, NW, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     const int ptiles = a.B * ((a.Ho + C::TH - 1) / C::TH) * ((a.Wo + C::TW - 1) / C::TW);
     hipLaunchKernelGGL((k_conv3x3s2_patch<BN, NW, ORD>), dim3(ptiles * (a.Cout_pad / BN)), dim3(C::NT), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
@@ -313,7 +313,7 @@ int launch_s2(const Y7TConvArgs& a, hipStream_t s) {
 // panel width the weights of a korder-4 layer are packed for (detector/weights.py::panel_pack_s2 uses the same rule)
 static int s2_bn(int Cout_pad) {
     static int force128 = -1;
-    if (force128 < 0) { const char* e = getenv("Y7T_CONV_PATCH_S2_BN"); force128 = (e && atoi(e) == 128) ? 1 : 0; }
+    if (force128 < 0) force128 = y7t_exp_switch("Y7T_CONV_PATCH_S2_BN", 0) == 128 ? 1 : 0;
     return (Cout_pad % 256 == 0 && !force128) ? 256 : 128;
 }
 

@@ -424,16 +424,17 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
             return 0;
         })) return e;
     static int wgs_env = -2;      // Y7T_CONV_WS_WGS: workgroups of a launch (default: one persistent workgroup per compute unit -- 150 KiB of LDS each)
-    if (wgs_env == -2) { const char* e = getenv("Y7T_CONV_WS_WGS"); wgs_env = e ? atoi(e) : -1; }
+    if (wgs_env == -2) wgs_env = y7t_exp_switch("Y7T_CONV_WS_WGS", -1);
     const int ncu = wgs_env > 0 ? wgs_env : y7t_num_cus();
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied a tile counter (A/B)
-    if (dyn_env < 0) { const char* e = getenv("Y7T_CONV_WS_DYN"); dyn_env = e ? atoi(e) : 1; }
+    if (dyn_env < 0) dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);
     const bool dyn = a.tile_ctr && dyn_env && ptiles < 65536;
     const int nchunks = (ptiles + C::CH - 1) / C::CH;
     const int grid = dyn ? (nchunks < ncu ? nchunks : ncu) : (ptiles < ncu ? ptiles : ncu);
+#if Y7T_ABLATE      // liby7t_ablate.so only: the timing ablations of the SiLU instance (wrong results; scripts/ws_probe.py)
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("Y7T_WS_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = y7t_exp_switch("Y7T_WS_ABLATE", 0);
     if (abl && a.act == Y7T_ACT_SILU) {
 #define Y7T_WS_ABL_CASE(N) \
         case N: \
@@ -449,6 +450,7 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
         y7t_note_kernel("ws64<16,16> ablated");
         return 0;
     }
+#endif
     if (dyn) {
         if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_SILU, 0, true>), dim3(grid), dim3(256), C::LDS, s, a);
         else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c64_ws<Y7T_ACT_LEAKY, 0, true>), dim3(grid), dim3(256), C::LDS, s, a);

@@ -366,7 +366,7 @@ int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s) {
     const int n_nt = a.Cout_pad / 128;
     const int ptiles = a.B * (a.H / C::TH) * (a.W / C::TW);
     static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied tile counters (A/B)
-    if (dyn_env < 0) { const char* e = getenv("Y7T_CONV_WS_DYN"); dyn_env = e ? atoi(e) : 1; }
+    if (dyn_env < 0) dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);
     const bool dyn = a.tile_ctr && dyn_env && n_nt <= C::MAX_NT && ptiles < 60000;
     const int units = dyn ? (ptiles + C::CH - 1) / C::CH : ptiles;      // what a workgroup starts on: a chunk, or a tile
     int grid = units * n_nt < ncu ? units * n_nt : ncu;

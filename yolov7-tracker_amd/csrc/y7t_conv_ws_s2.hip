@@ -290,21 +290,17 @@ int y7t_conv_ws_s2_launch(const Y7TConvArgs& a, hipStream_t s) {
                       "whose output is whole 2 x 32 tiles with an aligned fp16 output");
         return Y7T_E_ARG;
     }
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
 #define WS2_ATTR(ACT) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
                       Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3s2_c64_ws<ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         WS2_ATTR(Y7T_ACT_NONE) WS2_ATTR(Y7T_ACT_SILU) WS2_ATTR(Y7T_ACT_LEAKY)
 #undef WS2_ATTR
-        attr = true;
-    }
-    static int ncu = -1;      // one persistent workgroup per compute unit (154 KiB of LDS, 144 + registers of weights per lane)
-    if (ncu < 0) {
-        const char* e = getenv("Y7T_CONV_WS_WGS");
-        int dev = 0; hipDeviceProp_t prop;
-        ncu = e ? atoi(e) : (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256);
-        if (ncu <= 0) ncu = 256;
-    }
+        return 0;
+    })) return e_;
+    static int wgs_env = -2;      // Y7T_CONV_WS_WGS: workgroups of a launch (default: one persistent workgroup per compute unit -- 154 KiB of LDS, 144 + registers of weights per lane)
+    if (wgs_env == -2) wgs_env = y7t_exp_switch("Y7T_CONV_WS_WGS", -1);
+    const int ncu = wgs_env > 0 ? wgs_env : y7t_num_cus();
     const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     const int grid = ptiles < ncu ? ptiles : ncu;
     const bool fuse = a.korder == 11;      // + the twin 1x1 convolution behind it (its bank and biases follow this layer's)

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) k_spp3_lds(const half_t* __restrict__ in,
 
 // the three cascaded 5 x 5 / 1 pools of an SPP block as one launch; 1 if it cannot run this shape (the caller launches them one by one)
 int y7t_spp3_try(const half_t* in, int ldin, int cin_off, int B, int H, int W, int C, half_t* out, int ldout, int cout_off, hipStream_t s) {
-    static const int on = []() { const char* e = getenv("Y7T_SPP3"); return e ? atoi(e) : 1; }();
+    static const int on = y7t_exp_switch("Y7T_SPP3", 1);
     if (!on || C % 16 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8 || H * W > 1024) return 1;
     hipLaunchKernelGGL(k_spp3_lds, dim3(B * (C / 16)), dim3(256), (size_t)H * W * 64, s, in, ldin, cin_off, H, W, C, out, ldout, cout_off);
     Y7T_LAUNCH_CHECK();
@@ -271,7 +271,7 @@ int y7t_maxpool_launch(const half_t* in, int ldin, int cin_off, int B, int H, in
                        int cout_off, hipStream_t s) {
     if (C % 8 || ldin % 8 || cin_off % 8 || ldout % 8 || cout_off % 8) { y7t_set_error("maxpool: channel alignment"); return Y7T_E_ARG; }
     const int Ho = (H + 2 * pd - k) / st + 1, Wo = (W + 2 * pd - k) / st + 1;
-    static const int lds_pool = []() { const char* e = getenv("Y7T_POOL_LDS"); return e ? atoi(e) : 1; }();
+    static const int lds_pool = y7t_exp_switch("Y7T_POOL_LDS", 1);
     if (lds_pool && (k == 5 || k == 9 || k == 13) && st == 1 && pd == k / 2 && C % 16 == 0 && H * W <= 1024) {
         const dim3 grid(B * (C / 16)), blk(256);
         const size_t lds = (size_t)H * W * 64;

@@ -412,7 +412,7 @@ static int reid_forward_impl(y7t_reid* r, const void* frames_u8, int n_frames, i
             a.K = op.k * op.k * op.C; a.K_pad = (a.K + 63) / 64 * 64; a.M = N * op.Ho * op.Wo; a.act = Y7T_ACT_NONE; a.splitk_ws = r->splitk_ws;
             // plain (kh, kw, ci) weights: the generic kernel is the one tested on this layout for every shape here; Y7T_REID_PATCH=1 lets the
             // 64 / 128-channel stride-1 layers of large batches take the LDS-patch kernel (faster; enable by default once it is covered)
-            { static int rp = -1; if (rp < 0) { const char* e = getenv("Y7T_REID_PATCH"); rp = e ? atoi(e) : 0; } a.no_patch = !rp; }
+            { static int rp = -1; if (rp < 0) rp = y7t_exp_switch("Y7T_REID_PATCH", 0); a.no_patch = !rp; }
             if (int rc = y7t_conv_launch(a, s)) return rc;
             break;
         }

@@ -481,15 +481,15 @@ size_t y7t_reid_fused_blob_bytes() {
 }
 
 int y7t_reid_fused_launch(const Y7TReidFusedArgs& a, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_osnet_x025, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
-    }
+        return 0;
+    })) return e_;
     if (a.N <= 0) return 0;
     static int prof = -1;
     static long long* prof_dev = nullptr;
-    if (prof < 0) { const char* e = getenv("Y7T_REID_PROF"); prof = e ? atoi(e) : 0; if (prof) Y7T_HIP_CHECK(hipMalloc((void**)&prof_dev, 32 * sizeof(long long))); }
+    if (prof < 0) { prof = y7t_exp_switch("Y7T_REID_PROF", 0); if (prof) Y7T_HIP_CHECK(hipMalloc((void**)&prof_dev, 32 * sizeof(long long))); }
     Y7TReidFusedArgs b = a;
     b.prof = prof ? prof_dev : nullptr;
     hipLaunchKernelGGL(k_osnet_x025, dim3(a.N), dim3(NT), LDS_BYTES, s, b);

@@ -267,15 +267,15 @@ int y7t_stem_u8_launch(const void* frames_u8, int B, int H0, int W0, int H, int 
     a.tiles_x = (W / 2 + TS - 1) / TS; a.tiles_y = (H / 2 + TS - 1) / TS; a.n_tiles = B * a.tiles_x * a.tiles_y;
     const bool resize = !(new_h == H0 && new_w == W0 && (left & 1) == 0 && (W0 & 1) == 0 && W0 >= 2);   // (odd geometry: the generic sampler)
     int grid = a.n_tiles < 2048 ? a.n_tiles : 2048;
-    static bool attr = false;
+    static Y7TOncePerDevice attr;      // (the attribute is per device: ADVICE r4)
     constexpr int LDSL = 2 * PATCH_BYTES + 4 * 4096;
-    if (!attr) {
+    if (int e_ = y7t_once_per_device(attr, [&]() -> int {
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PATCH_BYTES));
         Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_stem_u8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSL));
-        attr = true;
-    }
-    static const int lines = []() { const char* e = getenv("Y7T_STEM_LINES"); return e ? atoi(e) : 1; }();      // full-line stores through LDS: 597 -> 546 us at 32 frames (profiles/r04_small_experiments.txt); 0 = straight from the registers
+        return 0;
+    })) return e_;
+    static const int lines = y7t_exp_switch("Y7T_STEM_LINES", 1);      // full-line stores through LDS: 597 -> 546 us at 32 frames (profiles/r04_small_experiments.txt); 0 = straight from the registers
     if (resize) hipLaunchKernelGGL((k_stem_u8<true, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);
     else if (lines) hipLaunchKernelGGL((k_stem_u8<false, true>), dim3(grid), dim3(256), LDSL, s, a);
     else hipLaunchKernelGGL((k_stem_u8<false, false>), dim3(grid), dim3(256), 2 * PATCH_BYTES, s, a);

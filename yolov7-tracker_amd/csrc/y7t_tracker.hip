@@ -312,7 +312,7 @@ static const unsigned kFastBytes = 128 * 1024;  // fast scratch per workgroup (o
 // lists falling back to the state blob made the in-pipeline chain 12 % slower (14.1 -> 15.8 ms per 32 frames).  Y7T_TRACKER_FAST_KB overrides.
 static unsigned step_fast_bytes(int n_dets) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("Y7T_TRACKER_FAST_KB"); forced = e ? atoi(e) * 1024 : 0; }
+    if (forced < 0) forced = y7t_exp_switch("Y7T_TRACKER_FAST_KB", 0) * 1024;
     if (forced > 0) return (unsigned)(forced < (int)kFastBytes ? forced : (int)kFastBytes);
     (void)n_dets;
     return kFastBytes;
@@ -431,7 +431,7 @@ extern "C" int y7t_lapjv_f64(const double* cost, int n, int m, double cost_limit
     const int nn = n + m;
     const int threads = nn <= 128 ? 64 : (nn <= 512 ? 256 : 1024);
     static int jv = -1;
-    if (jv < 0) { const char* e = getenv("Y7T_LAP_JV_EXTENDED"); jv = e ? atoi(e) : 0; }
+    if (jv < 0) jv = y7t_exp_switch("Y7T_LAP_JV_EXTENDED", 0);
     hipLaunchKernelGGL(k_lapjv, dim3(1), dim3(threads), kFastBytes + Y7T_LDS_HDR, S(stream), cost, n, m, cost_limit, x, y, opt,
                        workspace, kFastBytes, jv);
     Y7T_LAUNCH_CHECK();
@@ -598,7 +598,7 @@ extern "C" int y7t_tracker_step_frames(void* state, const float* const* dets, co
     // LDS of the launch: header | fast scratch (cost matrix, assignment work arrays) | the pool's index lists for the length of the launch (y7t_arena_*), when the
     // CU's 160 KiB hold them beside at least 64 KiB of fast scratch (the default capacities, 1024 tracks x 1024 detections: 68 KiB of lists, 91 KiB of scratch)
     static const unsigned kLdsMax = 160 * 1024;
-    static const int use_arena = []() { const char* e = getenv("Y7T_TRACKER_ARENA"); return e ? atoi(e) : 1; }();      // (thread-safe static initialisation)
+    static const int use_arena = y7t_switch("Y7T_TRACKER_ARENA", 1);      // (thread-safe static initialisation)
     const size_t ab = use_arena ? state_arena_bytes(state) : 0;
     unsigned arena = 0, fast = kFastBytes;
     if (ab && ab + 64 * 1024 + Y7T_LDS_HDR <= kLdsMax) { arena = (unsigned)((ab + 15) & ~(size_t)15); fast = (kLdsMax - Y7T_LDS_HDR - arena) & ~15u; if (fast > kFastBytes) fast = kFastBytes; }

@@ -15,6 +15,8 @@ import os
 
 import numpy as np
 
+from .. import _lib
+
 
 def make_divisible(x, divisor):
     return math.ceil(x / divisor) * divisor
@@ -142,7 +144,7 @@ def patch_panel_rows(H, W, cout, B):
     cout_pad = -(-cout // 64) * 64
     if cout_pad % 128:
         return 64
-    below = int(os.environ.get("Y7T_CONV_PATCH_PANEL64_BELOW", "256"))
+    below = int(_lib.switch("Y7T_CONV_PATCH_PANEL64_BELOW", "256"))
     return 64 if B * H * W // 256 * (cout_pad // 128) < below else 128
 
 
@@ -160,9 +162,9 @@ def patch_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, B=1 << 2
     channels at batch B (below that -- batch-1 latency mode -- the generic kernel with split-K fills the chip better)"""
     cout_pad = -(-cout // 64) * 64
     bn = patch_panel_rows(H, W, cout, B)
-    if B * H * W * (cout_pad // bn) < int(os.environ.get("Y7T_CONV_PATCH_MIN_PIX", str(PATCH_MIN_PIX_SHALLOW if cin <= 128 else PATCH_MIN_PIX))):      # (the switch: ONE threshold for the A/B)
+    if B * H * W * (cout_pad // bn) < int(_lib.switch("Y7T_CONV_PATCH_MIN_PIX", str(PATCH_MIN_PIX_SHALLOW if cin <= 128 else PATCH_MIN_PIX))):      # (the switch: ONE threshold for the A/B)
         return False
-    if os.environ.get("Y7T_CONV_PATCH", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    if _lib.switch("Y7T_CONV_PATCH", "1") == "0" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     if not (k == 3 and s == 1 and p == 1 and cin % 64 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0 and out_coff % 8 == 0):
         return False
@@ -177,15 +179,15 @@ def patch_s2_eligible(cin, cout, k, s, p, out_ld, out_coff, out_f32, M_out=1 << 
     320^2 / 160^2 / 80^2 inputs (672 -> 587, 598 -> 491, 415 -> 395, 188 -> 164 us); with 128-channel panels (Cout = 128, 384) and on the small maps
     (fewer than ~50 000 output pixels per launch: 40^2 inputs, batch-1 latency mode) it loses -- those keep the generic kernel.
     Y7T_CONV_PATCH_S2=0 switches it off; =1 takes every layer the kernel can run (the experiment's rule; Y7T_CONV_PATCH_S2_MIN_COUT, _BN as before)."""
-    mode = os.environ.get("Y7T_CONV_PATCH_S2", "auto")
-    if mode == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    mode = _lib.switch("Y7T_CONV_PATCH_S2", "auto")
+    if mode == "0" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     cout_pad = -(-cout // 64) * 64
     can = (k == 3 and s == 2 and p == 1 and cin % 64 == 0 and cout_pad % 128 == 0 and not out_f32 and cout % 8 == 0 and out_ld % 8 == 0
            and out_coff % 8 == 0)
     if mode == "1":
-        return can and cout_pad >= int(os.environ.get("Y7T_CONV_PATCH_S2_MIN_COUT", "128"))
-    return can and cout_pad % 256 == 0 and cin >= 128 and M_out >= 50000 and os.environ.get("Y7T_CONV_PATCH_S2_BN", "") != "128"
+        return can and cout_pad >= int(_lib.switch("Y7T_CONV_PATCH_S2_MIN_COUT", "128"))
+    return can and cout_pad % 256 == 0 and cin >= 128 and M_out >= 50000 and _lib.switch("Y7T_CONV_PATCH_S2_BN", "") != "128"
 
 
 def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
@@ -193,21 +195,21 @@ def ws_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_c
     persistent workgroup per compute unit.  Measured at 32 frames (round 3): 320^2 358 -> 312 us, 160^2 91 -> 78 us per layer against the multi-tile patch
     kernel (Y7T_CONV_WS=0 switches back); needs enough 16 x 16 tiles to give every compute unit a few (below that -- batch-1 latency mode -- the launch
     keeps its current kernel)."""
-    if os.environ.get("Y7T_CONV_WS", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    if _lib.switch("Y7T_CONV_WS", "1") == "0" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     tiles = B * -(-H // 16) * -(-W // 16)
     return (k == 3 and s == 1 and p == 1 and cin == 64 and cout == 64 and H % 16 == 0 and W % 16 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0
-            and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
+            and in_coff % 8 == 0 and tiles >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
 def ws_s2_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
     """mirror of y7t_conv_ws_s2_launch (csrc/y7t_conv_ws_s2.hip): the 64 -> 128 3x3 / stride 2 layer (the first down-sampling conv of yolov7-w6) with its filter bank in
     registers and a persistent workgroup per compute unit; needs enough 2 x 32 output tiles to give every compute unit a few.  Y7T_CONV_WS_S2=0 switches it off."""
-    if os.environ.get("Y7T_CONV_WS_S2", "1") == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    if _lib.switch("Y7T_CONV_WS_S2", "1") == "0" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     Ho, Wo = H // 2, W // 2
     return (k == 3 and s == 2 and p == 1 and cin == 64 and cout == 128 and H % 2 == 0 and W % 2 == 0 and Ho % 2 == 0 and Wo % 32 == 0 and not out_f32
-            and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and B * (Ho // 2) * (Wo // 32) >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
+            and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and B * (Ho // 2) * (Wo // 32) >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
 def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20, up=None, detect=False):
@@ -215,12 +217,12 @@ def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff
     igemm<128,128,32,2> on two boxes (profiles/r04_p8_measurements.txt): deep reductions (Cin >= 1024: 16+ K-tiles amortise the tile's ~8 us of prologue / epilogue /
     drain) and Cin >= 512 on grids of >= 3000 tiles (many rounds: little quantisation loss).  The shallower layers tie or lose and stay on the 128-pixel tiles.
     up = (up_c0, up_C) of an upsample-on-read layer.  Y7T_CONV_P8=0 switches it off, Y7T_CONV_P8=all takes every eligible shape (A/B inside one session)."""
-    mode = os.environ.get("Y7T_CONV_P8", "1")
-    if mode == "0" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0" or detect:
+    mode = _lib.switch("Y7T_CONV_P8", "1")
+    if mode == "0" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0" or detect:
         return False
     tiles = -(-(B * H * W) // 256) * (cout // 256 if cout % 256 == 0 else 0)
     ok = (k == 1 and s == 1 and cin % 64 == 0 and cout % 256 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0
-          and tiles >= int(os.environ.get("Y7T_CONV_P8_MIN_TILES", "256")))
+          and tiles >= int(_lib.switch("Y7T_CONV_P8_MIN_TILES", "256")))
     if mode != "all" and "Y7T_CONV_P8_MIN_TILES" not in os.environ:
         ok = ok and (cin >= 1024 or (cin >= 512 and tiles >= 3000))
     if up is not None:
@@ -228,18 +230,19 @@ def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff
     return bool(ok)
 
 
-WS128_DEFAULT = "0"      # until the tile-counter form has been measured in the pipeline (round 5)
+WS128_DEFAULT = "1"      # round 5, on the tile counter (profiles/r05_tile_counter.txt): the list 14.77 / 14.80 -> 14.70 / 14.64 ms in the pipeline, 14.22 -> 14.05 ms alone
 
 
 def ws128_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
     """mirror of y7t_conv_ws128_launch (csrc/y7t_conv_ws128.hip): the 128 -> 128 k 3x3 / stride 1 layers with a 128-channel output tile's filter bank in the
     registers of a persistent workgroup, tiles taken from the op's tile counter.  Round 4 measured its statically partitioned form: 5-19 % faster alone, 0.2 ms slower
-    in the pipeline (profiles/r04_ws128_measurement.txt).  Y7T_CONV_WS128=0 / 1."""
-    if os.environ.get("Y7T_CONV_WS128", WS128_DEFAULT) != "1" or os.environ.get("Y7T_CONV_VARIANT", "0") != "0":
+    in the pipeline (profiles/r04_ws128_measurement.txt); round 5 on the tile counter: faster in the pipeline too (one session, launch list 14.77 / 14.80 ms without,
+    14.70 / 14.64 ms with it; the static form again +0.34 ms: profiles/r05_tile_counter.txt).  Y7T_CONV_WS128=0 switches back to the LDS-patch kernels."""
+    if _lib.switch("Y7T_CONV_WS128", WS128_DEFAULT) != "1" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     tiles = B * (H // 4) * (W // 16)
     return (k == 3 and s == 1 and p == 1 and cin == 128 and cout % 128 == 0 and cout <= 512 and H % 4 == 0 and W % 16 == 0 and not out_f32 and out_ld % 8 == 0
-            and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and tiles >= int(os.environ.get("Y7T_CONV_WS_MIN_TILES", "1024")))
+            and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and tiles >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
 def lower(nodes, H, W, max_batch=1):
@@ -316,7 +319,7 @@ def lower(nodes, H, W, max_batch=1):
         nodes[0].home = None
     # ---- upsample-on-read (cfg/deploy/yolov7-w6.yaml:75,89,103): an nn.Upsample whose only consumer is a Concat that only 1x1 / stride-1
     # convs read is never materialised -- those convs fetch its channel range from the half-resolution tensor at (y >> 1, x >> 1) ----
-    if os.environ.get("Y7T_UPSAMPLE_ON_READ", "1") != "0":
+    if _lib.switch("Y7T_UPSAMPLE_ON_READ", "1") != "0":
         users = {}
         for m in nodes:
             if m.idx in live or m.kind == "detect":
@@ -375,14 +378,16 @@ def lower(nodes, H, W, max_batch=1):
         elif p8_eligible(src.h, src.w, cin, cout, n.k, n.s, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch,
                          up=(src.virt_up[1], src.virt_up[0].c) if getattr(src, "virt_up", None) is not None else None, detect=level >= 0):
             korder = 7                               # 1x1, Cout % 256 == 0, a tile per CU: 256 x 64 panels of the ping-pong pipeline (weights.panel_pack_p8)
-        elif n.k == 1 and cin % 32 == 0 and os.environ.get("Y7T_CONV_VARIANT", "0") == "0" and os.environ.get("Y7T_CONV_WPANEL", "1") != "0":
+        elif n.k == 1 and cin % 32 == 0 and _lib.switch("Y7T_CONV_VARIANT", "0") == "0" and _lib.switch("Y7T_CONV_WPANEL", "1") != "0":
             korder = 3                               # 1x1: contiguous per-K-step weight panels (weights.panel_pack_linear)
             if (cout_pad % 128 == 0 and level < 0 and getattr(src, "virt_up", None) is None and
-                    -(-max_batch * n.h * n.w // 128) * (cout_pad // 128) < int(os.environ.get("Y7T_CONV_1X1_PANEL64_BELOW", "500"))):
+                    -(-max_batch * n.h * n.w // 128) * (cout_pad // 128) < int(_lib.switch("Y7T_CONV_1X1_PANEL64_BELOW", "500"))):
                 korder = 10                          # ... as 64-row panels where 128-row tiles number fewer than 500 (round 4, profiles/r04_smallmap_patch.txt: the 20x20
                                                      # layers with <= 512 output channels 34 -> 30, 61 -> 53, 20 -> 18 us; at 800 tiles and above 64 rows lose)
         if fuse_twin is not None:
-            assert korder == 8 and cout == 128 and K_pad == K
+            if not (korder == 8 and cout == 128 and K_pad == K):
+                return False                         # this layer does not get the stride-2 weights-stationary kernel after all (a switch that only this path reads):
+                                                     # nothing has been emitted yet -- the caller emits the layer and its twin 1x1 as two ops
             korder = 11
         op["w_off"], op["bias_off"], op["korder"], op["detect_level"] = w_off, b_off, korder, level
         if fuse_twin is not None:
@@ -394,7 +399,7 @@ def lower(nodes, H, W, max_batch=1):
                                 b_off=b_off + 128, kind=kind, act=act, macs=n.h * n.w * (ta.c + tb.c) * n.c, fused_prev=True))
             w_off += 128 * K_pad + 128 * n.c
             b_off += 256
-            return
+            return True
         if getattr(src, "virt_up", None) is not None:      # upsample-on-read: part of this concat exists only at half resolution
             un, uoff = src.virt_up
             t = nodes[un.src[0]]
@@ -441,7 +446,7 @@ def lower(nodes, H, W, max_batch=1):
         pending_copies.setdefault(j, []).append((cidx, off))
     # ---- the 64 -> 128 stride-2 layer + the twin 1x1 behind it as one op (csrc/y7t_conv_ws_s2.hip, FUSE): when the twins are the layer's ONLY consumers ----
     fuse_s2 = {}       # idx of the 3x3 node -> (a, b); the twin op is not emitted
-    if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0":      # (measured, round 4: 667 + 328 us as two launches -> 913 us as one; in the pipeline the list -0.15 ms)
+    if _lib.switch("Y7T_CONV_WS_S2_FUSE", "1") != "0":      # (measured, round 4: 667 + 328 us as two launches -> 913 us as one; in the pipeline the list -0.15 ms)
         consumers = {}
         for m in nodes:
             if m.idx in live or m.kind == "detect":
@@ -465,7 +470,11 @@ def lower(nodes, H, W, max_batch=1):
                 continue
             if n.idx in fuse_s2:
                 ta, tb = fuse_s2[n.idx]
-                emit_conv(n, nodes[n.src[0]], ta.home, ta.ld, ta.coff, 0, ta.c + tb.c, n.act, n.wkey, fuse_twin=(ta, tb))
+                if emit_conv(n, nodes[n.src[0]], ta.home, ta.ld, ta.coff, 0, ta.c + tb.c, n.act, n.wkey, fuse_twin=(ta, tb)):
+                    table[n.home] = (0, 2)           # the tensor between the two layers stays in LDS: its arena buffer (320 x 320 x 128 fp16 per frame) is not needed
+                else:
+                    fused_twin_done.discard(min(ta.idx, tb.idx))
+                    emit_conv(n, nodes[n.src[0]], n.home, n.ld, n.coff, 0, n.c, n.act, n.wkey)
             elif n.idx in twins:
                 a, b = twins[n.idx]
                 fn = Node("conv", n.src, a.c + b.c, 1, 1, 0, n.act)

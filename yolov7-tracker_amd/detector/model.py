@@ -184,7 +184,7 @@ class Detector:
             plan.anchors = (ctypes.c_float * 24)(*(flat + [0.0] * (24 - len(flat))))
             _lib.check(self._L.y7t_det_set_detect(h, len(plan.heads), plan.det["na"], plan.det["no"], plan.strides, plan.anchors))
             plan.detect_ops = [i for i, op in enumerate(plan.ops) if int(op["type"]) == 0 and int(op["detect_level"]) >= 0]
-            plan.stem_fused = bool(self._L.y7t_det_stem_fusable(h)) and os.environ.get("Y7T_STEM_FUSED", "1") != "0"
+            plan.stem_fused = bool(self._L.y7t_det_stem_fusable(h)) and _lib.switch("Y7T_STEM_FUSED", "1") != "0"
             plan.fusable = plan.det["na"] * plan.det["no"] <= 64 and all(int(plan.ops[i]["Cin"]) % 64 == 0 for i in plan.detect_ops)
             self._plans[hw] = plan
         self.plan = self._plans[hw]

@@ -3,6 +3,8 @@
 utils/torch_utils.py initialize_weights), IDetect implicit-layer folding (what tools/reparameterization.ipynb does:
 m(x + ia) * im), and packing into the [Cout_pad][K_pad] fp16 layout of the implicit-GEMM kernel."""
 import numpy as np
+
+from .. import _lib
 import torch
 
 BN_EPS = 1e-3
@@ -161,7 +163,7 @@ def panel_pack_p8(blk):
 def s2_panel_width(cout_pad):
     """panel width of the stride-2 patch kernel for a layer (csrc/y7t_conv_patch_s2.hip::s2_bn, same rule)"""
     import os
-    return 256 if cout_pad % 256 == 0 and os.environ.get("Y7T_CONV_PATCH_S2_BN", "") != "128" else 128
+    return 256 if cout_pad % 256 == 0 and _lib.switch("Y7T_CONV_PATCH_S2_BN", "") != "128" else 128
 
 
 def panel_pack_s2(blk, cin_pad):

@@ -22,11 +22,14 @@ last_gather_stats = {}   # filled by rebase_and_gather: rows / payload bytes of 
 
 
 def pack_rows(rows):
-    """(n, >= 7) float rows [frame, id, x, y, w, h, cls, ...] -> (n, 7) int32 words (boxes as float32 bit patterns)"""
+    """(n, >= 7) float rows [frame, id, x, y, w, h, cls, ...] -> (n, 7) int32 words (boxes as float32 bit patterns).  The boxes are rounded to the result file's two
+    decimals (`%.2f`, tracker/track.py:257-270) in the precision they arrive in BEFORE they are narrowed to float32: a float32 holds a two-decimal pixel coordinate to
+    6e-5, so `%.2f` of what arrives prints the digits a single-process run prints from its float64 tlwh -- the gathered files do not depend on the transit precision
+    (ADVICE r4)."""
     out = torch.empty((rows.shape[0], ROW_WORDS), dtype=torch.int32, device=rows.device)
     if rows.shape[0]:
         out[:, 0:2] = rows[:, 0:2].to(torch.int32)
-        out[:, 2:6] = rows[:, 2:6].to(torch.float32).contiguous().view(torch.int32)
+        out[:, 2:6] = (torch.round(rows[:, 2:6].to(torch.float64) * 100.0) / 100.0).to(torch.float32).contiguous().view(torch.int32)
         out[:, 6] = rows[:, 6].to(torch.int32)
     return out
 
@@ -44,7 +47,8 @@ def unpack_rows(words):
 def rebase_and_gather(rows_by_seq, n_ids_by_seq, n_seqs, group=None, device="cpu"):
     """rows_by_seq: {seq index: float tensor (n, >= 7) [frame, id(local, 1-based), x, y, w, h, cls, ...]} of THIS rank;
     n_ids_by_seq: {seq index: ids handed out in that sequence}.  Returns on rank 0 the list (per sequence) of float64 rows
-    (n, 7) [frame, id(global), x, y, w, h, cls] (boxes at the float32 precision they travel in); None elsewhere.
+    (n, 7) [frame, id(global), x, y, w, h, cls] -- SEVEN columns: the score is not part of a result row (track.py:257-270) and does not travel; boxes rounded to the
+    file format's two decimals (pack_rows), also when world == 1, so every world size writes the same bytes; None elsewhere.
     Two small collectives (id counts + row counts, one all_reduce each) and ONE gather of 28-byte rows."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0

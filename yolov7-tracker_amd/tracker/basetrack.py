@@ -8,6 +8,7 @@ objects here are views: `update()` returns STrack views built from the rows the 
 everything else (`mean`, `cov`, `state`, `tracked_stracks`, ...) is read back lazily.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -320,6 +321,9 @@ class BaseTracker(object):
         self.threads = int(getattr(opts, "tracker_threads", 0))
         nbytes = int(self._L.y7t_tracker_state_bytes(self.cap_t, self.cap_d))
         self._state = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        # the release is tied to the BLOB's lifetime, not to this object's: a copied tracker object shares the tensor, and dropping one of the two must not take the
+        # kind / arena notes away from the survivor
+        weakref.finalize(self._state, BaseTracker._release_state, self._L, int(self._state.data_ptr()))
         # numpy >= 2 keeps the float32 dtype of a freshly initiated mean; follow the
         # reference as it runs in this environment
         self._flags = 1 if int(np.__version__.split(".")[0]) >= 2 else 0
@@ -345,11 +349,11 @@ class BaseTracker(object):
 
     # ------------------------------------------------------------------------------------------
 
-    def __del__(self):
-        # the state blob is about to return to the allocator: the library drops its host-side notes for that address (y7t_tracker_release)
+    @staticmethod
+    def _release_state(L, address):
+        # the state blob has returned to the allocator: the library drops its host-side notes for that address (y7t_tracker_release)
         try:
-            if getattr(self, "_state", None) is not None and self._L is not None:
-                self._L.y7t_tracker_release(_lib.ptr(self._state))
+            L.y7t_tracker_release(ctypes.c_void_p(address))
         except Exception:
             pass
 

@@ -102,7 +102,7 @@ def main(opts, cfgs):
                                                         device_preprocess=opts.device_preprocess)
         else:
             # track.py:126: the sequence folder ('origin') or the path file every sequence is filtered out of ('yolo')
-            path = os.path.join(DATA_ROOT, seq) if opts.data_format == 'origin' else os.path.join(opts.yolo_root, opts.dataset, 'test.txt')
+            path = os.path.join(DATA_ROOT, seq) if opts.data_format == 'origin' else os.path.join(getattr(opts, 'yolo_root', './'), opts.dataset, 'test.txt')
             loader = tracker_dataloader.TrackerLoader(path, opts.img_size, opts.data_format, seq,
                                                       pre_process_method='v7', model_stride=stride,
                                                       device_preprocess=opts.device_preprocess,
