@@ -192,6 +192,29 @@ r5_dyn)
   grep -h "ws64\|ws128\|patch<16,16,128>\|TOTAL\|total" $O/per_layer_dyn.txt $O/per_layer_static.txt $O/per_layer_dyn128.txt 2>/dev/null | cut -c1-200 | tee -a $O/summary.txt
   ;;
 
+r5_batch)
+  say "r5_batch: frames per step (bench.py --batch): tile quantisation of the 4-per-CU kernels against the batch (25 pixel tiles per 80 x 80 frame: 1600 workgroups on 512 slots at 32 frames)"
+  X="--steps 12 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  for b in ${BATCHES:-32 24 40 48 64 32}; do
+    timeout 400 python bench.py $X --batch $b > $O/bench_b$b.json 2> $O/bench_b$b.err; benchsum b$b
+  done
+  ;;
+
+r5_latency)
+  say "r5_latency: batch-1 latency mode (reference Timer semantics), the frame's H2D copy as 1 / 2 / 4 concurrent pieces, one session"
+  for n in 1 2 4 1 2; do
+    timeout 400 python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_other_workloads --upload_pieces $n > $O/bench_up$n.json 2> $O/bench_up$n.err
+    python3 - $O/bench_up$n.json $n <<'PY' | tee -a $O/summary.txt
+import json, sys
+try:
+    l = json.loads([x for x in open(sys.argv[1]).read().splitlines() if x.startswith("{")][-1])
+    print("upload pieces %s: latency mode %s" % (sys.argv[2], {k: v for k, v in l["latency_mode"].items() if k != "note"}))
+except Exception as e:
+    print("upload pieces %s: no line (%r)" % (sys.argv[2], e))
+PY
+  done
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3
