@@ -37,12 +37,19 @@ PEAK_HBM = 8.0e12           # HBM3E, same guide (6.3 TB/s achievable)
 GFLOP_PER_FRAME_W6 = 354.9   # 177.45 GMAC x 2, yolov7-w6 deploy graph, nc=10, 1280x1280
 
 
+# Frames per step.  Every kernel of the list that runs several workgroups per CU pays for its last, partly filled round of workgroups; how much depends on the batch:
+# at 32 frames the 80 x 80 layers have 25 x 32 pixel tiles x 2 channel tiles = 1600 workgroups on 512 slots (3.125 rounds -> 4), the 40 x 40 strips 663 on 512 (1.3 -> 2).
+# Measured in one session (profiles/r05_batch_and_latency.txt): 24 frames 0.3051 of the MFMA peak, 32 frames 0.3194 / 0.3200, 40 frames 0.3250 (2207 vs 2169 fps).
+# 40 is also the ceiling: the 640 x 640 x 64-channel tensor of 41 frames would pass the 2 GiB a buffer descriptor's 32-bit byte offsets reach (detector/model.py).
+DEFAULT_BATCH = 40
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="GPUs (= ranks) of this node; default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step (consecutive frames of the sequence)")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frames per step (consecutive frames of the sequence); default %d: see DEFAULT_BATCH" % DEFAULT_BATCH)
     ap.add_argument("--n_obj", type=int, default=None, help="objects in the synthetic scene (default: 80 for cfg2, 500 for cfg3)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
                     help="cfg2 (default, BASELINE's metric): w6@1280 + ByteTrack, ~80 objects.  cfg3: BASELINE configs[2], w6@1280 + BoT-SORT "
@@ -59,7 +66,6 @@ def parse():
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
-    ap.add_argument("--upload_pieces", type=int, default=2, help="latency mode: the frame's H2D copy as N concurrent pieces on N streams (detector/model.py::FrameUploader; 1 = one copy)")
     ap.add_argument("--chained_frames", type=int, default=8, help="frames of the chained detect -> NMS -> ByteTrack parity run in `parity.chained` (0: off)")
     ap.add_argument("--no_other_workloads", action="store_true", help="skip the short cfg3 / cfg4 runs behind the headline line (`other_workloads`)")
     ap.add_argument("--weights", default="conditioned", choices=["conditioned", "chaotic"],
@@ -394,13 +400,12 @@ def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10, sd=None
         dev_in = torch.empty((1,) + tuple(src[0].shape), dtype=src[0].dtype, device="cuda")
         dev_in.copy_(src[0][None])
         graph, _, _ = det1.capture(dev_in, 0.01, 0.45, None)
-        upload = model.FrameUploader(dev_in, args.upload_pieces)
         trk = ByteTrack(make_opts(), frame_rate=30)
         tot = 0.0
         for i in range(n_warm + n_timed):
             torch.cuda.synchronize()
             t0 = time.perf_counter()                                   # timer.tic()
-            upload(src[i % nf])                                         # model(img.to(device)): H2D inside the timer (as `upload_pieces` concurrent pieces)
+            dev_in.copy_(src[i % nf][None], non_blocking=True)          # model(img.to(device)): H2D inside the timer
             graph.replay()                                              # forward + non_max_suppression + scale_coords + round
             cur = trk.update(dets_seq[i], None)                         # tracker.update: rows come back to the host (syncs)
             _ = [c.tlwh for c in cur]
@@ -409,9 +414,8 @@ def latency_mode(args, nc, frames_host, dets_seq, n_timed=60, n_warm=10, sd=None
                 tot += time.perf_counter() - t0                         # timer.toc()
         res[mode] = {"fps": round(n_timed / tot, 1), "ms_per_frame": round(tot / n_timed * 1e3, 3)}
     BaseTrack._count = count0
-    res["upload_pieces"] = args.upload_pieces
-    res["note"] = ("batch 1, reference Timer semantics: host frame in -> track list out, H2D inside the timer (as %d concurrent pieces), device sync every frame, "
-                   "detector + NMS as a hipGraph replay; %d timed frames after %d warm-up" % (args.upload_pieces, n_timed, n_warm))
+    res["note"] = ("batch 1, reference Timer semantics: host frame in -> track list out, H2D inside the timer, device sync every frame, detector + NMS as a hipGraph replay; "
+                   "%d timed frames after %d warm-up" % (n_timed, n_warm))
     return res
 
 
@@ -928,7 +932,7 @@ def main():
     gflop_frame = det.gflop_per_frame
     conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
     traffic, traffic_meta = None, {}
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_conv_hbm_traffic.json", "r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
     if tpath:      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed WITH the launch list they were taken on
         traffic_meta = json.load(open(tpath))
     if rank == 0:
@@ -1040,10 +1044,10 @@ def main():
                 line["cpu_baseline"], line["parity"] = cpu_baseline(args, det, frames_host, dets_seq, heads0, dets0, cands0, kept_rows0)
                 line["parity"]["weights"] = args.weights
                 if conditioned:
-                    line["parity"]["note"] = ("frame 0 of the TIMED run (same weights, same launch list, 32 frames per forward) against the fp32 oracle: raw heads, the "
+                    line["parity"]["note"] = ("frame 0 of the TIMED run (same weights, same launch list, %d frames per forward) against the fp32 oracle: raw heads, the "
                                               "pre-NMS candidate set at SURVEY 8a's full bar (same class, IoU >= 0.99 or |dcoord| <= 1 px, |dconf| <= 5e-3: every candidate, all four "
                                               "Detect levels live), and the final boxes by anchor row (every row only one side keeps is traced to the greedy NMS decision that "
-                                              "flipped and shown to be a tie within the frame's measured score noise: `reasons`)")
+                                              "flipped and shown to be a tie within the frame's measured score noise: `reasons`)" % B)
                 else:
                     line["parity"]["note"] = ("the benchmarked weights are iid random (chaotic: rounding noise x ~300 over the depth); the same kernels "
                                               "on well-conditioned seeded weights:")

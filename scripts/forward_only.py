@@ -1,5 +1,5 @@
 """N forwards of the benchmarked detector configuration and nothing else (for rocprofv3 passes whose per-dispatch rows must be attributed
-to ops): YOLOv7-w6 @ 1280, 32 uint8 frames resident in HBM, fused stem + fused Detect decode -- the launch list bench.py times.
+to ops): YOLOv7-w6 @ 1280, bench.DEFAULT_BATCH uint8 frames resident in HBM, fused stem + fused Detect decode -- the launch list bench.py times.
 Prints the launch list (op index -> kernel variant, shape, algorithmic GFLOP / bytes) as JSON on the last line."""
 import json, os, sys
 import numpy as np, torch
@@ -7,10 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov7_tracker_amd import synth
 from yolov7_tracker_amd.detector import arch, model
 
-B = int(os.environ.get("B", "32"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 import hashlib, types
-import bench       # the timed run's weights (bench.py --weights conditioned, its default)
+import bench       # the timed run's weights (bench.py --weights conditioned, its default) and its frames per step
+B = int(os.environ.get("B", str(bench.DEFAULT_BATCH)))
 WEIGHTS = os.environ.get("WEIGHTS", "conditioned")
 frames_host = synth.make_frames(B, 80, 1280, seq_idx=0)
 sd = bench.conditioned_state_dict(types.SimpleNamespace(arch="yolov7-w6", img=1280), 10, frames_host) if WEIGHTS == "conditioned" else None

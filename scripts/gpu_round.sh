@@ -215,6 +215,13 @@ PY
   done
   ;;
 
+r5_b40)
+  say "r5_b40: the benchmarked configuration at 40 frames per forward: the pinned parity tests (launch list, every op teacher-forced, heads, candidates, boxes, all levels undamped), the tile-counter plan test"
+  timeout 1500 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -s -x > $O/t_b40_pinned.log 2>&1; echo "rc=$?" >> $O/t_b40_pinned.log
+  grep -h "launch list @\|candidates:\|oracle keeps" $O/t_b40_pinned.log | cut -c1-500 | tee -a $O/summary.txt; tailsum $O/t_b40_pinned.log 3
+  timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "tile_counter or weights_stationary" > $O/t_b40_ws.log 2>&1; echo "rc=$?" >> $O/t_b40_ws.log; tailsum $O/t_b40_ws.log 2
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-op table of the benchmarked launch list (one forward of 32 frames, kernels back to back, rocprofv3 --kernel-trace) under the CURRENT environment:
+# per-op table of the benchmarked launch list (one forward of bench.DEFAULT_BATCH frames -- or B=<n> --, kernels back to back, rocprofv3 --kernel-trace) under the CURRENT environment:
 #   NAME=<label> OUT=<dir> bash scripts/per_layer_table.sh      -> $OUT/per_layer_$NAME.txt
 # (the table part of `scripts/gpu_round.sh profile`; A/B experiments call it once per variant inside one session)
 set -u
@@ -10,4 +10,4 @@ T=/tmp/plt_$NAME; rm -rf $T /tmp/kt_$NAME; mkdir -p $T $OUT
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$NAME -- python $ROOT/scripts/forward_only.py 4 > $T/forward_only.log 2>&1
   f=$(find /tmp/kt_$NAME -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $T/forward_kernel_trace.csv
   python3 $ROOT/scripts/profile_reduce.py $T "" unknown > $T/reduce.log 2>&1; grep "per-layer" $T/reduce.log )
-cp $T/conv_per_layer_b32.txt $OUT/per_layer_$NAME.txt 2>/dev/null || { echo "no table for $NAME"; cat $T/reduce.log | cut -c1-12000; tail -5 $T/forward_only.log | cut -c1-300; }
+cp $(ls $T/conv_per_layer_b*.txt 2>/dev/null | head -1) $OUT/per_layer_$NAME.txt 2>/dev/null || { echo "no table for $NAME"; cat $T/reduce.log | cut -c1-12000; tail -5 $T/forward_only.log | cut -c1-300; }

@@ -29,11 +29,11 @@ res = {}
 pf, pw = last_forward("/tmp/pf", 3), last_forward("/tmp/pw", 3)
 if pf and pw:
     fetch_kb, write_kb = sum(d.get("FETCH_SIZE", 0) for d in pf), sum(d.get("WRITE_SIZE", 0) for d in pw)
-    frames = 32
+    frames = int(META.get("B", 32))
     hbm = (2 * fetch_kb + write_kb) * 1024 / frames
     json.dump({"commit": commit, "launch_list_sha": META.get("launch_list_sha"), "weights": META.get("weights"),
                "source": "scripts/gpu_round.sh profile: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python scripts/forward_only.py 3",
-               "kernels": "every launch of one forward of the benchmarked launch list (fused stem, convs, split-K reduces, pools; %d launches), 32 frames" % len(pf),
+               "kernels": "every launch of one forward of the benchmarked launch list (fused stem, convs, split-K reduces, pools; %d launches), %d frames" % (len(pf), frames),
                "frames_per_launch_list": frames, "FETCH_SIZE_KB_per_launch_list": fetch_kb, "WRITE_SIZE_KB_per_launch_list": write_kb,
                "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as reported (uncalibrated)",
                "hbm_bytes_per_frame": hbm, "algorithmic_bytes_per_frame": 1217000000.0, "ratio_to_algorithmic": hbm / 1217000000.0},
@@ -42,11 +42,11 @@ if pf and pw:
 mb = last_forward("/tmp/mb", 3)
 if mb:
     s = {c: sum(d.get(c, 0.0) for d in mb) for c in ctrs}
-    frames, gflop = 32, 354.9
+    frames, gflop = int(META.get("B", 32)), 354.9
     exp = frames * gflop * 1e9 / (2.0 * 32 * 32 * 16)
     cyc = s["GRBM_GUI_ACTIVE"] / 8.0
     r = {"commit": commit, "launch_list_sha": META.get("launch_list_sha"), "source": "scripts/gpu_round.sh profile: rocprofv3 --kernel-trace --pmc " + " ".join(ctrs) + " -- python scripts/forward_only.py 3",
-         "scope": "the %d launches of the last forward (32 frames)" % len(mb), "sum": s, "gpu_cycles_per_xcd": cyc,
+         "scope": "the %d launches of the last forward (%d frames)" % (len(mb), frames), "sum": s, "gpu_cycles_per_xcd": cyc,
          "mfma_busy_fraction": s["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), "mfma_insts": s["SQ_INSTS_MFMA"], "expected_mfma_insts": exp,
          "valu_per_mfma": s["SQ_INSTS_VALU"] / max(1.0, s["SQ_INSTS_MFMA"]),
          "wave_cycle_split": {"wait_any": s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"], "wait_inst_any": s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]}}
@@ -80,8 +80,9 @@ try:
         lines.append("%3d %-44s %4dx%-4d %4d->%-4d %d/%d %9.1f us %8.1f TF/s %7.0f GB/s" % (op["op"], op["kernel"], op["H"], op["W"], op["Cin"], op["Cout"], op["k"], op["s"],
                                                                                     d, gf / d * 1e3 if d else 0, by / d * 1e-3 if d else 0))
         tot_us += d; tot_gf += gf
-    open(out + "/conv_per_layer_b32.txt", "w").write("op kernel shape(HxW Cin->Cout k/s)  time  TFLOP/s  algorithmic GB/s   (one forward of 32 frames, kernels timed back to back by rocprofv3 --kernel-trace)\n" +
-                                                   "\n".join(lines) + "\nTOTAL %.3f ms per 32 frames -> %.1f TFLOP/s\n" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
+    nb = int(meta.get("B", 32))
+    open(out + "/conv_per_layer_b%d.txt" % nb, "w").write("op kernel shape(HxW Cin->Cout k/s)  time  TFLOP/s  algorithmic GB/s   (one forward of %d frames, kernels timed back to back by rocprofv3 --kernel-trace)\n" % nb +
+                                                   "\n".join(lines) + "\nTOTAL %.3f ms per %d frames -> %.1f TFLOP/s\n" % (tot_us / 1e3, nb, tot_gf / tot_us * 1e3))
     print("per-layer table: TOTAL %.3f ms -> %.1f TFLOP/s" % (tot_us / 1e3, tot_gf / tot_us * 1e3))
 except Exception as e:
     print("per-layer table failed:", repr(e))

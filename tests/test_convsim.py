@@ -302,14 +302,15 @@ def test_patch_kernel_source_on_the_host(case):
 
 
 def test_patch_kernel_burst_reads_schedule_on_the_host():
-    """Y7T_CONV_ABLATE=2048 (read once per process, hence the subprocess): the instances of the patch kernels that read a step's fragments as one burst behind the
+    """Y7T_CONV_ABLATE=2048 in the MEASURING build (-DY7T_ABLATE_BUILD: the product library neither has these instances nor reads the variable; read once per
+    process, hence the subprocess): the instances of the patch kernels that read a step's fragments as one burst behind the
     barrier (the form of rounds 1-3a, kept for A/B runs; the default spreads them over the step's MFMAs) -- every PATCH_CASES shape, same reference"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from tests import test_convsim as t, _convsim as cs\n"
             "for B, H, W, Cin, Cout, act, korder, kw in t.PATCH_CASES:\n"
-            "    name = t.run_case(cs.lib(), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=1, **kw)\n"
+            "    name = t.run_case(cs.lib(('-DY7T_ABLATE_BUILD',)), B, H, W, Cin, Cout, 3, 1, act, 0, korder=korder, force_patch=1, **kw)\n"
             "    assert name.endswith('burst-reads') or name.startswith('patch_mt'), name\n"
             "    print(name)\n" % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y7T_CONV_ABLATE="2048"), capture_output=True, text=True, timeout=1500)

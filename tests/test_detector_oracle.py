@@ -286,7 +286,7 @@ def test_patch_eligibility_rule():
 
 
 def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
-    """Which kernel family each conv of the benchmarked configuration (w6 @ 1280, 32 frames) is lowered to, as `korder` counts -- every rule behind them was set by
+    """Which kernel family each conv of the benchmarked configuration (w6 @ 1280, 40 frames per forward since round 5; 32 before) is lowered to, as `korder` counts -- every rule behind them was set by
     an in-session A/B on the device (profiles/r03_*, r04_*); a change here is a change of the measured launch list.  And the batch-1 list."""
     for k in ("Y7T_CONV_WS128", "Y7T_LIB", "Y7T_CONV_WS_S2_FUSE", "Y7T_CONV_PATCH_MIN_PIX", "Y7T_CONV_PATCH_PANEL64_BELOW", "Y7T_CONV_1X1_PANEL64_BELOW", "Y7T_CONV_P8", "Y7T_CONV_WS", "Y7T_CONV_WS_S2",
               "Y7T_CONV_PATCH_S2", "Y7T_CONV_PATCH", "Y7T_CONV_VARIANT", "Y7T_CONV_WPANEL"):
@@ -297,6 +297,7 @@ def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
     # 4 stride-2 LDS-patch; 5 weights-stationary 64 -> 64; 6 weights-stationary 128 -> 128 k (round 5: eleven of the former korder-2 launches); 7 p8; 9 patch with 64-row panels (the 20x20 layers); 10 1x1 with 64-row panels (< 500 tiles);
     # 11 the stride-2 weights-stationary layer + the twin 1x1 behind it in one launch
     assert hist(32) == {0: 1, 1: 3, 2: 22, 3: 24, 4: 4, 5: 7, 6: 11, 7: 5, 9: 10, 10: 7, 11: 1}
+    assert hist(40) == {0: 1, 1: 3, 2: 22, 3: 30, 4: 4, 5: 7, 6: 11, 7: 5, 9: 10, 10: 1, 11: 1}      # 40 frames: six of the 20x20 1x1 layers reach 500 tiles of 128 rows
     h1 = hist(1)
     assert h1 == {0: 1, 1: 33, 2: 8, 3: 8, 9: 16, 10: 28, 11: 1} and h1.get(5, 0) == 0 and h1.get(7, 0) == 0 and h1.get(4, 0) == 0      # one frame: no persistent 64 -> 64 / p8 / stride-2 patch launches
     monkeypatch.setenv("Y7T_CONV_WS_S2_FUSE", "0")      # an experiment switch: nothing changes for the product library ...

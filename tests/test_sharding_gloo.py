@@ -68,9 +68,13 @@ def test_two_ranks_equal_single_process_with_global_ids():
         n_rows.append(len(want))
         assert got[s].shape == (len(want), 7)                            # frame, id, x, y, w, h, cls
         np.testing.assert_array_equal(got[s][:, :2], want[:, :2])       # frame, id: bit-exact
-        np.testing.assert_array_equal(got[s][:, 2:6], want[:, 2:6].astype(np.float32).astype(np.float64))      # boxes: exactly the float32 they travelled as
+        # boxes: rounded to the result file's two decimals in float64 BEFORE they are narrowed to the float32 they travel as ...
+        np.testing.assert_array_equal(got[s][:, 2:6], (np.round(want[:, 2:6] * 100.0) / 100.0).astype(np.float32).astype(np.float64))
         np.testing.assert_array_equal(got[s][:, 6], want[:, 6])
-        assert np.abs(got[s][:, 2:6] - want[:, 2:6]).max() < 5e-4        # ... far inside the %.2f the result files are written with (track.py:266)
+        assert np.abs(got[s][:, 2:6] - want[:, 2:6]).max() <= 5e-3 + 1e-4    # ... so they are the float64 boxes to the half unit of that last digit, and `%.2f` of what arrives
+        fmt = lambda a: ["%.2f,%.2f,%.2f,%.2f" % tuple(r) for r in a]       # prints the digits a single-process run prints from its float64 tlwh (track.py:266)
+        a, b = fmt(got[s][:, 2:6]), fmt(want[:, 2:6])
+        assert sum(x != y for x, y in zip(a, b)) <= len(a) // 200, sum(x != y for x, y in zip(a, b))      # (a float64 value within 1e-12 of a rounding boundary may print either way)
     # the wire format: 28 bytes per row, one gather padded to the fuller rank
     per_rank = [sum(n_rows[s] for s in range(N_SEQ) if s % 2 == r) for r in range(2)]
     assert stats["bytes_per_row"] == 28 and stats["rows_per_rank"] == per_rank and stats["payload_bytes_per_rank"] == 28 * max(per_rank)
@@ -83,7 +87,9 @@ def test_single_rank_path():
     assert res[0][0, 1] == 1 and res[1][0, 1] == 4 and res[1][1, 1] == 5 and res[1].shape == (2, 7) and sharding.last_gather_stats["payload_bytes_per_rank"] == 0
     w = sharding.pack_rows(torch.tensor([[7, 3, 10.25, -2.5, 33.125, 1e3, 9, .5]], dtype=torch.float64))
     assert w.dtype == torch.int32 and w.shape == (1, 7) and w.numel() * 4 == 28
-    assert sharding.unpack_rows(w).tolist() == [[7, 3, 10.25, -2.5, 33.125, 1e3, 9]]
+    got = sharding.unpack_rows(w).tolist()
+    assert got[0][:2] == [7, 3] and got[0][6] == 9 and got[0][2] == 10.25 and got[0][3] == -2.5 and got[0][5] == 1e3
+    assert abs(got[0][4] - 33.12) < 1e-5 or abs(got[0][4] - 33.13) < 1e-5          # 33.125 travels as the two-decimal value it would be written as (track.py:266)
 
 
 # ---- single-stream mode: frame-sharded detection, tracker on rank 0 ----

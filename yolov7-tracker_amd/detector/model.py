@@ -104,39 +104,6 @@ class HeadOutput:
         return torch.float32
 
 
-class FrameUploader:
-    """Host -> device copy of ONE frame as `n` concurrent pieces on `n` streams (batch-1 latency mode: the frame's H2D copy sits inside the reference's timer,
-    tracker/track.py:140-145 `model(img.to(device))`).  A single hipMemcpyAsync of a 4.9 MB uint8 frame moves at ~24 GB/s (one SDMA engine, ~205 us:
-    profiles/r03_latency_trace.txt); pieces on separate streams are served by separate engines.  dst: a fixed device tensor (the captured hipGraph's input), src: a pinned
-    host tensor of the same shape and dtype.  The caller's current stream waits for all pieces."""
-
-    def __init__(self, dst, n=2):
-        self.dst = dst.view(-1)
-        self.n = max(1, int(n))
-        self.streams = [torch.cuda.Stream() for _ in range(self.n - 1)]
-        self.events = [torch.cuda.Event() for _ in range(self.n - 1)]
-        self.start = torch.cuda.Event()
-        tot = self.dst.numel()
-        step = -(-tot // self.n)
-        step = -(-step // 4096) * 4096
-        self.bounds = [(min(i * step, tot), min((i + 1) * step, tot)) for i in range(self.n)]
-
-    def __call__(self, src):
-        flat = src.view(-1)
-        cur = torch.cuda.current_stream()
-        if self.n > 1:
-            self.start.record(cur)
-        for i, (lo, hi) in enumerate(self.bounds[1:]):
-            with torch.cuda.stream(self.streams[i]):
-                self.streams[i].wait_event(self.start)      # the previous frame's readers of `dst` are done
-                self.dst[lo:hi].copy_(flat[lo:hi], non_blocking=True)
-                self.events[i].record(self.streams[i])
-        lo, hi = self.bounds[0]
-        self.dst[lo:hi].copy_(flat[lo:hi], non_blocking=True)
-        for e in self.events:
-            cur.wait_event(e)
-
-
 class Plan_PostSet:
     """workspace + outputs of one decode/NMS chain (y7t_det_postprocess)"""
 
