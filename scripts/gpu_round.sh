@@ -222,6 +222,18 @@ r5_b40)
   timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "tile_counter or weights_stationary" > $O/t_b40_ws.log 2>&1; echo "rc=$?" >> $O/t_b40_ws.log; tailsum $O/t_b40_ws.log 2
   ;;
 
+r5_branches)
+  say "r5_branches a: parity with the Detect branches side by side (product library, default): the benchmarked list op by op, candidates, boxes"
+  timeout 1200 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -x -k "launch_list or every_op or candidates_before or boxes_end_to_end" > $O/t_branches.log 2>&1; echo "rc=$?" >> $O/t_branches.log; tailsum $O/t_branches.log 3
+  say "r5_branches b: bench lines, measuring build (same kernels; it reads the experiment switches): Detect branches side by side (1) / in list order (0), alternating; then the small-map panel rules at 40 frames"
+  X="--steps 16 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  export Y7T_LIB=$LIBD/liby7t_ablate.so
+  for v in br1:Y7T_DETECT_BRANCHES=1 br0:Y7T_DETECT_BRANCHES=0 br1b:Y7T_DETECT_BRANCHES=1 br0b:Y7T_DETECT_BRANCHES=0 p128:Y7T_CONV_PATCH_PANEL64_BELOW=0 p64:Y7T_CONV_PATCH_PANEL64_BELOW=400 x64:Y7T_CONV_1X1_PANEL64_BELOW=600 x128:Y7T_CONV_1X1_PANEL64_BELOW=0 br1c:Y7T_DETECT_BRANCHES=1; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } timeout 300 python bench.py $X > $O/bench_$n.json 2> $O/bench_$n.err; benchsum $n
+  done
+  unset Y7T_LIB
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

@@ -45,6 +45,10 @@ OBJ_GAIN = 2.75
 SCENES = {"visdrone": ((0.9, 0.1, 0.0, 0.0), {"IDF1": 0.88, "MOTA": 0.88, "HOTA": 0.85}),
           "all_levels": (None, {"IDF1": 0.75})}
 EMULATION_MARGIN = 0.07
+# A-priori bound on |dconf| for this head (what the kept-set explanations may invoke): the objectness LOGIT error of the fp16 network is ~0.13 % of the logit spread per
+# candidate (sigma ~5e-3 at spread 4: tests/test_detector_pinned_gpu.py), ~5 sigma = 2.5e-2 at worst over 1e5 anchors; the gain multiplies it and the sigmoid's steepest
+# slope (0.25, where this head puts its confident rows) turns it into confidence: 0.25 x 2.5e-2 x 2.75 = 1.7e-2.  Measured over both scenes: 1.2e-2 ... 1.5e-2.
+CHAINED_SCORE_NOISE = 1.75e-2
 
 
 def device_chain(det, frames_host, conf_thresh=0.2):
@@ -72,9 +76,10 @@ def test_chained_detect_nms_bytetrack_against_the_oracle_chain(scene, tmp_path):
     import collections
     from oracle import chained, detector_torch as dt
     from tests import util
-    from tests.test_detector_pinned_gpu import SCORE_NOISE, _conditioned_detector, _device_candidates
+    from tests.test_detector_pinned_gpu import _conditioned_detector, _device_candidates
     quota, bars = SCENES[scene]
     det, frames_host, _ = _conditioned_detector(0.25, obj_gain=OBJ_GAIN, level_quota=quota)
+    frames_host = frames_host[:B]
     head, handed, dev_tracks = device_chain(det, frames_host)
     torch.cuda.synchronize()
     det.check_overflow()
@@ -99,7 +104,7 @@ def test_chained_detect_nms_bytetrack_against_the_oracle_chain(scene, tmp_path):
         oa, ob = chained.detection_set_difference(ora[b], handed[b])
         common = sorted(set(got) & set(want))
         noise = max(abs(got[r][1] - want[r][1]) for r in common)
-        allowed = SCORE_NOISE * OBJ_GAIN                                                             # the a-priori bound of the pinned tests, scaled by the gain put on the objectness logits
+        allowed = CHAINED_SCORE_NOISE
         assert noise <= allowed, (b, noise)
         worst_noise = max(worst_noise, noise)
         ex = dt.explain_kept_set_difference(got, kd, want, kw, score_noise=allowed)
@@ -114,7 +119,7 @@ def test_chained_detect_nms_bytetrack_against_the_oracle_chain(scene, tmp_path):
         thr_flips += int(hi(ora[b]) != hi(handed[b]))
         assert len(oa) <= max(4, 0.05 * len(ora[b])) and len(ob) <= max(4, 0.05 * len(handed[b])), (b, len(oa), len(ob))
     print("%s: hand-over of %d frames: %d frames bit-identical to the oracle's; %d rows kept on one side only, all explained: %s; frames whose count of rows >= 0.2 differs: %d; max |dconf| %.2e (allowed %.2e)"
-          % (scene, B, exact, one_sided, dict(reasons), thr_flips, worst_noise, SCORE_NOISE * OBJ_GAIN))
+          % (scene, B, exact, one_sided, dict(reasons), thr_flips, worst_noise, CHAINED_SCORE_NOISE))
 
     # (c) the chain, graded
     ora_tracks = chained.track("bytetrack", ora)
