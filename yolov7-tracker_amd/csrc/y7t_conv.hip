@@ -496,7 +496,7 @@ static int launch_conv_ut(const Y7TConvArgs& a, hipStream_t s) {
     Y7TConvArgs b = a;
     const int nk = a.K_pad / BK;
     int S = 1;
-    if (a.allow_splitk && !a.no_splitk && EPI == 0 && tiles < 256 && nk >= 8) {      // (below 512 tiles, measured in round 4: the 20x20 1x1 layers 34 -> 57 us, 61 -> 67 us)
+    if (a.allow_splitk && EPI == 0 && tiles < 256 && nk >= 8) {      // (below 512 tiles, measured in round 4: the 20x20 1x1 layers 34 -> 57 us, 61 -> 67 us)
         S = (512 + tiles - 1) / tiles;
         if (S > nk / 4) S = nk / 4;
         if (S > 16) S = 16;

@@ -50,7 +50,6 @@ struct Y7TConvArgs {
     // out (one counter per output-channel tile of the launch), [Y7T_TILE_CTR_DONE] workgroups that have left (the last one resets them all).  One set per op of a
     // detector's plan (y7t_detector.hip); null = static partition (the single-layer entry point).
     int* tile_ctr;
-    int no_splitk;     // this launch may run beside another launch of the same detector (the Detect branches): it must not use the detector's split-K workspace
 };
 #define Y7T_TILE_CTR_DONE 4
 #define Y7T_TILE_CTR_INTS 8

@@ -18,14 +18,6 @@ struct y7t_det {
     float* splitk_ws = nullptr;
     int* tile_ctr = nullptr;      // Y7T_TILE_CTR_INTS ints per op, zero between launches: the tile counters of the persistent conv kernels (Y7TConvArgs::tile_ctr)
     int max_batch;
-    // The Detect branches -- per level a 3x3 expander + the Detect 1x1 conv, the last ops of the list (cfg/deploy/yolov7-w6.yaml:152-158) -- do not depend on each
-    // other: launched one after the other each pays for its own partly filled last round of workgroups (at 40 frames: 80 x 80 256 -> 512 fills 6.25 rounds of 512
-    // slots, the 40 x 40 strips 3.2, the 20 x 20 strips 1.2, the 20 x 20 Detect conv an eighth of one).  Launched side by side on four streams they fill each
-    // other's tails.  tail0: first op of that group (-1: the plan does not end that way); branch[i]: the level whose stream op tail0 + i goes to.
-    int tail0 = -1;
-    std::vector<int> branch;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // Detect levels (y7t_det_set_detect)
     int nl = 0, na = 0, no = 0;
     float stride[4] = {0, 0, 0, 0}, anchors[24] = {0};
@@ -66,42 +58,12 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
         y7t_set_error("y7t_det_create: cannot allocate the tile counters");
         return Y7T_E_HIP;
     }
-    // ---- the independent Detect branches at the end of the list ----
-    {
-        int t0 = n_ops;
-        std::vector<int> lvl_of(n_ops, -1);
-        bool ok = true;
-        int nlev = 0;
-        for (int i = n_ops - 1; i >= 0 && ok; --i) {
-            const y7t_op& o = ops[i];
-            if (o.type != Y7T_OP_CONV) break;
-            if (o.detect_level >= 0) { lvl_of[i] = o.detect_level; t0 = i; nlev = nlev > o.detect_level + 1 ? nlev : o.detect_level + 1; continue; }
-            int user = -1, users = 0;      // an expander: its output is read by exactly one later op, a Detect conv
-            for (int k = i + 1; k < n_ops; ++k)
-                if (ops[k].in_buf == o.out_buf && ops[k].in_coff < o.out_coff + o.Cout && o.out_coff < ops[k].in_coff + ops[k].Cin) { user = k; ++users; }
-            if (users == 1 && ops[user].detect_level >= 0 && ops[user].type == Y7T_OP_CONV) { lvl_of[i] = ops[user].detect_level; t0 = i; }
-            else break;
-        }
-        // the group must hold, per level, one expander and one Detect conv, and nothing before it may read what the group writes
-        int cnt[4] = {0, 0, 0, 0};
-        for (int i = t0; i < n_ops; ++i) { if (lvl_of[i] < 0 || lvl_of[i] > 3) ok = false; else cnt[lvl_of[i]]++; }
-        for (int l = 0; l < nlev; ++l) ok = ok && cnt[l] == 2;
-        if (ok && nlev >= 2 && nlev <= 4 && n_ops - t0 == 2 * nlev) {
-            bool made = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) == hipSuccess;
-            for (int k = 0; k < nlev - 1 && made; ++k)
-                made = hipStreamCreateWithFlags(&d->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&d->ev_join[k], hipEventDisableTiming) == hipSuccess;
-            if (made) { d->tail0 = t0; d->branch.assign(lvl_of.begin() + t0, lvl_of.end()); }
-            else (void)hipGetLastError();      // no side streams: the list runs in order
-        }
-    }
     *out = d;
     return 0;
 }
 
 extern "C" int y7t_det_destroy(y7t_det* d) {
     if (!d) return 0;
-    for (int k = 0; k < 3; ++k) { if (d->side[k]) (void)hipStreamDestroy(d->side[k]); if (d->ev_join[k]) (void)hipEventDestroy(d->ev_join[k]); }
-    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->tile_ctr) (void)hipFree(d->tile_ctr);
     if (d->zeros) (void)hipFree(d->zeros);
     if (d->splitk_ws) (void)hipFree(d->splitk_ws);
@@ -117,21 +79,8 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
     Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
     if (last < 0) last = (int)d->ops.size();
     Y7T_ARG_CHECK(first >= 0 && first <= last && last <= (int)d->ops.size());
-    // the Detect branches side by side (see y7t_det): only when the call covers the whole group, and from 8 frames on (below that every launch is a few microseconds
-    // and the fork / join edges cost more than the tails they hide: profiles/r04_latency_lowering.txt)
-    static const int branches_on = y7t_exp_switch("Y7T_DETECT_BRANCHES", 1);
-    const bool fork = branches_on && d->tail0 >= 0 && first <= d->tail0 && last == (int)d->ops.size() && B >= 8;
-    hipStream_t const s_main = s;
     for (int oi = first; oi < last; ++oi) {
         const y7t_op& op = d->ops[oi];
-        if (fork && oi >= d->tail0) {
-            if (oi == d->tail0) {
-                Y7T_HIP_CHECK(hipEventRecord(d->ev_fork, s_main));
-                for (int k = 0; k < 3 && d->side[k]; ++k) Y7T_HIP_CHECK(hipStreamWaitEvent(d->side[k], d->ev_fork, 0));
-            }
-            const int l = d->branch[oi - d->tail0];
-            s = l == 0 ? s_main : d->side[l - 1];
-        }
         const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);
         void* outp = d->arena + d->bufs[op.out_buf];
         int rc = 0;
@@ -146,7 +95,6 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
             a.M = B * op.Ho * op.Wo; a.act = op.act; a.zeros = d->zeros; a.korder = op.korder; a.force_patch = 0;
             a.splitk_ws = d->splitk_ws;
             a.tile_ctr = d->tile_ctr + Y7T_TILE_CTR_INTS * oi;
-            a.no_splitk = fork && oi >= d->tail0;      // (the split-K slabs are ONE workspace per detector: launches that run side by side must not use it)
             if (op.up_C > 0) {
                 a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf]);
                 a.ldin2 = op.up_ld; a.cin2_off = op.up_coff; a.up_c0 = op.up_c0; a.up_C = op.up_C;
@@ -186,11 +134,6 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
         }
         if (rc) return rc;
     }
-    if (fork)
-        for (int k = 0; k < 3 && d->side[k]; ++k) {
-            Y7T_HIP_CHECK(hipEventRecord(d->ev_join[k], d->side[k]));
-            Y7T_HIP_CHECK(hipStreamWaitEvent(s_main, d->ev_join[k], 0));
-        }
     return 0;
 }
 
