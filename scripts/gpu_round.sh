@@ -263,7 +263,7 @@ profile)
   P=$O/prof; mkdir -p $P
   COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown)
   ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ks /tmp/kt /tmp/pf /tmp/pw /tmp/mb
-    timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode > $P/bench_under_rocprof.log 2>&1
+    timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode --no_other_workloads > $P/bench_under_rocprof.log 2>&1
     f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/bench_kernel_stats.csv
     timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $ROOT/scripts/forward_only.py 4 > $P/forward_only.log 2>&1
     f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && cp $f $P/forward_kernel_trace.csv
