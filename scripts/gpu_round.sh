@@ -234,6 +234,25 @@ r5_branches)
   unset Y7T_LIB
   ;;
 
+r5_panel240)
+  say "r5_panel240: 128-row panels for the six 20 x 20 512 -> 512 layers only (Y7T_CONV_PATCH_PANEL64_BELOW=240; measuring build), bench lines alternating + per-op tables"
+  X="--steps 16 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  export Y7T_LIB=$LIBD/liby7t_ablate.so
+  for v in base:X=1 p240:Y7T_CONV_PATCH_PANEL64_BELOW=240 base2:X=1 p240b:Y7T_CONV_PATCH_PANEL64_BELOW=240; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } timeout 300 python bench.py $X > $O/bench_$n.json 2> $O/bench_$n.err; benchsum $n
+  done
+  for v in base:X=1 p240:Y7T_CONV_PATCH_PANEL64_BELOW=240; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } NAME=$n OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  done
+  grep -h " 20x20 .*512->512\|TOTAL" $O/per_layer_base.txt $O/per_layer_p240.txt 2>/dev/null | cut -c1-160 | tee -a $O/summary.txt
+  unset Y7T_LIB
+  ;;
+
+suite_all)
+  say "suite_all: python -m pytest tests/ -q -m gpu (no -x)"
+  timeout 1500 python -m pytest tests/ -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 6
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

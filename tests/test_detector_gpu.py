@@ -281,6 +281,8 @@ def test_pingpong_1x1_kernel_is_deterministic_under_load(L):
 def test_pingpong_1x1_upsample_on_read_equals_materialised_upsample(monkeypatch):
     """the DUAL instance inside a network: with the ping-pong kernel taking every eligible 1x1 layer of a small forward (Y7T_CONV_P8_MIN_TILES=1), the plan that reads the
     three upsampled tensors through the loader equals the plan that materialises them, bit for bit (same kernel, same K order on both sides)"""
+    # (an EXPERIMENT switch: the lowering honours it only beside the measuring build -- named here; the p8 instances themselves are in the product library that is loaded)
+    monkeypatch.setenv("Y7T_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolov7-tracker_amd", "lib", "liby7t_ablate.so"))
     monkeypatch.setenv("Y7T_CONV_P8_MIN_TILES", "1")
     img = torch.rand((2, 3, 256, 320), generator=torch.Generator().manual_seed(9))
     det = build("yolov7-w6", 10, (256, 320), 2)
