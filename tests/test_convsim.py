@@ -403,7 +403,7 @@ def test_weights_stationary_kernel_source_on_the_host(case):
 # workgroup 0 takes its two static chunks and then EVERY chunk of the counter, workgroups 1 and 2 find it exhausted after their static chunks.  Cases: one chunk for one
 # workgroup; an odd tile count (the last chunk holds one tile); fewer chunks than two per workgroup (chunk 1 dead from the start); many chunks (the ring of ids wraps);
 # a map whose tile rows are odd (a chunk straddles two tile rows / two images)
-WS_DYN_CASES = WS_CASES + [
+WS_DYN_CASES = [WS_CASES[2], WS_CASES[4]] + [      # (two of the static form's cases: slices of concat buffers over two images; 5 one-tile images on 3 workgroups)
     (1, 16, 32, 1, {}),                                                                # 2 tiles = 1 chunk, one workgroup
     (3, 48, 48, 1, {}),                                                                # 27 tiles: 14 chunks, tile rows of 3 (chunks straddle rows and images), last chunk of one tile
     (1, 96, 64, 2, {"in_ld": 128, "in_coff": 64}),                                     # 24 tiles: 12 chunks, 6 static, 6 from the counter
@@ -436,8 +436,8 @@ WS128_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dyn", [0, 1], ids=["static", "tile_counter"])
-@pytest.mark.parametrize("case", WS128_CASES, ids=lambda c: "%dx%dx%d_%d_act%d" % c[:5])
+@pytest.mark.parametrize("case,dyn", [(c, d) for i, c in enumerate(WS128_CASES) for d in (0, 1) if d or i in (1, 3)],      # every case on the tile counter; two of them also statically partitioned
+                         ids=lambda v: ("%dx%dx%d_%d_act%d" % v[:5]) if isinstance(v, tuple) else ("tile_counter" if v else "static"))
 def test_weights_stationary_128_kernel_source_on_the_host(case, dyn):
     """static partition (the single-layer entry point) and on the tile counter (a detector's plan): with Cout = 256 the two channel tiles draw from two counters"""
     B, H, W, Cout, act, kw = case
