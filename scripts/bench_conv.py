@@ -31,7 +31,7 @@ for key, cnt in shapes.items():
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
     # `act` bits of y7t_conv2d_nhwc_f16 = the weight packing the plan would give this layer (the weights are random: only the kernel choice matters here)
     if graph.ws_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 65536      # the 64 -> 128 stride-2 layer, weights stationary (Y7T_CONV_WS_S2=0: off)
-    elif graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 16384        # the 128 -> 128 k layers, weights stationary (Y7T_CONV_WS128; this entry point has no tile counter: static partition)
+    elif graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B) or graph.ws128_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 16384        # the 128 -> 128 k layers, weights stationary (Y7T_CONV_WS128; this entry point has no tile counter: static partition)
     elif graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
     elif graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = 1 | 1024
     elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32, B * Ho * Wo): code = 1 | 4096          # stride-2 patch kernel where it measured faster

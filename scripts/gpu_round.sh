@@ -253,6 +253,25 @@ suite_all)
   timeout 1500 python -m pytest tests/ -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 6
   ;;
 
+r5_ws128s2)
+  say "r5_ws128s2 a: the stride-2 form of ws128 (csrc/y7t_conv_ws128.hip, S2): layer parity vs torch fp32 (static partition), then inside the benchmarked list op by op (tile counter; measuring build so that the lowering honours Y7T_CONV_WS128_S2)"
+  timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -k "weights_stationary_128" > $O/t_s2_layers.log 2>&1; echo "rc=$?" >> $O/t_s2_layers.log; tailsum $O/t_s2_layers.log 3
+  export Y7T_LIB=$LIBD/liby7t_ablate.so
+  Y7T_CONV_WS128_S2=1 timeout 900 python -m pytest tests/test_detector_pinned_gpu.py -q -m gpu -s -k "every_op or launch_list" > $O/t_s2_pinned.log 2>&1; echo "rc=$?" >> $O/t_s2_pinned.log
+  grep -h "launch list @" $O/t_s2_pinned.log | cut -c1-400 | tee -a $O/summary.txt; tailsum $O/t_s2_pinned.log 3
+  say "r5_ws128s2 b: bench lines, alternating (0 = patch_s2 for those two layers, 1 = ws128_s2)"
+  X="--steps 16 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  for v in s2off:Y7T_CONV_WS128_S2=0 s2on:Y7T_CONV_WS128_S2=1 s2offb:Y7T_CONV_WS128_S2=0 s2onb:Y7T_CONV_WS128_S2=1; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } timeout 300 python bench.py $X > $O/bench_$n.json 2> $O/bench_$n.err; benchsum $n
+  done
+  say "r5_ws128s2 c: per-op tables"
+  for v in s2off:Y7T_CONV_WS128_S2=0 s2on:Y7T_CONV_WS128_S2=1; do
+    n=${v%%:*}; e=${v#*:}; env ${e//,/ } NAME=$n OUT=$O bash scripts/per_layer_table.sh | tee -a $O/summary.txt
+  done
+  grep -h " 128->256  3/2\|TOTAL" $O/per_layer_s2off.txt $O/per_layer_s2on.txt 2>/dev/null | cut -c1-160 | tee -a $O/summary.txt
+  unset Y7T_LIB
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

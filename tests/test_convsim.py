@@ -452,6 +452,30 @@ def test_weights_stationary_128_kernel_source_on_the_host(case, dyn):
         L.cs_set_dyn(0)
 
 
+# the stride-2 form of the same kernel (S2: 2 x 16 output tiles, 5 x 33 patch with parity-split columns): B, H, W (input), Cout, act, slices
+WS128_S2_CASES = [
+    (1, 4, 32, 128, 1, {}),                                                            # one output tile (2 x 16): top / left padding only
+    (1, 12, 64, 128, 1, {}),                                                           # 3 x 2 tiles on 3 workgroups: interior rows and columns
+    (2, 8, 96, 256, 2, {"in_ld": 192, "in_coff": 64, "out_ld": 384, "out_coff": 128}),    # two images, two channel tiles, slices of wider buffers, LeakyReLU
+    (3, 4, 32, 128, 0, {"out_ld": 128}),                                               # three one-tile images: chunks straddle images, no activation
+]
+
+
+@pytest.mark.parametrize("case,dyn", [(c, d) for i, c in enumerate(WS128_S2_CASES) for d in (0, 1) if d or i in (1, 2)],
+                         ids=lambda v: ("%dx%dx%d_%d_act%d" % v[:5]) if isinstance(v, tuple) else ("tile_counter" if v else "static"))
+def test_weights_stationary_128_stride2_kernel_source_on_the_host(case, dyn):
+    B, H, W, Cout, act, kw = case
+    L = cs.lib()
+    L.cs_set_dyn(dyn)
+    try:
+        for rep in range(1 + dyn):
+            name = run_case(L, B, H, W, 128, Cout, 3, 2, act, 0, korder=6, seed=B * 1000 + H + W + rep, **kw)
+            assert name == ("ws128_s2<2,16> dyn" if dyn else "ws128_s2<2,16>"), name
+            assert all(L.cs_tile_counter(i) == 0 for i in range(8))
+    finally:
+        L.cs_set_dyn(0)
+
+
 def test_weights_stationary_128_fragment_reads_are_bank_conflict_free():
     """272-byte pixels (17 sixteen-byte slots), 5 KiB rows: the 16 addresses of a ds_read_b128 service group fall on 16 different 16-byte bank quads"""
     PIXB, RP = 272, 5120
@@ -463,6 +487,15 @@ def test_weights_stationary_128_fragment_reads_are_bank_conflict_free():
                     addr = [((l >> 4) * RP + (l & 15) * PIXB + hi * 16 + kw * PIXB + ks * 32) for l in g]
                     assert len({(a // 16) % 16 for a in addr}) == 16
     assert RP % 256 == 0 and RP >= 18 * PIXB
+    # stride-2 form: 9216-byte rows, an output row reads patch rows 2 r + kh, tap kw the even plane, the odd plane (behind 17 even pixels) or the even plane one column on
+    RP2, O_OFF = 9216, 17 * PIXB
+    for hi in (0, 1):
+        for g in groups:
+            for kwoff in (0, O_OFF, PIXB):
+                for ks in range(8):
+                    addr = [((l >> 4) * 2 * RP2 + (l & 15) * PIXB + hi * 16 + kwoff + ks * 32) for l in g]
+                    assert len({(a // 16) % 16 for a in addr}) == 16
+    assert RP2 % 256 == 0 and RP2 >= 33 * PIXB
 
 
 def test_weights_stationary_kernel_rejects_what_it_cannot_run():

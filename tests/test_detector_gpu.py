@@ -177,6 +177,22 @@ def test_weights_stationary_128_kernel_matches_torch_fp32(L, case):
     assert L.y7t_last_kernel().decode() == "ws128<4,16>"
 
 
+# ... and its stride-2 form (S2: 2 x 16 output tiles, parity-split 5 x 33 patch): the two w6 layers (128 -> 256 at 320 x 320 and 160 x 160) and small / sliced / multi-image cases
+WS128_S2_CASES = [
+    (1, 4, 32, 128, 128, 3, 2, 1 | 16384, 128, 0, 128, 0, 0),
+    (1, 48, 96, 128, 256, 3, 2, 1 | 16384, 128, 0, 256, 0, 0),
+    (3, 160, 160, 128, 256, 3, 2, 2 | 16384, 256, 128, 512, 256, 0),
+    (4, 320, 320, 128, 256, 3, 2, 1 | 16384, 128, 0, 512, 0, 0),
+    (7, 20, 64, 128, 128, 3, 2, 0 | 16384, 128, 0, 128, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS128_S2_CASES)
+def test_weights_stationary_128_stride2_kernel_matches_torch_fp32(L, case):
+    test_conv_layer_matches_torch_fp32(L, case)
+    assert L.y7t_last_kernel().decode() == "ws128_s2<2,16>"
+
+
 def test_weights_stationary_kernels_on_the_tile_counter_inside_a_plan(monkeypatch):
     """round 5: inside a detector's plan the persistent kernels take their tiles from the op's tile counter (Y7TConvArgs::tile_ctr, csrc/y7t_conv_ws.hip DYN).  A w6 plan
     at 16 frames of 640 x 640 with the 128-channel kernel switched on: the launch list names the tile-counter forms; three forwards in a row (the counters must come back

@@ -27,9 +27,10 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-# file, kernel name, pieces per wave and tile, stores per wave and tile, accumulator registers of one set
-KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0ELb[01]EE", 13, 8, 64),
-           "ws128": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dELb[01]EE", 8, 4, 32)}
+# file, kernel name, instance pattern, pieces per wave and tile, stores per wave and tile, accumulator registers of one set, MFMAs per wave and tile
+KERNELS = {"ws64": ("y7t_conv_ws.hip", "k_conv3x3_c64_ws", r"wsILi\dELi0ELb[01]EE", 13, 8, 64, 144),
+           "ws128": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dELb[01]ELb0EE", 8, 4, 32, 144),
+           "ws128_s2": ("y7t_conv_ws128.hip", "k_conv3x3_c128_ws", r"wsILi\dELb[01]ELb1EE", 12, 2, 16, 72)}
 
 
 @pytest.fixture(scope="module", params=sorted(KERNELS))
@@ -38,7 +39,7 @@ def kernels(request, tmp_path_factory):
         pytest.skip("hipcc not available")
     import importlib
     build = importlib.import_module("yolov7_tracker_amd.build")
-    fname, kname, inst, npw, nst, nacc = KERNELS[request.param]
+    fname, kname, inst, npw, nst, nacc, nmf = KERNELS[request.param]
     out = str(tmp_path_factory.mktemp("isa") / (request.param + ".s"))
     src = os.path.join(build.CSRC, fname)
     cmd = [HIPCC] + [f for f in build.FLAGS if f != "-fPIC"] + build.FILE_FLAGS[fname] + ["-S", "--cuda-device-only", "-o", out, src]
@@ -52,7 +53,7 @@ def kernels(request, tmp_path_factory):
     assert len(ks) == 6, sorted(ks)
     meta = {n: (int(re.search(r"\.name:\s+%s\n.*?\.private_segment_fixed_size:\s+(\d+)" % re.escape(n), text, re.S).group(1)),
                 int(re.search(r"\.name:\s+%s\n.*?\.vgpr_spill_count:\s+(\d+)" % re.escape(n), text, re.S).group(1))) for n in ks}
-    return ks, meta, (npw, nst, nacc)
+    return ks, meta, (npw, nst, nacc, nmf)
 
 
 def test_no_packed_fp32_no_scratch(kernels):
@@ -62,7 +63,7 @@ def test_no_packed_fp32_no_scratch(kernels):
         assert not [i for i in body if i.startswith("scratch_")], n
         # static partition: nothing spilled.  Tile-counter instances: no scratch either; the SiLU one parks two VGPRs (a store base address) in spare ACC registers
         # (v_accvgpr_write / read, eight moves per two tiles of 288 MFMAs)
-        assert meta[n][0] == 0 and meta[n][1] <= (2 if "Lb1EE" in n else 0), (n, meta[n])
+        assert meta[n][0] == 0 and meta[n][1] <= (2 if _is_dyn(n) else 0), (n, meta[n])
 
 
 def test_the_tile_counter_fetch_lands_in_registers_the_compiler_does_not_use(kernels):
@@ -71,7 +72,7 @@ def test_the_tile_counter_fetch_lands_in_registers_the_compiler_does_not_use(ker
     statements), the atomic must not be followed by a wait of the compiler's (`s_waitcnt vmcnt(0)` on the spot is what the builtin atomicAdd produced), and the ring of
     chunk ids is accessed with LDS instructions (a generic pointer made it flat loads with vmcnt(0) waits)."""
     ks, _, _ = kernels
-    dyn = {n: b for n, b in ks.items() if "Lb1EE" in n}
+    dyn = {n: b for n, b in ks.items() if _is_dyn(n)}
     assert len(dyn) == 3
     for n, body in dyn.items():
         named = [i for i, ins in enumerate(body) if re.search(r"\ba25[45]\b|a\[\d+:25[45]\]", ins)]
@@ -89,6 +90,11 @@ def test_the_tile_counter_fetch_lands_in_registers_the_compiler_does_not_use(ker
             assert not [ins for ins in body if re.search(r"\ba25[45]\b", ins) or ins.startswith("global_atomic")], n
 
 
+def _is_dyn(name):
+    """the tile-counter instances: k_conv3x3_c64_ws<ACT, 0, true>, k_conv3x3_c128_ws<ACT, true, S2>"""
+    return bool(re.search(r"c64_wsILi\dELi0ELb1EE|c128_wsILi\dELb1ELb[01]EE", name))
+
+
 def _bodies(body):
     bars = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
     assert len(bars) == 3, len(bars)                                              # first tile, and the two alternating bodies of the loop
@@ -97,25 +103,25 @@ def _bodies(body):
 
 
 def test_tile_bodies_have_the_spelled_out_slot_structure(kernels):
-    ks, _, (npw, nst, _) = kernels
+    ks, _, (npw, nst, _, nmf) = kernels
     for n, body in ks.items():
         for bi, _, seg in _bodies(body):
             mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]
-            assert len(mf) == 144, (n, bi, len(mf))
+            assert len(mf) == nmf, (n, bi, len(mf))
             seg = seg[:mf[-1] + 1]
-            assert sum(ins.startswith("ds_read_b128") for ins in seg) == 144                      # a few up front + one behind each MFMA until the tile's last substeps
+            assert sum(ins.startswith("ds_read_b128") for ins in seg) == nmf                      # a few up front + one behind each MFMA until the tile's last substeps
             assert sum(ins.startswith("buffer_load_dwordx4") for ins in seg) == npw               # the pieces of tile t + 2
             assert sum(ins.startswith("global_store_dwordx4") for ins in seg) == (0 if bi == 0 else nst)
             # a slot holds one transcendental and at most two other VALU instructions; the MFMA may sit anywhere inside its slot, so between two
             # consecutive MFMAs of the steady state (slots 8 .. 135) there are at most two slots' worth
-            for a, b in zip(mf[8:136], mf[9:137]):
+            for a, b in zip(mf[8:nmf - 8], mf[9:nmf - 7]):
                 slot = seg[a + 1:b]
                 assert sum(ins.startswith(("v_exp_f32", "v_rcp_f32")) for ins in slot) <= 2, (n, bi, slot)
                 assert sum(ins.startswith("v_") and not ins.startswith(("v_exp_f32", "v_rcp_f32")) for ins in slot) <= 6, (n, bi, slot)
 
 
 def test_nothing_touches_an_accumulator_for_eleven_wait_states_behind_a_tiles_last_mfma(kernels):
-    ks, _, (_, _, nacc) = kernels
+    ks, _, (_, _, nacc, _) = kernels
     for n, body in ks.items():
         for bi, b0, seg in _bodies(body):
             mf = [i for i, ins in enumerate(seg) if ins.startswith("v_mfma_f32_32x32x16_f16")]

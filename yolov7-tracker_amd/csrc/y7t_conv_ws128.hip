@@ -26,35 +26,45 @@ namespace {
 
 constexpr unsigned kOOB = 0xFF000000u;
 
-struct Ws128Cfg {
-    static constexpr int TW = 16, TH = 4;
+// S2 (round 5): the same kernel for the 3x3 / STRIDE 2 layers with 128 input channels (cfg/deploy/yolov7-w6.yaml:29 and :116: 128 -> 256 at 320 x 320 and at 160 x 160): an
+// output tile of 2 x 16 pixels (ONE 32-pixel MFMA tile per wave: 72 MFMAs per tile), its 5 x 33-pixel input patch with the columns split by parity (17 even ones, then 16
+// odd ones: tap kw reads a unit-stride run of 16 -- the layout of y7t_conv_ws_s2.hip), 45 KiB per buffer.  Everything else -- filter bank in registers, two accumulator
+// sets, epilogue micro-program, three-buffer ring, tile counter -- is the stride-1 kernel's.
+template <bool S2>
+struct Ws128CfgT {
+    static constexpr int S = S2 ? 2 : 1;
+    static constexpr int TW = 16, TH = S2 ? 2 : 4;                    // OUTPUT tile
     static constexpr int PIXB = 272;                                  // 128 channels x 2 B + 16 B pad (17 sixteen-byte slots: odd -> conflict-free column reads)
-    static constexpr int RP = 5120;                                   // patch row pitch: 18 x 272 = 4896 rounded up to a multiple of 256 B
-    static constexpr int PATCH_DMA = ((TH + 2) * RP + 1023) / 1024;   // 30 wave-wide 1 KiB pieces
+    static constexpr int ROWS = S2 ? 5 : TH + 2, COLS = S2 ? 33 : TW + 2;   // input patch
+    static constexpr int NE = 17;                                     // S2: even patch columns come first, the 16 odd ones behind them
+    static constexpr int O_OFF = NE * PIXB;
+    static constexpr int RP = S2 ? 9216 : 5120;                       // patch row pitch: 33 (18) x 272 rounded up to a multiple of 256 B
+    static constexpr int PATCH_DMA = (ROWS * RP + 1023) / 1024;       // 45 (30) wave-wide 1 KiB pieces
     static constexpr int PATCH_BYTES = PATCH_DMA * 1024;
-    static constexpr int NPW = (PATCH_DMA + 3) / 4;                   // pieces per wave per tile (8; a slot past the patch repeats its last KiB)
+    static constexpr int NPW = (PATCH_DMA + 3) / 4;                   // pieces per wave per tile (12 / 8; a slot past the patch repeats its last KiB)
     static constexpr int NBUF = 3;
     static constexpr int RING_OFF = NBUF * PATCH_BYTES;                // DYN: the chunk ids handed to this workgroup, a ring of four
     static constexpr int LDS = RING_OFF + 64;
     static constexpr int CH = 2;                                      // DYN: tiles per chunk of the tile counter
     static constexpr int MAX_NT = Y7T_TILE_CTR_DONE;                  // DYN: one counter per 128-channel output tile; tile_ctr[Y7T_TILE_CTR_DONE] counts the leavers
     static constexpr int NSUB = 72;                                   // k16 substeps per tile: 9 taps x 8
-    static constexpr int NJ = 2;                                      // 32-pixel MFMA tiles per wave and tile
+    static constexpr int NJ = S2 ? 1 : 2;                             // 32-pixel MFMA tiles per wave and tile
     static constexpr int NACCW = 63;                                  // weight fragments kept in ACC registers (the other 9 in arch VGPRs; a252 .. a255 stay free: the tile counter's fetch lands in a255)
 };
+typedef Ws128CfgT<false> Ws128Cfg;
 
-template <int ACT, bool DYN = false>
+template <int ACT, bool DYN = false, bool S2 = false>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = Ws128Cfg;
-    constexpr int TW = C::TW, TH = C::TH, PIXB = C::PIXB, RP = C::RP, NPW = C::NPW, NJ = C::NJ;
+    using C = Ws128CfgT<S2>;
+    constexpr int TW = C::TW, TH = C::TH, PIXB = C::PIXB, RP = C::RP, NPW = C::NPW, NJ = C::NJ, S = C::S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi32 = lane >> 5;
 
     // ---- this workgroup's output-channel tile and its contiguous range of pixel tiles (workgroup b: channel tile b % n_nt, so that the workgroups of an XCD --
     // every eighth -- cover all channel tiles of the same pixel ranges) ----
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH, ptiles = p.B * tiles_y * tiles_x;
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH, ptiles = p.B * tiles_y * tiles_x;      // (tiles of the OUTPUT map)
     const int n_nt = p.Cout_pad >> 7;
     const int ntile = (int)blockIdx.x % n_nt, wg = (int)blockIdx.x / n_nt, nwg = ((int)gridDim.x + n_nt - 1 - ntile) / n_nt;
     const int per = (ptiles + nwg - 1) / nwg;
@@ -68,34 +78,36 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
 
     // tile coordinates are stepped, not decoded (as in y7t_conv_ws.hip): P = index of the tile's first pixel in the NHWC map, (ty, tx) its place in the tile grid
-    struct TileIt { int P, ty, tx, n; };
+    // (Pi: index of the tile's first INPUT pixel (S h0, S w0); the same as P at stride 1)
+    struct TileIt { int P, Pi, ty, tx, n; };
     auto tile_it = [&](int pt) -> TileIt {
         int q = pt;
         const int txi = q % tiles_x; q /= tiles_x;
         const int tyi = q % tiles_y, b = q / tiles_y;
-        return TileIt{(b * p.H + tyi * TH) * p.W + txi * TW, tyi, txi, pt_first + nt - pt};
+        return TileIt{(b * p.Ho + tyi * TH) * p.Wo + txi * TW, (b * p.H + tyi * TH * S) * p.W + txi * TW * S, tyi, txi, pt_first + nt - pt};
     };
     auto chunk_it = [&](int id) __attribute__((always_inline)) -> TileIt {      // (id wave-uniform) -- every chunk is walked as CH tiles; a tile past the batch is dead
         const unsigned pt = (unsigned)id * CH;
         const unsigned q = tiles_x == 1 ? pt : __umulhi(pt, magic_x), txi = pt - q * (unsigned)tiles_x;
         const unsigned b = tiles_y == 1 ? q : __umulhi(q, magic_y), tyi = q - b * (unsigned)tiles_y;
-        return TileIt{(int)((b * (unsigned)p.H + tyi * TH) * (unsigned)p.W + txi * TW), (int)tyi, (int)txi, CH};
+        return TileIt{(int)((b * (unsigned)p.Ho + tyi * TH) * (unsigned)p.Wo + txi * TW), (int)((b * (unsigned)p.H + tyi * (TH * S)) * (unsigned)p.W + txi * (TW * S)), (int)tyi, (int)txi, CH};
     };
     auto tile_next = [&](TileIt& it, int hop) __attribute__((always_inline)) {
         if (DYN && it.n == 1) {      // the chunk is used up: the id of chunk `hop` of this workgroup's sequence is in the ring (written >= one barrier ago)
             it = chunk_it(__builtin_amdgcn_readfirstlane(ring[hop & 3]));
             return;
         }
-        it.P += TW; it.n -= 1;
-        if (++it.tx == tiles_x) { it.tx = 0; it.P += (TH - 1) * p.W; if (++it.ty == tiles_y) it.ty = 0; }
+        it.P += TW; it.Pi += TW * S; it.n -= 1;
+        if (++it.tx == tiles_x) { it.tx = 0; it.P += (TH - 1) * p.Wo; it.Pi += (TH * S - 1) * p.W; if (++it.ty == tiles_y) it.ty = 0; }
     };
-    struct TileAt { int org, ty, tx; bool live; };      // org: byte offset of the patch's first pixel (h0 - 1, w0 - 1)
-    const unsigned npix = (unsigned)(p.B * p.H * p.W);
+    struct TileAt { int org, ty, tx; bool live; };      // org: byte offset of the patch's first pixel (S h0 - 1, S w0 - 1)
+    const unsigned npix = (unsigned)(p.B * p.Ho * p.Wo);
     auto tile_at = [&](const TileIt& it) -> TileAt {      // (unsigned arithmetic: P keeps stepping past the last live tile)
-        return TileAt{(int)((((unsigned)it.P - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, DYN ? (unsigned)it.P < npix : it.n > 0};
+        return TileAt{(int)((((unsigned)it.Pi - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, DYN ? (unsigned)it.P < npix : it.n > 0};
     };
     // per-lane constants of piece i: where its 16-byte slot sits inside the 6 x 18 patch, and which halo sides it lies on (4 bits per piece)
-    unsigned pconst[NPW], pedge = 0;
+    unsigned pconst[NPW];
+    unsigned long long pedge = 0;      // (4 bits per piece: 12 pieces at stride 2)
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         int I = wave + 4 * i;
@@ -103,10 +115,12 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
         const int byte = I * 1024 + lane * 16;
         const int r = byte / RP, rb = byte - r * RP;
         const int x = rb / PIXB, cs = (rb - x * PIXB) >> 4;
-        const bool used = r < TH + 2 && x < TW + 2 && cs < 16;
-        pconst[i] = used ? (unsigned)(((r * p.W + x) * p.ldin + cs * 8) * 2) : 0u;
-        const unsigned e = used ? (unsigned)((r == 0) | ((r == TH + 1) << 1) | ((x == 0) << 2) | ((x == TW + 1) << 3)) : 0u;
-        pedge |= e << (4 * i);
+        const bool used = r < C::ROWS && x < C::COLS && cs < 16;
+        const int pc = !S2 ? x : x < C::NE ? 2 * x : 2 * (x - C::NE) + 1;      // patch column of this slot (S2: the even columns first)
+        pconst[i] = used ? (unsigned)(((r * p.W + pc) * p.ldin + cs * 8) * 2) : 0u;
+        // halo sides: top row, bottom row, first column, last column -- at stride 2 (even input map, pad 1) only the top row and the first column can lie outside
+        const unsigned e = used ? (S2 ? (unsigned)((r == 0) | ((pc == 0) << 2)) : (unsigned)((r == 0) | ((r == TH + 1) << 1) | ((x == 0) << 2) | ((x == TW + 1) << 3))) : 0u;
+        pedge |= (unsigned long long)e << (4 * i);
     }
     auto piece_offsets = [&](const TileAt& ta, unsigned (&pv)[NPW]) __attribute__((always_inline)) {
         const unsigned tmask = (unsigned)((ta.ty == 0) | ((ta.ty == tiles_y - 1) << 1) | ((ta.tx == 0) << 2) | ((ta.tx == tiles_x - 1) << 3));
@@ -118,7 +132,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
             for (int i = 0; i < NPW; ++i) pv[i] = pconst[i] + (unsigned)ta.org;
         } else {
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) pv[i] = ((pedge >> (4 * i)) & tmask) ? kOOB : pconst[i] + (unsigned)ta.org;
+            for (int i = 0; i < NPW; ++i) pv[i] = ((unsigned)(pedge >> (4 * i)) & tmask) ? kOOB : pconst[i] + (unsigned)ta.org;
         }
     };
     auto issue_piece = [&](int buf, unsigned v, int i) __attribute__((always_inline)) {
@@ -166,14 +180,14 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
     int* const ctr = DYN ? p.tile_ctr + ntile : nullptr;
 
     // fragment base of this lane inside a patch buffer: two 32-pixel MFMA tiles of two image rows each, rows 2 j, + 1
-    const int plane_off = (l31 >> 4) * RP + (l31 & 15) * PIXB + hi32 * 16;
+    const int plane_off = (l31 >> 4) * (S * RP) + (l31 & 15) * PIXB + hi32 * 16;      // (S2: output row r reads patch rows 2 r + kh)
     half_t* outp = (half_t*)p.out;
     typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
     typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
-    constexpr int NST = 4;                   // 16-byte stores per lane and tile (2 MFMA tiles x 2 group pairs): every one is issued, for every tile (whole tiles only)
-    const unsigned ovoff = (unsigned)(((((l31 >> 4) * p.W + (l31 & 15)) * p.ldout) + ntile * 128 + q4 * 32 + 8 * hi32) * 2);
+    constexpr int NST = 2 * NJ;              // 16-byte stores per lane and tile (NJ MFMA tiles x 2 group pairs): every one is issued, for every tile (whole tiles only)
+    const unsigned ovoff = (unsigned)(((((l31 >> 4) * p.Wo + (l31 & 15)) * p.ldout) + ntile * 128 + q4 * 32 + 8 * hi32) * 2);
     auto out_base = [&](const TileIt& it) -> char* { return (char*)outp + ((size_t)it.P * p.ldout + p.cout_off) * 2; };
-    const int jstep = 2 * p.W * p.ldout * 2;      // bytes between the row pairs of consecutive MFMA tiles
+    const int jstep = 2 * p.Wo * p.ldout * 2;      // bytes between the row pairs of consecutive MFMA tiles
 
     // ---- the epilogue micro-program of y7t_conv_ws.hip with four store groups instead of eight: group G = the 8 accumulator elements 8 (G & 1) + v of MFMA tile G / 2;
     // period G = slots 4 + 16 G + i: E_v at i = v, R_v at i = 8 + v, at most two plain fp32 instructions and one transcendental per slot ----
@@ -229,7 +243,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
             }
         }
     };
-    constexpr int PIECE_SLOT0 = EPI_SLOTS + 3, PIECE_STRIDE = 8;      // tile t+2's pieces: slots 76, 84, ..., 132 (behind the micro-program, which ends at slot 72)
+    constexpr int PIECE_SLOT0 = EPI_SLOTS + 3, PIECE_STRIDE = S2 ? 2 : 8;      // tile t+2's pieces: slots 76, 84, ..., 132 behind the micro-program, which ends at slot 72 (S2: slots 44, 46, ..., 66 of 72)
     static_assert(PIECE_SLOT0 + PIECE_STRIDE * (NPW - 1) < C::NSUB * NJ, "pieces fit behind the epilogue");
 
     // One tile: its 144 MFMAs into `cur` (the bias as the C operand of the first two), the PREVIOUS tile's epilogue out of `prev`, tile t+2's pieces.
@@ -263,7 +277,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xf[s][j] = *(const half8*)(pb + s * 32 + j * 2 * RP);      // substeps 0 .. 2: tap 0, channel groups 0 .. 2
+            for (int j = 0; j < NJ; ++j) xf[s][j] = *(const half8*)(pb + s * 32 + j * 2 * RP);      // substeps 0 .. 2: tap 0, channel groups 0 .. 2 (S2: NJ = 1)
         __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
         for (int s = 0; s < C::NSUB; ++s)
@@ -279,7 +293,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
 #endif
             if (s + 3 < C::NSUB) {          // fragment (s + 3, j): tap (kh, kw), 16-channel group ks -- into the registers this MFMA has just read
                 const int sn = s + 3, tap = sn >> 3, ks = sn & 7, kh = tap / 3, kw = tap - kh * 3;
-                xf[s % 3][j] = *(const half8*)(pb + kh * RP + kw * PIXB + ks * 32 + j * 2 * RP);
+                const int kwoff = !S2 ? kw * PIXB : kw == 1 ? C::O_OFF : kw == 2 ? PIXB : 0;      // (S2: tap kw = 1 reads the odd plane, kw = 2 the even plane one column on)
+                xf[s % 3][j] = *(const half8*)(pb + kh * RP + kwoff + ks * 32 + j * 2 * RP);
             }
             if (!FIRST) epi_step(prev, ob, k);
             if (k >= PIECE_SLOT0 && (k - PIECE_SLOT0) % PIECE_STRIDE == 0 && (k - PIECE_SLOT0) / PIECE_STRIDE < NPW)
@@ -342,29 +357,24 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
 
 }   // namespace
 
-// korder 6 layers only (detector/graph.py::ws128_eligible mirrors the conditions): 3x3 / 1 / 1, Cin == 128, Cout a multiple of 128, maps of whole 4 x 16 tiles
-int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s) {
-    using C = Ws128Cfg;
-    const bool ok = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 128 && a.Cout_pad % 128 == 0 && a.Cout == a.Cout_pad && !a.out_f32 &&
-                    !(a.ldout & 7) && !(a.cout_off & 7) && !(a.ldin & 7) && !(a.cin_off & 7) && a.Ho == a.H && a.Wo == a.W && a.in_bytes <= kOOB - (1u << 24) &&
-                    a.H % C::TH == 0 && a.W % C::TW == 0 && !a.epi && a.up_C == 0;      // whole tiles only: the kernel counts its stores (s_waitcnt vmcnt)
-    if (!ok) {
-        y7t_set_error("conv: weights are in the 128-channel register-fragment order (korder 6) but the layer is not a 3x3 / stride 1 / 128 -> 128 k convolution on a map of whole 4 x 16 tiles with an aligned fp16 output");
-        return Y7T_E_ARG;
-    }
+// korder 6 layers only (detector/graph.py::ws128_eligible / ws128_s2_eligible mirror the conditions): 3x3 / pad 1, Cin == 128, Cout a multiple of 128; stride 1 on maps of
+// whole 4 x 16 tiles, or stride 2 on an even map whose output is whole 2 x 16 tiles
+template <bool S2>
+static int ws128_go(const Y7TConvArgs& a, hipStream_t s) {
+    using C = Ws128CfgT<S2>;
     static Y7TOncePerDevice attr;
     if (int e = y7t_once_per_device(attr, []() -> int {
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_SILU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_LEAKY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_NONE, false, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_SILU, false, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_LEAKY, false, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_NONE, true, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_SILU, true, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv3x3_c128_ws<Y7T_ACT_LEAKY, true, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
             return 0;
         })) return e;
-    const int ncu = y7t_num_cus();      // one persistent workgroup per compute unit (90 KiB of LDS, 512 registers per lane)
+    const int ncu = y7t_num_cus();      // one persistent workgroup per compute unit (90 / 135 KiB of LDS, 512 registers per lane)
     const int n_nt = a.Cout_pad / 128;
-    const int ptiles = a.B * (a.H / C::TH) * (a.W / C::TW);
+    const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied tile counters (A/B)
     if (dyn_env < 0) dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);
     const bool dyn = a.tile_ctr && dyn_env && n_nt <= C::MAX_NT && ptiles < 60000;
@@ -372,17 +382,29 @@ int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s) {
     int grid = units * n_nt < ncu ? units * n_nt : ncu;
     if (grid < n_nt) grid = n_nt;
     if (dyn) {
-        if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_SILU, true>), dim3(grid), dim3(256), C::LDS, s, a);
-        else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_LEAKY, true>), dim3(grid), dim3(256), C::LDS, s, a);
-        else hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_NONE, true>), dim3(grid), dim3(256), C::LDS, s, a);
+        if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_SILU, true, S2>), dim3(grid), dim3(256), C::LDS, s, a);
+        else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_LEAKY, true, S2>), dim3(grid), dim3(256), C::LDS, s, a);
+        else hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_NONE, true, S2>), dim3(grid), dim3(256), C::LDS, s, a);
         Y7T_LAUNCH_CHECK();
-        y7t_note_kernel("ws128<4,16> dyn");
+        y7t_note_kernel(S2 ? "ws128_s2<2,16> dyn" : "ws128<4,16> dyn");
         return 0;
     }
-    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_SILU>), dim3(grid), dim3(256), C::LDS, s, a);
-    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_LEAKY>), dim3(grid), dim3(256), C::LDS, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_NONE>), dim3(grid), dim3(256), C::LDS, s, a);
+    if (a.act == Y7T_ACT_SILU) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_SILU, false, S2>), dim3(grid), dim3(256), C::LDS, s, a);
+    else if (a.act == Y7T_ACT_LEAKY) hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_LEAKY, false, S2>), dim3(grid), dim3(256), C::LDS, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_c128_ws<Y7T_ACT_NONE, false, S2>), dim3(grid), dim3(256), C::LDS, s, a);
     Y7T_LAUNCH_CHECK();
-    y7t_note_kernel("ws128<4,16>");
+    y7t_note_kernel(S2 ? "ws128_s2<2,16>" : "ws128<4,16>");
     return 0;
+}
+
+int y7t_conv_ws128_launch(const Y7TConvArgs& a, hipStream_t s) {
+    const bool common = a.KH == 3 && a.KW == 3 && a.pad == 1 && a.Cin == 128 && a.Cout_pad % 128 == 0 && a.Cout == a.Cout_pad && !a.out_f32 && !(a.ldout & 7) &&
+                        !(a.cout_off & 7) && !(a.ldin & 7) && !(a.cin_off & 7) && a.in_bytes <= kOOB - (1u << 24) && !a.epi && a.up_C == 0;
+    // whole tiles only: the kernel counts its stores (s_waitcnt vmcnt)
+    if (common && a.stride == 1 && a.Ho == a.H && a.Wo == a.W && a.H % Ws128CfgT<false>::TH == 0 && a.W % Ws128CfgT<false>::TW == 0) return ws128_go<false>(a, s);
+    if (common && a.stride == 2 && !(a.H & 1) && !(a.W & 1) && a.Ho * 2 == a.H && a.Wo * 2 == a.W && a.Ho % Ws128CfgT<true>::TH == 0 && a.Wo % Ws128CfgT<true>::TW == 0)
+        return ws128_go<true>(a, s);
+    y7t_set_error("conv: weights are in the 128-channel register-fragment order (korder 6) but the layer is neither a 3x3 / stride 1 / 128 -> 128 k convolution on a map of whole "
+                  "4 x 16 tiles nor a 3x3 / stride 2 one on an even map whose output is whole 2 x 16 tiles, with an aligned fp16 output");
+    return Y7T_E_ARG;
 }

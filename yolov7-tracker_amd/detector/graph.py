@@ -245,6 +245,20 @@ def ws128_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, i
             and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and tiles >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
+WS128_S2_DEFAULT = "0"      # until measured (round 5, last sessions)
+
+
+def ws128_s2_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
+    """mirror of y7t_conv_ws128_launch's stride-2 form (csrc/y7t_conv_ws128.hip, S2): the 3x3 / stride 2 layers with 128 input channels (w6: 128 -> 256 at 320 x 320 and at
+    160 x 160) with the filter bank of a 128-channel output tile in registers, 2 x 16 output tiles from the op's tile counter.  Same weight order as the stride-1 kernel
+    (korder 6).  Y7T_CONV_WS128_S2=1 / 0."""
+    if _lib.switch("Y7T_CONV_WS128_S2", WS128_S2_DEFAULT) != "1" or _lib.switch("Y7T_CONV_WS128", WS128_DEFAULT) != "1" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
+        return False
+    Ho, Wo = H // 2, W // 2
+    return (k == 3 and s == 2 and p == 1 and cin == 128 and cout % 128 == 0 and cout <= 512 and H % 2 == 0 and W % 2 == 0 and Ho % 2 == 0 and Wo % 16 == 0 and not out_f32
+            and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and B * (Ho // 2) * (Wo // 16) >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
+
+
 def lower(nodes, H, W, max_batch=1):
     det = next(n for n in nodes if n.kind == "detect")
     # ---- liveness: only what reaches the (main) Detect inputs ----
@@ -369,6 +383,8 @@ def lower(nodes, H, W, max_batch=1):
             korder = 8                               # ... and its stride-2 sibling for the 64 -> 128 down-sampling layer (weights.pack_ws_s2)
         elif ws128_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
             korder = 6                               # ... and its 128-channel sibling (weights.pack_ws128)
+        elif ws128_s2_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, src.ld, src.coff, max_batch):
+            korder = 6                               # ... and the stride-2 form of that kernel (same packing)
         elif patch_eligible(src.h, src.w, cin, cout, n.k, n.s, n.p, out_ld, out_coff, out_f32, max_batch):
             korder = 2                               # LDS-patch kernel: weights in its panel order (weights.panel_pack)
             if cout_pad % 128 == 0 and patch_panel_rows(src.h, src.w, cout, max_batch) == 64:
