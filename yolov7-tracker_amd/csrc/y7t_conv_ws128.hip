@@ -106,8 +106,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
         return TileAt{(int)((((unsigned)it.Pi - (unsigned)p.W - 1u) * (unsigned)p.ldin + (unsigned)p.cin_off) * 2u), it.ty, it.tx, DYN ? (unsigned)it.P < npix : it.n > 0};
     };
     // per-lane constants of piece i: where its 16-byte slot sits inside the 6 x 18 patch, and which halo sides it lies on (4 bits per piece)
-    unsigned pconst[NPW];
-    unsigned long long pedge = 0;      // (4 bits per piece: 12 pieces at stride 2)
+    unsigned pconst[NPW], pedge[NPW];      // (the halo sides of piece i: one word per piece -- twelve pieces at stride 2 do not fit four bits each into one register)
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         int I = wave + 4 * i;
@@ -120,7 +119,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
         pconst[i] = used ? (unsigned)(((r * p.W + pc) * p.ldin + cs * 8) * 2) : 0u;
         // halo sides: top row, bottom row, first column, last column -- at stride 2 (even input map, pad 1) only the top row and the first column can lie outside
         const unsigned e = used ? (S2 ? (unsigned)((r == 0) | ((pc == 0) << 2)) : (unsigned)((r == 0) | ((r == TH + 1) << 1) | ((x == 0) << 2) | ((x == TW + 1) << 3))) : 0u;
-        pedge |= (unsigned long long)e << (4 * i);
+        pedge[i] = e;
     }
     auto piece_offsets = [&](const TileAt& ta, unsigned (&pv)[NPW]) __attribute__((always_inline)) {
         const unsigned tmask = (unsigned)((ta.ty == 0) | ((ta.ty == tiles_y - 1) << 1) | ((ta.tx == 0) << 2) | ((ta.tx == tiles_x - 1) << 3));
@@ -132,7 +131,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c128_ws(const Y7TConvArgs p)
             for (int i = 0; i < NPW; ++i) pv[i] = pconst[i] + (unsigned)ta.org;
         } else {
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) pv[i] = ((unsigned)(pedge >> (4 * i)) & tmask) ? kOOB : pconst[i] + (unsigned)ta.org;
+            for (int i = 0; i < NPW; ++i) pv[i] = (pedge[i] & tmask) ? kOOB : pconst[i] + (unsigned)ta.org;
         }
     };
     auto issue_piece = [&](int buf, unsigned v, int i) __attribute__((always_inline)) {
