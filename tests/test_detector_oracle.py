@@ -197,6 +197,7 @@ def test_stride2_panel_packing_and_opt_in_lowering(monkeypatch):
             k = tap * cin + c * 16 + (s ^ ((r >> 3) & 1)) * 8
             assert np.array_equal(flat[o:o + 8], blk[tile * BN + r, k:k + 8])
     monkeypatch.setenv("Y7T_CONV_WS_S2", "0")      # (round 4: the 640^2 64 -> 128 layer otherwise goes to its own weights-stationary kernel, korder 8, before this rule is asked)
+    monkeypatch.setenv("Y7T_CONV_WS128", "0")      # (round 5: the two Cin = 128 layers otherwise go to ws128's stride-2 form, korder 6)
     monkeypatch.setenv("Y7T_CONV_PATCH_S2", "0")
     base = graph.lower(graph.parse(arch.ARCHS["yolov7-w6"](10))[0], 1280, 1280, max_batch=32)
     assert not any(int(op["korder"]) == 4 for op in base.ops)
@@ -239,11 +240,14 @@ def test_weights_stationary_128_packing_and_lowering(monkeypatch):
     assert not any(int(op["korder"]) == 6 for op in base.ops)
     monkeypatch.setenv("Y7T_CONV_WS128", "1")
     exp = low()
-    took = [(int(op["H"]), int(op["Cin"]), int(op["Cout"])) for op in exp.ops if int(op["korder"]) == 6]
-    assert sorted(took) == sorted([(160, 128, 128)] * 4 + [(80, 128, 128)] * 6 + [(160, 128, 256)]), took
+    took = [(int(op["H"]), int(op["Cin"]), int(op["Cout"]), int(op["stride"])) for op in exp.ops if int(op["korder"]) == 6]
+    assert sorted(took) == sorted([(160, 128, 128, 1)] * 4 + [(80, 128, 128, 1)] * 6 + [(160, 128, 256, 1)] + [(320, 128, 256, 2), (160, 128, 256, 2)]), took      # (the last two: the stride-2 form)
     for a, b in zip(base.ops, exp.ops):
         for f in a.dtype.names:
             assert f == "korder" or a[f] == b[f] or (f in ("Cout_pad", "w_off", "bias_off") and int(b["korder"]) == 6), (f, a[f], b[f])
+    monkeypatch.setenv("Y7T_LIB", "/somewhere/liby7t_ablate.so")      # beside the measuring build the stride-2 form alone can be switched off (an experiment switch)
+    monkeypatch.setenv("Y7T_CONV_WS128_S2", "0")
+    assert sum(int(op["korder"]) == 6 for op in low().ops) == 11
 
 
 def test_weights_stationary_packing_and_lowering(monkeypatch):
@@ -294,10 +298,10 @@ def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
     import collections
     hist = lambda B: dict(sorted(collections.Counter(int(o["korder"]) for o in graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, B).ops if int(o["type"]) == 0).items()))
     # 0 stem (fused frame -> conv kernel); 1 generic 3x3 (three stride-2 layers); 2 LDS-patch (16x16 tiles + 40-wide strips); 3 1x1 panels (incl. 3 upsample-on-read, 4 Detect);
-    # 4 stride-2 LDS-patch; 5 weights-stationary 64 -> 64; 6 weights-stationary 128 -> 128 k (round 5: eleven of the former korder-2 launches); 7 p8; 9 patch with 64-row panels (the 20x20 layers); 10 1x1 with 64-row panels (< 500 tiles);
+    # 4 stride-2 LDS-patch; 5 weights-stationary 64 -> 64; 6 weights-stationary 128 -> 128 k (round 5: eleven of the former korder-2 launches at stride 1 + the two Cin = 128 stride-2 layers, formerly korder 4); 7 p8; 9 patch with 64-row panels (the 20x20 layers); 10 1x1 with 64-row panels (< 500 tiles);
     # 11 the stride-2 weights-stationary layer + the twin 1x1 behind it in one launch
-    assert hist(32) == {0: 1, 1: 3, 2: 22, 3: 24, 4: 4, 5: 7, 6: 11, 7: 5, 9: 10, 10: 7, 11: 1}
-    assert hist(40) == {0: 1, 1: 3, 2: 22, 3: 30, 4: 4, 5: 7, 6: 11, 7: 5, 9: 10, 10: 1, 11: 1}      # 40 frames: six of the 20x20 1x1 layers reach 500 tiles of 128 rows
+    assert hist(32) == {0: 1, 1: 3, 2: 22, 3: 24, 4: 2, 5: 7, 6: 13, 7: 5, 9: 10, 10: 7, 11: 1}
+    assert hist(40) == {0: 1, 1: 3, 2: 22, 3: 30, 4: 2, 5: 7, 6: 13, 7: 5, 9: 10, 10: 1, 11: 1}      # 40 frames: six of the 20x20 1x1 layers reach 500 tiles of 128 rows
     h1 = hist(1)
     assert h1 == {0: 1, 1: 33, 2: 8, 3: 8, 9: 16, 10: 28, 11: 1} and h1.get(5, 0) == 0 and h1.get(7, 0) == 0 and h1.get(4, 0) == 0      # one frame: no persistent 64 -> 64 / p8 / stride-2 patch launches
     monkeypatch.setenv("Y7T_CONV_WS_S2_FUSE", "0")      # an experiment switch: nothing changes for the product library ...

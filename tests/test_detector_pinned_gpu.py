@@ -113,7 +113,9 @@ def test_launch_list_is_the_benchmarked_one(bench_det):
     if os.environ.get("Y7T_CONV_WS128", "1") != "0":                     # the 128 -> 128 k layers with the filter bank in registers, tiles from the op's tile counter (round 5)
         assert fam["ws128"] == 11 and all(n.endswith(" dyn") for n in names if n.startswith(("ws64", "ws128"))), hist
     # the stride-2 patch kernel where it measured faster than the generic kernel (four of the eight down-sampling layers; detector/graph.py::patch_s2_eligible)
-    assert fam["patch_s2"] == {"auto": 4, "0": 0, "1": 8}[os.environ.get("Y7T_CONV_PATCH_S2", "auto")], fam
+    ws128_on = os.environ.get("Y7T_CONV_WS128", "1") != "0"
+    assert fam["patch_s2"] == {"auto": 2 if ws128_on else 4, "0": 0, "1": 6 if ws128_on else 8}[os.environ.get("Y7T_CONV_PATCH_S2", "auto")], fam      # (the two Cin = 128 layers are on ws128's stride-2 form)
+    assert fam["ws128_s2"] == (2 if ws128_on else 0), fam
     if os.environ.get("Y7T_CONV_WS_S2", "1") != "0":
         assert names[1] == ("ws_s2<2,32> + 1x1" if os.environ.get("Y7T_CONV_WS_S2_FUSE", "1") != "0" else "ws_s2<2,32>"), names[1]      # the 640^2 64 -> 128 stride-2 layer: filter bank in registers
     else:

@@ -245,13 +245,13 @@ def ws128_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, i
             and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0 and tiles >= int(_lib.switch("Y7T_CONV_WS_MIN_TILES", "1024")))
 
 
-WS128_S2_DEFAULT = "0"      # until measured (round 5, last sessions)
+WS128_S2_DEFAULT = "1"      # round 5, sessions r5h / r5i: 786 -> 644 us and 190 -> 154 us per 40 frames alone, the list 18.22 / 18.25 -> 18.12 / 18.10 ms in the pipeline
 
 
 def ws128_s2_eligible(H, W, cin, cout, k, s, p, out_ld, out_coff, out_f32, in_ld, in_coff, B=1 << 20):
     """mirror of y7t_conv_ws128_launch's stride-2 form (csrc/y7t_conv_ws128.hip, S2): the 3x3 / stride 2 layers with 128 input channels (w6: 128 -> 256 at 320 x 320 and at
     160 x 160) with the filter bank of a 128-channel output tile in registers, 2 x 16 output tiles from the op's tile counter.  Same weight order as the stride-1 kernel
-    (korder 6).  Y7T_CONV_WS128_S2=1 / 0."""
+    (korder 6).  Follows Y7T_CONV_WS128 (=0 switches both forms off); Y7T_CONV_WS128_S2=0 alone is an experiment switch (measuring build)."""
     if _lib.switch("Y7T_CONV_WS128_S2", WS128_S2_DEFAULT) != "1" or _lib.switch("Y7T_CONV_WS128", WS128_DEFAULT) != "1" or _lib.switch("Y7T_CONV_VARIANT", "0") != "0":
         return False
     Ho, Wo = H // 2, W // 2
