@@ -7,6 +7,12 @@
 # Every step runs under its own `timeout`, writes to gpurun_out/$TAG/ and appends its verdict to gpurun_out/$TAG/summary.txt; a failing step does not
 # stop the others.  BEFORE calling (CPU): python -m yolov7_tracker_amd.build && git rev-parse HEAD > .commit_stamp
 # Steps:
+#   (round 5) r5_chained    the chained detect -> NMS -> ByteTrack parity run (tests/test_chained_gpu.py)
+#             r5_wgs        persistent kernels over-decomposed (no gain)         r5_dyn       tile counter in ws64 / ws128: parity, bench A/B, per-op tables
+#             r5_batch      frames per step (BATCHES="32 24 40 ...")             r5_latency   latency mode with a chunked H2D copy (measured, removed: needs --upload_pieces)
+#             r5_b40        the pinned parity tests at 40 frames                 r5_branches  the Detect branches on four streams (measured, removed) + panel rules at 40 frames
+#             r5_panel240   128-row panels for the 20 x 20 512-channel layers    r5_ws128s2   the stride-2 form of ws128: parity, bench A/B/A/B, per-op tables
+#             suite_all     the whole `-m gpu` suite without -x
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
