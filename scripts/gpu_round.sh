@@ -12,7 +12,7 @@
 #             r5_batch      frames per step (BATCHES="32 24 40 ...")             r5_latency   latency mode with a chunked H2D copy (measured, removed: needs --upload_pieces)
 #             r5_b40        the pinned parity tests at 40 frames                 r5_branches  the Detect branches on four streams (measured, removed) + panel rules at 40 frames
 #             r5_panel240   128-row panels for the 20 x 20 512-channel layers    r5_ws128s2   the stride-2 form of ws128: parity, bench A/B/A/B, per-op tables
-#             suite_all     the whole `-m gpu` suite without -x
+#             suite_all     the whole `-m gpu` suite without -x                  r5_coop      sparse association: scalar-register row contexts + register-resident wave solve of the large components (parity, step phases, cfg3 A/B)
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
@@ -276,6 +276,25 @@ r5_ws128s2)
   done
   grep -h " 128->256  3/2\|TOTAL" $O/per_layer_s2off.txt $O/per_layer_s2on.txt 2>/dev/null | cut -c1-160 | tee -a $O/summary.txt
   unset Y7T_LIB
+  ;;
+
+r5_coop)
+  say "r5_coop a: sparse association -- row contexts of the cost pass handed out through the scalar registers, large components on a wave with their state in registers: device parity (goldens, random scenes, cfg3 at full size vs the oracle, DeepSORT)"
+  timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py tests/test_reid_gpu.py -q -m gpu -k "not w6_1280 and not conv_layer and not nms_output" > $O/t_coop.log 2>&1; echo "rc=$?" >> $O/t_coop.log; tailsum $O/t_coop.log 4
+  say "r5_coop b: the frame step alone (scripts/time_tracker.py): previous library, this one, previous, this one"
+  for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so prevb:$LIBD/liby7t_prev.so newb:$LIBD/liby7t.so; do
+    n=${v%%:*}; l=${v#*:}; echo "-- $n" | tee -a $O/summary.txt
+    Y7T_LIB=$l timeout 300 python scripts/time_tracker.py > $O/time_tracker_$n.txt 2>&1; grep -h "n_obj=500\|sparse association" $O/time_tracker_$n.txt | grep -v "threads=64 \|threads=256 " | cut -c1-300 | tee -a $O/summary.txt
+  done
+  say "r5_coop c: cfg3 (BoT-SORT, 500 objects) and the headline, previous / this library alternating"
+  X="--steps 10 --warmup 3 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so prevb:$LIBD/liby7t_prev.so newb:$LIBD/liby7t.so; do
+    n=${v%%:*}; l=${v#*:}; Y7T_LIB=$l timeout 300 python bench.py $X --workload cfg3 > $O/bench_cfg3_$n.json 2> $O/bench_cfg3_$n.err; benchsum cfg3_$n
+  done
+  for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so; do
+    n=${v%%:*}; l=${v#*:}; Y7T_LIB=$l timeout 300 python bench.py --steps 16 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads > $O/bench_cfg2_$n.json 2> $O/bench_cfg2_$n.err; benchsum cfg2_$n
+    Y7T_LIB=$l timeout 300 python bench.py $X --workload cfg4 > $O/bench_cfg4_$n.json 2> $O/bench_cfg4_$n.err; benchsum cfg4_$n
+  done
   ;;
 
 suite)

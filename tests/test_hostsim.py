@@ -239,5 +239,10 @@ def test_hostsim_cfg3_full_size_botsort_equals_oracle():
     warps = synth.make_warps(300, seq_idx=0)
     from oracle import tracker_np
     want = tracker_np.run("botsort", dets, kalman_format="botsort", warps=warps)
+    before = [hs.lib().hs_next_stat(k) for k in range(4)]
     got = hs.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
     util.assert_same_tracks(got, want, "cfg3 full size")
+    # the large connected components of the crowded frames went through the register-resident wave solve (y7t_assoc_sparse_try step 4a, the host build runs its
+    # text with 64-element arrays), none had to be declined for more than 64 columns
+    on_wave, declined = hs.lib().hs_next_stat(2) - before[2], hs.lib().hs_next_stat(3) - before[3]
+    assert on_wave > 300 and declined == 0, (on_wave, declined)

@@ -115,6 +115,47 @@ __device__ __forceinline__ int y7t_wave_min_i(int v) {
 }
 #endif
 
+// ---- one wave as a 64-lane vector machine (y7t_assoc_sparse_try, step 4a): a per-lane variable is `T a[Y7T_WVN]` -- ONE register per lane on the device; the host
+//      build (one thread) keeps all 64 lanes' values and runs every lane statement as a loop, so the goldens walk the same text.  `wv_lane` must be in scope. ----
+#if Y7T_DEVICE
+__device__ __forceinline__ double y7t_readlane_d(double v, int s) {
+    const long long r = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)r, s), hi = __builtin_amdgcn_readlane((int)(r >> 32), s);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// a small trivially copyable struct from lane `s` (uniform) to every lane, word by word through the scalar registers
+template <class T>
+__device__ __forceinline__ T y7t_readlane_t(const T& v, int s) {
+    static_assert(sizeof(T) % 4 == 0, "words");
+    struct W { int w[sizeof(T) / 4]; };
+    W a = __builtin_bit_cast(W, v), b;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); ++k) b.w[k] = __builtin_amdgcn_readlane(a.w[k], s);
+    return __builtin_bit_cast(T, b);
+}
+__device__ __forceinline__ int y7t_ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+#define Y7T_WVN 1
+#define Y7T_WV_EACH(l) for (int l __attribute__((unused)) = wv_lane, l##_once = 1; l##_once; l##_once = 0)
+#define Y7T_WV(a, l) (a)[0]
+#define Y7T_WV_AT_I(a, s) __builtin_amdgcn_readlane((a)[0], (s))
+#define Y7T_WV_AT_D(a, s) y7t_readlane_d((a)[0], (s))
+#define Y7T_WV_GATHER_I(a, idx) __shfl((a)[0], (idx))
+#define Y7T_WV_SET(a, s, val) do { if (wv_lane == (s)) (a)[0] = (val); } while (0)
+#define Y7T_WV_MIN_D(out, l, expr) do { const int l = wv_lane; (void)l; (out) = y7t_wave_min_d(expr); } while (0)
+#define Y7T_WV_BALLOT(out, l, pred) do { const int l = wv_lane; (void)l; (out) = __ballot(pred); } while (0)
+#else
+static inline int y7t_ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+#define Y7T_WVN 64
+#define Y7T_WV_EACH(l) for (int l = 0; l < 64; ++l)
+#define Y7T_WV(a, l) (a)[l]
+#define Y7T_WV_AT_I(a, s) (a)[s]
+#define Y7T_WV_AT_D(a, s) (a)[s]
+#define Y7T_WV_GATHER_I(a, idx) (a)[idx]
+#define Y7T_WV_SET(a, s, val) do { (a)[s] = (val); } while (0)
+#define Y7T_WV_MIN_D(out, l, expr) do { (out) = HUGE_VAL; for (int l = 0; l < 64; ++l) { const double e_ = (expr); if (e_ < (out)) (out) = e_; } } while (0)
+#define Y7T_WV_BALLOT(out, l, pred) do { (out) = 0ull; for (int l = 0; l < 64; ++l) if (pred) (out) |= 1ull << l; } while (0)
+#endif
+
 // all-reduce: lexicographic minimum of (v, i) over the workgroup; every thread gets the result
 Y7T_FN void y7t_argmin(const Y7TExec& ex, double& v, int& i) {
 #if Y7T_DEVICE

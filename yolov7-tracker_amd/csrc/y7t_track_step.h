@@ -234,8 +234,11 @@ struct Y7TBox4 { double v[4]; };
 // arrays -- 24 entries per row keep a 500-object frame's lists (121 KB) in global memory, where every step of the per-component solves is a dependent L2
 // round trip; 16 per row (80 KB) fit in LDS and the largest row of that scene has 9 candidates.  A row that overflows the shorter stride repeats the
 // association with the full one.  (Round 3, measured: the 500-object frame step 932 -> 902 us, 80 objects unchanged; profiles/r03_tracker_phases.txt)
-template <class ColFn, class CostFn>
-Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost, const int MC) {
+#ifndef Y7T_NEXT_STAT
+#define Y7T_NEXT_STAT(k) do { } while (0)
+#endif
+template <class ColFn, class RowFn, class CostFn>
+Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost, const int MC) {
     const int tid = ex.tid, nt = ex.nt;
 #ifdef Y7T_ALWAYS_LITERAL
     return 2;
@@ -265,8 +268,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* rowcnt = (int*)(dd + nb + 2);                        // [na]
     int* rowlab = rowcnt + na;                                // [na]
     int* x = rowlab + na;                                     // [na]
-    int* nextrow = x + na;                                    // [na] (reserved)
-    int* colcnt = nextrow + na;                               // [nb]
+    int* csz = x + na;                                        // [na] rows of the component led by row i (step 4)
+    int* colcnt = csz + na;                                   // [nb]; behind the forced decisions: the leaders of the large components
     int* collab = colcnt + nb;                                // [nb]
     int* y = collab + nb;                                     // [nb]
     int* pred = y + nb;                                       // [nb]
@@ -275,18 +278,16 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* flag = nextcol + nb;                                 // [3] overflow / at-limit pair, changed, duplicate cost inside a component
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
-    for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; }
+    for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; csz[i] = 0; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
     if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; }
     y7t_sync(ex);
-    // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix) ----
+    // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix).  What the cost needs of a ROW is loaded 64 rows at a time, a lane each, and
+    // handed to the wave row by row through the scalar registers (round 5: a row's box used to be four dependent global loads in front of every pair's
+    // arithmetic -- 244 pairs per lane at 500 x 500, each a memory round trip: 368 of the step's 2217 kcycles, profiles/r03_tracker_phases.txt) ----
     {
-        const int lanes = nt < 64 ? nt : 64, nw = nt / lanes, wave = tid / lanes, lane = tid - wave * lanes;
-        for (int j = lane; j < nb; j += lanes) {
-            const auto cj = colctx(j);
-            for (int i = wave; i < na; i += nw) {
-                const double c = cost(i, j, cj);
-                if (c <= thresh_hi) {                         // (one compare on the common path: most pairs do not overlap at all)
+        auto edge = [&](int i, int j, double c) {
+            if (c <= thresh_hi) {                             // (one compare on the common path: most pairs do not overlap at all)
                 if (c >= thresh - Y7T_TIE_EPS) { flag[0] = 1; Y7T_TIE_REASON(4); }      // exactly at the limit: the optimum is not unique -> dense path, lapjv's own order
                 if (c <= thresh) {
                     const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
@@ -294,7 +295,32 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     else flag[0] = 1;
                     Y7T_FETCH_ADD(colcnt + j, 1);
                 }
+            }
+        };
+#if Y7T_DEVICE
+        if (nt >= 64) {
+            const int nw = nt >> 6, wave = tid >> 6, lane = tid & 63;
+            for (int jb = 0; jb < nb; jb += 64) {
+                const int j = jb + lane;
+                const bool jv = j < nb;
+                const auto cj = colctx(jv ? j : 0);
+                for (int ib = wave; ib < na; ib += nw * 64) {           // this wave's rows ib, ib + nw, ...: 64 of them at a time
+                    const int il = ib + nw * lane;
+                    const auto rl = rowctx(il < na ? il : 0);
+                    int nr = (na - ib + nw - 1) / nw;
+                    nr = nr < 64 ? nr : 64;
+                    for (int r = 0; r < nr; ++r) {
+                        const auto ri = y7t_readlane_t(rl, r);
+                        if (jv) edge(ib + nw * r, j, cost(ri, cj));
+                    }
                 }
+            }
+        } else
+#endif
+        {
+            for (int j = tid; j < nb; j += nt) {
+                const auto cj = colctx(j);
+                for (int i = 0; i < na; ++i) edge(i, j, cost(rowctx(i), cj));
             }
         }
     }
@@ -345,24 +371,25 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         y7t_sync(ex);
     }
     Y7T_SPROF(4);
-    // ---- 4. one lane per component: serial sparse shortest augmenting paths over the component's rows in ascending order ----
-    for (int lead = tid; lead < na; lead += nt) {
-        if (x[lead] != -1 || rowlab[lead] != lead) continue;
-        {   // tie watch: two candidate edges of this component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
-            int crow[8], ncr = 0;
-            for (int a = lead; a < na && ncr < 9; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
-            if (ncr <= 8) {
-                bool dup = false;
-                for (int ia = 0; ia < ncr && !dup; ++ia)
-                    for (int pq = 0; pq < rowcnt[crow[ia]] && !dup; ++pq) {
-                        const double ca = ccost[(size_t)crow[ia] * MC + pq];
-                        for (int q = pq + 1; q < rowcnt[crow[ia]]; ++q) dup |= (ccost[(size_t)crow[ia] * MC + q] == ca);
-                        for (int ib = ia + 1; ib < ncr; ++ib)
-                            for (int q = 0; q < rowcnt[crow[ib]]; ++q) dup |= (ccost[(size_t)crow[ib] * MC + q] == ca);
-                    }
-                if (dup) { flag[2] = 1; Y7T_TIE_REASON(5); }
-            }
+    // ---- 4. the assignment problem separates over components: serial sparse shortest augmenting paths over a component's rows in ascending order ----
+    // tie watch: two candidate edges of a component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
+    auto tie_watch = [&](int lead) {
+        int crow[8], ncr = 0;
+        for (int a = lead; a < na && ncr < 9; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
+        if (ncr <= 8) {
+            bool dup = false;
+            for (int ia = 0; ia < ncr && !dup; ++ia)
+                for (int pq = 0; pq < rowcnt[crow[ia]] && !dup; ++pq) {
+                    const double ca = ccost[(size_t)crow[ia] * MC + pq];
+                    for (int q = pq + 1; q < rowcnt[crow[ia]]; ++q) dup |= (ccost[(size_t)crow[ia] * MC + q] == ca);
+                    for (int ib = ia + 1; ib < ncr; ++ib)
+                        for (int q = 0; q < rowcnt[crow[ib]]; ++q) dup |= (ccost[(size_t)crow[ib] * MC + q] == ca);
+                }
+            if (dup) { flag[2] = 1; Y7T_TIE_REASON(5); }
         }
+    };
+    // one LANE walks a whole component: every step a chain of dependent reads of the work arrays
+    auto solve_by_lane = [&](int lead) {
         for (int start = lead; start < na; ++start) {
             if (rowlab[start] != lead || x[start] != -1) continue;
             // Dijkstra from `start`; the null column lives in registers (every component has its own)
@@ -407,6 +434,177 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             }
             for (int j = touched; j >= 0; ) { const int nx = nextcol[j]; st[j] = 0; j = nx; }
         }
+    };
+    // ---- 4a. LARGE components (more than Y7T_COOP_MIN rows).  A 500-object frame has ~200 components; all but one to three have <= 8 rows, the largest 10-20 --
+    // and that one, walked by ONE lane (rows x searches x candidates of dependent LDS reads, ~2000 clocks per search step), was the critical path of the frame's
+    // association: 890 of the step's 2217 kcycles (profiles/r03_tracker_phases.txt).  Round 4 gave such a component a wave but kept its state in LDS: a search
+    // step then costs a wave reduction plus the same four dependent round trips (profiles/r04_tracker_coop_experiment.txt: no gain).  Here the component's state
+    // lives in REGISTERS: lane l owns the component's l-th column (price, distance, mark, predecessor, the row matched to it) and its l-th row (the column
+    // matched to it), everything in slot numbers; a search step is one DPP minimum + a ballot (ties to the lowest lane = the lowest column, as the lane's scan),
+    // one read of the scanned row's candidate list, which the lanes hand to the owners of those columns through the scalar registers, and the relaxation in
+    // registers.  Same arithmetic in the same order as solve_by_lane, so the same prices and the same assignment.  Components of more than 64 rows or columns
+    // stay on a lane.  The host build (one thread) runs the same text with 64-element arrays (Y7T_WV_*). ----
+#ifndef Y7T_COOP_MIN
+#define Y7T_COOP_MIN 8
+#endif
+    bool coop = false;
+    int cw = 0;                                                // waves busy with large components (device); they skip 4b
+    {
+        for (int i = tid; i < na; i += nt) if (x[i] == -1) Y7T_ATOMIC_ADD(csz + rowlab[i], 1);
+        y7t_sync(ex);
+        int* big = colcnt;                                      // (colcnt is dead behind the forced decisions)
+        const int nbig = y7t_compact(ex, na, [&](int i) { return x[i] == -1 && rowlab[i] == i && csz[i] > Y7T_COOP_MIN && csz[i] <= 64; }, big, 0);
+        // the large components go to the first `cw` waves (at most half of them), the others start on the small ones (4b) at once
+#if Y7T_DEVICE
+        const int wv_lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+        coop = nbig > 0 && nbig <= nb && nwv >= 2;
+        cw = coop ? (nbig < nwv / 2 ? nbig : nwv / 2) : 0;
+#else
+        const int wv = 0;
+        coop = nbig > 0 && nbig <= nb;
+        cw = coop ? 1 : 0;
+#endif
+        if (coop && wv < cw) {
+            for (int bi = wv; bi < nbig; bi += cw) {
+                const int lead = big[bi];
+                const int nrw = csz[lead];
+                // slots: lane l <- the component's l-th column and l-th row (ascending)
+                int myj[Y7T_WVN], rid[Y7T_WVN];
+                int ncl = 0;
+#if Y7T_DEVICE
+                {
+                    myj[0] = -1; rid[0] = -1;
+                    for (int base = 0; base < nb; base += 64) {
+                        const int j = base + wv_lane;
+                        const unsigned long long b = __ballot(j < nb && collab[j] == lead);
+                        const int cnt = __popcll(b), k = wv_lane - ncl;
+                        if (k >= 0 && k < cnt) { unsigned long long m = b; for (int t = 0; t < k; ++t) m &= m - 1; myj[0] = base + __ffsll((long long)m) - 1; }
+                        ncl += cnt;
+                    }
+                    int pos = 0;
+                    for (int base = lead; base < na && pos < nrw; base += 64) {
+                        const int i = base + wv_lane;
+                        const unsigned long long b = __ballot(i < na && rowlab[i] == lead && x[i] == -1);
+                        const int cnt = __popcll(b), k = wv_lane - pos;
+                        if (k >= 0 && k < cnt) { unsigned long long m = b; for (int t = 0; t < k; ++t) m &= m - 1; rid[0] = base + __ffsll((long long)m) - 1; }
+                        pos += cnt;
+                    }
+                }
+#else
+                for (int l = 0; l < 64; ++l) { myj[l] = -1; rid[l] = -1; }
+                for (int j = 0; j < nb; ++j) if (collab[j] == lead) { if (ncl < 64) myj[ncl] = j; ++ncl; }
+                for (int i = lead, pos = 0; i < na && pos < nrw; ++i) if (rowlab[i] == lead && x[i] == -1) rid[pos++] = i;
+#endif
+                if (ncl > 64) {                                 // more columns than lanes: the lane's walk, by this wave's first lane
+#if Y7T_DEVICE
+                    if (wv_lane == 0)
+#endif
+                    { Y7T_NEXT_STAT(3); solve_by_lane(lead); }
+                    continue;
+                }
+                Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
+                if (Y7T_COOP_MIN < 8 && nrw <= 8) {             // (the watched sizes come here only with a lower Y7T_COOP_MIN)
+#if Y7T_DEVICE
+                    if (wv_lane == 0)
+#endif
+                    tie_watch(lead);
+                }
+                double vj[Y7T_WVN], dj[Y7T_WVN], cc[Y7T_WVN];     // my column: price, tentative distance; the scanned row's cost to it
+                int yr[Y7T_WVN], stj[Y7T_WVN], pr[Y7T_WVN], has[Y7T_WVN];      // my column: the row slot matched to it, mark, predecessor row slot, "the scanned row has an edge to it"
+                int xs[Y7T_WVN], rc[Y7T_WVN];                   // my row: the column slot matched to it (-1 none, 64 the null column), its number of candidates
+                Y7T_WV_EACH(l) {
+                    Y7T_WV(vj, l) = Y7T_WV(myj, l) >= 0 ? v[Y7T_WV(myj, l)] : 0.0;
+                    Y7T_WV(yr, l) = -1; Y7T_WV(xs, l) = -1;
+                    Y7T_WV(rc, l) = Y7T_WV(rid, l) >= 0 ? rowcnt[Y7T_WV(rid, l)] : 0;
+                    Y7T_WV(dj, l) = 0.0; Y7T_WV(cc, l) = 0.0; Y7T_WV(stj, l) = 0; Y7T_WV(pr, l) = -1; Y7T_WV(has, l) = 0;
+                }
+                // the candidates of row slot `rs` to the lanes that own their columns: cc / has
+                auto hand_out = [&](int rs) {
+                    const int i = Y7T_WV_AT_I(rid, rs), n = Y7T_WV_AT_I(rc, rs);
+#if Y7T_DEVICE
+                    int kc = 0; double kv = 0.0;
+                    if (wv_lane < n) { kc = ccol[(size_t)i * MC + wv_lane]; kv = ccost[(size_t)i * MC + wv_lane]; }
+                    has[0] = 0;
+                    for (int k = 0; k < n; ++k) {
+                        const int cj = __builtin_amdgcn_readlane(kc, k);
+                        const double cv = y7t_readlane_d(kv, k);
+                        if (myj[0] == cj) { cc[0] = cv; has[0] = 1; }
+                    }
+#else
+                    for (int l = 0; l < 64; ++l) {
+                        has[l] = 0;
+                        for (int k = 0; k < n; ++k) if (ccol[(size_t)i * MC + k] == myj[l]) { cc[l] = ccost[(size_t)i * MC + k]; has[l] = 1; }
+                    }
+#endif
+                };
+                for (int start = 0; start < nrw; ++start) {    // (every row of the component is unsettled here, and a search settles exactly its start row)
+                    double d_null = 0.0; int pred_null = start;
+                    hand_out(start);
+                    Y7T_WV_EACH(l) {
+                        Y7T_WV(stj, l) = 0;
+                        if (Y7T_WV(has, l)) { Y7T_WV(dj, l) = Y7T_WV(cc, l) - thresh - Y7T_WV(vj, l); Y7T_WV(pr, l) = start; Y7T_WV(stj, l) = 1; }
+                    }
+                    int final_s = -2; double mind = 0.0;
+                    for (int guard = 0; ; ++guard) {
+                        double mv; unsigned long long bm;
+                        if (guard > 66) { flag[2] = 1; final_s = 64; pred_null = start; break; }      // (a search scans every column at most once; never seen -- the caller would re-solve the problem densely)
+                        Y7T_WV_MIN_D(mv, l, Y7T_WV(stj, l) == 1 ? Y7T_WV(dj, l) : HUGE_VAL);
+                        Y7T_WV_BALLOT(bm, l, Y7T_WV(stj, l) == 1 && Y7T_WV(dj, l) == mv);
+                        int ms = bm ? y7t_ctz64(bm) : 64;           // ties to the lowest column; the null column (slot 64) loses a tie against a real one
+                        if (!bm || d_null < mv) { mv = d_null; ms = 64; }
+                        mind = mv;
+                        if (ms == 64) { final_s = 64; break; }
+                        const int is = Y7T_WV_AT_I(yr, ms);
+                        if (is < 0) { final_s = ms; break; }
+                        Y7T_WV_SET(stj, ms, 2);
+                        hand_out(is);
+                        const double hh = Y7T_WV_AT_D(cc, ms) - thresh - Y7T_WV_AT_D(vj, ms) - mind;
+                        Y7T_WV_EACH(l) {
+                            if (Y7T_WV(has, l) && Y7T_WV(stj, l) != 2) {
+                                const double cred = Y7T_WV(cc, l) - thresh - Y7T_WV(vj, l) - hh;
+                                if (Y7T_WV(stj, l) == 0) { Y7T_WV(dj, l) = cred; Y7T_WV(pr, l) = is; Y7T_WV(stj, l) = 1; }
+                                else if (cred < Y7T_WV(dj, l)) { Y7T_WV(dj, l) = cred; Y7T_WV(pr, l) = is; }
+                            }
+                        }
+                        if (-hh < d_null) { d_null = -hh; pred_null = is; }
+                    }
+                    Y7T_WV_EACH(l) { if (Y7T_WV(stj, l) == 2) Y7T_WV(vj, l) += Y7T_WV(dj, l) - mind; }
+                    {   // augment (slots; uniform scalars)
+                        int i = -1, j = final_s;
+                        for (int guard = 0; i != start && guard < 66; ++guard) {
+                            i = (j == 64) ? pred_null : Y7T_WV_AT_I(pr, j);
+                            if (j != 64) Y7T_WV_SET(yr, j, i);
+                            const int t = j;
+                            j = Y7T_WV_AT_I(xs, i);
+                            Y7T_WV_SET(xs, i, t);
+                        }
+                    }
+                }
+                Y7T_WV_EACH(l) {                               // slots back to indices
+                    if (Y7T_WV(myj, l) >= 0) {
+                        const int r = Y7T_WV(yr, l);
+                        const int ri = Y7T_WV_GATHER_I(rid, r < 0 ? 0 : r);
+                        y[Y7T_WV(myj, l)] = r < 0 ? -1 : ri;
+                        v[Y7T_WV(myj, l)] = Y7T_WV(vj, l);
+                    }
+                }
+                Y7T_WV_EACH(l) {
+                    const int c = Y7T_WV(xs, l);
+                    const int cj = Y7T_WV_GATHER_I(myj, (c < 0 || c >= 64) ? 0 : c);
+                    if (Y7T_WV(rid, l) >= 0) x[Y7T_WV(rid, l)] = c == 64 ? nb : cj;
+                }
+            }
+        }
+#if !Y7T_DEVICE
+        cw = 0;                                                  // (one thread: it goes on to the small components itself)
+#endif
+    }
+    // ---- 4b. one lane per (remaining) component ----
+    for (int lead = tid - cw * 64; lead < na && tid >= cw * 64; lead += nt - cw * 64) {
+        if (x[lead] != -1 || rowlab[lead] != lead) continue;
+        if (coop && csz[lead] > Y7T_COOP_MIN && csz[lead] <= 64) continue;
+        tie_watch(lead);
+        solve_by_lane(lead);
     }
     y7t_sync(ex);
     Y7T_SPROF(5);
@@ -417,19 +615,16 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     return 1;
 }
 
-template <class ColFn, class CostFn>
-Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, CostFn cost) {
+template <class ColFn, class RowFn, class CostFn>
+Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost) {
     const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
     int mc = Y7T_MAXC;
     if (ex.fast && work_bytes + 64 <= ex.fast_bytes)
         while (mc > 8 && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc -= 4;      // 24, 20, 16, 12, 8
     if (mc < Y7T_MAXC && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc = Y7T_MAXC;      // nothing fits: as before
-#ifndef Y7T_NEXT_STAT
-#define Y7T_NEXT_STAT(k) do { } while (0)
-#endif
     if (mc < Y7T_MAXC) Y7T_NEXT_STAT(0);                    // (host build: how often the short stride is used / has to be repeated)
-    int r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, cost, mc);
-    if (r == 0 && mc < Y7T_MAXC) { Y7T_NEXT_STAT(1); y7t_sync(ex); r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, cost, Y7T_MAXC); }
+    int r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, mc);
+    if (r == 0 && mc < Y7T_MAXC) { Y7T_NEXT_STAT(1); y7t_sync(ex); r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, Y7T_MAXC); }
     return r;
 }
 
@@ -437,7 +632,8 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
 Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
                                [&](int j) { return Y7TBox4{{s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]}}; },
-                               [&](int i, int, const Y7TBox4& q) { return y7t_iou_dist(s.ttlbr + 4 * i, q.v); });
+                               [&](int i) { return Y7TBox4{{s.ttlbr[4 * i], s.ttlbr[4 * i + 1], s.ttlbr[4 * i + 2], s.ttlbr[4 * i + 3]}}; },
+                               [&](const Y7TBox4& b, const Y7TBox4& q) { return y7t_iou_dist(b.v, q.v); });
 }
 
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
