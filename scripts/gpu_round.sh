@@ -281,8 +281,8 @@ r5_ws128s2)
 r5_coop)
   say "r5_coop a: sparse association -- row contexts of the cost pass handed out through the scalar registers, large components on a wave with their state in registers: device parity (goldens, random scenes, cfg3 at full size vs the oracle, DeepSORT)"
   timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py tests/test_reid_gpu.py -q -m gpu -k "not w6_1280 and not conv_layer and not nms_output" > $O/t_coop.log 2>&1; echo "rc=$?" >> $O/t_coop.log; tailsum $O/t_coop.log 4
-  say "r5_coop b: the frame step alone (scripts/time_tracker.py): previous library, this one, previous, this one"
-  for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so prevb:$LIBD/liby7t_prev.so newb:$LIBD/liby7t.so; do
+  say "r5_coop b: the frame step alone (scripts/time_tracker.py): previous library, this one"
+  for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so; do
     n=${v%%:*}; l=${v#*:}; echo "-- $n" | tee -a $O/summary.txt
     Y7T_LIB=$l timeout 300 python scripts/time_tracker.py > $O/time_tracker_$n.txt 2>&1; grep -h "n_obj=500\|sparse association" $O/time_tracker_$n.txt | grep -v "threads=64 \|threads=256 " | cut -c1-300 | tee -a $O/summary.txt
   done
@@ -293,8 +293,8 @@ r5_coop)
   done
   for v in prev:$LIBD/liby7t_prev.so new:$LIBD/liby7t.so; do
     n=${v%%:*}; l=${v#*:}; Y7T_LIB=$l timeout 300 python bench.py --steps 16 --warmup 4 --no_cpu_baseline --no_latency_mode --no_other_workloads > $O/bench_cfg2_$n.json 2> $O/bench_cfg2_$n.err; benchsum cfg2_$n
-    Y7T_LIB=$l timeout 300 python bench.py $X --workload cfg4 > $O/bench_cfg4_$n.json 2> $O/bench_cfg4_$n.err; benchsum cfg4_$n
   done
+  timeout 300 python bench.py $X --workload cfg4 > $O/bench_cfg4_new.json 2> $O/bench_cfg4_new.err; benchsum cfg4_new
   ;;
 
 suite)
