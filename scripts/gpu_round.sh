@@ -297,6 +297,20 @@ r5_coop)
   timeout 300 python bench.py $X --workload cfg4 > $O/bench_cfg4_new.json 2> $O/bench_cfg4_new.err; benchsum cfg4_new
   ;;
 
+r5_coop2)
+  say "r5_coop2: the wave solve's threshold (components of more than N rows go to a wave: 8 = the product library, 4, 2 = variant builds of y7t_tracker.hip with -DY7T_COOP_MIN=N) + the overlap pre-test of the IoU cost pass; parity of the product library first"
+  timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py -q -m gpu -k "not w6_1280 and not conv_layer and not nms_output" > $O/t_coop2.log 2>&1; echo "rc=$?" >> $O/t_coop2.log; tailsum $O/t_coop2.log 4
+  for v in ${LIBS:-prev:liby7t_prev.so min8:liby7t.so min4:liby7t_coop4.so min2:liby7t_coop2.so}; do
+    n=${v%%:*}; l=$LIBD/${v#*:}; [ -f $l ] || continue; echo "-- $n" | tee -a $O/summary.txt
+    Y7T_LIB=$l timeout 300 python scripts/time_tracker.py > $O/time_tracker_$n.txt 2>&1; grep -h "n_obj=500\|sparse association\|large components" $O/time_tracker_$n.txt | grep -v "threads=64 \|threads=256 " | cut -c1-300 | tee -a $O/summary.txt
+  done
+  X="--steps 10 --warmup 3 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  for v in ${LIBS:-prev:liby7t_prev.so min8:liby7t.so min4:liby7t_coop4.so min2:liby7t_coop2.so}; do
+    n=${v%%:*}; l=$LIBD/${v#*:}; [ -f $l ] || continue
+    Y7T_LIB=$l timeout 300 python bench.py $X --workload cfg3 > $O/bench_cfg3_$n.json 2> $O/bench_cfg3_$n.err; benchsum cfg3_$n
+  done
+  ;;
+
 suite)
   say "suite: python -m pytest tests/ -x -q -m gpu"
   timeout 1200 python -m pytest tests/ -x -q -m gpu > $O/t_suite.log 2>&1; echo "rc=$?" >> $O/t_suite.log; tailsum $O/t_suite.log 3

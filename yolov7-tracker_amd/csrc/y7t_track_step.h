@@ -225,6 +225,7 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #define Y7T_SPARSE_MIN 4096      // na * nb from which the sparse path is taken (64 x 64)
 #endif
 struct Y7TBox4 { double v[4]; };
+struct Y7TBox4G { double v[4], g[4]; };
 
 // colctx(j): whatever of column j the cost needs (loaded once per lane, outside the row loop); cost(i, j, ctx) -> double
 // Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
@@ -537,6 +538,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     }
 #endif
                 };
+#if Y7T_DEVICE
+                if (thresh == 0.9 && tid == 0) { s.h->prof[23] = nbig | (cw << 8) | (nrw << 16) | (ncl << 24); s.h->prof[29] = 0; }
+#endif
                 for (int start = 0; start < nrw; ++start) {    // (every row of the component is unsettled here, and a search settles exactly its start row)
                     double d_null = 0.0; int pred_null = start;
                     hand_out(start);
@@ -569,6 +573,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                         if (-hh < d_null) { d_null = -hh; pred_null = is; }
                     }
                     Y7T_WV_EACH(l) { if (Y7T_WV(stj, l) == 2) Y7T_WV(vj, l) += Y7T_WV(dj, l) - mind; }
+#if Y7T_DEVICE
+                    if (thresh == 0.9 && tid == 0) { unsigned long long bs; Y7T_WV_BALLOT(bs, l, Y7T_WV(stj, l) == 2); s.h->prof[29] += __popcll(bs) + 1; }      // diagnostics: search steps of wave 0's last component
+#endif
                     {   // augment (slots; uniform scalars)
                         int i = -1, j = final_s;
                         for (int guard = 0; i != start && guard < 66; ++guard) {
@@ -597,6 +604,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         }
 #if !Y7T_DEVICE
         cw = 0;                                                  // (one thread: it goes on to the small components itself)
+#else
+        if (thresh == 0.9 && tid == 0) { s.h->prof[22] = clock64(); if (!coop) s.h->prof[23] = 0; }      // diagnostics: when wave 0 was done with its large components
 #endif
     }
     // ---- 4b. one lane per (remaining) component ----
@@ -631,9 +640,16 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
 // the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
 Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
-                               [&](int j) { return Y7TBox4{{s.dtlbr[4 * j], s.dtlbr[4 * j + 1], s.dtlbr[4 * j + 2], s.dtlbr[4 * j + 3]}}; },
+                               [&](int j) {
+                                   const double* q = s.dtlbr + 4 * j;      // + the box grown by 2 px: a row box entirely outside it has iw <= -1 or ih <= -1, i.e. IoU 0, cost exactly 1
+                                   return Y7TBox4G{{q[0], q[1], q[2], q[3]}, {q[0] - 2.0, q[1] - 2.0, q[2] + 2.0, q[3] + 2.0}};
+                               },
                                [&](int i) { return Y7TBox4{{s.ttlbr[4 * i], s.ttlbr[4 * i + 1], s.ttlbr[4 * i + 2], s.ttlbr[4 * i + 3]}}; },
-                               [&](const Y7TBox4& b, const Y7TBox4& q) { return y7t_iou_dist(b.v, q.v); });
+                               [&](const Y7TBox4& b, const Y7TBox4G& q) {
+                                   // four compares reject the pairs that do not overlap (all but ~1 % of a crowded frame's) before the min / max / add chain of the exact formula
+                                   if (b.v[2] <= q.g[0] || q.g[2] <= b.v[0] || b.v[3] <= q.g[1] || q.g[3] <= b.v[1]) return 1.0;
+                                   return y7t_iou_dist(b.v, q.v);
+                               });
 }
 
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
