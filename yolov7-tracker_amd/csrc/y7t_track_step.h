@@ -436,37 +436,35 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             for (int j = touched; j >= 0; ) { const int nx = nextcol[j]; st[j] = 0; j = nx; }
         }
     };
-    // ---- 4a. LARGE components (more than Y7T_COOP_MIN rows).  A 500-object frame has ~200 components; all but one to three have <= 8 rows, the largest 10-20 --
-    // and that one, walked by ONE lane (rows x searches x candidates of dependent LDS reads, ~2000 clocks per search step), was the critical path of the frame's
-    // association: 890 of the step's 2217 kcycles (profiles/r03_tracker_phases.txt).  Round 4 gave such a component a wave but kept its state in LDS: a search
-    // step then costs a wave reduction plus the same four dependent round trips (profiles/r04_tracker_coop_experiment.txt: no gain).  Here the component's state
-    // lives in REGISTERS: lane l owns the component's l-th column (price, distance, mark, predecessor, the row matched to it) and its l-th row (the column
-    // matched to it), everything in slot numbers; a search step is one DPP minimum + a ballot (ties to the lowest lane = the lowest column, as the lane's scan),
-    // one read of the scanned row's candidate list, which the lanes hand to the owners of those columns through the scalar registers, and the relaxation in
-    // registers.  Same arithmetic in the same order as solve_by_lane, so the same prices and the same assignment.  Components of more than 64 rows or columns
-    // stay on a lane.  The host build (one thread) runs the same text with 64-element arrays (Y7T_WV_*). ----
+    // ---- 4a. components of more than Y7T_COOP_MIN rows (and at most 64 rows and columns): ONE WAVE each, the component's state in registers.
+    // A 500-object frame has ~200 components, ~80 of them with two or more rows, the largest 10-20.  One lane per component (rounds 2-4) had two costs: the
+    // largest component's walk (rows x searches x candidates of dependent LDS reads, ~2000 clocks per search step), and -- the larger one, measured in round 5 --
+    // the lanes of a wave walking 64 different components in lockstep: every nested loop of the tie watch and of the searches runs for the longest trip count
+    // among them (639 kcycles of per-component solves with only the components of more than 8 rows on waves; profiles/r05_tracker_association.txt).  Round 4
+    // gave a large component a wave but kept its state in LDS: a search step then costs a wave reduction plus the same four dependent round trips (no gain,
+    // profiles/r04_tracker_coop_experiment.txt).  Here lane l owns the component's l-th column (price, distance, mark, predecessor, the row matched to it) and
+    // its l-th row (the column matched to it), everything in slot numbers; a search step is one DPP minimum + a ballot (ties to the lowest lane = the lowest
+    // column, as the lane's scan), one read of the scanned row's candidate list, which the lanes hand to the owners of those columns through the scalar
+    // registers, and the relaxation in registers; control flow is uniform over the wave.  Same arithmetic in the same order as solve_by_lane, so the same prices
+    // and the same assignment.  The host build (one thread) runs the same text with 64-element arrays (Y7T_WV_*). ----
 #ifndef Y7T_COOP_MIN
-#define Y7T_COOP_MIN 8
+#define Y7T_COOP_MIN 1
 #endif
     bool coop = false;
-    int cw = 0;                                                // waves busy with large components (device); they skip 4b
     {
         for (int i = tid; i < na; i += nt) if (x[i] == -1) Y7T_ATOMIC_ADD(csz + rowlab[i], 1);
         y7t_sync(ex);
-        int* big = colcnt;                                      // (colcnt is dead behind the forced decisions)
+        int* big = colcnt;                                      // (colcnt is dead behind the forced decisions; components partition the columns, so there are at most nb of them)
         const int nbig = y7t_compact(ex, na, [&](int i) { return x[i] == -1 && rowlab[i] == i && csz[i] > Y7T_COOP_MIN && csz[i] <= 64; }, big, 0);
-        // the large components go to the first `cw` waves (at most half of them), the others start on the small ones (4b) at once
 #if Y7T_DEVICE
         const int wv_lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
-        coop = nbig > 0 && nbig <= nb && nwv >= 2;
-        cw = coop ? (nbig < nwv / 2 ? nbig : nwv / 2) : 0;
+        coop = nbig > 0 && nwv >= 1;
 #else
-        const int wv = 0;
-        coop = nbig > 0 && nbig <= nb;
-        cw = coop ? 1 : 0;
+        const int wv = 0, nwv = 1;
+        coop = nbig > 0;
 #endif
-        if (coop && wv < cw) {
-            for (int bi = wv; bi < nbig; bi += cw) {
+        if (coop) {
+            for (int bi = wv; bi < nbig; bi += nwv) {
                 const int lead = big[bi];
                 const int nrw = csz[lead];
                 // slots: lane l <- the component's l-th column and l-th row (ascending)
@@ -504,19 +502,38 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     continue;
                 }
                 Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
-                if (Y7T_COOP_MIN < 8 && nrw <= 8) {             // (the watched sizes come here only with a lower Y7T_COOP_MIN)
+                int xs[Y7T_WVN], rc[Y7T_WVN];                   // my row: the column slot matched to it (-1 none, 64 the null column), its number of candidates
+                Y7T_WV_EACH(l) { Y7T_WV(xs, l) = -1; Y7T_WV(rc, l) = Y7T_WV(rid, l) >= 0 ? rowcnt[Y7T_WV(rid, l)] : 0; }
+                if (nrw <= 8) {                                 // tie watch (see tie_watch): the component's candidate edges a lane each, every edge's cost against the lanes above it
+                    int er[Y7T_WVN]; double ev[Y7T_WVN];
+                    int ne = 0;
+                    Y7T_WV_EACH(l) { Y7T_WV(er, l) = -1; Y7T_WV(ev, l) = 0.0; }
+                    for (int r = 0; r < nrw; ++r) {
+                        const int i = Y7T_WV_AT_I(rid, r), n = Y7T_WV_AT_I(rc, r);
+                        Y7T_WV_EACH(l) { const int k = l - ne; if (k >= 0 && k < n) { Y7T_WV(er, l) = r; Y7T_WV(ev, l) = ccost[(size_t)i * MC + k]; } }
+                        ne += n;
+                    }
+                    if (ne <= 64) {
+                        bool dup = false;
+                        for (int e = 0; e + 1 < ne && !dup; ++e) {
+                            const double c = Y7T_WV_AT_D(ev, e);
+                            unsigned long long bm;
+                            Y7T_WV_BALLOT(bm, l, l > e && Y7T_WV(er, l) >= 0 && Y7T_WV(ev, l) == c);
+                            dup = bm != 0ull;
+                        }
+                        if (dup) { flag[2] = 1; Y7T_TIE_REASON(5); }
+                    } else {
 #if Y7T_DEVICE
-                    if (wv_lane == 0)
+                        if (wv_lane == 0)
 #endif
-                    tie_watch(lead);
+                        tie_watch(lead);
+                    }
                 }
                 double vj[Y7T_WVN], dj[Y7T_WVN], cc[Y7T_WVN];     // my column: price, tentative distance; the scanned row's cost to it
                 int yr[Y7T_WVN], stj[Y7T_WVN], pr[Y7T_WVN], has[Y7T_WVN];      // my column: the row slot matched to it, mark, predecessor row slot, "the scanned row has an edge to it"
-                int xs[Y7T_WVN], rc[Y7T_WVN];                   // my row: the column slot matched to it (-1 none, 64 the null column), its number of candidates
                 Y7T_WV_EACH(l) {
                     Y7T_WV(vj, l) = Y7T_WV(myj, l) >= 0 ? v[Y7T_WV(myj, l)] : 0.0;
-                    Y7T_WV(yr, l) = -1; Y7T_WV(xs, l) = -1;
-                    Y7T_WV(rc, l) = Y7T_WV(rid, l) >= 0 ? rowcnt[Y7T_WV(rid, l)] : 0;
+                    Y7T_WV(yr, l) = -1;
                     Y7T_WV(dj, l) = 0.0; Y7T_WV(cc, l) = 0.0; Y7T_WV(stj, l) = 0; Y7T_WV(pr, l) = -1; Y7T_WV(has, l) = 0;
                 }
                 // the candidates of row slot `rs` to the lanes that own their columns: cc / has
@@ -539,7 +556,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #endif
                 };
 #if Y7T_DEVICE
-                if (thresh == 0.9 && tid == 0) { s.h->prof[23] = nbig | (cw << 8) | (nrw << 16) | (ncl << 24); s.h->prof[29] = 0; }
+                if (thresh == 0.9 && tid == 0) { s.h->prof[23] = (long long)nbig | ((long long)nrw << 16) | ((long long)ncl << 24) | ((long long)((nbig - 1 - wv) / nwv + 1) << 32); s.h->prof[29] = 0; }
 #endif
                 for (int start = 0; start < nrw; ++start) {    // (every row of the component is unsettled here, and a search settles exactly its start row)
                     double d_null = 0.0; int pred_null = start;
@@ -602,14 +619,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 }
             }
         }
-#if !Y7T_DEVICE
-        cw = 0;                                                  // (one thread: it goes on to the small components itself)
-#else
-        if (thresh == 0.9 && tid == 0) { s.h->prof[22] = clock64(); if (!coop) s.h->prof[23] = 0; }      // diagnostics: when wave 0 was done with its large components
+#if Y7T_DEVICE
+        if (thresh == 0.9 && tid == 0) { s.h->prof[22] = clock64(); if (!coop) s.h->prof[23] = 0; }      // diagnostics: when wave 0 was done with its components
 #endif
     }
-    // ---- 4b. one lane per (remaining) component ----
-    for (int lead = tid - cw * 64; lead < na && tid >= cw * 64; lead += nt - cw * 64) {
+    // ---- 4b. one lane per remaining component (single rows, and what has more than 64 rows) ----
+    for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
         if (coop && csz[lead] > Y7T_COOP_MIN && csz[lead] <= 64) continue;
         tie_watch(lead);
