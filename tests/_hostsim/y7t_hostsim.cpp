@@ -100,6 +100,9 @@ void hs_laplit(const double* cost, int nr, int nc, double limit, int* x, int* y)
     free(ws);
 }
 
+// the float32 pre-test of the IoU pair passes (y7t_box_apart): 1 = "cannot overlap"; and the distance the passes use (pre-test + exact formula)
+int hs_box_apart(const double* b, const double* q) { return y7t_box_apart(y7t_box_row(b), -1, y7t_box_col(q)) ? 1 : 0; }
+double hs_box_iou_dist(const double* b, const double* q) { return y7t_box_iou_dist(y7t_box_row(b), -1, y7t_box_col(q)); }
 void hs_iou_cost(const double* a, int n, const double* b, int m, double* cost) {
     for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) cost[(size_t)i * m + j] = y7t_iou_dist(a + 4 * i, b + 4 * j);
 }

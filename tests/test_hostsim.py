@@ -246,3 +246,41 @@ def test_hostsim_cfg3_full_size_botsort_equals_oracle():
     # text with 64-element arrays), none had to be declined for more than 64 columns
     on_wave, declined = hs.lib().hs_next_stat(2) - before[2], hs.lib().hs_next_stat(3) - before[3]
     assert on_wave > 300 and declined == 0, (on_wave, declined)
+
+
+def test_hostsim_iou_pretest_never_rejects_an_overlapping_pair():
+    """y7t_box_apart (float32, column box grown by 2 px) may only say "apart" where matching.iou_distance's formula gives exactly 1 (iw <= 0 or ih <= 0 with its
+    +1 pixel convention); and the distance the cost / duplicate passes use (pre-test, then the exact formula) equals the plain formula bit for bit -- random
+    boxes, boxes that touch at 0 / 1 / 2 px (+- an ulp), coordinates up to 4e6 (beyond 2^21 the pre-test must stand aside), infinities and NaN"""
+    import ctypes
+    L = hs.lib()
+    L.hs_box_apart.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.hs_box_iou_dist.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.hs_box_iou_dist.restype = ctypes.c_double
+    rng = np.random.default_rng(5)
+    cases = []
+    for scale in (100.0, 1280.0, 5e4, 2e6, 4e6):
+        a = rng.uniform(-scale, scale, (400, 4)); a[:, 2:] = a[:, :2] + rng.uniform(0, scale / 8, (400, 2))
+        b = a + rng.normal(0, scale / 50, (400, 4))
+        cases += list(zip(a, b))
+        for gap in (0.0, 1.0, 2.0, 3.0):      # b to the right of / below a at exactly `gap`, one ulp less, one ulp more
+            for eps in (0.0, -1.0, 1.0):
+                for axis in (0, 1):
+                    q = a[:60].copy()
+                    shift = a[:60, 2 + axis] - a[:60, axis] + gap
+                    q[:, axis] += shift; q[:, 2 + axis] += shift
+                    q[:, axis] = np.nextafter(q[:, axis], q[:, axis] + eps) if eps else q[:, axis]
+                    cases += list(zip(a[:60], q)) + list(zip(q, a[:60]))
+    odd = np.array([[0, 0, 10, 10], [np.inf, 0, np.inf, 5], [np.nan, 0, 4, 4], [-np.inf, -np.inf, np.inf, np.inf], [5, 5, 1, 1], [3e6, 3e6, 3e6 + 4, 3e6 + 4]], float)
+    cases += [(x, y) for x in odd for y in odd]
+    n_apart = 0
+    for b, q in cases:
+        b, q = np.ascontiguousarray(b, np.float64), np.ascontiguousarray(q, np.float64)
+        want = np.zeros(1)
+        L.hs_iou_cost(b.ctypes.data, 1, q.ctypes.data, 1, want.ctypes.data)
+        got = L.hs_box_iou_dist(b.ctypes.data, q.ctypes.data)
+        assert got == want[0] or (np.isnan(got) and np.isnan(want[0])), (b, q, got, want[0])
+        if L.hs_box_apart(b.ctypes.data, q.ctypes.data):
+            n_apart += 1
+            assert want[0] == 1.0, (b, q, want[0])
+    assert n_apart > len(cases) // 10

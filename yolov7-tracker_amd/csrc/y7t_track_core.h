@@ -484,6 +484,74 @@ Y7T_FN double y7t_iou_dist(const double* b, const double* q) {
     return 1 - ov;
 }
 
+// a row's value out of the lane that loaded it (y7t_pairs): lane r of the wave, or the caller's own when r < 0 (host build, partial waves)
+#if Y7T_DEVICE
+__device__ __forceinline__ int y7t_row_at(int v, int r) { return r < 0 ? v : __builtin_amdgcn_readlane(v, r); }
+__device__ __forceinline__ float y7t_row_at(float v, int r) { return r < 0 ? v : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); }
+__device__ __forceinline__ double y7t_row_at(double v, int r) { return r < 0 ? v : y7t_readlane_d(v, r); }
+#else
+static inline int y7t_row_at(int v, int) { return v; }
+static inline float y7t_row_at(float v, int) { return v; }
+static inline double y7t_row_at(double v, int) { return v; }
+#endif
+
+// every (row, column) pair of an na x nb problem: body(i, j, rl, r, cj) with cj = colctx(j) and row i's context = y7t_row_at(rl.., r).  Device: a lane per column, a wave
+// per row residue; what the body needs of a ROW is loaded 64 rows at a time, a lane each, and taken out of that lane's registers through the scalar registers when the
+// row's turn comes (round 5: a row's box used to be four dependent global loads in front of every pair's arithmetic -- 244 pairs per lane at 500 x 500, each a memory
+// round trip: 368 of the ByteTrack step's 2217 kcycles, profiles/r03_tracker_phases.txt)
+template <class ColFn, class RowFn, class Body>
+Y7T_FN void y7t_pairs(const Y7TExec& ex, int na, int nb, ColFn colctx, RowFn rowctx, Body body) {
+#if Y7T_DEVICE
+    if (ex.nt >= 64) {
+        const int nw = ex.nt >> 6, wave = ex.tid >> 6, lane = ex.tid & 63;
+        for (int jb = 0; jb < nb; jb += 64) {
+            const int j = jb + lane;
+            const bool jv = j < nb;
+            const auto cj = colctx(jv ? j : 0);
+            for (int ib = wave; ib < na; ib += nw * 64) {               // this wave's rows ib, ib + nw, ...: 64 of them at a time
+                const int il = ib + nw * lane;
+                const auto rl = rowctx(il < na ? il : 0);
+                int nr = (na - ib + nw - 1) / nw;
+                nr = nr < 64 ? nr : 64;
+                for (int r = 0; r < nr; ++r)
+                    if (jv) body(ib + nw * r, j, rl, r, cj);
+            }
+        }
+        return;
+    }
+#endif
+    for (int j = ex.tid; j < nb; j += ex.nt) {
+        const auto cj = colctx(j);
+        for (int i = 0; i < na; ++i) body(i, j, rowctx(i), -1, cj);
+    }
+}
+
+// IoU pairs: the boxes with float32 copies for a pre-test.  A row box entirely outside the column box grown by 2 px has iw <= -1 or ih <= -1 in y7t_iou_dist, i.e. IoU 0
+// and cost exactly 1; the float32 copies are off by < 0.75 px for |coordinate| < 2^21, boxes beyond that (or NaN) get infinities that never reject.
+struct Y7TBoxC { double v[4]; float g[4]; };      // a column: the box, and the box grown by 2 px
+struct Y7TBoxR { double v[4]; float f[4]; };      // a row
+Y7T_FN Y7TBoxC y7t_box_col(const double* q) {
+    const bool ok = fabs(q[0]) < 2097152.0 && fabs(q[1]) < 2097152.0 && fabs(q[2]) < 2097152.0 && fabs(q[3]) < 2097152.0;
+    const float inf = (float)HUGE_VAL;
+    return Y7TBoxC{{q[0], q[1], q[2], q[3]}, {ok ? (float)(q[0] - 2.0) : -inf, ok ? (float)(q[1] - 2.0) : -inf, ok ? (float)(q[2] + 2.0) : inf, ok ? (float)(q[3] + 2.0) : inf}};
+}
+Y7T_FN Y7TBoxR y7t_box_row(const double* b) {
+    const bool ok = fabs(b[0]) < 2097152.0 && fabs(b[1]) < 2097152.0 && fabs(b[2]) < 2097152.0 && fabs(b[3]) < 2097152.0;
+    const float inf = (float)HUGE_VAL;
+    return Y7TBoxR{{b[0], b[1], b[2], b[3]}, {ok ? (float)b[0] : -inf, ok ? (float)b[1] : -inf, ok ? (float)b[2] : inf, ok ? (float)b[3] : inf}};
+}
+// true: the pair cannot overlap (four float32 subtractions and a maximum, against the ~20 float64 operations of the exact test)
+Y7T_FN bool y7t_box_apart(const Y7TBoxR& rl, int r, const Y7TBoxC& q) {
+    const float f0 = y7t_row_at(rl.f[0], r), f1 = y7t_row_at(rl.f[1], r), f2 = y7t_row_at(rl.f[2], r), f3 = y7t_row_at(rl.f[3], r);
+    return fmaxf(fmaxf(q.g[0] - f2, f0 - q.g[2]), fmaxf(q.g[1] - f3, f1 - q.g[3])) >= 0.0f;
+}
+Y7T_FN double y7t_box_iou_dist(const Y7TBoxR& rl, int r, const Y7TBoxC& q) {
+    if (y7t_box_apart(rl, r, q)) return 1.0;
+    const double b[4] = {y7t_row_at(rl.v[0], r), y7t_row_at(rl.v[1], r), y7t_row_at(rl.v[2], r), y7t_row_at(rl.v[3], r)};
+    return y7t_iou_dist(b, q.v);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // lap.lapjv(cost, extend_cost=True, cost_limit=limit): Jonker-Volgenant on the IMPLICIT
 // (nr+nc)^2 extended matrix [[cost, limit/2], [limit/2, 0]] -- never materialised.

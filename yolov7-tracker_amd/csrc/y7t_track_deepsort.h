@@ -457,7 +457,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
 #if Y7T_DEVICE
         if (ex.tid == 0) { h->prof[27] += 1; if (mixed) h->prof[28] += 1; }      // diagnostics: frames with several ages / with a contested detection
 #endif
-        if (!mixed && y7t_assoc_sparse_fn(ex, s, n_rows, n_hi, 0.9, [&](int c) { return s.left[c]; }, [&](int r) { return s.tmpb[r]; }, [&](int sl, int dj) { return gated_at(sl, dj); }) == 1) {
+        if (!mixed && y7t_assoc_sparse_fn(ex, s, n_rows, n_hi, 0.9, [&](int c) { return s.left[c]; }, [&](int r) { return s.tmpb[r]; }, [&](int sl, int r, int dj) { return gated_at(y7t_row_at(sl, r), dj); }) == 1) {
             // the cascade's match order: by age, inside an age by row
             const int nm2 = y7t_compact(ex, n_rows, [&](int r) { return s.xrow[r] >= 0; }, s.tmpa, 0);
             int* age = f.tmpd;
@@ -491,7 +491,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
         for (int c = ex.tid; c < n_to; c += ex.nt) s.left[c] = s.dhi[f.tomatch[c]];           // detection row of every column
         y7t_sync(ex);
         // linear_assignment(cost, 0.9): entries above the limit can never be matched, so the candidate-list solver sees the same problem
-        const int sp = y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r) { return s.tmpb[r]; }, [&](int sl, int dj) { return gated_at(sl, dj); });
+        const int sp = y7t_assoc_sparse_fn(ex, s, n_tl, n_to, 0.9, [&](int c) { return s.left[c]; }, [&](int r) { return s.tmpb[r]; }, [&](int sl, int r, int dj) { return gated_at(y7t_row_at(sl, r), dj); });
         if (sp == 1) {      // (also for the small levels: a handful of candidates, no dense matrix to fill)
             Y7T_CPROF(17);
         } else {

@@ -224,10 +224,8 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #ifndef Y7T_SPARSE_MIN
 #define Y7T_SPARSE_MIN 4096      // na * nb from which the sparse path is taken (64 x 64)
 #endif
-struct Y7TBox4 { double v[4]; };
-struct Y7TBox4G { double v[4], g[4]; };
 
-// colctx(j): whatever of column j the cost needs (loaded once per lane, outside the row loop); cost(i, j, ctx) -> double
+// colctx(j) / rowctx(i): whatever of column j / row i the cost needs (y7t_pairs); cost(rl, r, cj) -> double, the row's values taken with y7t_row_at(rl.., r)
 // Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
 // connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
 // caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
@@ -276,55 +274,26 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [3] overflow / at-limit pair, changed, duplicate cost inside a component
+    int* flag = nextcol + nb;                                 // [4] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; csz[i] = 0; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; }
     y7t_sync(ex);
-    // ---- 1. cost pass: lane per column, wave per row residue (like y7t_cost_matrix).  What the cost needs of a ROW is loaded 64 rows at a time, a lane each, and
-    // handed to the wave row by row through the scalar registers (round 5: a row's box used to be four dependent global loads in front of every pair's
-    // arithmetic -- 244 pairs per lane at 500 x 500, each a memory round trip: 368 of the step's 2217 kcycles, profiles/r03_tracker_phases.txt) ----
-    {
-        auto edge = [&](int i, int j, double c) {
-            if (c <= thresh_hi) {                             // (one compare on the common path: most pairs do not overlap at all)
-                if (c >= thresh - Y7T_TIE_EPS) { flag[0] = 1; Y7T_TIE_REASON(4); }      // exactly at the limit: the optimum is not unique -> dense path, lapjv's own order
-                if (c <= thresh) {
-                    const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
-                    if (k < MC) { ccol[(size_t)i * MC + k] = j; ccost[(size_t)i * MC + k] = c; }
-                    else flag[0] = 1;
-                    Y7T_FETCH_ADD(colcnt + j, 1);
-                }
-            }
-        };
-#if Y7T_DEVICE
-        if (nt >= 64) {
-            const int nw = nt >> 6, wave = tid >> 6, lane = tid & 63;
-            for (int jb = 0; jb < nb; jb += 64) {
-                const int j = jb + lane;
-                const bool jv = j < nb;
-                const auto cj = colctx(jv ? j : 0);
-                for (int ib = wave; ib < na; ib += nw * 64) {           // this wave's rows ib, ib + nw, ...: 64 of them at a time
-                    const int il = ib + nw * lane;
-                    const auto rl = rowctx(il < na ? il : 0);
-                    int nr = (na - ib + nw - 1) / nw;
-                    nr = nr < 64 ? nr : 64;
-                    for (int r = 0; r < nr; ++r) {
-                        const auto ri = y7t_readlane_t(rl, r);
-                        if (jv) edge(ib + nw * r, j, cost(ri, cj));
-                    }
-                }
-            }
-        } else
-#endif
-        {
-            for (int j = tid; j < nb; j += nt) {
-                const auto cj = colctx(j);
-                for (int i = 0; i < na; ++i) edge(i, j, cost(rowctx(i), cj));
+    // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers) ----
+    y7t_pairs(ex, na, nb, colctx, rowctx, [&](int i, int j, const auto& rl, int r, const auto& cj) {
+        const double c = cost(rl, r, cj);
+        if (c <= thresh_hi) {                                 // (one compare on the common path: most pairs do not overlap at all)
+            if (c >= thresh - Y7T_TIE_EPS) { flag[0] = 1; Y7T_TIE_REASON(4); }      // exactly at the limit: the optimum is not unique -> dense path, lapjv's own order
+            if (c <= thresh) {
+                const int k = Y7T_FETCH_ADD(rowcnt + i, 1);
+                if (k < MC) { ccol[(size_t)i * MC + k] = j; ccost[(size_t)i * MC + k] = c; }
+                else flag[0] = 1;
+                Y7T_FETCH_ADD(colcnt + j, 1);
             }
         }
-    }
+    });
     y7t_sync(ex);
     Y7T_SPROF(1);
     if (flag[0]) return 0;
@@ -376,7 +345,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // tie watch: two candidate edges of a component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
     auto tie_watch = [&](int lead) {
         int crow[8], ncr = 0;
-        for (int a = lead; a < na && ncr < 9; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
+        const int nrows = csz[lead];                          // (the scan stops at the component's last row, not at the end of the matrix)
+        for (int a = lead; a < na && ncr < 9 && ncr < nrows; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
         if (ncr <= 8) {
             bool dup = false;
             for (int ia = 0; ia < ncr && !dup; ++ia)
@@ -391,8 +361,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     };
     // one LANE walks a whole component: every step a chain of dependent reads of the work arrays
     auto solve_by_lane = [&](int lead) {
-        for (int start = lead; start < na; ++start) {
+        for (int start = lead, left = csz[lead]; start < na && left > 0; ++start) {
             if (rowlab[start] != lead || x[start] != -1) continue;
+            --left;
             // Dijkstra from `start`; the null column lives in registers (every component has its own)
             double d_null = 0.0; int pred_null = start;
             int touched = -1;
@@ -450,6 +421,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #ifndef Y7T_COOP_MIN
 #define Y7T_COOP_MIN 1
 #endif
+#ifndef Y7T_SERIAL_TIE
+#define Y7T_SERIAL_TIE 0
+#endif
+#ifndef Y7T_COOP_DIAG
+#define Y7T_COOP_DIAG 1      // wave 0's share of step 4 in the header's prof[] (scripts/time_tracker.py)
+#endif
     bool coop = false;
     {
         for (int i = tid; i < na; i += nt) if (x[i] == -1) Y7T_ATOMIC_ADD(csz + rowlab[i], 1);
@@ -464,7 +441,16 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         coop = nbig > 0;
 #endif
         if (coop) {
-            for (int bi = wv; bi < nbig; bi += nwv) {
+            for (;;) {                                          // the waves take the components off a counter: the largest one (10-20 rows) costs as much as ten small ones
+                int bi;
+#if Y7T_DEVICE
+                bi = 0;
+                if (wv_lane == 0) bi = Y7T_FETCH_ADD(flag + 3, 1);
+                bi = __builtin_amdgcn_readfirstlane(bi);
+#else
+                bi = flag[3]++;
+#endif
+                if (bi >= nbig) break;
                 const int lead = big[bi];
                 const int nrw = csz[lead];
                 // slots: lane l <- the component's l-th column and l-th row (ascending)
@@ -513,7 +499,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                         Y7T_WV_EACH(l) { const int k = l - ne; if (k >= 0 && k < n) { Y7T_WV(er, l) = r; Y7T_WV(ev, l) = ccost[(size_t)i * MC + k]; } }
                         ne += n;
                     }
-                    if (ne <= 64) {
+                    if (ne <= 64 && !Y7T_SERIAL_TIE) {
                         bool dup = false;
                         for (int e = 0; e + 1 < ne && !dup; ++e) {
                             const double c = Y7T_WV_AT_D(ev, e);
@@ -555,8 +541,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     }
 #endif
                 };
-#if Y7T_DEVICE
-                if (thresh == 0.9 && tid == 0) { s.h->prof[23] = (long long)nbig | ((long long)nrw << 16) | ((long long)ncl << 24) | ((long long)((nbig - 1 - wv) / nwv + 1) << 32); s.h->prof[29] = 0; }
+#if Y7T_DEVICE && Y7T_COOP_DIAG
+                if (thresh == 0.9 && tid == 0) { s.h->prof[23] = (long long)nbig | ((long long)nrw << 16) | ((long long)ncl << 24) | ((long long)(bi + 1) << 32); s.h->prof[29] = 0; }
 #endif
                 for (int start = 0; start < nrw; ++start) {    // (every row of the component is unsettled here, and a search settles exactly its start row)
                     double d_null = 0.0; int pred_null = start;
@@ -590,7 +576,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                         if (-hh < d_null) { d_null = -hh; pred_null = is; }
                     }
                     Y7T_WV_EACH(l) { if (Y7T_WV(stj, l) == 2) Y7T_WV(vj, l) += Y7T_WV(dj, l) - mind; }
-#if Y7T_DEVICE
+#if Y7T_DEVICE && Y7T_COOP_DIAG
                     if (thresh == 0.9 && tid == 0) { unsigned long long bs; Y7T_WV_BALLOT(bs, l, Y7T_WV(stj, l) == 2); s.h->prof[29] += __popcll(bs) + 1; }      // diagnostics: search steps of wave 0's last component
 #endif
                     {   // augment (slots; uniform scalars)
@@ -619,7 +605,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 }
             }
         }
-#if Y7T_DEVICE
+#if Y7T_DEVICE && Y7T_COOP_DIAG
         if (thresh == 0.9 && tid == 0) { s.h->prof[22] = clock64(); if (!coop) s.h->prof[23] = 0; }      // diagnostics: when wave 0 was done with its components
 #endif
     }
@@ -647,31 +633,30 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
         while (mc > 8 && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc -= 4;      // 24, 20, 16, 12, 8
     if (mc < Y7T_MAXC && work_bytes + 64 + (size_t)na * mc * (sizeof(int) + sizeof(double)) > ex.fast_bytes) mc = Y7T_MAXC;      // nothing fits: as before
     if (mc < Y7T_MAXC) Y7T_NEXT_STAT(0);                    // (host build: how often the short stride is used / has to be repeated)
-    int r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, mc);
-    if (r == 0 && mc < Y7T_MAXC) { Y7T_NEXT_STAT(1); y7t_sync(ex); r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, Y7T_MAXC); }
+    int r = 0;
+    for (int pass = 0; pass < 2; ++pass) {                    // (ONE inlined copy of the solver: the frame step's code is 200 KB as it is)
+        r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, mc);
+        if (r != 0 || mc == Y7T_MAXC) break;
+        Y7T_NEXT_STAT(1); y7t_sync(ex); mc = Y7T_MAXC;
+    }
     return r;
 }
 
 // the IoU instance (matching.iou_distance on the boxes gathered in ttlbr / dtlbr)
 Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
-                               [&](int j) {
-                                   const double* q = s.dtlbr + 4 * j;      // + the box grown by 2 px: a row box entirely outside it has iw <= -1 or ih <= -1, i.e. IoU 0, cost exactly 1
-                                   return Y7TBox4G{{q[0], q[1], q[2], q[3]}, {q[0] - 2.0, q[1] - 2.0, q[2] + 2.0, q[3] + 2.0}};
-                               },
-                               [&](int i) { return Y7TBox4{{s.ttlbr[4 * i], s.ttlbr[4 * i + 1], s.ttlbr[4 * i + 2], s.ttlbr[4 * i + 3]}}; },
-                               [&](const Y7TBox4& b, const Y7TBox4G& q) {
-                                   // four compares reject the pairs that do not overlap (all but ~1 % of a crowded frame's) before the min / max / add chain of the exact formula
-                                   if (b.v[2] <= q.g[0] || q.g[2] <= b.v[0] || b.v[3] <= q.g[1] || q.g[3] <= b.v[1]) return 1.0;
-                                   return y7t_iou_dist(b.v, q.v);
-                               });
+                               [&](int j) { return y7t_box_col(s.dtlbr + 4 * j); },
+                               [&](int i) { return y7t_box_row(s.ttlbr + 4 * i); },
+                               [&](const Y7TBoxR& rl, int r, const Y7TBoxC& q) { return y7t_box_iou_dist(rl, r, q); });
 }
 
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
 // dtlbr[0..nb)  ->  xrow[na] (det index or -1), ycol[nb] (track index or -1).
 // The LAP work arrays and, when it fits, the cost matrix are placed in the workgroup's fast
 // scratch (LDS on the device); otherwise they stay in the state blob (HBM/L2).
-Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+// NOT inlined: the step calls it three times, and three copies of the dense + sparse solvers took the frame step's code past the reach of a conditional branch
+// (+-128 KB) -- the build that crossed it mis-executed the BoT-SORT step (round 5, scripts/debug_botsort.py; -O1 and any smaller variant of the same text ran right)
+Y7T_NOINL void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     if (na == 0 || nb == 0) {  // empty cost matrix: everything unmatched (matching.py:31-32)
         for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = -1;
         for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = -1;
@@ -853,16 +838,14 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
         for (int i = ex.tid; i < n1; i += ex.nt) s.tmpa[i] = 0;
         for (int i = ex.tid; i < n2; i += ex.nt) s.tmpb[i] = 0;
         y7t_sync(ex);
-        const int tot = n1 * n2;
-        for (int k = ex.tid; k < tot; k += ex.nt) {
-            const int p = k / n2, q = k - p * n2;
-            const double dist = y7t_iou_dist(s.ttlbr + 4 * (size_t)p, lb + 4 * (size_t)q);
-            if (dist < 0.15) {
+        y7t_pairs(ex, n1, n2, [&](int q) { return y7t_box_col(lb + 4 * (size_t)q); }, [&](int p) { return y7t_box_row(s.ttlbr + 4 * (size_t)p); },
+                  [&](int p, int q, const Y7TBoxR& rl, int r, const Y7TBoxC& cq) {
+            if (y7t_box_iou_dist(rl, r, cq) < 0.15) {
                 const int a = s.tracked[p], b = s.lost[q];
                 const int timep = s.frame[a] - s.start[a], timeq = s.frame[b] - s.start[b];
                 if (timep > timeq) s.tmpb[q] = 1; else s.tmpa[p] = 1;  // benign same-value races
             }
-        }
+        });
         y7t_sync(ex);
         const int m1 = y7t_compact(ex, n1, [&](int i) { return !s.tmpa[i]; }, s.pool, 0);
         const int m2 = y7t_compact(ex, n2, [&](int i) { return !s.tmpb[i]; }, s.unconf, 0);
