@@ -274,12 +274,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [4] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a
+    int* flag = nextcol + nb;                                 // [5] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a, "a row is left for steps 3 and 4"
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; csz[i] = 0; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; flag[4] = 0; }
     y7t_sync(ex);
     // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers) ----
     y7t_pairs(ex, na, nb, colctx, rowctx, [&](int i, int j, const auto& rl, int r, const auto& cj) {
@@ -320,9 +320,13 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             const double red = ccost[(size_t)i * MC] - thresh;
             if (red < 0.0) { x[i] = j; y[j] = i; v[j] = red; }
         }
+        if (x[i] == -1) flag[4] = 1;
     }
     y7t_sync(ex);
     Y7T_SPROF(3);
+    // (the levels of DeepSORT's cascade are a dozen small problems per frame, most of them settled by now: steps 3 and 4 are ~10 barriers each)
+    const bool rows_left = flag[4] != 0;
+    if (rows_left) {
     // ---- 3. components of the candidate graph among the unsettled rows: label = smallest row index ----
     for (int it = 0; it < na + 2; ++it) {
         for (int i = tid; i < na; i += nt)
@@ -617,6 +621,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         solve_by_lane(lead);
     }
     y7t_sync(ex);
+    } else Y7T_SPROF(4);
     Y7T_SPROF(5);
     if (flag[2]) return 2;
     for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
