@@ -134,6 +134,7 @@ __device__ __forceinline__ T y7t_readlane_t(const T& v, int s) {
     return __builtin_bit_cast(T, b);
 }
 __device__ __forceinline__ int y7t_ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int y7t_popc64(unsigned long long m) { return __popcll(m); }
 #define Y7T_WVN 1
 #define Y7T_WV_EACH(l) for (int l __attribute__((unused)) = wv_lane, l##_once = 1; l##_once; l##_once = 0)
 #define Y7T_WV(a, l) (a)[0]
@@ -145,6 +146,7 @@ __device__ __forceinline__ int y7t_ctz64(unsigned long long m) { return __ffsll(
 #define Y7T_WV_BALLOT(out, l, pred) do { const int l = wv_lane; (void)l; (out) = __ballot(pred); } while (0)
 #else
 static inline int y7t_ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+static inline int y7t_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 #define Y7T_WVN 64
 #define Y7T_WV_EACH(l) for (int l = 0; l < 64; ++l)
 #define Y7T_WV(a, l) (a)[l]

@@ -267,7 +267,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* rowcnt = (int*)(dd + nb + 2);                        // [na]
     int* rowlab = rowcnt + na;                                // [na]
     int* x = rowlab + na;                                     // [na]
-    int* csz = x + na;                                        // [na] rows of the component led by row i (step 4)
+    int* csz = x + na;                                        // [na] 1: the component led by row i has two or more rows (set in step 3)
     int* colcnt = csz + na;                                   // [nb]; behind the forced decisions: the leaders of the large components
     int* collab = colcnt + nb;                                // [nb]
     int* y = collab + nb;                                     // [nb]
@@ -338,7 +338,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             if (x[i] == -1) {
                 int m = rowlab[i];
                 for (int k = 0; k < rowcnt[i]; ++k) { const int l = collab[ccol[(size_t)i * MC + k]]; m = l < m ? l : m; }
-                if (m != rowlab[i]) { rowlab[i] = m; flag[1] = 1; }
+                if (m != rowlab[i]) { rowlab[i] = m; flag[1] = 1; csz[m] = 1; }      // (csz: "this leader's component has a second row"; a mark on a row that stops being a leader is never read)
             }
         y7t_sync(ex);
         if (!flag[1]) break;
@@ -349,8 +349,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // tie watch: two candidate edges of a component with exactly the same cost (components of up to 8 rows; larger ones are not watched)
     auto tie_watch = [&](int lead) {
         int crow[8], ncr = 0;
-        const int nrows = csz[lead];                          // (the scan stops at the component's last row, not at the end of the matrix)
-        for (int a = lead; a < na && ncr < 9 && ncr < nrows; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
+        const int maxr = csz[lead] ? 9 : 1;                   // (a single row: no scan to the end of the matrix for its companions)
+        for (int a = lead; a < na && ncr < maxr; ++a) if (rowlab[a] == lead) { if (ncr < 8) crow[ncr] = a; ++ncr; }
         if (ncr <= 8) {
             bool dup = false;
             for (int ia = 0; ia < ncr && !dup; ++ia)
@@ -365,7 +365,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     };
     // one LANE walks a whole component: every step a chain of dependent reads of the work arrays
     auto solve_by_lane = [&](int lead) {
-        for (int start = lead, left = csz[lead]; start < na && left > 0; ++start) {
+        for (int start = lead, left = csz[lead] ? na : 1; start < na && left > 0; ++start) {
             if (rowlab[start] != lead || x[start] != -1) continue;
             --left;
             // Dijkstra from `start`; the null column lives in registers (every component has its own)
@@ -411,7 +411,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             for (int j = touched; j >= 0; ) { const int nx = nextcol[j]; st[j] = 0; j = nx; }
         }
     };
-    // ---- 4a. components of more than Y7T_COOP_MIN rows (and at most 64 rows and columns): ONE WAVE each, the component's state in registers.
+    // ---- 4a. components of two or more rows (and at most 64 rows and columns): ONE WAVE each, the component's state in registers.
     // A 500-object frame has ~200 components, ~80 of them with two or more rows, the largest 10-20.  One lane per component (rounds 2-4) had two costs: the
     // largest component's walk (rows x searches x candidates of dependent LDS reads, ~2000 clocks per search step), and -- the larger one, measured in round 5 --
     // the lanes of a wave walking 64 different components in lockstep: every nested loop of the tie watch and of the searches runs for the longest trip count
@@ -422,9 +422,6 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // column, as the lane's scan), one read of the scanned row's candidate list, which the lanes hand to the owners of those columns through the scalar
     // registers, and the relaxation in registers; control flow is uniform over the wave.  Same arithmetic in the same order as solve_by_lane, so the same prices
     // and the same assignment.  The host build (one thread) runs the same text with 64-element arrays (Y7T_WV_*). ----
-#ifndef Y7T_COOP_MIN
-#define Y7T_COOP_MIN 1
-#endif
 #ifndef Y7T_SERIAL_TIE
 #define Y7T_SERIAL_TIE 0
 #endif
@@ -433,18 +430,31 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #endif
     bool coop = false;
     {
-        for (int i = tid; i < na; i += nt) if (x[i] == -1) Y7T_ATOMIC_ADD(csz + rowlab[i], 1);
-        y7t_sync(ex);
-        int* big = colcnt;                                      // (colcnt is dead behind the forced decisions; components partition the columns, so there are at most nb of them)
-        const int nbig = y7t_compact(ex, na, [&](int i) { return x[i] == -1 && rowlab[i] == i && csz[i] > Y7T_COOP_MIN && csz[i] <= 64; }, big, 0);
 #if Y7T_DEVICE
-        const int wv_lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
-        coop = nbig > 0 && nwv >= 1;
+        const int wv_lane = tid & 63;
+        coop = nt >= 64 && na <= 4096;
 #else
-        const int wv = 0, nwv = 1;
-        coop = nbig > 0;
+        coop = na <= 4096;
 #endif
         if (coop) {
+            // the leaders of the components of two or more rows: every wave finds them for itself -- a ballot per 64 rows, the masks a lane each -- so that there is
+            // no list to build and no barrier to wait at (the levels of DeepSORT's cascade are a dozen small problems per frame)
+            int lm_lo[Y7T_WVN], lm_hi[Y7T_WVN];
+            int nbig = 0;
+            const int nch = (na + 63) >> 6;
+#if Y7T_DEVICE
+            lm_lo[0] = 0; lm_hi[0] = 0;
+            for (int c = 0; c < nch; ++c) {
+                const int i = c * 64 + wv_lane;
+                const unsigned long long b = __ballot(i < na && x[i] == -1 && rowlab[i] == i && csz[i] != 0);
+                if (wv_lane == c) { lm_lo[0] = (int)(unsigned)b; lm_hi[0] = (int)(unsigned)(b >> 32); }
+                nbig += __popcll(b);
+            }
+#else
+            for (int c = 0; c < 64; ++c) { lm_lo[c] = 0; lm_hi[c] = 0; }
+            for (int i = 0; i < na; ++i)
+                if (x[i] == -1 && rowlab[i] == i && csz[i] != 0) { if ((i & 63) < 32) lm_lo[i >> 6] |= (int)(1u << (i & 31)); else lm_hi[i >> 6] |= (int)(1u << (i & 31)); ++nbig; }
+#endif
             for (;;) {                                          // the waves take the components off a counter: the largest one (10-20 rows) costs as much as ten small ones
                 int bi;
 #if Y7T_DEVICE
@@ -455,11 +465,16 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 bi = flag[3]++;
 #endif
                 if (bi >= nbig) break;
-                const int lead = big[bi];
-                const int nrw = csz[lead];
+                int lead = -1;
+                for (int c = 0, k = bi; c < nch; ++c) {
+                    unsigned long long m = (unsigned long long)(unsigned)Y7T_WV_AT_I(lm_lo, c) | ((unsigned long long)(unsigned)Y7T_WV_AT_I(lm_hi, c) << 32);
+                    const int n = y7t_popc64(m);
+                    if (k < n) { for (int t = 0; t < k; ++t) m &= m - 1; lead = c * 64 + y7t_ctz64(m); break; }
+                    k -= n;
+                }
                 // slots: lane l <- the component's l-th column and l-th row (ascending)
                 int myj[Y7T_WVN], rid[Y7T_WVN];
-                int ncl = 0;
+                int ncl = 0, nrw = 0;
 #if Y7T_DEVICE
                 {
                     myj[0] = -1; rid[0] = -1;
@@ -470,25 +485,24 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                         if (k >= 0 && k < cnt) { unsigned long long m = b; for (int t = 0; t < k; ++t) m &= m - 1; myj[0] = base + __ffsll((long long)m) - 1; }
                         ncl += cnt;
                     }
-                    int pos = 0;
-                    for (int base = lead; base < na && pos < nrw; base += 64) {
+                    for (int base = lead; base < na; base += 64) {
                         const int i = base + wv_lane;
                         const unsigned long long b = __ballot(i < na && rowlab[i] == lead && x[i] == -1);
-                        const int cnt = __popcll(b), k = wv_lane - pos;
+                        const int cnt = __popcll(b), k = wv_lane - nrw;
                         if (k >= 0 && k < cnt) { unsigned long long m = b; for (int t = 0; t < k; ++t) m &= m - 1; rid[0] = base + __ffsll((long long)m) - 1; }
-                        pos += cnt;
+                        nrw += cnt;
                     }
                 }
 #else
                 for (int l = 0; l < 64; ++l) { myj[l] = -1; rid[l] = -1; }
                 for (int j = 0; j < nb; ++j) if (collab[j] == lead) { if (ncl < 64) myj[ncl] = j; ++ncl; }
-                for (int i = lead, pos = 0; i < na && pos < nrw; ++i) if (rowlab[i] == lead && x[i] == -1) rid[pos++] = i;
+                for (int i = lead; i < na; ++i) if (rowlab[i] == lead && x[i] == -1) { if (nrw < 64) rid[nrw] = i; ++nrw; }
 #endif
-                if (ncl > 64) {                                 // more columns than lanes: the lane's walk, by this wave's first lane
+                if (ncl > 64 || nrw > 64) {                     // more rows or columns than lanes: the lane's walk, by this wave's first lane
 #if Y7T_DEVICE
                     if (wv_lane == 0)
 #endif
-                    { Y7T_NEXT_STAT(3); solve_by_lane(lead); }
+                    { Y7T_NEXT_STAT(3); tie_watch(lead); solve_by_lane(lead); }
                     continue;
                 }
                 Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
@@ -616,7 +630,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // ---- 4b. one lane per remaining component (single rows, and what has more than 64 rows) ----
     for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
-        if (coop && csz[lead] > Y7T_COOP_MIN && csz[lead] <= 64) continue;
+        if (coop && csz[lead]) continue;
         tie_watch(lead);
         solve_by_lane(lead);
     }
@@ -843,14 +857,21 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
         for (int i = ex.tid; i < n1; i += ex.nt) s.tmpa[i] = 0;
         for (int i = ex.tid; i < n2; i += ex.nt) s.tmpb[i] = 0;
         y7t_sync(ex);
-        y7t_pairs(ex, n1, n2, [&](int q) { return y7t_box_col(lb + 4 * (size_t)q); }, [&](int p) { return y7t_box_row(s.ttlbr + 4 * (size_t)p); },
-                  [&](int p, int q, const Y7TBoxR& rl, int r, const Y7TBoxC& cq) {
-            if (y7t_box_iou_dist(rl, r, cq) < 0.15) {
-                const int a = s.tracked[p], b = s.lost[q];
-                const int timep = s.frame[a] - s.start[a], timeq = s.frame[b] - s.start[b];
-                if (timep > timeq) s.tmpb[q] = 1; else s.tmpa[p] = 1;  // benign same-value races
+        auto duplicate = [&](int p, int q) {
+            const int a = s.tracked[p], b = s.lost[q];
+            const int timep = s.frame[a] - s.start[a], timeq = s.frame[b] - s.start[b];
+            if (timep > timeq) s.tmpb[q] = 1; else s.tmpa[p] = 1;  // benign same-value races
+        };
+        const int tot = n1 * n2;
+        if (tot < 16384) {                                    // a thread per pair while that keeps every thread at a handful of pairs (80-object frames: 1-2)
+            for (int k = ex.tid; k < tot; k += ex.nt) {
+                const int p = k / n2, q = k - p * n2;
+                if (y7t_iou_dist(s.ttlbr + 4 * (size_t)p, lb + 4 * (size_t)q) < 0.15) duplicate(p, q);
             }
-        });
+        } else {                                              // crowded frames (500 tracked x a few hundred lost): a lane per lost box, the tracked boxes through the scalar registers
+            y7t_pairs(ex, n1, n2, [&](int q) { return y7t_box_col(lb + 4 * (size_t)q); }, [&](int p) { return y7t_box_row(s.ttlbr + 4 * (size_t)p); },
+                      [&](int p, int q, const Y7TBoxR& rl, int r, const Y7TBoxC& cq) { if (y7t_box_iou_dist(rl, r, cq) < 0.15) duplicate(p, q); });
+        }
         y7t_sync(ex);
         const int m1 = y7t_compact(ex, n1, [&](int i) { return !s.tmpa[i]; }, s.pool, 0);
         const int m2 = y7t_compact(ex, n2, [&](int i) { return !s.tmpb[i]; }, s.unconf, 0);
