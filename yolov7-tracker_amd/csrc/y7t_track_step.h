@@ -433,6 +433,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #if Y7T_DEVICE
         const int wv_lane = tid & 63;
         coop = nt >= 64 && na <= 4096;
+#ifdef Y7T_NO_COOP
+        coop = false;
+#endif
 #else
         coop = na <= 4096;
 #endif
@@ -673,9 +676,7 @@ Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, 
 // dtlbr[0..nb)  ->  xrow[na] (det index or -1), ycol[nb] (track index or -1).
 // The LAP work arrays and, when it fits, the cost matrix are placed in the workgroup's fast
 // scratch (LDS on the device); otherwise they stay in the state blob (HBM/L2).
-// NOT inlined: the step calls it three times, and three copies of the dense + sparse solvers took the frame step's code past the reach of a conditional branch
-// (+-128 KB) -- the build that crossed it mis-executed the BoT-SORT step (round 5, scripts/debug_botsort.py; -O1 and any smaller variant of the same text ran right)
-Y7T_NOINL void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+Y7T_FN void y7t_assoc_inl(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     if (na == 0 || nb == 0) {  // empty cost matrix: everything unmatched (matching.py:31-32)
         for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = -1;
         for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = -1;
@@ -708,6 +709,12 @@ Y7T_NOINL void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, dou
     for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = (L.y[j] >= na) ? -1 : L.y[j];
     y7t_sync(ex);
 }
+
+// y7t_tracker_step calls the association three times; three inlined copies of the dense + sparse solvers took that function's code to 234 KB, and the build that got
+// there mis-executed the BoT-SORT step (round 5, scripts/debug_botsort.py: -O1, and every smaller variant of the same text, ran right) -- so ONE copy, called.  A call
+// costs the caller ~10 % everywhere (what lives across it goes through scratch: measured on the DeepSORT step, profiles/r05_tracker_association.txt), which is why
+// y7t_tracker_step_deepsort (two call sites, its tests green at this size since round 2) keeps the inlined form.
+Y7T_NOINL void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) { y7t_assoc_inl(ex, s, na, nb, thresh); }
 
 // gather tlbr of listed pool tracks
 Y7T_FN void y7t_gather_track_tlbr(const Y7TExec& ex, const Y7TTrk& s, const int* list, int n) {
