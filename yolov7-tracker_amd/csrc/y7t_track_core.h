@@ -503,7 +503,7 @@ static inline double y7t_row_at(double v, int) { return v; }
 // round trip: 368 of the ByteTrack step's 2217 kcycles, profiles/r03_tracker_phases.txt)
 template <class ColFn, class RowFn, class Body>
 Y7T_FN void y7t_pairs(const Y7TExec& ex, int na, int nb, ColFn colctx, RowFn rowctx, Body body) {
-#if Y7T_DEVICE && !defined(Y7T_PAIRS_PLAIN)
+#if Y7T_DEVICE
     if (ex.nt >= 64) {
         const int nw = ex.nt >> 6, wave = ex.tid >> 6, lane = ex.tid & 63;
         for (int jb = 0; jb < nb; jb += 64) {

@@ -567,7 +567,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_gather_track_tlbr(ex, s, s.rem, n_t0);
     y7t_gather_det_tlbr(ex, s, s.left, n_to);
     y7t_sync(ex);
-    y7t_assoc_inl(ex, s, n_t0, n_to, 0.5);
+    y7t_assoc(ex, s, n_t0, n_to, 0.5);
     y7t_apply_matches(ex, s, s.rem, n_t0, s.left, dets, 0, na, nr);
     y7t_ds_append_features(ex, s, f, s.rem, n_t0, s.left, det_feats);
     Y7T_PROF(h, 5);
@@ -588,7 +588,7 @@ Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fb
     y7t_gather_track_tlbr(ex, s, s.unconf, n_unc);
     y7t_gather_det_tlbr(ex, s, s.dlo, n_d1);
     y7t_sync(ex);
-    y7t_assoc_inl(ex, s, n_unc, n_d1, 0.9);
+    y7t_assoc(ex, s, n_unc, n_d1, 0.9);
     y7t_apply_matches(ex, s, s.unconf, n_unc, s.dlo, dets, 2, na, nr);
     y7t_ds_append_features(ex, s, f, s.unconf, n_unc, s.dlo, det_feats);
     Y7T_PROF(h, 6);

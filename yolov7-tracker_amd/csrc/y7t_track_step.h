@@ -422,9 +422,6 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     // column, as the lane's scan), one read of the scanned row's candidate list, which the lanes hand to the owners of those columns through the scalar
     // registers, and the relaxation in registers; control flow is uniform over the wave.  Same arithmetic in the same order as solve_by_lane, so the same prices
     // and the same assignment.  The host build (one thread) runs the same text with 64-element arrays (Y7T_WV_*). ----
-#ifndef Y7T_SERIAL_TIE
-#define Y7T_SERIAL_TIE 0
-#endif
 #ifndef Y7T_COOP_DIAG
 #define Y7T_COOP_DIAG 1      // wave 0's share of step 4 in the header's prof[] (scripts/time_tracker.py)
 #endif
@@ -433,9 +430,6 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
 #if Y7T_DEVICE
         const int wv_lane = tid & 63;
         coop = nt >= 64 && na <= 4096;
-#ifdef Y7T_NO_COOP
-        coop = false;
-#endif
 #else
         coop = na <= 4096;
 #endif
@@ -520,7 +514,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                         Y7T_WV_EACH(l) { const int k = l - ne; if (k >= 0 && k < n) { Y7T_WV(er, l) = r; Y7T_WV(ev, l) = ccost[(size_t)i * MC + k]; } }
                         ne += n;
                     }
-                    if (ne <= 64 && !Y7T_SERIAL_TIE) {
+                    if (ne <= 64) {
                         bool dup = false;
                         for (int e = 0; e + 1 < ne && !dup; ++e) {
                             const double c = Y7T_WV_AT_D(ev, e);
@@ -676,7 +670,7 @@ Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, 
 // dtlbr[0..nb)  ->  xrow[na] (det index or -1), ycol[nb] (track index or -1).
 // The LAP work arrays and, when it fits, the cost matrix are placed in the workgroup's fast
 // scratch (LDS on the device); otherwise they stay in the state blob (HBM/L2).
-Y7T_FN void y7t_assoc_inl(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
+Y7T_FN void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) {
     if (na == 0 || nb == 0) {  // empty cost matrix: everything unmatched (matching.py:31-32)
         for (int i = ex.tid; i < na; i += ex.nt) s.xrow[i] = -1;
         for (int j = ex.tid; j < nb; j += ex.nt) s.ycol[j] = -1;
@@ -710,11 +704,6 @@ Y7T_FN void y7t_assoc_inl(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, do
     y7t_sync(ex);
 }
 
-// y7t_tracker_step calls the association three times; three inlined copies of the dense + sparse solvers took that function's code to 234 KB, and the build that got
-// there mis-executed the BoT-SORT step (round 5, scripts/debug_botsort.py: -O1, and every smaller variant of the same text, ran right) -- so ONE copy, called.  A call
-// costs the caller ~10 % everywhere (what lives across it goes through scratch: measured on the DeepSORT step, profiles/r05_tracker_association.txt), which is why
-// y7t_tracker_step_deepsort (two call sites, its tests green at this size since round 2) keeps the inlined form.
-Y7T_NOINL void y7t_assoc(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh) { y7t_assoc_inl(ex, s, na, nb, thresh); }
 
 // gather tlbr of listed pool tracks
 Y7T_FN void y7t_gather_track_tlbr(const Y7TExec& ex, const Y7TTrk& s, const int* list, int n) {
@@ -989,59 +978,63 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
         n_lo = y7t_compact(ex, n, [&](int j) { const float c = dets[6 * (size_t)j + 4]; return !(c >= det_t) && c > low_t; }, s.dlo, 0);
     }
     int na, nr;
-    // ---- first association: pool vs high-score detections ----
-    y7t_gather_track_tlbr(ex, s, s.pool, n_pool);
-    y7t_gather_det_tlbr(ex, s, s.dhi, n_hi);
-    y7t_sync(ex);
-    Y7T_PROF(h, 3);
-    y7t_assoc(ex, s, n_pool, n_hi, cfg.tracker == Y7T_SORT ? cfg.iou_thresh : 0.9);
-    Y7T_PROF(h, 4);
-    y7t_apply_matches(ex, s, s.pool, n_pool, s.dhi, dets, cfg.tracker == Y7T_SORT ? 1 : 0, na, nr);
-    Y7T_PROF(h, 5);
-    // unmatched detections, in detection order: left = [D_high[i] for i in u_dets]
-    int n_left = y7t_compact(ex, n_hi, [&](int j) { return s.ycol[j] < 0; }, s.tmpa, 0);
-    for (int k = ex.tid; k < n_left; k += ex.nt) s.left[k] = s.dhi[s.tmpa[k]];
-    y7t_sync(ex);
-    if (cfg.tracker == Y7T_SORT) {
-        // unmatched Tracked pool tracks -> Lost
-        const int nl_new = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && s.state[s.pool[i]] == Y7T_TRACKED; }, s.tmpa, 0);
-        for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.pool[s.tmpa[k]]; s.lostn[k] = sl; }
+    // ---- the three associations (bytetrack.py:104-160 / botsort.py:388-460 / basetrack.py SORT) as ONE loop: gather, assign, apply are the same text for each, and
+    // one inlined copy of the solvers keeps this function's code at ~100 KB (three copies took it to 234 KB, a size at which one build mis-executed the BoT-SORT step,
+    // and a called copy costs the caller ~10 % everywhere: profiles/r05_tracker_association.txt) ----
+    //   0: pool vs high-score detections     1: remaining pool tracks vs low-score detections (not SORT)     2: unconfirmed tracks vs leftover high detections
+    int n_left = 0;
+    const bool is_sort = cfg.tracker == Y7T_SORT;
+#if Y7T_DEVICE
+#pragma clang loop unroll(disable)
+#endif
+    for (int ph = 0; ph < 3; ++ph) {
+        const int* la; const int* ld;
+        int nA, nD, mode;
+        double th;
+        if (ph == 0) { la = s.pool; nA = n_pool; ld = s.dhi; nD = n_hi; th = is_sort ? cfg.iou_thresh : 0.9; mode = is_sort ? 1 : 0; }
+        else if (ph == 1) {
+            if (is_sort) {
+                // unmatched Tracked pool tracks -> Lost
+                const int nl_new = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && s.state[s.pool[i]] == Y7T_TRACKED; }, s.tmpa, 0);
+                for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.pool[s.tmpa[k]]; s.lostn[k] = sl; }
+                y7t_sync(ex);
+                for (int k = ex.tid; k < nl_new; k += ex.nt) s.state[s.lostn[k]] = Y7T_LOST;
+                if (ex.tid == 0) h->n_lostn_last = nl_new;
+                y7t_sync(ex);
+                continue;
+            }
+            // ByteTrack keeps only the still-Tracked leftovers (bytetrack.py:131); BoT-SORT takes every unmatched pool track (botsort.py:411)
+            const bool only_tracked = cfg.tracker != Y7T_BOTSORT;
+            const int n_rem = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && (!only_tracked || s.state[s.pool[i]] == Y7T_TRACKED); }, s.tmpa, 0);
+            for (int k = ex.tid; k < n_rem; k += ex.nt) s.rem[k] = s.pool[s.tmpa[k]];
+            y7t_sync(ex);
+            la = s.rem; nA = n_rem; ld = s.dlo; nD = n_lo; th = 0.5; mode = 0;
+        } else { la = s.unconf; nA = n_unc; ld = s.left; nD = n_left; th = is_sort ? cfg.iou_thresh + 0.1 : 0.7; mode = is_sort ? 1 : 2; }
+        y7t_gather_track_tlbr(ex, s, la, nA);
+        y7t_gather_det_tlbr(ex, s, ld, nD);
         y7t_sync(ex);
-        for (int k = ex.tid; k < nl_new; k += ex.nt) s.state[s.lostn[k]] = Y7T_LOST;
-        if (ex.tid == 0) h->n_lostn_last = nl_new;
-        y7t_sync(ex);
-    } else {
-        // ---- second association: remaining Tracked pool tracks vs low-score detections ----
-        // ByteTrack keeps only the still-Tracked leftovers (bytetrack.py:131); BoT-SORT takes every unmatched pool track (botsort.py:411)
-        const bool only_tracked = cfg.tracker != Y7T_BOTSORT;
-        const int n_rem = y7t_compact(ex, n_pool, [&](int i) { return s.xrow[i] < 0 && (!only_tracked || s.state[s.pool[i]] == Y7T_TRACKED); }, s.tmpa, 0);
-        for (int k = ex.tid; k < n_rem; k += ex.nt) s.rem[k] = s.pool[s.tmpa[k]];
-        y7t_sync(ex);
-        y7t_gather_track_tlbr(ex, s, s.rem, n_rem);
-        y7t_gather_det_tlbr(ex, s, s.dlo, n_lo);
-        y7t_sync(ex);
-        Y7T_PROF(h, 6);
-        y7t_assoc(ex, s, n_rem, n_lo, 0.5);
-        Y7T_PROF(h, 7);
-        y7t_apply_matches(ex, s, s.rem, n_rem, s.dlo, dets, 0, na, nr);
-        const int nl_new = y7t_compact(ex, n_rem, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
-        for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.rem[s.tmpa[k]]; s.lostn[k] = sl; s.state[sl] = Y7T_LOST; }
-        if (ex.tid == 0) h->n_lostn_last = nl_new;
-        y7t_sync(ex);
-    }
-    // ---- unconfirmed tracks vs leftover high detections ----
-    y7t_gather_track_tlbr(ex, s, s.unconf, n_unc);
-    y7t_gather_det_tlbr(ex, s, s.left, n_left);
-    y7t_sync(ex);
-    Y7T_PROF(h, 8);
-    y7t_assoc(ex, s, n_unc, n_left, cfg.tracker == Y7T_SORT ? cfg.iou_thresh + 0.1 : 0.7);
-    Y7T_PROF(h, 9);
-    y7t_apply_matches(ex, s, s.unconf, n_unc, s.left, dets, cfg.tracker == Y7T_SORT ? 1 : 2, na, nr);
-    {
-        const int n_rm = y7t_compact(ex, n_unc, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
-        for (int k = ex.tid; k < n_rm; k += ex.nt) { const int sl = s.unconf[s.tmpa[k]]; s.removedl[k] = sl; s.state[sl] = Y7T_REMOVED; }
-        if (ex.tid == 0) h->n_removed_last = n_rm;
-        y7t_sync(ex);
+        const int stamp = ph == 0 ? 3 : ph == 1 ? 6 : 8;
+        Y7T_PROF(h, stamp);
+        y7t_assoc(ex, s, nA, nD, th);
+        Y7T_PROF(h, stamp + 1);
+        y7t_apply_matches(ex, s, la, nA, ld, dets, mode, na, nr);
+        if (ph == 0) {
+            Y7T_PROF(h, 5);
+            // unmatched detections, in detection order: left = [D_high[i] for i in u_dets]
+            n_left = y7t_compact(ex, n_hi, [&](int j) { return s.ycol[j] < 0; }, s.tmpa, 0);
+            for (int k = ex.tid; k < n_left; k += ex.nt) s.left[k] = s.dhi[s.tmpa[k]];
+            y7t_sync(ex);
+        } else if (ph == 1) {
+            const int nl_new = y7t_compact(ex, nA, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
+            for (int k = ex.tid; k < nl_new; k += ex.nt) { const int sl = s.rem[s.tmpa[k]]; s.lostn[k] = sl; s.state[sl] = Y7T_LOST; }
+            if (ex.tid == 0) h->n_lostn_last = nl_new;
+            y7t_sync(ex);
+        } else {
+            const int n_rm = y7t_compact(ex, n_unc, [&](int i) { return s.xrow[i] < 0; }, s.tmpa, 0);
+            for (int k = ex.tid; k < n_rm; k += ex.nt) { const int sl = s.unconf[s.tmpa[k]]; s.removedl[k] = sl; s.state[sl] = Y7T_REMOVED; }
+            if (ex.tid == 0) h->n_removed_last = n_rm;
+            y7t_sync(ex);
+        }
     }
     // ---- new tracks from still-unmatched detections above the gate (activate; ids in order) ----
     {
