@@ -44,7 +44,7 @@ int hs_tracker_step(void* blob, const float* dets, int n, double* out_rows, int 
     y7t_tracker_step(hs_ex(), blob, dets, n, out_rows, out_cap, &cnt, warp);
     return cnt;
 }
-void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(H, mean, cov); }
+void hs_kf_gmc(const double* H, double* mean, double* cov) { y7t_kf_gmc(y7t_warp_load(H), mean, cov); }
 
 int hs_arena_begin(void* blob) {
     const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;

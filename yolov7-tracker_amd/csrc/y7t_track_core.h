@@ -418,28 +418,36 @@ Y7T_FN void y7t_kf_update(int kind, double* mean, double* cov, const double* z, 
 
 // botsort.py:250-269 multi_gmc: camera-motion compensation of one track.  H = [R | t] (2x3, row-major);
 // R8 = kron(I4, R):  mean <- R8 mean, mean[:2] += t,  cov <- R8 cov R8^T
-Y7T_FN void y7t_kf_gmc(const double* H, double* mean, double* cov) {
-    const double r00 = H[0], r01 = H[1], tx = H[2], r10 = H[3], r11 = H[4], ty = H[5];
+struct Y7TWarp { double r00, r01, tx, r10, r11, ty; };
+Y7T_FN Y7TWarp y7t_warp_load(const double* H) { return Y7TWarp{H[0], H[1], H[2], H[3], H[4], H[5]}; }
+Y7T_FN void y7t_kf_gmc(const Y7TWarp& H, double* mean, double* cov) {
+    const double r00 = H.r00, r01 = H.r01, tx = H.tx, r10 = H.r10, r11 = H.r11, ty = H.ty;
     for (int b = 0; b < 4; ++b) {
         const double a = mean[2 * b], c = mean[2 * b + 1];
         mean[2 * b] = r00 * a + r01 * c;
         mean[2 * b + 1] = r10 * a + r11 * c;
     }
     mean[0] = mean[0] + tx; mean[1] = mean[1] + ty;
-    // left multiply: rows (2b, 2b+1) <- R rows
-    for (int b = 0; b < 4; ++b)
+    // cov <- R8 cov R8^T, a row pair (2b, 2b+1) at a time: the left multiply mixes the two rows, the right multiply then mixes column pairs INSIDE each row -- the same
+    // products and sums on the same values as two in-place passes over the whole matrix, with every element loaded and stored once (round 5: the in-place passes, 128
+    // dependent loads and stores through a generic pointer per track, were the part of the BoT-SORT step that three builds of the frame step mis-executed on the device --
+    // right without camera-motion warps, right on the host; scripts/debug_botsort.py, profiles/r05_tracker_association.txt)
+    for (int b = 0; b < 4; ++b) {
+        double u[8], w[8];
         for (int c = 0; c < 8; ++c) {
             const double a = cov[(2 * b) * 8 + c], d = cov[(2 * b + 1) * 8 + c];
-            cov[(2 * b) * 8 + c] = r00 * a + r01 * d;
-            cov[(2 * b + 1) * 8 + c] = r10 * a + r11 * d;
+            u[c] = r00 * a + r01 * d;
+            w[c] = r10 * a + r11 * d;
         }
-    // right multiply by R8^T: columns (2b, 2b+1)
-    for (int r = 0; r < 8; ++r)
-        for (int b = 0; b < 4; ++b) {
-            const double a = cov[r * 8 + 2 * b], d = cov[r * 8 + 2 * b + 1];
-            cov[r * 8 + 2 * b] = a * r00 + d * r01;
-            cov[r * 8 + 2 * b + 1] = a * r10 + d * r11;
+        for (int q = 0; q < 4; ++q) {
+            const double a = u[2 * q], d = u[2 * q + 1];
+            cov[(2 * b) * 8 + 2 * q] = a * r00 + d * r01;
+            cov[(2 * b) * 8 + 2 * q + 1] = a * r10 + d * r11;
+            const double e = w[2 * q], f = w[2 * q + 1];
+            cov[(2 * b + 1) * 8 + 2 * q] = e * r00 + f * r01;
+            cov[(2 * b + 1) * 8 + 2 * q + 1] = e * r10 + f * r11;
         }
+    }
 }
 
 // kalman_filter.py:365-411: squared Mahalanobis distance of one measurement (metric='maha')

@@ -945,8 +945,10 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     Y7T_PROF(h, 1);
     y7t_multi_predict(ex, s, s.pool, n_pool);
     if (cfg.tracker == Y7T_BOTSORT && gmc_warp && n >= 0) {   // botsort.py:383-386: multi_gmc(strack_pool), multi_gmc(unconfirmed)
-        double Hm[6];
-        for (int c = 0; c < 6; ++c) Hm[c] = gmc_warp[c];
+        // six scalars, not a stack array: this was the one array of the BoT-SORT-only path, and builds of this function in which AMDGPUPromoteAlloca turned the
+        // small arrays into vectors mis-executed exactly that path (round 5: no tracks / an aperture violation, right with
+        // -mllvm -amdgpu-promote-alloca-to-vector-limit=1, whatever the code size; scripts/debug_botsort.py, profiles/r05_tracker_association.txt)
+        const Y7TWarp Hm = y7t_warp_load(gmc_warp);
         for (int i = ex.tid; i < n_pool + n_unc; i += ex.nt) {
             const int sl = i < n_pool ? s.pool[i] : s.unconf[i - n_pool];
             y7t_kf_gmc(Hm, s.mean + 8 * (size_t)sl, s.cov + 64 * (size_t)sl);

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_kf_gmc(double* mean, double* cov, const 
     for (int c = 0; c < 6; ++c) H[c] = warp[c];
     for (int c = 0; c < 8; ++c) m[c] = mean[8 * (size_t)k + c];
     for (int c = 0; c < 64; ++c) P[c] = cov[64 * (size_t)k + c];
-    y7t_kf_gmc(H, m, P);
+    y7t_kf_gmc(y7t_warp_load(H), m, P);
     for (int c = 0; c < 8; ++c) mean[8 * (size_t)k + c] = m[c];
     for (int c = 0; c < 64; ++c) cov[64 * (size_t)k + c] = P[c];
 }
