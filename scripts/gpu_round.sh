@@ -12,7 +12,7 @@
 #             r5_batch      frames per step (BATCHES="32 24 40 ...")             r5_latency   latency mode with a chunked H2D copy (measured, removed: needs --upload_pieces)
 #             r5_b40        the pinned parity tests at 40 frames                 r5_branches  the Detect branches on four streams (measured, removed) + panel rules at 40 frames
 #             r5_panel240   128-row panels for the 20 x 20 512-channel layers    r5_ws128s2   the stride-2 form of ws128: parity, bench A/B/A/B, per-op tables
-#             suite_all     the whole `-m gpu` suite without -x                  r5_coop      sparse association: scalar-register row contexts + register-resident wave solve of the large components (parity, step phases, cfg3 A/B)
+#             suite_all     the whole `-m gpu` suite without -x                  r5_coop / r5_coop2 / r5_tracker_ab   sparse association: scalar-register row contexts, register-resident wave solve of the components, threshold variants; the tracker against a previous build (profiles/r05_tracker_association.txt)
 #   tests           the GPU tests added this round (training graph, candidate parity, cfg3 full size, ADVICE cases, self-launched ranks)
 #   tests4          round 4's parity tests: all four Detect levels live, full 8a bar, explained kept-set differences
 #   exp_p8          the 256 x 256 x 64 ping-pong 1x1 kernel: parity, per-layer A/B against igemm<128,128,32,2>, bench lines with / without (Y7T_CONV_P8=0); exp_p8abl: its timing ablations (Y7T_CONV_ABLATE)
@@ -309,6 +309,20 @@ r5_coop2)
     n=${v%%:*}; l=$LIBD/${v#*:}; [ -f $l ] || continue
     Y7T_LIB=$l timeout 300 python bench.py $X --workload cfg3 > $O/bench_cfg3_$n.json 2> $O/bench_cfg3_$n.err; benchsum cfg3_$n
   done
+  ;;
+
+r5_tracker_ab)
+  say "r5_tracker_ab: the tracker of this commit against a previous build of the library (lib/liby7t_prev.so: copy one there first): device parity, the frame step alone (ByteTrack 80 / 500 objects, DeepSORT), cfg3 / cfg2 / cfg4 alternating"
+  timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_fullsize_gpu.py tests/test_reid_gpu.py tests/test_cli_gpu.py tests/test_multirank_gpu.py -q -m gpu -k "not w6_1280 and not conv_layer and not nms_output" > $O/t_tracker.log 2>&1; echo "rc=$?" >> $O/t_tracker.log; tailsum $O/t_tracker.log 4
+  for l in liby7t_prev.so liby7t.so; do [ -f $LIBD/$l ] || continue; echo "-- $l" | tee -a $O/summary.txt
+    Y7T_LIB=$LIBD/$l timeout 200 python scripts/time_tracker.py 2>&1 | grep "threads=1024\|total\|sparse assoc\|large comp" | cut -c1-300 | tee -a $O/summary.txt
+    Y7T_LIB=$LIBD/$l timeout 200 python scripts/time_deepsort.py 2>&1 | grep -A1 dim512 | cut -c1-200 | tee -a $O/summary.txt
+  done
+  X="--steps 10 --warmup 3 --no_cpu_baseline --no_latency_mode --no_other_workloads"
+  for w in cfg3 cfg2 cfg4; do for v in prev:liby7t_prev.so new:liby7t.so prevb:liby7t_prev.so newb:liby7t.so; do
+    n=${w}_${v%%:*}; l=$LIBD/${v#*:}; [ -f $l ] || continue
+    Y7T_LIB=$l timeout 300 python bench.py $X --workload $w > $O/bench_$n.json 2> $O/bench_$n.err; benchsum $n
+  done; done
   ;;
 
 suite)

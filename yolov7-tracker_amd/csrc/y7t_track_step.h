@@ -945,9 +945,6 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     Y7T_PROF(h, 1);
     y7t_multi_predict(ex, s, s.pool, n_pool);
     if (cfg.tracker == Y7T_BOTSORT && gmc_warp && n >= 0) {   // botsort.py:383-386: multi_gmc(strack_pool), multi_gmc(unconfirmed)
-        // six scalars, not a stack array: this was the one array of the BoT-SORT-only path, and builds of this function in which AMDGPUPromoteAlloca turned the
-        // small arrays into vectors mis-executed exactly that path (round 5: no tracks / an aperture violation, right with
-        // -mllvm -amdgpu-promote-alloca-to-vector-limit=1, whatever the code size; scripts/debug_botsort.py, profiles/r05_tracker_association.txt)
         const Y7TWarp Hm = y7t_warp_load(gmc_warp);
         for (int i = ex.tid; i < n_pool + n_unc; i += ex.nt) {
             const int sl = i < n_pool ? s.pool[i] : s.unconf[i - n_pool];
@@ -981,8 +978,8 @@ Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets
     }
     int na, nr;
     // ---- the three associations (bytetrack.py:104-160 / botsort.py:388-460 / basetrack.py SORT) as ONE loop: gather, assign, apply are the same text for each, and
-    // one inlined copy of the solvers keeps this function's code at ~100 KB (three copies took it to 234 KB, a size at which one build mis-executed the BoT-SORT step,
-    // and a called copy costs the caller ~10 % everywhere: profiles/r05_tracker_association.txt) ----
+    // one inlined copy of the solvers and of the Kalman updates keeps this function's code at 100 KB (three copies: 234 KB; a CALLED copy costs the caller ~10 % in
+    // every phase -- what lives across a call goes through scratch: profiles/r05_tracker_association.txt section 3) ----
     //   0: pool vs high-score detections     1: remaining pool tracks vs low-score detections (not SORT)     2: unconfirmed tracks vs leftover high detections
     int n_left = 0;
     const bool is_sort = cfg.tracker == Y7T_SORT;
