@@ -349,6 +349,24 @@ bench_variants)
   for n in default chaotic cu8 cu16 cu8nms default2; do [ -s $O/bench_$n.err ] && { echo "-- stderr of $n"; grep -v amdgpu.ids $O/bench_$n.err | tail -4; }; done | tee -a $O/summary.txt
   ;;
 
+stats)
+  say "stats: rocprofv3 --kernel-trace --stats of the bench command (kernel stats only; the per-op table and the PMC passes are the profile step)"
+  P=$O/prof; mkdir -p $P
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ks
+    timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_latency_mode --no_other_workloads > $P/bench_under_rocprof.log 2>&1
+    f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/bench_kernel_stats.csv )
+  head -14 $P/bench_kernel_stats.csv 2>/dev/null | cut -c1-160 | tee -a $O/summary.txt
+  grep -o '"value": [0-9.]*, "unit": "frames/s"\|"launch_list_ms": [0-9.]*' $P/bench_under_rocprof.log | head -2 | tee -a $O/summary.txt
+  ;;
+
+closing_small)
+  say "closing_small: the chained parity tests, smoke(), the driver's bench line"
+  timeout 600 python -m pytest tests/test_chained_gpu.py -q -m gpu > $O/t_chained.log 2>&1; echo "rc=$?" >> $O/t_chained.log; tailsum $O/t_chained.log 3
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log; tailsum $O/smoke.log 2
+  timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err; echo "rc=$?" | tee -a $O/summary.txt
+  cp $O/bench_line.json $O/bench_default.json; benchsum default
+  ;;
+
 profile)
   say "profile: rocprofv3 of the bench command + the launch list alone (kernel stats, per-op table, HBM traffic, MFMA busy)"
   P=$O/prof; mkdir -p $P
