@@ -284,3 +284,20 @@ def test_hostsim_iou_pretest_never_rejects_an_overlapping_pair():
             n_apart += 1
             assert want[0] == 1.0, (b, q, want[0])
     assert n_apart > len(cases) // 10
+
+
+@pytest.mark.parametrize("kind,extra", [("bytetrack", 0), ("bytetrack", 60), ("botsort", 0)])
+def test_hostsim_component_larger_than_a_wave(kind, extra):
+    """a 160-track lattice (tests/util.lattice_scene): the association's candidate graph is one connected component of 160 rows (and, with `extra`, of more than 64
+    columns beside few enough rows in the later associations) -- more than the 64 slots of the wave solve, which must hand it to the lane's walk (step 4a declines,
+    y7t_assoc_sparse_try) and still return the oracle's assignment"""
+    from oracle import tracker_np
+    dets = util.lattice_scene(extra_cols=extra)
+    fmt = "botsort" if kind == "botsort" else "default"
+    before, lit = hs.lib().hs_next_stat(3), hs.lib().hs_literal_calls()
+    want = tracker_np.run(kind, dets, kalman_format=fmt)
+    got = hs.run(kind, dets, kalman_format=fmt)
+    util.assert_same_tracks(got, want, "lattice %s +%d" % (kind, extra))
+    assert len(want[-1]) >= 150
+    assert hs.lib().hs_next_stat(3) > before, "the scene was meant to produce a component the wave solve declines"
+    assert hs.lib().hs_literal_calls() == lit, "the scene was meant to be free of ties (a tie sends the whole problem to the serial literal solver: tens of seconds on the device at this size)"

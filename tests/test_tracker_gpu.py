@@ -631,3 +631,4 @@ def test_frames_in_one_launch_equal_frame_by_frame(kind, fmt):
         got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
     util.assert_same_tracks(got, want, "%s, %d frames in launches of %d" % (kind, n_frames, chunk))
     assert t.frame_id == n_frames
+

@@ -171,3 +171,25 @@ def training_checkpoint_state_dict(spec, plan, seed=0, bn_bias_mean=0.0, calib_i
 
 
 from oracle.detector_torch import candidates as oracle_candidates, compare_candidate_sets  # noqa: E402,F401  (test-side names)
+
+
+def lattice_scene(n_frames=8, nx=40, ny=4, seed=0, extra_cols=0):
+    """a scene whose association graph is ONE connected component far larger than a wave: nx x ny boxes of 100 x 100 px on a 30 x 60 px lattice (every box overlaps
+    its neighbours two to the left / right and one up / down at IoU >= 0.1, i.e. ~11 candidate edges per track -- under the sparse solver's 24 per row), jittered by
+    +-3 px (sub-pixel) per frame so that no two costs tie.  extra_cols: that many additional detections per frame half a pitch off the lattice (unmatched high-score boxes: more
+    columns than rows).  -> list of (n, 6) float32 [x1, y1, x2, y2, conf, cls]"""
+    rng = np.random.default_rng(seed)
+    gx, gy = np.meshgrid(np.arange(nx) * 30.0, np.arange(ny) * 60.0)
+    base = np.stack([gx.ravel(), gy.ravel()], 1) + 20.0
+    out = []
+    for f in range(n_frames):
+        xy = base + rng.uniform(-3, 3, base.shape) + f * 1.5
+        if extra_cols and f > 0:
+            more = base[rng.choice(len(base), extra_cols, replace=False)] + np.array([15.0, 30.0]) + rng.uniform(-3, 3, (extra_cols, 2)) + f * 1.5
+            xy = np.concatenate([xy, more])
+        wh = 100.0 + rng.uniform(-2, 2, (len(xy), 2))
+        d = np.zeros((len(xy), 6), np.float32)
+        d[:, 0:2] = xy; d[:, 2:4] = xy + wh          # (sub-pixel coordinates: integer boxes of one size tie in IoU, and a tie sends the whole problem to the serial literal solver)
+        d[:, 4] = rng.uniform(0.6, 0.95, len(xy)); d[:, 5] = 0
+        out.append(d[rng.permutation(len(d))])
+    return out
