@@ -226,7 +226,8 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #endif
 
 // colctx(j) / rowctx(i): whatever of column j / row i the cost needs (y7t_pairs); cost(rl, r, cj) -> double, the row's values taken with y7t_row_at(rl.., r)
-// Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
+// Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 3: a connected component with more
+// than 64 rows or columns (the wave solve has 64 slots of each) -> dense path as well, without a second try on the longer stride; 2: two candidate edges of one
 // connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
 // caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
 // The row stride MC of the candidate lists is chosen at run time (y7t_assoc_sparse_fn below) so that the lists fit in the fast scratch next to the work
@@ -274,12 +275,12 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [5] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a, "a row is left for steps 3 and 4"
+    int* flag = nextcol + nb;                                 // [6] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a, "a row is left for steps 3 and 4", "a component has more rows or columns than a wave has lanes"
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; csz[i] = 0; }
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; flag[4] = 0; }
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; flag[4] = 0; flag[5] = 0; }
     y7t_sync(ex);
     // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers) ----
     y7t_pairs(ex, na, nb, colctx, rowctx, [&](int i, int j, const auto& rl, int r, const auto& cj) {
@@ -495,11 +496,13 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 for (int j = 0; j < nb; ++j) if (collab[j] == lead) { if (ncl < 64) myj[ncl] = j; ++ncl; }
                 for (int i = lead; i < na; ++i) if (rowlab[i] == lead && x[i] == -1) { if (nrw < 64) rid[nrw] = i; ++nrw; }
 #endif
-                if (ncl > 64 || nrw > 64) {                     // more rows or columns than lanes: the lane's walk, by this wave's first lane
-#if Y7T_DEVICE
-                    if (wv_lane == 0)
-#endif
-                    { Y7T_NEXT_STAT(3); tie_watch(lead); solve_by_lane(lead); }
+                if (ncl > 64 || nrw > 64) {                     // more rows or columns than lanes: not a problem for this solver -- the caller takes the dense one
+                    // (NOT "this wave's first lane walks it, then `continue`": lanes that skip a long divergent region in front of a loop's back edge are not
+                    // brought together with the one inside it before the next trip -- they went round without lane 0, read ticket 0 out of their own zeroed
+                    // register and took the same component again, for ever; found in the round's last GPU seconds on tests/util.lattice_scene and read in the
+                    // instruction stream afterwards)
+                    Y7T_NEXT_STAT(3);
+                    flag[5] = 1;
                     continue;
                 }
                 Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
@@ -624,7 +627,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
         if (thresh == 0.9 && tid == 0) { s.h->prof[22] = clock64(); if (!coop) s.h->prof[23] = 0; }      // diagnostics: when wave 0 was done with its components
 #endif
     }
-    // ---- 4b. one lane per remaining component (single rows, and what has more than 64 rows) ----
+    // ---- 4b. one lane per remaining component (single rows; every component when the workgroup is less than a wave or the matrix has more than 4096 rows) ----
     for (int lead = tid; lead < na; lead += nt) {
         if (x[lead] != -1 || rowlab[lead] != lead) continue;
         if (coop && csz[lead]) continue;
@@ -635,6 +638,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     } else Y7T_SPROF(4);
     Y7T_SPROF(5);
     if (flag[2]) return 2;
+    if (flag[5]) return 3;
     for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
     for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
     y7t_sync(ex);
