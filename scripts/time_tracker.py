@@ -45,6 +45,6 @@ for nobj in (80, 500):
     print("n_obj=%d  total %.0f kcycles: " % (nobj, acc.sum() / 1e3) + ", ".join("%s %.0f" % (n, v / 1e3) for n, v in zip(names, acc)))
     sp = np.diff(p[16:22]) / 1e3
     print("   sparse association #1 (kcycles, last frame): cost pass %.0f, candidate sort %.0f, forced decisions %.0f, components %.0f, per-component solves %.0f" % tuple(sp))
-    if p[23]:      # wave 0's share of the per-component solves: its large components on the register-resident path (y7t_assoc_sparse_try step 4a)
-        print("      large components %d on %d waves; wave 0 done after %.0f kcycles; its last component %d rows x %d columns, %d search steps"
-              % (p[23] & 255, (p[23] >> 8) & 255, (p[22] - p[20]) / 1e3, (p[23] >> 16) & 255, (p[23] >> 24) & 255, p[29]))
+    if p[23]:      # wave 0's share of the per-component solves (y7t_assoc_sparse_try step 4a; prof[23] = components | rows << 16 | columns << 24 | ticket << 32 of wave 0's last one)
+        print("      components of two or more rows: %d, each on a wave; wave 0 done after %.0f kcycles; its last component (ticket %d): %d rows x %d columns, %d search steps"
+              % (p[23] & 0xffff, (p[22] - p[20]) / 1e3, (p[23] >> 32) & 0xffff, (p[23] >> 16) & 255, (p[23] >> 24) & 255, p[29]))
