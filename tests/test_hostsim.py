@@ -300,4 +300,4 @@ def test_hostsim_component_larger_than_a_wave(kind, extra):
     util.assert_same_tracks(got, want, "lattice %s +%d" % (kind, extra))
     assert len(want[-1]) >= 150
     assert hs.lib().hs_next_stat(3) > before, "the scene was meant to produce a component the wave solve declines"
-    assert hs.lib().hs_literal_calls() == lit, "the scene was meant to be free of ties (a tie sends the whole problem to the serial literal solver: tens of seconds on the device at this size)"
+    assert hs.lib().hs_literal_calls() == lit, "the scene was meant to be free of ties (a tie sends the whole problem to the literal solver, whose order-dependent parts run on one thread)"

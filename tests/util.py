@@ -189,7 +189,7 @@ def lattice_scene(n_frames=8, nx=40, ny=4, seed=0, extra_cols=0):
             xy = np.concatenate([xy, more])
         wh = 100.0 + rng.uniform(-2, 2, (len(xy), 2))
         d = np.zeros((len(xy), 6), np.float32)
-        d[:, 0:2] = xy; d[:, 2:4] = xy + wh          # (sub-pixel coordinates: integer boxes of one size tie in IoU, and a tie sends the whole problem to the serial literal solver)
+        d[:, 0:2] = xy; d[:, 2:4] = xy + wh          # (sub-pixel coordinates: integer boxes of one size tie in IoU, and a tie sends the whole problem to the literal solver)
         d[:, 4] = rng.uniform(0.6, 0.95, len(xy)); d[:, 5] = 0
         out.append(d[rng.permutation(len(d))])
     return out
