@@ -301,3 +301,24 @@ def test_hostsim_component_larger_than_a_wave(kind, extra):
     assert len(want[-1]) >= 150
     assert hs.lib().hs_next_stat(3) > before, "the scene was meant to produce a component the wave solve declines"
     assert hs.lib().hs_literal_calls() == lit, "the scene was meant to be free of ties (a tie sends the whole problem to the literal solver, whose order-dependent parts run on one thread)"
+
+
+@pytest.mark.parametrize("n_obj,size", [(150, 480), (250, 640), (400, 640), (400, 480)])
+@pytest.mark.parametrize("kind", ["bytetrack", "botsort"])
+def test_hostsim_crowded_scenes_through_every_solver_path(kind, n_obj, size):
+    """crowds far denser than BASELINE's configs (150 .. 400 objects on a 480 / 640 px frame, 10 % misses and clutter, camera warps for BoT-SORT): the candidate graph of
+    the association then has components of every size -- hundreds go through the wave solve, and from ~250 objects on some have more than 64 rows or columns, which
+    sends the whole problem to the dense solver (return code 3 of y7t_assoc_sparse_try).  Every id and box of every frame equal to the oracle's."""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    fmt = "botsort" if kind == "botsort" else "default"
+    dets = synth.make_detections(14, n_obj, size, seq_idx=300 + n_obj, miss=0.1, fp=0.1)
+    warps = synth.make_warps(14, seq_idx=3) if kind == "botsort" else None
+    before = [hs.lib().hs_next_stat(k) for k in range(4)]
+    want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
+    got = hs.run(kind, dets, kalman_format=fmt, warps=warps, cap_t=2048, cap_d=1024)
+    util.assert_same_tracks(got, want, "%s, %d objects on %d px" % (kind, n_obj, size))
+    on_wave, declined = hs.lib().hs_next_stat(2) - before[2], hs.lib().hs_next_stat(3) - before[3]
+    assert on_wave > 0
+    if n_obj >= 400:
+        assert declined > 0, "the densest scenes were meant to produce components larger than a wave"
