@@ -2,6 +2,7 @@
 Oracle: the golden vectors recorded from the reference's own sources (tests/golden) and the CPU restatements in
 oracle/.  Bars: integer outputs (assignments, track ids) bit-exact; IoU cost bit-exact (same IEEE operations);
 Kalman within the stated float64 tolerances."""
+import os
 import types
 
 import numpy as np
@@ -631,4 +632,17 @@ def test_frames_in_one_launch_equal_frame_by_frame(kind, fmt):
         got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
     util.assert_same_tracks(got, want, "%s, %d frames in launches of %d" % (kind, n_frames, chunk))
     assert t.frame_id == n_frames
+
+
+@pytest.mark.skipif(os.environ.get("Y7T_TEST_LATTICE") != "1", reason="not yet run on a device (DESIGN.md section 7): first under a timeout with scripts/debug_lattice.py, then Y7T_TEST_LATTICE=1")
+@pytest.mark.parametrize("kind,extra", [("bytetrack", 0), ("bytetrack", 60), ("botsort", 0)])
+def test_component_larger_than_a_wave_on_the_device(kind, extra):
+    """the 160-track lattice of tests/util.lattice_scene: one connected component of 160 rows -- more than the 64 slots of the wave solve, so the candidate-list solver
+    returns 3 and the dense solver takes the frame; ids and boxes of every frame equal to the oracle's (the host build of the same text: tests/test_hostsim.py)"""
+    from oracle import tracker_np
+    dets = util.lattice_scene(extra_cols=extra)
+    fmt = "botsort" if kind == "botsort" else "default"
+    want = tracker_np.run(kind, dets, kalman_format=fmt)
+    got, _ = run_device_tracker(kind, fmt, dets, max_tracks=1024, max_dets=1024)
+    util.assert_same_tracks(got, want, "lattice %s +%d" % (kind, extra))
 
