@@ -1,0 +1,88 @@
+#!/bin/bash
+# Round 6's GPU script (same conventions as scripts/gpu_round.sh: every step under its own `timeout`, output under gpurun_out/$TAG/, verdicts appended to
+# gpurun_out/$TAG/summary.txt; a failing step does not stop the others).
+#   gpurun --timeout 1500 -- 'TAG=r6a bash scripts/r6.sh lattice crowd_tests time_large suite bench'
+# Steps:
+#   lattice      scripts/debug_lattice.py frame by frame under a hard timeout (a component of 160 rows: the path that had never run on a device), three scenes
+#   crowd_tests  the un-skipped lattice test + the natural crowds (250 / 400 objects on 640 / 480 px) on the device
+#   time_large   scripts/time_large_components.py: step time of frames on each fallback (large component on a wave, literal re-solve at 160 / 320 / 500 rows + columns)
+#   suite        the whole `-m gpu` suite as the driver runs it
+#   bench        the driver's bench line -> bench_line.json
+#   perlayer     per-op table of the launch list (scripts/per_layer_table.sh)
+#   profile      rocprofv3 kernel stats of the bench command + PMC passes (gpu_round.sh profile)
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${TAG:-r6}
+O=$ROOT/gpurun_out/$TAG; mkdir -p $O
+cd $ROOT
+say() { echo "=== $*" | tee -a $O/summary.txt; }
+tailsum() { tail -${2:-2} $1 | tee -a $O/summary.txt; }
+benchline() {  # file -> one summary line
+python3 - "$1" <<'PY' | tee -a $O/summary.txt
+import json, sys
+try:
+    l = json.loads([x for x in open(sys.argv[1]).read().splitlines() if x.startswith("{")][-1])
+    ph = l.get("phases_ms_per_step", {})
+    lm = l.get("latency_mode") or {}
+    ow = l.get("other_workloads") or {}
+    print("%7.0f fps  step %.2f ms  list %.2f ms  frac %.4f  chain %.2f ms | host-fed %s coupled %s | latency u8 %s f32 %s | cfg3 %s cfg4 %s"
+          % (l["value"], l["ms_per_step"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"], ph.get("tracker_chain", float("nan")),
+             (l.get("fps_incl_h2d") or {}).get("value"), (l.get("coupled") or {}).get("fps"),
+             (lm.get("u8_hwc_host") or {}).get("fps"), (lm.get("f32_chw_host") or {}).get("fps"),
+             {k: (ow.get("cfg3") or {}).get(k) for k in ("fps", "tracker_chain_ms", "launch_list_ms")}, {k: (ow.get("cfg4") or {}).get(k) for k in ("fps", "tracker_chain_ms", "launch_list_ms")}))
+except Exception as e:
+    print("no bench line in %s: %r" % (sys.argv[1], e))
+PY
+}
+
+for step in "$@"; do case $step in
+
+lattice)
+  say "lattice: the 160-row component on the device, frame by frame, hard timeout 150 s per scene"
+  for sc in "bytetrack 0" "bytetrack 60" "botsort 0"; do
+    n=$(echo $sc | tr ' ' '_')
+    timeout 150 python scripts/debug_lattice.py $sc > $O/lattice_$n.log 2>&1; echo "rc=$?" >> $O/lattice_$n.log
+    echo "--- $sc" | tee -a $O/summary.txt; grep -c "oracle's: True" $O/lattice_$n.log | sed 's/^/frames equal to the oracle: /' | tee -a $O/summary.txt; tailsum $O/lattice_$n.log 2
+  done
+  ;;
+
+crowd_tests)
+  say "crowd_tests: lattice + natural crowds on the device (tests/test_tracker_gpu.py)"
+  timeout 600 python -m pytest -q -m gpu tests/test_tracker_gpu.py -k "larger_than_a_wave or crowded" > $O/t_crowd.log 2>&1; echo "rc=$?" >> $O/t_crowd.log; tailsum $O/t_crowd.log 4
+  ;;
+
+time_large)
+  say "time_large: step time of the frames on each fallback"
+  timeout 600 python scripts/time_large_components.py > $O/time_large.log 2>&1; echo "rc=$?" >> $O/time_large.log
+  cat $O/time_large.log | cut -c1-260 | tee -a $O/summary.txt
+  ;;
+
+suite)
+  say "suite: python -m pytest tests -x -q -m gpu"
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/suite.log 2>&1; echo "rc=$?" >> $O/suite.log; tailsum $O/suite.log 4
+  ;;
+
+bench)
+  say "bench: python bench.py --steps 20 --warmup 5"
+  timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "rc=$?" | tee -a $O/summary.txt
+  benchline $O/bench_line.json
+  ;;
+
+bench_quick)
+  say "bench_quick: the headline only (no latency mode / cpu baseline / other workloads)"
+  timeout 600 python bench.py --steps 20 --warmup 5 --no_latency_mode --no_cpu_baseline --no_other_workloads > $O/bench_quick.json 2> $O/bench_quick.err; echo "rc=$?" | tee -a $O/summary.txt
+  benchline $O/bench_quick.json
+  ;;
+
+perlayer)
+  say "perlayer: per-op table of the launch list at 40 frames"
+  NAME=${NAME:-$TAG} OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/per_layer.log 2>&1; echo "rc=$?" | tee -a $O/summary.txt
+  tail -3 $O/per_layer_${NAME:-$TAG}.txt | cut -c1-300 | tee -a $O/summary.txt
+  ;;
+
+profile)
+  TAG=$TAG bash scripts/gpu_round.sh profile
+  ;;
+
+*) say "unknown step $step";;
+esac; done

@@ -243,7 +243,7 @@ def test_hostsim_cfg3_full_size_botsort_equals_oracle():
     got = hs.run("botsort", dets, warps=warps, kalman_format="botsort", cap_t=2048, cap_d=1024)
     util.assert_same_tracks(got, want, "cfg3 full size")
     # the large connected components of the crowded frames went through the register-resident wave solve (y7t_assoc_sparse_try step 4a, the host build runs its
-    # text with 64-element arrays), none had to be declined for more than 64 columns
+    # text with 64-element arrays), none had more than 64 rows or columns
     on_wave, declined = hs.lib().hs_next_stat(2) - before[2], hs.lib().hs_next_stat(3) - before[3]
     assert on_wave > 300 and declined == 0, (on_wave, declined)
 
@@ -289,8 +289,8 @@ def test_hostsim_iou_pretest_never_rejects_an_overlapping_pair():
 @pytest.mark.parametrize("kind,extra", [("bytetrack", 0), ("bytetrack", 60), ("botsort", 0)])
 def test_hostsim_component_larger_than_a_wave(kind, extra):
     """a 160-track lattice (tests/util.lattice_scene): the association's candidate graph is one connected component of 160 rows (and, with `extra`, of more than 64
-    columns beside few enough rows in the later associations) -- more than the 64 slots of the wave solve, which must hand it to the lane's walk (step 4a declines,
-    y7t_assoc_sparse_try) and still return the oracle's assignment"""
+    columns beside few enough rows in the later associations) -- more than the 64 slots of the register-resident wave solve: the wave then solves it with its state in
+    the work arrays (y7t_assoc_sparse_try step 4a, the `ncl > 64 || nrw > 64` branch, counted by statistic 3) and still returns the oracle's assignment"""
     from oracle import tracker_np
     dets = util.lattice_scene(extra_cols=extra)
     fmt = "botsort" if kind == "botsort" else "default"
@@ -299,7 +299,7 @@ def test_hostsim_component_larger_than_a_wave(kind, extra):
     got = hs.run(kind, dets, kalman_format=fmt)
     util.assert_same_tracks(got, want, "lattice %s +%d" % (kind, extra))
     assert len(want[-1]) >= 150
-    assert hs.lib().hs_next_stat(3) > before, "the scene was meant to produce a component the wave solve declines"
+    assert hs.lib().hs_next_stat(3) > before, "the scene was meant to produce a component larger than a wave"
     assert hs.lib().hs_literal_calls() == lit, "the scene was meant to be free of ties (a tie sends the whole problem to the literal solver, whose order-dependent parts run on one thread)"
 
 
@@ -307,8 +307,8 @@ def test_hostsim_component_larger_than_a_wave(kind, extra):
 @pytest.mark.parametrize("kind", ["bytetrack", "botsort"])
 def test_hostsim_crowded_scenes_through_every_solver_path(kind, n_obj, size):
     """crowds far denser than BASELINE's configs (150 .. 400 objects on a 480 / 640 px frame, 10 % misses and clutter, camera warps for BoT-SORT): the candidate graph of
-    the association then has components of every size -- hundreds go through the wave solve, and from ~250 objects on some have more than 64 rows or columns, which
-    sends the whole problem to the dense solver (return code 3 of y7t_assoc_sparse_try).  Every id and box of every frame equal to the oracle's."""
+    the association then has components of every size -- hundreds go through the register-resident wave solve, and from ~250 objects on some have more than 64 rows or
+    columns and are solved by a wave with its state in the work arrays (statistic 3 of y7t_assoc_sparse_try).  Every id and box of every frame equal to the oracle's."""
     from oracle import tracker_np
     from yolov7_tracker_amd import synth
     fmt = "botsort" if kind == "botsort" else "default"

@@ -634,11 +634,12 @@ def test_frames_in_one_launch_equal_frame_by_frame(kind, fmt):
     assert t.frame_id == n_frames
 
 
-@pytest.mark.skipif(os.environ.get("Y7T_TEST_LATTICE") != "1", reason="not yet run on a device (DESIGN.md section 7): first under a timeout with scripts/debug_lattice.py, then Y7T_TEST_LATTICE=1")
 @pytest.mark.parametrize("kind,extra", [("bytetrack", 0), ("bytetrack", 60), ("botsort", 0)])
 def test_component_larger_than_a_wave_on_the_device(kind, extra):
-    """the 160-track lattice of tests/util.lattice_scene: one connected component of 160 rows -- more than the 64 slots of the wave solve, so the candidate-list solver
-    returns 3 and the dense solver takes the frame; ids and boxes of every frame equal to the oracle's (the host build of the same text: tests/test_hostsim.py)"""
+    """the 160-track lattice of tests/util.lattice_scene: one connected component of 160 rows -- more than the 64 slots of the register-resident wave solve, so the
+    same wave solves it with its state in the work arrays (y7t_assoc_sparse_try step 4a, the `ncl > 64 || nrw > 64` branch); ids and boxes of every frame equal to
+    the oracle's (the host build of the same text: tests/test_hostsim.py).  Round 5's form of this path had never run on a device; round 6 ran it first under a
+    timeout (scripts/debug_lattice.py, profiles/r06_large_components.txt)"""
     from oracle import tracker_np
     dets = util.lattice_scene(extra_cols=extra)
     fmt = "botsort" if kind == "botsort" else "default"
@@ -646,3 +647,35 @@ def test_component_larger_than_a_wave_on_the_device(kind, extra):
     got, _ = run_device_tracker(kind, fmt, dets, max_tracks=1024, max_dets=1024)
     util.assert_same_tracks(got, want, "lattice %s +%d" % (kind, extra))
 
+
+@pytest.mark.parametrize("n_obj,size", [(250, 640), (400, 640), (400, 480)])
+@pytest.mark.parametrize("kind", ["bytetrack", "botsort"])
+def test_crowded_scenes_on_the_device(kind, n_obj, size):
+    """NATURAL components larger than a wave: crowds of 250 / 400 objects on a 640 / 480 px frame, 10 % misses and clutter, camera warps for
+    BoT-SORT -- the scenes of tests/test_hostsim.py::test_hostsim_crowded_scenes_through_every_solver_path, where the host build counts 1-2 of 42 associations (250
+    objects) to a third of them (400) with a component of more than 64 rows or columns.  Every id and box of every frame equal to the oracle's, per frame launches
+    and the frames of the scene in ONE launch (k_tracker_step_frames: the index lists in the LDS arena)"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    fmt = "botsort" if kind == "botsort" else "default"
+    dets = synth.make_detections(14, n_obj, size, seq_idx=300 + n_obj, miss=0.1, fp=0.1)
+    warps = synth.make_warps(14, seq_idx=3) if kind == "botsort" else None
+    want = tracker_np.run(kind, dets, kalman_format=fmt, warps=warps)
+    got, _ = run_device_tracker(kind, fmt, dets, warps=warps, max_tracks=2048, max_dets=1024)
+    util.assert_same_tracks(got, want, "%s, %d objects on %d px" % (kind, n_obj, size))
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.botsort import BoTSORT
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    t = (BoTSORT if kind == "botsort" else ByteTrack)(make_opts(kalman_format=fmt, max_tracks=2048, max_dets=1024), frame_rate=30)
+    dd = [torch.from_numpy(d).cuda() for d in dets]
+    ww = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64).reshape(6)).cuda() for w in warps] if warps is not None else None
+    outs = torch.zeros((len(dets), t.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    t._launch_frames(t.frames_table(dd, [outs[f] for f in range(len(dets))], ww))
+    torch.cuda.synchronize()
+    h = outs.cpu().numpy()
+    got = []
+    for f in range(len(dets)):
+        c = int(h[f, t.cap_t].view(np.int32)[0])
+        got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
+    util.assert_same_tracks(got, want, "%s, %d objects on %d px, one launch" % (kind, n_obj, size))

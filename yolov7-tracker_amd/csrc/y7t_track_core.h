@@ -144,6 +144,11 @@ __device__ __forceinline__ int y7t_popc64(unsigned long long m) { return __popcl
 #define Y7T_WV_SET(a, s, val) do { if (wv_lane == (s)) (a)[0] = (val); } while (0)
 #define Y7T_WV_MIN_D(out, l, expr) do { const int l = wv_lane; (void)l; (out) = y7t_wave_min_d(expr); } while (0)
 #define Y7T_WV_BALLOT(out, l, pred) do { const int l = wv_lane; (void)l; (out) = __ballot(pred); } while (0)
+// a wave striding over n items that live in MEMORY (the work arrays of a component with more rows or columns than a wave has lanes): lane l takes l, l + 64, ...;
+// Y7T_WV_FENCE between two phases that hand values from lane to lane through that memory -- a wave's own LDS / vector-memory operations complete in issue order,
+// so the fence only has to hold the compiler to the program order
+#define Y7T_WV_STRIDE(p, n) for (int p = wv_lane; p < (n); p += 64)
+#define Y7T_WV_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 static inline int y7t_ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 static inline int y7t_popc64(unsigned long long m) { return __builtin_popcountll(m); }
@@ -156,6 +161,8 @@ static inline int y7t_popc64(unsigned long long m) { return __builtin_popcountll
 #define Y7T_WV_SET(a, s, val) do { (a)[s] = (val); } while (0)
 #define Y7T_WV_MIN_D(out, l, expr) do { (out) = HUGE_VAL; for (int l = 0; l < 64; ++l) { const double e_ = (expr); if (e_ < (out)) (out) = e_; } } while (0)
 #define Y7T_WV_BALLOT(out, l, pred) do { (out) = 0ull; for (int l = 0; l < 64; ++l) if (pred) (out) |= 1ull << l; } while (0)
+#define Y7T_WV_STRIDE(p, n) for (int p = 0; p < (n); ++p)
+#define Y7T_WV_FENCE() do { } while (0)
 #endif
 
 // all-reduce: lexicographic minimum of (v, i) over the workgroup; every thread gets the result

@@ -226,8 +226,7 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #endif
 
 // colctx(j) / rowctx(i): whatever of column j / row i the cost needs (y7t_pairs); cost(rl, r, cj) -> double, the row's values taken with y7t_row_at(rl.., r)
-// Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 3: a connected component with more
-// than 64 rows or columns (the wave solve has 64 slots of each) -> dense path as well, without a second try on the longer stride; 2: two candidate edges of one
+// Returns 1: solved (s.xrow / s.ycol written); 0: not applicable (candidate overflow, a pair exactly at the limit) -> dense path; 2: two candidate edges of one
 // connected component cost EXACTLY the same (costs are float32 distances or IoUs of integer boxes: it happens) -> the optimum may not be unique and the
 // caller solves the dense problem with lapjv.cpp run literally (y7t_lap_solve_literal).
 // The row stride MC of the candidate lists is chosen at run time (y7t_assoc_sparse_fn below) so that the lists fit in the fast scratch next to the work
@@ -269,13 +268,13 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     int* rowlab = rowcnt + na;                                // [na]
     int* x = rowlab + na;                                     // [na]
     int* csz = x + na;                                        // [na] 1: the component led by row i has two or more rows (set in step 3)
-    int* colcnt = csz + na;                                   // [nb]; behind the forced decisions: the leaders of the large components
+    int* colcnt = csz + na;                                   // [nb]; behind the forced decisions (step 2): the column lists of the components larger than a wave (step 4a)
     int* collab = colcnt + nb;                                // [nb]
     int* y = collab + nb;                                     // [nb]
     int* pred = y + nb;                                       // [nb]
     int* st = pred + nb;                                      // [nb] 0 untouched, 1 touched (in the frontier), 2 scanned
     int* nextcol = st + nb;                                   // [nb] linked list of the touched columns
-    int* flag = nextcol + nb;                                 // [6] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a, "a row is left for steps 3 and 4", "a component has more rows or columns than a wave has lanes"
+    int* flag = nextcol + nb;                                 // [6] overflow / at-limit pair, changed, duplicate cost inside a component, the next component of step 4a, "a row is left for steps 3 and 4", how much of colcnt[] the column lists of the components larger than a wave have taken
     double* ccost = (double*)lbase;                           // [na][MAXC] candidate costs
     int* ccol = (int*)(ccost + (size_t)na * MC);        // [na][MAXC] candidate columns
     for (int i = tid; i < na; i += nt) { rowcnt[i] = 0; x[i] = -1; rowlab[i] = i; csz[i] = 0; }
@@ -444,14 +443,14 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
             lm_lo[0] = 0; lm_hi[0] = 0;
             for (int c = 0; c < nch; ++c) {
                 const int i = c * 64 + wv_lane;
-                const unsigned long long b = __ballot(i < na && x[i] == -1 && rowlab[i] == i && csz[i] != 0);
+                const unsigned long long b = __ballot(i < na && rowlab[i] == i && csz[i] != 0);      // (NOT x[i] == -1: a faster wave is already writing the x of the components it has solved, and every wave must see the same leader list behind the shared ticket counter; rowlab / csz are final since step 3's last barrier, and a leader with csz set is unsettled by construction)
                 if (wv_lane == c) { lm_lo[0] = (int)(unsigned)b; lm_hi[0] = (int)(unsigned)(b >> 32); }
                 nbig += __popcll(b);
             }
 #else
             for (int c = 0; c < 64; ++c) { lm_lo[c] = 0; lm_hi[c] = 0; }
             for (int i = 0; i < na; ++i)
-                if (x[i] == -1 && rowlab[i] == i && csz[i] != 0) { if ((i & 63) < 32) lm_lo[i >> 6] |= (int)(1u << (i & 31)); else lm_hi[i >> 6] |= (int)(1u << (i & 31)); ++nbig; }
+                if (rowlab[i] == i && csz[i] != 0) { if ((i & 63) < 32) lm_lo[i >> 6] |= (int)(1u << (i & 31)); else lm_hi[i >> 6] |= (int)(1u << (i & 31)); ++nbig; }
 #endif
             for (;;) {                                          // the waves take the components off a counter: the largest one (10-20 rows) costs as much as ten small ones
                 int bi;
@@ -496,13 +495,114 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 for (int j = 0; j < nb; ++j) if (collab[j] == lead) { if (ncl < 64) myj[ncl] = j; ++ncl; }
                 for (int i = lead; i < na; ++i) if (rowlab[i] == lead && x[i] == -1) { if (nrw < 64) rid[nrw] = i; ++nrw; }
 #endif
-                if (ncl > 64 || nrw > 64) {                     // more rows or columns than lanes: not a problem for this solver -- the caller takes the dense one
-                    // (NOT "this wave's first lane walks it, then `continue`": lanes that skip a long divergent region in front of a loop's back edge are not
-                    // brought together with the one inside it before the next trip -- they went round without lane 0, read ticket 0 out of their own zeroed
-                    // register and took the same component again, for ever; found in the round's last GPU seconds on tests/util.lattice_scene and read in the
-                    // instruction stream afterwards)
+                if (ncl > 64 || nrw > 64) {
+                    // ---- more rows or columns than a wave has lanes (crowds: 250+ objects on a 640-px frame).  The same wave solves the component with its state in
+                    // the work arrays instead of in registers -- v / dd / st / pred / x / y by real row and column index, exactly solve_by_lane's variables and
+                    // arithmetic -- and the lanes share what that walk does serially: the frontier minimum (a stride over the component's columns, DPP minimum of
+                    // the distance, then of the column index among the lanes at that distance: ties to the lowest column), the scanned row's candidates a lane
+                    // each (they are distinct columns: no two lanes touch one word).  Any size; control flow uniform over the wave.  (History: "lane 0 walks it,
+                    // then `continue`" never returned on the device -- lanes that skip a divergent region in front of a back edge went round without lane 0 --;
+                    // round 5 closed with "return 3, the caller solves the whole problem densely", which ran such frames at round 2's speed.) ----
                     Y7T_NEXT_STAT(3);
-                    flag[5] = 1;
+                    int off;                                    // the component's columns, ascending, in a range of colcnt[] (free since step 2; the components' column sets are disjoint)
+#if Y7T_DEVICE
+                    off = 0;
+                    if (wv_lane == 0) off = Y7T_FETCH_ADD(flag + 5, ncl);
+                    off = __builtin_amdgcn_readfirstlane(off);
+                    int* cl = colcnt + off;
+                    for (int base = 0, n0 = 0; base < nb; base += 64) {
+                        const int j = base + wv_lane;
+                        const bool mine = j < nb && collab[j] == lead;
+                        const unsigned long long b = __ballot(mine);
+                        if (mine) cl[n0 + __popcll(b & ((1ull << wv_lane) - 1ull))] = j;
+                        n0 += __popcll(b);
+                    }
+#else
+                    off = flag[5]; flag[5] += ncl;
+                    int* cl = colcnt + off;
+                    for (int j = 0, n0 = 0; j < nb; ++j) if (collab[j] == lead) cl[n0++] = j;
+#endif
+                    Y7T_WV_FENCE();
+                    for (int rbase = lead; rbase < na; rbase += 64) {      // the component's rows in ascending order, 64 at a time (all unsettled: a search settles exactly its start row)
+                        unsigned long long rm;
+#if Y7T_DEVICE
+                        rm = __ballot(rbase + wv_lane < na && rowlab[rbase + wv_lane] == lead);
+#else
+                        rm = 0ull;
+                        for (int l = 0; l < 64 && rbase + l < na; ++l) if (rowlab[rbase + l] == lead) rm |= 1ull << l;
+#endif
+                        while (rm) {
+                            const int start = rbase + y7t_ctz64(rm);
+                            rm &= rm - 1ull;
+                            double d_null = 0.0; int pred_null = start;
+                            {
+                                const int n = rowcnt[start];
+                                Y7T_WV_STRIDE(k, n) {
+                                    const int j = ccol[(size_t)start * MC + k];
+                                    dd[j] = ccost[(size_t)start * MC + k] - thresh - v[j]; pred[j] = start; st[j] = 1;
+                                }
+                            }
+                            Y7T_WV_FENCE();
+                            int final_j = -2; double mind = 0.0;
+                            for (int guard = 0; ; ++guard) {
+                                if (guard > ncl + 2) { flag[2] = 1; final_j = nb; pred_null = start; break; }      // (a search scans every column at most once; never seen -- the caller would re-solve the problem densely)
+                                double mv = HUGE_VAL; int mj = 0x7fffffff;
+                                Y7T_WV_STRIDE(p, ncl) {                     // (a lane's columns ascend and the compare is strict: its lowest column among equals)
+                                    const int j = cl[p];
+                                    if (st[j] == 1) { const double t = dd[j]; if (t < mv) { mv = t; mj = j; } }
+                                }
+#if Y7T_DEVICE
+                                {
+                                    const double m = y7t_wave_min_d(mv);
+                                    mj = y7t_wave_min_i(mv == m ? mj : 0x7fffffff);
+                                    mv = m;
+                                }
+#endif
+                                if (mj == 0x7fffffff || d_null < mv) { mv = d_null; mj = nb; }      // the null column (index nb) loses a tie against a real one
+                                mind = mv;
+                                if (mj == nb) { final_j = nb; break; }
+                                const int i = y[mj];
+                                if (i < 0) { final_j = mj; break; }
+                                const int n = rowcnt[i];
+                                double cij = 0.0;
+#if Y7T_DEVICE
+                                int kc = -1; double kv = 0.0;
+                                if (wv_lane < n) { kc = ccol[(size_t)i * MC + wv_lane]; kv = ccost[(size_t)i * MC + wv_lane]; }
+                                {
+                                    const unsigned long long bm = __ballot(kc == mj);      // (the matched edge is a candidate of its row)
+                                    cij = y7t_readlane_d(kv, bm ? y7t_ctz64(bm) : 0);
+                                }
+#else
+                                for (int k = 0; k < n; ++k) if (ccol[(size_t)i * MC + k] == mj) cij = ccost[(size_t)i * MC + k];
+#endif
+                                const double hh = cij - thresh - v[mj] - mind;
+                                Y7T_WV_STRIDE(k, n) {
+                                    const int j = ccol[(size_t)i * MC + k];
+                                    if (j == mj) st[j] = 2;
+                                    else if (st[j] != 2) {
+                                        const double cred = ccost[(size_t)i * MC + k] - thresh - v[j] - hh;
+                                        if (st[j] == 0) { dd[j] = cred; pred[j] = i; st[j] = 1; }
+                                        else if (cred < dd[j]) { dd[j] = cred; pred[j] = i; }
+                                    }
+                                }
+                                if (-hh < d_null) { d_null = -hh; pred_null = i; }
+                                Y7T_WV_FENCE();
+                            }
+                            Y7T_WV_STRIDE(p, ncl) { const int j = cl[p]; if (st[j] == 2) v[j] += dd[j] - mind; st[j] = 0; }
+                            Y7T_WV_FENCE();
+                            {   // augment: every lane walks the same path and writes the same words
+                                int i = -1, j = final_j;
+                                for (int guard = 0; i != start && guard < na + 2; ++guard) {
+                                    i = (j == nb) ? pred_null : pred[j];
+                                    if (j != nb) y[j] = i;
+                                    const int t = j;
+                                    j = x[i];
+                                    x[i] = t;
+                                }
+                            }
+                            Y7T_WV_FENCE();
+                        }
+                    }
                     continue;
                 }
                 Y7T_NEXT_STAT(2);                               // (host build: components solved on this path)
@@ -609,9 +709,9 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                     }
                 }
                 Y7T_WV_EACH(l) {                               // slots back to indices
+                    const int r = Y7T_WV(yr, l);
+                    const int ri = Y7T_WV_GATHER_I(rid, r < 0 ? 0 : r);      // (the gather is a ds_bpermute: outside the branch, or a lane without a column -- more rows than columns -- is an inactive source and hands out 0)
                     if (Y7T_WV(myj, l) >= 0) {
-                        const int r = Y7T_WV(yr, l);
-                        const int ri = Y7T_WV_GATHER_I(rid, r < 0 ? 0 : r);
                         y[Y7T_WV(myj, l)] = r < 0 ? -1 : ri;
                         v[Y7T_WV(myj, l)] = Y7T_WV(vj, l);
                     }
@@ -638,7 +738,6 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     } else Y7T_SPROF(4);
     Y7T_SPROF(5);
     if (flag[2]) return 2;
-    if (flag[5]) return 3;
     for (int i = tid; i < na; i += nt) s.xrow[i] = (x[i] >= nb || x[i] < 0) ? -1 : x[i];
     for (int j = tid; j < nb; j += nt) s.ycol[j] = y[j];
     y7t_sync(ex);
