@@ -201,7 +201,10 @@ int y7t_det_create(const y7t_op* ops_host, int n_ops, const int64_t* buf_offsets
 int y7t_det_destroy(y7t_det* det);
 
 /* models/yolo.py:345 `x = m(x)` for every layer: runs the whole launch list for B images whose input layout
- * (y7t_input_layout) is already in arena buffer 0.  Asynchronous on `stream`. */
+ * (y7t_input_layout) is already in arena buffer 0.  Asynchronous on `stream`.
+ * One forward of a detector at a time: the arena, the split-K slabs and the tile counters of the persistent kernels belong to the plan.  Launches on one
+ * stream are ordered; a forward (or a piece of one, y7t_det_forward_ops / _fused) issued on another stream than the previous one waits for it on the device.
+ * While `stream` is being captured into a hipGraph nothing is recorded or waited for: whoever replays the graph orders the replays. */
 int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
 /* the same launch list in pieces: ops [first, last) of the plan (last < 0: to the end), so that a caller can record an event between
  * two parts of Model.forward_once (models/yolo.py:321-351) -- bench.py starts the previous batch's decode+NMS on another stream once

@@ -93,6 +93,26 @@ def test_self_launched_two_ranks_share_the_gpu_through_the_same_code_path():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     g = d["config"]["result_gather"]
     assert d["n_gpus"] == 2 and g["id_base_per_rank"][0] == 0 and g["id_base_per_rank"][1] > 0
+    assert g["backend_reported"] == "gloo" and g["ranks_seen"] == 2
+    _assert_gather_equals_single_process(g)      # (the same check the RCCL test makes where two devices are visible)
+
+
+def _assert_gather_equals_single_process(g):
+    """the two sequences of `_bench_plain(2)` tracked by ONE process with the reference's global BaseTrack._count: rows, id bases and the digest of the global ids"""
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    BaseTrack._count = 0
+    rows, bases, digest, distinct = [], [], [], []
+    for seq in range(2):
+        bases.append(BaseTrack._count)
+        t = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5, max_tracks=512, max_dets=512))
+        ids = [[tr.track_id for tr in t.update(det, None)] for det in synth.make_detections(3 * 4, 40, 640, seq_idx=seq, bounce=True)]
+        rows.append(sum(len(f) for f in ids))
+        digest.append(sum((fi + 1) * i for fi, f in enumerate(ids) for i in f))
+        distinct.append(len({i for f in ids for i in f}))
+    assert g["rows_per_rank"] == rows and g["id_base_per_rank"] == bases and g["payload_bytes_per_rank"] == 28 * max(rows), (g, rows, bases)
+    assert g["frame_x_id_digest_per_rank"] == digest and g["distinct_ids_per_rank"] == distinct, "the gathered ids are not those of the single-process run"
 
 
 def test_rccl_two_ranks_on_two_devices():
@@ -109,10 +129,5 @@ def test_rccl_two_ranks_on_two_devices():
     from yolov7_tracker_amd import synth
     from yolov7_tracker_amd.tracker.basetrack import BaseTrack
     from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
-    BaseTrack._count = 0
-    rows, bases = [], []
-    for seq in range(2):
-        bases.append(BaseTrack._count)
-        t = ByteTrack(types.SimpleNamespace(conf_thresh=0.2, track_buffer=30, kalman_format="default", img_size=1280, iou_thresh=0.5, max_tracks=512, max_dets=512))
-        rows.append(sum(len(t.update(det, None)) for det in synth.make_detections(3 * 4, 40, 640, seq_idx=seq, bounce=True)))
-    assert g["rows_per_rank"] == rows and g["id_base_per_rank"] == bases and g["payload_bytes_per_rank"] == 28 * max(rows)
+    assert g["backend_reported"] == "nccl" and g["ranks_seen"] == 2
+    _assert_gather_equals_single_process(g)

@@ -65,6 +65,9 @@ def _build_one(force, verbose, ablate):
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, ablate), srcs))
     objs = [o for o, _ in res]
+    if verbose:      # which translation units hipcc actually compiled in this call (the build check must show that it built)
+        done = [s_ for s_, (_, c) in zip(srcs, res) if c]
+        print("%s: compiled %d of %d translation units for %s%s" % (os.path.basename(lib), len(done), len(srcs), ARCH, (": " + " ".join(done)) if done else " (objects newer than every source and header)"))
     if force or any(c for _, c in res) or not os.path.exists(lib):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

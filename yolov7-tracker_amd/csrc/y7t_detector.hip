@@ -18,6 +18,12 @@ struct y7t_det {
     float* splitk_ws = nullptr;
     int* tile_ctr = nullptr;      // Y7T_TILE_CTR_INTS ints per op, zero between launches: the tile counters of the persistent conv kernels (Y7TConvArgs::tile_ctr)
     int max_batch;
+    // single flight: the tile counters, the split-K slabs and the arena belong to ONE forward at a time.  Launches on one stream are ordered anyway; a
+    // forward issued on ANOTHER stream than the previous one first waits for the event the previous one left (not while a stream is being captured into a hipGraph:
+    // a captured list is replayed by its owner, who orders the replays).
+    hipEvent_t done_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
     // Detect levels (y7t_det_set_detect)
     int nl = 0, na = 0, no = 0;
     float stride[4] = {0, 0, 0, 0}, anchors[24] = {0};
@@ -58,6 +64,13 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
         y7t_set_error("y7t_det_create: cannot allocate the tile counters");
         return Y7T_E_HIP;
     }
+    // the memsets above ran on the legacy stream, which does not order against non-blocking streams: the counters are zero before any forward can start
+    if (hipDeviceSynchronize() != hipSuccess || hipEventCreateWithFlags(&d->done_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(d->zeros); (void)hipFree(d->splitk_ws); (void)hipFree(d->tile_ctr);
+        delete d;
+        y7t_set_error("y7t_det_create: cannot create the forward-done event");
+        return Y7T_E_HIP;
+    }
     *out = d;
     return 0;
 }
@@ -65,6 +78,7 @@ extern "C" int y7t_det_create(const y7t_op* ops, int n_ops, const int64_t* bufs,
 extern "C" int y7t_det_destroy(y7t_det* d) {
     if (!d) return 0;
     if (d->tile_ctr) (void)hipFree(d->tile_ctr);
+    if (d->done_ev) (void)hipEventDestroy(d->done_ev);
     if (d->zeros) (void)hipFree(d->zeros);
     if (d->splitk_ws) (void)hipFree(d->splitk_ws);
     delete d;
@@ -79,6 +93,13 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
     Y7T_ARG_CHECK(d && B > 0 && B <= d->max_batch);
     if (last < 0) last = (int)d->ops.size();
     Y7T_ARG_CHECK(first >= 0 && first <= last && last <= (int)d->ops.size());
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
+    if (!capturing && d->has_last && d->last_stream != s) Y7T_HIP_CHECK(hipStreamWaitEvent(s, d->done_ev, 0));      // single flight per detector
+    struct Done {      // every exit of this function (also a failed launch) leaves the event behind what has been enqueued
+        y7t_det* d; hipStream_t s; bool on;
+        ~Done() { if (on && hipEventRecord(d->done_ev, s) == hipSuccess) { d->last_stream = s; d->has_last = true; } }
+    } done{d, s, !capturing};
     for (int oi = first; oi < last; ++oi) {
         const y7t_op& op = d->ops[oi];
         const _Float16* in = (const _Float16*)(d->arena + d->bufs[op.in_buf]);

@@ -278,6 +278,65 @@ Y7T_FN int y7t_compact(const Y7TExec& ex, int n, F flag, int* out, int cnt0) {
 #endif
 }
 
+// exclusive prefix scans over the workgroup in thread order (thread t gets the reduction of the values of threads 0 .. t-1): minimum of doubles (HUGE_VAL for
+// thread 0), sum of ints (+ the total, uniform).  One thread (the host build): the identity / the value itself.
+Y7T_FN double y7t_block_excl_min_d(const Y7TExec& ex, double v) {
+#if Y7T_DEVICE
+    const int lane = ex.tid & 63, w = ex.tid >> 6, nw = (ex.nt + 63) >> 6;
+    double inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(inc, off); if (lane >= off) inc = fmin(inc, t); }
+    double exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = HUGE_VAL;
+    if (nw > 1) {
+        __syncthreads();
+        if (lane == 63) ex.rv[w] = inc;
+        __syncthreads();
+        for (int k = 0; k < w; ++k) exc = fmin(exc, ex.rv[k]);
+    }
+    return exc;
+#else
+    (void)ex; (void)v;
+    return HUGE_VAL;
+#endif
+}
+Y7T_FN int y7t_block_excl_sum_i(const Y7TExec& ex, int v, int& total) {
+#if Y7T_DEVICE
+    const int lane = ex.tid & 63, w = ex.tid >> 6, nw = (ex.nt + 63) >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    int exc = inc - v;
+    total = __shfl(inc, 63);
+    if (nw > 1) {
+        __syncthreads();
+        if (lane == 63) ex.ri[w] = inc;
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int k = 0; k < nw; ++k) { if (k < w) before += ex.ri[k]; all += ex.ri[k]; }
+        exc += before; total = all;
+    }
+    return exc;
+#else
+    (void)ex;
+    total = v;
+    return 0;
+#endif
+}
+// one int from thread 0 to every thread (two barriers on the device)
+Y7T_FN int y7t_bcast_i(const Y7TExec& ex, int v, int slot) {
+#if Y7T_DEVICE
+    if (ex.nt > 64) {
+        __syncthreads();
+        if (ex.tid == 0) ex.ri[slot] = v;
+        __syncthreads();
+        return ex.ri[slot];
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    (void)ex; (void)slot;
+    return v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kalman filters (8-d state; float64).  kind: 0 xyah ('default'), 2 xywh ('botsort'), 3 NSA
 // ('strongsort').  The 7-d 'naive' filter is not part of the ByteTrack/SORT hot path.
@@ -610,9 +669,11 @@ Y7T_FN void y7t_lap_bind(Y7TLap& L, void* ws, int n) {
 #define Y7T_LPROF(i) do { } while (0)
 #endif
 
-Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
+// lap's _ccrrt_dense (column reduction + reduction transfer) and its two _carr_dense passes (augmenting row reduction) with every scan a workgroup-wide reduction
+// whose ties go to the lowest index -- what the sequential strict-< scans do, so the state they leave (x, y, v, the free rows in fr[0 .. n_free) in lap's order) is
+// lap's own.  -> n_free.  Shared by y7t_lap_solve and y7t_lap_solve_literal.
+Y7T_FN int y7t_lap_reduce(const Y7TExec& ex, Y7TLap& L) {
     const int n = L.n, tid = ex.tid, nt = ex.nt;
-    if (n <= 0) return;
     Y7T_LPROF(0);
     // ---- column reduction (lap: _ccrrt_dense) ----
     for (int j = tid; j < n; j += nt) {
@@ -687,6 +748,13 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
     }
     Y7T_LPROF(3);
     if (L.prof && ex.tid == 0) L.prof[6] = n_free;
+    return n_free;
+}
+
+Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
+    const int n = L.n, tid = ex.tid, nt = ex.nt;
+    if (n <= 0) return;
+    const int n_free = y7t_lap_reduce(ex, L);
     // ---- augmentation: shortest augmenting paths (lap: _ca_dense / _find_path_dense) ----
     for (int f = 0; f < n_free; ++f) {
         const int start = L.fr[f];
@@ -766,9 +834,21 @@ Y7T_NOINL void y7t_lap_solve(const Y7TExec& ex, Y7TLap& L) {
 // ---------------------------------------------------------------------------------------------
 // lapjv.cpp LITERALLY (lap 0.4.0: _ccrrt_dense, _carr_dense x 2, _ca_dense with its `cols` permutation, find / scan order and "last free column of
 // the frontier" rule) on the implicit extended matrix.  Which optimum lapjv returns when there are several is a property of exactly these orders, so the
-// re-solve of a problem with ties runs them as written: the column minima in parallel, everything order-dependent by thread 0.  Rare (about one frame in
-// two thousand of the random-scene tests) and O(n^2) per free row at worst, so speed is not a concern here.
-// Work arrays as y7t_lap_solve (n = nr + nc each): cnt = `unique`, st = `cols`.
+// re-solve of a problem with ties runs them as written.  Rare (about one frame in two thousand of the random-scene tests).
+//
+// Round 6: the whole workgroup runs it.  Through round 5 everything order-dependent ran on thread 0, one dependent global load per matrix element: 9 ms at
+// 80 + 80 rows + columns, 35 ms at 160 + 160, 218 ms at 400 + 400 (profiles/r06_large_components.txt) -- a single tied pair in a crowded frame stalled the stream
+// for a fifth of a second.  Now:
+//   * the reduction phases are y7t_lap_reduce (workgroup-wide scans, ties to the lowest index = the sequential scans);
+//   * in the augmentation, what lapjv does PER COLUMN (d[j] = c - v, the relaxation cred < d[j]) is done by all threads, each on a contiguous run of positions
+//     of `cols`; what depends on the ORDER of the scan -- _find_dense's running minimum with its swaps, _scan_dense's swaps of the columns that reach the
+//     minimum and its stop at the first free one -- is reduced to the positions where something happens ("events": d <= the minimum of everything before it,
+//     found with an exclusive prefix minimum; cred == mind) and replayed by thread 0 in position order.  A swap writes position k and a position in front of it,
+//     so when the sequential scan reaches a position it still holds the column it held when the scan began: the events found on the unswapped `cols` are the
+//     sequential scan's events, and replaying them alone gives its permutation.  (The relaxations behind the position where _scan_dense stops are applied here and
+//     not there: they touch d / pred of columns that are neither READY nor on the path, which nothing reads before the next free row re-initialises them.)
+// One thread (the host build) runs the same text: its single run of positions is the whole scan.
+// Work arrays as y7t_lap_solve (n = nr + nc each): st = `cols`; cnt = the event list.
 // ---------------------------------------------------------------------------------------------
 #ifndef Y7T_COUNT_LITERAL
 #if Y7T_DEVICE
@@ -782,119 +862,102 @@ Y7T_NOINL void y7t_lap_solve_literal(const Y7TExec& ex, Y7TLap& L) {
     const int n = L.n, tid = ex.tid, nt = ex.nt;
     if (n <= 0) return;
     Y7T_COUNT_LITERAL();
-    for (int j = tid; j < n; j += nt) {              // v[j] = min_i c[i][j], y[j] = the first row that attains it
-        double best = Y7T_LARGE;
-        int bi = 0;
-        for (int i = 0; i < n; ++i) {
-            const double c = y7t_lap_cost(L, i, j);
-            if (c < best) { best = c; bi = i; }
-        }
-        L.v[j] = best; L.y[j] = bi; L.x[j] = -1; L.cnt[j] = 1;
-    }
-    y7t_sync(ex);
-    if (tid == 0) {
-        int* x = L.x; int* y = L.y; int* fr = L.fr; int* pred = L.pred; int* cols = L.st; int* unique = L.cnt;
-        double* v = L.v; double* d = L.d;
-        for (int j = n - 1; j >= 0; --j) {
-            const int i = y[j];
-            if (x[i] < 0) x[i] = j;
-            else { unique[i] = 0; y[j] = -1; }
-        }
-        int n_free = 0;
-        for (int i = 0; i < n; ++i) {
-            if (x[i] < 0) fr[n_free++] = i;
-            else if (unique[i]) {
-                const int j = x[i];
-                double mn = Y7T_LARGE;
-                for (int j2 = 0; j2 < n; ++j2) {
-                    if (j2 == j) continue;
-                    const double c = y7t_lap_cost(L, i, j2) - v[j2];
-                    if (c < mn) mn = c;
-                }
-                v[j] -= mn;
-            }
-        }
-        for (int pass = 0; pass < 2 && n_free > 0; ++pass) {      // _carr_dense
-            unsigned current = 0, rr_cnt = 0;
-            int new_free = 0;
-            while (current < (unsigned)n_free) {
-                rr_cnt++;
-                const int free_i = fr[current++];
-                int j1 = 0, j2 = -1;
-                double v1 = y7t_lap_cost(L, free_i, 0) - v[0], v2 = Y7T_LARGE;
-                for (int j = 1; j < n; ++j) {
-                    const double c = y7t_lap_cost(L, free_i, j) - v[j];
-                    if (c < v2) {
-                        if (c >= v1) { v2 = c; j2 = j; }
-                        else { v2 = v1; v1 = c; j2 = j1; j1 = j; }
-                    }
-                }
-                int i0 = y[j1];
-                const double v1_new = v[j1] - (v2 - v1);
-                const bool lowers = v1_new < v[j1];
-                if (rr_cnt < current * (unsigned)n) {
-                    if (lowers) v[j1] = v1_new;
-                    else if (i0 >= 0 && j2 >= 0) { j1 = j2; i0 = y[j2]; }
-                    if (i0 >= 0) {
-                        if (lowers) fr[--current] = i0;
-                        else fr[new_free++] = i0;
-                    }
-                } else if (i0 >= 0) fr[new_free++] = i0;
-                x[free_i] = j1;
-                y[j1] = free_i;
-            }
-            n_free = new_free;
-        }
-        for (int f = 0; f < n_free; ++f) {                         // _ca_dense / _find_path_dense
-            const int start = fr[f];
-            unsigned lo = 0, hi = 0, n_ready = 0;
-            int final_j = -1;
-            for (int j = 0; j < n; ++j) { cols[j] = j; pred[j] = start; d[j] = y7t_lap_cost(L, start, j) - v[j]; }
-            while (final_j == -1) {
-                if (lo == hi) {
-                    n_ready = lo;
-                    {                                              // _find_dense
-                        hi = lo + 1;
+    const int n_free = y7t_lap_reduce(ex, L);
+    int* x = L.x; int* y = L.y; int* fr = L.fr; int* pred = L.pred; int* cols = L.st; int* evl = L.cnt;
+    double* v = L.v; double* d = L.d;
+    for (int f = 0; f < n_free; ++f) {                         // _ca_dense / _find_path_dense
+        const int start = fr[f];
+        int lo = 0, hi = 0, n_ready = 0, final_j = -1;         // (uniform: every thread keeps its own copy)
+        for (int j = tid; j < n; j += nt) { cols[j] = j; pred[j] = start; d[j] = y7t_lap_cost(L, start, j) - v[j]; }
+        y7t_sync(ex);
+        while (final_j == -1) {
+            if (lo == hi) {
+                n_ready = lo;
+                {                                              // _find_dense: hi = lo + 1; mind = d[cols[lo]]; for k in (lo, n): if d[cols[k]] <= mind: (if <: hi = lo, mind = it); swap cols[k] <-> cols[hi++]
+                    const int cnt = n - lo, C = (cnt + nt - 1) / nt, k0 = lo + tid * C, k1 = (k0 + C < n) ? k0 + C : n;
+                    double cmin = HUGE_VAL;
+                    for (int k = k0; k < k1; ++k) { const double t = d[cols[k]]; cmin = t < cmin ? t : cmin; }
+                    double run = y7t_block_excl_min_d(ex, cmin);      // the minimum over the positions in front of this thread's run
+                    int ne = 0;
+                    for (int k = k0; k < k1; ++k) { const double t = d[cols[k]]; if (k > lo && t <= run) ++ne; run = t < run ? t : run; }
+                    int total;
+                    int off = y7t_block_excl_sum_i(ex, ne, total);
+                    run = y7t_block_excl_min_d(ex, cmin);      // (recomputed rather than kept: one register pair less across the barriers above)
+                    for (int k = k0; k < k1; ++k) { const double t = d[cols[k]]; if (k > lo && t <= run) evl[off++] = k; run = t < run ? t : run; }
+                    y7t_sync(ex);
+                    int h = lo + 1;
+                    if (tid == 0) {
                         double mind = d[cols[lo]];
-                        for (unsigned k = hi; k < (unsigned)n; ++k) {
-                            const int j = cols[k];
-                            if (d[j] <= mind) {
-                                if (d[j] < mind) { hi = lo; mind = d[j]; }
-                                cols[k] = cols[hi];
-                                cols[hi++] = j;
-                            }
+                        for (int e = 0; e < total; ++e) {
+                            const int k = evl[e], j = cols[k];
+                            if (d[j] < mind) { h = lo; mind = d[j]; }
+                            cols[k] = cols[h];
+                            cols[h++] = j;
                         }
                     }
-                    for (unsigned k = lo; k < hi; ++k) { const int j = cols[k]; if (y[j] < 0) final_j = j; }
+                    hi = y7t_bcast_i(ex, h, 30);
                 }
-                if (final_j == -1) {                               // _scan_dense (on its own copies of lo / hi: it returns without writing them back when it ends the search)
-                    unsigned lo2 = lo, hi2 = hi;
-                    while (lo2 != hi2 && final_j == -1) {
-                        int j = cols[lo2++];
-                        const int i = y[j];
-                        const double mind = d[j];
-                        const double h = y7t_lap_cost(L, i, j) - v[j] - mind;
-                        for (unsigned k = hi2; k < (unsigned)n; ++k) {
-                            j = cols[k];
-                            const double cred = y7t_lap_cost(L, i, j) - v[j] - h;
-                            if (cred < d[j]) {
-                                d[j] = cred;
-                                pred[j] = i;
-                                if (cred == mind) {
-                                    if (y[j] < 0) { final_j = j; break; }
-                                    cols[k] = cols[hi2];
-                                    cols[hi2++] = j;
-                                }
-                            }
+                {                                              // for k in [lo, hi): if y[cols[k]] < 0: final_j = cols[k]   (the LAST free column of the frontier)
+                    int best = 0x7fffffff, dummy = 0x7fffffff;
+                    for (int k = lo + tid; k < hi; k += nt) if (y[cols[k]] < 0 && -k < best) best = -k;
+                    y7t_imin2(ex, best, dummy);
+                    if (best != 0x7fffffff) final_j = cols[-best];
+                    y7t_sync(ex);
+                }
+            }
+            if (final_j == -1) {                               // _scan_dense (on its own copies of lo / hi: it returns without writing them back when it ends the search)
+                int lo2 = lo, hi2 = hi;
+                while (lo2 != hi2 && final_j == -1) {
+                    const int jc = cols[lo2++];
+                    const int i = y[jc];
+                    const double mind = d[jc];
+                    const double h = y7t_lap_cost(L, i, jc) - v[jc] - mind;
+                    const int cnt = n - hi2, C = (cnt + nt - 1) / nt, k0 = hi2 + tid * C, k1 = (k0 + C < n) ? k0 + C : n;
+                    int ne = 0;
+                    unsigned long long hitm = 0ull;            // (runs of up to 64 positions per thread: n <= 64 * nt)
+                    for (int k = k0; k < k1; ++k) {
+                        const int j = cols[k];
+                        const double cred = y7t_lap_cost(L, i, j) - v[j] - h;
+                        if (cred < d[j]) {
+                            d[j] = cred;
+                            pred[j] = i;
+                            if (cred == mind) { ++ne; if (k - k0 < 64) hitm |= 1ull << (k - k0); }
                         }
                     }
-                    if (final_j == -1) { lo = lo2; hi = hi2; }
+                    int total;
+                    int off = y7t_block_excl_sum_i(ex, ne, total);
+                    if (C <= 64) { for (int k = k0; k < k1; ++k) if ((hitm >> (k - k0)) & 1ull) evl[off++] = k; }
+                    else if (ne) { for (int k = k0; k < k1; ++k) { const int j = cols[k]; if (pred[j] == i && d[j] == mind) evl[off++] = k; } }      // (a run longer than 64: a tiny workgroup on a large matrix -- re-derive the hits: relaxed by this row to exactly mind)
+                    y7t_sync(ex);
+                    int fj = -1, h2 = hi2;
+                    if (tid == 0) {
+                        for (int e = 0; e < total; ++e) {
+                            const int k = evl[e], j = cols[k];
+                            if (y[j] < 0) { fj = j; break; }
+                            cols[k] = cols[h2];
+                            cols[h2++] = j;
+                        }
+                    }
+#if Y7T_DEVICE
+                    if (nt > 64) {                             // thread 0's verdict to everybody (one pair of barriers for both words)
+                        __syncthreads();
+                        if (tid == 0) { ex.ri[30] = fj; ex.ri[31] = h2; }
+                        __syncthreads();
+                        fj = ex.ri[30]; h2 = ex.ri[31];
+                    } else { fj = __builtin_amdgcn_readfirstlane(fj); h2 = __builtin_amdgcn_readfirstlane(h2); }
+#endif
+                    hi2 = h2;
+                    final_j = fj;
                 }
+                if (final_j == -1) { lo = lo2; hi = hi2; }
             }
-            {
-                const double mind = d[cols[lo]];
-                for (unsigned k = 0; k < n_ready; ++k) { const int j = cols[k]; v[j] += d[j] - mind; }
-            }
+        }
+        {
+            const double mind = d[cols[lo]];
+            y7t_sync(ex);
+            for (int k = tid; k < n_ready; k += nt) { const int j = cols[k]; v[j] += d[j] - mind; }
+        }
+        if (tid == 0) {
             int i = -1, j = final_j;
             while (i != start) {
                 i = pred[j];
@@ -902,8 +965,8 @@ Y7T_NOINL void y7t_lap_solve_literal(const Y7TExec& ex, Y7TLap& L) {
                 const int t = j; j = x[i]; x[i] = t;
             }
         }
+        y7t_sync(ex);
     }
-    y7t_sync(ex);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -223,7 +223,7 @@ def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff
     tiles = -(-(B * H * W) // 256) * (cout // 256 if cout % 256 == 0 else 0)
     ok = (k == 1 and s == 1 and cin % 64 == 0 and cout % 256 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0
           and tiles >= int(_lib.switch("Y7T_CONV_P8_MIN_TILES", "256")))
-    if mode != "all" and "Y7T_CONV_P8_MIN_TILES" not in os.environ:
+    if mode != "all" and _lib.switch("Y7T_CONV_P8_MIN_TILES", None) is None:      # (through the same gate as the threshold: an experiment variable in the environment does not change the PRODUCT's lowering)
         ok = ok and (cin >= 1024 or (cin >= 512 and tiles >= 3000))
     if up is not None:
         ok = ok and up[0] % 64 == 0 and up[1] % 64 == 0 and H % 2 == 0 and W % 2 == 0

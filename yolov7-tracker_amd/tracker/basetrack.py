@@ -391,10 +391,12 @@ class BaseTracker(object):
         self.frame_id += 1
         self._snap_cache = None
 
-    def frames_table(self, dets_dev, outs, warps=None):
+    def frames_table(self, dets_dev, outs, warps=None, counts_dev=None):
         """device pointer tables of y7t_tracker_step_frames for a fixed set of consecutive frames (build once, launch many times):
         dets_dev = list of (n, 6) float32 device tensors, outs = list of (cap_t + 1, 8) float64 device tensors (row cap_t receives the count),
-        warps = optional list of 2x3 float64 device tensors"""
+        warps = optional list of 2x3 float64 device tensors.  counts_dev: an int32 device tensor with one row count per frame that the launch reads ON THE
+        DEVICE (e.g. `ndets` of Detector.postprocess, with dets_dev = the rows of its `dets`): the detector's NMS output feeds the tracker without a host
+        round trip; each dets_dev[i] then only gives the address and the capacity of frame i's rows"""
         ds = [d.reshape(-1, 6) for d in dets_dev]
         for d in ds:
             if d.device.type != "cuda" or d.dtype != torch.float32 or not d.is_contiguous():
@@ -404,7 +406,12 @@ class BaseTracker(object):
         n = len(ds)
         tab = torch.tensor([[d.data_ptr() for d in ds], [o.data_ptr() for o in outs], [o.data_ptr() + self.cap_t * 8 * 8 for o in outs],
                             [w.data_ptr() for w in warps] if warps is not None else [0] * n], dtype=torch.int64).cuda()
-        cnt = torch.tensor([d.shape[0] for d in ds], dtype=torch.int32).cuda()
+        if counts_dev is not None:
+            if counts_dev.device.type != "cuda" or counts_dev.dtype != torch.int32 or not counts_dev.is_contiguous() or counts_dev.numel() < n:
+                raise _lib.Y7TError("frames_table: counts_dev must be a contiguous int32 device tensor with one entry per frame")
+            cnt = counts_dev
+        else:
+            cnt = torch.tensor([d.shape[0] for d in ds], dtype=torch.int32).cuda()
         nmax = max([d.shape[0] for d in ds] + [0])
         threads = self.threads if self.threads else (1024 if nmax > 384 else 256)      # the library's rule for one frame (csrc/y7t_tracker.hip::step_threads)
         return (tab, cnt, n, warps is not None, (ds, outs, warps), threads)      # (the buffers stay alive with the table)
