@@ -84,5 +84,30 @@ profile)
   TAG=$TAG bash scripts/gpu_round.sh profile
   ;;
 
+owncu_ab)
+  say "owncu_ab: tracker step kernels asking for the CU's whole LDS (default) against asking for what they use (measuring build, Y7T_TRACKER_OWN_CU=0): headline + cfg3 / cfg4 child runs, A/B/A"
+  for v in own1_a own0 own1_b; do
+    case $v in own0) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so Y7T_TRACKER_OWN_CU=0";; *) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so Y7T_TRACKER_OWN_CU=1";; esac
+    env $E timeout 900 python bench.py --steps 10 --warmup 3 --no_latency_mode --no_cpu_baseline --no_coupled > $O/bench_$v.json 2> $O/bench_$v.err; echo "$v rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_$v.json
+  done
+  ;;
+
+hipgraph2)
+  say "hipgraph2: the conv launch list as two captured hipGraphs per candidate set (bench.py --hipgraph 2) against the plain launches, A/B/A"
+  for v in plain_a graph plain_b; do
+    case $v in graph) F="--hipgraph 2";; *) F="";; esac
+    timeout 600 python bench.py --steps 20 --warmup 5 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled $F > $O/bench_hg_$v.json 2> $O/bench_hg_$v.err; echo "$v rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_hg_$v.json
+  done
+  ;;
+
+mfma_ceiling)
+  say "mfma_ceiling: the register-only MFMA loop on random / zero operands (scripts/ubench/mfma_power.hip), re-measured this round"
+  ( cd scripts/ubench && bash build.sh > $O/ubench_build.log 2>&1 )
+  timeout 300 scripts/ubench/mfma_power > $O/mfma_power.txt 2>&1; echo "rc=$?" | tee -a $O/summary.txt
+  cat $O/mfma_power.txt | cut -c1-200 | tee -a $O/summary.txt
+  ;;
+
 *) say "unknown step $step";;
 esac; done

@@ -581,6 +581,12 @@ static int conv_dispatch(const Y7TConvArgs& a0, hipStream_t s) {
         if (!fast) { y7t_set_error("conv: Detect-decode / upsample-on-read need a 1x1 stride-1 layer with Cin %% 64 == 0"); return Y7T_E_ARG; }
         if (a.epi) {
             if (a.Cout_pad != 64 || a.up_C > 0) { y7t_set_error("conv: fused Detect decode needs na * (5 + nc) <= 64 output channels (got %d)", a.Cout); return Y7T_E_ARG; }
+            // round 6: a Detect conv has ONE channel tile and no split-K (its epilogue decodes), so on the small maps a workgroup walks the whole K = 768 / 1024 with one
+            // K-step in flight per round trip -- 33 us for 0.04 GFLOP-per-frame layers at 40 frames, 28 us at one frame.  A four-stage ring keeps three K-steps in flight
+            // (48 KiB of LDS: three workgroups per CU instead of four, which these grids of <= 2000 workgroups do not miss).  The 160 x 160 level at 40 frames (8000
+            // tiles, HBM-bound) keeps the two-stage ring.  Measuring build: Y7T_CONV_DETECT_NST=2 is the old form.
+            static const int deep = y7t_exp_switch("Y7T_CONV_DETECT_NST", 4);
+            if (deep == 4 && (a.M + 127) / 128 <= 4096) return launch_conv_ut<128, 64, 32, 4, true, 1, 1, false>(a, s);
             return launch_conv_ut<128, 64, 32, 2, true, 1, 1, false>(a, s);
         }
         if (a.up_c0 % 32 || a.up_C % 32 || a.up_c0 + a.up_C > a.Cin || (a.H & 1) || (a.W & 1) || a.ldin2 % 8 || a.cin2_off % 8) {

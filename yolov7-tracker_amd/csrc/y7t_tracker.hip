@@ -318,6 +318,9 @@ static unsigned step_fast_bytes(int n_dets) {
     return kFastBytes;
 }
 
+// (Round 6 measured the step kernels asking for the CU's WHOLE 160 KiB so that no convolution workgroup shares their CU: cfg3 chain 26.95 / 26.91 ms with, 27.01 without;
+// cfg4 35.02 / 35.01 vs 35.17; cfg2 11.21 / 11.27 vs 11.33 -- nothing, removed (profiles/r06_small_experiments.txt).  What slows the step beside a running detector is
+// not a neighbour on its CU.)
 template <class K>
 static int ensure_lds(K kernel, unsigned bytes) {
     Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
