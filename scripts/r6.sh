@@ -109,5 +109,45 @@ mfma_ceiling)
   cat $O/mfma_power.txt | cut -c1-200 | tee -a $O/summary.txt
   ;;
 
+detect_nst)
+  say "detect_nst: Detect convs on the four-stage ring (default) against the two-stage one (measuring build, Y7T_CONV_DETECT_NST=2): parity tests, per-op tables at 40 frames and at one frame"
+  timeout 900 python -m pytest -x -q -m gpu tests/test_detector_pinned_gpu.py -k "fused_detect or candidates or launch_list" > $O/t_detect.log 2>&1; echo "rc=$?" >> $O/t_detect.log; tailsum $O/t_detect.log 3
+  for v in nst4 nst2; do
+    case $v in nst2) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so Y7T_CONV_DETECT_NST=2";; *) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so";; esac
+    env $E NAME=b40_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b40_$v.log 2>&1
+    env $E B=1 NAME=b1_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b1_$v.log 2>&1
+    for b in b40 b1; do echo "--- $b $v" | tee -a $O/summary.txt; grep "detect-decode\|TOTAL" $O/per_layer_${b}_$v.txt | cut -c1-200 | tee -a $O/summary.txt; done
+  done
+  ;;
+
+splitk_b1)
+  say "splitk_b1: the batch-1 launch list without split-K (measuring build, Y7T_CONV_SPLITK=0) against the default, per-op tables"
+  E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so"
+  env $E Y7T_CONV_SPLITK=0 B=1 NAME=b1_nosplit OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b1_nosplit.log 2>&1
+  tail -1 $O/per_layer_b1_nosplit.txt | tee -a $O/summary.txt
+  ;;
+
+latency)
+  say "latency: bench.py's latency mode alone (reference Timer semantics, batch 1), three runs"
+  for k in 1 2 3; do
+    timeout 600 python scripts/latency_mode.py > $O/latency_$k.log 2>&1; echo "rc=$?" >> $O/latency_$k.log; grep -h "fps" $O/latency_$k.log | cut -c1-300 | tee -a $O/summary.txt
+  done
+  ;;
+
+tracker_phases)
+  say "tracker_phases: scripts/time_tracker.py (frame step alone: latency, kernel-only, phase table at 80 and 500 objects)"
+  timeout 600 python scripts/time_tracker.py > $O/time_tracker.log 2>&1; echo "rc=$?" >> $O/time_tracker.log; cat $O/time_tracker.log | cut -c1-400 | tee -a $O/summary.txt
+  ;;
+
+tests_tracker)
+  say "tests_tracker: tracker / CLI / chained / multirank device tests"
+  timeout 1500 python -m pytest -x -q -m gpu tests/test_tracker_gpu.py tests/test_cli_gpu.py tests/test_chained_gpu.py tests/test_multirank_gpu.py > $O/t_tracker.log 2>&1; echo "rc=$?" >> $O/t_tracker.log; tailsum $O/t_tracker.log 3
+  ;;
+
+tests_fullsize)
+  say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
+  timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3
+  ;;
+
 *) say "unknown step $step";;
 esac; done

@@ -23,11 +23,13 @@
 #define Y7T_FN __device__ __forceinline__
 #define Y7T_HD __host__ __device__ __forceinline__
 #define Y7T_NOINL __device__ __noinline__
+#define Y7T_MFN __device__ __forceinline__      /* member functions */
 #define Y7T_DEVICE 1
 #else
 #define Y7T_FN static inline
 #define Y7T_HD static inline
 #define Y7T_NOINL static
+#define Y7T_MFN inline
 #define Y7T_DEVICE 0
 #endif
 
@@ -574,28 +576,62 @@ static inline double y7t_row_at(double v, int) { return v; }
 // every (row, column) pair of an na x nb problem: body(i, j, rl, r, cj) with cj = colctx(j) and row i's context = y7t_row_at(rl.., r).  Device: a lane per column, a wave
 // per row residue; what the body needs of a ROW is loaded 64 rows at a time, a lane each, and taken out of that lane's registers through the scalar registers when the
 // row's turn comes (round 5: a row's box used to be four dependent global loads in front of every pair's arithmetic -- 244 pairs per lane at 500 x 500, each a memory
-// round trip: 368 of the ByteTrack step's 2217 kcycles, profiles/r03_tracker_phases.txt)
-template <class ColFn, class RowFn, class Body>
-Y7T_FN void y7t_pairs(const Y7TExec& ex, int na, int nb, ColFn colctx, RowFn rowctx, Body body) {
+// round trip: 368 of the ByteTrack step's 2217 kcycles, profiles/r03_tracker_phases.txt).
+// Round 6 -- GROUP REJECTION (geo.on): the columns are enumerated through `colperm` (position -> column: the caller has sorted them by x), so the 64 columns of a wave
+// are neighbours in the image; geo.group() bounds them (a wave reduction per 64 columns), every lane tests the row IT has loaded against that bound, and only the rows
+// of the ballot are walked at all -- 64 row tests for the price of one pair.  A skipped pair is one the body would have seen at "apart" (cost exactly 1), so the body
+// sees every pair that can matter, under the SAME indices: only the order of enumeration changes, which no caller depends on (candidate appends are unordered already).
+struct Y7TNoGeo {
+    static constexpr bool on = false;
+    struct G { int none; };
+    template <class C> Y7T_MFN G group(const C&, bool) const { return G{0}; }
+    template <class R> Y7T_MFN bool near(const R&, const G&) const { return true; }
+    template <class C> Y7T_MFN double key(const C&) const { return 0.0; }
+};
+// position -> column in ascending order of key[] (rank sort by the whole workgroup: nb broadcast reads per column; ties and NaN keys by column index, so `perm` is a
+// permutation whatever the keys are).  key[] and perm[] are nb entries of fast scratch.
+Y7T_FN void y7t_rank_perm(const Y7TExec& ex, int nb, const double* key, int* perm) {
+    for (int j = ex.tid; j < nb; j += ex.nt) {
+        const double kj = key[j];
+        int rank = 0;
+        for (int k = 0; k < nb; ++k) { const double kk = key[k]; rank += (kk < kj) || (kk == kj && k < j); }
+        perm[rank] = j;
+    }
+    y7t_sync(ex);
+}
+template <class ColFn, class RowFn, class Body, class Geo = Y7TNoGeo>
+Y7T_FN void y7t_pairs(const Y7TExec& ex, int na, int nb, ColFn colctx, RowFn rowctx, Body body, const int* colperm = nullptr, Geo geo = Geo()) {
 #if Y7T_DEVICE
     if (ex.nt >= 64) {
         const int nw = ex.nt >> 6, wave = ex.tid >> 6, lane = ex.tid & 63;
         for (int jb = 0; jb < nb; jb += 64) {
-            const int j = jb + lane;
-            const bool jv = j < nb;
-            const auto cj = colctx(jv ? j : 0);
+            const bool jv = jb + lane < nb;
+            const int jp = jv ? jb + lane : 0;
+            const int j = colperm ? colperm[jp] : jp;
+            const auto cj = colctx(j);
+            const auto grp = geo.group(cj, jv);
             for (int ib = wave; ib < na; ib += nw * 64) {               // this wave's rows ib, ib + nw, ...: 64 of them at a time
                 const int il = ib + nw * lane;
                 const auto rl = rowctx(il < na ? il : 0);
                 int nr = (na - ib + nw - 1) / nw;
                 nr = nr < 64 ? nr : 64;
-                for (int r = 0; r < nr; ++r)
-                    if (jv) body(ib + nw * r, j, rl, r, cj);
+                if (Geo::on) {
+                    unsigned long long m = __ballot(lane < nr && geo.near(rl, grp));
+                    while (m) {
+                        const int r = y7t_ctz64(m);
+                        m &= m - 1ull;
+                        if (jv) body(ib + nw * r, j, rl, r, cj);
+                    }
+                } else {
+                    for (int r = 0; r < nr; ++r)
+                        if (jv) body(ib + nw * r, j, rl, r, cj);
+                }
             }
         }
         return;
     }
 #endif
+    (void)colperm; (void)geo;
     for (int j = ex.tid; j < nb; j += ex.nt) {
         const auto cj = colctx(j);
         for (int i = 0; i < na; ++i) body(i, j, rowctx(i), -1, cj);
@@ -626,6 +662,25 @@ Y7T_FN double y7t_box_iou_dist(const Y7TBoxR& rl, int r, const Y7TBoxC& q) {
     const double b[4] = {y7t_row_at(rl.v[0], r), y7t_row_at(rl.v[1], r), y7t_row_at(rl.v[2], r), y7t_row_at(rl.v[3], r)};
     return y7t_iou_dist(b, q.v);
 }
+// group rejection for box pairs (y7t_pairs): the union of a wave's GROWN column boxes; a row box apart from the union is apart from every one of them (y7t_box_apart's
+// own test against a larger box), i.e. every pair of that row and those columns costs exactly 1.  Infinities (coordinates beyond 2^21, NaN) make a bound that rejects nothing.
+struct Y7TBoxGeo {
+    static constexpr bool on = true;
+    struct G { float x0, y0, x1, y1; };
+    Y7T_MFN G group(const Y7TBoxC& c, bool valid) const {
+        const float inf = (float)HUGE_VAL;
+        float x0 = valid ? c.g[0] : inf, y0 = valid ? c.g[1] : inf, x1 = valid ? c.g[2] : -inf, y1 = valid ? c.g[3] : -inf;
+#if Y7T_DEVICE
+        for (int o = 32; o > 0; o >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, o)); y0 = fminf(y0, __shfl_xor(y0, o));
+            x1 = fmaxf(x1, __shfl_xor(x1, o)); y1 = fmaxf(y1, __shfl_xor(y1, o));
+        }
+#endif
+        return G{x0, y0, x1, y1};
+    }
+    Y7T_MFN double key(const Y7TBoxC& c) const { return c.v[0] == c.v[0] ? c.v[0] : HUGE_VAL; }      // the left edge (NaN sorts last)
+    Y7T_MFN bool near(const Y7TBoxR& r, const G& g) const { return !(fmaxf(fmaxf(g.x0 - r.f[2], r.f[0] - g.x1), fmaxf(g.y0 - r.f[3], r.f[1] - g.y1)) >= 0.0f); }
+};
 
 
 // ---------------------------------------------------------------------------------------------

@@ -236,8 +236,8 @@ Y7T_FN void y7t_cost_matrix(const Y7TExec& ex, const double* a, int na, const do
 #ifndef Y7T_NEXT_STAT
 #define Y7T_NEXT_STAT(k) do { } while (0)
 #endif
-template <class ColFn, class RowFn, class CostFn>
-Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost, const int MC) {
+template <class ColFn, class RowFn, class CostFn, class Geo>
+Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost, const int MC, Geo geo) {
     const int tid = ex.tid, nt = ex.nt;
 #ifdef Y7T_ALWAYS_LITERAL
     return 2;
@@ -281,7 +281,18 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     for (int j = tid; j < nb; j += nt) { colcnt[j] = 0; y[j] = -1; v[j] = 0.0; st[j] = 0; collab[j] = 0x7fffffff; }
     if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; flag[4] = 0; flag[5] = 0; }
     y7t_sync(ex);
-    // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers) ----
+    // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers).  Round 6: with a geometry
+    // (IoU costs: Y7TBoxGeo) and more than two waves of columns, the columns are walked in ascending order of their left edge, so a wave's 64 columns are a strip of
+    // the image and a row outside the strip is skipped for all 64 at once (y7t_pairs: group rejection; the keys borrow dd[], the order nextcol[] -- both idle until step 4) ----
+    const int* colperm = nullptr;
+#if Y7T_DEVICE
+    if (Geo::on && nb > 128 && nt >= 64) {
+        for (int j = tid; j < nb; j += nt) dd[j] = geo.key(colctx(j));
+        y7t_sync(ex);
+        y7t_rank_perm(ex, nb, dd, nextcol);
+        colperm = nextcol;
+    }
+#endif
     y7t_pairs(ex, na, nb, colctx, rowctx, [&](int i, int j, const auto& rl, int r, const auto& cj) {
         const double c = cost(rl, r, cj);
         if (c <= thresh_hi) {                                 // (one compare on the common path: most pairs do not overlap at all)
@@ -293,7 +304,7 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
                 Y7T_FETCH_ADD(colcnt + j, 1);
             }
         }
-    });
+    }, colperm, geo);
     y7t_sync(ex);
     Y7T_SPROF(1);
     if (flag[0]) return 0;
@@ -744,8 +755,8 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     return 1;
 }
 
-template <class ColFn, class RowFn, class CostFn>
-Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost) {
+template <class ColFn, class RowFn, class CostFn, class Geo = Y7TNoGeo>
+Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, double thresh, ColFn colctx, RowFn rowctx, CostFn cost, Geo geo = Geo()) {
     const size_t work_bytes = (size_t)(2 * nb + 2) * sizeof(double) + (size_t)(4 * na + 6 * nb + 16) * sizeof(int);
     int mc = Y7T_MAXC;
     if (ex.fast && work_bytes + 64 <= ex.fast_bytes)
@@ -754,7 +765,7 @@ Y7T_FN int y7t_assoc_sparse_fn(const Y7TExec& ex, const Y7TTrk& s, int na, int n
     if (mc < Y7T_MAXC) Y7T_NEXT_STAT(0);                    // (host build: how often the short stride is used / has to be repeated)
     int r = 0;
     for (int pass = 0; pass < 2; ++pass) {                    // (ONE inlined copy of the solver: the frame step's code is 200 KB as it is)
-        r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, mc);
+        r = y7t_assoc_sparse_try(ex, s, na, nb, thresh, colctx, rowctx, cost, mc, geo);
         if (r != 0 || mc == Y7T_MAXC) break;
         Y7T_NEXT_STAT(1); y7t_sync(ex); mc = Y7T_MAXC;
     }
@@ -766,7 +777,7 @@ Y7T_FN int y7t_assoc_sparse(const Y7TExec& ex, const Y7TTrk& s, int na, int nb, 
     return y7t_assoc_sparse_fn(ex, s, na, nb, thresh,
                                [&](int j) { return y7t_box_col(s.dtlbr + 4 * j); },
                                [&](int i) { return y7t_box_row(s.ttlbr + 4 * i); },
-                               [&](const Y7TBoxR& rl, int r, const Y7TBoxC& q) { return y7t_box_iou_dist(rl, r, q); });
+                               [&](const Y7TBoxR& rl, int r, const Y7TBoxC& q) { return y7t_box_iou_dist(rl, r, q); }, Y7TBoxGeo());
 }
 
 // iou_distance + matching.linear_assignment(cost, thresh) for the boxes gathered in ttlbr[0..na) /
@@ -968,8 +979,20 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
                 if (y7t_iou_dist(s.ttlbr + 4 * (size_t)p, lb + 4 * (size_t)q) < 0.15) duplicate(p, q);
             }
         } else {                                              // crowded frames (500 tracked x a few hundred lost): a lane per lost box, the tracked boxes through the scalar registers
+            // (round 6: the lost boxes in ascending order of their left edge, a tracked box outside a wave's strip of 64 skipped at once -- y7t_pairs' group rejection;
+            //  keys behind the boxes in `cost`, the order in rem[], which is rewritten below)
+            const int* perm = nullptr;
+#if Y7T_DEVICE
+            if (n2 > 128 && ex.nt >= 64) {
+                double* key = lb + 4 * (size_t)n2;
+                for (int q = ex.tid; q < n2; q += ex.nt) { const double x = lb[4 * (size_t)q]; key[q] = x == x ? x : HUGE_VAL; }
+                y7t_sync(ex);
+                y7t_rank_perm(ex, n2, key, s.rem);
+                perm = s.rem;
+            }
+#endif
             y7t_pairs(ex, n1, n2, [&](int q) { return y7t_box_col(lb + 4 * (size_t)q); }, [&](int p) { return y7t_box_row(s.ttlbr + 4 * (size_t)p); },
-                      [&](int p, int q, const Y7TBoxR& rl, int r, const Y7TBoxC& cq) { if (y7t_box_iou_dist(rl, r, cq) < 0.15) duplicate(p, q); });
+                      [&](int p, int q, const Y7TBoxR& rl, int r, const Y7TBoxC& cq) { if (y7t_box_iou_dist(rl, r, cq) < 0.15) duplicate(p, q); }, perm, Y7TBoxGeo());
         }
         y7t_sync(ex);
         const int m1 = y7t_compact(ex, n1, [&](int i) { return !s.tmpa[i]; }, s.pool, 0);
