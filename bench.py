@@ -67,6 +67,8 @@ def parse():
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
     ap.add_argument("--cpu_frames", type=int, default=3)
     ap.add_argument("--chained_frames", type=int, default=8, help="frames of the chained detect -> NMS -> ByteTrack parity run in `parity.chained` (0: off)")
+    ap.add_argument("--nms_gate_div", type=int, default=NMS_GATE_DIV, help="the previous batch's rank sort + NMS is released when the forward reaches its first op on a map of "
+                    "img / this (8: behind the 640^2 / 320^2 layers; 16: behind the 160^2 ones too)")
     ap.add_argument("--no_coupled", action="store_true", help="skip the third timed pass (`coupled`: the tracker steps consume the same step's NMS output on the device)")
     ap.add_argument("--no_other_workloads", action="store_true", help="skip the short cfg3 / cfg4 runs behind the headline line (`other_workloads`)")
     ap.add_argument("--weights", default="conditioned", choices=["conditioned", "chaotic"],
@@ -99,6 +101,7 @@ def make_opts():
                                  max_tracks=512, max_dets=512, tracker_threads=TRACKER_THREADS)
 
 
+NMS_GATE_DIV = 8
 LEVEL_QUOTA = (0.55, 0.2, 0.15, 0.1)      # share of the candidates each Detect level (stride 8 / 16 / 32 / 64) supplies: all four live, weighted towards the fine ones
 
 
@@ -803,7 +806,7 @@ def main():
 
     # ops of the launch list that run on the 640^2 / 320^2 maps: memory-bound; the previous batch's decode+NMS (memory-bound too)
     # is held back until the forward is past them (an event recorded between two pieces of the list)
-    k_mid = next((i for i, op in enumerate(det.plan.ops) if int(op["H"]) <= H // 8), 0)
+    k_mid = next((i for i, op in enumerate(det.plan.ops) if int(op["H"]) <= H // args.nms_gate_div), 0)
     ev_mid = [torch.cuda.Event() for _ in range(NS)]
     pending = []          # (step, staged heads) whose decode+NMS and tracker steps are not enqueued yet
     fwd_graphs = fwd_out = None

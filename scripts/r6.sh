@@ -144,6 +144,14 @@ tests_tracker)
   timeout 1500 python -m pytest -x -q -m gpu tests/test_tracker_gpu.py tests/test_cli_gpu.py tests/test_chained_gpu.py tests/test_multirank_gpu.py > $O/t_tracker.log 2>&1; echo "rc=$?" >> $O/t_tracker.log; tailsum $O/t_tracker.log 3
   ;;
 
+nms_gate)
+  say "nms_gate: where the previous batch's rank sort + NMS is released into the forward (bench.py --nms_gate_div 8 / 16 / 32), A/B/C/A"
+  for v in 8 16 32 8; do
+    timeout 600 python bench.py --steps 20 --warmup 5 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled --nms_gate_div $v > $O/bench_gate_$v.json 2> $O/bench_gate_$v.err; echo "gate_div $v rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_gate_$v.json
+  done
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3

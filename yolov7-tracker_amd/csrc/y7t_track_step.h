@@ -282,14 +282,14 @@ Y7T_FN int y7t_assoc_sparse_try(const Y7TExec& ex, const Y7TTrk& s, int na, int 
     if (tid == 0) { flag[0] = 0; flag[1] = 0; flag[2] = 0; flag[3] = 0; flag[4] = 0; flag[5] = 0; }
     y7t_sync(ex);
     // ---- 1. cost pass (y7t_pairs: a lane per column, a wave per row residue, the rows' contexts handed out through the scalar registers).  Round 6: with a geometry
-    // (IoU costs: Y7TBoxGeo) and more than two waves of columns, the columns are walked in ascending order of their left edge, so a wave's 64 columns are a strip of
+    // (IoU costs: Y7TBoxGeo) and more than two waves of columns, the columns are walked in the order of 64 bins of their left edge (y7t_bin_perm), so a wave's 64 columns are a strip of
     // the image and a row outside the strip is skipped for all 64 at once (y7t_pairs: group rejection; the keys borrow dd[], the order nextcol[] -- both idle until step 4) ----
     const int* colperm = nullptr;
 #if Y7T_DEVICE
     if (Geo::on && nb > 128 && nt >= 64) {
         for (int j = tid; j < nb; j += nt) dd[j] = geo.key(colctx(j));
         y7t_sync(ex);
-        y7t_rank_perm(ex, nb, dd, nextcol);
+        y7t_bin_perm(ex, nb, dd, nextcol, pred);            // (pred[]: nb > 128 ints, idle until step 4)
         colperm = nextcol;
     }
 #endif
@@ -985,9 +985,9 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
 #if Y7T_DEVICE
             if (n2 > 128 && ex.nt >= 64) {
                 double* key = lb + 4 * (size_t)n2;
-                for (int q = ex.tid; q < n2; q += ex.nt) { const double x = lb[4 * (size_t)q]; key[q] = x == x ? x : HUGE_VAL; }
+                for (int q = ex.tid; q < n2; q += ex.nt) key[q] = lb[4 * (size_t)q];
                 y7t_sync(ex);
-                y7t_rank_perm(ex, n2, key, s.rem);
+                y7t_bin_perm(ex, n2, key, s.rem, s.pool);      // (pool[]: rewritten by the compaction below)
                 perm = s.rem;
             }
 #endif
