@@ -966,7 +966,7 @@ def main():
     gflop_frame = det.gflop_per_frame
     conv_tflops = gflop_frame * B / (np.mean(fwd_ms) * 1e-3) / 1e3
     traffic, traffic_meta = None, {}
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_conv_hbm_traffic.json", "r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_conv_hbm_traffic.json", "r05_conv_hbm_traffic.json", "r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json")) if os.path.exists(q)), "")
     if tpath:      # PMC counters cannot be collected inside the timed run: separate rocprofv3 --pmc passes, committed WITH the launch list they were taken on
         traffic_meta = json.load(open(tpath))
     if rank == 0:
@@ -990,9 +990,11 @@ def main():
                        "result_gather": gathered_info if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(conv_tflops * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
-                         "sustained_peak": 1550.0,
+                         "sustained_peak": 1627.0,
                          "sustained_peak_note": "register-only v_mfma_f32_32x32x16_f16 loop with random operands (power-limited clock; "
-                                                "2300-2390 with zero/constant operands): scripts/ubench/mfma_power.hip, profiles/r01_mfma_power.txt",
+                                                "2278-2389 with zero / constant operands): scripts/ubench/mfma_power.hip, re-measured in round 6 "
+                                                "(1624 / 1631 TFLOP/s, profiles/r06_small_experiments.txt; round 1: 1550-1565)",
+                         "frac_of_sustained_peak": round(conv_tflops / 1627.0, 4),
                          "traffic_note": None,
                          "kernel": "the conv launch list of one forward (107 convs in 96 launches + 1 pool launch: k_stem_u8, k_conv3x3s2_c64_ws, k_conv3x3_c64_ws, k_conv3x3_c128_ws, k_conv3x3_patch*, "
                                    "k_conv3x3s2_patch, k_conv1x1_p8, k_conv_igemm, k_spp3_lds; nearest-x2 upsamples folded into their consumers' loaders, Detect decode + "

@@ -679,3 +679,35 @@ def test_crowded_scenes_on_the_device(kind, n_obj, size):
         c = int(h[f, t.cap_t].view(np.int32)[0])
         got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
     util.assert_same_tracks(got, want, "%s, %d objects on %d px, one launch" % (kind, n_obj, size))
+
+
+def test_frames_launch_reads_the_row_counts_on_the_device():
+    """the coupled hand-over (bench.py `coupled`): the rows of y7t_det_postprocess' (B, 300, 6) output as the frames' detections and its `ndets` array
+    as the counts, both read by y7t_tracker_step_frames on the device -- here with padded rows of a scene whose frames have different counts (and garbage behind the
+    count, which the step must not look at); ids and boxes equal to the oracle's"""
+    from oracle import tracker_np
+    from yolov7_tracker_amd import synth
+    from yolov7_tracker_amd.tracker.basetrack import BaseTrack
+    from yolov7_tracker_amd.tracker.bytetrack import ByteTrack
+    dets = synth.make_detections(24, 60, 640, seq_idx=4, miss=0.2, fp=0.1)
+    dets[5] = np.zeros((0, 6), np.float32)
+    want = tracker_np.run("bytetrack", dets)
+    rows = torch.full((len(dets), 300, 6), 1e9, dtype=torch.float32)
+    for f, d in enumerate(dets):
+        rows[f, :len(d)] = torch.from_numpy(d)
+    rows = rows.cuda()
+    counts = torch.tensor([len(d) for d in dets], dtype=torch.int32).cuda()
+    BaseTrack._count = 0
+    t = ByteTrack(make_opts(), frame_rate=30)
+    outs = torch.zeros((len(dets), t.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+    t._launch_frames(t.frames_table([rows[f] for f in range(len(dets))], [outs[f] for f in range(len(dets))], None, counts_dev=counts))
+    torch.cuda.synchronize()
+    assert t._status() == 0
+    h = outs.cpu().numpy()
+    got = []
+    for f in range(len(dets)):
+        c = int(h[f, t.cap_t].view(np.int32)[0])
+        got.append([(int(r[0]), r[1:5].copy(), float(r[5]), float(r[6])) for r in h[f, :c]])
+    util.assert_same_tracks(got, want, "frames launch with device-side row counts")
+    with pytest.raises(Exception):
+        t.frames_table([rows[0]], [outs[0]], None, counts_dev=counts.cpu())
