@@ -118,18 +118,17 @@ def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=No
     f = frames_host[:1]
     img = (torch.from_numpy(f[..., ::-1].copy()).permute(0, 3, 1, 2).float() / 255.0).contiguous()
     sd = {k: v for k, v in det._sd.items()}
-    # "the box's own host cores".  The detector oracle is timed with EVERY core of the host and with 32 threads (torch's CPU convolutions stop
-    # scaling, and on some hosts thrash, beyond a few dozen threads); the faster of the two is the baseline, and both are in the line.
-    by_threads = {}
-    for ncores in sorted({os.cpu_count(), min(os.cpu_count(), 32)}, reverse=True):
-        torch.set_num_threads(ncores)
-        dt.forward(det.nodes, sd, img, det.spec["anchors"])      # (untimed: thread pool, allocator)
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_frames):
-            dec, raw_ref = dt.forward(det.nodes, sd, img, det.spec["anchors"])
-        by_threads[ncores] = (time.perf_counter() - t0) / args.cpu_frames
-    ncores = min(by_threads, key=by_threads.get)
-    t_det = by_threads[ncores]
+    # "the box's own host cores" -- why 32 threads and not os.cpu_count(): measured on the GPU box in round 6 (session r6g, 256 logical cores): the
+    # detector oracle takes 82.3 s per frame with 256 threads against 0.395 s with 32 (torch's CPU convolutions oversubscribe and thrash), and timing that inside
+    # every bench run would cost five minutes.  The baseline is the port at the thread count where it is FASTEST on such hosts; hosts with fewer cores use them all.
+    ncores = min(os.cpu_count(), 32)
+    torch.set_num_threads(ncores)
+    dt.forward(det.nodes, sd, img, det.spec["anchors"])      # (untimed: thread pool, allocator)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_frames):
+        dec, raw_ref = dt.forward(det.nodes, sd, img, det.spec["anchors"])
+    t_det = (time.perf_counter() - t0) / args.cpu_frames
+    by_threads = {ncores: t_det}
     torch.set_num_threads(ncores)
     parity = None
     if gpu_heads0 is not None:      # the heads the timed launch list left for frame 0 vs the fp32 oracle's (same weights, same frame)
@@ -190,6 +189,8 @@ def cpu_baseline(args, det, frames_host, dets_seq, gpu_heads0=None, gpu_dets0=No
     fps = 1.0 / (t_det + t_nms + t_trk)
     return {"value": round(fps, 3), "unit": "frames/s", "cores": ncores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "detector_s_per_frame_by_threads": {str(k_): round(v_, 3) for k_, v_ in by_threads.items()},
+            "why_not_every_core": "measured on a 256-core GPU box (round 6, profiles/r06_small_experiments.txt): 82.3 s per frame with 256 threads against 0.395 s with 32 -- "
+                                  "torch's CPU convolutions thrash when oversubscribed; 32 threads is where the port is fastest on such hosts",
             "reference_over_port": {"as_its_cli_runs_it_no_no_grad": 0.27, "with_no_grad": 0.56,
                                     "note": "fps of the reference's OWN Model + non_max_suppression + ByteTrack divided by this port's, same job, the 8-core build container "
                                             "(the reference does not exist on the GPU box): 0.45 and 0.93 fps vs 1.65 fps, outputs equal -- profiles/r03_cpu_reference_vs_port.txt. "
@@ -714,6 +715,7 @@ def main():
                 if q:
                     st.wait_event(fork)
                 if s in coupled_tables:                                # third pass: the rows and the row counts y7t_det_postprocess left for this step's frames
+                    det.plan.post[s % 2].dets[:B, :, 4].mul_(coupled_conf)      # (the score gain, see below)
                     trk_coupled._launch_frames(coupled_tables[s])
                     continue_frames = False
                 elif args.tracker_launch == "frames" and not cfg4:      # one launch for the sequence's frames of this step (pointer tables built before the timed region)
@@ -833,8 +835,22 @@ def main():
     host_rows = [torch.empty((B,) + tuple(results.shape[1:]), dtype=results.dtype).pin_memory() for _ in range(2)]
     ev_d2h = [torch.cuda.Event() for _ in range(NS)]
 
+    coupled_conf = None
     if coupled_pass:      # the device NMS output feeding the device tracker inside the timed pipeline: a fresh ByteTrack, one launch per step
-        trk_coupled = ByteTrack(make_opts(), frame_rate=30)
+        # A random head is never confident (0.4 of its 300 rows per frame reach ByteTrack's 0.2, none its birth gate of 0.3): fed as they are, the coupled tracker idles.
+        # The hand-over therefore multiplies the SCORE column of the step's NMS rows by one constant (a strided in-place multiply on the tracker's stream, in front of
+        # the launch) chosen so that every frame's n_obj-th best row sits at 0.5: the detector, the candidates and the NMS are the headline's, the tracker gets as many
+        # confident rows per frame as the headline's scene has detections -- boxes of a random head, so births and losses every frame.
+        with torch.cuda.stream(sA):
+            d_, n_ = det.postprocess(det.forward(frames, fuse_decode=CONF), CONF, 0.45, None)
+        torch.cuda.synchronize()
+        sc_ = d_[:B, :, 4].clone()
+        sc_[torch.arange(sc_.shape[1], device=sc_.device)[None, :] >= n_[:B, None]] = -1.0
+        kth = torch.sort(sc_, dim=1, descending=True).values[:, min(args.n_obj, sc_.shape[1]) - 1]
+        coupled_conf = 0.5 / float(torch.median(kth[kth > 0]).item()) if bool((kth > 0).any()) else 1.0      # the score gain
+        oc = make_opts()
+        oc.max_tracks = 2048      # (a random head's boxes: more births and lost tracks than a scene's)
+        trk_coupled = ByteTrack(oc, frame_rate=30)
         for s_ in range(2 * (K + Wm), 3 * (K + Wm)):
             pp = det.plan.post[s_ % 2]
             coupled_tables[s_] = trk_coupled.frames_table([pp.dets[i] for i in range(B)], [results[s_ * B + i] for i in range(B)], None, counts_dev=pp.ndets)
@@ -1029,9 +1045,12 @@ def main():
                                "nms_rows_at_or_above_track_thresholds_mean": {"0.2": round(float(np.mean([(dl[b, :nd_last[b], 4] >= 0.2).sum() for b in range(B)])), 1),
                                                                               "0.15": round(float(np.mean([(dl[b, :nd_last[b], 4] >= 0.15).sum() for b in range(B)])), 1)},
                                "tracks_per_frame_mean": round(float(cnts.mean()), 1), "tracker_status": int(trk_coupled._status()),
+                               "score_gain_in_the_handover": round(coupled_conf, 3),
                                "note": "third timed pass: frames from pinned host memory, forward, rank sort + NMS, and the SAME step's (300, 6) rows and row counts read by "
-                                       "y7t_tracker_step_frames on the device (no synthetic detections, no host round trip), track rows to the host; a fresh ByteTrack. Random "
-                                       "weights with the planted objectness: what the tracker sees is the random head's boxes, not a scene"}
+                                       "y7t_tracker_step_frames on the device (no synthetic detections, no host round trip), track rows to the host; a fresh ByteTrack with the CLI's "
+                                       "thresholds. A random head is never confident, so the hand-over multiplies the rows' score column by one constant (every frame's "
+                                       "n_obj-th best row -> 0.5; `nms_rows_at_or_above_track_thresholds_mean` is after that gain). What the tracker sees are a random head's "
+                                       "boxes, not a scene: births and losses every frame"}
         exps = {k: v for k, v in os.environ.items() if k.startswith("Y7T_") and k != "Y7T_TEST_EXPERIMENTS"}
         if exps:      # a run with experiment switches in the environment says so in its own line (none in the driver's run)
             line["config"]["environment_switches"] = exps
