@@ -659,7 +659,7 @@ def main():
     frames = torch.from_numpy(frames_host).cuda()
     extra_passes = world == 1 and args.mode == "sequences" and args.halves == 1
     coupled_pass = extra_passes and not cfg3 and not cfg4 and max(1, args.seqs) == 1 and args.tracker_launch == "frames" and args.hipgraph == 0 and not args.no_coupled
-    n_frames *= (3 if coupled_pass else 2) if extra_passes else 1   # second pass: the same pipeline fed from host memory; third: the tracker steps read the SAME step's NMS output on the device
+    n_frames *= 2 if extra_passes else 1   # second pass: the same pipeline fed from host memory (a third, `coupled`, has its own tracker and result rows)
     S = max(1, args.seqs)
     if B % S:
         raise SystemExit("--seqs must divide --batch")
@@ -738,7 +738,7 @@ def main():
     frame_tables = {}
     coupled_tables, trk_coupled = {}, None      # filled below, once the post-processing sets exist
     if args.tracker_launch == "frames" and not cfg4:
-        for s_ in range((2 if coupled_pass else n_frames // B // (K + Wm)) * (K + Wm)):
+        for s_ in range(n_frames // B):
             for q in range(S):
                 ts = [s_ * B + i for i in range(q * Bq, (q + 1) * Bq)]
                 frame_tables[(s_, q)] = trks[q].frames_table([dets_dev[t] for t in ts], [results[t] for t in ts], [warps_dev[t] for t in ts] if cfg3 else None)
@@ -851,9 +851,13 @@ def main():
         oc = make_opts()
         oc.max_tracks = 2048      # (a random head's boxes: more births and lost tracks than a scene's)
         trk_coupled = ByteTrack(oc, frame_rate=30)
+        # (its own result rows: the pool is twice as large as the headline tracker's, and a tracker writes `cap_t` rows + the count per frame)
+        results_c = torch.zeros(((K + Wm) * B, trk_coupled.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+        host_rows_c = [torch.empty((B,) + tuple(results_c.shape[1:]), dtype=results_c.dtype).pin_memory() for _ in range(2)]
         for s_ in range(2 * (K + Wm), 3 * (K + Wm)):
             pp = det.plan.post[s_ % 2]
-            coupled_tables[s_] = trk_coupled.frames_table([pp.dets[i] for i in range(B)], [results[s_ * B + i] for i in range(B)], None, counts_dev=pp.ndets)
+            f0 = (s_ - 2 * (K + Wm)) * B
+            coupled_tables[s_] = trk_coupled.frames_table([pp.dets[i] for i in range(B)], [results_c[f0 + i] for i in range(B)], None, counts_dev=pp.ndets)
 
     def finish(prev, gate):
         """rank sort + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
@@ -875,7 +879,11 @@ def main():
             sD.wait_event(ev_trk1[ps])
             if ps >= 2:
                 sD.wait_event(ev_d2h[ps - 2])
-            host_rows[ps % 2].copy_(results[ps * B:(ps + 1) * B], non_blocking=True)
+            if ps in coupled_tables:
+                f0 = (ps - 2 * (K + Wm)) * B
+                host_rows_c[ps % 2].copy_(results_c[f0:f0 + B], non_blocking=True)
+            else:
+                host_rows[ps % 2].copy_(results[ps * B:(ps + 1) * B], non_blocking=True)
             ev_d2h[ps].record(sD)
 
     def step(s):
@@ -1035,7 +1043,7 @@ def main():
                               "host-fed pipeline with the tracker consuming the step's own NMS output")
         if dt_coupled is not None:
             s0c = 2 * (K + Wm) + Wm
-            cnts = torch.stack([results[t, trk.cap_t].view(torch.int32)[0] for t in range(s0c * B, (s0c + K) * B, 4)]).cpu().numpy()
+            cnts = torch.stack([results_c[t, trk_coupled.cap_t].view(torch.int32)[0] for t in range(Wm * B, (Wm + K) * B, 4)]).cpu().numpy()
             nd_last = det.plan.post[(3 * (K + Wm) - 1) % 2].ndets[:B].cpu().numpy()
             dl = det.plan.post[(3 * (K + Wm) - 1) % 2].dets[:B].cpu().numpy()
             line["coupled"] = {"fps": round(K * B / dt_coupled, 2), "ms_per_step": round(dt_coupled / K * 1e3, 3),
