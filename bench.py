@@ -714,9 +714,11 @@ def main():
             with torch.cuda.stream(st):
                 if q:
                     st.wait_event(fork)
-                if s in coupled_tables:                                # third pass: the rows and the row counts y7t_det_postprocess left for this step's frames
-                    det.plan.post[s % 2].dets[:B, :, 4].mul_(coupled_conf)      # (the score gain, see below)
-                    trk_coupled._launch_frames(coupled_tables[s])
+                if s in coupled_tables:                                # coupled passes: the rows and the row counts y7t_det_postprocess left for this step's frames
+                    cv = coupled_tables[s]
+                    if cv["gain"] != 1.0:
+                        det.plan.post[s % 2].dets[:B, :, 4].mul_(cv["gain"])      # (the score gain of the second coupled pass, see below)
+                    cv["trk"]._launch_frames(cv["tables"][s])
                     continue_frames = False
                 elif args.tracker_launch == "frames" and not cfg4:      # one launch for the sequence's frames of this step (pointer tables built before the timed region)
                     trks[q]._launch_frames(frame_tables[(s, q)])
@@ -736,7 +738,7 @@ def main():
                     j.record(st)
                     cur.wait_event(j)          # join: the step's chain is complete on the caller's stream
     frame_tables = {}
-    coupled_tables, trk_coupled = {}, None      # filled below, once the post-processing sets exist
+    coupled_tables, coupled_variants = {}, []      # step -> variant; filled below, once the post-processing sets exist
     if args.tracker_launch == "frames" and not cfg4:
         for s_ in range(n_frames // B):
             for q in range(S):
@@ -791,7 +793,7 @@ def main():
         from yolov7_tracker_amd import _lib as _y7t_lib
         sA, sB = _y7t_lib.cu_masked_streams(args.cu_reserve)
         sC = sB if args.cu_reserve_nms else sA      # NMS on the reserved CUs beside the tracker chain, or on the detector's share (an unmasked stream would be free to use the reserved CUs)
-    NS = 3 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory; pass 2 (N=1, configs[1]): coupled
+    NS = 4 * (K + Wm)                  # pass 0: frames resident in HBM (`value`); pass 1 (N=1 only): the same pipeline fed from pinned host memory; passes 2, 3 (N=1, configs[1]): coupled
     ev_staged = [torch.cuda.Event() for _ in range(NS)]
     ev_fwd0 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
     ev_fwd1 = [torch.cuda.Event(enable_timing=True) for _ in range(NS)]
@@ -835,29 +837,34 @@ def main():
     host_rows = [torch.empty((B,) + tuple(results.shape[1:]), dtype=results.dtype).pin_memory() for _ in range(2)]
     ev_d2h = [torch.cuda.Event() for _ in range(NS)]
 
-    coupled_conf = None
     if coupled_pass:      # the device NMS output feeding the device tracker inside the timed pipeline: a fresh ByteTrack, one launch per step
-        # A random head is never confident (0.4 of its 300 rows per frame reach ByteTrack's 0.2, none its birth gate of 0.3): fed as they are, the coupled tracker idles.
-        # The hand-over therefore multiplies the SCORE column of the step's NMS rows by one constant (a strided in-place multiply on the tracker's stream, in front of
-        # the launch) chosen so that every frame's n_obj-th best row sits at 0.5: the detector, the candidates and the NMS are the headline's, the tracker gets as many
-        # confident rows per frame as the headline's scene has detections -- boxes of a random head, so births and losses every frame.
+        # Two passes.  `coupled`: the step's (300, 6) NMS rows and row counts as they are -- with random weights 0.4 of a frame's 300 rows reach ByteTrack's 0.2 and none
+        # its birth gate of 0.3, so the tracker reads, gathers and thresholds 300 rows per frame and tracks nothing: the cost of the DATA PATH.  `coupled_confident_rows`:
+        # the hand-over multiplies the rows' score column by one constant (a strided in-place multiply on the tracker's stream, in front of the launch) chosen so that
+        # every frame's n_obj-th best row sits at det_thresh: as many rows per frame above the threshold as the headline's scene has detections, and the rows behind
+        # them in the low-score association.  The detector, the candidates and the NMS are the headline's in both; the boxes are a random head's (up to 1000+ px, heavily
+        # overlapping), so the second pass is an ill-posed association, not a scene.
         with torch.cuda.stream(sA):
             d_, n_ = det.postprocess(det.forward(frames, fuse_decode=CONF), CONF, 0.45, None)
         torch.cuda.synchronize()
         sc_ = d_[:B, :, 4].clone()
         sc_[torch.arange(sc_.shape[1], device=sc_.device)[None, :] >= n_[:B, None]] = -1.0
         kth = torch.sort(sc_, dim=1, descending=True).values[:, min(args.n_obj, sc_.shape[1]) - 1]
-        coupled_conf = 0.5 / float(torch.median(kth[kth > 0]).item()) if bool((kth > 0).any()) else 1.0      # the score gain
-        oc = make_opts()
-        oc.max_tracks = 2048      # (a random head's boxes: more births and lost tracks than a scene's)
-        trk_coupled = ByteTrack(oc, frame_rate=30)
-        # (its own result rows: the pool is twice as large as the headline tracker's, and a tracker writes `cap_t` rows + the count per frame)
-        results_c = torch.zeros(((K + Wm) * B, trk_coupled.cap_t + 1, 8), dtype=torch.float64, device="cuda")
-        host_rows_c = [torch.empty((B,) + tuple(results_c.shape[1:]), dtype=results_c.dtype).pin_memory() for _ in range(2)]
-        for s_ in range(2 * (K + Wm), 3 * (K + Wm)):
-            pp = det.plan.post[s_ % 2]
-            f0 = (s_ - 2 * (K + Wm)) * B
-            coupled_tables[s_] = trk_coupled.frames_table([pp.dets[i] for i in range(B)], [results_c[f0 + i] for i in range(B)], None, counts_dev=pp.ndets)
+        gain2 = (make_opts().conf_thresh + 1e-4) / float(torch.median(kth[kth > 0]).item()) if bool((kth > 0).any()) else 1.0
+        for vi, (vname, vgain) in enumerate((("coupled", 1.0), ("coupled_confident_rows", gain2))):
+            oc = make_opts()
+            oc.max_tracks = 2048      # (a random head's boxes: more births and lost tracks than a scene's)
+            tc = ByteTrack(oc, frame_rate=30)
+            # (its own result rows: the pool is twice as large as the headline tracker's, and a tracker writes `cap_t` rows + the count per frame)
+            rc_ = torch.zeros(((K + Wm) * B, tc.cap_t + 1, 8), dtype=torch.float64, device="cuda")
+            cv = {"name": vname, "gain": vgain, "trk": tc, "results": rc_, "first": (2 + vi) * (K + Wm), "tables": {},
+                  "host_rows": [torch.empty((B,) + tuple(rc_.shape[1:]), dtype=rc_.dtype).pin_memory() for _ in range(2)]}
+            for s_ in range(cv["first"], cv["first"] + K + Wm):
+                pp = det.plan.post[s_ % 2]
+                f0 = (s_ - cv["first"]) * B
+                cv["tables"][s_] = tc.frames_table([pp.dets[i] for i in range(B)], [rc_[f0 + i] for i in range(B)], None, counts_dev=pp.ndets)
+                coupled_tables[s_] = cv
+            coupled_variants.append(cv)
 
     def finish(prev, gate):
         """rank sort + NMS of batch `prev` on stream C (after `gate`, if any), then its tracker frame steps on stream B"""
@@ -880,8 +887,9 @@ def main():
             if ps >= 2:
                 sD.wait_event(ev_d2h[ps - 2])
             if ps in coupled_tables:
-                f0 = (ps - 2 * (K + Wm)) * B
-                host_rows_c[ps % 2].copy_(results_c[f0:f0 + B], non_blocking=True)
+                cv = coupled_tables[ps]
+                f0 = (ps - cv["first"]) * B
+                cv["host_rows"][ps % 2].copy_(cv["results"][f0:f0 + B], non_blocking=True)
             else:
                 host_rows[ps % 2].copy_(results[ps * B:(ps + 1) * B], non_blocking=True)
             ev_d2h[ps].record(sD)
@@ -951,12 +959,12 @@ def main():
     dt_s = timed_pass(0)
     dt_h2d = None
     second_pass = extra_passes and graph is None
-    dt_coupled = None
+    dt_coupled = {}
     if second_pass:       # PCIe-inclusive rate: never `value`, reported beside it
         host_feed = (torch.from_numpy(frames_host).pin_memory(), [torch.empty_like(frames), torch.empty_like(frames)])
         dt_h2d = timed_pass(K + Wm)
-        if coupled_pass:  # ... and with it the coupled chain: host-fed frames -> forward -> NMS -> the tracker steps on that NMS's rows -> track rows on the host
-            dt_coupled = timed_pass(2 * (K + Wm))
+        for cv in coupled_variants:  # ... and with it the coupled chain: host-fed frames -> forward -> NMS -> the tracker steps on that NMS's rows -> track rows on the host
+            dt_coupled[cv["name"]] = timed_pass(cv["first"])
         host_feed = None
     if dist is not None:
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=cdev)
@@ -1041,24 +1049,27 @@ def main():
         line["value_note"] = ("frames resident in HBM when the timed region starts (the measurement contract of this build: a PCIe-inclusive rate is never `value`); "
                               "the reference's own timer starts with the frame on the host (tracker/track.py:140): that rate is `fps_incl_h2d`, and `coupled` is the same "
                               "host-fed pipeline with the tracker consuming the step's own NMS output")
-        if dt_coupled is not None:
-            s0c = 2 * (K + Wm) + Wm
-            cnts = torch.stack([results_c[t, trk_coupled.cap_t].view(torch.int32)[0] for t in range(Wm * B, (Wm + K) * B, 4)]).cpu().numpy()
-            nd_last = det.plan.post[(3 * (K + Wm) - 1) % 2].ndets[:B].cpu().numpy()
-            dl = det.plan.post[(3 * (K + Wm) - 1) % 2].dets[:B].cpu().numpy()
-            line["coupled"] = {"fps": round(K * B / dt_coupled, 2), "ms_per_step": round(dt_coupled / K * 1e3, 3),
-                               "tracker_chain_ms": round(float(np.mean([ev_trk0[s_].elapsed_time(ev_trk1[s_]) for s_ in range(s0c, s0c + K)])), 3),
-                               "launch_list_ms": round(float(np.mean([ev_fwd0[s_].elapsed_time(ev_fwd1[s_]) for s_ in range(s0c, s0c + K)])), 3),
-                               "nms_rows_per_frame_mean": round(float(nd_last.mean()), 1),
-                               "nms_rows_at_or_above_track_thresholds_mean": {"0.2": round(float(np.mean([(dl[b, :nd_last[b], 4] >= 0.2).sum() for b in range(B)])), 1),
-                                                                              "0.15": round(float(np.mean([(dl[b, :nd_last[b], 4] >= 0.15).sum() for b in range(B)])), 1)},
-                               "tracks_per_frame_mean": round(float(cnts.mean()), 1), "tracker_status": int(trk_coupled._status()),
-                               "score_gain_in_the_handover": round(coupled_conf, 3),
-                               "note": "third timed pass: frames from pinned host memory, forward, rank sort + NMS, and the SAME step's (300, 6) rows and row counts read by "
-                                       "y7t_tracker_step_frames on the device (no synthetic detections, no host round trip), track rows to the host; a fresh ByteTrack with the CLI's "
-                                       "thresholds. A random head is never confident, so the hand-over multiplies the rows' score column by one constant (every frame's "
-                                       "n_obj-th best row -> 0.5; `nms_rows_at_or_above_track_thresholds_mean` is after that gain). What the tracker sees are a random head's "
-                                       "boxes, not a scene: births and losses every frame"}
+        for cv in coupled_variants:
+            s0c, tc, rc_, dtc = cv["first"] + Wm, cv["trk"], cv["results"], dt_coupled[cv["name"]]
+            cnts = torch.stack([rc_[t, tc.cap_t].view(torch.int32)[0] for t in range(Wm * B, (Wm + K) * B, 4)]).cpu().numpy()
+            line[cv["name"]] = {"fps": round(K * B / dtc, 2), "ms_per_step": round(dtc / K * 1e3, 3),
+                                "tracker_chain_ms": round(float(np.mean([ev_trk0[s_].elapsed_time(ev_trk1[s_]) for s_ in range(s0c, s0c + K)])), 3),
+                                "launch_list_ms": round(float(np.mean([ev_fwd0[s_].elapsed_time(ev_fwd1[s_]) for s_ in range(s0c, s0c + K)])), 3),
+                                "score_gain_in_the_handover": round(cv["gain"], 3),
+                                "tracks_per_frame_mean": round(float(cnts.mean()), 1), "tracker_status": int(tc._status())}
+        if coupled_variants:
+            pl_ = det.plan.post[(coupled_variants[-1]["first"] + K + Wm - 1) % 2]      # the rows of the very last step (the second pass's gain already in them)
+            nd_last, dl = pl_.ndets[:B].cpu().numpy(), pl_.dets[:B].cpu().numpy()
+            g2 = coupled_variants[-1]["gain"]
+            line["coupled"]["nms_rows_per_frame_mean"] = round(float(nd_last.mean()), 1)
+            for nm_, div_ in (("coupled", g2), ("coupled_confident_rows", 1.0)):
+                line[nm_]["rows_at_or_above_0.3_0.2_0.15_mean"] = [round(float(np.mean([(dl[b, :nd_last[b], 4] / div_ >= th_).sum() for b in range(B)])), 1) for th_ in (0.3, 0.2, 0.15)]
+            line["coupled"]["note"] = ("third timed pass: frames from pinned host memory, forward, rank sort + NMS, and the SAME step's (300, 6) rows and row counts read by "
+                                       "y7t_tracker_step_frames on the device (no synthetic detections, no host round trip), track rows to the host; a fresh ByteTrack with the "
+                                       "CLI's thresholds. Random weights: hardly a row of a frame's 300 reaches 0.2, none the birth gate -- this pass times the data path")
+            line["coupled_confident_rows"]["note"] = ("fourth timed pass: the same, with the rows' score column multiplied by one constant in the hand-over (every frame's n_obj-th best row -> "
+                                                      "det_thresh), so that the tracker associates as many confident rows per frame as the headline's scene has detections. The boxes "
+                                                      "are a random head's (up to 1000+ px, heavily overlapping): an ill-posed association, the tracker's worst case rather than a scene")
         exps = {k: v for k, v in os.environ.items() if k.startswith("Y7T_") and k != "Y7T_TEST_EXPERIMENTS"}
         if exps:      # a run with experiment switches in the environment says so in its own line (none in the driver's run)
             line["config"]["environment_switches"] = exps

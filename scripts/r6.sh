@@ -27,7 +27,7 @@ try:
     ow = l.get("other_workloads") or {}
     print("%7.0f fps  step %.2f ms  list %.2f ms  frac %.4f  chain %.2f ms | host-fed %s coupled %s | latency u8 %s f32 %s | cfg3 %s cfg4 %s"
           % (l["value"], l["ms_per_step"], l["roofline"].get("launch_list_ms", float("nan")), l["roofline"]["frac"], ph.get("tracker_chain", float("nan")),
-             (l.get("fps_incl_h2d") or {}).get("value"), (l.get("coupled") or {}).get("fps"),
+             (l.get("fps_incl_h2d") or {}).get("value"), "%s / confident rows %s (chain %s ms)" % ((l.get("coupled") or {}).get("fps"), (l.get("coupled_confident_rows") or {}).get("fps"), (l.get("coupled_confident_rows") or {}).get("tracker_chain_ms")),
              (lm.get("u8_hwc_host") or {}).get("fps"), (lm.get("f32_chw_host") or {}).get("fps"),
              {k: (ow.get("cfg3") or {}).get(k) for k in ("fps", "tracker_chain_ms", "launch_list_ms")}, {k: (ow.get("cfg4") or {}).get(k) for k in ("fps", "tracker_chain_ms", "launch_list_ms")}))
 except Exception as e:
