@@ -67,7 +67,7 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
     assert r.returncode == 0 and "--nproc-per-node 2" in " ".join(json.loads(r.stdout.strip().splitlines()[-1])["launch"]), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name,workload", [("r04_bench_line.json", "configs[1]"), ("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),
+@pytest.mark.parametrize("name,workload", [("r06_bench_line.json", "configs[1]"), ("r04_bench_line.json", "configs[1]"), ("r03_bench_line.json", "configs[1]"), ("r02_bench_line.json", "configs[1]"), ("r02_bench_line_cfg3.json", "configs[2]"),
                                            ("r02_bench_line_cfg4.json", "configs[3]")])
 def test_committed_bench_lines_keep_the_contract(name, workload):
     l = _line(name)
@@ -136,3 +136,29 @@ def test_round4_line_measures_what_the_reference_timer_measures():
     t = json.load(open(os.path.join(ROOT, "profiles", "r04_conv_hbm_traffic.json")))
     assert t["launch_list_sha"] == c["launch_list_sha"] and len(t["commit"]) == 40
     assert l["roofline"]["traffic"] is None or abs(l["roofline"]["traffic"] - t["hbm_bytes_per_frame"] * 32 / 1e9) / l["roofline"]["traffic"] < 0.05 or l["roofline"]["traffic"] > 0
+
+
+def test_round6_line_carries_the_coupled_passes_and_says_what_value_is():
+    """round 6: the tracker fed by the step's own NMS rows on the device is TIMED (`coupled`: the rows as they are; `coupled_confident_rows`: with the
+    score gain that gives the tracker the headline's association load), `value` says which pass it is and why, the CPU baseline says why it does not use every core, the
+    roofline object carries the re-measured random-operand ceiling, and the PMC traffic belongs to this very launch list"""
+    l = _line("r06_bench_line.json")
+    assert "never `value`" in l["value_note"] and l["fps_incl_h2d"]["value"] > 0
+    c, cc = l["coupled"], l["coupled_confident_rows"]
+    for v in (c, cc):
+        assert v["fps"] > 0 and v["tracker_status"] == 0 and v["launch_list_ms"] > 0 and v["tracker_chain_ms"] > 0 and v["note"]
+    assert c["score_gain_in_the_handover"] == 1.0 and cc["score_gain_in_the_handover"] > 1.0
+    assert c["nms_rows_per_frame_mean"] > 100                                                     # the tracker reads the full NMS output, most of it below its thresholds
+    assert cc["rows_at_or_above_0.3_0.2_0.15_mean"][1] >= 0.5 * l["config"]["dets_per_frame_timed_mean"]      # ... and with the gain as many confident rows as the scene has detections
+    assert cc["tracks_per_frame_mean"] > c["tracks_per_frame_mean"]
+    b = l["cpu_baseline"]
+    assert b["kind"] == "port" and b["cores"] <= b["host_cpu_count"] and "thrash" in b["why_not_every_core"] and str(b["cores"]) in b["detector_s_per_frame_by_threads"]
+    r = l["roofline"]
+    assert r["sustained_peak"] == 1627.0 and abs(r["frac_of_sustained_peak"] - r["achieved"] / 1627.0) < 1e-3
+    t = json.load(open(os.path.join(ROOT, "profiles", "r06_conv_hbm_traffic.json")))
+    assert t["launch_list_sha"] == l["config"]["launch_list_sha"] and len(t["commit"]) == 40 and t["frames_per_launch_list"] == l["config"]["frames_per_step"]
+    assert r["traffic"] is not None and abs(r["traffic"] - t["hbm_bytes_per_frame"] * 40) / r["traffic"] < 0.05
+    ow = l["other_workloads"]
+    assert ow["cfg3"]["fps"] > 0 and ow["cfg4"]["fps"] > 0 and ow["cfg4"]["roofline_reid"]["frac"] > 0
+    lm = l["latency_mode"]
+    assert lm["u8_hwc_host"]["fps"] > lm["f32_chw_host"]["fps"] > 300
