@@ -152,6 +152,14 @@ nms_gate)
   done
   ;;
 
+latency_prof)
+  say "latency_prof: rocprofv3 kernel stats of the batch-1 latency loop (scripts/latency_mode.py): which kernels a frame's 2.5 ms are"
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/lp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lp -- python $ROOT/scripts/latency_mode.py 40 > $O/latency_prof.log 2>&1
+    f=$(find /tmp/lp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/latency_kernel_stats.csv )
+  head -25 $O/latency_kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3

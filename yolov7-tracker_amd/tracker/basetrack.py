@@ -346,6 +346,7 @@ class BaseTracker(object):
         self._det_host = torch.zeros((self.cap_d, 6), dtype=torch.float32).pin_memory()
         self._det_dev = torch.zeros((self.cap_d, 6), dtype=torch.float32, device="cuda")
         self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._up_stream = self._up_event = None
 
     # ------------------------------------------------------------------------------------------
 
@@ -374,7 +375,15 @@ class BaseTracker(object):
                     raise _lib.Y7TError("%d detections exceed the pool capacity max_dets=%d" % (a.shape[0], self.cap_d))
                 self._det_host[:a.shape[0]].numpy()[...] = a
                 d = self._det_dev[:a.shape[0]]
-                d.copy_(self._det_host[:a.shape[0]], non_blocking=True)
+                # the rows go up on a copy stream of their own and the step waits for that copy's event: beside a detector forward already enqueued on the caller's
+                # stream (track.py's loop, bench.py's latency mode) the upload overlaps it instead of sitting between the forward's last kernel and the step
+                cur = torch.cuda.current_stream()
+                if self._up_stream is None:
+                    self._up_stream, self._up_event = torch.cuda.Stream(), torch.cuda.Event()
+                with torch.cuda.stream(self._up_stream):
+                    d.copy_(self._det_host[:a.shape[0]], non_blocking=True)
+                    self._up_event.record(self._up_stream)
+                cur.wait_event(self._up_event)
             else:
                 d = torch.as_tensor(np.ascontiguousarray(det_results, dtype=np.float32)).cuda()
             d = d.reshape(-1, 6)
