@@ -160,6 +160,15 @@ latency_prof)
   head -25 $O/latency_kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt
   ;;
 
+nms_ab)
+  say "nms_ab: rank sort + kept-list NMS at one frame and at 40 (scripts/time_nms.py): the previous build (lib/liby7t_prev.so) / this one, A/B/A; NMS parity tests"
+  for v in prev new prev2 new2; do
+    case $v in prev*) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_prev.so";; *) E="Y7T_X=0";; esac
+    env $E timeout 300 python scripts/time_nms.py > $O/nms_$v.log 2>&1; echo "--- $v rc=$?" | tee -a $O/summary.txt; grep "^B=" $O/nms_$v.log | cut -c1-200 | tee -a $O/summary.txt
+  done
+  timeout 900 python -m pytest -x -q -m gpu tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -k "nms or boxes or postprocess or candidates" > $O/t_nms.log 2>&1; echo "rc=$?" >> $O/t_nms.log; tailsum $O/t_nms.log 3
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3
