@@ -169,6 +169,14 @@ nms_ab)
   timeout 900 python -m pytest -x -q -m gpu tests/test_detector_gpu.py tests/test_detector_pinned_gpu.py -k "nms or boxes or postprocess or candidates" > $O/t_nms.log 2>&1; echo "rc=$?" >> $O/t_nms.log; tailsum $O/t_nms.log 3
   ;;
 
+nms_prof)
+  say "nms_prof: rocprofv3 kernel stats of scripts/time_nms.py (min = one frame, max = 40 frames)"
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/np
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np -- python $ROOT/scripts/time_nms.py > $O/nms_prof.log 2>&1
+    f=$(find /tmp/np -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/nms_kernel_stats.csv )
+  grep "k_rank_sort\|k_nms_keep" $O/nms_kernel_stats.csv | cut -c1-40,150-260 | tee -a $O/summary.txt
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3

@@ -212,7 +212,7 @@ extern "C" int y7t_det_postprocess(const float* const* head, const int* ny, cons
     Y7T_ARG_CHECK(letterbox && dets && ndets && keep_idx && ws);
     Y7T_ARG_CHECK(head == nullptr || (ny && nx && strides && anchors));
     Y7T_ARG_CHECK(nl >= 1 && nl <= 4 && na >= 1 && na <= 3 && no >= 6 && B >= 1 && cap >= 64 && max_det >= 1 && max_nms >= 1);
-    Y7T_ARG_CHECK(iou_thres >= 0.0f);      // (the NMS skips the division for boxes that do not intersect: exact for a threshold that IoU = 0 does not exceed)
+    Y7T_ARG_CHECK(iou_thres >= 0.0f && conf_thres >= 0.0f);      // (conf_thres >= 0: every candidate score is positive, which the rank sort's bit-pattern keys rely on)      // (the NMS skips the division for boxes that do not intersect: exact for a threshold that IoU = 0 does not exceed)
     Y7TPostArgs a;
     memset(&a, 0, sizeof(a));
     a.predecoded = head == nullptr;

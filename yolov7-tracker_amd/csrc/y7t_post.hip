@@ -377,25 +377,35 @@ __global__ void __launch_bounds__(256) k_decode_filter(const DecodeArgs a, int l
 __global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbox, const float* __restrict__ cscore, const float* __restrict__ ccls,
                                                    const int* __restrict__ cidx, const int* __restrict__ count, int cap, int max_nms,
                                                    float* __restrict__ sbox, int* __restrict__ sorder, int* __restrict__ nsorted, int mcap) {
-    __shared__ float ss[256];
-    __shared__ int si[256];
+    // round 6: (score desc, row index asc) as ONE unsigned 64-bit key -- the score's bit pattern (scores are positive floats: their bit patterns order like their
+    // values) over the complement of the row index -- so a comparison is one LDS read and one 64-bit compare instead of two reads and three compares (k_rank_sort at one
+    // frame: 52 us of the batch-1 frame).  Keys are unique (row indices are), so `>` alone gives the rank; an empty slot has key 0 and outranks nothing.
+    __shared__ unsigned long long sk[256];
     const int b = blockIdx.y;
     int n = count[b]; if (n > cap) n = cap;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256 >= n) return;
     const float* sc = cscore + (size_t)b * cap;
     const int* ix = cidx + (size_t)b * cap;
-    const float my_s = i < n ? sc[i] : 0.f;
-    const int my_i = i < n ? ix[i] : 0;
+    auto key_of = [&](int j) -> unsigned long long {
+        const float v = sc[j];
+        if (!(v > 0.f)) return 0ull;      // (not a candidate score: conf_thres > 0 keeps every real one positive; NaN sorts last)
+        return ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ix[j]);
+    };
+    const unsigned long long my_k = i < n ? key_of(i) : 0ull;
     int rank = 0;
     for (int base = 0; base < n; base += 256) {
         const int j = base + threadIdx.x;
         __syncthreads();
-        ss[threadIdx.x] = j < n ? sc[j] : -1.f;
-        si[threadIdx.x] = j < n ? ix[j] : 0x7fffffff;
+        sk[threadIdx.x] = j < n ? key_of(j) : 0ull;
         __syncthreads();
         const int lim = (n - base) < 256 ? (n - base) : 256;
-        for (int t = 0; t < lim; ++t) rank += (ss[t] > my_s) || (ss[t] == my_s && si[t] < my_i);
+        if (lim == 256) {
+#pragma unroll 8
+            for (int t = 0; t < 256; ++t) rank += sk[t] > my_k;
+        } else {
+            for (int t = 0; t < lim; ++t) rank += sk[t] > my_k;
+        }
     }
     if (i < n && rank < max_nms) {
         const float off = ccls[(size_t)b * cap + i] * 4096.f;
@@ -431,10 +441,11 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
                                                   const float* __restrict__ cbox, const float* __restrict__ cscore, const float* __restrict__ ccls, int cap,
                                                   int mcap, float thr, int max_det, const float* __restrict__ lb /*[B][5] gain,padw,padh,H0,W0*/,
                                                   float* __restrict__ dets /*[B][max_det][6]*/, int* __restrict__ ndets, int* __restrict__ keep_idx /*[B][max_det]*/) {
-    extern __shared__ float ksm[];                 // kept boxes [max_det][4] | areas [max_det]
+    extern __shared__ float ksm[];                 // kept boxes [max_det][4] | areas [max_det] | their positions in the sorted list [max_det]
     __shared__ int s_nkeep;
     float* kbox = ksm;
     float* karea = ksm + 4 * max_det;
+    int* kidx = (int*)(ksm + 5 * max_det);         // (round 6: the keep loop's global store per kept box moved out of the serial chain)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = nsorted[b];
     const float* sb = sbox + (size_t)b * mcap * 4;
@@ -487,7 +498,7 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
                     if (lane == t) {
                         kbox[4 * nk] = bx[0]; kbox[4 * nk + 1] = bx[1]; kbox[4 * nk + 2] = bx[2]; kbox[4 * nk + 3] = bx[3];
                         karea[nk] = area;
-                        keep_idx[(size_t)b * max_det + nk] = i;
+                        kidx[nk] = i;
                         alive = false;
                     }
                     ++nk;
@@ -506,7 +517,7 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
     const int* so = sorder + (size_t)b * mcap;
     const float gain = lb[b * 5 + 0], padw = lb[b * 5 + 1], padh = lb[b * 5 + 2], H0 = lb[b * 5 + 3], W0 = lb[b * 5 + 4];
     for (int k = tid; k < nkeep; k += 256) {
-        const int i = so[keep_idx[(size_t)b * max_det + k]];
+        const int i = so[kidx[k]];
         const float* bo = cbox + ((size_t)b * cap + i) * 4;
         float x1 = (bo[0] - padw) / gain, y1 = (bo[1] - padh) / gain, x2 = (bo[2] - padw) / gain, y2 = (bo[3] - padh) / gain;
         x1 = fminf(fmaxf(x1, 0.f), W0); x2 = fminf(fmaxf(x2, 0.f), W0);
@@ -515,8 +526,7 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
         o[0] = rintf(x1); o[1] = rintf(y1); o[2] = rintf(x2); o[3] = rintf(y2);
         o[4] = cscore[(size_t)b * cap + i]; o[5] = ccls[(size_t)b * cap + i];
     }
-    __syncthreads();
-    for (int k = tid; k < nkeep; k += 256) keep_idx[(size_t)b * max_det + k] = so[keep_idx[(size_t)b * max_det + k]];   // candidate slots, for callers that want raw boxes
+    for (int k = tid; k < nkeep; k += 256) keep_idx[(size_t)b * max_det + k] = so[kidx[k]];   // candidate slots, for callers that want raw boxes
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -546,9 +556,9 @@ Y7TCandWs y7t_post_cand_ws(void* ws, int B, int cap) {
 
 int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     const int B = a.B, cap = a.cap;
-    if (a.max_det <= 0 || (size_t)a.max_det * 5 * sizeof(float) > 60u * 1024u) {      // k_nms_keep holds the kept boxes in LDS: 20 bytes each
+    if (a.max_det <= 0 || (size_t)a.max_det * 6 * sizeof(float) > 60u * 1024u) {      // k_nms_keep holds the kept boxes in LDS: 24 bytes each (box, area, position)
         y7t_set_error("postprocess: max_det = %d outside (0, %d] (the kept-list NMS keeps max_det boxes in LDS; the reference uses 300, general.py:619)",
-                      a.max_det, (int)(60u * 1024u / (5 * sizeof(float))));
+                      a.max_det, (int)(60u * 1024u / (6 * sizeof(float))));
         return Y7T_E_ARG;
     }
     const size_t mcap = (size_t)(cap < a.max_nms ? cap : a.max_nms);
@@ -585,7 +595,7 @@ int y7t_post_run(const Y7TPostArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_rank_sort, dim3((cap + 255) / 256, B), dim3(256), 0, s, cbox, cscore, ccls, cidx, count, cap, a.max_nms, sbox, sorder, nsorted, (int)mcap);
     Y7T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_keep, dim3(B), dim3(256), (size_t)a.max_det * 5 * sizeof(float), s, sbox, nsorted, sorder, cbox, cscore, ccls, cap, (int)mcap,
+    hipLaunchKernelGGL(k_nms_keep, dim3(B), dim3(256), (size_t)a.max_det * 6 * sizeof(float), s, sbox, nsorted, sorder, cbox, cscore, ccls, cap, (int)mcap,
                        a.iou_thres, a.max_det, lb, a.dets, a.ndets, a.keep_idx);
     Y7T_LAUNCH_CHECK();
     if (a.count_out) Y7T_HIP_CHECK(hipMemcpyAsync(a.count_out, count, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
