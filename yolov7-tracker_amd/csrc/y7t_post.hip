@@ -490,6 +490,22 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
             for (; k < k1; ++k) dead |= nms_overlaps(kbox + 4 * k, karea[k], bx[0], bx[1], bx[2], bx[3], area, thr);
             return dead;
         };
+        // the wave's own pairs, ahead of its turn: bit j of `ov` = THIS lane's box, were it kept, suppresses candidate j of the wave (j > lane) -- the very test the
+        // keep loop used to make per kept box (kept box first, candidate second: aa + ab - inter in that order).  Built once, over the lanes that are alive at that
+        // moment (a lane that dies later only leaves bits nobody reads), while the wave would otherwise wait; the keep loop is then scalar bit arithmetic.
+        unsigned long long ov = 0ull;
+        bool have_ov = false;
+        auto build_ov = [&]() {
+            unsigned long long it = __ballot(alive);
+            while (it) {
+                const int j = __ffsll((long long)it) - 1;
+                it &= it - 1ull;
+                auto rl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
+                const float jx1 = rl(bx[0]), jy1 = rl(bx[1]), jx2 = rl(bx[2]), jy2 = rl(bx[3]), ja = rl(area);
+                if (alive && lane < j && nms_overlaps(bx, area, jx1, jy1, jx2, jy2, ja, thr)) ov |= 1ull << j;
+            }
+            have_ov = true;
+        };
         int tested = 0, nk = 0, turn = 0;
         for (;;) {                                 // (uniform over the wave: turn / nk are workgroup-scope atomic loads of one word each)
             turn = __hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);      // the turn FIRST: whatever it shows, the kept boxes of every chunk in front of it are published
@@ -497,29 +513,36 @@ __global__ void __launch_bounds__(256) k_nms_keep(const float* __restrict__ sbox
             if (nk > tested) {
                 if (alive && against_kept(tested, nk)) alive = false;
                 tested = nk;
-            } else if (turn != c && turn != kTurnDone) __builtin_amdgcn_s_sleep(2);
+            } else if (turn != c && turn != kTurnDone) {
+                if (!have_ov) build_ov();          // nothing new to test against: the wave's own pairs now
+                else __builtin_amdgcn_s_sleep(2);
+            }
             if (turn == c || turn == kTurnDone) break;
         }
         if (turn == kTurnDone) break;              // max_det boxes are kept: nothing behind them is looked at (general.py:684-685)
-        {   // my turn: every chunk in front of this one is final and tested against; resolve the wave's 64 candidates with ballots (the first alive lane is kept, the later
-            // lanes test against it, repeat)
-            unsigned long long m = __ballot(alive);
-            while (m && nk < max_det) {
-                const int t = __ffsll((long long)m) - 1;
-                // (t is wave-uniform: the kept lane's box through the scalar registers -- v_readlane -- instead of five ds_bpermute round trips per keep)
-                auto rl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t)); };
-                const float tx1 = rl(bx[0]), ty1 = rl(bx[1]), tx2 = rl(bx[2]), ty2 = rl(bx[3]), ta = rl(area);
-                if (lane == t) {
-                    kbox[4 * nk] = bx[0]; kbox[4 * nk + 1] = bx[1]; kbox[4 * nk + 2] = bx[2]; kbox[4 * nk + 3] = bx[3];
-                    karea[nk] = area;
-                    kidx[nk] = i;
-                    alive = false;
-                }
-                ++nk;
-                const float kb[4] = {tx1, ty1, tx2, ty2};
-                if (alive && lane > t && nms_overlaps(kb, ta, bx[0], bx[1], bx[2], bx[3], area, thr)) alive = false;
-                m = __ballot(alive) & ~((2ull << t) - 1ull);
+        {   // my turn: every chunk in front of this one is final and tested against.  The greedy walk over the wave's 64 candidates: the first alive lane is kept, the
+            // candidates its box suppresses (its row of `ov`, fetched through the scalar registers) leave the alive set, repeat -- scalar bit arithmetic, ~10 instructions
+            // per kept box where the loop used to be five lane broadcasts, an overlap test with its division and a ballot.  The kept lanes then write their boxes at once.
+            if (!have_ov) build_ov();
+            unsigned long long am = __ballot(alive), kept = 0ull;
+            int nk1 = nk;
+            const unsigned ov_lo = (unsigned)ov, ov_hi = (unsigned)(ov >> 32);
+            while (am && nk1 < max_det) {
+                const int t = __ffsll((long long)am) - 1;
+                const unsigned long long row = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ov_lo, t) |
+                                               ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ov_hi, t) << 32);
+                kept |= 1ull << t;
+                ++nk1;
+                am &= ~row;
+                am &= ~(1ull << t);
             }
+            if ((kept >> lane) & 1ull) {
+                const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+                kbox[4 * pos] = bx[0]; kbox[4 * pos + 1] = bx[1]; kbox[4 * pos + 2] = bx[2]; kbox[4 * pos + 3] = bx[3];
+                karea[pos] = area;
+                kidx[pos] = i;
+            }
+            nk = nk1;
             // publish: the boxes, then their count, then the turn (release: a wave that sees the count sees the boxes; one that sees the turn sees the count)
             if (lane == 0) {
                 __hip_atomic_store(&s_nkeep, nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
