@@ -394,11 +394,13 @@ __global__ void __launch_bounds__(256) k_rank_sort(const float* __restrict__ cbo
     };
     const unsigned long long my_k = i < n ? key_of(i) : 0ull;
     int rank = 0;
+    unsigned long long nxt = (int)threadIdx.x < n ? key_of(threadIdx.x) : 0ull;      // the next chunk's key: its two global loads are in flight while the current chunk is compared
     for (int base = 0; base < n; base += 256) {
-        const int j = base + threadIdx.x;
         __syncthreads();
-        sk[threadIdx.x] = j < n ? key_of(j) : 0ull;
+        sk[threadIdx.x] = nxt;
         __syncthreads();
+        const int jn = base + 256 + threadIdx.x;
+        nxt = jn < n ? key_of(jn) : 0ull;
         const int lim = (n - base) < 256 ? (n - base) : 256;
         if (lim == 256) {
 #pragma unroll 8
