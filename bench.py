@@ -788,7 +788,7 @@ def main():
         return
     # the forward's stream gets the high hardware priority: its workgroups are dispatched ahead of the NMS / tracker kernels that run beside it
     sA = torch.cuda.Stream(priority=-1) if args.prio == 1 else torch.cuda.Stream()
-    sB, sC, sH = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    sB, sC, sH = (torch.cuda.Stream(priority=-1) if args.prio == 2 else torch.cuda.Stream()), torch.cuda.Stream(), torch.cuda.Stream()
     if args.cu_reserve > 0:    # the tracker chain on compute units of its own (include/y7t.h: y7t_stream_create_cu_mask)
         from yolov7_tracker_amd import _lib as _y7t_lib
         sA, sB = _y7t_lib.cu_masked_streams(args.cu_reserve)

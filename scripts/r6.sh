@@ -177,6 +177,14 @@ nms_prof)
   grep "k_rank_sort\|k_nms_keep" $O/nms_kernel_stats.csv | cut -c1-40,150-260 | tee -a $O/summary.txt
   ;;
 
+prio_ab)
+  say "prio_ab: the tracker chain's stream at high queue priority (bench.py --prio 2) against the default, cfg4 / cfg3 / cfg2, A/B/A"
+  for wl in cfg4 cfg3 cfg2; do for v in 0 2 0b; do
+    timeout 600 python bench.py --workload $wl --steps 8 --warmup 3 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled --prio ${v%b} > $O/bench_prio_${wl}_$v.json 2> $O/bench_prio_${wl}_$v.err; echo "$wl prio $v rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_prio_${wl}_$v.json
+  done; done
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3
