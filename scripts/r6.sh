@@ -185,6 +185,14 @@ prio_ab)
   done; done
   ;;
 
+cu_reserve_cfg4)
+  say "cu_reserve_cfg4: the tracker chain's stream on reserved CUs (bench.py --cu_reserve N) for cfg4 (four dependent launches per frame) and cfg3, against the default"
+  for wl in cfg4 cfg3; do for v in 0 2 8 0b; do
+    timeout 600 python bench.py --workload $wl --steps 8 --warmup 3 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled --cu_reserve ${v%b} > $O/bench_cur_${wl}_$v.json 2> $O/bench_cur_${wl}_$v.err; echo "$wl cu_reserve $v rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_cur_${wl}_$v.json
+  done; done
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3
