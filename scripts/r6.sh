@@ -10,6 +10,10 @@
 #   bench        the driver's bench line -> bench_line.json
 #   perlayer     per-op table of the launch list (scripts/per_layer_table.sh)
 #   profile      rocprofv3 kernel stats of the bench command + PMC passes (gpu_round.sh profile)
+#   owncu_ab / hipgraph2 / mfma_ceiling / detect_nst / splitk_b1 / latency / tracker_phases / tests_tracker / tests_fullsize / nms_gate / prio_ab / cu_reserve_cfg4
+#                the round's small experiments (profiles/r06_small_experiments.txt says what each one measured)
+#   latency_prof / nms_ab / nms_prof   the batch-1 frame under rocprofv3; rank sort + NMS alone (scripts/time_nms.py) against lib/liby7t_prev.so (a copy of an earlier
+#                build: `git stash; python -m yolov7_tracker_amd.build --product-only; cp lib/liby7t.so lib/liby7t_prev.so; git stash pop; rebuild`)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${TAG:-r6}
