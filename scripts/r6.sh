@@ -197,6 +197,16 @@ cu_reserve_cfg4)
   done; done
   ;;
 
+reduce_ab)
+  say "reduce_ab: k_splitk_reduce with its slab loads issued four at a time against the previous build (lib/liby7t_prev.so): batch-1 per-op tables A/B/A, layer parity tests"
+  for v in prev new prev2 new2; do
+    case $v in prev*) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_prev.so";; *) E="Y7T_X=0";; esac
+    env $E B=1 NAME=b1_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b1_$v.log 2>&1
+    echo "--- $v" | tee -a $O/summary.txt; tail -1 $O/per_layer_b1_$v.txt | tee -a $O/summary.txt
+  done
+  timeout 900 python -m pytest -x -q -m gpu tests/test_detector_gpu.py -k "conv or split or layer" > $O/t_conv.log 2>&1; echo "rc=$?" >> $O/t_conv.log; tailsum $O/t_conv.log 3
+  ;;
+
 tests_fullsize)
   say "tests_fullsize: BASELINE-size properties incl. cfg3 (300 frames x 500 objects, BoT-SORT) against the oracle"
   timeout 1500 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py > $O/t_fullsize.log 2>&1; echo "rc=$?" >> $O/t_fullsize.log; tailsum $O/t_fullsize.log 3

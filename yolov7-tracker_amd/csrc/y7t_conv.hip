@@ -465,11 +465,18 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
         const int m = (int)(t / c4), n = (int)(t - (long long)m * c4) * 4;
         if (n >= Cout) continue;
         typedef __attribute__((ext_vector_type(4))) float float4v;
-        float4v a = *(const float4v*)(partial + (size_t)m * Cout_pad + n);
-        for (int s = 1; s < S; ++s) {
-            const float4v b = *(const float4v*)(partial + ((size_t)s * M + m) * Cout_pad + n);
-            a += b;
+        // the slabs are summed in split order (deterministic), but their loads are issued four at a time: with one load per trip the loop paid a memory round trip per
+        // slab -- S = 4 .. 16 of them in a row in a kernel that has nothing else to do (round 6: 56 of these launches are 13 % of the batch-1 frame)
+        const float* p0 = partial + (size_t)m * Cout_pad + n;
+        const size_t slab = (size_t)M * Cout_pad;
+        float4v a = *(const float4v*)p0;
+        int s = 1;
+        for (; s + 4 <= S; s += 4) {
+            const float4v b0 = *(const float4v*)(p0 + (size_t)s * slab), b1 = *(const float4v*)(p0 + (size_t)(s + 1) * slab);
+            const float4v b2 = *(const float4v*)(p0 + (size_t)(s + 2) * slab), b3 = *(const float4v*)(p0 + (size_t)(s + 3) * slab);
+            a += b0; a += b1; a += b2; a += b3;
         }
+        for (; s < S; ++s) a += *(const float4v*)(p0 + (size_t)s * slab);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fn(a[e] + bias[n + e], act);
