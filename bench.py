@@ -40,8 +40,11 @@ GFLOP_PER_FRAME_W6 = 354.9   # 177.45 GMAC x 2, yolov7-w6 deploy g
 # Frames per step.  Every kernel of the list that runs several workgroups per CU pays for its last, partly filled round of workgroups; how much depends on the batch:
 # at 32 frames the 80 x 80 layers have 25 x 32 pixel tiles x 2 channel tiles = 1600 workgroups on 512 slots (3.125 rounds -> 4), the 40 x 40 strips 663 on 512 (1.3 -> 2).
 # Measured in one session (profiles/r05_batch_and_latency.txt): 24 frames 0.3051 of the MFMA peak, 32 frames 0.3194 / 0.3200, 40 frames 0.3250 (2207 vs 2169 fps).
-# 40 is also the ceiling: the 640 x 640 x 64-channel tensor of 41 frames would pass the 2 GiB a buffer descriptor's 32-bit byte offsets reach (detector/model.py).
-DEFAULT_BATCH = 40
+# Round 6: 40 was the ceiling while a batch had to keep every tensor below the 2 GiB a buffer descriptor's 32-bit byte offsets reach (the 640 x 640 x 64-channel tensor of 41
+# frames passes it); now a conv whose tensors are larger goes out as several launches over runs of frames (csrc/y7t_detector.hip::forward_impl) and one session measured
+# 40 frames 0.3197 / 0.3194, 48 0.3274, 56 0.3300, 64 0.3343 / 0.3331, 80 0.3390, 96 0.3408, 128 0.3429 (profiles/r06_batch_80.txt): 80 is where the curve bends
+# (the 20 x 20 layers are then 250 / 500 tiles on 256 CUs x 1 / 2 slots, the 40 x 40 strips 6.5 rounds).
+DEFAULT_BATCH = 80
 
 
 def parse():

@@ -27,11 +27,12 @@ for i in range(N):
     torch.cuda.synchronize()
 p = det.plan
 ops, ci = [], 0
+n_launches = det.launches_per_op(B)      # (a conv whose tensors pass 2 GiB at B frames: several launches over runs of frames)
 for oi, op in enumerate(p.ops):
     if int(op["type"]) == 0 and int(op["detect_level"]) >= 0 and p.fusable:
         nst = 4 if (B * int(op["Ho"]) * int(op["Wo"]) + 127) // 128 <= 4096 and os.environ.get("Y7T_CONV_DETECT_NST", "4") == "4" else 2      # (csrc/y7t_conv.hip::conv_dispatch, the Detect branch)
         names[oi] = "igemm<128,64,32,%d> 1x1 detect-decode" % nst      # (launch_list probes the ops in plain mode; the fused forward never splits K here)
-    d = {"op": oi, "kernel": names[oi], "H": int(op["H"]), "W": int(op["W"]), "Cin": int(op["Cin"]), "Cout": int(op["Cout"]), "k": int(op["KH"]), "s": int(op["stride"])}
+    d = {"op": oi, "kernel": names[oi], "H": int(op["H"]), "W": int(op["W"]), "Cin": int(op["Cin"]), "Cout": int(op["Cout"]), "k": int(op["KH"]), "s": int(op["stride"]), "launches": n_launches[oi]}
     if int(op["type"]) == 0:
         wl = p.wlayout[ci]; ci += 1
         macs = wl["macs"]

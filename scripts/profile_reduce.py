@@ -71,6 +71,8 @@ try:
             lines.append("%3d %-44s %4dx%-4d %4d->%-4d %d/%d %9s    (in the launch of the row above)" % (op["op"], op["kernel"], op["H"], op["W"], op["Cin"], op["Cout"], op["k"], op["s"], "-"))
             continue
         r, d = next(it)
+        for _ in range(int(op.get("launches", 1)) - 1):      # a conv that went out as several launches over runs of frames (tensors above 2 GiB)
+            d += next(it)[1]
         if "k_spp3" in r["Kernel_Name"]:
             spp_skip = 2
             op = dict(op, kernel="spp3<5,5,5> lds")

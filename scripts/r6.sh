@@ -8,6 +8,7 @@
 #   time_large   scripts/time_large_components.py: step time of frames on each fallback (large component on a wave, literal re-solve at 160 / 320 / 500 rows + columns)
 #   suite        the whole `-m gpu` suite as the driver runs it
 #   bench        the driver's bench line -> bench_line.json
+#   batch_sweep  frames per step 40 / 48 / 56 / 64 (convs over runs of frames past 2 GiB)
 #   perlayer     per-op table of the launch list (scripts/per_layer_table.sh)
 #   profile      rocprofv3 kernel stats of the bench command + PMC passes (gpu_round.sh profile)
 #   owncu_ab / hipgraph2 / mfma_ceiling / detect_nst / splitk_b1 / latency / tracker_phases / tests_tracker / tests_fullsize / nms_gate / prio_ab / cu_reserve_cfg4
@@ -70,6 +71,30 @@ bench)
   say "bench: python bench.py --steps 20 --warmup 5"
   timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; echo "rc=$?" | tee -a $O/summary.txt
   benchline $O/bench_line.json
+  ;;
+
+batch_sweep)
+  say "batch_sweep: frames per step above the 40 that 2 GiB tensors allowed (conv launches over runs of frames, csrc/y7t_detector.hip): the chunk test, then the headline at 40 / 48 / 56 / 64 / 40"
+  timeout 600 python -m pytest -x -q -m gpu tests/test_fullsize_gpu.py -k "runs_of_frames" > $O/t_runs.log 2>&1; echo "rc=$?" >> $O/t_runs.log; tailsum $O/t_runs.log 3
+  for b in ${SWEEP:-40 48 56 64 40}; do
+    timeout 900 python bench.py --steps 12 --warmup 4 --batch $b --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled > $O/bench_b$b.json 2> $O/bench_b$b.err; echo "b$b rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_b$b.json; tail -2 $O/bench_b$b.err | cut -c1-300
+  done
+  ;;
+
+perlayer_b)
+  say "perlayer_b: per-op tables at B=${B:-80} frames: the default lowering, every eligible 1x1 on p8 (Y7T_CONV_P8=all), 64-row panels kept for the small maps (as at 40 frames)"
+  E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so"
+  for v in ${VARIANTS:-default p8all panel64}; do
+    case $v in default) X="";; p8all) X="Y7T_CONV_P8=all";; p8t200) X="Y7T_CONV_P8=all Y7T_CONV_P8_MIN_TILES=200";; panel64) X="Y7T_CONV_PATCH_PANEL64_BELOW=512 Y7T_CONV_1X1_PANEL64_BELOW=1000";; esac
+    env $E $X B=${B:-80} NAME=b${B:-80}_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b${B:-80}_$v.log 2>&1
+    echo "--- $v" | tee -a $O/summary.txt; tail -1 $O/per_layer_b${B:-80}_$v.txt | tee -a $O/summary.txt
+  done
+  ;;
+
+tests_pinned)
+  say "tests_pinned: the pinned-configuration detector tests (80 frames) + the full-size property tests"
+  timeout 2400 python -m pytest -x -q -m gpu tests/test_detector_pinned_gpu.py tests/test_fullsize_gpu.py > $O/t_pinned.log 2>&1; echo "rc=$?" >> $O/t_pinned.log; tailsum $O/t_pinned.log 4
   ;;
 
 bench_quick)

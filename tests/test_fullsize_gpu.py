@@ -22,6 +22,36 @@ def test_w6_1280_batch_permutation_is_exact():
     assert sum(int(x[0].numel()) for x in a) == 102000 * 15            # (160^2 + 80^2 + 40^2 + 20^2) * 3 anchors * (5 + nc)
 
 
+def test_w6_1280_batch_above_2_gib_tensors_goes_out_in_runs_of_frames():
+    """44 frames of 1280 x 1280: the 640^2 x 64 and 320^2 x 256 tensors are 2.3 GB, past the 2 GiB a 32-bit byte offset reaches, so the stem and the first
+    ELAN block go out as two launches over 22 frames each (csrc/y7t_detector.hip::forward_impl).  The same frame in run 0 and in run 1 gives the same heads bit
+    for bit, a rotation of the batch that moves every frame to another position (and 19 of them to the other run) gives the rotated heads, and the first frames
+    equal what a two-frame detector computes for them within the same-precision bar of the whole-network tests (another lowering: tile counts, split-K)."""
+    from yolov7_tracker_amd.detector import arch, model
+    B = 44
+    det = model.Detector(arch.ARCHS["yolov7-w6"](10), None, img_size=(1280, 1280), max_batch=B, seed=0)
+    assert max(det.launches_per_op(B)) == 2 and det.launches_per_op(40) == [1] * len(det.plan.ops)
+    f = torch.randint(0, 256, (B, 1280, 1280, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(12))
+    f[B - 1] = f[0]
+    f[30] = f[5]
+    f = f.cuda()
+    a = [t.clone() for t in det(f)[0].raw()]
+    for x in a:
+        assert x.shape[0] == B and torch.isfinite(x).all() and float(x.float().std()) > 0
+        assert torch.equal(x[B - 1], x[0]) and torch.equal(x[30], x[5]) and not torch.equal(x[1], x[0])
+    b = det(f.roll(19, 0).contiguous())[0].raw()
+    for x, y in zip(a, b):
+        assert torch.equal(x.roll(19, 0), y)
+    del det
+    det2 = model.Detector(arch.ARCHS["yolov7-w6"](10), None, img_size=(1280, 1280), max_batch=2, seed=0)
+    c = det2(f[:2].contiguous())[0].raw()
+    for x, y in zip(a, c):
+        d, scale = (x[:2].float() - y.float()).abs(), float(y.float().std())
+        # (the bar of test_whole_network_heads_match_oracle for two runs at the same storage precision whose summation orders differ: a randomly initialised
+        #  network amplifies one-ulp fp16 flips 1.1-1.3 x per layer; measured here: mean 1.1 % of the logit spread)
+        assert float(d.mean()) < 3e-2 * scale and float(d.max()) < 0.5 * scale, (float(d.mean()), float(d.max()), scale)
+
+
 @pytest.mark.parametrize("shape", [(320, 320, 64, 64), (80, 80, 256, 256), (40, 40, 384, 384), (320, 320, 256, 128)])
 def test_conv_layer_is_linear_at_full_size(shape):
     """conv(2 x) == 2 conv(x) exactly (powers of two commute with every rounding) for full-size layers of the w6 list at 8 frames:

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_c64_ws(const Y7TConvArgs p) 
     int nt = DYN ? 0 : ((ptiles - pt_first) < per ? (ptiles - pt_first) : per);
     if (!DYN && nt <= 0) return;
     constexpr int CH = C::CH;
-    const unsigned magic_x = 0xFFFFFFFFu / (unsigned)tiles_x + 1u, magic_y = 0xFFFFFFFFu / (unsigned)tiles_y + 1u;      // exact quotients for numerators < 2^16 (the launcher checks)
+    const unsigned magic_x = 0xFFFFFFFFu / (unsigned)tiles_x + 1u, magic_y = 0xFFFFFFFFu / (unsigned)tiles_y + 1u;      // exact quotients for numerator x divisor < 2^32 (the launcher checks)
     volatile LDS_AS int* const ring = (volatile LDS_AS int*)(smem + C::RING_OFF);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
@@ -429,7 +429,8 @@ int y7t_conv_ws_launch(const Y7TConvArgs& a, hipStream_t s) {
     const int ptiles = a.B * ((a.H + C::TH - 1) / C::TH) * ((a.W + C::TW - 1) / C::TW);
     static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied a tile counter (A/B)
     if (dyn_env < 0) dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);
-    const bool dyn = a.tile_ctr && dyn_env && ptiles < 65536;
+    // (the kernel's quotients by tiles_x / tiles_y are __umulhi(n, 0xFFFFFFFF / d + 1): exact for n * d < 2^32 -- d <= 1024 here: maps of <= 16384 pixels a side)
+    const bool dyn = a.tile_ctr && dyn_env && ptiles < (1 << 22) && a.H <= 16384 && a.W <= 16384;
     const int nchunks = (ptiles + C::CH - 1) / C::CH;
     const int grid = dyn ? (nchunks < ncu ? nchunks : ncu) : (ptiles < ncu ? ptiles : ncu);
 #if Y7T_ABLATE      // liby7t_ablate.so only: the timing ablations of the SiLU instance (wrong results; scripts/ws_probe.py)

@@ -376,7 +376,9 @@ static int ws128_go(const Y7TConvArgs& a, hipStream_t s) {
     const int ptiles = a.B * (a.Ho / C::TH) * (a.Wo / C::TW);
     static int dyn_env = -1;      // Y7T_CONV_WS_DYN=0: static partition although the caller supplied tile counters (A/B)
     if (dyn_env < 0) dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);
-    const bool dyn = a.tile_ctr && dyn_env && n_nt <= C::MAX_NT && ptiles < 60000;
+    // (the kernel's quotients by tiles_x / tiles_y are __umulhi(n, 0xFFFFFFFF / d + 1): exact for n * d < 2^32 -- d <= 1024 here: maps of <= 4096 pixels a side.  Through
+    //  round 5 the bound was 60000 tiles, which the 320^2 stride-2 layer passes at 75 frames)
+    const bool dyn = a.tile_ctr && dyn_env && n_nt <= C::MAX_NT && ptiles < (1 << 22) && a.H <= 4096 && a.W <= 4096;
     const int units = dyn ? (ptiles + C::CH - 1) / C::CH : ptiles;      // what a workgroup starts on: a chunk, or a tile
     int grid = units * n_nt < ncu ? units * n_nt : ncu;
     if (grid < n_nt) grid = n_nt;

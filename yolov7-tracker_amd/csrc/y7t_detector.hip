@@ -134,7 +134,23 @@ static int forward_impl(y7t_det* d, int B, int first, int last, const Y7TFused* 
                 q.conf_thres = fused->conf_thres; q.cap = fused->cap;
                 q.cbox = fused->ws.cbox; q.cscore = fused->ws.cscore; q.ccls = fused->ws.ccls; q.cidx = fused->ws.cidx; q.count = fused->ws.count;
             }
-            rc = y7t_conv_launch(a, s);
+            // frames per launch: the kernels address a tensor through 32-bit byte offsets (2 GiB); a batch whose input or output tensor is larger goes out as several launches
+            // over consecutive runs of frames (batch-major NHWC: a run of frames is a contiguous piece of every tensor of the op) -- the 640^2 / 320^2 layers of w6 @ 1280
+            // above 40 frames, thousands of tiles each, so nothing is lost to the extra launch; the tile counters are zero again when a launch ends
+            const long long f_in = (long long)op.H * op.W * op.in_ld * 2, f_out = (long long)op.Ho * op.Wo * op.out_ld * (op.out_f32 ? 4 : 2);
+            const long long f_in2 = op.up_C > 0 ? (long long)(op.H / 2) * (op.W / 2) * op.up_ld * 2 : 0;
+            const long long f_max = f_in > f_out ? f_in : f_out, lim = (1ll << 31) - 1;
+            if (f_max > lim) { y7t_set_error("conv: one frame of op %d is larger than 2 GiB", oi); return Y7T_E_ARG; }
+            const int n_runs = (int)(((long long)B * f_max + lim - 1) / lim), run = (B + n_runs - 1) / n_runs;
+            if (n_runs > 1 && a.epi) { y7t_set_error("fused Detect: op %d would need %d launches per batch (candidate rows are indexed by the frame of the launch)", oi, n_runs); return Y7T_E_ARG; }
+            for (int b0 = 0; b0 < B && rc == 0; b0 += run) {
+                const int nb = B - b0 < run ? B - b0 : run;
+                a.in = (const _Float16*)((const char*)in + b0 * f_in);
+                a.out = (char*)outp + b0 * f_out;
+                if (op.up_C > 0) a.in2 = (const _Float16*)(d->arena + d->bufs[op.up_buf] + b0 * f_in2);
+                a.B = nb; a.M = nb * op.Ho * op.Wo;
+                rc = y7t_conv_launch(a, s);
+            }
         } else if (op.type == Y7T_OP_UPSAMPLE2X) {
             rc = y7t_upsample_launch(in, op.in_ld, op.in_coff, B, op.H, op.W, op.Cin, (_Float16*)outp, op.out_ld, op.out_coff, s);
         } else {
@@ -178,8 +194,17 @@ extern "C" int y7t_det_forward_stem_u8(y7t_det* d, const void* frames_u8, int B,
     const y7t_op& op = d->ops[0];
     const int H = op.H * 2, W = op.W * 2;
     Y7T_ARG_CHECK(top + new_h <= H && left + new_w <= W);
-    return y7t_stem_u8_launch(frames_u8, B, H0, W0, H, W, new_h, new_w, top, left, d->w + op.w_off, op.K_pad, d->bias + op.bias_off,
-                              (_Float16*)(d->arena + d->bufs[op.out_buf]), op.out_ld, op.out_coff, op.act, (hipStream_t)stream);
+    // (frames per launch as in forward_impl: the stem's output tensor passes 2 GiB at 41 frames of 1280 x 1280)
+    const long long f_out = (long long)op.H * op.W * op.out_ld * 2, f_in = (long long)H0 * W0 * 3, lim = (1ll << 31) - 1;
+    const long long f_max = f_out > f_in ? f_out : f_in;
+    Y7T_ARG_CHECK(f_max <= lim);
+    const int n_runs = (int)(((long long)B * f_max + lim - 1) / lim), run = (B + n_runs - 1) / n_runs;
+    for (int b0 = 0; b0 < B; b0 += run) {
+        const int nb = B - b0 < run ? B - b0 : run;
+        if (int rc = y7t_stem_u8_launch((const char*)frames_u8 + b0 * f_in, nb, H0, W0, H, W, new_h, new_w, top, left, d->w + op.w_off, op.K_pad, d->bias + op.bias_off,
+                                        (_Float16*)(d->arena + d->bufs[op.out_buf] + b0 * f_out), op.out_ld, op.out_coff, op.act, (hipStream_t)stream)) return rc;
+    }
+    return 0;
 }
 
 extern "C" int y7t_det_set_detect(y7t_det* d, int nl, int na, int no, const float* strides, const float* anchors) {

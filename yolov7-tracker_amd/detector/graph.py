@@ -138,13 +138,13 @@ class Plan:
 
 
 def patch_panel_rows(H, W, cout, B):
-    """rows of a weight panel (= output channels of a workgroup) of the LDS-patch kernel: 128 when Cout allows -- unless that leaves fewer than 256 workgroups of
+    """rows of a weight panel (= output channels of a workgroup) of the LDS-patch kernel: 128 when Cout allows -- unless that leaves fewer than 512 workgroups of
     256 pixels for the whole batch: then 64 (korder 9), twice the workgroups.  Measured at 32 frames (round 4, profiles/r04_smallmap_patch.txt): the 20x20 layers with
     256 output channels 71 -> 51 us and 39 -> 28 us against the generic kernel, 61 / 36 us with 128-row panels.  Y7T_CONV_PATCH_PANEL64_BELOW=0 switches the rule off."""
     cout_pad = -(-cout // 64) * 64
     if cout_pad % 128:
         return 64
-    below = int(_lib.switch("Y7T_CONV_PATCH_PANEL64_BELOW", "256"))
+    below = int(_lib.switch("Y7T_CONV_PATCH_PANEL64_BELOW", "512"))      # (round 6, 80 frames: the 20 x 20 512 -> 512 layers at 500 tiles 167 -> 159 us on 64-row panels; round 5 at 40 frames: 250 tiles, 104 -> 95 us)
     return 64 if B * H * W // 256 * (cout_pad // 128) < below else 128
 
 
@@ -222,9 +222,12 @@ def p8_eligible(H, W, cin, cout, k, s, out_ld, out_coff, out_f32, in_ld, in_coff
         return False
     tiles = -(-(B * H * W) // 256) * (cout // 256 if cout % 256 == 0 else 0)
     ok = (k == 1 and s == 1 and cin % 64 == 0 and cout % 256 == 0 and not out_f32 and out_ld % 8 == 0 and out_coff % 8 == 0 and in_ld % 8 == 0 and in_coff % 8 == 0
-          and tiles >= int(_lib.switch("Y7T_CONV_P8_MIN_TILES", "256")))
+          and tiles >= int(_lib.switch("Y7T_CONV_P8_MIN_TILES", "230")))
     if mode != "all" and _lib.switch("Y7T_CONV_P8_MIN_TILES", None) is None:      # (through the same gate as the threshold: an experiment variable in the environment does not change the PRODUCT's lowering)
-        ok = ok and (cin >= 1024 or (cin >= 512 and tiles >= 3000))
+        fill = tiles / float(max(1, -(-tiles // 256)) * 256)      # how full the last round of one-tile-per-CU workgroups is on 256 CUs
+        # >= 1500 tiles (six rounds of the chip), or Cin >= 512 on a grid that fills its rounds to >= 90 % (the 20 x 20 512-output-channel layers at 80 frames: 250 tiles):
+        # round 6 at 80 frames, every such launch 2-27 % ahead of igemm<128,128,32,2>; 40 x 40 384 -> 256 (500 tiles, six K-tiles) loses 8 % and stays (profiles/r06_batch_80.txt)
+        ok = ok and (cin >= 1024 or (cin >= 512 and tiles >= 3000) or tiles >= 1500 or (cin >= 512 and fill >= 0.9))
     if up is not None:
         ok = ok and up[0] % 64 == 0 and up[1] % 64 == 0 and H % 2 == 0 and W % 2 == 0
     return bool(ok)

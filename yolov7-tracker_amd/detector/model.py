@@ -141,11 +141,18 @@ class Detector:
                 raise ValueError("input %dx%d is not a multiple of the max stride %d" % (hw[0], hw[1], s))
             nodes, _ = graph.parse(self.spec)
             plan = graph.lower(nodes, hw[0], hw[1], self.max_batch)
-            big = max(e * isz for e, isz in plan.buf_elems) * self.max_batch
-            if big >= 1 << 31:      # the conv kernels address a tensor through 32-bit buffer offsets (csrc/y7t_conv.hip)
-                raise ValueError("max_batch=%d at %dx%d: the largest activation tensor would be %.1f GiB (limit 2 GiB per tensor); "
-                                 "split the batch (max_batch <= %d)" % (self.max_batch, hw[0], hw[1], big / 2 ** 30,
-                                                                         (1 << 31) // (big // self.max_batch + 1)))
+            # the kernels address a tensor through 32-bit byte offsets (2 GiB).  A conv whose input or output tensor of `max_batch` frames is larger goes out as
+            # several launches over runs of frames (csrc/y7t_detector.hip::forward_impl; w6 @ 1280: the 640^2 / 320^2 layers above 40 frames); the pools, the
+            # materialised upsample and the input layout kernel are single launches
+            one = max(e * isz for e, isz in plan.buf_elems)
+            if one >= 1 << 31:
+                raise ValueError("%dx%d: the largest activation tensor of ONE frame would be %.1f GiB (limit 2 GiB)" % (hw[0], hw[1], one / 2 ** 30))
+            single = [max(int(o["H"]) * int(o["W"]) * int(o["in_ld"]), int(o["Ho"]) * int(o["Wo"]) * int(o["out_ld"])) * 2 for o in plan.ops if int(o["type"]) != 0]
+            single.append(plan.buf_elems[0][0] * plan.buf_elems[0][1])
+            if max(single) * self.max_batch >= 1 << 31:
+                raise ValueError("max_batch=%d at %dx%d: a tensor of a single-launch op (pool / upsample / input layout) would be %.1f GiB (limit 2 GiB); "
+                                 "split the batch (max_batch <= %d)" % (self.max_batch, hw[0], hw[1], max(single) * self.max_batch / 2 ** 30,
+                                                                         ((1 << 31) - 1) // max(single)))
             if self._sd is None:
                 self._sd = weights.calibrate_bn(nodes, weights.random_state_dict(plan.wlayout, self._seed, bn_bias_mean=self._bn_bias_mean),
                                                 seed=self._seed, image=self._calib_image)
@@ -341,6 +348,23 @@ class Detector:
             names.append(self._L.y7t_last_kernel().decode())
         torch.cuda.synchronize()
         return names
+
+    def launches_per_op(self, B=None):
+        """kernel launches of every op of the current plan at batch B: 1, or the number of runs of frames a conv whose input or output tensor of B frames passes
+        2 GiB goes out in (the rule of csrc/y7t_detector.hip::forward_impl, restated: the per-op table of the profiles attributes dispatches to ops with it)"""
+        B = self.max_batch if B is None else int(B)
+        lim, out = (1 << 31) - 1, []
+        for i, o in enumerate(self.plan.ops):
+            n = 1
+            if int(o["type"]) == 0:
+                f_in = int(o["H"]) * int(o["W"]) * int(o["in_ld"]) * 2
+                f_out = int(o["Ho"]) * int(o["Wo"]) * int(o["out_ld"]) * (4 if int(o["out_f32"]) else 2)
+                if i == 0 and self.plan.stem_fused:      # (the uint8 frame is the stem kernel's input)
+                    f_in = self.plan.H * self.plan.W * 3
+                runs = -(-B * max(f_in, f_out) // lim)
+                n = -(-B // -(-B // runs))
+            out.append(n)
+        return out
 
     @staticmethod
     def letterbox_params(shape, new_shape, stride, auto=True, scaleup=True):
