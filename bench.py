@@ -96,7 +96,7 @@ def parse():
     return args
 
 
-TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (four waves up to 384 detections, sixteen beyond: csrc/y7t_tracker.hip::step_threads)
+TRACKER_THREADS = 0      # --tracker_threads: 0 = the library's rule (four waves up to 384 detections, eight beyond: csrc/y7t_tracker.hip::step_threads)
 
 
 def make_opts():

@@ -14,7 +14,7 @@ def opts(**kw):
 for nobj, nf in ((80, 300), (500, 60)):
     dets = synth.make_detections(nf, nobj, seq_idx=0)
     ddev = [torch.from_numpy(d).cuda() for d in dets]
-    for threads in (64, 256, 1024):
+    for threads in (64, 256, 512, 1024):
         BaseTrack._count = 0
         t = ByteTrack(opts(tracker_threads=threads))
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -33,6 +33,14 @@
 #define Y7T_DEVICE 0
 #endif
 
+// full unrolling of the fixed-size loops of the Kalman arithmetic: their local arrays (K, W, S, L: 100 doubles in y7t_kf_update) are indexed by the loop counters, and a
+// loop the optimiser leaves rolled keeps them in SCRATCH memory (1088 bytes per lane in the frame step: every element a round trip to the L2); unrolled they are registers
+#if Y7T_DEVICE
+#define Y7T_UNROLL _Pragma("unroll")
+#else
+#define Y7T_UNROLL
+#endif
+
 #define Y7T_LARGE 1000000.0
 #define Y7T_SP (1.0 / 20)
 #define Y7T_SV (1.0 / 160)
@@ -348,7 +356,9 @@ Y7T_FN double y7t_sq(double a) { return a * a; }
 // kalman_filter.py:190-221 / :436-467.  z = measurement (xyah or xywh).  f32_std reproduces the
 // reference under numpy>=2: a float32 measurement keeps the std products in float32 (NEP 50).
 Y7T_FN void y7t_kf_initiate(int kind, const double* z, int f32_std, double* mean, double* cov) {
+    Y7T_UNROLL
     for (int i = 0; i < 4; ++i) { mean[i] = z[i]; mean[4 + i] = 0.0; }
+    Y7T_UNROLL
     for (int i = 0; i < 64; ++i) cov[i] = 0.0;
     double std_[8];
     if (f32_std) {
@@ -357,6 +367,7 @@ Y7T_FN void y7t_kf_initiate(int kind, const double* z, int f32_std, double* mean
             const float w = (float)z[2], h = (float)z[3];
             const float s[8] = {p2 * w, p2 * h, p2 * w, p2 * h, v10 * w, v10 * h, v10 * w, v10 * h};
             // every entry is float32 there, so np.square runs in float32 too
+            Y7T_UNROLL
             for (int i = 0; i < 8; ++i) { const float q = s[i] * s[i]; cov[i * 9] = (double)q; }
             return;
         }
@@ -373,6 +384,7 @@ Y7T_FN void y7t_kf_initiate(int kind, const double* z, int f32_std, double* mean
         std_[0] = 2 * Y7T_SP * h; std_[1] = 2 * Y7T_SP * h; std_[2] = 1e-2; std_[3] = 2 * Y7T_SP * h;
         std_[4] = 10 * Y7T_SV * h; std_[5] = 10 * Y7T_SV * h; std_[6] = 1e-5; std_[7] = 10 * Y7T_SV * h;
     }
+    Y7T_UNROLL
     for (int i = 0; i < 8; ++i) cov[i * 9] = y7t_sq(std_[i]);
 }
 
@@ -389,12 +401,17 @@ Y7T_FN void y7t_kf_predict(int kind, double* mean, double* cov) {
         q[0] = Y7T_SP * h; q[1] = Y7T_SP * h; q[2] = 1e-2; q[3] = Y7T_SP * h;
         q[4] = Y7T_SV * h; q[5] = Y7T_SV * h; q[6] = 1e-5; q[7] = Y7T_SV * h;
     }
+    Y7T_UNROLL
     for (int i = 0; i < 4; ++i) mean[i] = mean[i] + mean[4 + i];
     // left = F P : rows 0..3 += rows 4..7
+    Y7T_UNROLL
     for (int r = 0; r < 4; ++r)
+        Y7T_UNROLL
         for (int c = 0; c < 8; ++c) cov[r * 8 + c] = cov[r * 8 + c] + cov[(r + 4) * 8 + c];
     // (F P) F^T : cols 0..3 += cols 4..7 ; + Q
+    Y7T_UNROLL
     for (int r = 0; r < 8; ++r) {
+        Y7T_UNROLL
         for (int c = 0; c < 4; ++c) cov[r * 8 + c] = cov[r * 8 + c] + cov[r * 8 + c + 4];
         cov[r * 9] = cov[r * 9] + y7t_sq(q[r]);
     }
@@ -416,8 +433,10 @@ Y7T_FN void y7t_kf_rstd(int kind, const double* mean, double conf, double* r) {
 Y7T_FN void y7t_kf_project(int kind, const double* mean, const double* cov, double conf, double* pm, double* S) {
     double r[4];
     y7t_kf_rstd(kind, mean, conf, r);
+    Y7T_UNROLL
     for (int a = 0; a < 4; ++a) {
         pm[a] = mean[a];
+        Y7T_UNROLL
         for (int b = 0; b < 4; ++b) S[a * 4 + b] = cov[a * 8 + b];
         S[a * 5] = S[a * 5] + y7t_sq(r[a]);
     }
@@ -425,13 +444,17 @@ Y7T_FN void y7t_kf_project(int kind, const double* mean, const double* cov, doub
 
 // lower Cholesky of a 4x4 SPD matrix (LAPACK dpotrf 'L' order of operations)
 Y7T_FN void y7t_chol4(const double* S, double* L) {
+    Y7T_UNROLL
     for (int j = 0; j < 4; ++j) {
         double s = S[j * 4 + j];
+        Y7T_UNROLL
         for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
         const double d = sqrt(s);
         L[j * 4 + j] = d;
+        Y7T_UNROLL
         for (int i = j + 1; i < 4; ++i) {
             double t = S[i * 4 + j];
+            Y7T_UNROLL
             for (int k = 0; k < j; ++k) t -= L[i * 4 + k] * L[j * 4 + k];
             L[i * 4 + j] = t / d;
         }
@@ -440,13 +463,17 @@ Y7T_FN void y7t_chol4(const double* S, double* L) {
 
 // solve (L L^T) x = b in place
 Y7T_FN void y7t_chol4_solve(const double* L, double* b) {
+    Y7T_UNROLL
     for (int i = 0; i < 4; ++i) {
         double t = b[i];
+        Y7T_UNROLL
         for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * b[k];
         b[i] = t / L[i * 4 + i];
     }
+    Y7T_UNROLL
     for (int i = 3; i >= 0; --i) {
         double t = b[i];
+        Y7T_UNROLL
         for (int k = i + 1; k < 4; ++k) t -= L[k * 4 + i] * b[k];
         b[i] = t / L[i * 4 + i];
     }
@@ -457,28 +484,39 @@ Y7T_FN void y7t_kf_update(int kind, double* mean, double* cov, const double* z, 
     double pm[4], S[16], L[16], K[32], W[32];
     y7t_kf_project(kind, mean, cov, conf, pm, S);
     y7t_chol4(S, L);
+    Y7T_UNROLL
     for (int r = 0; r < 8; ++r) {
         double b[4] = {cov[r * 8 + 0], cov[r * 8 + 1], cov[r * 8 + 2], cov[r * 8 + 3]};
         y7t_chol4_solve(L, b);
+        Y7T_UNROLL
         for (int a = 0; a < 4; ++a) K[r * 4 + a] = b[a];
     }
     double innov[4];
+    Y7T_UNROLL
     for (int a = 0; a < 4; ++a) innov[a] = z[a] - pm[a];
+    Y7T_UNROLL
     for (int r = 0; r < 8; ++r) {
         double s = 0.0;
+        Y7T_UNROLL
         for (int a = 0; a < 4; ++a) s += innov[a] * K[r * 4 + a];
         mean[r] = mean[r] + s;
     }
     // numpy multi_dot((K, S, K^T)) with equal costs evaluates K (S K^T)
+    Y7T_UNROLL
     for (int a = 0; a < 4; ++a)
+        Y7T_UNROLL
         for (int c = 0; c < 8; ++c) {
             double s = 0.0;
+            Y7T_UNROLL
             for (int b = 0; b < 4; ++b) s += S[a * 4 + b] * K[c * 4 + b];
             W[a * 8 + c] = s;
         }
+    Y7T_UNROLL
     for (int r = 0; r < 8; ++r)
+        Y7T_UNROLL
         for (int c = 0; c < 8; ++c) {
             double s = 0.0;
+            Y7T_UNROLL
             for (int a = 0; a < 4; ++a) s += K[r * 4 + a] * W[a * 8 + c];
             cov[r * 8 + c] = cov[r * 8 + c] - s;
         }
@@ -490,6 +528,7 @@ struct Y7TWarp { double r00, r01, tx, r10, r11, ty; };
 Y7T_FN Y7TWarp y7t_warp_load(const double* H) { return Y7TWarp{H[0], H[1], H[2], H[3], H[4], H[5]}; }
 Y7T_FN void y7t_kf_gmc(const Y7TWarp& H, double* mean, double* cov) {
     const double r00 = H.r00, r01 = H.r01, tx = H.tx, r10 = H.r10, r11 = H.r11, ty = H.ty;
+    Y7T_UNROLL
     for (int b = 0; b < 4; ++b) {
         const double a = mean[2 * b], c = mean[2 * b + 1];
         mean[2 * b] = r00 * a + r01 * c;
@@ -500,13 +539,16 @@ Y7T_FN void y7t_kf_gmc(const Y7TWarp& H, double* mean, double* cov) {
     // products and sums on the same values as two in-place passes over the whole matrix, with every element loaded and stored once (round 5: the in-place passes, 128
     // dependent loads and stores through a generic pointer per track, were the part of the BoT-SORT step that three builds of the frame step mis-executed on the device --
     // right without camera-motion warps, right on the host; scripts/debug_botsort.py, profiles/r05_tracker_association.txt)
+    Y7T_UNROLL
     for (int b = 0; b < 4; ++b) {
         double u[8], w[8];
+        Y7T_UNROLL
         for (int c = 0; c < 8; ++c) {
             const double a = cov[(2 * b) * 8 + c], d = cov[(2 * b + 1) * 8 + c];
             u[c] = r00 * a + r01 * d;
             w[c] = r10 * a + r11 * d;
         }
+        Y7T_UNROLL
         for (int q = 0; q < 4; ++q) {
             const double a = u[2 * q], d = u[2 * q + 1];
             cov[(2 * b) * 8 + 2 * q] = a * r00 + d * r01;
@@ -525,19 +567,25 @@ Y7T_FN double y7t_kf_gating(int kind, const double* mean, const double* cov, con
     const int n = only_position ? 2 : 4;
     // Cholesky of the leading n x n block, forward substitution
     double acc = 0.0, yv[4];
+    Y7T_UNROLL
     for (int j = 0; j < n; ++j) {
         double s = S[j * 4 + j];
+        Y7T_UNROLL
         for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
         const double d = sqrt(s);
         L[j * 4 + j] = d;
+        Y7T_UNROLL
         for (int i = j + 1; i < n; ++i) {
             double t = S[i * 4 + j];
+            Y7T_UNROLL
             for (int k = 0; k < j; ++k) t -= L[i * 4 + k] * L[j * 4 + k];
             L[i * 4 + j] = t / d;
         }
     }
+    Y7T_UNROLL
     for (int i = 0; i < n; ++i) {
         double t = z[i] - pm[i];
+        Y7T_UNROLL
         for (int k = 0; k < i; ++k) t -= L[i * 4 + k] * yv[k];
         yv[i] = t / L[i * 4 + i];
         acc += yv[i] * yv[i];

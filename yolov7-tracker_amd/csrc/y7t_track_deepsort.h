@@ -367,8 +367,9 @@ Y7T_FN void y7t_assign_on_cost(const Y7TExec& ex, const Y7TTrk& s, int na, int n
 // One DeepSORT frame (deepsort.py:79-227).  dets: n x 6 float32 rows; det_feats: n x dim float32, row j = appearance feature of
 // detection row j (rows with conf <= det_thresh are never read).  f.app must hold this frame's nearest-embedding distances
 // (y7t_feat_normalize_dets, then y7t_embed_slot for every slot of the tracked / lost lists) -- they do not depend on the Kalman state.
-Y7T_NOINL void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fblob, const float* dets, int n, const float* det_feats,
-                                         double* out_rows, int out_cap, int* out_count) {
+// (inlined into its one kernel, k_tracker_step_deepsort<MAXT>: a called function would not inherit the kernel's __launch_bounds__ -- see y7t_tracker_step_body)
+Y7T_FN void y7t_tracker_step_deepsort(const Y7TExec& ex, void* blob, void* fblob, const float* dets, int n, const float* det_feats,
+                                      double* out_rows, int out_cap, int* out_count) {
     Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
     const Y7TTrkCfg cfg = h->cfg;
     const Y7TTrk s = y7t_trk_bind(blob, cfg.cap_t, cfg.cap_d);

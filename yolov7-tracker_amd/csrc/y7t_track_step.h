@@ -1038,8 +1038,11 @@ Y7T_FN void y7t_finish(const Y7TExec& ex, const Y7TTrk& s, double* out_rows, int
 }
 
 // One frame.  dets: n x 6 float32 rows [x1, y1, x2, y2, conf, cls] (n < 0: update_without_detection)
-Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets, int n, double* out_rows, int out_cap,
-                                int* out_count, const double* gmc_warp) {
+// The body is inlined where it is named: y7t_tracker_step (below) is the CALLED copy every launch of more than 256 threads shares; the <= 256-thread kernels
+// (csrc/y7t_tracker.hip) inline it, because a called function does not inherit its kernel's __launch_bounds__ -- compiled for the default 1024 threads a lane has 128
+// registers, and what the frame step keeps live around its Kalman updates spills to scratch memory; under __launch_bounds__(256) a lane may use 512 (round 6)
+Y7T_FN void y7t_tracker_step_body(const Y7TExec& ex, void* blob, const float* dets, int n, double* out_rows, int out_cap,
+                                  int* out_count, const double* gmc_warp) {
     Y7TTrkHdr* h = (Y7TTrkHdr*)blob;
     const Y7TTrkCfg cfg = h->cfg;
     const Y7TTrk s = y7t_trk_bind_ex(ex, blob, cfg.cap_t, cfg.cap_d);
@@ -1234,4 +1237,8 @@ Y7T_FN void y7t_tracker_init(const Y7TExec& ex, void* blob, const Y7TTrkCfg& cfg
         s.state[k] = Y7T_NEW; s.act[k] = 0; s.inrem[k] = 0; s.tid[k] = 0; s.f32m[k] = 0; s.mark[k] = 0;
     }
     y7t_sync(ex);
+}
+
+Y7T_NOINL void y7t_tracker_step(const Y7TExec& ex, void* blob, const float* dets, int n, double* out_rows, int out_cap, int* out_count, const double* gmc_warp) {
+    y7t_tracker_step_body(ex, blob, dets, n, out_rows, out_cap, out_count, gmc_warp);
 }

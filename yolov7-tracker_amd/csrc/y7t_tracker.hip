@@ -174,21 +174,27 @@ __global__ void k_tracker_step(void* const* states, const float* const* dets, co
     y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b, warps ? warps[b] : nullptr);
 }
 
-__global__ void k_tracker_step1(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count,
-                                unsigned fast_bytes, const double* warp) {
+// MAXT: the launch's thread bound.  Compiled for 1024 threads a lane has 128 registers and the frame step spills what it keeps live around its Kalman updates to SCRATCH
+// memory; the <= 256-thread launches (scenes of up to ~384 objects: step_threads) run an instance compiled for 256 threads with the step's body inlined (round 6)
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_tracker_step1(void* state, const float* dets, int n, double* out_rows, int out_cap, int* out_count,
+                                                         unsigned fast_bytes, const double* warp) {
     const Y7TExec ex = make_exec(fast_bytes);
-    y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
+    if (MAXT <= 512) y7t_tracker_step_body(ex, state, dets, n, out_rows, out_cap, out_count, warp);      // inlined: under this kernel's register budget
+    else y7t_tracker_step(ex, state, dets, n, out_rows, out_cap, out_count, warp);
 }
 
 // n_frames consecutive frames of ONE tracker in one launch: the same frame step, frame after frame, by the same workgroup (the state stays hot in
 // this CU's caches and nothing is launched between frames).  For pipelines that have a whole batch's detections before the tracker runs.
-__global__ void k_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
-                                      int n_frames, unsigned fast_bytes, unsigned arena_bytes, const double* const* warps) {
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_tracker_step_frames(void* state, const float* const* dets, const int* n_dets, double* const* out_rows, int* const* out_count, int out_cap,
+                                                               int n_frames, unsigned fast_bytes, unsigned arena_bytes, const double* const* warps) {
     Y7TExec ex = make_exec(fast_bytes);
     if (arena_bytes) { ex.arena = y7t_smem + Y7T_LDS_HDR + fast_bytes; ex.arena_bytes = arena_bytes; }      // the index lists live in LDS for the whole launch
     y7t_arena_load(ex, state);
     for (int f = 0; f < n_frames; ++f) {
-        y7t_tracker_step(ex, state, dets[f], n_dets[f], out_rows[f], out_cap, out_count[f], warps ? warps[f] : nullptr);
+        if (MAXT <= 512) y7t_tracker_step_body(ex, state, dets[f], n_dets[f], out_rows[f], out_cap, out_count[f], warps ? warps[f] : nullptr);
+        else y7t_tracker_step(ex, state, dets[f], n_dets[f], out_rows[f], out_cap, out_count[f], warps ? warps[f] : nullptr);
         y7t_sync(ex);
     }
     y7t_arena_store(ex, state);
@@ -284,8 +290,9 @@ __global__ void __launch_bounds__(256) k_ds_store(void* fblob, const float* __re
     y7t_feat_store_pending(ex, f, det_feats);
 }
 
-__global__ void k_tracker_step_deepsort(void* state, void* fblob, const float* dets, int n, const float* det_feats, double* out_rows,
-                                        int out_cap, int* out_count, unsigned fast_bytes) {
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_tracker_step_deepsort(void* state, void* fblob, const float* dets, int n, const float* det_feats, double* out_rows,
+                                                                 int out_cap, int* out_count, unsigned fast_bytes) {
     const Y7TExec ex = make_exec(fast_bytes);
     y7t_tracker_step_deepsort(ex, state, fblob, dets, n, det_feats, out_rows, out_cap, out_count);
 }
@@ -537,7 +544,9 @@ static int step_threads(int threads, int n_hint = -1) {
     // chose ONE wave for ~100-object scenes from stand-alone timings (no cross-wave barriers in the LAP reductions); inside the pipeline, where the step
     // runs beside the detector's kernels, four waves hide the longer memory round trips: tracker chain 14.1 -> 12.1 ms per 32 frames on the same box
     // (bench.py --tracker_threads 0 / 256, profiles/r02_bench_variants.txt), and stand-alone they are no slower any more (179 vs 186 us).
-    if (threads == 0) return (n_hint > 384) ? 1024 : 256;
+    // Round 6: the <= 512-thread launches run instances with the step's body inlined under their own register budget (no scratch spills: k_tracker_step1<MAXT>); 80 objects
+    // 169 -> 98 us with four waves (105 with eight), 500 objects 434 us with sixteen waves (the called copy, 128 registers a lane) -> 362 with four -> 261 with eight
+    if (threads == 0) return (n_hint > 384) ? 512 : 256;
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) return -1;
     return threads;
 }
@@ -578,11 +587,18 @@ extern "C" int y7t_tracker_step(void* state, const float* dets, int n, double* o
                       "(appearance rings); only the predict-only step (n < 0) is shared");
         return Y7T_E_STATE;
     }
-    static std::atomic<unsigned long long> attr_done{0};
-    if (int e = ensure_lds_once(k_tracker_step1, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0}, attr_done_m{0};
     const unsigned fb = step_fast_bytes(n);
-    hipLaunchKernelGGL(k_tracker_step1, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap,
-                       out_count, fb, gmc_warp);
+    if (nt <= 256) {
+        if (int e = ensure_lds_once(k_tracker_step1<256>, kFastBytes + Y7T_LDS_HDR, attr_done_s)) return e;
+        hipLaunchKernelGGL(k_tracker_step1<256>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap, out_count, fb, gmc_warp);
+    } else if (nt <= 512) {
+        if (int e = ensure_lds_once(k_tracker_step1<512>, kFastBytes + Y7T_LDS_HDR, attr_done_m)) return e;
+        hipLaunchKernelGGL(k_tracker_step1<512>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap, out_count, fb, gmc_warp);
+    } else {
+        if (int e = ensure_lds_once(k_tracker_step1<1024>, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
+        hipLaunchKernelGGL(k_tracker_step1<1024>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, dets, n, out_rows, out_cap, out_count, fb, gmc_warp);
+    }
     Y7T_LAUNCH_CHECK();
     return 0;
 }
@@ -605,10 +621,20 @@ extern "C" int y7t_tracker_step_frames(void* state, const float* const* dets, co
     const size_t ab = use_arena ? state_arena_bytes(state) : 0;
     unsigned arena = 0, fast = kFastBytes;
     if (ab && ab + 64 * 1024 + Y7T_LDS_HDR <= kLdsMax) { arena = (unsigned)((ab + 15) & ~(size_t)15); fast = (kLdsMax - Y7T_LDS_HDR - arena) & ~15u; if (fast > kFastBytes) fast = kFastBytes; }
-    static std::atomic<unsigned long long> attr_done{0};
-    if (int e = ensure_lds_once(k_tracker_step_frames, kLdsMax, attr_done)) return e;
-    hipLaunchKernelGGL(k_tracker_step_frames, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
-                       fast, arena, gmc_warps);
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0}, attr_done_m{0};
+    if (nt <= 256) {
+        if (int e = ensure_lds_once(k_tracker_step_frames<256>, kLdsMax, attr_done_s)) return e;
+        hipLaunchKernelGGL(k_tracker_step_frames<256>, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
+                           fast, arena, gmc_warps);
+    } else if (nt <= 512) {
+        if (int e = ensure_lds_once(k_tracker_step_frames<512>, kLdsMax, attr_done_m)) return e;
+        hipLaunchKernelGGL(k_tracker_step_frames<512>, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
+                           fast, arena, gmc_warps);
+    } else {
+        if (int e = ensure_lds_once(k_tracker_step_frames<1024>, kLdsMax, attr_done)) return e;
+        hipLaunchKernelGGL(k_tracker_step_frames<1024>, dim3(1), dim3(nt), Y7T_LDS_HDR + fast + arena, S(stream), state, dets, n_dets, out_rows, out_count, out_cap, n_frames,
+                           fast, arena, gmc_warps);
+    }
     Y7T_LAUNCH_CHECK();
     return 0;
 }
@@ -632,8 +658,10 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
     Y7T_ARG_CHECK(n == 0 || (dets && det_feats));
     const int nt = step_threads(threads, n);
     Y7T_ARG_CHECK(nt > 0);
-    static std::atomic<unsigned long long> attr_done{0};
-    if (int e = ensure_lds_once(k_tracker_step_deepsort, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0}, attr_done_m{0};
+    if (int e = nt <= 256 ? ensure_lds_once(k_tracker_step_deepsort<256>, kFastBytes + Y7T_LDS_HDR, attr_done_s)
+              : nt <= 512 ? ensure_lds_once(k_tracker_step_deepsort<512>, kFastBytes + Y7T_LDS_HDR, attr_done_m)
+                          : ensure_lds_once(k_tracker_step_deepsort<1024>, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
     if (n > 0) {
         hipLaunchKernelGGL(k_ds_normalize, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats, n);      // a wave per detection
         Y7T_LAUNCH_CHECK();
@@ -641,8 +669,9 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
         Y7T_LAUNCH_CHECK();
     }
     const unsigned fb = step_fast_bytes(n);
-    hipLaunchKernelGGL(k_tracker_step_deepsort, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats,
-                       out_rows, out_cap, out_count, fb);
+    if (nt <= 256) hipLaunchKernelGGL(k_tracker_step_deepsort<256>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats, out_rows, out_cap, out_count, fb);
+    else if (nt <= 512) hipLaunchKernelGGL(k_tracker_step_deepsort<512>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats, out_rows, out_cap, out_count, fb);
+    else hipLaunchKernelGGL(k_tracker_step_deepsort<1024>, dim3(1), dim3(nt), fb + Y7T_LDS_HDR, S(stream), state, feat_state, dets, n, det_feats, out_rows, out_cap, out_count, fb);
     Y7T_LAUNCH_CHECK();
     if (n > 0) {
         hipLaunchKernelGGL(k_ds_store, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats);

@@ -422,7 +422,7 @@ class BaseTracker(object):
         else:
             cnt = torch.tensor([d.shape[0] for d in ds], dtype=torch.int32).cuda()
         nmax = max([d.shape[0] for d in ds] + [0])
-        threads = self.threads if self.threads else (1024 if nmax > 384 else 256)      # the library's rule for one frame (csrc/y7t_tracker.hip::step_threads)
+        threads = self.threads if self.threads else (512 if nmax > 384 else 256)      # the library's rule for one frame (csrc/y7t_tracker.hip::step_threads)
         return (tab, cnt, n, warps is not None, (ds, outs, warps), threads)      # (the buffers stay alive with the table)
 
     def _launch_frames(self, table):
