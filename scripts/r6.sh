@@ -206,6 +206,23 @@ nms_prof)
   grep "k_rank_sort\|k_nms_keep" $O/nms_kernel_stats.csv | cut -c1-40,150-260 | tee -a $O/summary.txt
   ;;
 
+deepsort_prof)
+  say "deepsort_prof: scripts/time_deepsort.py alone (kernel-only us per frame, phase stamps), then its kernels under rocprofv3 --kernel-trace --stats"
+  timeout 600 python scripts/time_deepsort.py > $O/time_deepsort.log 2>&1; echo "rc=$?" >> $O/time_deepsort.log; cut -c1-300 $O/time_deepsort.log | tee -a $O/summary.txt
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/dp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dp -- python $ROOT/scripts/time_deepsort.py > $O/deepsort_prof.log 2>&1
+    f=$(find /tmp/dp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/deepsort_kernel_stats.csv )
+  head -12 $O/deepsort_kernel_stats.csv | cut -c1-60,100-260 | tee -a $O/summary.txt
+  ;;
+
+cfg4_trace)
+  say "cfg4_trace: rocprofv3 --kernel-trace of a short cfg4 bench (where a DeepSORT frame's four launches wait beside the detector) -> cfg4_kernel_trace.csv"
+  ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/c4
+    timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/c4 -- python $ROOT/bench.py --workload ${WL:-cfg4} --steps 3 --warmup 1 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled > $O/cfg4_trace.log 2>&1
+    f=$(find /tmp/c4 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $ROOT/scripts/trace_compact.py $f $O/${WL:-cfg4}_kernel_trace.csv )
+  wc -l $O/${WL:-cfg4}_kernel_trace.csv | tee -a $O/summary.txt; tail -2 $O/cfg4_trace.log | cut -c1-300
+  ;;
+
 prio_ab)
   say "prio_ab: the tracker chain's stream at high queue priority (bench.py --prio 2) against the default, cfg4 / cfg3 / cfg2, A/B/A"
   for wl in cfg4 cfg3 cfg2; do for v in 0 2 0b; do

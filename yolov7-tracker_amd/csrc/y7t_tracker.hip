@@ -167,11 +167,13 @@ __global__ void k_tracker_init(void* blob, Y7TTrkCfg cfg, unsigned long long idc
     y7t_tracker_init(ex, blob, cfg, idc);
 }
 
-__global__ void k_tracker_step(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
-                               int* out_count, int out_cap, unsigned fast_bytes, const double* const* warps) {
+template <int MAXT>      // (the thread bound of the launch: see k_tracker_step1)
+__global__ void __launch_bounds__(MAXT) k_tracker_step(void* const* states, const float* const* dets, const int* n_dets, double* const* out_rows,
+                                                        int* out_count, int out_cap, unsigned fast_bytes, const double* const* warps) {
     const int b = blockIdx.x;
     const Y7TExec ex = make_exec(fast_bytes);
-    y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b, warps ? warps[b] : nullptr);
+    if (MAXT <= 512) y7t_tracker_step_body(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b, warps ? warps[b] : nullptr);
+    else y7t_tracker_step(ex, states[b], dets[b], n_dets[b], out_rows[b], out_cap, out_count + b, warps ? warps[b] : nullptr);
 }
 
 // MAXT: the launch's thread bound.  Compiled for 1024 threads a lane has 128 registers and the frame step spills what it keeps live around its Kalman updates to SCRATCH
@@ -568,10 +570,14 @@ extern "C" int y7t_tracker_step_batch(void* const* states, const float* const* d
     Y7T_ARG_CHECK(states && dets && n_dets && out_rows && out_count);
     const int nt = step_threads(threads);
     Y7T_ARG_CHECK(nt > 0);
-    static std::atomic<unsigned long long> attr_done{0};
-    if (int e = ensure_lds_once(k_tracker_step, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
-    hipLaunchKernelGGL(k_tracker_step, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows,
-                       out_count, out_cap, kFastBytes, gmc_warps);
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_m{0};
+    if (nt <= 512) {
+        if (int e = ensure_lds_once(k_tracker_step<512>, kFastBytes + Y7T_LDS_HDR, attr_done_m)) return e;
+        hipLaunchKernelGGL(k_tracker_step<512>, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows, out_count, out_cap, kFastBytes, gmc_warps);
+    } else {
+        if (int e = ensure_lds_once(k_tracker_step<1024>, kFastBytes + Y7T_LDS_HDR, attr_done)) return e;
+        hipLaunchKernelGGL(k_tracker_step<1024>, dim3(batch), dim3(nt), kFastBytes + Y7T_LDS_HDR, S(stream), states, dets, n_dets, out_rows, out_count, out_cap, kFastBytes, gmc_warps);
+    }
     Y7T_LAUNCH_CHECK();
     return 0;
 }
