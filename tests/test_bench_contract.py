@@ -157,7 +157,7 @@ def test_round6_line_carries_the_coupled_passes_and_says_what_value_is():
     assert r["sustained_peak"] == 1627.0 and abs(r["frac_of_sustained_peak"] - r["achieved"] / 1627.0) < 1e-3
     t = json.load(open(os.path.join(ROOT, "profiles", "r06_conv_hbm_traffic.json")))
     assert t["launch_list_sha"] == l["config"]["launch_list_sha"] and len(t["commit"]) == 40 and t["frames_per_launch_list"] == l["config"]["frames_per_step"]
-    assert r["traffic"] is not None and abs(r["traffic"] - t["hbm_bytes_per_frame"] * 40) / r["traffic"] < 0.05
+    assert r["traffic"] is not None and abs(r["traffic"] - t["hbm_bytes_per_frame"] * t["frames_per_launch_list"]) / r["traffic"] < 0.05
     ow = l["other_workloads"]
     assert ow["cfg3"]["fps"] > 0 and ow["cfg4"]["fps"] > 0 and ow["cfg4"]["roofline_reid"]["frac"] > 0
     lm = l["latency_mode"]
