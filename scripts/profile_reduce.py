@@ -26,7 +26,7 @@ def last_forward(d, n_fwd):
     if per is None: return None
     return [disp[i] for i in ids[-per:]]
 res = {}
-pf, pw = last_forward("/tmp/pf", 3), last_forward("/tmp/pw", 3)
+pf, pw = (last_forward("/tmp/pf", 3), last_forward("/tmp/pw", 3)) if ctrs else (None, None)      # (no counter list: the per-op table only -- scripts/per_layer_table.sh; a box may still hold an earlier call's /tmp)
 if pf and pw:
     fetch_kb, write_kb = sum(d.get("FETCH_SIZE", 0) for d in pf), sum(d.get("WRITE_SIZE", 0) for d in pw)
     frames = int(META.get("B", 32))
@@ -39,7 +39,7 @@ if pf and pw:
                "hbm_bytes_per_frame": hbm, "algorithmic_bytes_per_frame": 1217000000.0, "ratio_to_algorithmic": hbm / 1217000000.0},
               open(out + "/conv_hbm_traffic.json", "w"), indent=1)
     print(open(out + "/conv_hbm_traffic.json").read())
-mb = last_forward("/tmp/mb", 3)
+mb = last_forward("/tmp/mb", 3) if ctrs else None
 if mb:
     s = {c: sum(d.get(c, 0.0) for d in mb) for c in ctrs}
     frames, gflop = int(META.get("B", 32)), 354.9

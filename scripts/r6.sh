@@ -223,6 +223,19 @@ cfg4_trace)
   wc -l $O/${WL:-cfg4}_kernel_trace.csv | tee -a $O/summary.txt; tail -2 $O/cfg4_trace.log | cut -c1-300
   ;;
 
+closing_ab)
+  say "closing_ab: the 80-frame headline against (b) persistent conv kernels on a static partition (Y7T_CONV_WS_DYN=0), (c) 96 frames, (d) the list as captured hipGraphs, (e) NMS gate variants; A first and last"
+  Q="--steps 16 --warmup 4 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled"
+  run() { n=$1; shift; env "$@" > /dev/null 2>&1; }
+  timeout 600 python bench.py $Q > $O/ab_a.json 2> $O/ab_a.err; echo "a default rc=$?" | tee -a $O/summary.txt; benchline $O/ab_a.json
+  Y7T_CONV_WS_DYN=0 timeout 600 python bench.py $Q > $O/ab_b.json 2> $O/ab_b.err; echo "b static partition rc=$?" | tee -a $O/summary.txt; benchline $O/ab_b.json
+  timeout 600 python bench.py $Q --batch 96 > $O/ab_c.json 2> $O/ab_c.err; echo "c 96 frames rc=$?" | tee -a $O/summary.txt; benchline $O/ab_c.json
+  timeout 600 python bench.py $Q --hipgraph 2 > $O/ab_d.json 2> $O/ab_d.err; echo "d hipgraph 2 rc=$?" | tee -a $O/summary.txt; benchline $O/ab_d.json
+  timeout 600 python bench.py $Q --nms_gate_div 16 > $O/ab_e.json 2> $O/ab_e.err; echo "e nms gate 16 rc=$?" | tee -a $O/summary.txt; benchline $O/ab_e.json
+  timeout 600 python bench.py $Q --tracker_launch per_frame > $O/ab_f.json 2> $O/ab_f.err; echo "f tracker per frame rc=$?" | tee -a $O/summary.txt; benchline $O/ab_f.json
+  timeout 600 python bench.py $Q > $O/ab_a2.json 2> $O/ab_a2.err; echo "a2 default rc=$?" | tee -a $O/summary.txt; benchline $O/ab_a2.json
+  ;;
+
 prio_ab)
   say "prio_ab: the tracker chain's stream at high queue priority (bench.py --prio 2) against the default, cfg4 / cfg3 / cfg2, A/B/A"
   for wl in cfg4 cfg3 cfg2; do for v in 0 2 0b; do
@@ -247,6 +260,17 @@ reduce_ab)
     echo "--- $v" | tee -a $O/summary.txt; tail -1 $O/per_layer_b1_$v.txt | tee -a $O/summary.txt
   done
   timeout 900 python -m pytest -x -q -m gpu tests/test_detector_gpu.py -k "conv or split or layer" > $O/t_conv.log 2>&1; echo "rc=$?" >> $O/t_conv.log; tailsum $O/t_conv.log 3
+  ;;
+
+prev_ab)
+  say "prev_ab: per-op tables at 80 frames, this build against lib/liby7t_prev.so, A/B/A/B; then the p8 / stem / pinned parity tests"
+  for v in prev new prev2 new2; do
+    case $v in prev*) E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_prev.so";; *) E="Y7T_X=0";; esac
+    env $E NAME=b80_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b80_$v.log 2>&1
+    echo "--- $v" | tee -a $O/summary.txt; grep "${ROWS:-p8\|stem}" $O/per_layer_b80_$v.txt | awk '{u+=$(NF-5)} END {print "rows of interest:", u, "us"}' | tee -a $O/summary.txt; tail -1 $O/per_layer_b80_$v.txt | tee -a $O/summary.txt
+  done
+  timeout 900 python -m pytest -x -q -m gpu tests/test_detector_gpu.py -k "pingpong or stem or u8" > $O/t_p8.log 2>&1; echo "rc=$?" >> $O/t_p8.log; tailsum $O/t_p8.log 3
+  timeout 900 python -m pytest -x -q -m gpu tests/test_detector_pinned_gpu.py -k "every_op or launch_list" > $O/t_pin.log 2>&1; echo "rc=$?" >> $O/t_pin.log; tailsum $O/t_pin.log 3
   ;;
 
 tests_fullsize)
