@@ -204,7 +204,9 @@ int y7t_det_destroy(y7t_det* det);
  * (y7t_input_layout) is already in arena buffer 0.  Asynchronous on `stream`.
  * One forward of a detector at a time: the arena, the split-K slabs and the tile counters of the persistent kernels belong to the plan.  Launches on one
  * stream are ordered; a forward (or a piece of one, y7t_det_forward_ops / _fused) issued on another stream than the previous one waits for it on the device.
- * While `stream` is being captured into a hipGraph nothing is recorded or waited for: whoever replays the graph orders the replays. */
+ * While `stream` is being captured into a hipGraph nothing is recorded or waited for: whoever replays the graph orders the replays.
+ * The kernels address a tensor through 32-bit byte offsets: a conv whose input or output tensor of B images is larger than 2 GiB goes out as several launches over
+ * runs of consecutive images (w6 @ 1280 x 1280: the 640^2 / 320^2 layers from 41 images on); results do not depend on where the runs are cut. */
 int y7t_det_forward(y7t_det* det, int B, y7t_stream stream);
 /* the same launch list in pieces: ops [first, last) of the plan (last < 0: to the end), so that a caller can record an event between
  * two parts of Model.forward_once (models/yolo.py:321-351) -- bench.py starts the previous batch's decode+NMS on another stream once
