@@ -369,11 +369,13 @@ def chained_parity(args, nc, frames_host, n_frames):
 
 def other_workloads(args):
     """configs[2] (BoT-SORT, 500 objects) and configs[3] (DeepSORT + OSNet ReID) in the driver's default run -- two short runs of this script
-    (--steps 5, no CPU baseline, no latency mode) as child processes AFTER the headline's timed region, their lines reduced to the figures that matter."""
+    (--steps 16, no CPU baseline, no latency mode) as child processes AFTER the headline's timed region, their lines reduced to the figures that matter.
+    (Round 6: 16 steps instead of 5 -- the timed region ends when the LAST batch's tracker chain has drained, one chain of ~35-54 ms behind the last forward; over five steps
+    of 35 ms that tail was a fifth of the quoted time per step: cfg3 41-43 ms per step with a 35 ms list AND a 35 ms chain, kernel trace in profiles/r06_batch_80.txt.)"""
     import subprocess
     out = {}
     for wl in ("cfg3", "cfg4"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", "5", "--warmup", "2", "--no_cpu_baseline", "--no_latency_mode",
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", "16", "--warmup", "3", "--no_cpu_baseline", "--no_latency_mode",
                "--no_other_workloads", "--batch", str(args.batch), "--img", str(args.img), "--arch", args.arch]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         try:

@@ -236,6 +236,24 @@ closing_ab)
   timeout 600 python bench.py $Q > $O/ab_a2.json 2> $O/ab_a2.err; echo "a2 default rc=$?" | tee -a $O/summary.txt; benchline $O/ab_a2.json
   ;;
 
+threads_sweep)
+  say "threads_sweep: threads of the tracker step workgroup inside the pipeline (bench.py --tracker_threads), per workload"
+  for wl in cfg2 cfg3 cfg4; do for t in ${THREADS:-0 128 256 512}; do
+    timeout 600 python bench.py --workload $wl --steps 8 --warmup 3 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled --tracker_threads $t > $O/bench_thr_${wl}_$t.json 2> $O/bench_thr_${wl}_$t.err; echo "$wl threads $t rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_thr_${wl}_$t.json
+  done; done
+  ;;
+
+cfg4_ab)
+  say "cfg4_ab: DeepSORT device tests, scripts/time_deepsort.py, then the cfg4 bench (k_embed_dist over the live slots)"
+  timeout 900 python -m pytest -x -q -m gpu tests/test_tracker_gpu.py tests/test_reid_gpu.py -k "deepsort or DeepSORT or reid or embed" > $O/t_ds.log 2>&1; echo "rc=$?" >> $O/t_ds.log; tailsum $O/t_ds.log 3
+  timeout 600 python scripts/time_deepsort.py > $O/time_deepsort.log 2>&1; grep "kernel-only" $O/time_deepsort.log | cut -c1-200 | tee -a $O/summary.txt
+  for k in 1 2; do
+    timeout 600 python bench.py --workload cfg4 --steps 8 --warmup 3 --no_latency_mode --no_cpu_baseline --no_other_workloads --no_coupled > $O/bench_cfg4_$k.json 2> $O/bench_cfg4_$k.err; echo "cfg4 run $k rc=$?" | tee -a $O/summary.txt
+    benchline $O/bench_cfg4_$k.json
+  done
+  ;;
+
 prio_ab)
   say "prio_ab: the tracker chain's stream at high queue priority (bench.py --prio 2) against the default, cfg4 / cfg3 / cfg2, A/B/A"
   for wl in cfg4 cfg3 cfg2; do for v in 0 2 0b; do

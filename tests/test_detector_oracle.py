@@ -280,7 +280,8 @@ def test_patch_eligibility_rule():
     ok = lambda H, W, ci, co, B, **kw: graph.patch_eligible(H, W, ci, co, kw.get("k", 3), kw.get("s", 1), kw.get("p", 1), co, 0, 0, B)
     assert ok(80, 80, 256, 256, 32) and ok(320, 320, 64, 64, 32) and ok(40, 40, 384, 384, 32) and ok(20, 20, 512, 1024, 32)
     assert ok(20, 20, 512, 512, 32) and ok(20, 20, 256, 256, 32)      # round 4: 64-row panels (korder 9) where 128 rows give fewer than 256 workgroups, threshold 200
-    assert graph.patch_panel_rows(20, 20, 512, 32) == 64 and graph.patch_panel_rows(20, 20, 1024, 32) == 128 and graph.patch_panel_rows(80, 80, 192, 32) == 64
+    assert graph.patch_panel_rows(20, 20, 512, 32) == 64 and graph.patch_panel_rows(20, 20, 1024, 80) == 128 and graph.patch_panel_rows(80, 80, 192, 32) == 64
+    assert graph.patch_panel_rows(20, 20, 512, 80) == 64 and graph.patch_panel_rows(20, 20, 1024, 32) == 64      # round 6, measured at 80 frames: 64-row panels below 512 tiles of 128 rows (500 for the 20 x 20 512 -> 512 layers)
     assert ok(20, 20, 512, 512, 8) and not ok(20, 20, 512, 512, 4)      # 100 workgroups' worth of 256-pixel tiles (64-row panels): 8 * 400 * 8; 4 frames are too few
     assert ok(80, 80, 256, 256, 1) and not ok(80, 80, 256, 128, 1)      # batch 1 (round 4, profiles/r04_latency_lowering.txt): 100 workgroups win against split-K, 50 with Cin = 256 lose
     assert ok(80, 80, 128, 128, 1) and not ok(40, 40, 128, 128, 1)      # ... 50 are enough when K is short (Cin <= 128)
@@ -290,7 +291,7 @@ def test_patch_eligibility_rule():
 
 
 def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
-    """Which kernel family each conv of the benchmarked configuration (w6 @ 1280, 40 frames per forward since round 5; 32 before) is lowered to, as `korder` counts -- every rule behind them was set by
+    """Which kernel family each conv of the benchmarked configuration (w6 @ 1280, 80 frames per forward since round 6; 40 in round 5, 32 before) is lowered to, as `korder` counts -- every rule behind them was set by
     an in-session A/B on the device (profiles/r03_*, r04_*); a change here is a change of the measured launch list.  And the batch-1 list."""
     for k in ("Y7T_CONV_WS128", "Y7T_LIB", "Y7T_CONV_WS_S2_FUSE", "Y7T_CONV_PATCH_MIN_PIX", "Y7T_CONV_PATCH_PANEL64_BELOW", "Y7T_CONV_1X1_PANEL64_BELOW", "Y7T_CONV_P8", "Y7T_CONV_WS", "Y7T_CONV_WS_S2",
               "Y7T_CONV_PATCH_S2", "Y7T_CONV_PATCH", "Y7T_CONV_VARIANT", "Y7T_CONV_WPANEL"):
@@ -300,14 +301,16 @@ def test_lowering_of_the_benchmarked_list_by_weight_order(monkeypatch):
     # 0 stem (fused frame -> conv kernel); 1 generic 3x3 (three stride-2 layers); 2 LDS-patch (16x16 tiles + 40-wide strips); 3 1x1 panels (incl. 3 upsample-on-read, 4 Detect);
     # 4 stride-2 LDS-patch; 5 weights-stationary 64 -> 64; 6 weights-stationary 128 -> 128 k (round 5: eleven of the former korder-2 launches at stride 1 + the two Cin = 128 stride-2 layers, formerly korder 4); 7 p8; 9 patch with 64-row panels (the 20x20 layers); 10 1x1 with 64-row panels (< 500 tiles);
     # 11 the stride-2 weights-stationary layer + the twin 1x1 behind it in one launch
-    assert hist(32) == {0: 1, 1: 3, 2: 22, 3: 24, 4: 2, 5: 7, 6: 13, 7: 5, 9: 10, 10: 7, 11: 1}
-    assert hist(40) == {0: 1, 1: 3, 2: 22, 3: 30, 4: 2, 5: 7, 6: 13, 7: 5, 9: 10, 10: 1, 11: 1}      # 40 frames: six of the 20x20 1x1 layers reach 500 tiles of 128 rows
+    # (round 6: p8 on every 1x1 grid of >= 1500 tiles or of one full round of the chip, 64-row strip panels below 512 tiles: profiles/r06_batch_80.txt)
+    assert hist(80) == {0: 1, 1: 3, 2: 22, 3: 13, 4: 2, 5: 7, 6: 13, 7: 23, 9: 10, 11: 1}      # the benchmarked list
+    assert hist(32) == {0: 1, 1: 3, 2: 21, 3: 19, 4: 2, 5: 7, 6: 13, 7: 10, 9: 11, 10: 7, 11: 1}
+    assert hist(40) == {0: 1, 1: 3, 2: 21, 3: 18, 4: 2, 5: 7, 6: 13, 7: 17, 9: 11, 10: 1, 11: 1}      # 40 frames: six of the 20x20 1x1 layers reach 500 tiles of 128 rows
     h1 = hist(1)
     assert h1 == {0: 1, 1: 33, 2: 8, 3: 8, 9: 16, 10: 28, 11: 1} and h1.get(5, 0) == 0 and h1.get(7, 0) == 0 and h1.get(4, 0) == 0      # one frame: no persistent 64 -> 64 / p8 / stride-2 patch launches
     monkeypatch.setenv("Y7T_CONV_WS_S2_FUSE", "0")      # an experiment switch: nothing changes for the product library ...
     assert hist(32)[11] == 1
     monkeypatch.setenv("Y7T_LIB", "/somewhere/liby7t_ablate.so")      # ... beside the measuring build the fusion can be switched off
-    assert hist(32)[8] == 1 and 11 not in hist(32) and hist(32)[3] == 25
+    assert hist(32)[8] == 1 and 11 not in hist(32) and hist(32)[3] == 20
 
 
 def test_training_graph_spec_and_liveness():

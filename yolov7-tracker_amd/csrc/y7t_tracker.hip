@@ -218,69 +218,96 @@ __global__ void __launch_bounds__(256) k_ds_normalize(void* fblob, const float* 
     y7t_feat_normalize_dets(ex, f, det_feats, n);
 }
 
-// nearest-embedding distances, tiled: workgroup (slot, 64 detections), the slot's stored rows 32 at a time, 32-deep k chunks of both operands in LDS,
+// nearest-embedding distances, tiled: a workgroup takes (slot, 64 detections), the slot's stored rows 32 at a time, 32-deep k chunks of both operands in LDS,
 // 2 x 4 products per thread.  Every product is the sequential FMA chain over k = 0 .. dim-1 of y7t_embed_slot (= numpy's sgemm), so the costs -- and
 // the assignment that follows them -- are bit-identical; only the order in which DIFFERENT products advance changes.
+// Round 6: the grid is (Y7T_EMBED_WORKERS, detection tiles) instead of (cap_tracks, detection tiles).  Every workgroup walks the state column once, ranks the live
+// slots (Tracked / Lost) in slot order and takes those whose rank is its blockIdx.x modulo the worker count: a frame with 64 live tracks of a 512-slot pool launched
+// 1024 workgroups of which ~900 found nothing to do -- beside the detector each of them queued for a CU slot first (the kernel ran 128 us per frame in the cfg4
+// pipeline against 38 us alone, profiles/r06_batch_80.txt section 4).
+#define Y7T_EMBED_WORKERS 128
 __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int n) {
     const Y7TTrkHdr* h = (const Y7TTrkHdr*)blob;
     const Y7TTrk s = y7t_trk_bind(blob, h->cfg.cap_t, h->cfg.cap_d);
-    const int slot = blockIdx.x, j0 = blockIdx.y * 64;
-    if (slot >= h->cfg.cap_t) return;
+    const int j0 = blockIdx.y * 64, cap_t = h->cfg.cap_t;
     if (n > h->cfg.cap_d) n = h->cfg.cap_d;
-    const int st = s.state[slot];
-    if (st != Y7T_TRACKED && st != Y7T_LOST) return;
     const Y7TFeat f = y7t_feat_bind(fblob);
-    const int nf = f.nfeat[slot], dim = f.h->dim;
-    if (dim & 31) {      // feature dimensions that are not a multiple of the k chunk: the plain form, one workgroup per slot
-        if (blockIdx.y == 0) {
-            Y7TExec ex;
-            ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
-            y7t_embed_slot(ex, f, slot, n, s.tsu[slot]);
-        }
-        return;
-    }
-    if (nf <= 0 || j0 >= n) return;
+    const int dim = f.h->dim, tid = threadIdx.x;
     __shared__ float sA[32][33], sB[64][33], smin[16][64];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lrow = tid >> 3, kq = (tid & 7) * 4;
-    const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
-    float best[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-    for (int h0 = 0; h0 < nf; h0 += 32) {
-        float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        for (int k0 = 0; k0 < dim; k0 += 32) {
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb0 = va, vb1 = va;
-            if (h0 + lrow < nf) va = *(const float4*)(hist + (size_t)(h0 + lrow) * dim + k0 + kq);
-            if (j0 + lrow < n) vb0 = *(const float4*)(f.detn + (size_t)(j0 + lrow) * dim + k0 + kq);
-            if (j0 + 32 + lrow < n) vb1 = *(const float4*)(f.detn + (size_t)(j0 + 32 + lrow) * dim + k0 + kq);
-            __syncthreads();
-            sA[lrow][kq] = va.x; sA[lrow][kq + 1] = va.y; sA[lrow][kq + 2] = va.z; sA[lrow][kq + 3] = va.w;
-            sB[lrow][kq] = vb0.x; sB[lrow][kq + 1] = vb0.y; sB[lrow][kq + 2] = vb0.z; sB[lrow][kq + 3] = vb0.w;
-            sB[32 + lrow][kq] = vb1.x; sB[32 + lrow][kq + 1] = vb1.y; sB[32 + lrow][kq + 2] = vb1.z; sB[32 + lrow][kq + 3] = vb1.w;
-            __syncthreads();
+    __shared__ int s_cnt[4], s_own[64], s_nown;
+    // ---- the live slots of rank = blockIdx.x (mod gridDim.x), in slot order ----
+    if (tid == 0) s_nown = 0;
+    int seen = 0;      // live slots below `base` (uniform)
+    for (int base = 0; base < cap_t; base += 256) {
+        const int sl = base + tid;
+        bool live = false;
+        if (sl < cap_t) { const int st = s.state[sl]; live = st == Y7T_TRACKED || st == Y7T_LOST; }
+        const unsigned long long bal = __ballot(live);
+        __syncthreads();                                   // (s_cnt of the previous round has been read; s_nown's initial store is visible)
+        if ((tid & 63) == 0) s_cnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = seen;
+        for (int w = 0; w < (tid >> 6); ++w) before += s_cnt[w];
+        const int rank = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (live && rank % (int)gridDim.x == (int)blockIdx.x) { const int k = rank / (int)gridDim.x; if (k < 64) s_own[k] = sl; atomicMax(&s_nown, k + 1); }
+        seen += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+    __syncthreads();
+    const int n_own = s_nown < 64 ? s_nown : 64;      // (64 x the worker count live tracks: more than any pool this library is given; the launcher checks cap_tracks)
+    for (int oi = 0; oi < n_own; ++oi) {
+        const int slot = s_own[oi];
+        const int nf = f.nfeat[slot];
+        if (dim & 31) {      // feature dimensions that are not a multiple of the k chunk: the plain form, one workgroup per slot
+            if (blockIdx.y == 0) {
+                Y7TExec ex;
+                ex.tid = threadIdx.x; ex.nt = blockDim.x; ex.rv = nullptr; ex.ri = nullptr; ex.fast = nullptr; ex.fast_bytes = 0; ex.arena = nullptr; ex.arena_bytes = 0;
+                y7t_embed_slot(ex, f, slot, n, s.tsu[slot]);
+            }
+            continue;
+        }
+        if (nf <= 0 || j0 >= n) continue;
+        const int ty = tid >> 4, tx = tid & 15, lrow = tid >> 3, kq = (tid & 7) * 4;
+        const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
+        float best[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        for (int h0 = 0; h0 < nf; h0 += 32) {
+            float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int k0 = 0; k0 < dim; k0 += 32) {
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb0 = va, vb1 = va;
+                if (h0 + lrow < nf) va = *(const float4*)(hist + (size_t)(h0 + lrow) * dim + k0 + kq);
+                if (j0 + lrow < n) vb0 = *(const float4*)(f.detn + (size_t)(j0 + lrow) * dim + k0 + kq);
+                if (j0 + 32 + lrow < n) vb1 = *(const float4*)(f.detn + (size_t)(j0 + 32 + lrow) * dim + k0 + kq);
+                __syncthreads();
+                sA[lrow][kq] = va.x; sA[lrow][kq + 1] = va.y; sA[lrow][kq + 2] = va.z; sA[lrow][kq + 3] = va.w;
+                sB[lrow][kq] = vb0.x; sB[lrow][kq + 1] = vb0.y; sB[lrow][kq + 2] = vb0.z; sB[lrow][kq + 3] = vb0.w;
+                sB[32 + lrow][kq] = vb1.x; sB[32 + lrow][kq + 1] = vb1.y; sB[32 + lrow][kq + 2] = vb1.z; sB[32 + lrow][kq + 3] = vb1.w;
+                __syncthreads();
 #pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const float a0 = sA[2 * ty][k], a1 = sA[2 * ty + 1][k];
+                for (int k = 0; k < 32; ++k) {
+                    const float a0 = sA[2 * ty][k], a1 = sA[2 * ty + 1][k];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float b = sB[tx + 16 * c][k];
-                    acc[0][c] = __builtin_fmaf(a0, b, acc[0][c]);
-                    acc[1][c] = __builtin_fmaf(a1, b, acc[1][c]);
+                    for (int c = 0; c < 4; ++c) {
+                        const float b = sB[tx + 16 * c][k];
+                        acc[0][c] = __builtin_fmaf(a0, b, acc[0][c]);
+                        acc[1][c] = __builtin_fmaf(a1, b, acc[1][c]);
+                    }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (h0 + 2 * ty + r < nf)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = 1.0f - acc[r][c]; best[c] = d < best[c] ? d : best[c]; }
         }
+        __syncthreads();                                   // (the previous slot's reduction has read smin)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-            if (h0 + 2 * ty + r < nf)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const float d = 1.0f - acc[r][c]; best[c] = d < best[c] ? d : best[c]; }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) smin[ty][tx + 16 * c] = best[c];
-    __syncthreads();
-    if (tid < 64 && j0 + tid < n) {
-        float m = smin[0][tid];
-        for (int q = 1; q < 16; ++q) m = smin[q][tid] < m ? smin[q][tid] : m;
-        f.app[(size_t)slot * f.h->cap_d + j0 + tid] = m;
-        if ((double)m <= 0.15) { const int a = s.tsu[slot]; atomicMin(f.cmin + j0 + tid, a); atomicMax(f.cmax + j0 + tid, a); }
+        for (int c = 0; c < 4; ++c) smin[ty][tx + 16 * c] = best[c];
+        __syncthreads();
+        if (tid < 64 && j0 + tid < n) {
+            float m = smin[0][tid];
+            for (int q = 1; q < 16; ++q) m = smin[q][tid] < m ? smin[q][tid] : m;
+            f.app[(size_t)slot * f.h->cap_d + j0 + tid] = m;
+            if ((double)m <= 0.15) { const int a = s.tsu[slot]; atomicMin(f.cmin + j0 + tid, a); atomicMax(f.cmax + j0 + tid, a); }
+        }
     }
 }
 
@@ -662,6 +689,7 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
                                          double* out_rows, int out_cap, int* out_count, int threads, y7t_stream stream) {
     Y7T_ARG_CHECK(state && feat_state && out_rows && out_count && out_cap >= 0 && cap_tracks > 0 && n >= 0);
     Y7T_ARG_CHECK(n == 0 || (dets && det_feats));
+    Y7T_ARG_CHECK(cap_tracks <= 64 * Y7T_EMBED_WORKERS);      // (k_embed_dist: a workgroup owns at most 64 live slots)
     const int nt = step_threads(threads, n);
     Y7T_ARG_CHECK(nt > 0);
     static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0}, attr_done_m{0};
@@ -671,7 +699,7 @@ extern "C" int y7t_tracker_step_deepsort(void* state, void* feat_state, int cap_
     if (n > 0) {
         hipLaunchKernelGGL(k_ds_normalize, dim3((n + 3) / 4), dim3(256), 0, S(stream), feat_state, det_feats, n);      // a wave per detection
         Y7T_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_embed_dist, dim3(cap_tracks, (n + 63) / 64), dim3(256), 0, S(stream), state, feat_state, n);
+        hipLaunchKernelGGL(k_embed_dist, dim3(cap_tracks < Y7T_EMBED_WORKERS ? cap_tracks : Y7T_EMBED_WORKERS, (n + 63) / 64), dim3(256), 0, S(stream), state, feat_state, n);
         Y7T_LAUNCH_CHECK();
     }
     const unsigned fb = step_fast_bytes(n);
