@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--rotate_batches", type=int, default=4, help="distinct resident input batches consumed round-robin by the timed steps (1 = the same batch every step)")
     ap.add_argument("--hipgraph", type=int, default=0, help="1: replay detector+NMS as one captured hipGraph (no NMS overlap); "
                     "2: the forward as two captured hipGraphs (before / after the gate event), same pipeline as eager")
-    ap.add_argument("--cpu_frames", type=int, default=3)
+    ap.add_argument("--cpu_frames", type=int, default=20, help="frames of the detector oracle in the CPU baseline (about 10 s of CPU work on a GPU box at 32 threads)")
     ap.add_argument("--chained_frames", type=int, default=8, help="frames of the chained detect -> NMS -> ByteTrack parity run in `parity.chained` (0: off)")
     ap.add_argument("--nms_gate_div", type=int, default=NMS_GATE_DIV, help="the previous batch's rank sort + NMS is released when the forward reaches its first op on a map of "
                     "img / this (8: behind the 640^2 / 320^2 layers; 16: behind the 160^2 ones too)")
