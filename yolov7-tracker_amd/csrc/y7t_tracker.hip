@@ -269,18 +269,26 @@ __global__ void __launch_bounds__(256) k_embed_dist(void* blob, void* fblob, int
         const int ty = tid >> 4, tx = tid & 15, lrow = tid >> 3, kq = (tid & 7) * 4;
         const float* hist = f.ring + (size_t)slot * f.h->budget * dim;
         float best[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        // (round 6: the NEXT k chunk's global loads are issued before the current chunk's products -- beside the detector a load takes several times what it takes alone,
+        //  and the loop used to wait for every chunk with nothing else to do)
+        auto fetch = [&](int h0, int k0, float4& va, float4& vb0, float4& vb1) {
+            va = make_float4(0.f, 0.f, 0.f, 0.f); vb0 = va; vb1 = va;
+            if (h0 + lrow < nf) va = *(const float4*)(hist + (size_t)(h0 + lrow) * dim + k0 + kq);
+            if (j0 + lrow < n) vb0 = *(const float4*)(f.detn + (size_t)(j0 + lrow) * dim + k0 + kq);
+            if (j0 + 32 + lrow < n) vb1 = *(const float4*)(f.detn + (size_t)(j0 + 32 + lrow) * dim + k0 + kq);
+        };
+        float4 va, vb0, vb1;
+        fetch(0, 0, va, vb0, vb1);
         for (int h0 = 0; h0 < nf; h0 += 32) {
             float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             for (int k0 = 0; k0 < dim; k0 += 32) {
-                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb0 = va, vb1 = va;
-                if (h0 + lrow < nf) va = *(const float4*)(hist + (size_t)(h0 + lrow) * dim + k0 + kq);
-                if (j0 + lrow < n) vb0 = *(const float4*)(f.detn + (size_t)(j0 + lrow) * dim + k0 + kq);
-                if (j0 + 32 + lrow < n) vb1 = *(const float4*)(f.detn + (size_t)(j0 + 32 + lrow) * dim + k0 + kq);
                 __syncthreads();
                 sA[lrow][kq] = va.x; sA[lrow][kq + 1] = va.y; sA[lrow][kq + 2] = va.z; sA[lrow][kq + 3] = va.w;
                 sB[lrow][kq] = vb0.x; sB[lrow][kq + 1] = vb0.y; sB[lrow][kq + 2] = vb0.z; sB[lrow][kq + 3] = vb0.w;
                 sB[32 + lrow][kq] = vb1.x; sB[32 + lrow][kq + 1] = vb1.y; sB[32 + lrow][kq + 2] = vb1.z; sB[32 + lrow][kq + 3] = vb1.w;
                 __syncthreads();
+                if (k0 + 32 < dim) fetch(h0, k0 + 32, va, vb0, vb1);
+                else if (h0 + 32 < nf) fetch(h0 + 32, 0, va, vb0, vb1);
 #pragma unroll 8
                 for (int k = 0; k < 32; ++k) {
                     const float a0 = sA[2 * ty][k], a1 = sA[2 * ty + 1][k];
