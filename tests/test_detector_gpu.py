@@ -256,6 +256,11 @@ P8_CASES = [
     (3, 80, 80, 512, 256, 1, 1, 1 | 32768, 512, 0, 512, 256, 0),
     (8, 80, 80, 1024, 512, 1, 1, 1 | 32768, 1024, 0, 512, 0, 0),
     (8, 40, 40, 1536, 768, 1, 1, 1 | 32768, 1536, 0, 768, 0, 0),
+    # round 6, the persistent form (a workgroup walks a column of pixel tiles: more tiles than CUs, an even number of K-tiles): three channel tiles on 255 workgroups with a
+    # ragged last pixel tile; one channel tile, slices of wider buffers, LeakyReLU; two K-tiles per tile (the shortest loop the cross-tile prefetch allows)
+    (5, 79, 79, 512, 768, 1, 1, 1 | 32768, 512, 0, 768, 0, 0),
+    (12, 80, 80, 256, 256, 1, 1, 2 | 32768, 512, 256, 768, 512, 0),
+    (6, 120, 120, 128, 256, 1, 1, 1 | 32768, 128, 0, 256, 0, 0),
 ]
 
 

@@ -271,6 +271,237 @@ __global__ void __launch_bounds__(512, 2) k_conv1x1_p8(const Y7TConvArgs p) {
 #endif
 }
 
+
+// ---- round 6: the PERSISTENT form (profiles/r06_batch_80.txt: p8 is the list's largest family at 80 frames, and a tile's fixed cost -- workgroup launch, the prologue's
+// first DMA round trip, drain -- is a quarter of it).  One workgroup per CU walks a COLUMN of pixel tiles with one channel tile (tile_m = lane, lane + Gn, ...), and the
+// schedule's tail, which the one-tile kernel fills with zero-fills, stages the NEXT tile's K-tiles 0 and 1 instead: K-tile nk of the current tile IS K-tile 0 of the next
+// (nk even, so it lands in buffer 0), and when the loop ends the ring is exactly in the state the prologue leaves -- P0 C0 C1 P1 of K-tile 0 and P0 C0 of K-tile 1 issued,
+// the last eight pieces in flight under `vmcnt(8)`.  The epilogue cannot use the whole ring as scratch any more: a wave transposes its 128 pixels x 64 channels 32 pixels
+// at a time through 4 KiB of the two half-tiles nothing is staged into before the next tile's first phase (P1 and C1 of buffer 1: last read in phases 1-2 of the last
+// K-tile, re-staged by phases 0-1 of the next tile's first), a barrier on either side.  The counted waits stay `vmcnt(8)`: with the epilogue's stores in the queue the
+// count can only force MORE than it needs (loads return in order among loads), never less.
+// DYN: the column is not walked at a fixed stride -- after its first tile a workgroup takes pixel tiles of its channel tile from the op's tile counter (Y7TConvArgs::tile_ctr, one
+// counter per channel tile as in y7t_conv_ws128.hip; the ticket of the tile after next is fetched a whole tile ahead, so the prefetch always knows where it goes): what
+// round 5 measured for every persistent kernel beside co-running work, and columns of 5-6 tiles (the 40 x 40 layers) stop ending a tile apart.
+template <int ACT, bool DUAL, bool DYN>
+__global__ void __launch_bounds__(512, 2) k_conv1x1_p8p(const Y7TConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = P8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wq = wave & 3, l31 = lane & 31, hi32 = lane >> 5;
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n_tiles_n = p.Cout_pad / C::BN, Gn = (int)gridDim.x / n_tiles_n;      // (the launcher: gridDim.x a multiple of n_tiles_n)
+    const int tile_n = bid % n_tiles_n, m_tiles = (p.M + C::BM - 1) / C::BM;
+    int tile_m = bid / n_tiles_n;
+    if (tile_m >= m_tiles) return;
+    const int n0 = tile_n * C::BN, nk = p.Cin / C::BK;      // nk even (the launcher)
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (unsigned)p.Cout_pad * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.in2 : p.in), 0, DUAL ? p.in2_bytes : p.in_bytes, 0x00020000);
+
+    const int srow = wave * 8 + (lane >> 3);
+    const int gch = (lane & 7) ^ ((srow >> 1) & 7);
+    struct Off { int x[2][2]; int x2[DUAL ? 2 : 1][2]; };
+    auto offsets = [&](int m0, Off& o) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int m = m0 + rd * 128 + h * 64 + srow;
+                o.x[h][rd] = (int)C::OOB;
+                if (DUAL) o.x2[h][rd] = (int)C::OOB;
+                if (m < p.M) {
+                    o.x[h][rd] = (m * p.ldin + p.cin_off + gch * 8) * 2;
+                    if (DUAL) {
+                        const int HW = p.H * p.W, b = m / HW, rem = m - b * HW, y = rem / p.W, x = rem - y * p.W;
+                        o.x2[h][rd] = (((b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1)) * p.ldin2 + p.cin2_off + gch * 8) * 2;
+                    }
+                }
+            }
+    };
+    Off cur, nxt;
+    bool has_next = false;
+    volatile int* const tkt = (volatile int*)(smem + C::LDS);      // DYN: two ticket slots behind the bias
+    int* const ctr = DYN ? p.tile_ctr + tile_n : nullptr;
+    if (DYN && tid == 0) tkt[0] = atomicAdd(ctr, 1);      // the ticket of this workgroup's SECOND tile (visible behind the prologue's barrier)
+    const int wvo = tile_n * nk * (2 * C::HALF) + wave * 1024 + lane * 16;
+
+    // piece rd of pixel half h of K-tile T of the CURRENT tile -> buffer b; T >= nk: K-tile T - nk of the NEXT tile of this workgroup's column (none left: zeros)
+    auto stage_p1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {
+        char* dst = smem + b * C::BUF + h * C::HALF + wave * 1024 + rd * 8192;
+        const bool own = T < nk, live = own || has_next;
+        const int ci = (own ? T : T - nk) * C::BK;
+        const bool up = DUAL && live && ci >= p.up_c0 && ci < p.up_c0 + p.up_C;
+        const int xo = own ? cur.x[h][rd] : nxt.x[h][rd];
+        if (up) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (LDS_AS void*)dst, 16, own ? cur.x2[DUAL ? h : 0][rd] : nxt.x2[DUAL ? h : 0][rd], (ci - p.up_c0) * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (LDS_AS void*)dst, 16, live ? xo : (int)C::OOB, live ? ci * 2 : 0, 0, 0);
+    };
+    auto stage_c1 = [&](int h, int b, int T, int rd) __attribute__((always_inline)) {
+        char* dst = smem + b * C::BUF + (2 + h) * C::HALF + wave * 1024 + rd * 8192;
+        const bool own = T < nk, live = own || has_next;
+        const int Tw = own ? T : T - nk;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (LDS_AS void*)dst, 16, live ? wvo + h * C::HALF + rd * 8192 : (int)C::OOB, live ? Tw * (2 * C::HALF) : 0, 0, 0);
+    };
+    auto stage_p = [&](int h, int b, int T) __attribute__((always_inline)) { stage_p1(h, b, T, 0); stage_p1(h, b, T, 1); };
+    auto stage_c = [&](int h, int b, int T) __attribute__((always_inline)) { stage_c1(h, b, T, 0); stage_c1(h, b, T, 1); };
+
+    const int swl = (l31 >> 1) & 7;
+    const int prow = (grp * 64 + l31) * C::ROWB, crow = (wq * 32 + l31) * C::ROWB;
+    half8 pf[2][4], c0[4], c1[4];
+    auto read_p = [&](int hP, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) pf[j][ks] = *(const half8*)(smem + b * C::BUF + hP * C::HALF + prow + j * 32 * C::ROWB + (((ks * 2 + hi32) ^ swl) << 4));
+    };
+    auto read_c = [&](half8 (&cf)[4], int hC, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const half8*)(smem + b * C::BUF + (2 + hC) * C::HALF + crow + (((ks * 2 + hi32) ^ swl) << 4));
+    };
+    floatx16 acc[2][2][2];
+    auto mma = [&](int hP, const half8 (&cf)[4], int hC) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[hP][j][hC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], pf[j][ks], acc[hP][j][hC], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto ktile = [&](int T, auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        read_p(0, b); read_c(c0, 0, b);
+        stage_c(1, b ^ 1, T + 1);
+        P8_VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        mma(0, c0, 0);
+        __builtin_amdgcn_s_barrier();
+        read_c(c1, 1, b);
+        stage_p(1, b ^ 1, T + 1);
+        P8_VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        mma(0, c1, 1);
+        __builtin_amdgcn_s_barrier();
+        read_p(1, b);
+        stage_p(0, b, T + 2);
+        P8_VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        mma(1, c1, 1);
+        __builtin_amdgcn_s_barrier();
+        stage_c(0, b, T + 2);
+        P8_VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        mma(1, c0, 0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue of the workgroup's FIRST tile (every later tile finds the ring in this state when the previous tile's loop ends) ----
+    offsets(tile_m * C::BM, cur);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (LDS_AS void*)(smem + C::BIAS + wq * 256), 4, (n0 + wq * 64 + lane) * 4, 0, 0, 0);
+    stage_p(0, 0, 0); stage_c(0, 0, 0); stage_c(1, 0, 0); stage_p(1, 0, 0); stage_p(0, 1, 1); stage_c(0, 1, 1);
+    P8_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    typedef __attribute__((ext_vector_type(4))) unsigned uint4v;
+    half_t* outp = (half_t*)p.out;
+    char* const scr = smem + C::BUF + (wave < 4 ? 1 : 3) * C::HALF + (wave & 3) * 4096;      // 4 KiB of P1 / C1 of buffer 1 (see above)
+    for (int it = 0;; ++it) {
+        const int m0 = tile_m * C::BM, tile_next = DYN ? Gn + __builtin_amdgcn_readfirstlane(tkt[it & 1]) : tile_m + Gn;
+        has_next = tile_next < m_tiles;
+        // the ticket of the tile after next: a returning atomic whose result the COMPILER must not wait for (its s_waitcnt vmcnt(0) here would drain this wave's eight
+        // in-flight half-tile pieces and the previous epilogue's stores).  Issued as inline asm: by the time the K loop is over this wave has issued >= 16 younger
+        // loads behind >= 8 `vmcnt(8)` waits, and loads return in order -- the register holds the ticket when it is read below.
+        int fetched = 0;
+        if (DYN && tid == 0 && has_next) {
+#if defined(Y7T_CONVSIM)
+            fetched = atomicAdd(ctr, 1);
+#else
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fetched) : "v"(ctr), "v"(1) : "memory");
+#endif
+        }
+        if (has_next) offsets(tile_next * C::BM, nxt);
+#pragma unroll
+        for (int hC = 0; hC < 2; ++hC)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef __attribute__((ext_vector_type(4))) float float4v;
+                const float4v bv = *(const float4v*)(smem + C::BIAS + (wq * 64 + hC * 32 + 8 * g + 4 * hi32) * 4);
+#pragma unroll
+                for (int hP = 0; hP < 2; ++hP)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[hP][j][hC][g * 4 + e] = bv[e];
+            }
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int T = 0; T < nk; T += 2) {
+            ktile(T, std::integral_constant<int, 0>{});
+            ktile(T + 1, std::integral_constant<int, 1>{});
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();      // re-align the groups: every wave is past its last fragment read
+        if (DYN && tid == 0 && has_next) tkt[(it + 1) & 1] = fetched;      // (read at the start of the next tile, behind the barrier at the end of this one)
+        // ---- epilogue, 32 pixels x 64 channels at a time through this wave's 4 KiB ----
+#pragma unroll
+        for (int hP = 0; hP < 2; ++hP)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int hC = 0; hC < 2; ++hC)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int g = gp * 2 + gg;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(acc[hP][j][hC][g * 4 + e]);
+                            typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+                            half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                            w[gg][0] = __builtin_bit_cast(unsigned, h0);
+                            w[gg][1] = __builtin_bit_cast(unsigned, h1);
+                        }
+                        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        uint4v pk = {r0[0], r1[0], r0[1], r1[1]};
+                        const int ch = hC * 4 + gp * 2 + hi32;
+                        *(uint4v*)(scr + l31 * 128 + ((ch ^ (l31 & 7)) << 4)) = pk;
+                    }
+                P8_WAVE_SYNC();
+                uint4v v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = k * 8 + (lane >> 3), ch = lane & 7;
+                    v4[k] = *(const uint4v*)(scr + px * 128 + ((ch ^ (px & 7)) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = k * 8 + (lane >> 3), ch = lane & 7;
+                    const int m = m0 + grp * 128 + hP * 64 + j * 32 + px, n = n0 + wq * 64 + ch * 8;
+                    if (m < p.M && n < p.Cout) *(uint4v*)(outp + (size_t)m * p.ldout + p.cout_off + n) = v4[k];
+                }
+                P8_WAVE_SYNC();
+            }
+        if (!has_next) break;
+        __builtin_amdgcn_s_barrier();                    // nobody reads its scratch any more: the next tile's first phases stage C1 / P1 of K-tile 1 over it
+        cur = nxt;
+        tile_m = tile_next;
+    }
+    P8_VMCNT(0);      // (the last tile's tail: zero-fills into half-tiles nobody reads, landed before the workgroup's LDS is handed on)
+    if (DYN && tid == 0) {      // the last workgroup to leave hands every counter of the op back at zero
+        if (atomicAdd(p.tile_ctr + Y7T_TILE_CTR_DONE, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i <= Y7T_TILE_CTR_DONE; ++i) p.tile_ctr[i] = 0;
+        }
+    }
+#endif
+}
+
 }   // namespace
 
 // korder 7 layers only (detector/graph.py::p8_eligible mirrors the conditions)
@@ -295,6 +526,34 @@ int y7t_conv_p8_launch(const Y7TConvArgs& a, hipStream_t s) {
     })) return e_;
     const int grid = ((a.M + C::BM - 1) / C::BM) * (a.Cout_pad / C::BN);
     const bool dual = a.up_C > 0;
+    // the persistent form (k_conv1x1_p8p) where a workgroup gets more than one tile and the K-tiles of a tile are an even number (the ring's parity)
+    static const int persist = y7t_exp_switch("Y7T_CONV_P8_PERSIST", 1);
+    const int n_tiles_n = a.Cout_pad / C::BN, ncu = y7t_num_cus(), gp_ = (ncu / n_tiles_n) * n_tiles_n;
+    // (at least two tiles per workgroup on average: with 500 tiles on 256 workgroups -- the 20 x 20 layers at 80 frames -- the persistent form measured 0-3 % behind, r6ax)
+    if (persist && !a.ablate && ((a.Cin / C::BK) & 1) == 0 && gp_ > 0 && grid >= 2 * gp_) {
+        static Y7TOncePerDevice attrp;
+        if (int e_ = y7t_once_per_device(attrp, [&]() -> int {
+#define P8P_ATTR(ACT, DUAL) Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8p<ACT, DUAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + 16)); \
+                            Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8p<ACT, DUAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + 16));
+            P8P_ATTR(Y7T_ACT_NONE, false) P8P_ATTR(Y7T_ACT_SILU, false) P8P_ATTR(Y7T_ACT_LEAKY, false) P8P_ATTR(Y7T_ACT_NONE, true) P8P_ATTR(Y7T_ACT_SILU, true) P8P_ATTR(Y7T_ACT_LEAKY, true)
+#undef P8P_ATTR
+            return 0;
+        })) return e_;
+        static const int dyn_env = y7t_switch("Y7T_CONV_WS_DYN", 1);      // (the persistent kernels' product switch: =0 the static column)
+        const bool dyn = a.tile_ctr && dyn_env && n_tiles_n <= Y7T_TILE_CTR_DONE;
+#define P8P_GO(ACT) \
+        do { if (dual && dyn) hipLaunchKernelGGL((k_conv1x1_p8p<ACT, true, true>), dim3(gp_), dim3(C::NT), C::LDS + 16, s, a); \
+             else if (dual) hipLaunchKernelGGL((k_conv1x1_p8p<ACT, true, false>), dim3(gp_), dim3(C::NT), C::LDS + 16, s, a); \
+             else if (dyn) hipLaunchKernelGGL((k_conv1x1_p8p<ACT, false, true>), dim3(gp_), dim3(C::NT), C::LDS + 16, s, a); \
+             else hipLaunchKernelGGL((k_conv1x1_p8p<ACT, false, false>), dim3(gp_), dim3(C::NT), C::LDS + 16, s, a); } while (0)
+        if (a.act == Y7T_ACT_SILU) P8P_GO(Y7T_ACT_SILU);
+        else if (a.act == Y7T_ACT_LEAKY) P8P_GO(Y7T_ACT_LEAKY);
+        else P8P_GO(Y7T_ACT_NONE);
+#undef P8P_GO
+        Y7T_LAUNCH_CHECK();
+        y7t_note_kernel("p8<256,256,64> 1x1%s", dual ? " upsample-on-read" : "");
+        return 0;
+    }
 #if Y7T_ABLATE      // liby7t_ablate.so only
     if (a.ablate && a.act == Y7T_ACT_SILU && !dual) {      // timing ablations of the plain SiLU instance (Y7T_CONV_ABLATE=1|2|4|8|16; wrong results)
 #define P8_ABL(N) case N: Y7T_HIP_CHECK(hipFuncSetAttribute((const void*)k_conv1x1_p8<Y7T_ACT_SILU, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS)); \
