@@ -50,7 +50,7 @@ def build(defs=()):
     p8 = open(srcs[7]).read()                                                     # the 256 x 256 x 64 ping-pong kernel: its waits are a macro that becomes the DMA model's cs_vmcnt
     assert "asm volatile" in p8 and "P8_VMCNT" in p8
     p8, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char smem\[\];", "", p8)
-    assert n == 1
+    assert n == 2      # (the one-tile kernel and the persistent form, round 6)
     open(os.path.join(bdir, "convsim_p8.cpp"), "w").write(p8)
     ws2 = open(srcs[8]).read()                                                    # the stride-2 weights-stationary kernel (64 -> 128): waits as a macro, like p8
     assert "WS2_VMCNT" in ws2

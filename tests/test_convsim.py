@@ -141,6 +141,10 @@ P8_CASES = [
     (1, 16, 16, 64, 512, 2, {"in_ld": 128, "in_coff": 64, "out_ld": 768, "out_coff": 256}),   # ONE K-tile (prologue + zero-fill tail only), two channel tiles, slices, LeakyReLU
     (1, 15, 20, 192, 256, 0, {}),                                                       # three K-tiles (odd: the loop ends on buffer 0), 300 pixels, no activation
     (2, 12, 16, 320, 256, 1, {"out_ld": 512, "out_coff": 0}),                           # five K-tiles, 384 pixels over two images
+    # round 6, the persistent form (k_conv1x1_p8p: the host model has 3 compute units, so >= 6 tiles with one channel tile / >= 4 with two and an even number of K-tiles take it):
+    # three workgroups x two tiles, two K-tiles per tile (the shortest loop the cross-tile prefetch allows); two channel tiles, three tiles per workgroup, a ragged last tile, four K-tiles
+    (2, 24, 32, 128, 256, 1, {}),
+    (1, 35, 40, 256, 512, 2, {"out_ld": 640, "out_coff": 128}),
 ]
 
 
