@@ -86,7 +86,7 @@ perlayer_b)
   say "perlayer_b: per-op tables at B=${B:-80} frames: the default lowering, every eligible 1x1 on p8 (Y7T_CONV_P8=all), 64-row panels kept for the small maps (as at 40 frames)"
   E="Y7T_LIB=$ROOT/yolov7-tracker_amd/lib/liby7t_ablate.so"
   for v in ${VARIANTS:-default p8all panel64}; do
-    case $v in default) X="";; p8all) X="Y7T_CONV_P8=all";; p8t200) X="Y7T_CONV_P8=all Y7T_CONV_P8_MIN_TILES=200";; panel64) X="Y7T_CONV_PATCH_PANEL64_BELOW=512 Y7T_CONV_1X1_PANEL64_BELOW=1000";; esac
+    case $v in default) X="";; p8all) X="Y7T_CONV_P8=all";; p8t200) X="Y7T_CONV_P8=all Y7T_CONV_P8_MIN_TILES=200";; s2all) X="Y7T_CONV_PATCH_S2=1";; nopersist) X="Y7T_CONV_P8_PERSIST=0";; panel64) X="Y7T_CONV_PATCH_PANEL64_BELOW=512 Y7T_CONV_1X1_PANEL64_BELOW=1000";; esac
     env $E $X B=${B:-80} NAME=b${B:-80}_$v OUT=$O timeout 600 bash scripts/per_layer_table.sh > $O/pl_b${B:-80}_$v.log 2>&1
     echo "--- $v" | tee -a $O/summary.txt; tail -1 $O/per_layer_b${B:-80}_$v.txt | tee -a $O/summary.txt
   done
