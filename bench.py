@@ -50,8 +50,8 @@ DEFAULT_BATCH = 80
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="GPUs (= ranks) of this node; default: WORLD_SIZE under a launcher, else 1")
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frames per step (consecutive frames of the sequence); default %d: see DEFAULT_BATCH" % DEFAULT_BATCH)
     ap.add_argument("--n_obj", type=int, default=None, help="objects in the synthetic scene (default: 80 for cfg2, 500 for cfg3)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
