@@ -9,6 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 import os
 KORDER = int(os.environ.get('KORDER', '1'))
+ACT = int(os.environ.get('ACT', '1'))      # activation of the timed layers (1 SiLU as in the network, 0 none, 2 LeakyReLU): what the epilogue's activation costs
 L = _lib.load()
 plan = graph.lower(graph.parse(arch.yolov7_w6(10))[0], 1280, 1280, B)
 shapes = collections.OrderedDict()
@@ -30,14 +31,14 @@ for key, cnt in shapes.items():
     b = torch.randn(Cout_pad, device="cuda")
     out = torch.empty((B, Ho, Wo, out_ld), device="cuda", dtype=torch.float32 if f32 else torch.float16)
     # `act` bits of y7t_conv2d_nhwc_f16 = the weight packing the plan would give this layer (the weights are random: only the kernel choice matters here)
-    if graph.ws_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 65536      # the 64 -> 128 stride-2 layer, weights stationary (Y7T_CONV_WS_S2=0: off)
-    elif graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B) or graph.ws128_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 16384        # the 128 -> 128 k layers, weights stationary (Y7T_CONV_WS128; this entry point has no tile counter: static partition)
-    elif graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = 1 | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
-    elif graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = 1 | 1024
-    elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32, B * Ho * Wo): code = 1 | 4096          # stride-2 patch kernel where it measured faster
-    elif k == 3 and Cin % 64 == 0: code = 1 | (KORDER << 8)
-    elif graph.p8_eligible(H, W, Cin, Cout, k, s, out_ld, 0, f32, in_ld, 0, B): code = 1 | 32768            # 1x1, Cout % 256 == 0: the 256 x 256 x 64 ping-pong pipeline (Y7T_CONV_P8=0: off)
-    elif k == 1 and Cin % 32 == 0 and KORDER and os.environ.get('Y7T_CONV_WPANEL', '1') != '0': code = 1 | 2048
+    if graph.ws_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = ACT | 65536      # the 64 -> 128 stride-2 layer, weights stationary (Y7T_CONV_WS_S2=0: off)
+    elif graph.ws128_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B) or graph.ws128_s2_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = ACT | 16384        # the 128 -> 128 k layers, weights stationary (Y7T_CONV_WS128; this entry point has no tile counter: static partition)
+    elif graph.ws_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, in_ld, 0, B): code = ACT | 8192               # opt-in: Y7T_CONV_WS=1 (weights stationary in registers)
+    elif graph.patch_eligible(H, W, Cin, Cout, k, s, pad, out_ld, 0, f32, B) and KORDER: code = ACT | 1024
+    elif graph.patch_s2_eligible(Cin, Cout, k, s, pad, out_ld, 0, f32, B * Ho * Wo): code = ACT | 4096          # stride-2 patch kernel where it measured faster
+    elif k == 3 and Cin % 64 == 0: code = ACT | (KORDER << 8)
+    elif graph.p8_eligible(H, W, Cin, Cout, k, s, out_ld, 0, f32, in_ld, 0, B): code = ACT | 32768            # 1x1, Cout % 256 == 0: the 256 x 256 x 64 ping-pong pipeline (Y7T_CONV_P8=0: off)
+    elif k == 1 and Cin % 32 == 0 and KORDER and os.environ.get('Y7T_CONV_WPANEL', '1') != '0': code = ACT | 2048
     else: code = 1
     def run():
         _lib.check(L.y7t_conv2d_nhwc_f16(_lib.ptr(x), in_ld, 0, B, H, W, Cin, _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), out_ld, 0, f32, Cout, Cout_pad,
